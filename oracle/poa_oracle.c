@@ -1,0 +1,713 @@
+/* oracle/poa_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Plain-C, flat-array restatement of the reference's per-window POA path
+ * (see poa_oracle.h).  Citations are file:line under /root/reference/.
+ * No reference code is reproduced: linked lists become bounded arrays, the
+ * in-place LPO translation becomes an out-of-place rebuild, the score rows
+ * become full matrices.  Behaviour (including tie-breaks and quirks) follows
+ * the reference; tests/test_oracle_vs_reference.py proves it byte-for-byte
+ * against the real binary in oracle/_ref/.
+ */
+#include "poa_oracle.h"
+
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ a1 --- */
+
+static void build_gap_arrays(po_params *m)
+{
+  /* seq_util.c:168-196 */
+  int i, T = m->trunc_gap_length, D = m->decay_gap_length;
+  m->max_gap_length = T + D;
+  memset(m->gap_penalty_x, 0, sizeof m->gap_penalty_x);
+  memset(m->gap_penalty_y, 0, sizeof m->gap_penalty_y);
+  m->gap_penalty_x[0] = m->gap_set[0][0];
+  m->gap_penalty_y[0] = m->gap_set[1][0];
+  for (i = 1; i < T; i++) {
+    m->gap_penalty_x[i] = m->gap_set[0][1];
+    m->gap_penalty_y[i] = m->gap_set[1][1];
+  }
+  for (i = 0; i < D; i++) {
+    double dx = (m->gap_set[0][1] - m->gap_set[0][2]) / ((double)(D + 1));
+    double dy = (m->gap_set[1][1] - m->gap_set[1][2]) / ((double)(D + 1));
+    m->gap_penalty_x[i + T] = (int)(m->gap_set[0][1] - (i + 1) * dx);
+    m->gap_penalty_y[i + T] = (int)(m->gap_set[1][1] - (i + 1) * dy);
+  }
+  m->gap_penalty_x[m->max_gap_length] = m->gap_set[0][2];
+  m->gap_penalty_y[m->max_gap_length] = m->gap_set[1][2];
+  m->gap_penalty_x[m->max_gap_length + 1] = 0;
+  m->gap_penalty_y[m->max_gap_length + 1] = 0;
+}
+
+void po_default_params(po_params *m)
+{
+  /* the numbers in src/poa-graph/blosum80.mat:8-42 (not BLOSUM80: identity 0,
+   * every mismatch -10, 31 symbols, gaps 10/5/5, trunc 10, decay 5) */
+  static const char alphabet[] = "ARNDCQEGHILKMFPSTWYVBZX?agtcu]n";
+  int i, j;
+  memset(m, 0, sizeof *m);
+  m->nsymbol = (int)strlen(alphabet);
+  strcpy(m->symbol, alphabet);
+  for (i = 0; i < m->nsymbol; i++)
+    for (j = 0; j < m->nsymbol; j++)
+      m->score[i][j] = (i == j) ? 0 : -10;
+  m->gap_set[0][0] = m->gap_set[1][0] = 10;
+  m->gap_set[0][1] = m->gap_set[1][1] = 5;
+  m->gap_set[0][2] = m->gap_set[1][2] = 5;
+  m->trunc_gap_length = 10;
+  m->decay_gap_length = 5;
+  build_gap_arrays(m);
+}
+
+int po_read_matrix(const char *path, po_params *m)
+{
+  /* seq_util.c:82-166 */
+  char line[1024];
+  int i, j, k, nsymb = 0, have_symbols = 0, isymb;
+  FILE *f;
+  memset(m, 0, sizeof *m);
+  m->gap_set[0][0] = m->gap_set[1][0] = 12;   /* :89-93 defaults */
+  m->gap_set[0][1] = m->gap_set[1][1] = 2;
+  m->gap_set[0][2] = m->gap_set[1][2] = 0;
+  m->trunc_gap_length = 16;                   /* TRUNCATE_GAP_LENGTH poa.h:13 */
+  m->decay_gap_length = 0;                    /* DECAY_GAP_LENGTH   poa.h:19 */
+  f = fopen(path, "r");
+  if (!f) return -2;
+  while (fgets(line, 1023, f)) {
+    if (line[0] == '#' || line[0] == '\n') continue;
+    if (1 == sscanf(line, "GAP-TRUNCATION-LENGTH=%d", &i)) { m->trunc_gap_length = i; continue; }
+    if (1 == sscanf(line, "GAP-DECAY-LENGTH=%d", &i)) { m->decay_gap_length = i; continue; }
+    if (3 == sscanf(line, "GAP-PENALTIES=%d %d %d", &i, &j, &k)) {
+      m->gap_set[0][0] = m->gap_set[1][0] = i;
+      m->gap_set[0][1] = m->gap_set[1][1] = j;
+      m->gap_set[0][2] = m->gap_set[1][2] = k;
+      continue;
+    }
+    if (3 == sscanf(line, "GAP-PENALTIES-X=%d %d %d", &i, &j, &k)) {
+      /* :119-123 -- the "-X" directive lands in set [1] (the y arrays). Kept. */
+      m->gap_set[1][0] = i; m->gap_set[1][1] = j; m->gap_set[1][2] = k;
+      continue;
+    }
+    if (!have_symbols) {                       /* :134-139 */
+      for (i = 0; line[i]; i++)
+        if (!isspace((unsigned char)line[i]) && nsymb < PO_MAX_SYMBOL)
+          m->symbol[nsymb++] = line[i];
+      have_symbols = 1;
+      continue;
+    }
+    /* score row :141-164 (the reference reuses its flag; same effect) */
+    for (isymb = nsymb - 1; isymb >= 0; isymb--)
+      if (m->symbol[isymb] == line[0]) break;
+    /* the reference scans with LOOP, a backward loop (default.h:24), and stops
+     * at its first hit: with duplicate symbols the highest index wins. */
+    if (isymb < 0) { fclose(f); return -1; }
+    j = 1;
+    for (i = 0; i < nsymb; i++) {
+      if (1 == sscanf(line + j, "%d%n", &m->score[isymb][i], &k)) j += k;
+      else { fclose(f); return -1; }
+    }
+  }
+  fclose(f);
+  m->symbol[nsymb] = '\0';
+  m->nsymbol = nsymb;
+  build_gap_arrays(m);
+  return nsymb;
+}
+
+int po_write_matrix(const char *path, const po_params *m)
+{
+  int i, j;
+  FILE *f = fopen(path, "w");
+  if (!f) return -1;
+  fprintf(f, "# scoring parameters written by elector_amd (same grammar as poaV2 matrix files)\n");
+  fprintf(f, "GAP-TRUNCATION-LENGTH=%d\n", m->trunc_gap_length);
+  fprintf(f, "GAP-DECAY-LENGTH=%d\n", m->decay_gap_length);
+  fprintf(f, "GAP-PENALTIES=%d %d %d\n", m->gap_set[0][0], m->gap_set[0][1], m->gap_set[0][2]);
+  if (memcmp(m->gap_set[0], m->gap_set[1], sizeof m->gap_set[0]))
+    fprintf(f, "GAP-PENALTIES-X=%d %d %d\n", m->gap_set[1][0], m->gap_set[1][1], m->gap_set[1][2]);
+  fprintf(f, " ");
+  for (i = 0; i < m->nsymbol; i++) fprintf(f, " %c", m->symbol[i]);
+  fprintf(f, "\n");
+  for (i = 0; i < m->nsymbol; i++) {
+    fprintf(f, "%c", m->symbol[i]);
+    for (j = 0; j < m->nsymbol; j++) fprintf(f, " %d", m->score[i][j]);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ a2 --- */
+
+int po_symbolize(const po_params *m, const char *raw, int rawlen, unsigned char *out)
+{
+  /* create_seq.c:121-132 (strip whitespace, tolower), seq_util.c:253-263
+   * (limit_residues: anything outside the alphabet becomes symbol[0]),
+   * seq_util.c:37-52 (index_symbols: first matching index, default nsymb-1). */
+  int i, j, n = 0;
+  for (i = 0; i < rawlen; i++) {
+    unsigned char c = (unsigned char)raw[i];
+    int k;
+    if (c == 0) break;
+    if (isspace(c)) continue;
+    c = (unsigned char)tolower(c);
+    if (!memchr(m->symbol, c, (size_t)m->nsymbol)) c = (unsigned char)m->symbol[0];
+    k = m->nsymbol - 1;
+    for (j = 0; j < m->nsymbol; j++)
+      if ((unsigned char)m->symbol[j] == c) { k = j; break; }
+    out[n++] = (unsigned char)k;
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------ a3 --- */
+
+po_graph *po_graph_new(int cap)
+{
+  po_graph *g = (po_graph *)calloc(1, sizeof *g);
+  if (cap < 1) cap = 1;
+  g->cap = cap;
+  g->letter = (unsigned char *)calloc((size_t)cap, 1);
+  g->npred = (int *)calloc((size_t)cap, sizeof(int));
+  g->pred = (int (*)[PO_MAXL])calloc((size_t)cap, sizeof(int[PO_MAXL]));
+  g->nsucc = (int *)calloc((size_t)cap, sizeof(int));
+  g->succ = (int (*)[PO_MAXL])calloc((size_t)cap, sizeof(int[PO_MAXL]));
+  g->nsrc = (int *)calloc((size_t)cap, sizeof(int));
+  g->src_seq = (int (*)[PO_MAXS])calloc((size_t)cap, sizeof(int[PO_MAXS]));
+  g->src_pos = (int (*)[PO_MAXS])calloc((size_t)cap, sizeof(int[PO_MAXS]));
+  g->ring_id = (int *)calloc((size_t)cap, sizeof(int));
+  g->align_ring = (int *)calloc((size_t)cap, sizeof(int));
+  return g;
+}
+
+void po_graph_free(po_graph *g)
+{
+  if (!g) return;
+  free(g->letter); free(g->npred); free(g->pred); free(g->nsucc); free(g->succ);
+  free(g->nsrc); free(g->src_seq); free(g->src_pos); free(g->ring_id); free(g->align_ring);
+  free(g);
+}
+
+static void graph_reserve(po_graph *g, int cap)
+{
+  if (cap <= g->cap) return;
+  g->letter = (unsigned char *)realloc(g->letter, (size_t)cap);
+  g->npred = (int *)realloc(g->npred, (size_t)cap * sizeof(int));
+  g->pred = (int (*)[PO_MAXL])realloc(g->pred, (size_t)cap * sizeof(int[PO_MAXL]));
+  g->nsucc = (int *)realloc(g->nsucc, (size_t)cap * sizeof(int));
+  g->succ = (int (*)[PO_MAXL])realloc(g->succ, (size_t)cap * sizeof(int[PO_MAXL]));
+  g->nsrc = (int *)realloc(g->nsrc, (size_t)cap * sizeof(int));
+  g->src_seq = (int (*)[PO_MAXS])realloc(g->src_seq, (size_t)cap * sizeof(int[PO_MAXS]));
+  g->src_pos = (int (*)[PO_MAXS])realloc(g->src_pos, (size_t)cap * sizeof(int[PO_MAXS]));
+  g->ring_id = (int *)realloc(g->ring_id, (size_t)cap * sizeof(int));
+  g->align_ring = (int *)realloc(g->align_ring, (size_t)cap * sizeof(int));
+  g->cap = cap;
+}
+
+void po_graph_linear(po_graph *g, const unsigned char *seq, int len)
+{
+  /* lpo.c:11-32: chain i-1 <- i -> i+1, source (0,i), ring = self */
+  int i;
+  graph_reserve(g, len);
+  g->n = len;
+  for (i = 0; i < len; i++) {
+    g->letter[i] = seq[i];
+    g->npred[i] = (i > 0);           g->pred[i][0] = i - 1;
+    g->nsucc[i] = (i < len - 1);     g->succ[i][0] = i + 1;
+    g->nsrc[i] = 1; g->src_seq[i][0] = 0; g->src_pos[i][0] = i;
+    g->ring_id[i] = g->align_ring[i] = i;
+  }
+  g->nseq = 1;
+  g->seq_len[0] = len;
+  g->seq_weight[0] = 1;              /* save_lpo_source(...,1,NO_BUNDLE,...) lpo.c:30 */
+  g->seq_bundle[0] = -1;
+}
+
+/* ------------------------------------------------------------- a4 a5 a7 --- */
+
+#define NODE_INITIAL 1
+#define NODE_FINAL 2
+
+/* DP predecessor list of a node (align_lpo_po2.c:46-79): stored left links, or
+ * [-1] when there are none; INITIAL nodes whose first stored link is not -1 get
+ * a virtual -1 prepended. Returns count. */
+static int dp_preds(const po_graph *g, int i, int type, int *out)
+{
+  int n = 0, k;
+  if (g->npred[i] == 0) { out[0] = -1; return 1; }
+  if (type & NODE_INITIAL) out[n++] = -1;
+  for (k = 0; k < g->npred[i]; k++) out[n++] = g->pred[i][k];
+  return n;
+}
+
+static int node_type(const po_graph *g, int i)
+{
+  int t = 0, k;
+  for (k = 0; k < g->nsrc[i]; k++) {
+    if (g->src_pos[i][k] == 0) t |= NODE_INITIAL;
+    if (g->src_pos[i][k] == g->seq_len[g->src_seq[i][k]] - 1) t |= NODE_FINAL;
+  }
+  return t;
+}
+
+int po_align(const po_graph *x, const po_graph *y, const po_params *m,
+             int *x_to_y, int *y_to_x, int *best_x_out, int *best_y_out,
+             unsigned char *moves_out, int64_t *ncells)
+{
+  const int lx = x->n, ly = y->n, M = m->max_gap_length;
+  const int W = lx + 1;                       /* row stride incl. column -1 */
+  int *S = (int *)malloc((size_t)(ly + 1) * W * sizeof(int));
+  short *G = (short *)calloc((size_t)(ly + 1) * W, sizeof(short));
+  unsigned char *mvx = (unsigned char *)calloc((size_t)ly * lx + 1, 1);
+  unsigned char *mvy = (unsigned char *)calloc((size_t)ly * lx + 1, 1);
+  int *tx = (int *)malloc((size_t)lx * sizeof(int)), *ty = (int *)malloc((size_t)ly * sizeof(int));
+  int (*px)[PO_MAXL + 1] = (int (*)[PO_MAXL + 1])malloc((size_t)lx * sizeof(int[PO_MAXL + 1]));
+  int (*py)[PO_MAXL + 1] = (int (*)[PO_MAXL + 1])malloc((size_t)ly * sizeof(int[PO_MAXL + 1]));
+  int *npx = (int *)malloc((size_t)lx * sizeof(int)), *npy = (int *)malloc((size_t)ly * sizeof(int));
+  int gpx[PO_MAX_GAPTAB], gpy[PO_MAX_GAPTAB], nxt[PO_MAX_GAPTAB];
+  int i, j, a, b, best_score = PO_NEG, best_x = -1, best_y = -1;
+#define SC(r, c) S[((r) + 1) * W + (c) + 1]
+#define GT(r, c) G[((r) + 1) * W + (c) + 1]
+
+  for (j = 0; j < lx; j++) { tx[j] = node_type(x, j); npx[j] = dp_preds(x, j, tx[j], px[j]); }
+  for (i = 0; i < ly; i++) { ty[i] = node_type(y, i); npy[i] = dp_preds(y, i, ty[i], py[i]); }
+
+  /* align_lpo_po2.c:224-249: tag transition; global mode treats the initial
+   * state M+1 like 0 */
+  for (i = 0; i <= M; i++) { gpx[i] = m->gap_penalty_x[i]; gpy[i] = m->gap_penalty_y[i]; nxt[i] = (i < M) ? i + 1 : i; }
+  gpx[M + 1] = gpx[0]; gpy[M + 1] = gpy[0]; nxt[M + 1] = nxt[0];
+
+  /* row -1 (:272-286) */
+  SC(-1, -1) = 0; GT(-1, -1) = (short)(M + 1);
+  for (j = 0; j < lx; j++) {
+    SC(-1, j) = PO_NEG;
+    for (a = 0; a < npx[j]; a++) {
+      int p = px[j][a], g = GT(-1, p), t = SC(-1, p) - gpx[g];
+      if (t > SC(-1, j)) { SC(-1, j) = t; GT(-1, j) = (short)nxt[g]; }
+    }
+  }
+  /* column -1 (:290-302) */
+  for (i = 0; i < ly; i++) {
+    SC(i, -1) = PO_NEG;
+    for (b = 0; b < npy[i]; b++) {
+      int q = py[i][b], g = GT(q, -1), t = SC(q, -1) - gpy[g];
+      if (t > SC(i, -1)) { SC(i, -1) = t; GT(i, -1) = (short)nxt[g]; }
+    }
+  }
+
+  /* main loop (:309-418) */
+  for (i = 0; i < ly; i++) {
+    for (j = 0; j < lx; j++) {
+      int match = PO_NEG, mx = 0, my = 0;
+      int insx = PO_NEG, ix = 0, ixg = 0;
+      int insy = PO_NEG, iy = 0, iyg = 0;
+      int end_ok = (tx[j] & NODE_FINAL) && (ty[i] & NODE_FINAL);
+      int s, g;
+      for (b = 0; b < npy[i]; b++) {
+        int q = py[i][b];
+        int pg = GT(q, j), t = SC(q, j) - gpy[pg];
+        if (t > insy) { insy = t; iy = b + 1; iyg = pg; }
+        for (a = 0; a < npx[j]; a++) {
+          t = SC(q, px[j][a]);
+          if (t > match) { match = t; mx = a + 1; my = b + 1; }
+        }
+      }
+      for (a = 0; a < npx[j]; a++) {
+        int p = px[j][a];
+        int pg = GT(i, p), t = SC(i, p) - gpx[pg];
+        if (t > insx) { insx = t; ix = a + 1; ixg = pg; }
+      }
+      match += m->score[x->letter[j]][y->letter[i]];   /* align_score.c:23-31 */
+      if (match > insy && match > insx) { s = match; g = 0; mvx[i * lx + j] = (unsigned char)mx; mvy[i * lx + j] = (unsigned char)my; }
+      else if (insx > insy)             { s = insx; g = nxt[ixg]; mvx[i * lx + j] = (unsigned char)ix; mvy[i * lx + j] = 0; }
+      else                              { s = insy; g = nxt[iyg]; mvx[i * lx + j] = 0; mvy[i * lx + j] = (unsigned char)iy; }
+      SC(i, j) = s; GT(i, j) = (short)g;
+      if (end_ok && s >= best_score) {
+        if (s > best_score || (j == best_x && i < best_y) || j < best_x) { best_score = s; best_x = j; best_y = i; }
+      }
+    }
+  }
+  if (ncells) *ncells += (int64_t)lx * ly;
+
+  /* traceback (:108-168) */
+  for (j = 0; j < lx; j++) x_to_y[j] = -1;
+  for (i = 0; i < ly; i++) y_to_x[i] = -1;
+  {
+    int bx = best_x, by = best_y;
+    while (bx >= 0 && by >= 0) {
+      int xm = mvx[by * lx + bx], ym = mvy[by * lx + bx];
+      if (xm > 0 && ym > 0) { x_to_y[bx] = by; y_to_x[by] = bx; }
+      if (xm == 0 && ym == 0) { x_to_y[bx] = by; y_to_x[by] = bx; break; }
+      { int nbx = bx, nby = by;
+        if (xm > 0) nbx = px[bx][xm - 1];
+        if (ym > 0) nby = py[by][ym - 1];
+        bx = nbx; by = nby; }
+    }
+  }
+  if (moves_out)
+    for (i = 0; i < ly * lx; i++) moves_out[i] = (unsigned char)((mvx[i] << 4) | mvy[i]);
+  if (best_x_out) *best_x_out = best_x;
+  if (best_y_out) *best_y_out = best_y;
+  free(S); free(G); free(mvx); free(mvy); free(tx); free(ty); free(px); free(py); free(npx); free(npy);
+#undef SC
+#undef GT
+  return best_score;
+}
+
+/* ------------------------------------------------------------------ a8 --- */
+
+static void add_link(int *n, int *list, int v)
+{
+  /* lpo.c:227-241: append unless already present */
+  int k;
+  for (k = 0; k < *n; k++) if (list[k] == v) return;
+  if (*n >= PO_MAXL) { fprintf(stderr, "poa_oracle: link list overflow\n"); abort(); }
+  list[(*n)++] = v;
+}
+
+static void crosslink(po_graph *g, int a, int b)
+{
+  /* lpo.c:325-346 */
+  int r, t;
+  if (g->ring_id[a] == g->ring_id[b]) return;
+  if (g->ring_id[a] < g->ring_id[b]) { r = b; do g->ring_id[r] = g->ring_id[a]; while ((r = g->align_ring[r]) != b); }
+  else                               { r = a; do g->ring_id[r] = g->ring_id[b]; while ((r = g->align_ring[r]) != a); }
+  t = g->align_ring[a]; g->align_ring[a] = g->align_ring[b]; g->align_ring[b] = t;
+}
+
+void po_fuse(po_graph *x, const po_graph *y, const int *x_to_y, const int *y_to_x)
+{
+  const int lx = x->n, ly = y->n;
+  int *new_x = (int *)malloc((size_t)(lx + 1) * sizeof(int));
+  int *new_y = (int *)malloc((size_t)(ly + 1) * sizeof(int));
+  char *do_fuse = (char *)calloc((size_t)ly + 1, 1);
+  int i_x, i_y, i_ring, end_of_ring = -1, new_len = 0, i, k;
+  po_graph *o;
+
+  /* mark_fusion_segments, only the identity rule is compiled (lpo.c:379-382) */
+  for (i_y = 0; i_y < ly; i_y++)
+    if (y_to_x[i_y] >= 0 && x->letter[y_to_x[i_y]] == y->letter[i_y]) do_fuse[i_y] = 1;
+
+  /* reindex_lpo_fusion (lpo.c:431-459) */
+  for (i_x = i_y = 0; i_x < lx; i_x++) {
+    for (i_ring = i_x; i_ring < lx && x->ring_id[i_ring] == x->ring_id[i_x]; i_ring++)
+      if (x_to_y[i_ring] >= 0) {
+        while (i_y < x_to_y[i_ring]) new_y[i_y++] = new_len++;
+        break;
+      }
+    if (x_to_y[i_x] >= 0 && i_y < ly) {
+      for (i_ring = y->align_ring[i_y]; i_ring != i_y; i_ring = y->align_ring[i_ring])
+        if (i_ring > end_of_ring) end_of_ring = i_ring;
+      if (do_fuse[i_y]) new_y[i_y++] = new_len;
+      else new_y[i_y++] = new_len++;
+    }
+    new_x[i_x] = new_len++;
+    while (i_y <= end_of_ring) new_y[i_y++] = new_len++;
+  }
+  while (i_y < ly) new_y[i_y++] = new_len++;
+
+  /* rebuild out of place (same result as realloc + translate_lpo, lpo.c:577-598,622-636) */
+  o = po_graph_new(new_len);
+  o->n = new_len;
+  for (i = 0; i < new_len; i++) { o->ring_id[i] = o->align_ring[i] = i; }
+  for (i_x = 0; i_x < lx; i_x++) {
+    int n = new_x[i_x];
+    o->letter[n] = x->letter[i_x];
+    o->npred[n] = x->npred[i_x];
+    for (k = 0; k < x->npred[i_x]; k++) o->pred[n][k] = new_x[x->pred[i_x][k]];
+    o->nsucc[n] = x->nsucc[i_x];
+    for (k = 0; k < x->nsucc[i_x]; k++) o->succ[n][k] = new_x[x->succ[i_x][k]];
+    o->nsrc[n] = x->nsrc[i_x];
+    for (k = 0; k < x->nsrc[i_x]; k++) { o->src_seq[n][k] = x->src_seq[i_x][k]; o->src_pos[n][k] = x->src_pos[i_x][k]; }
+    o->ring_id[n] = new_x[x->ring_id[i_x]];
+    o->align_ring[n] = new_x[x->align_ring[i_x]];
+  }
+  /* copy_lpo_letter for y (lpo.c:308-320, 640-641): sources appended with the
+   * sequence index shifted past x's sources, links appended if new */
+  for (i_y = ly - 1; i_y >= 0; i_y--) {
+    int n = new_y[i_y];
+    o->letter[n] = y->letter[i_y];
+    for (k = 0; k < y->nsrc[i_y]; k++) {
+      if (o->nsrc[n] >= PO_MAXS) { fprintf(stderr, "poa_oracle: source overflow\n"); abort(); }
+      o->src_seq[n][o->nsrc[n]] = x->nseq + y->src_seq[i_y][k];
+      o->src_pos[n][o->nsrc[n]] = y->src_pos[i_y][k];
+      o->nsrc[n]++;
+    }
+    for (k = 0; k < y->npred[i_y]; k++) add_link(&o->npred[n], o->pred[n], new_y[y->pred[i_y][k]]);
+    for (k = 0; k < y->nsucc[i_y]; k++) add_link(&o->nsucc[n], o->succ[n], new_y[y->succ[i_y][k]]);
+  }
+  /* copy_old_ring_to_new for y (lpo.c:351-359, 644-645) */
+  for (i_y = ly - 1; i_y >= 0; i_y--) {
+    int ipos, next;
+    for (ipos = i_y; (next = y->align_ring[ipos]) != i_y; ipos = next)
+      crosslink(o, new_y[ipos], new_y[next]);
+  }
+  /* aligned pairs join rings (lpo.c:647-649) */
+  for (i_x = lx - 1; i_x >= 0; i_x--)
+    if (x_to_y[i_x] >= 0) crosslink(o, new_x[i_x], new_y[x_to_y[i_x]]);
+
+  /* source bookkeeping (save_lpo_source_list, lpo.c:207-221,638-639) */
+  o->nseq = x->nseq;
+  for (k = 0; k < x->nseq; k++) { o->seq_len[k] = x->seq_len[k]; o->seq_weight[k] = x->seq_weight[k]; o->seq_bundle[k] = x->seq_bundle[k]; }
+  for (k = 0; k < y->nseq; k++) {
+    if (o->nseq >= PO_MAXS) { fprintf(stderr, "poa_oracle: too many sources\n"); abort(); }
+    o->seq_len[o->nseq] = y->seq_len[k]; o->seq_weight[o->nseq] = y->seq_weight[k]; o->seq_bundle[o->nseq] = y->seq_bundle[k];
+    o->nseq++;
+  }
+
+  /* move o into x */
+  { po_graph tmp = *x; *x = *o; *o = tmp; }
+  po_graph_free(o);
+  free(new_x); free(new_y); free(do_fuse);
+}
+
+/* ----------------------------------------------------------------- a10 --- */
+
+int po_msa_rows(const po_graph *g, const po_params *m, char *rows, int rows_cap)
+{
+  /* lpo_format.c:346-371: a new column whenever ring_id changes (starting from 0) */
+  int i, k, cur = 0, nring = 0, iring = 0;
+  for (i = 0; i < g->n; i++) if (g->ring_id[i] != cur) { cur = g->ring_id[i]; nring++; }
+  nring++;
+  if (g->nseq * nring > rows_cap) return -1;
+  memset(rows, '.', (size_t)g->nseq * nring);
+  cur = 0;
+  for (i = 0; i < g->n; i++) {
+    if (g->ring_id[i] != cur) { cur = g->ring_id[i]; iring++; }
+    for (k = 0; k < g->nsrc[i]; k++)
+      rows[g->src_seq[i][k] * nring + iring] =
+          (g->letter[i] < m->nsymbol) ? m->symbol[g->letter[i]] : (char)g->letter[i];
+  }
+  return nring;
+}
+
+/* ----------------------------------------------------------------- a12 --- */
+
+static int heaviest_path(const po_graph *g, int *path_out)
+{
+  /* heaviest_bundle.c:16-78 */
+  const int len = g->n;
+  int *path = (int *)malloc((size_t)len * sizeof(int));
+  int *score = (int *)calloc((size_t)len, sizeof(int));
+  int contains[PO_MAXS];
+  int i, k, r, ibest = -1, best_score = PO_NEG, n = 0;
+  for (i = len - 1; i >= 0; i--) {
+    int right_score = 0, right_overlap = 0, best_right = -1;
+    memset(contains, 0, sizeof contains);    /* :35 (overrides the -1 init at :30-31) */
+    for (k = 0; k < g->nsrc[i]; k++)
+      if (g->seq_weight[g->src_seq[i][k]] > 0) contains[g->src_seq[i][k]] = g->src_pos[i][k] + 1;
+    for (r = 0; r < g->nsucc[i]; r++) {
+      int rn = g->succ[i][r], ov = 0;
+      for (k = 0; k < g->nsrc[rn]; k++)
+        if (contains[g->src_seq[rn][k]] == g->src_pos[rn][k]) ov += g->seq_weight[g->src_seq[rn][k]];
+      if (ov > right_overlap || (ov == right_overlap && score[rn] > right_score)) {
+        right_overlap = ov; right_score = score[rn]; best_right = rn;
+      }
+    }
+    path[i] = best_right;
+    score[i] = right_score + right_overlap;
+    if (score[i] > best_score) { ibest = i; best_score = score[i]; }
+  }
+  for (; ibest >= 0; ibest = path[ibest]) path_out[n++] = ibest;
+  free(path); free(score);
+  return n;
+}
+
+int po_generate_bundles(po_graph *g, float minimum_fraction, int *bundle_counts)
+{
+  /* heaviest_bundle.c:144-172, :83-110, lpo.c:762-781 */
+  int nbundled = 0, ibundle = 0;
+  int *path = (int *)malloc((size_t)(g->n + 1) * sizeof(int));
+  while (nbundled < g->nseq) {
+    int cnt[PO_MAXS] = {0}, count = 0, i, k, plen, iseq;
+    plen = heaviest_path(g, path);
+    if (plen < 10) break;
+    for (i = 0; i < plen; i++)
+      for (k = 0; k < g->nsrc[path[i]]; k++) cnt[g->src_seq[path[i]][k]]++;
+    for (i = g->nseq - 1; i >= 0; i--)
+      if (g->seq_bundle[i] < 0 && g->seq_len[i] * minimum_fraction <= cnt[i]) {
+        g->seq_bundle[i] = ibundle; g->seq_weight[i] = 0; count++;
+      }
+    if (g->nseq >= PO_MAXS) { fprintf(stderr, "poa_oracle: too many sources\n"); abort(); }
+    iseq = g->nseq++;
+    g->seq_len[iseq] = plen; g->seq_weight[iseq] = 0; g->seq_bundle[iseq] = ibundle;
+    for (i = 0; i < plen; i++) {
+      int n = path[i];
+      if (g->nsrc[n] >= PO_MAXS) { fprintf(stderr, "poa_oracle: source overflow\n"); abort(); }
+      g->src_seq[n][g->nsrc[n]] = iseq; g->src_pos[n][g->nsrc[n]] = i; g->nsrc[n]++;
+    }
+    if (bundle_counts) bundle_counts[ibundle] = count;
+    ibundle++;
+    nbundled += count;
+    if (count < 1) break;
+  }
+  free(path);
+  return ibundle;
+}
+
+/* -------------------------------------------------------------- a9 a11 --- */
+
+int po_window_triple(const po_params *m,
+                     const unsigned char *ref, int lr,
+                     const unsigned char *cor, int lc,
+                     const unsigned char *unc, int lu,
+                     int with_bundles,
+                     char *rows_out, int rows_cap, int *ncol, int *nrows,
+                     int *dbg, int64_t *ncells, int *bundle_counts)
+{
+  /* buildup_lpo.c:381-401,481-534: merge order is fixed: ref <- cor, then
+   * (ref+cor) <- unc; x is always the growing graph (cluster 0). */
+  po_graph *g, *y;
+  int *x2y, *y2x, bx, by, sc, nc, rc = 0;
+  if (lr < 1 || lc < 1 || lu < 1) return -22;
+  g = po_graph_new(lr + lc + lu + 1);
+  y = po_graph_new(lc > lu ? lc : lu);
+  x2y = (int *)malloc((size_t)(lr + lc + 1) * sizeof(int));
+  y2x = (int *)malloc((size_t)((lc > lu ? lc : lu) + 1) * sizeof(int));
+  po_graph_linear(g, ref, lr);
+
+  po_graph_linear(y, cor, lc);
+  sc = po_align(g, y, m, x2y, y2x, &bx, &by, NULL, ncells);
+  if (dbg) { dbg[0] = sc; dbg[1] = bx; dbg[2] = by; }
+  po_fuse(g, y, x2y, y2x);
+  if (dbg) dbg[6] = g->n;
+
+  po_graph_linear(y, unc, lu);
+  sc = po_align(g, y, m, x2y, y2x, &bx, &by, NULL, ncells);
+  if (dbg) { dbg[3] = sc; dbg[4] = bx; dbg[5] = by; }
+  po_fuse(g, y, x2y, y2x);
+  if (dbg) dbg[7] = g->n;
+
+  if (with_bundles) po_generate_bundles(g, 0.9f, bundle_counts);
+  nc = po_msa_rows(g, m, rows_out, rows_cap);
+  if (nc < 0) rc = -28;
+  else { if (ncol) *ncol = nc; if (nrows) *nrows = g->nseq; }
+  po_graph_free(g); po_graph_free(y); free(x2y); free(y2x);
+  return rc;
+}
+
+/* --- FASTA in, as read_fasta sees it (fasta_format.c:10-66) ------------- */
+
+typedef struct { char *name, *title; unsigned char *sym; int len; } fa_rec;
+
+static int read_fasta_records(const char *path, const po_params *m, fa_rec **out)
+{
+  FILE *f = fopen(path, "r");
+  char *line = NULL; size_t cap = 0; ssize_t n;
+  fa_rec *recs = NULL; int nrec = 0, capr = 0;
+  char *name = NULL, *title = NULL, *seq = NULL; size_t seqlen = 0, seqcap = 0;
+  int have_name = 0;
+  if (!f) return -1;
+#define FLUSH_RECORD() do { \
+    if (have_name && seqlen > 0) { \
+      if (nrec == capr) { capr = capr ? 2 * capr : 64; recs = (fa_rec *)realloc(recs, (size_t)capr * sizeof *recs); } \
+      recs[nrec].name = name; recs[nrec].title = title; \
+      recs[nrec].sym = (unsigned char *)malloc(seqlen + 1); \
+      recs[nrec].len = po_symbolize(m, seq, (int)seqlen, recs[nrec].sym); \
+      if (recs[nrec].len > 0) { nrec++; name = title = NULL; } \
+      else free(recs[nrec].sym); \
+    } } while (0)
+  while ((n = getline(&line, &cap, f)) >= 0) {
+    char *nl = strrchr(line, '\n');
+    if (nl) *nl = '\0';
+    if (line[0] == '#') { /* comment */ }
+    else if (line[0] == '>') {
+      char *p = line + 1, *q;
+      FLUSH_RECORD();
+      free(name); free(title); name = title = NULL; have_name = 0; seqlen = 0;
+      while (*p && isspace((unsigned char)*p)) p++;
+      q = p; while (*q && !isspace((unsigned char)*q)) q++;
+      if (q > p) {
+        name = strndup(p, (size_t)(q - p)); have_name = 1;
+        while (*q && isspace((unsigned char)*q)) q++;
+        title = strdup(*q ? q : "untitled");      /* :35-37 */
+      }
+    }
+    else if (line[0] == '*') { }
+    else if (have_name) {
+      size_t l = strlen(line);
+      if (seqlen + l + 1 > seqcap) { seqcap = 2 * (seqlen + l + 1); seq = (char *)realloc(seq, seqcap); }
+      memcpy(seq + seqlen, line, l); seqlen += l;
+    }
+  }
+  FLUSH_RECORD();
+#undef FLUSH_RECORD
+  free(name); free(title); free(seq); free(line);
+  fclose(f);
+  *out = recs;
+  return nrec;
+}
+
+static void free_records(fa_rec *r, int n)
+{
+  int i;
+  for (i = 0; i < n; i++) { free(r[i].name); free(r[i].title); free(r[i].sym); }
+  free(r);
+}
+
+int po_run_files(const char *matrix, const char *ref_fa, const char *cor_fa,
+                 const char *unc_fa, const char *out_path, int with_bundles)
+{
+  /* main.c:149-155,241-287 */
+  po_params *m = (po_params *)malloc(sizeof *m);
+  fa_rec *R = NULL, *C = NULL, *U = NULL;
+  int nr, nc, nu, i, rc;
+  FILE *o;
+  if (po_read_matrix(matrix, m) <= 0) { free(m); return -1; }
+  nc = read_fasta_records(cor_fa, m, &C);
+  nu = read_fasta_records(unc_fa, m, &U);
+  nr = read_fasta_records(ref_fa, m, &R);
+  if (nr <= 0 || nc < nr || nu < nr) { free(m); return -2; }   /* the reference would read past its arrays */
+  o = fopen(out_path, "w");
+  if (!o) { free(m); return -3; }
+  rc = nr;
+  for (i = 0; i < nr; i++) {
+    int cap = (R[i].len + C[i].len + U[i].len + 2) * PO_MAXS, ncol = 0, nrows = 0, k;
+    int bcounts[PO_MAXS] = {0};
+    char *rows = (char *)malloc((size_t)cap);
+    if (po_window_triple(m, R[i].sym, R[i].len, C[i].sym, C[i].len, U[i].sym, U[i].len,
+                         with_bundles, rows, cap, &ncol, &nrows, NULL, NULL, bcounts)) { free(rows); rc = -4; break; }
+    for (k = 0; k < nrows; k++) {
+      /* lpo_format.c:410-419: ">name title" then "\n" before the first char */
+      const fa_rec *src = (k == 0) ? &R[i] : (k == 1) ? &C[i] : &U[i];
+      if (k < 3) fprintf(o, ">%s %s\n", src->name, src->title);
+      else fprintf(o, ">CONSENS%d consensus produced by heaviest_bundle, containing %d seqs\n", k - 3, bcounts[k - 3]);
+      fwrite(rows + (size_t)k * ncol, 1, (size_t)ncol, o);
+      fputc('\n', o);
+    }
+    free(rows);
+  }
+  fclose(o);
+  free_records(R, nr); free_records(C, nc); free_records(U, nu); free(m);
+  return rc;
+}
+
+int64_t po_batch(const po_params *m, int n, const char *bases, const int64_t *off,
+                 char *rows, int64_t rows_cap, int64_t *row_off, int *ncol, int *scores)
+{
+  int w;
+  int64_t cells = 0, used = 0;
+  unsigned char *buf = NULL; size_t bufcap = 0;
+  row_off[0] = 0;
+  for (w = 0; w < n; w++) {
+    int64_t a = off[3 * w], b = off[3 * w + 1], c = off[3 * w + 2], d = off[3 * w + 3];
+    size_t need = (size_t)(d - a) + 3;
+    int lr, lc, lu, nc = 0, dbg[8];
+    if (need > bufcap) { bufcap = 2 * need; buf = (unsigned char *)realloc(buf, bufcap); }
+    lr = po_symbolize(m, bases + a, (int)(b - a), buf);
+    lc = po_symbolize(m, bases + b, (int)(c - b), buf + lr);
+    lu = po_symbolize(m, bases + c, (int)(d - c), buf + lr + lc);
+    if (po_window_triple(m, buf, lr, buf + lr, lc, buf + lr + lc, lu, 0,
+                         rows + used, (int)((rows_cap - used) > 0x7fffffff ? 0x7fffffff : (rows_cap - used)),
+                         &nc, NULL, dbg, &cells, NULL)) { free(buf); return -1; }
+    if (ncol) ncol[w] = nc;
+    if (scores) { scores[2 * w] = dbg[0]; scores[2 * w + 1] = dbg[3]; }
+    used += 3 * (int64_t)nc;
+    row_off[w + 1] = used;
+  }
+  free(buf);
+  return cells;
+}
