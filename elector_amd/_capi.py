@@ -1,0 +1,81 @@
+"""ctypes binding of the C ABI declared in include/elector_poa.h.
+
+This is the same stub a maintainer would add to the reference to call the
+library instead of spawning `bin/poa`.  Loading fails
+loudly when the HIP library has not been built: there is no fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libelector_poa.so")
+
+ELECTOR_MAX_SYMBOL = 32
+ELECTOR_MAX_GAPTAB = 64
+ELECTOR_MAX_SEQ = 16384
+
+E_WINDOW = -7
+W_OK, W_EMPTY, W_TOOLONG, W_INTERNAL = 0, 1, 2, 3
+
+
+class ElectorParams(C.Structure):
+    _fields_ = [
+        ("nsymbol", C.c_int32),
+        ("symbol", C.c_char * (ELECTOR_MAX_SYMBOL + 4)),
+        ("score", (C.c_int32 * ELECTOR_MAX_SYMBOL) * ELECTOR_MAX_SYMBOL),
+        ("max_gap_length", C.c_int32),
+        ("gap_penalty_x", C.c_int32 * ELECTOR_MAX_GAPTAB),
+        ("gap_penalty_y", C.c_int32 * ELECTOR_MAX_GAPTAB),
+    ]
+
+
+EXPORTS = [
+    "elector_version", "elector_strerror", "elector_device_count",
+    "elector_params_default", "elector_params_read",
+    "elector_ctx_create", "elector_ctx_destroy", "elector_ctx_last_error",
+    "elector_poa_batch", "elector_poa_batch_device", "elector_ctx_sync",
+    "elector_ctx_timing_enable", "elector_ctx_timing_read", "elector_ctx_timing_reset",
+    "elector_ctx_last_po_sizes",
+]
+
+_lib = None
+
+
+class ElectorError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = lib().elector_strerror(code).decode()
+        super().__init__("elector: %s (%d)%s" % (msg, code, (": " + detail) if detail else ""))
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "HIP library %s is missing: run `python -m elector_amd.build` "
+            "(this package has no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.elector_version.restype = C.c_char_p
+    L.elector_strerror.restype = C.c_char_p
+    L.elector_strerror.argtypes = [C.c_int]
+    L.elector_device_count.restype = C.c_int
+    L.elector_params_default.argtypes = [C.POINTER(ElectorParams)]
+    L.elector_params_default.restype = None
+    L.elector_params_read.argtypes = [C.c_char_p, C.POINTER(ElectorParams)]
+    L.elector_ctx_create.argtypes = [C.c_int, C.POINTER(ElectorParams), C.POINTER(vp)]
+    L.elector_ctx_destroy.argtypes = [vp]
+    L.elector_ctx_destroy.restype = None
+    L.elector_ctx_last_error.argtypes = [vp]
+    L.elector_ctx_last_error.restype = C.c_char_p
+    L.elector_poa_batch.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.elector_poa_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    L.elector_ctx_sync.argtypes = [vp]
+    L.elector_ctx_timing_enable.argtypes = [vp, C.c_int]
+    L.elector_ctx_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.elector_ctx_timing_reset.argtypes = [vp]
+    L.elector_ctx_last_po_sizes.argtypes = [vp, i64, vp]
+    _lib = L
+    return L

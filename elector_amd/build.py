@@ -1,0 +1,46 @@
+"""Build the HIP shared library in-tree (elector_amd/lib/libelector_poa.so).
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only
+container as well as on the GPU box.  Usage: python -m elector_amd.build [--force]
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, "csrc", f) for f in ("poa_kernels.hip", "poa_host.hip")]
+HDR = [os.path.join(HERE, "csrc", "poa_device.h"), os.path.join(ROOT, "include", "elector_poa.h")]
+OUT = os.path.join(HERE, "lib", "libelector_poa.so")
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def up_to_date():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    return all(os.path.getmtime(p) <= t for p in SRC + HDR)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+           "-o", OUT] + SRC
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,90 @@
+// elector_amd/csrc/poa_device.h -- shared device/host definitions of the POA engine.
+//
+// Data layout in HBM (all arrays are per batch, owned by the context workspace):
+//
+//   off[3n+1]     int64   byte offsets of (ref, cor, unc) per window in `bases`
+//   sym[total]    u8      symbol indices (a2), same offsets as `bases`
+//   "node space"  window w owns slots  nb = off[3w] + w  ..  nb + Lr+Lc+Lu  (inclusive)
+//                 i.e. one more slot than it has bases, so that 1-based node
+//                 indices jj = 1..|PO| and the virtual start node jj = 0 fit.
+//       xinfo[nb+jj]  int2  DP view of node jj of the graph after fusion #1:
+//                             .x = pp1 | pp2<<16   (DP predecessor list, 1-based,
+//                                                   0 = virtual start, 0xFFFF = none)
+//                             .y = letter | flags<<8
+//       ring1[nb+j]   u16   ring id (column id) of node j
+//       map16[nb+j]   u16   x_to_y of the alignment being traced (0xFFFF = unaligned)
+//       carry[nb+jj]  i32   packed (score, tag) of the last row of a DP strip
+//   moves         u32     per window and alignment: [strip][t>>3][lane] dwords,
+//                         8 steps x 4 bits per dword (see mv_index)
+//   cols[3*off[3w] + 3c + r]  u8   the window's MSA, column-interleaved
+//
+// DP geometry: lanes are ROWS (the linear read y), time is the anti-diagonal:
+// lane l of strip s owns row ii = 63 s + l (ii = 0 is the virtual row -1 of the
+// reference's DP, align_lpo_po2.c:272-286); at step t it computes node
+// jj = t - l.  Lane 0 does not compute: it replays the previous strip's last
+// row (or the virtual row) so that lane 1 can read it like any other neighbour.
+#pragma once
+#include <stdint.h>
+
+namespace elector {
+
+constexpr int kStripRows = 63;
+constexpr int kNeg = -999999;           // min_score, align_lpo_po2.c:198
+constexpr uint32_t kNone16 = 0xFFFFu;
+constexpr int kTagBits = 6;             // packed cell = score << 6 | tag
+
+// node flags (xinfo.y >> 8)
+constexpr int kFlagFinal = 1, kFlagHasRef = 2, kFlagHasCor = 4, kFlagInitial = 8;
+
+// move nibble = x-ordinal (0..2) | y-ordinal (0..1) << 2   (align_lpo_po2.c:12-16)
+constexpr int kMoveX1 = 1, kMoveX2 = 2, kMoveY = 4;
+
+struct DevTables {
+  int32_t gpx[64];
+  int32_t gpy[64];
+  int32_t sub[32 * 32];
+  uint8_t lut[256];     // raw byte -> symbol index (a2)
+  uint8_t chr[32];      // symbol index -> output character (a10)
+};
+
+struct KParams {
+  int M;                 // max_gap_length
+  int open_x, ext_x, open_y, ext_y, match, mismatch;   // used when !GEN
+};
+
+// dwords of move storage per strip for an alignment with Lx columns
+__host__ __device__ inline int mv_tw(int Lx) { return (Lx + 71) >> 3; }
+__host__ __device__ inline int n_strips(int Ly) { return (Ly + kStripRows - 1) / kStripRows; }
+// dword index of the nibble of cell (ii, jj), ii >= 1 (1-based row), jj >= 1
+__host__ __device__ inline int64_t mv_index(int tw, int ii, int jj, int *shift)
+{
+  int s = (ii - 1) / kStripRows, lane = (ii - 1) % kStripRows + 1, t = jj + lane;
+  *shift = 4 * (t & 7);
+  return ((int64_t)s * tw + (t >> 3)) * 64 + lane;
+}
+
+struct BatchArgs {
+  int64_t n;                 // windows in this launch range
+  const uint32_t *perm;      // processing order (window ids)
+  const int64_t *off;        // [3n+1]
+  const uint8_t *bases;      // raw
+  uint8_t *sym;
+  int2 *xinfo;
+  uint16_t *ring1;
+  uint16_t *map16;
+  int32_t *carry;
+  uint32_t *moves;
+  const int64_t *mv1;        // dword offset of alignment #1 moves per window
+  const int64_t *mv2;
+  int32_t *n1;               // |PO| after fusion #1
+  uint8_t *cls;              // ring class needed by alignment #2 (0,1,2; 3 = unsupported)
+  int32_t *score1, *score2, *bx2;
+  uint8_t *cols;
+  int32_t *ncol;
+  int32_t *status;
+  const int32_t *linx, *liny;   // packed border cells: k gap steps from the origin
+  const DevTables *tab;
+  KParams kp;
+};
+
+}  // namespace elector

@@ -1,0 +1,610 @@
+// elector_amd/csrc/poa_host.hip -- host side of the C ABI (include/elector_poa.h):
+// scoring-parameter parsing (a1), context/workspace management and the batch
+// orchestration that replaces one `poa` process (src/poa-graph/main.c:241-287).
+// There is no CPU compute path in this file: without a gfx950 device every
+// compute entry fails with ELECTOR_E_NODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "elector_poa.h"
+#include "poa_device.h"
+
+namespace elector {
+void launch_symbolize(const uint8_t *in, uint8_t *out, int64_t nbytes, const DevTables *tab, hipStream_t st);
+void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st);
+void launch_fuse1(const BatchArgs &a, hipStream_t st);
+void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st);
+void launch_fuse2(const BatchArgs &a, hipStream_t st);
+void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
+                 uint8_t *rows, int64_t n, hipStream_t st);
+}  // namespace elector
+
+using namespace elector;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes)
+  {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 4096;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return ELECTOR_E_NOMEM; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct HostPinned {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes)
+  {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return ELECTOR_E_NOMEM; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct TimedSpan { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct elector_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  elector_params params;
+  KParams kp;
+  bool gen = false;
+  std::string err;
+  std::mutex mu;
+  // constant tables
+  DevBuf d_tab, d_linx, d_liny;
+  // per-batch workspace
+  DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
+      d_n1, d_cls, d_score1, d_score2, d_bx2;
+  // host API staging
+  DevBuf d_bases, d_cols, d_ncol, d_status, d_scores, d_rowoff, d_rows;
+  HostPinned h_meta;
+  // timing
+  bool timing = false;
+  std::vector<TimedSpan> spans;
+  double ms_acc[3] = {0, 0, 0};
+  int64_t launches_acc[3] = {0, 0, 0};
+  int64_t last_n = 0;
+};
+
+static int fail(elector_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+  }
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                        \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) return fail((ctx), ELECTOR_E_HIP, #call, e_);          \
+  } while (0)
+
+// ------------------------------------------------------------------ probes ---
+
+extern "C" const char *elector_version(void) { return "elector_amd 0.1 (gfx950)"; }
+
+extern "C" const char *elector_strerror(int code)
+{
+  switch (code) {
+    case ELECTOR_OK: return "ok";
+    case ELECTOR_E_INVAL: return "invalid argument";
+    case ELECTOR_E_NODEVICE: return "no usable gfx950 device (this library has no CPU fallback)";
+    case ELECTOR_E_NOMEM: return "out of memory";
+    case ELECTOR_E_HIP: return "HIP runtime error";
+    case ELECTOR_E_PARAMS: return "scoring parameters outside device limits";
+    case ELECTOR_E_IO: return "matrix file unreadable or malformed";
+    case ELECTOR_E_WINDOW: return "one or more windows failed (see status[])";
+    default: return "unknown error";
+  }
+}
+
+static bool device_is_gfx950(int dev)
+{
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" int elector_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; ++d) ok += device_is_gfx950(d) ? 1 : 0;
+  return ok;
+}
+
+// --------------------------------------------------------------------- a1 ---
+
+static void build_gap_arrays(elector_params *p, const int set[2][3], int T, int D)
+{
+  // seq_util.c:168-196
+  const int M = T + D;
+  p->max_gap_length = M;
+  std::memset(p->gap_penalty_x, 0, sizeof p->gap_penalty_x);
+  std::memset(p->gap_penalty_y, 0, sizeof p->gap_penalty_y);
+  if (M + 1 >= ELECTOR_MAX_GAPTAB || M < 0) return;
+  p->gap_penalty_x[0] = set[0][0];
+  p->gap_penalty_y[0] = set[1][0];
+  for (int i = 1; i < T; ++i) { p->gap_penalty_x[i] = set[0][1]; p->gap_penalty_y[i] = set[1][1]; }
+  for (int i = 0; i < D; ++i) {
+    const double dx = (set[0][1] - set[0][2]) / (double)(D + 1);
+    const double dy = (set[1][1] - set[1][2]) / (double)(D + 1);
+    p->gap_penalty_x[i + T] = (int)(set[0][1] - (i + 1) * dx);
+    p->gap_penalty_y[i + T] = (int)(set[1][1] - (i + 1) * dy);
+  }
+  p->gap_penalty_x[M] = set[0][2];
+  p->gap_penalty_y[M] = set[1][2];
+  p->gap_penalty_x[M + 1] = 0;
+  p->gap_penalty_y[M + 1] = 0;
+}
+
+extern "C" void elector_params_default(elector_params *p)
+{
+  // the values ELECTOR ships (src/poa-graph/blosum80.mat:8-42): 31 symbols,
+  // identity 0 / mismatch -10, GAP-PENALTIES=10 5 5, truncation 10, decay 5
+  static const char alphabet[] = "ARNDCQEGHILKMFPSTWYVBZX?agtcu]n";
+  std::memset(p, 0, sizeof *p);
+  p->nsymbol = (int)std::strlen(alphabet);
+  std::memcpy(p->symbol, alphabet, (size_t)p->nsymbol);
+  for (int i = 0; i < p->nsymbol; ++i)
+    for (int j = 0; j < p->nsymbol; ++j) p->score[i][j] = (i == j) ? 0 : -10;
+  const int set[2][3] = {{10, 5, 5}, {10, 5, 5}};
+  build_gap_arrays(p, set, 10, 5);
+}
+
+extern "C" int elector_params_read(const char *path, elector_params *p)
+{
+  // replaces read_score_matrix (seq_util.c:82-217): '#'/blank lines skipped,
+  // GAP-* directives, then the symbol line, then one score row per symbol.
+  if (!path || !p) return ELECTOR_E_INVAL;
+  std::FILE *f = std::fopen(path, "r");
+  if (!f) return ELECTOR_E_IO;
+  std::memset(p, 0, sizeof *p);
+  int set[2][3] = {{12, 2, 0}, {12, 2, 0}};     // :89-91
+  int T = 16, D = 0;                            // poa.h:13,19
+  char line[1024];
+  int nsym = 0;
+  bool have_symbols = false;
+  int rc = ELECTOR_OK;
+  while (std::fgets(line, 1023, f)) {
+    int i, j, k;
+    if (line[0] == '#' || line[0] == '\n') continue;
+    if (std::sscanf(line, "GAP-TRUNCATION-LENGTH=%d", &i) == 1) { T = i; continue; }
+    if (std::sscanf(line, "GAP-DECAY-LENGTH=%d", &i) == 1) { D = i; continue; }
+    if (std::sscanf(line, "GAP-PENALTIES=%d %d %d", &i, &j, &k) == 3) {
+      set[0][0] = set[1][0] = i; set[0][1] = set[1][1] = j; set[0][2] = set[1][2] = k;
+      continue;
+    }
+    if (std::sscanf(line, "GAP-PENALTIES-X=%d %d %d", &i, &j, &k) == 3) {
+      set[1][0] = i; set[1][1] = j; set[1][2] = k;             // lands in the y arrays (:119-123)
+      continue;
+    }
+    if (!have_symbols) {
+      for (const char *c = line; *c; ++c)
+        if (!std::isspace((unsigned char)*c)) {
+          if (nsym >= ELECTOR_MAX_SYMBOL) { rc = ELECTOR_E_PARAMS; break; }
+          p->symbol[nsym++] = *c;
+        }
+      have_symbols = true;
+      if (rc) break;
+      continue;
+    }
+    int row = -1;
+    for (int s = nsym - 1; s >= 0; --s)
+      if (p->symbol[s] == line[0]) { row = s; break; }           // backward scan, first hit (default.h:24)
+    if (row < 0) { rc = ELECTOR_E_IO; break; }
+    int pos = 1;
+    for (int c = 0; c < nsym; ++c) {
+      int v, used;
+      if (std::sscanf(line + pos, "%d%n", &v, &used) != 1) { rc = ELECTOR_E_IO; break; }
+      p->score[row][c] = v;
+      pos += used;
+    }
+    if (rc) break;
+  }
+  std::fclose(f);
+  if (rc) return rc;
+  if (nsym <= 0) return ELECTOR_E_IO;
+  p->nsymbol = nsym;
+  if (T < 0 || D < 0 || T + D + 2 > ELECTOR_MAX_GAPTAB) return ELECTOR_E_PARAMS;
+  build_gap_arrays(p, set, T, D);
+  return ELECTOR_OK;
+}
+
+// ---------------------------------------------------------------- context ---
+
+static int validate_params(const elector_params *p)
+{
+  if (p->nsymbol < 1 || p->nsymbol > ELECTOR_MAX_SYMBOL) return ELECTOR_E_PARAMS;
+  if (p->max_gap_length < 0 || p->max_gap_length + 2 > ELECTOR_MAX_GAPTAB) return ELECTOR_E_PARAMS;
+  // scores must stay far from the packed-cell range: |score| * (2*MAX_SEQ) < 2^25
+  for (int i = 0; i < p->nsymbol; ++i)
+    for (int j = 0; j < p->nsymbol; ++j)
+      if (std::abs(p->score[i][j]) > 500) return ELECTOR_E_PARAMS;
+  for (int g = 0; g <= p->max_gap_length + 1; ++g)
+    if (std::abs(p->gap_penalty_x[g]) > 500 || std::abs(p->gap_penalty_y[g]) > 500) return ELECTOR_E_PARAMS;
+  return ELECTOR_OK;
+}
+
+// Can the DP kernels use compile-time-simple scoring?  (uniform substitution
+// scores, one extension penalty per direction) -- true for the shipped matrix.
+static bool params_are_simple(const elector_params *p, KParams *kp)
+{
+  const int M = p->max_gap_length;
+  kp->M = M;
+  if (M < 1) return false;
+  const int match = p->score[0][0], mismatch = p->nsymbol > 1 ? p->score[0][1] : 0;
+  for (int i = 0; i < p->nsymbol; ++i)
+    for (int j = 0; j < p->nsymbol; ++j)
+      if (p->score[i][j] != (i == j ? match : mismatch)) return false;
+  for (int g = 1; g <= M; ++g)
+    if (p->gap_penalty_x[g] != p->gap_penalty_x[1] || p->gap_penalty_y[g] != p->gap_penalty_y[1]) return false;
+  kp->open_x = p->gap_penalty_x[0]; kp->ext_x = p->gap_penalty_x[1];
+  kp->open_y = p->gap_penalty_y[0]; kp->ext_y = p->gap_penalty_y[1];
+  kp->match = match; kp->mismatch = mismatch;
+  return true;
+}
+
+extern "C" int elector_ctx_create(int device, const elector_params *p, elector_ctx **out)
+{
+  if (!p || !out) return ELECTOR_E_INVAL;
+  *out = nullptr;
+  int rc = validate_params(p);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ELECTOR_E_NODEVICE;
+  if (device < 0 || device >= ndev || !device_is_gfx950(device)) return ELECTOR_E_NODEVICE;
+  elector_ctx *c = new (std::nothrow) elector_ctx();
+  if (!c) return ELECTOR_E_NOMEM;
+  c->device = device;
+  c->params = *p;
+  c->gen = !params_are_simple(p, &c->kp);
+  if (std::getenv("ELECTOR_FORCE_GENERAL")) c->gen = true;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return ELECTOR_E_HIP;
+  }
+  // constant tables
+  DevTables tab;
+  std::memset(&tab, 0, sizeof tab);
+  const int M = p->max_gap_length;
+  for (int g = 0; g <= M; ++g) { tab.gpx[g] = p->gap_penalty_x[g]; tab.gpy[g] = p->gap_penalty_y[g]; }
+  tab.gpx[M + 1] = tab.gpx[0]; tab.gpy[M + 1] = tab.gpy[0];   // global mode (align_lpo_po2.c:244-246)
+  for (int i = 0; i < p->nsymbol; ++i)
+    for (int j = 0; j < p->nsymbol; ++j) tab.sub[i * 32 + j] = p->score[i][j];
+  for (int b = 0; b < 256; ++b) {
+    // a2: tolower, then anything outside the alphabet becomes symbol[0]
+    const char ch = (char)std::tolower(b);
+    int idx = -1;
+    for (int s = 0; s < p->nsymbol; ++s) if (p->symbol[s] == ch) { idx = s; break; }
+    if (idx < 0) for (int s = 0; s < p->nsymbol; ++s) if (p->symbol[s] == p->symbol[0]) { idx = s; break; }
+    tab.lut[b] = (uint8_t)idx;
+  }
+  for (int s = 0; s < p->nsymbol; ++s) tab.chr[s] = (uint8_t)p->symbol[s];
+  // border cells: k gap steps from the origin along x (row -1) and y (column -1)
+  std::vector<int32_t> linx(ELECTOR_MAX_SEQ + 2), liny(ELECTOR_MAX_SEQ + 2);
+  {
+    int sx = 0, gx = 0, sy = 0, gy = 0;
+    for (int k = 0; k < ELECTOR_MAX_SEQ + 2; ++k) {
+      linx[k] = (sx << kTagBits) | gx;
+      liny[k] = (sy << kTagBits) | gy;
+      sx -= tab.gpx[gx]; gx = std::min(gx + 1, M);
+      sy -= tab.gpy[gy]; gy = std::min(gy + 1, M);
+    }
+  }
+  rc = c->d_tab.ensure(sizeof tab) | c->d_linx.ensure(linx.size() * 4) | c->d_liny.ensure(liny.size() * 4);
+  if (!rc) {
+    if (hipMemcpy(c->d_tab.p, &tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_linx.p, linx.data(), linx.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_liny.p, liny.data(), liny.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      rc = ELECTOR_E_HIP;
+  }
+  if (rc) { elector_ctx_destroy(c); return rc; }
+  *out = c;
+  return ELECTOR_OK;
+}
+
+extern "C" void elector_ctx_destroy(elector_ctx *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  DevBuf *bufs[] = {&c->d_tab, &c->d_linx, &c->d_liny, &c->d_off, &c->d_perm, &c->d_mv1, &c->d_mv2, &c->d_sym,
+                    &c->d_xinfo, &c->d_ring1, &c->d_map16, &c->d_carry, &c->d_moves, &c->d_n1, &c->d_cls,
+                    &c->d_score1, &c->d_score2, &c->d_bx2, &c->d_bases, &c->d_cols, &c->d_ncol, &c->d_status,
+                    &c->d_scores, &c->d_rowoff, &c->d_rows};
+  for (DevBuf *b : bufs) b->release();
+  c->h_meta.release();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char *elector_ctx_last_error(const elector_ctx *c) { return c ? c->err.c_str() : ""; }
+
+extern "C" int elector_ctx_sync(elector_ctx *c)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ELECTOR_OK;
+}
+
+// ----------------------------------------------------------------- timing ---
+
+extern "C" int elector_ctx_timing_enable(elector_ctx *c, int on)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  c->timing = on != 0;
+  return ELECTOR_OK;
+}
+
+static void span_begin(elector_ctx *c, int kind)
+{
+  if (!c->timing) return;
+  TimedSpan s;
+  s.kind = kind;
+  if (hipEventCreate(&s.a) != hipSuccess) return;
+  if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
+  (void)hipEventRecord(s.a, c->stream);
+  c->spans.push_back(s);
+}
+
+static void span_end(elector_ctx *c)
+{
+  if (!c->timing || c->spans.empty()) return;
+  (void)hipEventRecord(c->spans.back().b, c->stream);
+}
+
+static void spans_collect(elector_ctx *c)
+{
+  for (auto &s : c->spans) {
+    float ms = 0;
+    if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      c->ms_acc[s.kind] += ms;
+      c->launches_acc[s.kind] += 1;
+    }
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  c->spans.clear();
+}
+
+extern "C" int elector_ctx_timing_read(elector_ctx *c, int kernel, double *ms, int64_t *launches)
+{
+  if (!c || kernel < 0 || kernel > 2) return ELECTOR_E_INVAL;
+  (void)hipSetDevice(c->device);
+  spans_collect(c);
+  if (ms) *ms = c->ms_acc[kernel];
+  if (launches) *launches = c->launches_acc[kernel];
+  return ELECTOR_OK;
+}
+
+extern "C" int elector_ctx_timing_reset(elector_ctx *c)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  (void)hipSetDevice(c->device);
+  spans_collect(c);
+  for (int k = 0; k < 3; ++k) { c->ms_acc[k] = 0; c->launches_acc[k] = 0; }
+  return ELECTOR_OK;
+}
+
+extern "C" int elector_ctx_last_po_sizes(elector_ctx *c, int64_t n, int32_t *po_nodes)
+{
+  if (!c || !po_nodes || n < 0 || n > c->last_n) return ELECTOR_E_INVAL;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(po_nodes, c->d_n1.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return ELECTOR_OK;
+}
+
+// ------------------------------------------------------------------ batch ---
+
+// Moves scratch is the only part of the workspace that grows faster than the
+// input; windows are processed in chunks whose scratch stays below this.
+static const int64_t kMovesBudgetDwords = (int64_t)3 << 28;   // 3 GiB
+
+static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *off,
+                            uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status, int32_t *d_scores)
+{
+  if (n == 0) return ELECTOR_OK;
+  const int64_t total = off[3 * n];
+  if (off[0] != 0 || total < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
+
+  // ---- host metadata: status, moves offsets, processing order ----
+  int rc = c->h_meta.ensure((size_t)n * (4 + 8 + 8 + 4));
+  if (rc) return fail(c, rc, "pinned metadata");
+  int32_t *h_status = c->h_meta.as<int32_t>();
+  int64_t *h_mv1 = reinterpret_cast<int64_t *>(h_status + n + (n & 1));
+  int64_t *h_mv2 = h_mv1 + n;
+  uint32_t *h_perm = reinterpret_cast<uint32_t *>(h_mv2 + n);
+
+  struct Chunk { int64_t w0, w1, dwords; };
+  std::vector<Chunk> chunks;
+  {
+    int64_t w0 = 0, acc = 0;
+    for (int64_t w = 0; w < n; ++w) {
+      const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
+                    lu = off[3 * w + 3] - off[3 * w + 2];
+      int st = ELECTOR_W_OK;
+      if (lr < 0 || lc < 0 || lu < 0) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
+      if (lr == 0 || lc == 0 || lu == 0) st = ELECTOR_W_EMPTY;
+      else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ) st = ELECTOR_W_TOOLONG;
+      h_status[w] = st;
+      int64_t d1 = 0, d2 = 0;
+      if (!st) {
+        d1 = (int64_t)n_strips((int)lc) * mv_tw((int)lr) * 64;
+        d2 = (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64;   // |PO| <= Lr + Lc
+      }
+      if (acc + d1 + d2 > kMovesBudgetDwords && w > w0) { chunks.push_back({w0, w, acc}); w0 = w; acc = 0; }
+      h_mv1[w] = acc; acc += d1;
+      h_mv2[w] = acc; acc += d2;
+    }
+    chunks.push_back({w0, n, acc});
+  }
+  int64_t max_dwords = 0;
+  for (auto &ch : chunks) max_dwords = std::max(max_dwords, ch.dwords);
+
+  // processing order inside each chunk: coarse counting sort, largest first
+  for (auto &ch : chunks) {
+    constexpr int NB = 256;
+    int64_t cnt[NB + 1] = {0};
+    auto key = [&](int64_t w) {
+      const int64_t m = std::max(off[3 * w + 1] - off[3 * w], off[3 * w + 3] - off[3 * w + 2]);
+      int k = (int)(m >> 3);
+      if (k >= NB) k = NB - 1;
+      return NB - 1 - k;                                   // descending size
+    };
+    for (int64_t w = ch.w0; w < ch.w1; ++w) cnt[key(w) + 1]++;
+    for (int k = 0; k < NB; ++k) cnt[k + 1] += cnt[k];
+    for (int64_t w = ch.w0; w < ch.w1; ++w) h_perm[ch.w0 + cnt[key(w)]++] = (uint32_t)w;
+  }
+
+  // ---- workspace ----
+  const size_t nodes = (size_t)total + (size_t)n + 8;
+  rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_perm.ensure((size_t)n * 4) | c->d_mv1.ensure((size_t)n * 8) |
+       c->d_mv2.ensure((size_t)n * 8) | c->d_sym.ensure((size_t)total + 64) | c->d_xinfo.ensure(nodes * 8) |
+       c->d_ring1.ensure(nodes * 2) | c->d_map16.ensure(nodes * 2) | c->d_carry.ensure(nodes * 4) |
+       c->d_moves.ensure((size_t)max_dwords * 4 + 1024) | c->d_n1.ensure((size_t)n * 4) | c->d_cls.ensure((size_t)n) |
+       c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) | c->d_bx2.ensure((size_t)n * 4);
+  if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
+
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->d_off.p, off, (size_t)(3 * n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_perm.p, h_perm, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_mv1.p, h_mv1, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
+
+  span_begin(c, 2);
+  launch_symbolize(d_bases, c->d_sym.as<uint8_t>(), total, c->d_tab.as<DevTables>(), st);
+
+  BatchArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.off = c->d_off.as<int64_t>();
+  a.bases = d_bases;
+  a.sym = c->d_sym.as<uint8_t>();
+  a.xinfo = c->d_xinfo.as<int2>();
+  a.ring1 = c->d_ring1.as<uint16_t>();
+  a.map16 = c->d_map16.as<uint16_t>();
+  a.carry = c->d_carry.as<int32_t>();
+  a.moves = c->d_moves.as<uint32_t>();
+  a.mv1 = c->d_mv1.as<int64_t>();
+  a.mv2 = c->d_mv2.as<int64_t>();
+  a.n1 = c->d_n1.as<int32_t>();
+  a.cls = c->d_cls.as<uint8_t>();
+  a.score1 = c->d_score1.as<int32_t>();
+  a.score2 = c->d_score2.as<int32_t>();
+  a.bx2 = c->d_bx2.as<int32_t>();
+  a.cols = d_cols;
+  a.ncol = d_ncol;
+  a.status = d_status;
+  a.linx = c->d_linx.as<int32_t>();
+  a.liny = c->d_liny.as<int32_t>();
+  a.tab = c->d_tab.as<DevTables>();
+  a.kp = c->kp;
+
+  for (auto &ch : chunks) {
+    a.n = ch.w1 - ch.w0;
+    a.perm = c->d_perm.as<uint32_t>() + ch.w0;
+    if (c->timing) { span_end(c); span_begin(c, 0); }
+    launch_dp1(a, c->gen, st);
+    if (c->timing) { span_end(c); span_begin(c, 2); }
+    launch_fuse1(a, st);
+    if (c->timing) { span_end(c); span_begin(c, 1); }
+    for (int cls = 0; cls < 3; ++cls) launch_dp2(a, c->gen, cls, st);
+    if (c->timing) { span_end(c); span_begin(c, 2); }
+    launch_fuse2(a, st);
+  }
+  span_end(c);
+  HIPCHK(c, hipGetLastError());
+
+  if (d_scores) {
+    // interleave (score1, score2) per window
+    HIPCHK(c, hipMemcpy2DAsync(d_scores, 8, c->d_score1.p, 4, 4, (size_t)n, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpy2DAsync(d_scores + 1, 8, c->d_score2.p, 4, 4, (size_t)n, hipMemcpyDeviceToDevice, st));
+  }
+  c->last_n = n;
+  return ELECTOR_OK;
+}
+
+extern "C" int elector_poa_batch_device(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *off,
+                                         uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status, int32_t *d_scores)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n < 0 || n > 0x7fffffff || !off || (n > 0 && (!d_bases || !d_cols || !d_ncol || !d_status)))
+    return fail(c, ELECTOR_E_INVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  return run_device_batch(c, n, d_bases, off, d_cols, d_ncol, d_status, d_scores);
+}
+
+extern "C" int elector_poa_batch(elector_ctx *c, int64_t n, const uint8_t *bases, const int64_t *off, uint8_t *rows,
+                                 int64_t rows_cap, int64_t *row_off, int32_t *ncol, int32_t *status, int32_t *scores)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n < 0 || n > 0x7fffffff || !off || !row_off || (n > 0 && (!bases || !rows || !ncol || !status)))
+    return fail(c, ELECTOR_E_INVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  row_off[0] = 0;
+  if (n == 0) return ELECTOR_OK;
+  const int64_t total = off[3 * n];
+  if (off[0] != 0 || total < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
+  int rc = c->d_bases.ensure((size_t)total + 64) | c->d_cols.ensure((size_t)3 * total + 64) |
+           c->d_ncol.ensure((size_t)n * 4) | c->d_status.ensure((size_t)n * 4) | c->d_scores.ensure((size_t)n * 8) |
+           c->d_rowoff.ensure((size_t)(n + 1) * 8);
+  if (rc) return fail(c, ELECTOR_E_NOMEM, "device staging");
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->d_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+  rc = run_device_batch(c, n, c->d_bases.as<uint8_t>(), off, c->d_cols.as<uint8_t>(), c->d_ncol.as<int32_t>(),
+                        c->d_status.as<int32_t>(), scores ? c->d_scores.as<int32_t>() : nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(ncol, c->d_ncol.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(status, c->d_status.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (scores) HIPCHK(c, hipMemcpyAsync(scores, c->d_scores.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  bool any_bad = false;
+  for (int64_t w = 0; w < n; ++w) {
+    if (status[w]) { any_bad = true; ncol[w] = 0; }
+    row_off[w + 1] = row_off[w] + 3 * (int64_t)ncol[w];
+  }
+  if (row_off[n] > rows_cap) return fail(c, ELECTOR_E_INVAL, "rows buffer too small");
+  rc = c->d_rows.ensure((size_t)row_off[n] + 64);
+  if (rc) return fail(c, ELECTOR_E_NOMEM, "device rows");
+  HIPCHK(c, hipMemcpyAsync(c->d_rowoff.p, row_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+  launch_rows(c->d_cols.as<uint8_t>(), c->d_off.as<int64_t>(), c->d_ncol.as<int32_t>(), c->d_rowoff.as<int64_t>(),
+              c->d_rows.as<uint8_t>(), n, st);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(rows, c->d_rows.p, (size_t)row_off[n], hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return any_bad ? ELECTOR_E_WINDOW : ELECTOR_OK;
+}

@@ -1,0 +1,542 @@
+// elector_amd/csrc/poa_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the
+// triplet-MSA engine.  One wavefront = one window for the two dynamic programs;
+// one lane = one window for the light serial stages (traceback, fusion, rows).
+//
+//   k_symbolize   a2   raw bytes -> symbol indices           (seq_util.c:37-52,253-263; create_seq.c:129-132)
+//   k_dp1         a5   linear(ref) x linear(cor) DP          (align_lpo_po2.c:178-433)
+//   k_fuse1       a7+a8 traceback #1 + fusion #1 -> PO graph (align_lpo_po2.c:108-168; lpo.c:413-463,602-656)
+//   k_dp2         a4+a5 PO(ref+cor) x linear(unc) DP         (align_lpo_po2.c:29-105,178-433)
+//   k_fuse2       a7+a8+a10 traceback #2 + fusion #2 + MSA columns (lpo_format.c:337-393)
+//   k_rows        column-interleaved MSA -> three rows (host-buffer API only)
+//
+// No MFMA: the recurrence is an integer max-plus chain, not a contraction.
+#include <hip/hip_runtime.h>
+#include "poa_device.h"
+
+namespace elector {
+
+// ---------------------------------------------------------------- helpers ---
+
+__device__ __forceinline__ int wave_shr1(int v)
+{
+  // DPP wave_shr:1 -- lane l receives lane l-1's value, lane 0 keeps its own.
+  return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ int pack_cell(int s, int g) { return (s << kTagBits) | g; }
+__device__ __forceinline__ int cell_score(int p) { return p >> kTagBits; }
+__device__ __forceinline__ int cell_tag(int p) { return p & ((1 << kTagBits) - 1); }
+
+// carry rows are handed from one strip to the next through memory by the same
+// wave; sc1 accesses keep the per-CU L1 out of the picture.
+__device__ __forceinline__ int ld_carry(const int32_t *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_carry(int32_t *p, int v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool GEN>
+struct Scoring {
+  const int *gpx, *gpy, *sub;   // LDS tables when GEN
+  KParams kp;
+  __device__ __forceinline__ int pen_x(int g) const { return GEN ? gpx[g] : (g ? kp.ext_x : kp.open_x); }
+  __device__ __forceinline__ int pen_y(int g) const { return GEN ? gpy[g] : (g ? kp.ext_y : kp.open_y); }
+  __device__ __forceinline__ int subst(int a, int b) const
+  {
+    return GEN ? sub[a * 32 + b] : (a == b ? kp.match : kp.mismatch);
+  }
+  // gap-tag transition (align_lpo_po2.c:230-249); the initial tag M+1 behaves
+  // exactly like 0 in global mode, so borders use 0.
+  __device__ __forceinline__ int next_tag(int g) const { return min(g + 1, kp.M); }
+};
+
+template <bool GEN>
+__device__ __forceinline__ void load_tables(int *lds, const DevTables *tab, int lane)
+{
+  if (GEN) {
+    for (int i = lane; i < 64; i += 64) { lds[i] = tab->gpx[i]; lds[64 + i] = tab->gpy[i]; }
+    for (int i = lane; i < 1024; i += 64) lds[128 + i] = tab->sub[i];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------ k_symbolize ---
+
+__global__ void __launch_bounds__(256) k_symbolize(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                    int64_t nbytes, const DevTables *__restrict__ tab)
+{
+  __shared__ uint8_t lut[256];
+  lut[threadIdx.x] = tab->lut[threadIdx.x];
+  __syncthreads();
+  const int64_t nvec = nbytes >> 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    uint4 v = reinterpret_cast<const uint4 *>(in)[i];
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t x = w[k];
+      w[k] = (uint32_t)lut[x & 255] | ((uint32_t)lut[(x >> 8) & 255] << 8) |
+             ((uint32_t)lut[(x >> 16) & 255] << 16) | ((uint32_t)lut[x >> 24] << 24);
+    }
+    reinterpret_cast<uint4 *>(out)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // tail bytes
+  for (int64_t i = (nvec << 4) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride)
+    out[i] = lut[in[i]];
+}
+
+// ------------------------------------------------------------------ k_dp1 ---
+// Alignment #1: x = reference (linear), y = corrected (linear).  Every column
+// has the single predecessor jj-1, so the three neighbours of a cell come from
+// registers: left = own previous step, up = lane-1 previous step (DPP), diag =
+// the `up` received one step earlier.
+
+template <bool GEN>
+__global__ void __launch_bounds__(64) k_dp1(BatchArgs a)
+{
+  __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
+  const int lane = threadIdx.x;
+  load_tables<GEN>(lds_tab, a.tab, lane);
+  Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
+
+  if ((int64_t)blockIdx.x >= a.n) return;
+  const uint32_t w = a.perm[blockIdx.x];
+  if (a.status[w]) return;
+  const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2];
+  const int Lx = (int)(o1 - o0), Ly = (int)(o2 - o1);
+  const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
+  uint32_t *mv = a.moves + a.mv1[w];
+  int32_t *carry = a.carry + (o0 + w);
+  const int tw = mv_tw(Lx), ns = n_strips(Ly);
+
+  for (int s = 0; s < ns; ++s) {
+    const int ii = s * kStripRows + lane;
+    const bool rowok = lane >= 1 && ii <= Ly;
+    const int yl = rowok ? ys[ii - 1] : 0;
+    const int colp = a.liny[min(ii, Ly)];
+    const int32_t *src0 = (s == 0) ? a.linx : carry;
+    const bool wr_carry = (s + 1 < ns);
+    const int nl = min(kStripRows, Ly - s * kStripRows);
+    const int T = Lx + nl;
+    int S1 = 0, g1 = 0, sdiag = 0, xl = 0, xblk = 0, c0blk = 0;
+    uint32_t mvacc = 0;
+    for (int t = 0; t <= T; ++t) {
+      if ((t & 63) == 0) {
+        const int j = t + lane;
+        xblk = (j >= 1 && j <= Lx) ? xs[j - 1] : 0;
+        c0blk = (j <= Lx) ? ld_carry(src0 + j) : 0;
+      }
+      const int x0 = __builtin_amdgcn_readlane(xblk, t & 63);
+      const int c0 = __builtin_amdgcn_readlane(c0blk, t & 63);
+      const int s_up = wave_shr1(S1), g_up = wave_shr1(g1);
+      xl = wave_shr1(xl);
+      if (lane == 0) xl = x0;
+      const int jj = t - lane;
+      const bool cell = rowok && jj >= 1 && jj <= Lx;
+
+      const int insY = s_up - sc.pen_y(g_up);
+      const int mat = sdiag + sc.subst(xl, yl);
+      const int insX = S1 - sc.pen_x(g1);
+      const bool m = (mat > insY) && (mat > insX);          // align_lpo_po2.c:384
+      const bool xw = !m && (insX > insY);                  // :392
+      int S = m ? mat : (xw ? insX : insY);
+      int g = m ? 0 : sc.next_tag(xw ? g1 : g_up);
+      uint32_t nib = m ? (kMoveX1 | kMoveY) : (xw ? kMoveX1 : kMoveY);
+      if (!cell) { S = S1; g = g1; nib = 0; }
+      if (jj == 0) { S = cell_score(colp); g = cell_tag(colp); }
+      if (lane == 0) { S = cell_score(c0); g = cell_tag(c0); }
+      sdiag = s_up;
+      S1 = S; g1 = g;
+
+      mvacc |= nib << (4 * (t & 7));
+      if ((t & 7) == 7 || t == T) { mv[((int64_t)s * tw + (t >> 3)) * 64 + lane] = mvacc; mvacc = 0; }
+      if (wr_carry && lane == 63 && jj >= 0 && jj <= Lx) st_carry(carry + jj, pack_cell(S, g));
+      if (cell && ii == Ly && jj == Lx) a.score1[w] = S;    // the only FINAL x FINAL cell
+    }
+    if (wr_carry) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_dp2 ---
+// Alignment #2: x = PO graph of (ref + cor), y = uncorrected (linear).  A node
+// has at most two DP predecessors (one per source read, or the virtual start
+// plus one).  Predecessors can be any number of nodes back, so every lane keeps
+// its last D results in an LDS ring indexed by time: cell (ii, pp) was produced
+// by this lane d = jj - pp steps ago, and (ii-1, pp) by lane-1 one step before
+// that.  Bank = lane, so ring accesses never conflict.
+
+template <bool GEN, int D>
+__global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls)
+{
+  __shared__ int ring[D * 64];
+  __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
+  const int lane = threadIdx.x;
+  load_tables<GEN>(lds_tab, a.tab, lane);
+  Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
+
+  if ((int64_t)blockIdx.x >= a.n) return;
+  const uint32_t w = a.perm[blockIdx.x];
+  if (a.status[w] || a.cls[w] != cls) return;
+  const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
+  const int Lx = a.n1[w], Ly = (int)(o3 - o2);
+  const uint8_t *ys = a.sym + o2;
+  const int2 *xinfo = a.xinfo + (o0 + w);
+  uint32_t *mv = a.moves + a.mv2[w];
+  int32_t *carry = a.carry + (o0 + w);
+  const int tw = mv_tw(Lx), ns = n_strips(Ly);
+  constexpr int MASK = D - 1;
+  constexpr int kNoPred = (int)(kNone16 << 16);   // pp1 = 0 (virtual), pp2 = none
+
+  int best = kNeg, bestx = -1;
+  for (int s = 0; s < ns; ++s) {
+    const int ii = s * kStripRows + lane;
+    const bool rowok = lane >= 1 && ii <= Ly;
+    const bool rowvirt = (s == 0 && lane == 0);
+    const int yl = rowok ? ys[ii - 1] : 0;
+    const int col_own = a.liny[min(ii, Ly)];
+    const int col_dg = a.liny[min(max(ii - 1, 0), Ly)];
+    const bool wr_carry = (s + 1 < ns);
+    const int nl = min(kStripRows, Ly - s * kStripRows);
+    const int T = Lx + nl;
+    int S1 = 0, g1 = 0, xlo = kNoPred, xhi = 0, xb_lo = kNoPred, xb_hi = 0, c0blk = 0;
+    uint32_t mvacc = 0;
+    for (int t = 0; t <= T; ++t) {
+      if ((t & 63) == 0) {
+        const int j = t + lane;
+        int2 xi = (j >= 1 && j <= Lx) ? xinfo[j] : make_int2(kNoPred, 0);
+        xb_lo = xi.x; xb_hi = xi.y;
+        c0blk = (s > 0 && j <= Lx) ? ld_carry(carry + j) : 0;
+      }
+      const int x0lo = __builtin_amdgcn_readlane(xb_lo, t & 63);
+      const int x0hi = __builtin_amdgcn_readlane(xb_hi, t & 63);
+      const int c0 = __builtin_amdgcn_readlane(c0blk, t & 63);
+      const int s_up = wave_shr1(S1), g_up = wave_shr1(g1);
+      xlo = wave_shr1(xlo); xhi = wave_shr1(xhi);
+      if (lane == 0) { xlo = x0lo; xhi = x0hi; }
+      const int jj = t - lane;
+      const bool incol = jj >= 1 && jj <= Lx;
+      const int pp1 = xlo & 0xFFFF, pp2 = (int)((uint32_t)xlo >> 16);
+      const int xl = xhi & 0xFF;
+      const bool has2 = incol && (pp2 != (int)kNone16);
+      const bool virt1 = !incol || pp1 == 0;
+      const int lm1 = max(lane - 1, 0);
+
+      // predecessor cells: own row from this lane's ring, row above from lane-1's
+      int own1 = col_own, dg1 = col_dg, own2 = 0, dg2 = 0;
+      if (!virt1) {
+        const int d = jj - pp1;
+        own1 = ring[((t - d) & MASK) * 64 + lane];
+        dg1 = ring[((t - d - 1) & MASK) * 64 + lm1];
+      }
+      if (has2) {
+        const int d = jj - pp2;
+        own2 = ring[((t - d) & MASK) * 64 + lane];
+        dg2 = ring[((t - d - 1) & MASK) * 64 + lm1];
+      }
+      // X-insertion: first maximum over the predecessor list wins (:361-371)
+      const int gx1 = cell_tag(own1), gx2 = cell_tag(own2);
+      const int cx1 = cell_score(own1) - sc.pen_x(gx1);
+      const int cx2 = has2 ? cell_score(own2) - sc.pen_x(gx2) : kNeg;
+      const bool px2 = cx2 > cx1;
+      const int insX = px2 ? cx2 : cx1, gX = px2 ? gx2 : gx1;
+      // match: first maximum over (y-pred outer, x-pred inner) (:348-357,374-376)
+      const int m1 = cell_score(dg1), m2 = has2 ? cell_score(dg2) : kNeg;
+      const bool pm2 = m2 > m1;
+      int mat = (pm2 ? m2 : m1) + sc.subst(xl, yl);
+      // Y-insertion: y is linear, one predecessor (:334-345)
+      int insY = s_up - sc.pen_y(g_up);
+      if (rowvirt) { mat = kNeg; insY = kNeg; }              // row -1: gaps along x only (:275-286)
+
+      const bool m = (mat > insY) && (mat > insX);
+      const bool xw = !m && (insX > insY);
+      int S = m ? mat : (xw ? insX : insY);
+      int g = m ? 0 : sc.next_tag(xw ? gX : g_up);
+      uint32_t nib = m ? ((pm2 ? kMoveX2 : kMoveX1) | kMoveY) : (xw ? (px2 ? kMoveX2 : kMoveX1) : kMoveY);
+      const bool cell = rowok && incol;
+      if (!(cell || (rowvirt && incol))) { S = S1; g = g1; }
+      if (!cell) nib = 0;
+      if (jj == 0) { S = cell_score(col_own); g = cell_tag(col_own); }
+      if (lane == 0 && s > 0) { S = cell_score(c0); g = cell_tag(c0); }
+      S1 = S; g1 = g;
+
+      ring[(t & MASK) * 64 + lane] = pack_cell(S, g);
+      __builtin_amdgcn_wave_barrier();
+
+      mvacc |= nib << (4 * (t & 7));
+      if ((t & 7) == 7 || t == T) { mv[((int64_t)s * tw + (t >> 3)) * 64 + lane] = mvacc; mvacc = 0; }
+      if (wr_carry && lane == 63 && jj >= 0 && jj <= Lx) st_carry(carry + jj, pack_cell(S, g));
+      // end cell: FINAL x node on the last row; ties keep the smaller column (:410-417)
+      if (cell && ii == Ly && ((xhi >> 8) & kFlagFinal) && S > best) { best = S; bestx = jj - 1; }
+    }
+    if (wr_carry) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  if (lane == (Ly - 1) % kStripRows + 1) { a.score2[w] = best; a.bx2[w] = bestx; }
+}
+
+// ---------------------------------------------------------------- k_fuse1 ---
+// One lane per window: trace alignment #1 back (align_lpo_po2.c:108-168) and
+// fuse the corrected read into the reference chain (lpo.c:413-463, 602-656).
+// Both inputs are linear, so rings are single nodes and the walk needs only the
+// running "previous node of each read" to build predecessor lists.
+
+__device__ __forceinline__ uint32_t get_move(const uint32_t *mv, int tw, int ii, int jj)
+{
+  int sh;
+  const int64_t idx = mv_index(tw, ii, jj, &sh);
+  return (mv[idx] >> sh) & 15u;
+}
+
+struct NodeWriter {
+  int2 *xinfo;
+  uint16_t *ring1;
+  int maxd;
+  bool bad;
+  // sa, sb: stored predecessors (new indices) in stored order, -1 = none
+  __device__ __forceinline__ void emit(int n, int letter, int flags, int ring, int sa, int sb)
+  {
+    int pp1, pp2 = (int)kNone16;
+    const int jj = n + 1;
+    if (sa < 0) { pp1 = 0; }                                   // no stored link: [-1]
+    else if (flags & kFlagInitial) { pp1 = 0; pp2 = sa + 1; if (sb >= 0) bad = true; }   // virtual -1 first (:69-79)
+    else { pp1 = sa + 1; if (sb >= 0) pp2 = sb + 1; }
+    if (pp1 > 0) maxd = max(maxd, jj - pp1);
+    if (pp2 != (int)kNone16 && pp2 > 0) maxd = max(maxd, jj - pp2);
+    xinfo[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
+    ring1[n] = (uint16_t)ring;
+  }
+};
+
+__global__ void __launch_bounds__(64) k_fuse1(BatchArgs a)
+{
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= a.n) return;
+  const uint32_t w = a.perm[tid];
+  if (a.status[w]) return;
+  const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2];
+  const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1);
+  const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
+  const uint32_t *mv = a.moves + a.mv1[w];
+  const int tw = mv_tw(Lr);
+  const int64_t nb = o0 + w;
+  uint16_t *x2y = a.map16 + nb;
+  NodeWriter nw{a.xinfo + nb, a.ring1 + nb, 1, false};
+
+  for (int j = 0; j < Lr; ++j) x2y[j] = (uint16_t)kNone16;
+  {
+    int x = Lr - 1, y = Lc - 1, guard = Lr + Lc + 2;
+    while (x >= 0 && y >= 0 && guard-- > 0) {
+      const uint32_t nib = get_move(mv, tw, y + 1, x + 1);
+      const int xo = nib & 3, yo = nib >> 2;
+      if (xo && yo) x2y[x] = (uint16_t)y;
+      if (!xo && !yo) { nw.bad = true; break; }
+      if (xo) --x;
+      if (yo) --y;
+    }
+  }
+
+  int n = 0, iy = 0, lastx = -1, lasty = -1;
+  for (int ix = 0; ix < Lr; ++ix) {
+    const int ay = x2y[ix];
+    const bool al = ay != (int)kNone16;
+    if (al)
+      while (iy < ay) {                                         // pending y-only letters go first (lpo.c:432-438)
+        const int fl = kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0);
+        nw.emit(n, ys[iy], fl, n, lasty, -1);
+        lasty = n; ++n; ++iy;
+      }
+    int fl = kFlagHasRef | (ix == 0 ? kFlagInitial : 0) | (ix == Lr - 1 ? kFlagFinal : 0);
+    int sa = lastx, sb = -1, ring = n;
+    if (al && iy < Lc) {
+      if (xs[ix] == ys[iy]) {                                   // identical letters fuse (lpo.c:379-382,447-448)
+        fl |= kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0);
+        if (lasty >= 0 && lasty != lastx) { if (sa < 0) sa = lasty; else sb = lasty; }
+        nw.emit(n, xs[ix], fl, n, sa, sb);
+        lastx = lasty = n; ++n; ++iy;
+        continue;
+      }
+      // mismatch: y gets its own node immediately before x and shares x's ring (lpo.c:449-450,647-649)
+      const int fy = kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0);
+      nw.emit(n, ys[iy], fy, n, lasty, -1);
+      ring = n; lasty = n; ++n; ++iy;
+    }
+    nw.emit(n, xs[ix], fl, ring, sa, sb);
+    lastx = n; ++n;
+  }
+  while (iy < Lc) {                                             // tail of y (lpo.c:457-459)
+    const int fl = kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0);
+    nw.emit(n, ys[iy], fl, n, lasty, -1);
+    lasty = n; ++n; ++iy;
+  }
+  a.n1[w] = n;
+  // ring depth class for k_dp2: D must cover max predecessor distance + 2
+  const int need = nw.maxd + 2;
+  a.cls[w] = (uint8_t)(need <= 32 ? 0 : need <= 256 ? 1 : 2);
+  if (need > 512) a.status[w] = 2;      // ELECTOR_W_TOOLONG: predecessor farther back than the deepest ring
+  if (nw.bad) a.status[w] = 3;
+}
+
+// ---------------------------------------------------------------- k_fuse2 ---
+// One lane per window: trace alignment #2 back through the PO predecessor
+// lists, fuse the uncorrected read (lpo.c:413-463 with non-trivial x rings) and
+// emit the MSA directly as columns (lpo_format.c:346-371: a new column whenever
+// the ring id changes).  The fused graph itself is never materialised.
+
+__global__ void __launch_bounds__(64) k_fuse2(BatchArgs a)
+{
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= a.n) return;
+  const uint32_t w = a.perm[tid];
+  if (a.status[w]) { a.ncol[w] = 0; return; }
+  const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
+  const int n1 = a.n1[w], Lu = (int)(o3 - o2);
+  const uint8_t *ys = a.sym + o2;
+  const uint32_t *mv = a.moves + a.mv2[w];
+  const int tw = mv_tw(n1);
+  const int64_t nb = o0 + w;
+  const int2 *xinfo = a.xinfo + nb;
+  const uint16_t *ring1 = a.ring1 + nb;
+  uint16_t *x2y = a.map16 + nb;
+  uint8_t *cols = a.cols + 3 * o0;
+  const uint8_t *chr = a.tab->chr;
+  bool bad = false;
+
+  for (int j = 0; j < n1; ++j) x2y[j] = (uint16_t)kNone16;
+  {
+    int x = a.bx2[w], y = Lu - 1, guard = n1 + Lu + 2;
+    while (x >= 0 && y >= 0 && guard-- > 0) {
+      const uint32_t nib = get_move(mv, tw, y + 1, x + 1);
+      const int xo = nib & 3, yo = nib >> 2;
+      if (xo && yo) x2y[x] = (uint16_t)y;
+      if (!xo && !yo) { bad = true; break; }
+      if (xo) {
+        const uint32_t pl = (uint32_t)xinfo[x + 1].x;
+        const int pp = (xo == 1) ? (int)(pl & 0xFFFF) : (int)(pl >> 16);
+        x = pp - 1;
+      }
+      if (yo) --y;
+    }
+  }
+
+  // column writer
+  int col = 0, prev_ring = 0;
+  uint8_t c0 = '.', c1 = '.', c2 = '.';
+  auto flush = [&]() { cols[3 * col] = c0; cols[3 * col + 1] = c1; cols[3 * col + 2] = c2; };
+  auto place = [&](int ring, int letter, bool r, bool c, bool u) {
+    if (ring != prev_ring) { flush(); ++col; c0 = c1 = c2 = '.'; prev_ring = ring; }
+    const uint8_t ch = chr[letter];
+    if (r) c0 = ch;
+    if (c) c1 = ch;
+    if (u) c2 = ch;
+  };
+
+  int n = 0, iy = 0, blk_old = -1, blk_new = -1;
+  for (int ix = 0; ix < n1; ++ix) {
+    const int r0 = ring1[ix];
+    if (r0 != blk_old) { blk_old = r0; blk_new = -1; }
+    // if any later member of this ring block is aligned, its pending y letters come first (lpo.c:432-438)
+    for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
+      const int ay = x2y[k];
+      if (ay != (int)kNone16) {
+        while (iy < ay) { place(n, ys[iy], false, false, true); ++n; ++iy; }
+        break;
+      }
+    }
+    const int xi = xinfo[ix + 1].y;
+    const int letter = xi & 0xFF, fl = xi >> 8;
+    bool fused = false;
+    if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
+      if (letter == ys[iy]) fused = true;
+      else {
+        if (blk_new < 0) blk_new = n;                           // y becomes the ring's smallest index
+        place(blk_new, ys[iy], false, false, true);
+        ++n;
+      }
+      ++iy;
+    }
+    if (blk_new < 0) blk_new = n;
+    place(blk_new, letter, (fl & kFlagHasRef) != 0, (fl & kFlagHasCor) != 0, fused);
+    ++n;
+  }
+  while (iy < Lu) { place(n, ys[iy], false, false, true); ++n; ++iy; }
+  flush();
+  a.ncol[w] = col + 1;
+  if (bad) a.status[w] = 3;
+}
+
+// ----------------------------------------------------------------- k_rows ---
+// column-interleaved MSA -> three contiguous rows per window (host-buffer API)
+
+__global__ void __launch_bounds__(256) k_rows(const uint8_t *__restrict__ cols, const int64_t *__restrict__ off,
+                                               const int32_t *__restrict__ ncol, const int64_t *__restrict__ row_off,
+                                               uint8_t *__restrict__ rows, int64_t n)
+{
+  const int64_t w = blockIdx.x;
+  if (w >= n) return;
+  const int nc = ncol[w];
+  const uint8_t *src = cols + 3 * off[3 * w];
+  uint8_t *dst = rows + row_off[w];
+  for (int i = threadIdx.x; i < 3 * nc; i += blockDim.x) {
+    const int r = i / nc, c = i - r * nc;
+    dst[i] = src[3 * c + r];
+  }
+}
+
+// ---------------------------------------------------------------- launchers ---
+
+void launch_symbolize(const uint8_t *in, uint8_t *out, int64_t nbytes, const DevTables *tab, hipStream_t st)
+{
+  if (nbytes <= 0) return;
+  int64_t blocks = (nbytes / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_symbolize, dim3((unsigned)blocks), dim3(256), 0, st, in, out, nbytes, tab);
+}
+
+void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st)
+{
+  if (gen) hipLaunchKernelGGL(k_dp1<true>, dim3((unsigned)a.n), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_dp1<false>, dim3((unsigned)a.n), dim3(64), 0, st, a);
+}
+
+void launch_fuse1(const BatchArgs &a, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_fuse1, dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, st, a);
+}
+
+void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st)
+{
+  const dim3 g((unsigned)a.n), b(64);
+  if (gen) {
+    if (cls == 0) hipLaunchKernelGGL((k_dp2<true, 32>), g, b, 0, st, a, cls);
+    else if (cls == 1) hipLaunchKernelGGL((k_dp2<true, 256>), g, b, 0, st, a, cls);
+    else hipLaunchKernelGGL((k_dp2<true, 512>), g, b, 0, st, a, cls);
+  } else {
+    if (cls == 0) hipLaunchKernelGGL((k_dp2<false, 32>), g, b, 0, st, a, cls);
+    else if (cls == 1) hipLaunchKernelGGL((k_dp2<false, 256>), g, b, 0, st, a, cls);
+    else hipLaunchKernelGGL((k_dp2<false, 512>), g, b, 0, st, a, cls);
+  }
+}
+
+void launch_fuse2(const BatchArgs &a, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_fuse2, dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, st, a);
+}
+
+void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
+                 uint8_t *rows, int64_t n, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_rows, dim3((unsigned)n), dim3(256), 0, st, cols, off, ncol, row_off, rows, n);
+}
+
+}  // namespace elector

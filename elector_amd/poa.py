@@ -1,0 +1,130 @@
+"""PoaEngine -- host-side handle on one GPU's triplet-MSA context.
+
+Mirrors what one `poa` process does for ELECTOR (reference:
+elector/alignment.py:59-63 -> src/poa-graph/main.c:241-287): a batch of
+(reference, corrected, uncorrected) windows in, three MSA rows per window out.
+All computation happens in the HIP library behind the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import ElectorError, ElectorParams
+
+
+def default_params():
+    p = ElectorParams()
+    _capi.lib().elector_params_default(C.byref(p))
+    return p
+
+
+def read_params(matrix_path):
+    """a1: parse a poaV2 scoring-matrix file (what `-pathMatrix` names)."""
+    p = ElectorParams()
+    rc = _capi.lib().elector_params_read(str(matrix_path).encode(), C.byref(p))
+    if rc:
+        raise ElectorError(rc, str(matrix_path))
+    return p
+
+
+def pack_windows(triples):
+    """[(ref, cor, unc) bytes] -> (bases uint8[total], off int64[3n+1])"""
+    n = len(triples)
+    off = np.zeros(3 * n + 1, dtype=np.int64)
+    lens = np.fromiter((len(s) for t in triples for s in t), dtype=np.int64, count=3 * n)
+    np.cumsum(lens, out=off[1:])
+    bases = np.frombuffer(b"".join(s for t in triples for s in t), dtype=np.uint8)
+    return bases, off
+
+
+class PoaEngine:
+    def __init__(self, device=0, params=None):
+        self._lib = _capi.lib()
+        self.params = params if params is not None else default_params()
+        h = C.c_void_p()
+        rc = self._lib.elector_ctx_create(int(device), C.byref(self.params), C.byref(h))
+        if rc:
+            raise ElectorError(rc)
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.elector_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow_window=False):
+        if rc and not (allow_window and rc == _capi.E_WINDOW):
+            raise ElectorError(rc, self._lib.elector_ctx_last_error(self._h).decode())
+
+    # ---- host-buffer path (PCIe inclusive) --------------------------------
+    def align_packed(self, bases, off, want_scores=False, strict=True):
+        """bases uint8[total], off int64[3n+1] -> (rows uint8, row_off int64[n+1],
+        ncol int32[n], status int32[n], scores int32[n,2] | None)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        n = (len(off) - 1) // 3
+        cap = 3 * int(off[-1]) + 16
+        rows = np.empty(cap, dtype=np.uint8)
+        row_off = np.zeros(n + 1, dtype=np.int64)
+        ncol = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        scores = np.zeros((n, 2), dtype=np.int32) if want_scores else None
+        rc = self._lib.elector_poa_batch(
+            self._h, n, bases.ctypes.data, off.ctypes.data, rows.ctypes.data, cap,
+            row_off.ctypes.data, ncol.ctypes.data, status.ctypes.data,
+            scores.ctypes.data if want_scores else None)
+        self._check(rc, allow_window=not strict)
+        return rows[: row_off[-1]], row_off, ncol, status, scores
+
+    def align(self, triples, want_scores=False, strict=True):
+        """[(ref, cor, unc)] -> list of (ref_row, cor_row, unc_row) bytes (None for failed windows)"""
+        bases, off = pack_windows(triples)
+        rows, row_off, ncol, status, scores = self.align_packed(bases, off, want_scores, strict)
+        out = []
+        buf = rows.tobytes()
+        for w in range(len(triples)):
+            if status[w]:
+                out.append(None)
+                continue
+            a, nc = int(row_off[w]), int(ncol[w])
+            out.append((buf[a:a + nc], buf[a + nc:a + 2 * nc], buf[a + 2 * nc:a + 3 * nc]))
+        return (out, scores) if want_scores else out
+
+    # ---- device-resident path (what bench.py times) -----------------------
+    def align_device(self, d_bases, off, d_cols, d_ncol, d_status, d_scores=None):
+        """torch CUDA tensors for the bulk data, numpy int64 host offsets.
+        Enqueues on the engine's stream; call sync() before reading results."""
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        n = (len(off) - 1) // 3
+        rc = self._lib.elector_poa_batch_device(
+            self._h, n, d_bases.data_ptr(), off.ctypes.data, d_cols.data_ptr(),
+            d_ncol.data_ptr(), d_status.data_ptr(),
+            d_scores.data_ptr() if d_scores is not None else None)
+        self._check(rc)
+
+    def sync(self):
+        self._check(self._lib.elector_ctx_sync(self._h))
+
+    def timing_enable(self, on=True):
+        self._check(self._lib.elector_ctx_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._check(self._lib.elector_ctx_timing_reset(self._h))
+
+    def timing_read(self, kernel):
+        ms, k = C.c_double(), C.c_int64()
+        self._check(self._lib.elector_ctx_timing_read(self._h, kernel, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
+    def last_po_sizes(self, n):
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.elector_ctx_last_po_sizes(self._h, n, out.ctypes.data))
+        return out

@@ -1,0 +1,127 @@
+/* include/elector_poa.h -- C ABI of the MI355X-native triplet-MSA engine.
+ *
+ * This is the drop-in boundary for the one hot path of kamimrcht/ELECTOR that
+ * this library replaces: the per-window (reference, corrected, uncorrected)
+ * partial-order alignment that ELECTOR obtains today by spawning its embedded
+ * poaV2 binary,
+ *
+ *     bin/poa -pir OUT -corrected_reads_fasta F3 -reference_reads_fasta F1
+ *             -uncorrected_reads_fasta F2 -pathMatrix blosum80.mat
+ *                                   (reference: elector/alignment.py:59-63,
+ *                                    src/poa-graph/main.c:241-287)
+ *
+ * Every entry point is plain C (pointers + sizes, no torch / HIP types), is
+ * re-entrant per context, returns 0 or a negative ELECTOR_E_* code and never
+ * calls exit()/abort().  There is NO CPU fallback: without a usable gfx950
+ * device every compute entry returns ELECTOR_E_NODEVICE.
+ *
+ * Vocabulary: a *window* is one (reference, corrected, uncorrected) triple of
+ * short sequences as the splitter emits them; its result is a 3-row MSA of
+ * `ncol` columns (rows in the order reference, corrected, uncorrected, gap
+ * character '.', lower-case letters; unknown symbols print as 'A').
+ */
+#ifndef ELECTOR_POA_H
+#define ELECTOR_POA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELECTOR_MAX_SYMBOL 32     /* device alphabet limit (shipped matrix: 31) */
+#define ELECTOR_MAX_GAPTAB 64     /* max_gap_length + 2 must fit               */
+#define ELECTOR_MAX_SEQ    16384  /* longest sequence of a window (bases)      */
+
+/* error codes (negative) */
+#define ELECTOR_OK            0
+#define ELECTOR_E_INVAL      (-1)   /* bad argument / malformed offsets            */
+#define ELECTOR_E_NODEVICE   (-2)   /* no HIP device, or not gfx950                */
+#define ELECTOR_E_NOMEM      (-3)   /* device or host allocation failed            */
+#define ELECTOR_E_HIP        (-4)   /* a HIP runtime call failed                   */
+#define ELECTOR_E_PARAMS     (-5)   /* scoring parameters outside device limits    */
+#define ELECTOR_E_IO         (-6)   /* matrix file unreadable / malformed          */
+#define ELECTOR_E_WINDOW     (-7)   /* at least one window failed: see status[]    */
+/* per-window status values */
+#define ELECTOR_W_OK          0
+#define ELECTOR_W_EMPTY       1     /* a sequence of the window is empty           */
+#define ELECTOR_W_TOOLONG     2     /* a sequence exceeds ELECTOR_MAX_SEQ          */
+#define ELECTOR_W_INTERNAL    3     /* graph invariant violated on device          */
+
+/* Scoring parameters = what the reference's read_score_matrix() leaves behind
+ * (src/poa-graph/seq_util.c:82-217): alphabet, substitution scores and the two
+ * gap-penalty arrays indexed by the per-cell gap tag 0..max_gap_length+1. */
+typedef struct elector_params {
+  int32_t nsymbol;
+  char    symbol[ELECTOR_MAX_SYMBOL + 4];
+  int32_t score[ELECTOR_MAX_SYMBOL][ELECTOR_MAX_SYMBOL];
+  int32_t max_gap_length;                         /* M = trunc + decay */
+  int32_t gap_penalty_x[ELECTOR_MAX_GAPTAB];      /* [0..M+1]          */
+  int32_t gap_penalty_y[ELECTOR_MAX_GAPTAB];
+} elector_params;
+
+typedef struct elector_ctx elector_ctx;
+
+/* library / device probes (no GPU needed) */
+const char *elector_version(void);
+const char *elector_strerror(int code);
+int  elector_device_count(void);                  /* number of usable gfx950 devices */
+
+/* a1: scoring parameters.
+ * elector_params_default = the values ELECTOR ships in src/poa-graph/blosum80.mat;
+ * elector_params_read replaces read_score_matrix (seq_util.c:82-217). */
+void elector_params_default(elector_params *p);
+int  elector_params_read(const char *matrix_path, elector_params *p);
+
+/* one context per GPU (stream + workspace); thread-safe per context */
+int  elector_ctx_create(int device, const elector_params *p, elector_ctx **out);
+void elector_ctx_destroy(elector_ctx *ctx);
+/* last error text of this context (HIP error strings etc.) */
+const char *elector_ctx_last_error(const elector_ctx *ctx);
+
+/* a2-a11 for a batch of n windows, HOST buffers (PCIe-inclusive path).
+ *   bases : concatenated raw ASCII sequences (no whitespace), order per window
+ *           reference, corrected, uncorrected
+ *   off   : 3n+1 byte offsets into bases (off[0] = 0)
+ *   rows  : out, capacity rows_cap bytes; window w occupies
+ *           rows[row_off[w] .. row_off[w+1]) = 3 rows of ncol[w] bytes each
+ *           (reference row, corrected row, uncorrected row), no terminators
+ *   row_off : out, n+1 entries       ncol : out, n entries
+ *   status  : out, n entries (ELECTOR_W_*)
+ *   scores  : optional out, 2n entries: best score of alignment #1 and #2
+ * Replaces one `poa` process over n records (main.c:265-284). */
+int elector_poa_batch(elector_ctx *ctx, int64_t n,
+                      const uint8_t *bases, const int64_t *off,
+                      uint8_t *rows, int64_t rows_cap, int64_t *row_off,
+                      int32_t *ncol, int32_t *status, int32_t *scores);
+
+/* Same computation with the bulk data resident in device memory (the hot-path
+ * entry bench.py times).  `off` stays a HOST array (metadata); d_bases is a
+ * device pointer to off[3n] bytes.  Results stay on the device:
+ *   d_cols : device buffer of 3*off[3n] bytes; window w's MSA is stored
+ *            column-interleaved at d_cols[3*off[3w] + 3*c + r]
+ *            (r = 0 reference, 1 corrected, 2 uncorrected), c < ncol[w]
+ *   d_ncol, d_status : device int32[n];  d_scores: optional device int32[2n]
+ * Work is enqueued on the context's stream; elector_ctx_sync() waits for it. */
+int elector_poa_batch_device(elector_ctx *ctx, int64_t n,
+                             const uint8_t *d_bases, const int64_t *off,
+                             uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status,
+                             int32_t *d_scores);
+int elector_ctx_sync(elector_ctx *ctx);
+
+/* measurement hooks for bench.py: HIP-event time (ms) and span count of a
+ * kernel class accumulated since the last reset, measured with events on the
+ * context's own stream.  kernel: 0 = k_dp1 (alignment #1), 1 = k_dp2
+ * (alignment #2, its three ring-depth launches as one span), 2 = the light
+ * stages (symbolize, traceback + fusion). */
+int elector_ctx_timing_enable(elector_ctx *ctx, int on);
+int elector_ctx_timing_read(elector_ctx *ctx, int kernel, double *ms, int64_t *launches);
+int elector_ctx_timing_reset(elector_ctx *ctx);
+/* diagnostics: |PO| (nodes after fusion #1) of the first n windows of the last
+ * batch, so callers can count the DP cells of alignment #2 (|PO| x Lu). */
+int elector_ctx_last_po_sizes(elector_ctx *ctx, int64_t n, int32_t *po_nodes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
