@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- triplet-MSA throughput of the HIP hot path on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+A *step* is one pass of the hot path (symbolize -> alignment #1 -> fusion ->
+alignment #2 -> fusion + MSA columns) over one batch of window triples that is
+already resident in HBM.  The batch is what ELECTOR's own batch protocol hands
+to its POA engine: the windows of `--reads` synthetic long reads
+(BASELINE.json configs[1] profile: E. coli 30X SimLord-like PacBio reads, 15 %
+error, LoRDEC-like 1 % corrected), cut by this repository's reference-compatible
+splitter on the host before the timed region.  Weak scaling: every rank
+processes its own shard of reads (independent triples, no data-path
+collective); rank 0 gathers the per-read column counters over RCCL at the end.
+
+Prints ONE JSON line (rank 0).  `value` = reference-read bases of all ranks per
+second of the slowest rank.  `roofline` prices the dominant kernel against HBM
+peak using the algorithmic bytes of DESIGN.md; `cpu_baseline` times the
+reference poaV2 binary (oracle/_ref/poa, when it travelled with the snapshot)
+or the C oracle port on this host's cores over a bounded sample.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("ELECTOR_BENCH_READS", "4000")),
+                    help="synthetic long reads per rank and step")
+    ap.add_argument("--profile", default="ecoli30x_simlord_lordec")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(windows, ref_bases_per_window, seconds):
+    """Reference poaV2 (or the oracle port) on this host's cores over a bounded
+    sample of the same window stream.  Test infrastructure: uses oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    ncores = os.cpu_count() or 1
+    off = windows.off
+    nwin = windows.n_windows
+    ref_poa = os.path.join(oracle_lib.REF_DIR, "poa")
+    if os.path.exists(ref_poa):
+        # ~0.3 Mbases/s/core for the reference binary -> sample size
+        target_bases = 0.3e6 * ncores * seconds
+        cum = np.cumsum(ref_bases_per_window)
+        ns = int(min(nwin, max(ncores, np.searchsorted(cum, target_bases) + 1)))
+        b = windows.bases.tobytes()
+        with tempfile.TemporaryDirectory() as d:
+            mat = oracle_lib.write_matrix(os.path.join(d, "params.mat"))
+            per = (ns + ncores - 1) // ncores
+            cmds = []
+            for p in range(ncores):
+                lo, hi = p * per, min(ns, (p + 1) * per)
+                if lo >= hi:
+                    break
+                names = [os.path.join(d, "out%d_%d" % (k, p)) for k in (1, 2, 3)]
+                with open(names[0], "wb") as fr, open(names[1], "wb") as fu, open(names[2], "wb") as fc:
+                    for w in range(lo, hi):
+                        h = b">w%d\n" % w
+                        fr.write(h + b[off[3 * w]:off[3 * w + 1]] + b"\n")
+                        fc.write(h + b[off[3 * w + 1]:off[3 * w + 2]] + b"\n")
+                        fu.write(h + b[off[3 * w + 2]:off[3 * w + 3]] + b"\n")
+                # same command line ELECTOR issues (elector/alignment.py:60)
+                cmds.append([ref_poa, "-pir", os.path.join(d, "smsa%d" % p), "-preserve_seqorder",
+                             "-corrected_reads_fasta", names[2], "-reference_reads_fasta", names[0],
+                             "-uncorrected_reads_fasta", names[1], "-preserve_seqorder", "-threads", "1",
+                             "-pathMatrix", mat])
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen(c, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for c in cmds]
+            for p in procs:
+                p.wait()
+            dt = time.perf_counter() - t0
+        nb = float(cum[ns - 1])
+        return {"value": round(nb / dt / 1e6, 4), "unit": "Mbases/s", "cores": len(cmds), "kind": "reference",
+                "sample": "%d windows (%d reference bases) of the step's window stream, one reference poa "
+                          "process per core as elector/alignment.py's Pool does, wall %.2f s" % (ns, int(nb), dt)}
+    # port: single-threaded C oracle
+    target_bases = 0.4e6 * seconds
+    cum = np.cumsum(ref_bases_per_window)
+    ns = int(min(nwin, np.searchsorted(cum, target_bases) + 1))
+    t0 = time.perf_counter()
+    oracle_lib.batch(windows.bases[: off[3 * ns]], off[: 3 * ns + 1])
+    dt = time.perf_counter() - t0
+    nb = float(cum[ns - 1])
+    return {"value": round(nb / dt / 1e6, 4), "unit": "Mbases/s", "cores": 1, "kind": "port",
+            "sample": "%d windows (%d reference bases), oracle/poa_oracle.c single thread, wall %.2f s" % (ns, int(nb), dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from elector_amd import split, synthetic
+    from elector_amd.poa import PoaEngine
+
+    # ---- untimed setup: synthetic reads -> windows (host), upload --------
+    reads = synthetic.read_triples(args.profile, args.reads, seed=1000 + rank)
+    read_bases = int(sum(len(r[0]) for r in reads))
+    nthreads = max(1, (os.cpu_count() or 1) // max(1, world))
+    win = split.split_reads(reads, 0.1, None, nthreads=nthreads)
+    del reads
+    off = win.off
+    n = win.n_windows
+    lr = off[1::3] - off[0:-1:3]
+    lc = off[2::3] - off[1:-1:3]
+    lu = off[3::3] - off[2:-1:3]
+    dev = torch.device("cuda", local)
+    d_bases = torch.from_numpy(win.bases).to(dev)
+    d_cols = torch.empty(3 * int(off[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_ncol = torch.empty(n, dtype=torch.int32, device=dev)
+    d_status = torch.empty(n, dtype=torch.int32, device=dev)
+    eng = PoaEngine(local)
+
+    def step():
+        eng.align_device(d_bases, off, d_cols, d_ncol, d_status)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.timing_enable(True)
+    eng.timing_reset()
+
+    # ---- timed region ----------------------------------------------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+
+    # ---- after the clock: checks, counters, gather -------------------------
+    status = d_status.cpu().numpy()
+    ncol = d_ncol.cpu().numpy().astype(np.int64)
+    if status.any():
+        raise SystemExit("bench: %d windows failed on device" % int((status != 0).sum()))
+    po = eng.last_po_sizes(n).astype(np.int64)
+    cells1, cells2 = int((lr * lc).sum()), int((po * lu).sum())
+    t_dp1, k_dp1 = eng.timing_read(0)
+    t_dp2, k_dp2 = eng.timing_read(1)
+    t_oth, _ = eng.timing_read(2)
+    # per-read counters (column count per read) -> rank 0 over RCCL
+    read_cols = np.add.reduceat(ncol, win.read_first[:-1]) if n else np.zeros(0, dtype=np.int64)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([read_bases, n, cells1 + cells2], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        mine = torch.from_numpy(read_cols).to(dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([mine.numel()], dtype=torch.int64, device=dev))
+        cap = int(max(s.item() for s in sizes))
+        padded = torch.zeros(cap, dtype=torch.int64, device=dev)
+        padded[: mine.numel()] = mine
+        gathered = [torch.zeros(cap, dtype=torch.int64, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(padded, gathered, dst=0)
+        if rank == 0:
+            read_cols = np.concatenate([g[: int(s.item())].cpu().numpy() for g, s in zip(gathered, sizes)])
+    dt_max = float(tmax.item())
+    bases_all, windows_all, cells_all = (int(x) for x in tot.tolist())
+
+    if rank == 0:
+        value = bases_all * args.steps / dt_max / 1e6
+        # roofline of the dominant kernel: algorithmic bytes = 8-bit inputs + 8-bit MSA out + descriptors
+        alg_bytes = int((lr + lc + lu).sum() + 3 * ncol.sum() + 28 * n)
+        dom = ("k_dp2", t_dp2, k_dp2) if t_dp2 >= t_dp1 else ("k_dp1", t_dp1, k_dp1)
+        launches = max(1, dom[2])
+        avg_ms = dom[1] / launches
+        bytes_per_launch = alg_bytes * args.steps / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = os.environ.get("ELECTOR_BENCH_TRAFFIC_BYTES")
+        out = {
+            "metric": "triplet-MSA Mbases/s", "value": round(value, 3), "unit": "Mbases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "E. coli 30X SimLord-like PacBio (15%% err), LoRDEC-like corrected (1%% err): "
+                                   "%d reads x ~8 kb per GPU per step, cut into windows by the ELECTOR splitter rules"
+                                   % args.reads,
+                       "profile": args.profile, "reads_per_gpu": args.reads, "windows_per_gpu": n,
+                       "ref_bases_per_gpu": read_bases, "parallelism": "shard-by-read x%d" % world},
+            "gcups": round(cells_all * args.steps / dt_max / 1e9, 3),
+            "kernel_ms_per_step": {"k_dp1": round(t_dp1 / args.steps, 3), "k_dp2": round(t_dp2 / args.steps, 3),
+                                   "light_stages": round(t_oth / args.steps, 3)},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": int(traffic) if traffic else None,
+                         "launches": int(launches), "avg_launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+            "reads_gathered": int(len(read_cols)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(win, lr, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

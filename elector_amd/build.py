@@ -10,8 +10,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("poa_kernels.hip", "poa_host.hip")]
-HDR = [os.path.join(HERE, "csrc", "poa_device.h"), os.path.join(ROOT, "include", "elector_poa.h")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("poa_kernels.hip", "poa_host.hip", "splitter.cpp")]
+HDR = [os.path.join(HERE, "csrc", "poa_device.h"), os.path.join(ROOT, "include", "elector_poa.h"),
+       os.path.join(ROOT, "include", "elector_split.h")]
 OUT = os.path.join(HERE, "lib", "libelector_poa.so")
 
 
@@ -33,7 +34,7 @@ def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
            "-o", OUT] + SRC
     if verbose:

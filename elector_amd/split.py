@@ -1,0 +1,123 @@
+"""Host-side binding of the window splitter and window merger
+(include/elector_split.h): the stages either side of the POA engine.
+
+Reference: src/split/Master_Splitter.cpp (masterSplitter) and
+src/split/Donatello.cpp, spawned from elector/alignment.py:99-101,120-122.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import ElectorError
+
+
+class ElectorWindows(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_int64), ("n_windows", C.c_int64),
+        ("bases", C.POINTER(C.c_uint8)), ("off", C.POINTER(C.c_int64)),
+        ("read_first", C.POINTER(C.c_int64)), ("read_index", C.POINTER(C.c_int64)),
+        ("small_reads", C.c_int64), ("wrong_reads", C.c_int64),
+    ]
+
+
+class ElectorMsa(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_int64), ("rows", C.POINTER(C.c_uint8)),
+        ("row_off", C.POINTER(C.c_int64)), ("cols", C.POINTER(C.c_int64)),
+    ]
+
+
+def _lib():
+    L = _capi.lib()
+    if not getattr(L, "_split_bound", False):
+        L.elector_split_reads.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                          C.POINTER(ElectorWindows)]
+        L.elector_windows_free.argtypes = [C.POINTER(ElectorWindows)]
+        L.elector_windows_free.restype = None
+        L.elector_merge_windows.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(ElectorMsa)]
+        L.elector_msa_free.argtypes = [C.POINTER(ElectorMsa)]
+        L.elector_msa_free.restype = None
+        L._split_bound = True
+    return L
+
+
+def _np(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class Windows:
+    """Result of split_reads: numpy copies of the library-owned buffers."""
+    __slots__ = ("n_reads", "n_windows", "bases", "off", "read_first", "read_index", "small_reads", "wrong_reads")
+
+    def triples(self):
+        b = self.bases.tobytes()
+        o = self.off
+        return [(b[o[3 * w]:o[3 * w + 1]], b[o[3 * w + 1]:o[3 * w + 2]], b[o[3 * w + 2]:o[3 * w + 3]])
+                for w in range(self.n_windows)]
+
+
+def split_reads(reads, size_threshold=0.1, headers=None, nthreads=1):
+    """reads: [(reference, corrected, uncorrected)] full-length read triples (bytes).
+    headers: per-read header lines (incl. '>'); only their length matters.
+    Returns Windows in the engine's layout (reference, corrected, uncorrected per window)."""
+    n = len(reads)
+    off = np.zeros(3 * n + 1, dtype=np.int64)
+    # masterSplitter's own order: reference, uncorrected, corrected
+    parts = [s for (r, c, u) in reads for s in (r, u, c)]
+    lens = np.fromiter((len(s) for s in parts), dtype=np.int64, count=3 * n)
+    np.cumsum(lens, out=off[1:])
+    buf = np.frombuffer(b"".join(parts), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+    if headers is None:
+        hl = np.full(n, 2, dtype=np.int32)
+    else:
+        hl = np.fromiter((len(h) for h in headers), dtype=np.int32, count=n)
+    return split_packed(buf, off, hl, size_threshold, nthreads)
+
+
+def split_packed(buf, off, hdr_len, size_threshold=0.1, nthreads=1):
+    L = _lib()
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    hdr_len = np.ascontiguousarray(hdr_len, dtype=np.int32)
+    n = (len(off) - 1) // 3
+    w = ElectorWindows()
+    rc = L.elector_split_reads(n, buf.ctypes.data, off.ctypes.data, hdr_len.ctypes.data,
+                               float(size_threshold), int(nthreads), C.byref(w))
+    if rc:
+        raise ElectorError(rc)
+    try:
+        out = Windows()
+        out.n_reads, out.n_windows = int(w.n_reads), int(w.n_windows)
+        out.off = _np(w.off, 3 * out.n_windows + 1, np.int64)
+        out.bases = _np(w.bases, int(out.off[-1]) if out.n_windows else 0, np.uint8)
+        out.read_first = _np(w.read_first, out.n_reads + 1, np.int64)
+        out.read_index = _np(w.read_index, out.n_reads, np.int64)
+        out.small_reads, out.wrong_reads = int(w.small_reads), int(w.wrong_reads)
+        return out
+    finally:
+        L.elector_windows_free(C.byref(w))
+
+
+def merge_windows(read_first, rows, row_off, ncol):
+    """Per-read concatenation of window rows with the 'n' columns of the
+    corrected row dropped.  -> (rows uint8, row_off int64[n+1], cols int64[n])"""
+    L = _lib()
+    read_first = np.ascontiguousarray(read_first, dtype=np.int64)
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+    ncol = np.ascontiguousarray(ncol, dtype=np.int32)
+    n = len(read_first) - 1
+    m = ElectorMsa()
+    rc = L.elector_merge_windows(n, read_first.ctypes.data, rows.ctypes.data, row_off.ctypes.data,
+                                 ncol.ctypes.data, C.byref(m))
+    if rc:
+        raise ElectorError(rc)
+    try:
+        ro = _np(m.row_off, n + 1, np.int64)
+        return _np(m.rows, int(ro[-1]) if n else 0, np.uint8), ro, _np(m.cols, n, np.int64)
+    finally:
+        L.elector_msa_free(C.byref(m))

@@ -1,0 +1,71 @@
+/* include/elector_split.h -- C ABI of the window splitter and the window merger,
+ * the two stages either side of the POA hot path.
+ *
+ *   elector_split_reads   replaces the per-read work of `bin/masterSplitter`
+ *                         (reference: src/split/Master_Splitter.cpp:175-332
+ *                          split/best_split, :396-446 the read loop;
+ *                          spawned from elector/alignment.py:99-101)
+ *   elector_merge_windows replaces `bin/Donatello`
+ *                         (reference: src/split/Donatello.cpp:13-93;
+ *                          spawned from elector/alignment.py:120-122)
+ *
+ * Both are host-side byte/integer work (the reference's are single-threaded
+ * CPU programs too); the splitter runs on `nthreads` host threads.
+ * Plain C: pointers + sizes; results live in library-owned buffers released by
+ * the matching *_free call.  Return 0 or a negative ELECTOR_E_* code
+ * (include/elector_poa.h).
+ */
+#ifndef ELECTOR_SPLIT_H
+#define ELECTOR_SPLIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Windows of a batch of reads, already in the layout elector_poa_batch takes. */
+typedef struct elector_windows {
+  int64_t n_reads;       /* reads that produced output (reference length > 2)      */
+  int64_t n_windows;
+  uint8_t *bases;        /* per window: reference, corrected, uncorrected           */
+  int64_t *off;          /* 3*n_windows + 1 byte offsets into bases                 */
+  int64_t *read_first;   /* n_reads + 1: windows of emitted read r are
+                            [read_first[r], read_first[r+1])                        */
+  int64_t *read_index;   /* n_reads: index of the emitted read in the input batch   */
+  int64_t small_reads;   /* corrected shorter than threshold * reference (:425-431) */
+  int64_t wrong_reads;   /* no usable anchor chain (:417-423)                       */
+} elector_windows;
+
+/* reads: concatenated sequences, per read in the order reference, uncorrected,
+ * corrected (masterSplitter's argument order, Master_Splitter.cpp:354-356);
+ * read_off: 3*n_reads_in + 1 offsets; hdr_len: length of each read's header
+ * line including '>' (it takes part in best_split's fragment-size comparison,
+ * Master_Splitter.cpp:158-169,313-331).
+ * size_threshold: SIZE_CORRECTED_READ_THRESHOLD (argv[10]). */
+int  elector_split_reads(int64_t n_reads_in, const uint8_t *reads, const int64_t *read_off,
+                         const int32_t *hdr_len, double size_threshold, int nthreads,
+                         elector_windows *out);
+void elector_windows_free(elector_windows *w);
+
+/* Merged per-read MSA (what Donatello appends to msa.fa): for emitted read r the
+ * three rows each have read_cols[r] columns; columns whose corrected letter is
+ * 'n' are dropped (Donatello.cpp:13-31). */
+typedef struct elector_msa {
+  int64_t n_reads;
+  uint8_t *rows;         /* per read: reference row, corrected row, uncorrected row */
+  int64_t *row_off;      /* n_reads + 1 offsets (3 * cols bytes per read)           */
+  int64_t *cols;         /* n_reads                                                 */
+} elector_msa;
+
+/* window_rows / row_off / ncol: the output of elector_poa_batch for the windows
+ * described by `read_first` (n_reads + 1 entries). */
+int  elector_merge_windows(int64_t n_reads, const int64_t *read_first,
+                           const uint8_t *window_rows, const int64_t *row_off, const int32_t *ncol,
+                           elector_msa *out);
+void elector_msa_free(elector_msa *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
