@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* with the REAL reference binaries (oracle/_ref, built by
+oracle/Makefile from /root/reference).  Runs only in the container that has the
+reference; the fixtures it writes are plain data (inputs + expected outputs).
+
+  windows_example.tsv     the 62 windows masterSplitter cuts from the reference's
+                          own example/{perfect,uncorrected,corrected}_reads.fasta,
+                          with the three MSA rows `poa` prints for each
+  windows_synth.tsv       seeded synthetic windows (tests/synth.py) incl. >63-row
+                          (multi-strip) ones, rows from `poa`
+  windows_adversarial.tsv tie-heavy / degenerate windows, rows from `poa`
+  bundles.tsv             windows + the 4th+ rows of the heaviest-bundle driver
+  splitter_reads.tsv      read triples -> window list from masterSplitter
+  merger.tsv              poa output of a few reads -> Donatello's msa.fa text
+  params.json             what the reference matrix file parses to
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib  # noqa: E402
+import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+EXAMPLE = "/root/reference/example"
+MATRIX = "/root/reference/src/poa-graph/blosum80.mat"
+
+
+def run_poa(triples, d, hb=False):
+    n1, n2, n3 = synth.write_fasta_triples(triples, os.path.join(d, "in"))
+    out = os.path.join(d, "smsa")
+    if hb:
+        subprocess.run([os.path.join(REF, "poa_hb"), MATRIX, n1, n3, n2, out], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    else:
+        subprocess.run([os.path.join(REF, "poa"), "-pir", out, "-preserve_seqorder", "-corrected_reads_fasta", n3,
+                        "-reference_reads_fasta", n1, "-uncorrected_reads_fasta", n2, "-preserve_seqorder",
+                        "-threads", "1", "-pathMatrix", MATRIX], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = open(out, "rb").read().split(b"\n")
+    return lines
+
+
+def rows_per_window(lines, n):
+    assert len(lines) >= 6 * n
+    return [(lines[6 * w + 1], lines[6 * w + 3], lines[6 * w + 5]) for w in range(n)]
+
+
+def write_windows(name, triples, d):
+    rows = rows_per_window(run_poa(triples, d), len(triples))
+    with open(os.path.join(GOLD, name), "wb") as f:
+        f.write(b"#ref\tcor\tunc\trow_ref\trow_cor\trow_unc\n")
+        for t, r in zip(triples, rows):
+            f.write(b"\t".join(t + r) + b"\n")
+    print(name, len(triples), "windows")
+
+
+def run_splitter(reads, headers, thr, d):
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    with open(d + "/r.fa", "wb") as fr, open(d + "/u.fa", "wb") as fu, open(d + "/c.fa", "wb") as fc:
+        for (r, c, u), h in zip(reads, headers):
+            fr.write(h + b"\n" + r + b"\n")
+            fc.write(h + b"\n" + c + b"\n")
+            fu.write(h + b"\n" + u + b"\n")
+    subprocess.run([os.path.join(REF, "masterSplitter"), d + "/r.fa", d + "/u.fa", d + "/c.fa", d + "/out1",
+                    d + "/out2", d + "/out3", "7", "200", "10000", str(thr), d], stdout=subprocess.DEVNULL)
+
+    def cat(p):
+        hs, out = [], []
+        for i in range(200):
+            ls = open(d + "/" + p + str(i), "rb").read().split(b"\n")
+            hs += [ls[k] for k in range(0, len(ls) - 1, 2)]
+            out += [ls[k + 1] for k in range(0, len(ls) - 1, 2)]
+        return hs, out
+    hs, R = cat("out1")
+    _, U = cat("out2")
+    _, Cc = cat("out3")
+    small = int(open(d + "/small_reads.txt").read())
+    wrong = int(open(d + "/wrongly_cor_reads.txt").read())
+    return hs, list(zip(R, Cc, U)), small, wrong
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    with tempfile.TemporaryDirectory() as d:
+        # --- the reference's own example, cut by its own splitter
+        def fa(p):
+            ls = open(p, "rb").read().split(b"\n")
+            return [(ls[i], ls[i + 1]) for i in range(0, len(ls) - 1, 2)]
+        per, unc, cor = (fa(os.path.join(EXAMPLE, f)) for f in
+                         ("perfect_reads.fasta", "uncorrected_reads.fasta", "corrected_reads.fasta"))
+        reads = [(p[1], c[1], u[1]) for p, c, u in zip(per, cor, unc)]
+        headers = [p[0] for p in per]
+        hs, windows, small, wrong = run_splitter(reads, headers, 0.1, os.path.join(d, "sp"))
+        write_windows("windows_example.tsv", windows, d)
+        # --- synthetic
+        write_windows("windows_synth.tsv",
+                      synth.window_triples(101, 120, 1, 70) + synth.window_triples(102, 40, 60, 200) +
+                      synth.window_triples(103, 6, 300, 420) + synth.window_triples(104, 30, 20, 120, 0.3, 0.25), d)
+        write_windows("windows_adversarial.tsv", synth.adversarial_triples(105, 240, hi=70), d)
+        # --- heaviest bundle
+        tr = synth.window_triples(106, 40, 8, 120) + synth.adversarial_triples(107, 36, hi=60)
+        lines = run_poa(tr, d, hb=True)
+        with open(os.path.join(GOLD, "bundles.tsv"), "wb") as f:
+            f.write(b"#ref\tcor\tunc\t(header\trow)*  -- every record the heaviest-bundle driver printed for the window\n")
+            k = 0
+            for t in tr:
+                recs = []
+                # records of this window: 3 sources then CONSENS* until the next window's first header
+                cnt = 0
+                while k + 1 < len(lines) and lines[k].startswith(b">"):
+                    if cnt >= 3 and not lines[k].startswith(b">CONSENS"):
+                        break
+                    recs += [lines[k], lines[k + 1]]
+                    k += 2
+                    cnt += 1
+                f.write(b"\t".join(t + tuple(recs)) + b"\n")
+        print("bundles.tsv", len(tr), "windows")
+        # --- splitter: reads -> windows
+        import numpy as np
+        rng = np.random.default_rng(9)
+        rs = synth.read_triples(108, 6, 2500) + synth.read_triples(109, 4, 300, min_len=1)
+        r2 = []
+        for (r, c, u) in synth.read_triples(110, 6, 3000):
+            kk = int(rng.integers(0, 3))
+            c = c[len(c) // 3:] if kk == 0 else (c[: len(c) // 2] if kk == 1 else c[len(c) // 4: 3 * len(c) // 4])
+            r2.append((r, c, u))
+        rs += r2 + [(b"AC", b"AC", b"AC"), (b"ACGTACGTAC" * 30, b"ACGT", b"ACGTACGTAC" * 30)] + reads
+        hd = [b">g%d_0" % i + b"x" * (i * 11 % 60) for i in range(len(rs))]
+        hs, windows, small, wrong = run_splitter(rs, hd, 0.1, os.path.join(d, "sp2"))
+        with open(os.path.join(GOLD, "splitter_reads.tsv"), "wb") as f:
+            f.write(b"#R\theader\tref\tcor\tunc   then  #W\theader\tref\tcor\tunc per window; #C small wrong\n")
+            for h, t in zip(hd, rs):
+                f.write(b"R\t" + h + b"\t" + b"\t".join(t) + b"\n")
+            for h, t in zip(hs, windows):
+                f.write(b"W\t" + h + b"\t" + b"\t".join(t) + b"\n")
+            f.write(b"C\t%d\t%d\n" % (small, wrong))
+        print("splitter_reads.tsv", len(rs), "reads", len(windows), "windows")
+        # --- merger: poa text of the example windows -> Donatello
+        n1, n2, n3 = synth.write_fasta_triples(windows[:0], os.path.join(d, "none"))
+        hs_e, win_e, _, _ = run_splitter(r2[:3] + reads, [b">m%d_0" % i for i in range(3 + len(reads))], 0.1,
+                                         os.path.join(d, "sp3"))
+        with open(os.path.join(d, "m1"), "wb") as fr, open(os.path.join(d, "m2"), "wb") as fu, \
+                open(os.path.join(d, "m3"), "wb") as fc:
+            for h, (r, c, u) in zip(hs_e, win_e):
+                fr.write(h + b"\n" + r + b"\n")
+                fc.write(h + b"\n" + c + b"\n")
+                fu.write(h + b"\n" + u + b"\n")
+        smsa = os.path.join(d, "smsa_m")
+        subprocess.run([os.path.join(REF, "poa"), "-pir", smsa, "-corrected_reads_fasta", os.path.join(d, "m3"),
+                        "-reference_reads_fasta", os.path.join(d, "m1"), "-uncorrected_reads_fasta",
+                        os.path.join(d, "m2"), "-pathMatrix", MATRIX], stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, check=True)
+        msa = os.path.join(d, "msa.fa")
+        subprocess.run([os.path.join(REF, "Donatello"), smsa, msa], check=True)
+        with open(os.path.join(GOLD, "merger.tsv"), "wb") as f:
+            f.write(b"#S = one line of the poa output (input of the merger), M = one line of Donatello's output\n")
+            for ln in open(smsa, "rb").read().split(b"\n")[:-1]:
+                f.write(b"S\t" + ln + b"\n")
+            for ln in open(msa, "rb").read().split(b"\n")[:-1]:
+                f.write(b"M\t" + ln + b"\n")
+        print("merger.tsv")
+    # --- parameters
+    import ctypes
+    p = oracle_lib.read_params(MATRIX)
+
+    class P(ctypes.Structure):
+        _fields_ = [("nsymbol", ctypes.c_int), ("symbol", ctypes.c_char * 129),
+                    ("_pad", ctypes.c_char * 3), ("score", (ctypes.c_int * 128) * 128),
+                    ("gap_set", (ctypes.c_int * 3) * 2), ("trunc", ctypes.c_int), ("decay", ctypes.c_int),
+                    ("M", ctypes.c_int), ("gpx", ctypes.c_int * 256), ("gpy", ctypes.c_int * 256)]
+    q = P.from_buffer(p)
+    ns = q.nsymbol
+    json.dump({"nsymbol": ns, "symbol": q.symbol.decode(), "max_gap_length": q.M,
+               "gap_penalty_x": list(q.gpx[: q.M + 2]), "gap_penalty_y": list(q.gpy[: q.M + 2]),
+               "score": [[q.score[i][j] for j in range(ns)] for i in range(ns)]},
+              open(os.path.join(GOLD, "params.json"), "w"))
+    print("params.json", ns, q.symbol.decode(), q.M, list(q.gpx[: q.M + 2]))
+
+
+if __name__ == "__main__":
+    main()

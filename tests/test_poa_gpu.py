@@ -43,3 +43,76 @@ def test_noisy_corrected(engine):
 
 def test_long_windows(engine):
     check(engine, synth.window_triples(16, 12, 1500, 3000))
+
+
+@pytest.mark.parametrize("name", ["windows_example.tsv", "windows_synth.tsv", "windows_adversarial.tsv"])
+def test_golden_vectors(engine, name):
+    """HIP path against rows printed by the real reference binary (tests/golden)."""
+    import golden_io
+    gold = golden_io.windows(name)
+    got = engine.align([g[0] for g in gold])
+    for w, (t, exp) in enumerate(gold):
+        assert got[w] == exp, (w, t)
+
+
+GENERAL_MATRIX = ("GAP-TRUNCATION-LENGTH=3\nGAP-DECAY-LENGTH=4\nGAP-PENALTIES=9 4 1\nGAP-PENALTIES-X=7 3 2\n"
+                  "  A a c g t n\nA 1 -3 -3 -3 -3 -1\na -3 4 -5 -2 -5 -1\nc -3 -5 4 -5 -2 -1\n"
+                  "g -3 -2 -5 4 -5 -1\nt -3 -5 -2 -5 4 -1\nn -1 -1 -1 -1 -1 0\n")
+
+
+def test_general_scoring_matrix(tmp_path):
+    """Non-uniform substitution scores, decaying gap penalties, different x/y
+    penalties: the table-driven kernel variant against the oracle."""
+    from elector_amd import poa
+    path = tmp_path / "g.mat"
+    path.write_text(GENERAL_MATRIX)
+    eng = poa.PoaEngine(0, poa.read_params(path))
+    par = oracle_lib.read_params(path)
+    try:
+        for triples in (synth.window_triples(17, 1200, 1, 140), synth.adversarial_triples(18, 600),
+                        synth.window_triples(19, 60, 150, 400)):
+            bases, off = synth.pack_windows(triples)
+            exp_rows, _, exp_scores, _ = oracle_lib.batch(np.frombuffer(bases, dtype=np.uint8), off, par)
+            got, scores = eng.align(triples, want_scores=True)
+            assert got == exp_rows
+            assert np.array_equal(scores, exp_scores)
+    finally:
+        eng.close()
+
+
+def test_window_status_codes(engine):
+    from elector_amd import _capi
+    triples = [(b"ACGT", b"ACGT", b"ACGT"), (b"ACGT", b"", b"ACGT"), (b"A" * 20000, b"ACGT", b"ACGT"),
+               (b"GATTACA", b"GATACA", b"GATTTACA")]
+    with pytest.raises(_capi.ElectorError):
+        engine.align(triples)
+    got = engine.align(triples, strict=False)
+    assert got[1] is None and got[2] is None
+    assert got[0] == (b"acgt", b"acgt", b"acgt")
+    bases, off = synth.pack_windows([triples[3]])
+    assert got[3] == oracle_lib.batch(np.frombuffer(bases, dtype=np.uint8), off)[0][0]
+
+
+def test_empty_batch(engine):
+    assert engine.align([]) == []
+
+
+def test_round_trip_property_large(engine):
+    """Full-size property check (no oracle): removing the gaps from each MSA row
+    gives back the lower-cased input sequence, rows have equal length, no column
+    is all gaps."""
+    from elector_amd import split, synthetic
+    reads = synthetic.read_triples("ecoli30x_simlord_lordec", 300, seed=5)
+    win = split.split_reads(reads, 0.1, None, nthreads=8)
+    rows, row_off, ncol, status, _ = engine.align_packed(win.bases, win.off)
+    assert not status.any()
+    b = win.bases.tobytes().lower()
+    r = rows.tobytes()
+    off = win.off
+    for w in range(0, win.n_windows, 7):
+        a, nc = int(row_off[w]), int(ncol[w])
+        r0, r1, r2 = r[a:a + nc], r[a + nc:a + 2 * nc], r[a + 2 * nc:a + 3 * nc]
+        assert r0.replace(b".", b"") == b[off[3 * w]:off[3 * w + 1]]
+        assert r1.replace(b".", b"") == b[off[3 * w + 1]:off[3 * w + 2]]
+        assert r2.replace(b".", b"") == b[off[3 * w + 2]:off[3 * w + 3]]
+        assert all(not (x == 46 and y == 46 and z == 46) for x, y, z in zip(r0, r1, r2))
