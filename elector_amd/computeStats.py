@@ -1,0 +1,367 @@
+"""Drop-in mirror of the reference's elector/computeStats.py for call site #2 of
+the hot path (elector/__main__.py:141):
+
+    outputRecallPrecision(correctedFileName, outDir, logFile, smallReadNumber,
+                          wronglyCorrectedReadsNumber, reportedHomopolThreshold,
+                          SIZE_CORRECTED_READ_THRESHOLD, fileSizeName, clipsNb,
+                          beg=0, end=0, soft=None)  -> 19-tuple
+
+Same signature, same return tuple (including the two str members), same stdout
+block, log text and side files (`*per_read_metrics.txt`, the read-size file).
+The per-column work (computeStats.py:61-189, 291-328, 371-440, 472-498, 712-752)
+runs on the GPU behind the C ABI (include/elector_stats.h) and returns integers;
+every ratio, mean and round() below is computed on the host in read order, so the
+numbers do not depend on how reads are sharded over GPUs.
+
+There is no CPU fallback: without the HIP library / a gfx950 device this raises.
+"""
+import ctypes as C
+import os
+import statistics
+
+import numpy as np
+
+from . import _capi
+from ._capi import ElectorError
+
+THRESH = 5     # computeStats.py:40
+THRESH2 = 20   # computeStats.py:41
+
+# counter indices (include/elector_stats.h)
+(ES_TP, ES_FP, ES_FN, ES_COR, ES_UNC, ES_UCOR, ES_UUNC, ES_GC_REF, ES_GC_COR, ES_INS_U, ES_DEL_U, ES_SUB_U,
+ ES_INS_C, ES_DEL_C, ES_SUB_C, ES_LEN_REF, ES_LEN_COR, ES_LEN_UNC, ES_GAPS_LEFT, ES_GAPS_RIGHT, ES_EXT_LEFT,
+ ES_EXT_RIGHT, ES_MISSING, ES_MISSING_LAST, ES_PROCESSED, ES_NCOUNTERS) = range(26)
+
+_engine = None
+
+
+def _default_engine():
+    """One context on this process's GPU (LOCAL_RANK when launched by torchrun)."""
+    global _engine
+    if _engine is None:
+        from .poa import PoaEngine
+        _engine = PoaEngine(int(os.environ.get("LOCAL_RANK", "0")))
+    return _engine
+
+
+def _bind(L):
+    if not getattr(L, "_stats_bound", False):
+        vp, i64 = C.c_void_p, C.c_int64
+        L.elector_stats_batch.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp]
+        L.elector_homopolymer_pairs.restype = i64
+        L.elector_homopolymer_pairs.argtypes = [i64, vp, vp, vp, vp, C.c_int32, vp, i64]
+        L._stats_bound = True
+    return L
+
+
+class Pieces:
+    """msa.fa parsed into the C-ABI layout."""
+    __slots__ = ("headers", "header_nos", "rows", "row_off", "cols", "read_first", "n_split_reads_flags")
+
+
+def getSplit(fileName):
+    """computeStats.py:45-56 without the `grep | uniq -c` subprocess: run lengths of
+    identical header lines // 3, keyed by the header with blanks removed."""
+    readToSplit = dict()
+    prev, cnt = None, 0
+
+    def flush():
+        if prev is not None:
+            readToSplit[prev.split(">")[1].replace(" ", "").replace("\t", "")] = int(cnt / 3)
+    with open(fileName) as f:
+        for line in f:
+            if ">" in line:
+                line = line.rstrip("\n")
+                if line == prev:
+                    cnt += 1
+                else:
+                    flush()
+                    prev, cnt = line, 1
+    flush()
+    return readToSplit
+
+
+def parse_msa(fileName, readsToSplit):
+    """Walk the file the way computeMetrics does (computeStats.py:546-658): six
+    lines per piece, readsToSplit[header] pieces per read."""
+    with open(fileName) as f:
+        lines = f.readlines()
+    headers, header_nos, chunks, cols, read_first = [], [], [], [], [0]
+    nb = 0
+    header_no = header = None
+    while nb < len(lines):
+        if ">" not in lines[nb]:
+            nfrag = readsToSplit[header_no]
+            for _ in range(nfrag if nfrag > 1 else 1):
+                if nb >= len(lines):
+                    break
+                ref = lines[nb].rstrip(); nb += 2
+                cor = lines[nb].rstrip() if nb < len(lines) else ""; nb += 2
+                unc = lines[nb].rstrip() if nb < len(lines) else ""; nb += 1
+                n = len(ref)
+                if len(cor) != n or len(unc) != n:
+                    raise ValueError("msa rows of unequal length for read %r" % header)
+                headers.append(header)
+                header_nos.append(header_no)
+                chunks.append(ref + cor + unc)
+                cols.append(n)
+                if nb < len(lines):
+                    header_no = lines[nb].split(">")[1].split(" ")[0]
+                    header = lines[nb].split(">")[1].rstrip()
+                    nb += 1
+            read_first.append(len(cols))
+        else:
+            header_no = lines[nb].split(">")[1].split(" ")[0]
+            header = lines[nb].split(">")[1].rstrip()
+            nb += 1
+    p = Pieces()
+    p.headers, p.header_nos = headers, header_nos
+    p.cols = np.asarray(cols, dtype=np.int64)
+    p.row_off = np.zeros(len(cols) + 1, dtype=np.int64)
+    np.cumsum(3 * p.cols, out=p.row_off[1:])
+    p.rows = np.frombuffer("".join(chunks).encode("latin-1"), dtype=np.uint8)
+    p.read_first = np.asarray(read_first, dtype=np.int64)
+    return p
+
+
+def stats_counters(pieces, clipsNb=None, engine=None):
+    """-> (counters int64[n_pieces, ES_NCOUNTERS], last_mask uint8[...]) from the GPU."""
+    engine = engine or _default_engine()
+    L = _bind(_capi.lib())
+    n_pieces = len(pieces.cols)
+    n_reads = len(pieces.read_first) - 1
+    counters = np.zeros((n_pieces, ES_NCOUNTERS), dtype=np.int64)
+    clips = None
+    if clipsNb:
+        clips = np.zeros((n_pieces, 2), dtype=np.int32)
+        for i, h in enumerate(pieces.headers):
+            if h in clipsNb:
+                clips[i, 0], clips[i, 1] = clipsNb[h][0], clipsNb[h][1]
+    last_cols = int(pieces.cols[pieces.read_first[-2]:].sum()) if n_reads else 0
+    last_mask = np.zeros(last_cols + 1, dtype=np.uint8)
+    rc = L.elector_stats_batch(engine._h, n_reads, pieces.read_first.ctypes.data, n_pieces,
+                               pieces.rows.ctypes.data, pieces.row_off.ctypes.data, pieces.cols.ctypes.data,
+                               clips.ctypes.data if clips is not None else None, counters.ctypes.data,
+                               last_mask.ctypes.data)
+    if rc:
+        raise ElectorError(rc, L.elector_ctx_last_error(engine._h).decode())
+    return counters, last_mask[:last_cols]
+
+
+def homopolymer_ratios(pieces, last_mask, threshold):
+    """Ratios of the LAST read (the only ones the reference reports,
+    computeStats.py:560,671-674): round(corrected_run / reference_run, 2) per homopolymer."""
+    L = _bind(_capi.lib())
+    n_reads = len(pieces.read_first) - 1
+    if n_reads == 0:
+        return []
+    p0 = int(pieces.read_first[-2])
+    npieces = len(pieces.cols) - p0
+    cols = np.ascontiguousarray(pieces.cols[p0:])
+    row_off = np.ascontiguousarray(pieces.row_off[p0:] - pieces.row_off[p0])
+    rows = np.ascontiguousarray(pieces.rows[pieces.row_off[p0]:])
+    cap = int(cols.sum()) + 1
+    pairs = np.zeros((cap, 2), dtype=np.int32)
+    mask = np.ascontiguousarray(last_mask, dtype=np.uint8)
+    n = L.elector_homopolymer_pairs(npieces, rows.ctypes.data, row_off.ctypes.data, cols.ctypes.data,
+                                    mask.ctypes.data, int(threshold), pairs.ctypes.data, cap)
+    if n < 0:
+        raise ElectorError(int(n))
+    return [round(int(c) * 1.0 / int(r), 2) for c, r in pairs[:n]]
+
+
+def aggregate(pieces, counters, ratios, outPerReadMetrics):
+    """The host half of computeMetrics (computeStats.py:519-675): per-read ratios in
+    read order from the integer counters."""
+    nbReadsToDivide = 0
+    countReadSplit = countReadExtended = countReadTrimmed = 0
+    extendedBasesCount, missingSize = [], []
+    indelsubsCorr, indelsubsUncorr = [0, 0, 0], [0, 0, 0]
+    allLenCorrected, allLenUncorrected = [], []
+    precision, recall, corBasesRate, uncorCorBasesRate = [], [], [], []
+    totalCorBases = totalUncorBases = 0
+    GCRateRef, GCRateCorr = [], []
+    n_reads = len(pieces.read_first) - 1
+    for r in range(n_reads):
+        p0, p1 = int(pieces.read_first[r]), int(pieces.read_first[r + 1])
+        nfrag = p1 - p0
+        split = nfrag > 1
+        if split:
+            countReadSplit += 1
+        isExtended = isTrimmed = False
+        TPs = FPs = FNs = cors = uncs = ucors = uuncs = 0
+        any_piece = False
+        gcr = gcc = 0
+        emitted = False
+        missingInRead = 0
+        for k, p in enumerate(range(p0, p1)):
+            c = counters[p]
+            if not c[ES_PROCESSED]:
+                continue
+            any_piece = True
+            if k == 0 or not split:
+                allLenUncorrected.append(int(c[ES_LEN_UNC]))
+            for side in (ES_EXT_LEFT, ES_EXT_RIGHT):
+                if c[side] >= 0:
+                    isExtended = True
+                    extendedBasesCount.append(int(c[side]))
+            missingInRead = int(c[ES_MISSING])
+            if missingInRead > THRESH:
+                isTrimmed = True
+            indelsubsCorr[0] += int(c[ES_INS_C]); indelsubsCorr[1] += int(c[ES_DEL_C]); indelsubsCorr[2] += int(c[ES_SUB_C])
+            indelsubsUncorr[0] += int(c[ES_INS_U]); indelsubsUncorr[1] += int(c[ES_DEL_U]); indelsubsUncorr[2] += int(c[ES_SUB_U])
+            TPs += int(c[ES_TP]); FPs += int(c[ES_FP]); FNs += int(c[ES_FN])
+            cors += int(c[ES_COR]); uncs += int(c[ES_UNC]); ucors += int(c[ES_UCOR]); uuncs += int(c[ES_UUNC])
+            allLenCorrected.append(int(c[ES_LEN_COR]))
+            gcr = round(int(c[ES_GC_REF]) * 1.0 / int(c[ES_LEN_REF]), 3)
+            gcc = round(int(c[ES_GC_COR]) * 1.0 / int(c[ES_LEN_COR]), 3)
+            if split and p == p1 - 1:
+                missingInRead = int(c[ES_MISSING_LAST])
+                emitted = True
+            elif not split:
+                emitted = True
+        if not emitted:
+            continue
+        # outputMetrics (computeStats.py:444-468); a processed piece always left entries in the lists
+        if any_piece:
+            rec = TPs / (TPs + FNs) if (TPs + FNs) != 0 else 0
+            prec = TPs / (TPs + FPs) if (TPs + FPs) != 0 else 0
+            if missingInRead != 0:
+                missingSize.append(missingInRead)
+            corBRate = cors / (cors + uncs) if (cors + uncs) != 0 else 0
+            uncorCorBRate = ucors / (ucors + uuncs) if (ucors + uuncs) != 0 else 0
+            outPerReadMetrics.write(str(rec) + " recall\n")
+            outPerReadMetrics.write(str(prec) + " precision\n")
+            outPerReadMetrics.write(str(corBRate) + " correct_rate\n")
+            recall.append(rec); precision.append(prec)
+            corBasesRate.append(corBRate); uncorCorBasesRate.append(uncorCorBRate)
+            totalCorBases += cors
+            totalUncorBases += uncs
+        GCRateRef.append(gcr)
+        GCRateCorr.append(gcc)
+        if isExtended:
+            countReadExtended += 1
+        if isTrimmed and not split:
+            countReadTrimmed += 1
+        nbReadsToDivide += 1
+
+    GCRateRef = round(sum(GCRateRef) / len(GCRateRef), 3)
+    GCRateCorr = round(sum(GCRateCorr) / len(GCRateCorr), 3)
+    recall = sum(recall) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
+    precision = sum(precision) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
+    corBasesRate = sum(corBasesRate) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
+    uncorCorBasesRate = sum(uncorCorBasesRate) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
+    throughput = sum(allLenCorrected)
+    uncorThroughput = sum(allLenUncorrected)
+    errorRate = 1 - (totalCorBases / (totalCorBases + totalUncorBases))
+    uncorErrorRate = 1 - (totalUncorBases / (totalCorBases + totalUncorBases))
+    meanRatioHomopolymers = statistics.mean(ratios) if len(ratios) > 1 else 1
+    return (nbReadsToDivide, throughput, uncorThroughput, precision, recall, corBasesRate, errorRate,
+            uncorCorBasesRate, uncorErrorRate, missingSize, GCRateRef, GCRateCorr, indelsubsUncorr, indelsubsCorr,
+            meanRatioHomopolymers, allLenCorrected, countReadSplit, countReadTrimmed, countReadExtended,
+            extendedBasesCount)
+
+
+def computeMetrics(fileName, outPerReadMetrics, correctedFileName, reportedThreshold, clipsNb, readsToSplit,
+                   engine=None):
+    """Same return tuple as the reference's computeMetrics (computeStats.py:519-675)."""
+    pieces = parse_msa(fileName, readsToSplit)
+    counters, last_mask = stats_counters(pieces, clipsNb, engine)
+    ratios = homopolymer_ratios(pieces, last_mask, reportedThreshold)
+    return aggregate(pieces, counters, ratios, outPerReadMetrics)
+
+
+def outputReadSizeDistribution(correctedFileName, outFileName, outDir, trimmedOrSplit, lenAllReads):
+    """computeStats.py:273-286"""
+    out = open(outDir + "/" + outFileName, 'w')
+    out.write("size type\n")
+    for readSize in lenAllReads:
+        out.write(str(readSize) + " reads\n")
+    if trimmedOrSplit != 0:
+        cor = open(correctedFileName)
+        l = cor.readline()
+        while l != "":
+            l = cor.readline()[:-1]
+            out.write(str(len(l)) + " sequences\n")
+            l = cor.readline()
+        cor.close()
+    out.close()
+
+
+def outputRecallPrecision(correctedFileName, outDir, logFile, smallReadNumber, wronglyCorrectedReadsNumber,
+                          reportedHomopolThreshold, SIZE_CORRECTED_READ_THRESHOLD, fileSizeName, clipsNb,
+                          beg=0, end=0, soft=None):
+    """computeStats.py:196-263"""
+    print(soft)
+    if soft is not None:
+        outMetrics = open(outDir + "/" + soft + "_per_read_metrics.txt", 'w')
+        msa = outDir + "/msa_" + soft + ".fa"
+    else:
+        outMetrics = open(outDir + "/per_read_metrics.txt", 'w')
+        msa = outDir + "/msa.fa"
+    outMetrics.write("score metric\n")
+    readsToSplit = getSplit(msa)
+    (nbReads, throughput, uncorThroughput, precision, recall, corBasesRate, errorRate, uncorCorBasesRate,
+     uncorErrorRate, missingSize, GCRateRef, GCRateCorr, indelsubsUncorr, indelsubsCorr, ratioHomopolymers,
+     lenAllCorrectedReads, countReadSplit, countReadTrimmed, countReadExtended, extendedBasesCount) = \
+        computeMetrics(msa, outMetrics, correctedFileName, reportedHomopolThreshold, clipsNb, readsToSplit)
+
+    outputReadSizeDistribution(correctedFileName, fileSizeName, outDir, countReadSplit + countReadTrimmed,
+                               lenAllCorrectedReads)
+    outMetrics.close()
+    meanMissingSize = 0
+    if countReadSplit + countReadTrimmed > 0:
+        meanMissingSize = round(sum(missingSize) / (countReadSplit + countReadTrimmed), 1)
+    meanExtendedBases = 0
+    if countReadExtended > 0:
+        meanExtendedBases = round(sum(extendedBasesCount) / countReadExtended, 1)
+    if soft is not None:
+        print(soft)
+
+    recall = round(recall, 7)
+    precision = round(precision, 7)
+    corBasesRate = round(corBasesRate, 7)
+    errorRate = round(errorRate, 7)
+    GCRateRef = round(GCRateRef * 100, 7)
+    GCRateCorr = round(GCRateCorr * 100, 7)
+
+    # (stdout prefix, log prefix, value): one row per reported quantity.  print(a, b)
+    # joins with one blank, so stdout prefixes carry the blank(s) the reference's
+    # print calls produce (computeStats.py:232-262).
+    pct = SIZE_CORRECTED_READ_THRESHOLD * 100
+    report = [
+        ("Assessed reads:  ", "Assessed reads: ", nbReads),
+        ("Throughput (uncorrected) ", "\nThroughput (uncorrected): ", uncorThroughput),
+        ("Throughput (corrected):  ", "\nThroughput (corrected): ", throughput),
+        ("Recall: ", "\nRecall (computed only on corrected bases):", recall),
+        ("Precision: ", "\nPrecision (computed only on corrected bases):", precision),
+        ("Average correct bases rate (uncorrected):  ", "\nAverage correct bases rate (uncorrected):", uncorCorBasesRate),
+        ("Error rate (uncorrected): ", "\nError rate (uncorrected): ", 1 - uncorCorBasesRate),
+        ("Average correct bases rate (corrected):  ", "\nAverage correct bases rate (corrected):", corBasesRate),
+        ("Error rate (corrected): ", "\nError rate (corrected): ", 1 - corBasesRate),
+        ("Number of trimmed/split reads: ", "\nNumber of trimmed/split reads:", countReadSplit + countReadTrimmed),
+        ("Mean missing size in trimmed/split reads: ", "\nMean missing size in trimmed/split reads:", meanMissingSize),
+        ("Number of over-corrected reads by extention:  ", "\nNumber of over-corrected reads by extention: ", countReadExtended),
+        ("Mean extension size in over-corrected reads:  ", "\nMean extension size in over-corrected reads: ", meanExtendedBases),
+        ("%GC in reference reads:  ", "\n%GC in reference reads: ", GCRateRef),
+        ("%GC in corrected reads:  ", "\n%GC in corrected reads: ", GCRateCorr),
+        ("Number of corrected reads which length is < " + str(pct) + " % of the original read: ",
+         "\nNumber of corrected reads which length is <" + str(pct) + "% of the original read:", smallReadNumber),
+        ("Number of very low quality corrected reads:  ", "\nNumber of very low quality corrected reads: ", wronglyCorrectedReadsNumber),
+        ("Number of insertions in uncorrected:  ", "\nNumber of insertions in uncorrected: ", indelsubsUncorr[0]),
+        ("Number of insertions in corrected:  ", "\nNumber of insertions in corrected: ", indelsubsCorr[0]),
+        ("Number of deletions in uncorrected:  ", "\nNumber of deletions in uncorrected: ", indelsubsUncorr[1]),
+        ("Number of deletions in corrected:  ", "\nNumber of deletions in corrected: ", indelsubsCorr[1]),
+        ("Number of substitutions in uncorrected:  ", "\nNumber of substitutions in uncorrected: ", indelsubsUncorr[2]),
+        ("Number of substitutions in corrected:  ", "\nNumber of substitutions in corrected: ", indelsubsCorr[2]),
+        ("Ratio of homopolymer sizes in corrected vs reference: ", "\nRatio of homopolymer sizes in corrected vs reference: ", ratioHomopolymers),
+    ]
+    banner = "*********** SUMMARY ***********"
+    print(banner)
+    for out_label, _, value in report:
+        print(out_label + str(value))
+    logFile.write(banner + "\n" + "".join(log_label + str(value) for _, log_label, value in report) + "\n")
+    return (nbReads, throughput, precision, recall, corBasesRate, 1 - corBasesRate, smallReadNumber,
+            wronglyCorrectedReadsNumber, GCRateRef, GCRateCorr, str(countReadSplit + countReadTrimmed),
+            meanMissingSize, str(countReadExtended), meanExtendedBases, SIZE_CORRECTED_READ_THRESHOLD,
+            indelsubsUncorr, indelsubsCorr, countReadSplit + countReadTrimmed, ratioHomopolymers)

@@ -1,0 +1,92 @@
+// elector_amd/csrc/ctx.h -- the context object behind the C ABI (one per GPU):
+// stream, constant tables, grow-on-demand device workspace, error text, timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "elector_poa.h"
+#include "poa_device.h"
+
+namespace elector {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes)
+  {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 4096;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return ELECTOR_E_NOMEM; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct HostPinned {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes)
+  {
+    if (bytes <= cap) return 0;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return ELECTOR_E_NOMEM; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct TimedSpan { hipEvent_t a, b; int kind; };
+
+}  // namespace elector
+
+struct elector_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  elector_params params;
+  elector::KParams kp;
+  bool gen = false;
+  std::string err;
+  std::mutex mu;
+  // constant tables
+  elector::DevBuf d_tab, d_linx, d_liny;
+  // per-batch workspace
+  elector::DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
+      d_n1, d_cls, d_score1, d_score2, d_bx2;
+  // host API staging
+  elector::DevBuf d_bases, d_cols, d_ncol, d_status, d_scores, d_rowoff, d_rows;
+  elector::HostPinned h_meta;
+  // statistics workspace
+  elector::DevBuf d_st_rows, d_st_rowoff, d_st_cols, d_st_first, d_st_clips, d_st_cnt, d_st_mask, d_st_scr, d_st_scroff;
+  // timing
+  bool timing = false;
+  std::vector<elector::TimedSpan> spans;
+  double ms_acc[3] = {0, 0, 0};
+  int64_t launches_acc[3] = {0, 0, 0};
+  int64_t last_n = 0;
+};
+
+inline int elector_fail(elector_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+  }
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                        \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) return elector_fail((ctx), ELECTOR_E_HIP, #call, e_);          \
+  } while (0)
+

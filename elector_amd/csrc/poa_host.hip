@@ -29,82 +29,9 @@ void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, c
 
 using namespace elector;
 
-namespace {
+#include "ctx.h"
 
-struct DevBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t bytes)
-  {
-    if (bytes <= cap) return 0;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 8 + 4096;
-    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return ELECTOR_E_NOMEM; }
-    cap = want;
-    return 0;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct HostPinned {
-  void *p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t bytes)
-  {
-    if (bytes <= cap) return 0;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 8 + 4096;
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return ELECTOR_E_NOMEM; }
-    cap = want;
-    return 0;
-  }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct TimedSpan { hipEvent_t a, b; int kind; };
-
-}  // namespace
-
-struct elector_ctx {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  elector_params params;
-  KParams kp;
-  bool gen = false;
-  std::string err;
-  std::mutex mu;
-  // constant tables
-  DevBuf d_tab, d_linx, d_liny;
-  // per-batch workspace
-  DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
-      d_n1, d_cls, d_score1, d_score2, d_bx2;
-  // host API staging
-  DevBuf d_bases, d_cols, d_ncol, d_status, d_scores, d_rowoff, d_rows;
-  HostPinned h_meta;
-  // timing
-  bool timing = false;
-  std::vector<TimedSpan> spans;
-  double ms_acc[3] = {0, 0, 0};
-  int64_t launches_acc[3] = {0, 0, 0};
-  int64_t last_n = 0;
-};
-
-static int fail(elector_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
-{
-  if (c) {
-    c->err = what;
-    if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
-  }
-  return code;
-}
-
-#define HIPCHK(ctx, call)                                                        \
-  do {                                                                           \
-    hipError_t e_ = (call);                                                      \
-    if (e_ != hipSuccess) return fail((ctx), ELECTOR_E_HIP, #call, e_);          \
-  } while (0)
+static int fail(elector_ctx *c, int code, const char *what, hipError_t e = hipSuccess) { return elector_fail(c, code, what, e); }
 
 // ------------------------------------------------------------------ probes ---
 
@@ -341,7 +268,8 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
   DevBuf *bufs[] = {&c->d_tab, &c->d_linx, &c->d_liny, &c->d_off, &c->d_perm, &c->d_mv1, &c->d_mv2, &c->d_sym,
                     &c->d_xinfo, &c->d_ring1, &c->d_map16, &c->d_carry, &c->d_moves, &c->d_n1, &c->d_cls,
                     &c->d_score1, &c->d_score2, &c->d_bx2, &c->d_bases, &c->d_cols, &c->d_ncol, &c->d_status,
-                    &c->d_scores, &c->d_rowoff, &c->d_rows};
+                    &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
+                    &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_scroff};
   for (DevBuf *b : bufs) b->release();
   c->h_meta.release();
   if (c->stream) (void)hipStreamDestroy(c->stream);

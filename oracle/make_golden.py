@@ -22,6 +22,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib  # noqa: E402
 import synth  # noqa: E402
@@ -185,5 +186,35 @@ def main():
     print("params.json", ns, q.symbol.decode(), q.M, list(q.gpx[: q.M + 2]))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--stats-only" not in sys.argv:
     main()
+
+
+def make_stats_golden():
+    """tests/golden/stats_golden.json: msa.fa texts -> what the REAL reference module
+    (elector/computeStats.py imported from /root/reference) returns and prints."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_import
+    import msa_gen
+    cases = []
+    for seed, n, L, clips in ((11, 14, 700, False), (12, 10, 1100, True), (13, 6, 400, False)):
+        reads = msa_gen.make_reads(seed, n, L)
+        txt, small, wrong = msa_gen.msa_text(reads)
+        cl = {}
+        if clips:
+            hs = sorted({ln[1:].rstrip() for ln in txt.split("\n") if ln.startswith(">")})
+            for i, h in enumerate(hs[::3]):
+                cl[h] = (5 + i, 9 + 2 * i)
+        with tempfile.TemporaryDirectory() as d:
+            open(d + "/msa.fa", "w").write(txt)
+            open(d + "/cor.fa", "w").write("".join(">x\n" + r[2].decode() + "\n" for r in reads))
+            tup, out, log = ref_import.run_reference(d + "/msa.fa", d + "/cor.fa", d, small, wrong, clips=cl)
+            per = open(d + "/per_read_metrics.txt").read()
+        cases.append({"msa": txt, "small": small, "wrong": wrong, "clips": {k: list(v) for k, v in cl.items()},
+                      "tuple": json.loads(json.dumps(tup)), "stdout": out, "log": log, "per_read": per})
+        print("stats case", seed, "reads", tup[0], "split/trimmed", tup[10], "extended", tup[12])
+    json.dump(cases, open(os.path.join(GOLD, "stats_golden.json"), "w"))
+
+
+if __name__ == "__main__":
+    make_stats_golden()
