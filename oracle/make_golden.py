@@ -186,7 +186,7 @@ def main():
     print("params.json", ns, q.symbol.decode(), q.M, list(q.gpx[: q.M + 2]))
 
 
-if __name__ == "__main__" and "--stats-only" not in sys.argv:
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
 
 
@@ -216,5 +216,54 @@ def make_stats_golden():
     json.dump(cases, open(os.path.join(GOLD, "stats_golden.json"), "w"))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and ("--stats-only" in sys.argv or len(sys.argv) == 1):
     make_stats_golden()
+
+
+def make_pipeline_golden():
+    """tests/golden/pipeline_*.json: three sorted FASTA texts -> the msa.fa the
+    REFERENCE chain writes (masterSplitter -> poa per slot -> Donatello per slot,
+    exactly elector/alignment.py:98-122) and its two counters."""
+    import msa_gen
+    cases = []
+
+    def fa(p):
+        ls = open(p, "rb").read().split(b"\n")
+        return [(ls[i], ls[i + 1]) for i in range(0, len(ls) - 1, 2)]
+    per, unc, cor = (fa(os.path.join(EXAMPLE, f)) for f in
+                     ("perfect_reads.fasta", "uncorrected_reads.fasta", "corrected_reads.fasta"))
+    example = [(p[0] + b"_0", p[1], c[1], u[1]) for p, c, u in zip(per, cor, unc)]
+    synth_reads = msa_gen.make_reads(31, 16, 1300)
+    tiny = [(b">tiny_0", b"AC", b"AC", b"AC"), (b">small_0 with a title", b"ACGTACGTAC" * 40, b"ACGTAC", b"ACGTACGTAC" * 40)]
+    for name, reads in (("example", example), ("synthetic", synth_reads + tiny)):
+        with tempfile.TemporaryDirectory() as d:
+            for fn, k in (("ref.fa", 1), ("cor.fa", 2), ("unc.fa", 3)):
+                with open(os.path.join(d, fn), "wb") as f:
+                    for r in reads:
+                        f.write(r[0] + b"\n" + r[k] + b"\n")
+            rc = 1
+            small = wrong = 0
+            msa = os.path.join(d, "msa.fa")
+            while rc != 0:
+                rc = subprocess.run([os.path.join(REF, "masterSplitter"), d + "/ref.fa", d + "/unc.fa", d + "/cor.fa",
+                                     d + "/out1", d + "/out2", d + "/out3", "7", "200", "10000", "0.1", d],
+                                    stdout=subprocess.DEVNULL).returncode
+                small += int(open(d + "/small_reads.txt").readline())
+                wrong += int(open(d + "/wrongly_cor_reads.txt").readline())
+                for i in range(200):
+                    if os.stat(d + "/out3%d" % i).st_size != 0:
+                        subprocess.run([os.path.join(REF, "poa"), "-pir", d + "/smsa%d" % i, "-preserve_seqorder",
+                                        "-corrected_reads_fasta", d + "/out3%d" % i, "-reference_reads_fasta",
+                                        d + "/out1%d" % i, "-uncorrected_reads_fasta", d + "/out2%d" % i,
+                                        "-preserve_seqorder", "-threads", "1", "-pathMatrix", MATRIX],
+                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                for i in range(200):
+                    subprocess.run([os.path.join(REF, "Donatello"), d + "/smsa%d" % i, msa])
+            cases.append({"name": name, "ref": open(d + "/ref.fa").read(), "cor": open(d + "/cor.fa").read(),
+                          "unc": open(d + "/unc.fa").read(), "msa": open(msa).read(), "small": small, "wrong": wrong})
+            print("pipeline", name, len(reads), "reads ->", len(cases[-1]["msa"]), "bytes of msa.fa, small", small, "wrong", wrong)
+    json.dump(cases, open(os.path.join(GOLD, "pipeline_golden.json"), "w"))
+
+
+if __name__ == "__main__" and ("--pipeline-only" in sys.argv or len(sys.argv) == 1):
+    make_pipeline_golden()

@@ -78,3 +78,13 @@ def test_pack_windows_layout():
     bases, off = poa.pack_windows(tr)
     assert bases.tobytes() == b"ACGTACAGGGGGG"
     assert off.tolist() == [0, 4, 6, 7, 8, 10, 13]
+
+
+def test_poa_header_text():
+    from elector_amd.alignment import _poa_header
+    assert _poa_header(b">read7_0") == b">read7_0 untitled"
+    assert _poa_header(b">read7_0 some title  ") == b">read7_0 some title  "
+    assert _poa_header(b">  spaced   t") == b">spaced t"
+    # Donatello then drops the last 11 characters ("_0 untitled") and adds a blank (Donatello.cpp:71-73)
+    h = _poa_header(b">read7_0")
+    assert h[: len(h) - 11] + b" " == b">read7 "
