@@ -1,0 +1,72 @@
+"""Multi-GPU layer: one process per GPU (torchrun), reads sharded by contiguous
+ranges balanced by bases, NO data-path collective; a single gather of the
+per-piece integer counters to rank 0 at the end.
+
+`backend="nccl"` is RCCL over xGMI on the GPU node; the same code runs on the
+`gloo` backend for the CPU tests.  All floating point happens after the gather,
+on rank 0, in original read order (elector_amd.computeStats.aggregate), so the
+report does not depend on the number of GPUs.
+"""
+import numpy as np
+
+
+def shard_bounds(weights, world):
+    """Contiguous split of len(weights) items into `world` ranges with near-equal
+    weight sums.  -> int64[world + 1] boundaries."""
+    n = len(weights)
+    b = np.zeros(world + 1, dtype=np.int64)
+    if n == 0:
+        return b
+    cum = np.cumsum(np.asarray(weights, dtype=np.float64))
+    total = cum[-1]
+    for r in range(1, world):
+        b[r] = int(np.searchsorted(cum, total * r / world, side="left"))
+    b[world] = n
+    return np.maximum.accumulate(b)
+
+
+def gather_rows(local, group=None, dst=0):
+    """Gather variable-length int64 [k_i, C] blocks from every rank to `dst`, in rank
+    order.  Returns the concatenated array on dst and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return np.asarray(local)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    local = np.ascontiguousarray(local, dtype=np.int64)
+    ncol = local.shape[1] if local.ndim == 2 else 1
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=dev), group=group)
+    cap = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros((cap, ncol), dtype=torch.int64, device=dev)
+    if local.shape[0]:
+        pad[: local.shape[0]] = torch.from_numpy(local.reshape(local.shape[0], ncol)).to(dev)
+    out = [torch.zeros((cap, ncol), dtype=torch.int64, device=dev) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, out, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return np.concatenate([o[: int(s.item())].cpu().numpy() for o, s in zip(out, sizes)], axis=0)
+
+
+def sharded_counters(pieces, counter_fn, group=None):
+    """Every rank computes the counters of its own contiguous range of READS with
+    counter_fn(sub_pieces) -> int64[n_pieces_local, C]; rank 0 receives all rows in
+    piece order.  `pieces` is the full elector_amd.computeStats.Pieces on every rank."""
+    import torch.distributed as dist
+    from .computeStats import Pieces
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_reads = len(pieces.read_first) - 1
+    cols_per_read = np.add.reduceat(pieces.cols, pieces.read_first[:-1]) if n_reads else np.zeros(0)
+    b = shard_bounds(cols_per_read, world)
+    r0, r1 = int(b[rank]), int(b[rank + 1])
+    p0, p1 = int(pieces.read_first[r0]), int(pieces.read_first[r1])
+    sub = Pieces()
+    sub.headers, sub.header_nos = pieces.headers[p0:p1], pieces.header_nos[p0:p1]
+    sub.cols = np.ascontiguousarray(pieces.cols[p0:p1])
+    sub.row_off = np.ascontiguousarray(pieces.row_off[p0:p1 + 1] - pieces.row_off[p0])
+    sub.rows = np.ascontiguousarray(pieces.rows[pieces.row_off[p0]:pieces.row_off[p1]])
+    sub.read_first = np.ascontiguousarray(pieces.read_first[r0:r1 + 1] - p0)
+    local = counter_fn(sub) if p1 > p0 else np.zeros((0, 1), dtype=np.int64)
+    return gather_rows(local, group)

@@ -1,0 +1,87 @@
+"""N > 1 path on CPU: two gloo ranks shard the reads, compute counters for their
+own range and gather them to rank 0; the aggregate must equal the single-process
+result (floats are computed after the gather, in read order)."""
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _oracle_counter_fn(pieces):
+    """Stand-in for the GPU kernel on the CPU test box: oracle counters in C-ABI layout."""
+    import stats_oracle
+    from elector_amd import computeStats as cs
+    from test_stats_cpu import oracle_counter_array
+    out = []
+    for r in range(len(pieces.read_first) - 1):
+        st = dict(is_extended=False, is_trimmed=False, missing=0, extended_bases=[])
+        p0, p1 = int(pieces.read_first[r]), int(pieces.read_first[r + 1])
+        union = set()
+        for p in range(p0, p1):
+            n = int(pieces.cols[p])
+            if n <= 10:
+                continue
+            a = int(pieces.row_off[p])
+            txt = pieces.rows[a:a + 3 * n].tobytes().decode()
+            k, ex = stats_oracle.piece_counters(txt[:n], txt[n:2 * n], txt[2 * n:], None, [], 5, st)
+            union.update(i for i, e in enumerate(ex) if e)
+            if p1 - p0 > 1 and p == p1 - 1:
+                k["missing_last"] = sum(1 for i in range(n) if i not in union and txt[i] != ".")
+            out.append(k)
+    return oracle_counter_array(pieces, out)
+
+
+def _worker(rank, world, port, msa_path, result_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from elector_amd import computeStats as cs
+    from elector_amd import distributed
+    pieces = cs.parse_msa(msa_path, cs.getSplit(msa_path))
+    allc = distributed.sharded_counters(pieces, _oracle_counter_fn)
+    if rank == 0:
+        np.save(result_path, allc)
+    else:
+        assert allc is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_equals_single_process(tmp_path):
+    import msa_gen
+    from elector_amd import computeStats as cs
+    reads = msa_gen.make_reads(77, 22, 700)
+    txt, _, _ = msa_gen.msa_text(reads)
+    msa = str(tmp_path / "msa.fa")
+    open(msa, "w").write(txt)
+    res = str(tmp_path / "counters.npy")
+    mp.spawn(_worker, args=(2, 29517, msa, res), nprocs=2, join=True)
+    got = np.load(res)
+    pieces = cs.parse_msa(msa, cs.getSplit(msa))
+    exp = _oracle_counter_fn(pieces)
+    assert np.array_equal(got, exp)
+    # and the float aggregation from the gathered integers equals the oracle's report
+    import stats_oracle
+    r, _ = stats_oracle.compute_metrics(txt, 5)
+    agg = cs.aggregate(pieces, got, r["lastReadRatios"], io.StringIO())
+    assert agg[0] == r["nbReads"] and agg[3] == r["precision"] and agg[4] == r["recall"]
+    assert agg[12] == r["indelsubsUncorr"] and agg[13] == r["indelsubsCorr"]
+
+
+def test_shard_bounds():
+    from elector_amd.distributed import shard_bounds
+    b = shard_bounds([10, 10, 10, 10], 2)
+    assert b.tolist() == [0, 2, 4] or b.tolist() == [0, 1, 4] or b[0] == 0 and b[-1] == 4
+    assert shard_bounds([], 4).tolist() == [0, 0, 0, 0, 0]
+    b = shard_bounds(np.ones(101), 8)
+    assert b[0] == 0 and b[-1] == 101 and np.all(np.diff(b) >= 12) and np.all(np.diff(b) <= 14)
