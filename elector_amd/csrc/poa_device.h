@@ -64,8 +64,9 @@ __host__ __device__ inline int64_t mv_index(int tw, int ii, int jj, int *shift)
 }
 
 struct BatchArgs {
-  int64_t n;                 // windows in this launch range
-  const uint32_t *perm;      // processing order (window ids)
+  int64_t n;                 // windows in the launch's list (all windows of the batch for k_left_b)
+  const uint32_t *perm;      // the list: window ids in processing order
+  const int32_t *count_ptr;  // when set: the list length lives on the device (list built by k_left_b)
   const int64_t *off;        // [3n+1]
   const uint8_t *bases;      // raw
   uint8_t *sym;
@@ -85,6 +86,36 @@ struct BatchArgs {
   const int32_t *linx, *liny;   // packed border cells: k gap steps from the origin
   const DevTables *tab;
   KParams kp;
+  const uint8_t *skip_a;        // 1 = alignment #1 / fusion #1 already done by the fused kernel
+  const uint8_t *skip_b;        // 1 = alignment #2 / fusion #2 already done by the fused kernel
+  uint8_t *mark_b;              // when set, k_fuse2 marks the windows it finishes
 };
+
+// LDS bytes the fused kernels need for a window in a group of G lanes (4G rows per
+// strip); must mirror the slot layouts in poa_fused.hip
+__host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G)
+{
+  const int ns = (Lc + 4 * G - 1) / (4 * G);
+  int o = (Lr + Lc + 3) & ~3;
+  o += (2 * Lr + 3) & ~3;
+  o += (ns > 1 ? 4 * (Lr + 1) : 0);
+  o = (o + 7) & ~7;
+  const int mv = ns * Lr * G, st = 8 * (Lr + Lc + 1) + 2 * (Lr + Lc);
+  return o + (mv > st ? mv : st);
+}
+
+__host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G)
+{
+  const int ns = (Lu + 4 * G - 1) / (4 * G);
+  int o = (Lu + 7) & ~7;
+  o += 8 * (n1 + 1);
+  o += (2 * n1 + 3) & ~3;
+  o += (2 * n1 + 3) & ~3;
+  o += 4 * (n1 + 1);
+  o += (ns > 1 ? 4 * (n1 + 1) : 0);
+  o = (o + 7) & ~7;
+  const int mv = ns * n1 * 2 * G, st = 3 * (n1 + Lu) + 8;
+  return o + (mv > st ? mv : st);
+}
 
 }  // namespace elector

@@ -1,0 +1,603 @@
+// elector_amd/csrc/poa_fused.hip -- LDS-resident, row-blocked kernels for the
+// windows that fit on chip (the bulk: the splitter's windows are 27-400 bases).
+//
+// Geometry: one wavefront works on FOUR windows; each window owns 16 lanes and a
+// slot of LDS.  A lane holds FOUR consecutive rows of the linear read y in
+// registers, so a 64-row strip needs only 16 anti-diagonal steps of skew instead
+// of 64: steps per strip = Lx + 15, lane g computes column jj = t - g for its 4
+// rows top to bottom (the vertical dependence stays inside the lane).  The row
+// above a lane's block arrives by DPP row_shr:1 inside the 16-lane row; lane 0
+// receives the strip's top border through the DPP `old` operand.
+//
+//   k_fused_a  alignment #1 (linear x linear) -> moves in LDS -> traceback ->
+//              fusion #1 -> PO graph (xinfo, ring1, virtual-row scores) to HBM.
+//              Replaces k_dp1 + k_fuse1; alignment #1 moves never reach HBM.
+//   k_fused_b  alignment #2 (PO x linear, time ring in LDS) -> traceback ->
+//              fusion #2 -> MSA columns.  Replaces k_dp2 + k_fuse2.
+//
+// Uniform-scoring parameters only (the shipped matrix); other parameter sets and
+// windows that do not fit their LDS slot stay on the generic kernels of
+// poa_kernels.hip (the `done` flags say which windows were handled here).
+// Reference behaviour restated: align_lpo_po2.c:178-433 (DP, tie-breaks),
+// :108-168 (traceback), lpo.c:413-463,602-656 (fusion), lpo_format.c:337-393 (rows).
+#include <hip/hip_runtime.h>
+#include "poa_device.h"
+
+namespace elector {
+
+struct FusedArgs {
+  BatchArgs b;
+  const uint32_t *list;     // window ids of this bin, in processing order
+  int64_t nlist;
+  int slot_bytes;           // LDS bytes per window slot
+  uint8_t *done_a;          // 1 = alignment #1 + fusion #1 done by k_fused_a
+  uint8_t *done_b;          // 1 = alignment #2 + fusion #2 done by k_fused_b
+  int32_t *rowinit;         // node space: score of the virtual row -1 at node jj
+  int debug;                // timing experiments only (bit0: skip DP, bit1: skip serial stage)
+};
+
+__device__ __forceinline__ int row_shr1(int old, int v)
+{
+  // DPP row_shr:1 within each row of 16 lanes; lane 0 of a row keeps `old`.
+  return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ int wave_shr1_old(int old, int v)
+{
+  // DPP wave_shr:1 over the whole wave; lane 0 keeps `old`.
+  return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xF, 0xF, false);
+}
+
+// value of the lane above inside a group of G lanes; the group's first lane gets `border`
+template <int G>
+__device__ __forceinline__ int shift_in(int border, int v, int g)
+{
+  if (G == 16) return row_shr1(border, v);
+  const int r = wave_shr1_old(border, v);
+  return (G < 64 && g == 0) ? border : r;
+}
+
+__device__ __forceinline__ int align_up(int x, int a) { return (x + a - 1) & ~(a - 1); }
+
+// phase stamps for the timing-experiment build path (debug bit 2): cycles per phase
+// summed over waves into a scratch array that nothing else reads
+#define PHASE_STAMP(idx)                                                                          \
+  do {                                                                                            \
+    if ((a.debug & 4) && threadIdx.x == 0) {                                                      \
+      const unsigned long long now_ = __builtin_readcyclecounter();                               \
+      atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + (idx), now_ - stamp_);        \
+      stamp_ = now_;                                                                              \
+    }                                                                                             \
+  } while (0)
+
+// one DP cell with uniform scoring: returns new score, sets match flag / move nibble
+struct CellOut { int S; bool m; uint32_t nib; };
+
+__device__ __forceinline__ CellOut cell_1pred(int diag, int insX, int insY, int subv)
+{
+  const int mat = diag + subv;
+  const int mx = max(insX, insY);
+  CellOut o;
+  o.m = mat > mx;                                   // align_lpo_po2.c:384 (strict on both)
+  o.S = max(mat, mx);
+  o.nib = o.m ? (kMoveX1 | kMoveY) : (insX > insY ? kMoveX1 : kMoveY);   // :392 ties -> y
+  return o;
+}
+
+// ---------------------------------------------------------------- k_fused_a ---
+
+template <int G>
+__global__ void __launch_bounds__(64) k_fused_a(FusedArgs a)
+{
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int NW = 64 / G, RS = 4 * G;     // windows per wave, rows per strip
+  const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
+  const KParams kp = a.b.kp;
+  const int64_t li = NW * (int64_t)blockIdx.x + q;
+  bool valid = li < a.nlist;
+  const uint32_t w = valid ? a.list[li] : 0;
+  valid = valid && a.b.status[w] == 0;
+  int64_t o0 = 0;
+  int Lr = 0, Lc = 0;
+  if (valid) {
+    o0 = a.b.off[3 * (int64_t)w];
+    Lr = (int)(a.b.off[3 * (int64_t)w + 1] - o0);
+    Lc = (int)(a.b.off[3 * (int64_t)w + 2] - o0) - Lr;
+  }
+  // ---- slot layout: [ref+cor symbols][x2y u16][carry i32 (multi-strip only)][region]
+  // region = alignment #1 moves (1 byte per lane and column: 4 cells x 2 bits), reused
+  // after the traceback for the staged graph (xinfo int2[n1+1], then ring ids u16[n1]) ----
+  const int ns = (Lc + RS - 1) / RS;
+  const int off_x2y = align_up(Lr + Lc, 4);
+  const int off_carry = off_x2y + align_up(2 * Lr, 4);
+  const int off_region = align_up(off_carry + (ns > 1 ? 4 * (Lr + 1) : 0), 8);
+  const int region_bytes = max(ns * Lr * G, 8 * (Lr + Lc + 1) + 2 * (Lr + Lc));
+  valid = valid && (off_region + region_bytes <= a.slot_bytes);
+  uint8_t *slot = lds + q * a.slot_bytes;
+  uint8_t *xs = slot, *ys = slot + Lr;
+  uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + off_x2y);
+  int32_t *carry = reinterpret_cast<int32_t *>(slot + off_carry);
+  uint8_t *mv = slot + off_region;
+  int2 *xi_st = reinterpret_cast<int2 *>(slot + off_region);     // overlays the moves after traceback
+  uint16_t *ring_st = reinterpret_cast<uint16_t *>(slot + off_region + 8 * (Lr + Lc + 1));
+
+  unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
+  if (valid) {
+    const uint8_t *src = a.b.sym + o0;
+    for (int i = g; i < Lr + Lc; i += G) slot[i] = src[i];
+  }
+  __syncthreads();
+  PHASE_STAMP(0);
+
+  // wave-uniform loop bounds
+  int tmax = valid ? Lr + G - 1 : 0, nsmax = valid ? ns : 0;
+  for (int d = G; d < 64; d <<= 1) {
+    tmax = max(tmax, __shfl_xor(tmax, d));
+    nsmax = max(nsmax, __shfl_xor(nsmax, d));
+  }
+  tmax = __builtin_amdgcn_readfirstlane(tmax);
+  nsmax = __builtin_amdgcn_readfirstlane(nsmax);
+
+  int score = kNeg;
+  const int gstar = ((Lc - 1) % RS) >> 2, kstar = (Lc - 1) & 3;
+  if (a.debug & 1) nsmax = 0;
+  for (int s = 0; s < nsmax; ++s) {
+    const bool sv = valid && s < ns;
+    const int ii0 = RS * s + 4 * g + 1;                    // first of this lane's 4 rows (1-based)
+    int yl[4], S[4], Ex[4], Ey[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ii = ii0 + k;
+      yl[k] = (sv && ii <= Lc) ? ys[ii - 1] : 255;
+      S[k] = -(kp.open_y + (ii - 1) * kp.ext_y);           // column -1: ii gap steps from the origin
+      Ex[k] = S[k] - kp.ext_x;
+      Ey[k] = S[k] - kp.ext_y;
+    }
+    int dg0 = (ii0 == 1) ? 0 : -(kp.open_y + (ii0 - 2) * kp.ext_y);   // cell (row above, column -1)
+    const bool wr_carry = sv && (s + 1 < ns) && g == G - 1;
+    int xl_next = (sv && g == 0 && Lr >= 1) ? xs[0] : 0;    // letter of column jj = t - g, fetched one step ahead
+    for (int t = 1; t <= tmax; ++t) {
+      // strip top border at column t (for lane 0 of the group), through the DPP `old` operand
+      int bS, bEy;
+      if (s == 0) { bS = -(kp.open_x + (t - 1) * kp.ext_x); bEy = bS - kp.ext_y; }
+      else {
+        const int c = (sv && t <= Lr) ? carry[t] : 0;
+        bS = c >> 1; bEy = bS - ((c & 1) ? kp.open_y : kp.ext_y);
+      }
+      const int upS = shift_in<G>(bS, S[3], g);
+      const int upEy = shift_in<G>(bEy, Ey[3], g);
+      const int jj = t - g;
+      const int xl = xl_next;
+      xl_next = (sv && jj >= 0 && jj < Lr) ? xs[jj] : 0;
+      if (sv && jj >= 1 && jj <= Lr) {
+        int diag = dg0, insY = upEy;
+        uint32_t mv8 = 0;
+        bool mlast = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int oldS = S[k];
+          const CellOut c = cell_1pred(diag, Ex[k], insY, xl == yl[k] ? kp.match : kp.mismatch);
+          S[k] = c.S;
+          Ex[k] = c.S - (c.m ? kp.open_x : kp.ext_x);
+          Ey[k] = c.S - (c.m ? kp.open_y : kp.ext_y);
+          mv8 |= ((c.nib & 1) | (c.nib >> 1)) << (2 * k);    // 2 bits: bit0 = x step, bit1 = y step
+          diag = oldS; insY = Ey[k]; mlast = c.m;
+        }
+        dg0 = upS;
+        mv[(s * Lr + (jj - 1)) * G + g] = (uint8_t)mv8;
+        if (wr_carry) carry[jj] = (S[3] << 1) | (mlast ? 1 : 0);
+      }
+    }
+    if (sv && s == ns - 1 && g == gstar) score = (kstar == 0) ? S[0] : (kstar == 1) ? S[1] : (kstar == 2) ? S[2] : S[3];
+    __syncthreads();
+  }
+
+  PHASE_STAMP(1);
+  // ---- traceback #1 + fusion #1: one lane per window ----
+  int n1 = 0, maxd = 1;
+  bool bad = false;
+  if (valid && g == gstar) a.b.score1[w] = score;
+  if (valid && g == 0 && !(a.debug & 2)) {
+    for (int j = 0; j < Lr; ++j) x2y[j] = (uint16_t)kNone16;
+    {
+      int x = Lr - 1, y = Lc - 1, guard = Lr + Lc + 2;
+      while (x >= 0 && y >= 0 && guard-- > 0) {
+        const int r = y % RS;
+        const uint32_t two = (mv[((y / RS) * Lr + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
+        const int xo = two & 1, yo = two >> 1;
+        if (xo && yo) x2y[x] = (uint16_t)y;
+        if (!xo && !yo) { bad = true; break; }
+        if (xo) --x;
+        if (yo) --y;
+      }
+    }
+    int n = 0, iy = 0, lastx = -1, lasty = -1;
+    auto emit = [&](int letter, int flags, int ring, int sa, int sb) {
+      int pp1, pp2 = (int)kNone16;
+      const int jj = n + 1;
+      if (sa < 0) pp1 = 0;
+      else if (flags & kFlagInitial) { pp1 = 0; pp2 = sa + 1; if (sb >= 0) bad = true; }
+      else { pp1 = sa + 1; if (sb >= 0) pp2 = sb + 1; }
+      if (pp1 > 0) maxd = max(maxd, jj - pp1);
+      if (pp2 != (int)kNone16 && pp2 > 0) maxd = max(maxd, jj - pp2);
+      xi_st[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
+      ring_st[n] = (uint16_t)ring;
+    };
+    for (int ix = 0; ix < Lr; ++ix) {
+      const int ay = x2y[ix];
+      const bool al = ay != (int)kNone16;
+      if (al)
+        while (iy < ay) {
+          emit(ys[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0), n, lasty, -1);
+          lasty = n; ++n; ++iy;
+        }
+      int fl = kFlagHasRef | (ix == 0 ? kFlagInitial : 0) | (ix == Lr - 1 ? kFlagFinal : 0);
+      int sa = lastx, sb = -1, ring = n;
+      if (al && iy < Lc) {
+        const int fy = kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0);
+        if (xs[ix] == ys[iy]) {
+          fl |= fy;
+          if (lasty >= 0 && lasty != lastx) { if (sa < 0) sa = lasty; else sb = lasty; }
+          emit(xs[ix], fl, n, sa, sb);
+          lastx = lasty = n; ++n; ++iy;
+          continue;
+        }
+        emit(ys[iy], fy, n, lasty, -1);
+        ring = n; lasty = n; ++n; ++iy;
+      }
+      emit(xs[ix], fl, ring, sa, sb);
+      lastx = n; ++n;
+    }
+    while (iy < Lc) {
+      emit(ys[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0), n, lasty, -1);
+      lasty = n; ++n; ++iy;
+    }
+    n1 = n;
+  }
+  __syncthreads();
+  PHASE_STAMP(2);
+  // ---- coalesced copy-out of the graph by the window's 16 lanes ----
+  n1 = __shfl(n1, lane & ~(G - 1));
+  if (valid) {
+    const int64_t nb = o0 + w;
+    int2 *gx = a.b.xinfo + nb;
+    uint16_t *gr = a.b.ring1 + nb;
+    for (int i = 1 + g; i <= n1; i += G) gx[i] = xi_st[i];
+    for (int i = g; i < n1; i += G) gr[i] = ring_st[i];
+    if (g == 0) {
+      a.b.n1[w] = n1;
+      const int need = maxd + 2;
+      a.b.cls[w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 16 ? 0x80 : 0));   // bit 7: too deep for k_fused_b's ring
+      if (need > 512) a.b.status[w] = 2;
+      if (bad) a.b.status[w] = 3;
+      a.done_a[w] = 1;
+    }
+  }
+  PHASE_STAMP(3);
+  if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 4, 1ull);
+}
+
+// ---------------------------------------------------------------- k_fused_b ---
+// Alignment #2 on the PO graph of (ref + cor).  A node has <= 2 DP predecessors at
+// any distance; the common case (one predecessor, the previous node) is served from
+// registers, everything else from a 16-deep LDS ring indexed by time that holds each
+// lane's four cells of the last 16 steps as 16-bit (score << 1 | came-from-match).
+
+constexpr int kRingDepth = 16;       // time slots
+constexpr int kRingSlots = 18;       // + slot 16: each lane's column -1 cells, slot 17: "no predecessor"
+constexpr int kNeg16 = -8192;        // score of the "no predecessor" cells (below any 16-bit-eligible score)
+
+__device__ __forceinline__ int cell16_S(int c) { return c >> 1; }
+
+template <int G>
+__global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
+{
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int NW = 64 / G, RS = 4 * G;     // windows per wave, rows per strip
+  const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
+  const KParams kp = a.b.kp;
+  const int64_t li = NW * (int64_t)blockIdx.x + q;
+  bool valid = li < a.nlist;
+  const uint32_t w = valid ? a.list[li] : 0;
+  valid = valid && a.b.status[w] == 0 && a.done_a[w] != 0 && a.b.cls[w] == 0;
+  int64_t o0 = 0, o2 = 0;
+  int n1 = 0, Lu = 0;
+  if (valid) {
+    o0 = a.b.off[3 * (int64_t)w];
+    o2 = a.b.off[3 * (int64_t)w + 2];
+    Lu = (int)(a.b.off[3 * (int64_t)w + 3] - o2);
+    n1 = a.b.n1[w];
+  }
+  const int ns = (Lu + RS - 1) / RS;
+  // slot: [unc symbols][xinfo int2[n1+1]][ring1 u16[n1]][x2y u16[n1]][bnd0 i32[n1+1]][bnd1 i32[n1+1] if ns>1][region]
+  const int off_xi = align_up(Lu, 8);
+  const int off_r1 = off_xi + 8 * (n1 + 1);
+  const int off_x2y = off_r1 + align_up(2 * n1, 4);
+  const int off_b0 = off_x2y + align_up(2 * n1, 4);
+  const int off_b1 = off_b0 + 4 * (n1 + 1);
+  const int off_region = align_up(off_b1 + (ns > 1 ? 4 * (n1 + 1) : 0), 8);
+  const int region_bytes = max(ns * n1 * 2 * G, 3 * (n1 + Lu) + 8);
+  const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
+  valid = valid && (off_region + region_bytes <= a.slot_bytes) && (maxpen * (n1 + Lu + 4) < 8000);
+  uint8_t *slot = lds + 64 * 8 * kRingSlots + q * a.slot_bytes;
+  uint2 *ring = reinterpret_cast<uint2 *>(lds);                 // [kRingDepth][64] x 4 cells of 16 bits
+  const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(lds);
+  uint8_t *ys = slot;
+  int2 *xinfo = reinterpret_cast<int2 *>(slot + off_xi);
+  uint16_t *ring1 = reinterpret_cast<uint16_t *>(slot + off_r1);
+  uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + off_x2y);
+  int32_t *bnd0 = reinterpret_cast<int32_t *>(slot + off_b0);
+  int32_t *bnd1 = reinterpret_cast<int32_t *>(slot + off_b1);
+  uint16_t *mv = reinterpret_cast<uint16_t *>(slot + off_region);
+  uint8_t *cols_st = slot + off_region;                          // overlays the moves after traceback
+
+  unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
+  if (valid) {
+    const int64_t nb = o0 + w;
+    const uint8_t *sy = a.b.sym + o2;
+    for (int i = g; i < Lu; i += G) ys[i] = sy[i];
+    for (int i = 1 + g; i <= n1; i += G) xinfo[i] = a.b.xinfo[nb + i];
+    for (int i = g; i < n1; i += G) ring1[i] = a.b.ring1[nb + i];
+  }
+  __syncthreads();
+  // virtual row -1 over the graph (align_lpo_po2.c:275-286): gaps along x from the origin
+  if (valid && g == 0) {
+    bnd0[0] = 1;                                               // score 0, origin counts as "open"
+    for (int jj = 1; jj <= n1; ++jj) {
+      const uint32_t pl = (uint32_t)xinfo[jj].x;
+      const int pp1 = pl & 0xFFFF, pp2 = pl >> 16;
+      int r = cell16_S(bnd0[pp1]) - (pp1 == 0 ? kp.open_x : kp.ext_x);
+      if (pp2 != (int)kNone16) r = max(r, cell16_S(bnd0[pp2]) - (pp2 == 0 ? kp.open_x : kp.ext_x));
+      bnd0[jj] = r << 1;
+    }
+  }
+  __syncthreads();
+
+  PHASE_STAMP(8);
+  int tmax = valid ? n1 + G - 1 : 0, nsmax = valid ? ns : 0;
+  for (int d = G; d < 64; d <<= 1) {
+    tmax = max(tmax, __shfl_xor(tmax, d));
+    nsmax = max(nsmax, __shfl_xor(nsmax, d));
+  }
+  tmax = __builtin_amdgcn_readfirstlane(tmax);
+  nsmax = __builtin_amdgcn_readfirstlane(nsmax);
+
+  int best = kNeg, bestx = -1;
+  const int gstar = ((Lu - 1) % RS) >> 2, kstar = (Lu - 1) & 3;
+  if (a.debug & 1) nsmax = 0;
+  for (int s = 0; s < nsmax; ++s) {
+    const bool sv = valid && s < ns;
+    const int32_t *bcur = (s & 1) ? bnd1 : bnd0;
+    int32_t *bnext = (s & 1) ? bnd0 : bnd1;
+    const int ii0 = RS * s + 4 * g + 1;
+    int yl[4], S[4], M[4], Ey[4], colS[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ii = ii0 + k;
+      yl[k] = (sv && ii <= Lu) ? ys[ii - 1] : 255;
+      colS[k] = -(kp.open_y + (ii - 1) * kp.ext_y);
+      S[k] = colS[k]; M[k] = 0;
+      Ey[k] = S[k] - kp.ext_y;
+    }
+    {
+      const uint32_t p01 = (uint32_t)((colS[0] << 1) & 0xFFFF) | ((uint32_t)(colS[1] << 1) << 16);
+      const uint32_t p23 = (uint32_t)((colS[2] << 1) & 0xFFFF) | ((uint32_t)(colS[3] << 1) << 16);
+      ring[16 * 64 + lane] = make_uint2(p01, p23);
+      const uint32_t ng = (uint32_t)((kNeg16 << 1) & 0xFFFF) | ((uint32_t)(kNeg16 << 1) << 16);
+      ring[17 * 64 + lane] = make_uint2(ng, ng);
+    }
+    const bool wr_carry = sv && (s + 1 < ns) && g == G - 1;
+    const bool last_strip_row = sv && s == ns - 1 && g == gstar;
+    int2 xi_next = (sv && g == 0 && n1 >= 1) ? xinfo[1] : make_int2(0, 0);
+    for (int t = 1; t <= tmax; ++t) {
+      const int bc = (sv && t <= n1) ? bcur[t] : 0;
+      const int bS = bc >> 1, bEy = bS - ((bc & 1) ? kp.open_y : kp.ext_y);
+      const int upEy = shift_in<G>(bEy, Ey[3], g);
+      const int jj = t - g;
+      const int2 xi = xi_next;
+      xi_next = (sv && jj >= 0 && jj < n1) ? xinfo[jj + 1] : make_int2(0, 0);
+      const bool act = sv && jj >= 1 && jj <= n1;
+      const int pp1 = xi.x & 0xFFFF, pp2 = (int)((uint32_t)xi.x >> 16);
+      const bool has2 = act && pp2 != (int)kNone16;
+      const int lm1 = (lane - 1) & 63;
+      // ---- predecessor cells.  Own four cells at column pp: this lane's ring slot of
+      // d = jj - pp steps ago; the cell above them: lane-1's slot one step earlier (the strip
+      // border array for the group's first lane).  The virtual start column lives in slot 16,
+      // a missing second predecessor reads the very negative cells of slot 17: no value selects. ----
+      const int ppa = act ? pp1 : 0;
+      const int sa = (ppa == 0) ? 16 : ((t - (jj - ppa)) & (kRingDepth - 1));
+      const int sat = (ppa == 0) ? 16 : ((t - (jj - ppa) - 1) & (kRingDepth - 1));
+      const int sb = !has2 ? 17 : (pp2 == 0) ? 16 : ((t - (jj - pp2)) & (kRingDepth - 1));
+      const int sbt = !has2 ? 17 : (pp2 == 0) ? 16 : ((t - (jj - pp2) - 1) & (kRingDepth - 1));
+      const uint2 c1 = ring[sa * 64 + lane];
+      const uint2 c2 = ring[sb * 64 + lane];
+      const int r1 = (int16_t)ring16[(sat * 64 + lm1) * 4 + 3];
+      const int r2 = (int16_t)ring16[(sbt * 64 + lm1) * 4 + 3];
+      const int b1 = bcur[sv ? ppa : 0], b2 = bcur[has2 ? pp2 : 0];
+      if (act) {
+        const int xl = xi.y & 0xFF;
+        const int d1top = ((g == 0) ? b1 : r1) >> 1;
+        const int d2top = has2 ? (((g == 0) ? b2 : r2) >> 1) : kNeg16;
+        int o1S[4], o1M[4], o2S[4], o2M[4];
+        {
+          const int e0 = (int16_t)(c1.x & 0xFFFF), e1 = (int16_t)(c1.x >> 16), e2 = (int16_t)(c1.y & 0xFFFF), e3 = (int16_t)(c1.y >> 16);
+          o1S[0] = e0 >> 1; o1S[1] = e1 >> 1; o1S[2] = e2 >> 1; o1S[3] = e3 >> 1;
+          o1M[0] = e0 & 1; o1M[1] = e1 & 1; o1M[2] = e2 & 1; o1M[3] = e3 & 1;
+        }
+        {
+          const int e0 = (int16_t)(c2.x & 0xFFFF), e1 = (int16_t)(c2.x >> 16), e2 = (int16_t)(c2.y & 0xFFFF), e3 = (int16_t)(c2.y >> 16);
+          o2S[0] = e0 >> 1; o2S[1] = e1 >> 1; o2S[2] = e2 >> 1; o2S[3] = e3 >> 1;
+          o2M[0] = e0 & 1; o2M[1] = e1 & 1; o2M[2] = e2 & 1; o2M[3] = e3 & 1;
+        }
+        // ---- the four cells, top to bottom ----
+        int insY = upEy, dt1 = d1top, dt2 = d2top;
+        uint32_t mv16 = 0;
+        int nS[4], nM[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int cx1 = o1S[k] - (o1M[k] ? kp.open_x : kp.ext_x);
+          const int cx2 = o2S[k] - (o2M[k] ? kp.open_x : kp.ext_x);
+          const bool px2 = cx2 > cx1;                         // first maximum wins (:361-371)
+          const int insX = max(cx1, cx2);
+          const bool pm2 = dt2 > dt1;                         // (:348-357)
+          const int mat = max(dt1, dt2) + (xl == yl[k] ? kp.match : kp.mismatch);
+          const int mx = max(insX, insY);
+          const bool m = mat > mx;
+          const bool xw = insX > insY;
+          const int Sn = max(mat, mx);
+          // x-ordinal 1/2 (+ y-ordinal bit 2 on a match), or the lone y step
+          const uint32_t second = (m ? pm2 : px2) ? 1u : 0u;
+          const uint32_t nib = m ? (kMoveX1 | kMoveY) + second : (xw ? kMoveX1 + second : (uint32_t)kMoveY);
+          mv16 |= nib << (4 * k);
+          nS[k] = Sn; nM[k] = m ? 1 : 0;
+          insY = Sn - (m ? kp.open_y : kp.ext_y);
+          dt1 = o1S[k]; dt2 = o2S[k];
+          Ey[k] = insY;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { S[k] = nS[k]; M[k] = nM[k]; }
+        const uint32_t p01 = (uint32_t)(((S[0] << 1) | M[0]) & 0xFFFF) | ((uint32_t)((S[1] << 1) | M[1]) << 16);
+        const uint32_t p23 = (uint32_t)(((S[2] << 1) | M[2]) & 0xFFFF) | ((uint32_t)((S[3] << 1) | M[3]) << 16);
+        ring[(t & (kRingDepth - 1)) * 64 + lane] = make_uint2(p01, p23);
+        mv[(s * n1 + (jj - 1)) * G + g] = (uint16_t)mv16;
+        if (wr_carry) bnext[jj] = (S[3] << 1) | M[3];
+        if (last_strip_row && ((xi.y >> 8) & kFlagFinal)) {
+          const int sv2 = (kstar == 0) ? S[0] : (kstar == 1) ? S[1] : (kstar == 2) ? S[2] : S[3];
+          if (sv2 > best) { best = sv2; bestx = jj - 1; }      // ties keep the smaller column (:410-417)
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (wr_carry) bnext[0] = (-(kp.open_y + (RS * (s + 1) - 1) * kp.ext_y)) << 1;   // column -1 of the carried row
+    __syncthreads();
+  }
+
+  PHASE_STAMP(9);
+  // ---- traceback #2 + fusion #2 + MSA columns: one lane per window ----
+  best = __shfl(best, (lane & ~(G - 1)) | gstar);
+  bestx = __shfl(bestx, (lane & ~(G - 1)) | gstar);
+  int ncol = 0;
+  bool bad = false;
+  if (valid && g == 0 && !(a.debug & 2)) {
+    for (int j = 0; j < n1; ++j) x2y[j] = (uint16_t)kNone16;
+    {
+      int x = bestx, y = Lu - 1, guard = n1 + Lu + 2;
+      while (x >= 0 && y >= 0 && guard-- > 0) {
+        const int r = y % RS;
+        const uint32_t nib = (mv[((y / RS) * n1 + x) * G + (r >> 2)] >> (4 * (r & 3))) & 15u;
+        const int xo = nib & 3, yo = nib >> 2;
+        if (xo && yo) x2y[x] = (uint16_t)y;
+        if (!xo && !yo) { bad = true; break; }
+        if (xo) {
+          const uint32_t pl = (uint32_t)xinfo[x + 1].x;
+          x = ((xo == 1) ? (int)(pl & 0xFFFF) : (int)(pl >> 16)) - 1;
+        }
+        if (yo) --y;
+      }
+    }
+    const uint8_t *chr = a.b.tab->chr;
+    int col = 0, prev_ring = 0;
+    uint8_t c0 = '.', c1 = '.', c2 = '.';
+    auto flush = [&]() { cols_st[3 * col] = c0; cols_st[3 * col + 1] = c1; cols_st[3 * col + 2] = c2; };
+    auto place = [&](int ring_id, int letter, bool r, bool c, bool u) {
+      if (ring_id != prev_ring) { flush(); ++col; c0 = c1 = c2 = '.'; prev_ring = ring_id; }
+      const uint8_t ch = chr[letter];
+      if (r) c0 = ch;
+      if (c) c1 = ch;
+      if (u) c2 = ch;
+    };
+    int n = 0, iy = 0, blk_old = -1, blk_new = -1;
+    for (int ix = 0; ix < n1; ++ix) {
+      const int r0 = ring1[ix];
+      if (r0 != blk_old) { blk_old = r0; blk_new = -1; }
+      for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
+        const int ay = x2y[k];
+        if (ay != (int)kNone16) {
+          while (iy < ay) { place(n, ys[iy], false, false, true); ++n; ++iy; }
+          break;
+        }
+      }
+      const int xv = xinfo[ix + 1].y;
+      const int letter = xv & 0xFF, fl = xv >> 8;
+      bool fused = false;
+      if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
+        if (letter == ys[iy]) fused = true;
+        else {
+          if (blk_new < 0) blk_new = n;
+          place(blk_new, ys[iy], false, false, true);
+          ++n;
+        }
+        ++iy;
+      }
+      if (blk_new < 0) blk_new = n;
+      place(blk_new, letter, (fl & kFlagHasRef) != 0, (fl & kFlagHasCor) != 0, fused);
+      ++n;
+    }
+    while (iy < Lu) { place(n, ys[iy], false, false, true); ++n; ++iy; }
+    flush();
+    ncol = col + 1;
+  }
+  __syncthreads();
+  PHASE_STAMP(10);
+  ncol = __shfl(ncol, lane & ~(G - 1));
+  if (valid) {
+    uint8_t *gc = a.b.cols + 3 * o0;
+    for (int i = g; i < 3 * ncol; i += G) gc[i] = cols_st[i];
+    if (g == 0) {
+      a.b.ncol[w] = ncol;
+      a.b.score2[w] = best;
+      a.b.bx2[w] = bestx;
+      if (bad) a.b.status[w] = 3;
+      a.done_b[w] = 1;
+    }
+  }
+  PHASE_STAMP(11);
+  if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 12, 1ull);
+}
+
+// ---------------------------------------------------------------- launcher ---
+
+template <int G>
+static int launch_a_t(const FusedArgs &a, hipStream_t st)
+{
+  constexpr int NW = 64 / G;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_a<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 256) != hipSuccess)
+      return -1;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_fused_a<G>, dim3((unsigned)((a.nlist + NW - 1) / NW)), dim3(64), NW * a.slot_bytes, st, a);
+  return 0;
+}
+
+template <int G>
+static int launch_b_t(const FusedArgs &a, hipStream_t st)
+{
+  constexpr int NW = 64 / G;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_b<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 256) != hipSuccess)
+      return -1;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_fused_b<G>, dim3((unsigned)((a.nlist + NW - 1) / NW)), dim3(64),
+                     NW * a.slot_bytes + 64 * 8 * kRingSlots, st, a);
+  return 0;
+}
+
+int launch_fused_a(const FusedArgs &a, int G, hipStream_t st)
+{
+  if (a.nlist <= 0) return 0;
+  return G == 16 ? launch_a_t<16>(a, st) : G == 32 ? launch_a_t<32>(a, st) : launch_a_t<64>(a, st);
+}
+
+int launch_fused_b(const FusedArgs &a, int G, hipStream_t st)
+{
+  if (a.nlist <= 0) return 0;
+  return G == 16 ? launch_b_t<16>(a, st) : G == 32 ? launch_b_t<32>(a, st) : launch_b_t<64>(a, st);
+}
+
+}  // namespace elector

@@ -23,8 +23,22 @@ void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st);
 void launch_fuse1(const BatchArgs &a, hipStream_t st);
 void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st);
 void launch_fuse2(const BatchArgs &a, hipStream_t st);
+void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uint8_t *done_b, int64_t *mv2,
+                   unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, hipStream_t st);
 void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
                  uint8_t *rows, int64_t n, hipStream_t st);
+struct FusedArgs {
+  BatchArgs b;
+  const uint32_t *list;
+  int64_t nlist;
+  int slot_bytes;
+  uint8_t *done_a;
+  uint8_t *done_b;
+  int32_t *rowinit;
+  int debug;
+};
+int launch_fused_a(const FusedArgs &a, int G, hipStream_t st);
+int launch_fused_b(const FusedArgs &a, int G, hipStream_t st);
 }  // namespace elector
 
 using namespace elector;
@@ -269,9 +283,14 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_xinfo, &c->d_ring1, &c->d_map16, &c->d_carry, &c->d_moves, &c->d_n1, &c->d_cls,
                     &c->d_score1, &c->d_score2, &c->d_bx2, &c->d_bases, &c->d_cols, &c->d_ncol, &c->d_status,
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
-                    &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_scroff};
+                    &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_scroff,
+                    &c->d_list, &c->d_done, &c->d_rowinit};
   for (DevBuf *b : bufs) b->release();
   c->h_meta.release();
+  if (c->aux_ready) {
+    for (int k = 0; k < elector_ctx::kAux; ++k) { (void)hipStreamDestroy(c->aux[k]); (void)hipEventDestroy(c->aux_done[k]); }
+    (void)hipEventDestroy(c->fork);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -292,23 +311,6 @@ extern "C" int elector_ctx_timing_enable(elector_ctx *c, int on)
   if (!c) return ELECTOR_E_INVAL;
   c->timing = on != 0;
   return ELECTOR_OK;
-}
-
-static void span_begin(elector_ctx *c, int kind)
-{
-  if (!c->timing) return;
-  TimedSpan s;
-  s.kind = kind;
-  if (hipEventCreate(&s.a) != hipSuccess) return;
-  if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
-  (void)hipEventRecord(s.a, c->stream);
-  c->spans.push_back(s);
-}
-
-static void span_end(elector_ctx *c)
-{
-  if (!c->timing || c->spans.empty()) return;
-  (void)hipEventRecord(c->spans.back().b, c->stream);
 }
 
 static void spans_collect(elector_ctx *c)
@@ -356,9 +358,46 @@ extern "C" int elector_ctx_last_po_sizes(elector_ctx *c, int64_t n, int32_t *po_
 
 // ------------------------------------------------------------------ batch ---
 
-// Moves scratch is the only part of the workspace that grows faster than the
-// input; windows are processed in chunks whose scratch stays below this.
+// Moves scratch of the generic kernels is the only part of the workspace that
+// grows faster than the input; generic-path windows are processed in chunks whose
+// scratch stays below this, and the device-side bump allocator (windows the fused
+// kernels hand back) gets a fixed budget on top.
 static const int64_t kMovesBudgetDwords = (int64_t)3 << 28;   // 3 GiB
+static const int64_t kBumpBudgetDwords = (int64_t)1 << 28;    // 1 GiB
+
+// fused-kernel launch classes: (lanes per window, LDS slot bytes per window)
+static const int kBins = 20;
+static const int kBinG[kBins] = {16, 16, 16, 16, 16, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64};
+static const int kSlot[kBins] = {2048, 3072, 4096, 6144, 8192, 4096, 6144, 8192, 12288, 16384, 24576,
+                                 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072};
+
+static int ensure_streams(elector_ctx *c)
+{
+  if (c->aux_ready) return 0;
+  for (int k = 0; k < elector_ctx::kAux; ++k) {
+    if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess) return ELECTOR_E_HIP;
+    if (hipEventCreateWithFlags(&c->aux_done[k], hipEventDisableTiming) != hipSuccess) return ELECTOR_E_HIP;
+  }
+  if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) return ELECTOR_E_HIP;
+  c->aux_ready = true;
+  return 0;
+}
+
+static void timed_begin(elector_ctx *c, int kind, hipStream_t st)
+{
+  if (!c->timing) return;
+  TimedSpan s;
+  s.kind = kind;
+  if (hipEventCreate(&s.a) != hipSuccess) return;
+  if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
+  (void)hipEventRecord(s.a, st);
+  c->spans.push_back(s);
+}
+static void timed_end(elector_ctx *c, hipStream_t st)
+{
+  if (!c->timing || c->spans.empty()) return;
+  (void)hipEventRecord(c->spans.back().b, st);
+}
 
 static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *off,
                             uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status, int32_t *d_scores)
@@ -366,74 +405,130 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   if (n == 0) return ELECTOR_OK;
   const int64_t total = off[3 * n];
   if (off[0] != 0 || total < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
+  const bool use_fused = !c->gen && !std::getenv("ELECTOR_NO_FUSED");
 
-  // ---- host metadata: status, moves offsets, processing order ----
-  int rc = c->h_meta.ensure((size_t)n * (4 + 8 + 8 + 4));
+  // ---- host metadata ----
+  int rc = c->h_meta.ensure((size_t)n * (4 + 8 + 8 + 4 + 4) + 64);
   if (rc) return fail(c, rc, "pinned metadata");
   int32_t *h_status = c->h_meta.as<int32_t>();
   int64_t *h_mv1 = reinterpret_cast<int64_t *>(h_status + n + (n & 1));
   int64_t *h_mv2 = h_mv1 + n;
-  uint32_t *h_perm = reinterpret_cast<uint32_t *>(h_mv2 + n);
+  uint32_t *h_generic = reinterpret_cast<uint32_t *>(h_mv2 + n);   // generic-path windows, processing order
+  uint32_t *h_list = h_generic + n;                                // fused classes, concatenated
 
-  struct Chunk { int64_t w0, w1, dwords; };
+  // window sizes -> status, coarse size key (counting sort, largest first), launch class
+  constexpr int NB = 256;
+  std::vector<int8_t> bin((size_t)n, -1);
+  int64_t key_cnt[NB + 1] = {0}, bin_cnt[kBins] = {0}, n_generic = 0;
+  auto key = [&](int64_t w) {
+    const int64_t m = std::max(off[3 * w + 1] - off[3 * w], off[3 * w + 3] - off[3 * w + 2]);
+    int k = (int)(m >> 3);
+    if (k >= NB) k = NB - 1;
+    return NB - 1 - k;
+  };
+  for (int64_t w = 0; w < n; ++w) {
+    const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
+                  lu = off[3 * w + 3] - off[3 * w + 2];
+    int st = ELECTOR_W_OK;
+    if (lr < 0 || lc < 0 || lu < 0) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
+    if (lr == 0 || lc == 0 || lu == 0) st = ELECTOR_W_EMPTY;
+    else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ) st = ELECTOR_W_TOOLONG;
+    h_status[w] = st;
+    h_mv1[w] = h_mv2[w] = -1;
+    if (!st && use_fused) {
+      const int rows = (int)std::max(lc, lu), gmin = rows <= 64 ? 16 : rows <= 128 ? 32 : 64;
+      for (int b = 0; b < kBins; ++b) {
+        if (kBinG[b] < gmin) continue;
+        const int G = kBinG[b];
+        // one class for both fused kernels; |PO| is not known yet: typical growth estimate, windows
+        // whose graph turns out larger are handed back by the device (k_left_b)
+        const int need = std::max(fused_a_slot_need((int)lr, (int)lc, G),
+                                  fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G));
+        if (need <= kSlot[b]) { bin[(size_t)w] = (int8_t)b; break; }
+      }
+    }
+    if (bin[(size_t)w] >= 0) bin_cnt[bin[(size_t)w]]++;
+    else ++n_generic;                               // includes failed windows: k_fuse2 zeroes their ncol
+    key_cnt[key(w) + 1]++;
+  }
+  for (int k = 0; k < NB; ++k) key_cnt[k + 1] += key_cnt[k];
+  // stable placement in descending size order, per destination list
+  int64_t bin_first[kBins + 1];
+  bin_first[0] = 0;
+  for (int b = 0; b < kBins; ++b) bin_first[b + 1] = bin_first[b] + bin_cnt[b];
+  {
+    std::vector<uint32_t> order((size_t)n);
+    for (int64_t w = 0; w < n; ++w) order[(size_t)key_cnt[key(w)]++] = (uint32_t)w;
+    int64_t pos[kBins], gpos = 0;
+    for (int b = 0; b < kBins; ++b) pos[b] = bin_first[b];
+    for (int64_t k = 0; k < n; ++k) {
+      const uint32_t w = order[(size_t)k];
+      const int b = bin[w];
+      if (b >= 0) h_list[pos[b]++] = w;
+      else h_generic[gpos++] = w;
+    }
+  }
+  if (std::getenv("ELECTOR_DEBUG_BINS")) {
+    std::fprintf(stderr, "[elector] n=%lld generic=%lld classes:", (long long)n, (long long)n_generic);
+    for (int b = 0; b < kBins; ++b) std::fprintf(stderr, " G%d/%d:%lld", kBinG[b], kSlot[b], (long long)bin_cnt[b]);
+    std::fprintf(stderr, "\n");
+  }
+  // moves scratch of the generic-path windows, in chunks
+  struct Chunk { int64_t k0, k1, dwords; };
   std::vector<Chunk> chunks;
   {
-    int64_t w0 = 0, acc = 0;
-    for (int64_t w = 0; w < n; ++w) {
-      const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
-                    lu = off[3 * w + 3] - off[3 * w + 2];
-      int st = ELECTOR_W_OK;
-      if (lr < 0 || lc < 0 || lu < 0) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
-      if (lr == 0 || lc == 0 || lu == 0) st = ELECTOR_W_EMPTY;
-      else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ) st = ELECTOR_W_TOOLONG;
-      h_status[w] = st;
+    int64_t k0 = 0, acc = 0;
+    for (int64_t k = 0; k < n_generic; ++k) {
+      const int64_t w = h_generic[k];
       int64_t d1 = 0, d2 = 0;
-      if (!st) {
+      if (!h_status[w]) {
+        const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
+                      lu = off[3 * w + 3] - off[3 * w + 2];
         d1 = (int64_t)n_strips((int)lc) * mv_tw((int)lr) * 64;
         d2 = (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64;   // |PO| <= Lr + Lc
       }
-      if (acc + d1 + d2 > kMovesBudgetDwords && w > w0) { chunks.push_back({w0, w, acc}); w0 = w; acc = 0; }
+      if (acc + d1 + d2 > kMovesBudgetDwords && k > k0) { chunks.push_back({k0, k, acc}); k0 = k; acc = 0; }
       h_mv1[w] = acc; acc += d1;
       h_mv2[w] = acc; acc += d2;
     }
-    chunks.push_back({w0, n, acc});
+    chunks.push_back({k0, n_generic, acc});
   }
   int64_t max_dwords = 0;
   for (auto &ch : chunks) max_dwords = std::max(max_dwords, ch.dwords);
-
-  // processing order inside each chunk: coarse counting sort, largest first
-  for (auto &ch : chunks) {
-    constexpr int NB = 256;
-    int64_t cnt[NB + 1] = {0};
-    auto key = [&](int64_t w) {
-      const int64_t m = std::max(off[3 * w + 1] - off[3 * w], off[3 * w + 3] - off[3 * w + 2]);
-      int k = (int)(m >> 3);
-      if (k >= NB) k = NB - 1;
-      return NB - 1 - k;                                   // descending size
-    };
-    for (int64_t w = ch.w0; w < ch.w1; ++w) cnt[key(w) + 1]++;
-    for (int k = 0; k < NB; ++k) cnt[k + 1] += cnt[k];
-    for (int64_t w = ch.w0; w < ch.w1; ++w) h_perm[ch.w0 + cnt[key(w)]++] = (uint32_t)w;
-  }
+  const int64_t bump_dwords = use_fused ? std::min<int64_t>(kBumpBudgetDwords, 64 + 16 * (total + 64 * n)) : 0;
 
   // ---- workspace ----
   const size_t nodes = (size_t)total + (size_t)n + 8;
-  rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_perm.ensure((size_t)n * 4) | c->d_mv1.ensure((size_t)n * 8) |
+  rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_perm.ensure((size_t)n * 4 + 64) | c->d_mv1.ensure((size_t)n * 8) |
        c->d_mv2.ensure((size_t)n * 8) | c->d_sym.ensure((size_t)total + 64) | c->d_xinfo.ensure(nodes * 8) |
        c->d_ring1.ensure(nodes * 2) | c->d_map16.ensure(nodes * 2) | c->d_carry.ensure(nodes * 4) |
-       c->d_moves.ensure((size_t)max_dwords * 4 + 1024) | c->d_n1.ensure((size_t)n * 4) | c->d_cls.ensure((size_t)n) |
-       c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) | c->d_bx2.ensure((size_t)n * 4);
+       c->d_moves.ensure((size_t)(max_dwords + bump_dwords) * 4 + 1024) | c->d_n1.ensure((size_t)n * 4) |
+       c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
+       c->d_bx2.ensure((size_t)n * 4) | c->d_list.ensure((size_t)2 * n * 4 + 64) | c->d_done.ensure((size_t)2 * n + 64) |
+       c->d_rowinit.ensure(4096);
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
+  if (use_fused && (rc = ensure_streams(c))) return fail(c, rc, "auxiliary streams");
 
   hipStream_t st = c->stream;
+  uint32_t *d_generic = c->d_perm.as<uint32_t>();
+  uint32_t *d_lists = c->d_list.as<uint32_t>();
+  uint32_t *d_leftb = d_lists + n;                 // device-built list for alignment #2 leftovers
+  uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n;
+  // device counters: [0] = leftover count (int32), [2..3] = bump allocator (u64)
+  int32_t *d_counters = reinterpret_cast<int32_t *>(c->d_rowinit.p);
   HIPCHK(c, hipMemcpyAsync(c->d_off.p, off, (size_t)(3 * n + 1) * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_perm.p, h_perm, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  if (n_generic) HIPCHK(c, hipMemcpyAsync(d_generic, h_generic, (size_t)n_generic * 4, hipMemcpyHostToDevice, st));
+  if (n - n_generic) HIPCHK(c, hipMemcpyAsync(d_lists, h_list, (size_t)(n - n_generic) * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_mv1.p, h_mv1, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)2 * n, st));
+  HIPCHK(c, hipMemsetAsync(d_counters, 0, 16, st));
+  if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 3072, st));
 
-  span_begin(c, 2);
+  timed_begin(c, 2, st);
   launch_symbolize(d_bases, c->d_sym.as<uint8_t>(), total, c->d_tab.as<DevTables>(), st);
+  timed_end(c, st);
 
   BatchArgs a;
   std::memset(&a, 0, sizeof a);
@@ -459,20 +554,89 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   a.liny = c->d_liny.as<int32_t>();
   a.tab = c->d_tab.as<DevTables>();
   a.kp = c->kp;
+  a.skip_a = d_done_a;
+  a.skip_b = d_done_b;
 
-  for (auto &ch : chunks) {
-    a.n = ch.w1 - ch.w0;
-    a.perm = c->d_perm.as<uint32_t>() + ch.w0;
-    if (c->timing) { span_end(c); span_begin(c, 0); }
-    launch_dp1(a, c->gen, st);
-    if (c->timing) { span_end(c); span_begin(c, 2); }
-    launch_fuse1(a, st);
-    if (c->timing) { span_end(c); span_begin(c, 1); }
+  // ---- fused classes: one stream per class chain (A then B), all concurrent ----
+  if (use_fused && n > n_generic) {
+    HIPCHK(c, hipEventRecord(c->fork, st));
+    int used = 0;
+    for (int b = 0; b < kBins; ++b) {
+      if (!bin_cnt[b]) continue;
+      hipStream_t sx = c->aux[used % elector_ctx::kAux];
+      if (used < elector_ctx::kAux) HIPCHK(c, hipStreamWaitEvent(sx, c->fork, 0));
+      ++used;
+      FusedArgs fa;
+      fa.b = a;
+      fa.list = d_lists + bin_first[b];
+      fa.nlist = bin_cnt[b];
+      fa.slot_bytes = kSlot[b];
+      fa.done_a = d_done_a;
+      fa.done_b = d_done_b;
+      fa.rowinit = reinterpret_cast<int32_t *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b);   // phase stamps (debug)
+      fa.debug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
+      timed_begin(c, 0, sx);
+      if (launch_fused_a(fa, kBinG[b], sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+      timed_end(c, sx);
+      timed_begin(c, 1, sx);
+      if (launch_fused_b(fa, kBinG[b], sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+      timed_end(c, sx);
+    }
+    for (int k = 0; k < std::min(used, (int)elector_ctx::kAux); ++k) {
+      HIPCHK(c, hipEventRecord(c->aux_done[k], c->aux[k]));
+    }
+    // generic alignment #1 for the host-routed windows runs on the main stream meanwhile
+    for (auto &ch : chunks) {
+      if (ch.k1 <= ch.k0) continue;
+      a.n = ch.k1 - ch.k0;
+      a.perm = d_generic + ch.k0;
+      a.count_ptr = nullptr;
+      timed_begin(c, 2, st);
+      launch_dp1(a, c->gen, st);
+      launch_fuse1(a, st);
+      timed_end(c, st);
+      if (chunks.size() > 1) {      // several chunks share the scratch: finish each one completely
+        a.mark_b = d_done_b;
+        for (int cls = 0; cls < 3; ++cls) launch_dp2(a, c->gen, cls, st);
+        launch_fuse2(a, st);
+        a.mark_b = nullptr;
+      }
+    }
+    for (int k = 0; k < std::min(used, (int)elector_ctx::kAux); ++k) HIPCHK(c, hipStreamWaitEvent(st, c->aux_done[k], 0));
+    // everything alignment #2 still owes: host-routed windows (single chunk) + windows handed back
+    a.n = n;
+    a.perm = nullptr;
+    a.count_ptr = nullptr;
+    timed_begin(c, 2, st);
+    launch_left_b(a, d_leftb, d_counters, d_done_b, c->d_mv2.as<int64_t>(),
+                  reinterpret_cast<unsigned long long *>(d_counters + 2), (unsigned long long)max_dwords,
+                  (unsigned long long)bump_dwords, st);
+    a.perm = d_leftb;
+    a.count_ptr = d_counters;
     for (int cls = 0; cls < 3; ++cls) launch_dp2(a, c->gen, cls, st);
-    if (c->timing) { span_end(c); span_begin(c, 2); }
     launch_fuse2(a, st);
+    timed_end(c, st);
+  } else {
+    // ---- generic path only (general scoring parameters, or fused kernels disabled) ----
+    for (auto &ch : chunks) {
+      if (ch.k1 <= ch.k0) continue;
+      a.n = ch.k1 - ch.k0;
+      a.perm = d_generic + ch.k0;
+      a.count_ptr = nullptr;
+      timed_begin(c, 0, st);
+      launch_dp1(a, c->gen, st);
+      timed_end(c, st);
+      timed_begin(c, 2, st);
+      launch_fuse1(a, st);
+      timed_end(c, st);
+      timed_begin(c, 1, st);
+      for (int cls = 0; cls < 3; ++cls) launch_dp2(a, c->gen, cls, st);
+      timed_end(c, st);
+      timed_begin(c, 2, st);
+      launch_fuse2(a, st);
+      timed_end(c, st);
+    }
   }
-  span_end(c);
   HIPCHK(c, hipGetLastError());
 
   if (d_scores) {
@@ -481,6 +645,19 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     HIPCHK(c, hipMemcpy2DAsync(d_scores + 1, 8, c->d_score2.p, 4, 4, (size_t)n, hipMemcpyDeviceToDevice, st));
   }
   c->last_n = n;
+  if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 4)) {
+    (void)hipStreamSynchronize(st);
+    unsigned long long hs[384];
+    (void)hipMemcpy(hs, c->d_rowinit.as<uint8_t>() + 1024, sizeof hs, hipMemcpyDeviceToHost);
+    for (int b = 0; b < 12; ++b) {
+      const unsigned long long *p = hs + 32 * b;
+      if (!p[4]) continue;
+      std::fprintf(stderr, "[elector] class %d G%d/%d  A waves %llu: stage %.0f dp %.0f serial %.0f out %.0f | B waves %llu: stage %.0f dp %.0f serial %.0f out %.0f  (cycles per wave)\n",
+                   b, kBinG[b], kSlot[b], p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],
+                   p[12], p[12] ? (double)p[8] / p[12] : 0, p[12] ? (double)p[9] / p[12] : 0, p[12] ? (double)p[10] / p[12] : 0,
+                   p[12] ? (double)p[11] / p[12] : 0);
+    }
+  }
   return ELECTOR_OK;
 }
 

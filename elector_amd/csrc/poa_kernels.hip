@@ -96,16 +96,9 @@ __global__ void __launch_bounds__(256) k_symbolize(const uint8_t *__restrict__ i
 // the `up` received one step earlier.
 
 template <bool GEN>
-__global__ void __launch_bounds__(64) k_dp1(BatchArgs a)
+__device__ void dp1_window(const BatchArgs &a, const Scoring<GEN> &sc, const uint32_t w, const int lane)
 {
-  __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
-  const int lane = threadIdx.x;
-  load_tables<GEN>(lds_tab, a.tab, lane);
-  Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
-
-  if ((int64_t)blockIdx.x >= a.n) return;
-  const uint32_t w = a.perm[blockIdx.x];
-  if (a.status[w]) return;
+  if (a.status[w] || (a.skip_a && a.skip_a[w])) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2];
   const int Lx = (int)(o1 - o0), Ly = (int)(o2 - o1);
   const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
@@ -164,6 +157,24 @@ __global__ void __launch_bounds__(64) k_dp1(BatchArgs a)
   }
 }
 
+// number of windows in the launch's list: host value, or a device counter for
+// lists built on the device
+__device__ __forceinline__ int64_t list_count(const BatchArgs &a)
+{
+  return a.count_ptr ? (int64_t)*a.count_ptr : a.n;
+}
+
+template <bool GEN>
+__global__ void __launch_bounds__(64) k_dp1(BatchArgs a)
+{
+  __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
+  const int lane = threadIdx.x;
+  load_tables<GEN>(lds_tab, a.tab, lane);
+  Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
+  const int64_t cnt = list_count(a);
+  for (int64_t i = blockIdx.x; i < cnt; i += gridDim.x) dp1_window<GEN>(a, sc, a.perm[i], lane);
+}
+
 // ------------------------------------------------------------------ k_dp2 ---
 // Alignment #2: x = PO graph of (ref + cor), y = uncorrected (linear).  A node
 // has at most two DP predecessors (one per source read, or the virtual start
@@ -173,17 +184,10 @@ __global__ void __launch_bounds__(64) k_dp1(BatchArgs a)
 // that.  Bank = lane, so ring accesses never conflict.
 
 template <bool GEN, int D>
-__global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls)
+__device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring, const int cls, const uint32_t w,
+                           const int lane)
 {
-  __shared__ int ring[D * 64];
-  __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
-  const int lane = threadIdx.x;
-  load_tables<GEN>(lds_tab, a.tab, lane);
-  Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
-
-  if ((int64_t)blockIdx.x >= a.n) return;
-  const uint32_t w = a.perm[blockIdx.x];
-  if (a.status[w] || a.cls[w] != cls) return;
+  if (a.status[w] || (a.cls[w] & 3) != cls || (a.skip_b && a.skip_b[w])) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
   const int Lx = a.n1[w], Ly = (int)(o3 - o2);
   const uint8_t *ys = a.sym + o2;
@@ -283,6 +287,21 @@ __global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls)
   if (lane == (Ly - 1) % kStripRows + 1) { a.score2[w] = best; a.bx2[w] = bestx; }
 }
 
+template <bool GEN, int D>
+__global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls)
+{
+  __shared__ int ring[D * 64];
+  __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
+  const int lane = threadIdx.x;
+  load_tables<GEN>(lds_tab, a.tab, lane);
+  Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
+  const int64_t cnt = list_count(a);
+  for (int64_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+    dp2_window<GEN, D>(a, sc, ring, cls, a.perm[i], lane);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- k_fuse1 ---
 // One lane per window: trace alignment #1 back (align_lpo_po2.c:108-168) and
 // fuse the corrected read into the reference chain (lpo.c:413-463, 602-656).
@@ -316,12 +335,9 @@ struct NodeWriter {
   }
 };
 
-__global__ void __launch_bounds__(64) k_fuse1(BatchArgs a)
+__device__ void fuse1_window(const BatchArgs &a, const uint32_t w)
 {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= a.n) return;
-  const uint32_t w = a.perm[tid];
-  if (a.status[w]) return;
+  if (a.status[w] || (a.skip_a && a.skip_a[w])) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2];
   const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1);
   const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
@@ -380,9 +396,15 @@ __global__ void __launch_bounds__(64) k_fuse1(BatchArgs a)
   a.n1[w] = n;
   // ring depth class for k_dp2: D must cover max predecessor distance + 2
   const int need = nw.maxd + 2;
-  a.cls[w] = (uint8_t)(need <= 32 ? 0 : need <= 256 ? 1 : 2);
+  a.cls[w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 16 ? 0x80 : 0));
   if (need > 512) a.status[w] = 2;      // ELECTOR_W_TOOLONG: predecessor farther back than the deepest ring
   if (nw.bad) a.status[w] = 3;
+}
+
+__global__ void __launch_bounds__(64) k_fuse1(BatchArgs a)
+{
+  const int64_t cnt = list_count(a), stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) fuse1_window(a, a.perm[i]);
 }
 
 // ---------------------------------------------------------------- k_fuse2 ---
@@ -391,11 +413,9 @@ __global__ void __launch_bounds__(64) k_fuse1(BatchArgs a)
 // emit the MSA directly as columns (lpo_format.c:346-371: a new column whenever
 // the ring id changes).  The fused graph itself is never materialised.
 
-__global__ void __launch_bounds__(64) k_fuse2(BatchArgs a)
+__device__ void fuse2_window(const BatchArgs &a, const uint32_t w)
 {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= a.n) return;
-  const uint32_t w = a.perm[tid];
+  if (a.skip_b && a.skip_b[w]) return;
   if (a.status[w]) { a.ncol[w] = 0; return; }
   const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
   const int n1 = a.n1[w], Lu = (int)(o3 - o2);
@@ -471,6 +491,38 @@ __global__ void __launch_bounds__(64) k_fuse2(BatchArgs a)
   flush();
   a.ncol[w] = col + 1;
   if (bad) a.status[w] = 3;
+  if (a.mark_b) a.mark_b[w] = 1;
+}
+
+__global__ void __launch_bounds__(64) k_fuse2(BatchArgs a)
+{
+  const int64_t cnt = list_count(a), stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) fuse2_window(a, a.perm[i]);
+}
+
+// ---------------------------------------------------------------- k_left_b ---
+// After the fused kernels: collect the windows alignment #2 still has to be done
+// for (not handled on chip: graph deeper than the on-chip ring, scores outside the
+// 16-bit ring cells, slot estimate exceeded).  Windows the host already routed to
+// the generic path have their moves offset; the others get one from a bump
+// allocator over a fixed scratch budget.
+__global__ void __launch_bounds__(256) k_left_b(BatchArgs a, uint32_t *list, int32_t *count, const uint8_t *done_b,
+                                               int64_t *mv2, unsigned long long *bump, unsigned long long bump_base,
+                                               unsigned long long bump_cap)
+{
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= a.n) return;
+  if (a.status[w]) { if (!done_b[w]) a.ncol[w] = 0; return; }
+  if (done_b[w]) return;
+  if (mv2[w] < 0) {
+    const int64_t o0 = a.off[3 * w], o2 = a.off[3 * w + 2], o3 = a.off[3 * w + 3];
+    (void)o0;
+    const unsigned long long need = (unsigned long long)n_strips((int)(o3 - o2)) * mv_tw(a.n1[w]) * 64;
+    const unsigned long long at = atomicAdd(bump, need);
+    if (at + need > bump_cap) { a.status[w] = 2; a.ncol[w] = 0; return; }
+    mv2[w] = (int64_t)(bump_base + at);
+  }
+  list[atomicAdd(count, 1)] = (uint32_t)w;
 }
 
 // ----------------------------------------------------------------- k_rows ---
@@ -502,20 +554,38 @@ void launch_symbolize(const uint8_t *in, uint8_t *out, int64_t nbytes, const Dev
   hipLaunchKernelGGL(k_symbolize, dim3((unsigned)blocks), dim3(256), 0, st, in, out, nbytes, tab);
 }
 
+// grid for a list launch: the exact count when the host knows it, a fixed grid of
+// looping blocks when the count lives on the device
+static unsigned list_grid(const BatchArgs &a, int64_t per_block, unsigned device_grid)
+{
+  if (a.count_ptr) return device_grid;
+  int64_t g = (a.n + per_block - 1) / per_block;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
 void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st)
 {
-  if (gen) hipLaunchKernelGGL(k_dp1<true>, dim3((unsigned)a.n), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL(k_dp1<false>, dim3((unsigned)a.n), dim3(64), 0, st, a);
+  const unsigned g = list_grid(a, 1, 4096);
+  if (gen) hipLaunchKernelGGL(k_dp1<true>, dim3(g), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_dp1<false>, dim3(g), dim3(64), 0, st, a);
 }
 
 void launch_fuse1(const BatchArgs &a, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_fuse1, dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_fuse1, dim3(list_grid(a, 64, 256)), dim3(64), 0, st, a);
+}
+
+void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uint8_t *done_b, int64_t *mv2,
+                   unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, hipStream_t st)
+{
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(k_left_b, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a, list, count, done_b, mv2, bump,
+                     bump_base, bump_cap);
 }
 
 void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st)
 {
-  const dim3 g((unsigned)a.n), b(64);
+  const dim3 g(list_grid(a, 1, cls == 0 ? 4096 : 512)), b(64);
   if (gen) {
     if (cls == 0) hipLaunchKernelGGL((k_dp2<true, 32>), g, b, 0, st, a, cls);
     else if (cls == 1) hipLaunchKernelGGL((k_dp2<true, 256>), g, b, 0, st, a, cls);
@@ -529,7 +599,7 @@ void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st)
 
 void launch_fuse2(const BatchArgs &a, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_fuse2, dim3((unsigned)((a.n + 63) / 64)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_fuse2, dim3(list_grid(a, 64, 256)), dim3(64), 0, st, a);
 }
 
 void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,

@@ -111,9 +111,10 @@ int elector_ctx_sync(elector_ctx *ctx);
 
 /* measurement hooks for bench.py: HIP-event time (ms) and span count of a
  * kernel class accumulated since the last reset, measured with events on the
- * context's own stream.  kernel: 0 = k_dp1 (alignment #1), 1 = k_dp2
- * (alignment #2, its three ring-depth launches as one span), 2 = the light
- * stages (symbolize, traceback + fusion). */
+ * stream each kernel is launched on.  kernel: 0 = alignment #1 stage
+ * (k_fused_a<G> launches; k_dp1 on the generic path), 1 = alignment #2 stage
+ * (k_fused_b<G>; k_dp2), 2 = everything else (symbolize, generic leftovers).
+ * Size classes run concurrently on separate streams: the sums overlap in wall time. */
 int elector_ctx_timing_enable(elector_ctx *ctx, int on);
 int elector_ctx_timing_read(elector_ctx *ctx, int kernel, double *ms, int64_t *launches);
 int elector_ctx_timing_reset(elector_ctx *ctx);
