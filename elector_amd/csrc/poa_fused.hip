@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(64) k_fused_a(FusedArgs a)
 
 constexpr int kRingDepth = 16;       // time slots
 constexpr int kRingSlots = 18;       // + slot 16: each lane's column -1 cells, slot 17: "no predecessor"
-constexpr int kNeg16 = -8192;        // score of the "no predecessor" cells (below any 16-bit-eligible score)
+constexpr int kNeg16 = -16383;       // score of the "no predecessor" cells (below any 16-bit-eligible score)
 
 __device__ __forceinline__ int cell16_S(int c) { return c >> 1; }
 
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
   const int off_region = align_up(off_b1 + (ns > 1 ? 4 * (n1 + 1) : 0), 8);
   const int region_bytes = max(ns * n1 * 2 * G, 3 * (n1 + Lu) + 8);
   const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
-  valid = valid && (off_region + region_bytes <= a.slot_bytes) && (maxpen * (n1 + Lu + 4) < 8000);
+  valid = valid && (off_region + region_bytes <= a.slot_bytes) && (maxpen * (n1 + Lu + 4) < 16000);
   uint8_t *slot = lds + 64 * 8 * kRingSlots + q * a.slot_bytes;
   uint2 *ring = reinterpret_cast<uint2 *>(lds);                 // [kRingDepth][64] x 4 cells of 16 bits
   const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(lds);

@@ -39,6 +39,18 @@ struct FusedArgs {
 };
 int launch_fused_a(const FusedArgs &a, int G, hipStream_t st);
 int launch_fused_b(const FusedArgs &a, int G, hipStream_t st);
+struct LaneArgs {
+  BatchArgs b;
+  const uint32_t *list;
+  int64_t nlist;
+  const int64_t *mv_off;
+  const int32_t *dims;
+  int cap;
+  uint8_t *done_a;
+  uint8_t *done_b;
+};
+int launch_lane_a(const LaneArgs &a, hipStream_t st);
+int launch_lane_b(const LaneArgs &a, hipStream_t st);
 }  // namespace elector
 
 using namespace elector;
@@ -284,7 +296,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_score1, &c->d_score2, &c->d_bx2, &c->d_bases, &c->d_cols, &c->d_ncol, &c->d_status,
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_scroff,
-                    &c->d_list, &c->d_done, &c->d_rowinit};
+                    &c->d_list, &c->d_done, &c->d_rowinit, &c->d_lanemeta};
   for (DevBuf *b : bufs) b->release();
   c->h_meta.release();
   if (c->aux_ready) {
@@ -371,6 +383,12 @@ static const int kBinG[kBins] = {16, 16, 16, 16, 16, 32, 32, 32, 32, 32, 32, 64,
 static const int kSlot[kBins] = {2048, 3072, 4096, 6144, 8192, 4096, 6144, 8192, 12288, 16384, 24576,
                                  8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072};
 
+// lane-per-window classes: reference length cap (columns of alignment #1) and node cap of
+// alignment #2 (|PO| is usually a few percent above Lr; larger graphs are handed back)
+static const int kLaneClasses = 6;
+static const int kLaneCapA[kLaneClasses] = {32, 48, 64, 80, 96, 128};
+static const int kLaneCapB[kLaneClasses] = {42, 60, 78, 96, 114, 150};
+
 static int ensure_streams(elector_ctx *c)
 {
   if (c->aux_ready) return 0;
@@ -419,7 +437,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // window sizes -> status, coarse size key (counting sort, largest first), launch class
   constexpr int NB = 256;
   std::vector<int8_t> bin((size_t)n, -1);
-  int64_t key_cnt[NB + 1] = {0}, bin_cnt[kBins] = {0}, n_generic = 0;
+  std::vector<int8_t> lcls((size_t)n, -1);
+  // lane-per-window kernels: experimental, slower than the fused kernels at present
+  const bool use_lane = use_fused && std::getenv("ELECTOR_LANE") != nullptr;
+  int64_t key_cnt[NB + 1] = {0}, bin_cnt[kBins] = {0}, n_generic = 0, lane_cnt[kLaneClasses] = {0};
   auto key = [&](int64_t w) {
     const int64_t m = std::max(off[3 * w + 1] - off[3 * w], off[3 * w + 3] - off[3 * w + 2]);
     int k = (int)(m >> 3);
@@ -435,7 +456,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ) st = ELECTOR_W_TOOLONG;
     h_status[w] = st;
     h_mv1[w] = h_mv2[w] = -1;
-    if (!st && use_fused) {
+    if (!st && use_lane && lr <= kLaneCapA[kLaneClasses - 1] && lc <= 1023 && lu <= 1023) {
+      for (int k = 0; k < kLaneClasses; ++k)
+        if (lr <= kLaneCapA[k]) { lcls[(size_t)w] = (int8_t)k; lane_cnt[k]++; break; }
+    } else if (!st && use_fused) {
       const int rows = (int)std::max(lc, lu), gmin = rows <= 64 ? 16 : rows <= 128 ? 32 : 64;
       for (int b = 0; b < kBins; ++b) {
         if (kBinG[b] < gmin) continue;
@@ -448,7 +472,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       }
     }
     if (bin[(size_t)w] >= 0) bin_cnt[bin[(size_t)w]]++;
-    else ++n_generic;                               // includes failed windows: k_fuse2 zeroes their ncol
+    else if (lcls[(size_t)w] < 0) ++n_generic;      // includes failed windows: k_left_b zeroes their ncol
     key_cnt[key(w) + 1]++;
   }
   for (int k = 0; k < NB; ++k) key_cnt[k + 1] += key_cnt[k];
@@ -465,13 +489,58 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       const uint32_t w = order[(size_t)k];
       const int b = bin[w];
       if (b >= 0) h_list[pos[b]++] = w;
-      else h_generic[gpos++] = w;
+      else if (lcls[w] < 0) h_generic[gpos++] = w;
+    }
+  }
+  // lane-per-window classes: 64 windows per wave, sorted so that a wave's windows have nearly
+  // the same reference and uncorrected lengths (counting sort on (Lr, Lu/4), longest first)
+  int64_t lane_first[kLaneClasses + 1];
+  lane_first[0] = bin_first[kBins];
+  for (int k = 0; k < kLaneClasses; ++k) lane_first[k + 1] = lane_first[k] + lane_cnt[k];
+  const int64_t n_lane = lane_first[kLaneClasses] - lane_first[0];
+  std::vector<int64_t> lane_mvoff_a, lane_mvoff_b;
+  std::vector<int32_t> lane_dims;
+  int64_t lane_blk_first[kLaneClasses + 1] = {0};
+  int64_t lane_dwords = 0;
+  if (n_lane) {
+    constexpr int KB = (128 + 1) * 256;
+    std::vector<int64_t> kc((size_t)KB + 1, 0);
+    auto lkey = [&](int64_t w) {
+      const int lr = (int)(off[3 * w + 1] - off[3 * w]);
+      const int lu4 = (int)std::min<int64_t>((off[3 * w + 3] - off[3 * w + 2]) >> 2, 255);
+      return (KB - 1) - (lr * 256 + lu4);               // descending
+    };
+    for (int64_t w = 0; w < n; ++w) if (lcls[(size_t)w] >= 0) kc[(size_t)lkey(w) + 1]++;
+    for (int k = 0; k < KB; ++k) kc[(size_t)k + 1] += kc[(size_t)k];
+    // classes are contiguous Lr ranges, so one global sort keeps them contiguous too (largest class first)
+    std::vector<uint32_t> tmp((size_t)n_lane);
+    for (int64_t w = 0; w < n; ++w) if (lcls[(size_t)w] >= 0) tmp[(size_t)kc[(size_t)lkey(w)]++] = (uint32_t)w;
+    // place per class (descending within class)
+    int64_t pos[kLaneClasses];
+    for (int k = 0; k < kLaneClasses; ++k) pos[k] = lane_first[k];
+    for (int64_t i = 0; i < n_lane; ++i) { const uint32_t w = tmp[(size_t)i]; h_list[pos[lcls[w]]++] = w; }
+    // per wave: maxima and moves tiles
+    for (int k = 0; k < kLaneClasses; ++k) {
+      lane_blk_first[k + 1] = lane_blk_first[k] + (lane_cnt[k] + 63) / 64;
+      for (int64_t b0 = lane_first[k]; b0 < lane_first[k + 1]; b0 += 64) {
+        int32_t mr = 0, mc = 0, mu = 0, mb = 0;
+        for (int64_t i = b0; i < std::min(b0 + 64, lane_first[k + 1]); ++i) {
+          const int64_t w = h_list[i];
+          const int32_t lr = (int32_t)(off[3 * w + 1] - off[3 * w]), lc = (int32_t)(off[3 * w + 2] - off[3 * w + 1]),
+                        lu = (int32_t)(off[3 * w + 3] - off[3 * w + 2]);
+          mr = std::max(mr, lr); mc = std::max(mc, lc); mu = std::max(mu, lu); mb = std::max(mb, lr + lc);
+        }
+        lane_dims.push_back(mr); lane_dims.push_back(mc); lane_dims.push_back(mu); lane_dims.push_back(mb);
+        lane_mvoff_a.push_back(lane_dwords); lane_dwords += (int64_t)mc * ((mr + 7) / 8) * 64;
+        lane_mvoff_b.push_back(lane_dwords); lane_dwords += (int64_t)mu * ((mb + 7) / 8) * 64;
+      }
     }
   }
   if (std::getenv("ELECTOR_DEBUG_BINS")) {
     std::fprintf(stderr, "[elector] n=%lld generic=%lld classes:", (long long)n, (long long)n_generic);
     for (int b = 0; b < kBins; ++b) std::fprintf(stderr, " G%d/%d:%lld", kBinG[b], kSlot[b], (long long)bin_cnt[b]);
-    std::fprintf(stderr, "\n");
+    for (int k = 0; k < kLaneClasses; ++k) std::fprintf(stderr, " L%d:%lld", kLaneCapA[k], (long long)lane_cnt[k]);
+    std::fprintf(stderr, " lane scratch %.1f MB\n", lane_dwords * 4e-6);
   }
   // moves scratch of the generic-path windows, in chunks
   struct Chunk { int64_t k0, k1, dwords; };
@@ -502,7 +571,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_perm.ensure((size_t)n * 4 + 64) | c->d_mv1.ensure((size_t)n * 8) |
        c->d_mv2.ensure((size_t)n * 8) | c->d_sym.ensure((size_t)total + 64) | c->d_xinfo.ensure(nodes * 8) |
        c->d_ring1.ensure(nodes * 2) | c->d_map16.ensure(nodes * 2) | c->d_carry.ensure(nodes * 4) |
-       c->d_moves.ensure((size_t)(max_dwords + bump_dwords) * 4 + 1024) | c->d_n1.ensure((size_t)n * 4) |
+       c->d_moves.ensure((size_t)(max_dwords + bump_dwords + lane_dwords) * 4 + 1024) |
+       c->d_lanemeta.ensure(lane_dims.size() * 4 + lane_mvoff_a.size() * 16 + 64) | c->d_n1.ensure((size_t)n * 4) |
        c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
        c->d_bx2.ensure((size_t)n * 4) | c->d_list.ensure((size_t)2 * n * 4 + 64) | c->d_done.ensure((size_t)2 * n + 64) |
        c->d_rowinit.ensure(4096);
@@ -519,6 +589,18 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemcpyAsync(c->d_off.p, off, (size_t)(3 * n + 1) * 8, hipMemcpyHostToDevice, st));
   if (n_generic) HIPCHK(c, hipMemcpyAsync(d_generic, h_generic, (size_t)n_generic * 4, hipMemcpyHostToDevice, st));
   if (n - n_generic) HIPCHK(c, hipMemcpyAsync(d_lists, h_list, (size_t)(n - n_generic) * 4, hipMemcpyHostToDevice, st));
+  const size_t nblk = lane_mvoff_a.size();
+  int64_t *d_lane_mva = c->d_lanemeta.as<int64_t>(), *d_lane_mvb = d_lane_mva + nblk;
+  int32_t *d_lane_dims = reinterpret_cast<int32_t *>(d_lane_mvb + nblk);
+  if (nblk) {
+    // tiles live after the generic chunk scratch and the bump region
+    for (auto &v : lane_mvoff_a) v += max_dwords + bump_dwords;
+    for (auto &v : lane_mvoff_b) v += max_dwords + bump_dwords;
+    HIPCHK(c, hipMemcpyAsync(d_lane_mva, lane_mvoff_a.data(), nblk * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_lane_mvb, lane_mvoff_b.data(), nblk * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_lane_dims, lane_dims.data(), nblk * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));      // the host vectors go out of scope before the copies would run
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_mv1.p, h_mv1, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -561,7 +643,30 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   if (use_fused && n > n_generic) {
     HIPCHK(c, hipEventRecord(c->fork, st));
     int used = 0;
-    for (int b = 0; b < kBins; ++b) {
+    for (int k = kLaneClasses - 1; k >= 0; --k) {
+      if (!lane_cnt[k]) continue;
+      hipStream_t sx = c->aux[used % elector_ctx::kAux];
+      if (used < elector_ctx::kAux) HIPCHK(c, hipStreamWaitEvent(sx, c->fork, 0));
+      ++used;
+      LaneArgs la;
+      la.b = a;
+      la.list = d_lists + lane_first[k];
+      la.nlist = lane_cnt[k];
+      la.dims = d_lane_dims + 4 * lane_blk_first[k];
+      la.done_a = d_done_a;
+      la.done_b = d_done_b;
+      la.mv_off = d_lane_mva + lane_blk_first[k];
+      la.cap = kLaneCapA[k];
+      timed_begin(c, 0, sx);
+      if (launch_lane_a(la, sx)) return fail(c, ELECTOR_E_HIP, "lane kernel attribute");
+      timed_end(c, sx);
+      la.mv_off = d_lane_mvb + lane_blk_first[k];
+      la.cap = kLaneCapB[k];
+      timed_begin(c, 1, sx);
+      if (launch_lane_b(la, sx)) return fail(c, ELECTOR_E_HIP, "lane kernel attribute");
+      timed_end(c, sx);
+    }
+    for (int b = kBins - 1; b >= 0; --b) {          // long-running big-window classes first
       if (!bin_cnt[b]) continue;
       hipStream_t sx = c->aux[used % elector_ctx::kAux];
       if (used < elector_ctx::kAux) HIPCHK(c, hipStreamWaitEvent(sx, c->fork, 0));
@@ -647,6 +752,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   c->last_n = n;
   if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 4)) {
     (void)hipStreamSynchronize(st);
+    int32_t hc[4];
+    (void)hipMemcpy(hc, c->d_rowinit.p, sizeof hc, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[elector] windows handed back to the generic alignment #2: %d\n", hc[0]);
     unsigned long long hs[384];
     (void)hipMemcpy(hs, c->d_rowinit.as<uint8_t>() + 1024, sizeof hs, hipMemcpyDeviceToHost);
     for (int b = 0; b < 12; ++b) {
