@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <time.h>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -426,6 +429,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const bool use_fused = !c->gen && !std::getenv("ELECTOR_NO_FUSED");
 
   // ---- host metadata ----
+  const bool host_prof = std::getenv("ELECTOR_DEBUG_HOST") != nullptr;
+  auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+  const double tp0 = now_ms();
   int rc = c->h_meta.ensure((size_t)n * (4 + 8 + 8 + 4 + 4) + 64);
   if (rc) return fail(c, rc, "pinned metadata");
   int32_t *h_status = c->h_meta.as<int32_t>();
@@ -447,34 +453,67 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     if (k >= NB) k = NB - 1;
     return NB - 1 - k;
   };
-  for (int64_t w = 0; w < n; ++w) {
-    const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
-                  lu = off[3 * w + 3] - off[3 * w + 2];
-    int st = ELECTOR_W_OK;
-    if (lr < 0 || lc < 0 || lu < 0) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
-    if (lr == 0 || lc == 0 || lu == 0) st = ELECTOR_W_EMPTY;
-    else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ) st = ELECTOR_W_TOOLONG;
-    h_status[w] = st;
-    h_mv1[w] = h_mv2[w] = -1;
-    if (!st && use_lane && lr <= kLaneCapA[kLaneClasses - 1] && lc <= 1023 && lu <= 1023) {
-      for (int k = 0; k < kLaneClasses; ++k)
-        if (lr <= kLaneCapA[k]) { lcls[(size_t)w] = (int8_t)k; lane_cnt[k]++; break; }
-    } else if (!st && use_fused) {
-      const int rows = (int)std::max(lc, lu), gmin = rows <= 64 ? 16 : rows <= 128 ? 32 : 64;
-      for (int b = 0; b < kBins; ++b) {
-        if (kBinG[b] < gmin) continue;
-        const int G = kBinG[b];
-        // one class for both fused kernels; |PO| is not known yet: typical growth estimate, windows
-        // whose graph turns out larger are handed back by the device (k_left_b)
-        const int need = std::max(fused_a_slot_need((int)lr, (int)lc, G),
-                                  fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G));
-        if (need <= kSlot[b]) { bin[(size_t)w] = (int8_t)b; break; }
-      }
-    }
-    if (bin[(size_t)w] >= 0) bin_cnt[bin[(size_t)w]]++;
-    else if (lcls[(size_t)w] < 0) ++n_generic;      // includes failed windows: k_left_b zeroes their ncol
-    key_cnt[key(w) + 1]++;
+  // first slot class of each group size in kBinG/kSlot
+  int g_first[3] = {kBins, kBins, kBins}, g_end[3] = {0, 0, 0};
+  for (int b = 0; b < kBins; ++b) {
+    const int gi = kBinG[b] == 16 ? 0 : kBinG[b] == 32 ? 1 : 2;
+    g_first[gi] = std::min(g_first[gi], b);
+    g_end[gi] = b + 1;
   }
+  std::vector<uint8_t> wkey((size_t)n);
+  std::atomic<int> bad_offsets(0);
+  {
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
+    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + kLaneClasses + 1, 0));
+    auto work = [&](int t) {
+      const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
+      int64_t *cnt = tcnt[(size_t)t].data();
+      for (int64_t w = w0; w < w1; ++w) {
+        const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
+                      lu = off[3 * w + 3] - off[3 * w + 2];
+        int st = ELECTOR_W_OK;
+        if (lr < 0 || lc < 0 || lu < 0) { bad_offsets.store(1); continue; }
+        if (lr == 0 || lc == 0 || lu == 0) st = ELECTOR_W_EMPTY;
+        else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ) st = ELECTOR_W_TOOLONG;
+        h_status[w] = st;
+        h_mv1[w] = h_mv2[w] = -1;
+        if (!st && use_lane && lr <= kLaneCapA[kLaneClasses - 1] && lc <= 1023 && lu <= 1023) {
+          for (int k = 0; k < kLaneClasses; ++k)
+            if (lr <= kLaneCapA[k]) { lcls[(size_t)w] = (int8_t)k; cnt[NB + kBins + k]++; break; }
+        } else if (!st && use_fused) {
+          // one class for both fused kernels; |PO| is not known yet: typical growth estimate, windows
+          // whose graph turns out larger are handed back by the device (k_left_b)
+          const int rows = (int)std::max(lc, lu);
+          for (int gi = rows <= 64 ? 0 : rows <= 128 ? 1 : 2; gi < 3 && bin[(size_t)w] < 0; ++gi) {
+            const int G = 16 << gi;
+            const int need = std::max(fused_a_slot_need((int)lr, (int)lc, G),
+                                      fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G));
+            for (int b = g_first[gi]; b < g_end[gi]; ++b)
+              if (need <= kSlot[b]) { bin[(size_t)w] = (int8_t)b; break; }
+          }
+        }
+        if (bin[(size_t)w] >= 0) cnt[NB + bin[(size_t)w]]++;
+        else if (lcls[(size_t)w] < 0) cnt[NB + kBins + kLaneClasses]++;   // generic (incl. failed windows)
+        const int64_t mlen = std::max(lr, lu);
+        int k = (int)(mlen >> 3);
+        if (k >= NB) k = NB - 1;
+        wkey[(size_t)w] = (uint8_t)(NB - 1 - k);
+        cnt[NB - 1 - k]++;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (int t = 0; t < T; ++t) {
+      for (int k = 0; k < NB; ++k) key_cnt[k + 1] += tcnt[(size_t)t][(size_t)k];
+      for (int b = 0; b < kBins; ++b) bin_cnt[b] += tcnt[(size_t)t][(size_t)(NB + b)];
+      for (int k = 0; k < kLaneClasses; ++k) lane_cnt[k] += tcnt[(size_t)t][(size_t)(NB + kBins + k)];
+      n_generic += tcnt[(size_t)t][(size_t)(NB + kBins + kLaneClasses)];
+    }
+  }
+  if (bad_offsets.load()) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
+  const double tp1 = now_ms();
   for (int k = 0; k < NB; ++k) key_cnt[k + 1] += key_cnt[k];
   // stable placement in descending size order, per destination list
   int64_t bin_first[kBins + 1];
@@ -482,7 +521,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   for (int b = 0; b < kBins; ++b) bin_first[b + 1] = bin_first[b] + bin_cnt[b];
   {
     std::vector<uint32_t> order((size_t)n);
-    for (int64_t w = 0; w < n; ++w) order[(size_t)key_cnt[key(w)]++] = (uint32_t)w;
+    for (int64_t w = 0; w < n; ++w) order[(size_t)key_cnt[wkey[(size_t)w]]++] = (uint32_t)w;
     int64_t pos[kBins], gpos = 0;
     for (int b = 0; b < kBins; ++b) pos[b] = bin_first[b];
     for (int64_t k = 0; k < n; ++k) {
@@ -542,6 +581,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     for (int k = 0; k < kLaneClasses; ++k) std::fprintf(stderr, " L%d:%lld", kLaneCapA[k], (long long)lane_cnt[k]);
     std::fprintf(stderr, " lane scratch %.1f MB\n", lane_dwords * 4e-6);
   }
+  const double tp2 = now_ms();
   // moves scratch of the generic-path windows, in chunks
   struct Chunk { int64_t k0, k1, dwords; };
   std::vector<Chunk> chunks;
@@ -579,6 +619,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
   if (use_fused && (rc = ensure_streams(c))) return fail(c, rc, "auxiliary streams");
 
+  const double tp3 = now_ms();
   hipStream_t st = c->stream;
   uint32_t *d_generic = c->d_perm.as<uint32_t>();
   uint32_t *d_lists = c->d_list.as<uint32_t>();
@@ -608,6 +649,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemsetAsync(d_counters, 0, 16, st));
   if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 3072, st));
 
+  const double tp4 = now_ms();
+  if (host_prof)
+    std::fprintf(stderr, "[elector] host: classify %.2f ms, sort+lists %.2f ms, chunks+workspace %.2f ms, uploads %.2f ms\n",
+                 tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
   timed_begin(c, 2, st);
   launch_symbolize(d_bases, c->d_sym.as<uint8_t>(), total, c->d_tab.as<DevTables>(), st);
   timed_end(c, st);
