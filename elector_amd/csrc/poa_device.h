@@ -96,7 +96,7 @@ struct BatchArgs {
 __host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G)
 {
   const int ns = (Lc + 4 * G - 1) / (4 * G);
-  int o = (Lr + Lc + 3) & ~3;
+  int o = 16 + ((Lr + Lc + 3) & ~3);
   o += (2 * Lr + 3) & ~3;
   o += (ns > 1 ? 4 * (Lr + 1) : 0);
   o = (o + 7) & ~7;
@@ -107,13 +107,13 @@ __host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G)
 __host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G)
 {
   const int ns = (Lu + 4 * G - 1) / (4 * G);
-  int o = (Lu + 7) & ~7;
-  o += 8 * (n1 + 1);
-  o += (2 * n1 + 3) & ~3;
-  o += (2 * n1 + 3) & ~3;
+  int o = (Lu + 3) & ~3;
   o += 4 * (n1 + 1);
-  o += (ns > 1 ? 4 * (n1 + 1) : 0);
-  o = (o + 7) & ~7;
+  o += (2 * n1 + 3) & ~3;
+  o += (2 * n1 + 3) & ~3;
+  o += (2 * (n1 + 1) + 3) & ~3;
+  o += (ns > 1 ? 2 * (n1 + 1) : 0);
+  o = (o + 3) & ~3;
   const int mv = ns * n1 * 2 * G, st = 3 * (n1 + Lu) + 8;
   return o + (mv > st ? mv : st);
 }

@@ -86,47 +86,65 @@ __device__ __forceinline__ CellOut cell_1pred(int diag, int insX, int insY, int 
 
 // ---------------------------------------------------------------- k_fused_a ---
 
+// one window of k_fused_a: ids, lengths and its LDS slot layout
+// slot: [header 16 B: n1, maxd, bad][ref+cor symbols][x2y u16][carry i32 (multi-strip only)][region]
+// region = alignment #1 moves (1 byte per lane and column: 4 cells x 2 bits), reused after the
+// traceback for the staged graph (xinfo int2[n1+1], then ring ids u16[n1])
+struct WinA {
+  bool valid;
+  uint32_t w;
+  int64_t o0;
+  int Lr, Lc, ns, off_x2y, off_carry, off_region;
+};
+
 template <int G>
-__global__ void __launch_bounds__(64) k_fused_a(FusedArgs a)
+__device__ __forceinline__ WinA load_win_a(const FusedArgs &a, int64_t li)
+{
+  constexpr int RS = 4 * G;
+  WinA v;
+  v.valid = li < a.nlist;
+  v.w = v.valid ? a.list[li] : 0;
+  v.valid = v.valid && a.b.status[v.w] == 0;
+  v.o0 = 0; v.Lr = 0; v.Lc = 0;
+  if (v.valid) {
+    v.o0 = a.b.off[3 * (int64_t)v.w];
+    v.Lr = (int)(a.b.off[3 * (int64_t)v.w + 1] - v.o0);
+    v.Lc = (int)(a.b.off[3 * (int64_t)v.w + 2] - v.o0) - v.Lr;
+  }
+  v.ns = (v.Lc + RS - 1) / RS;
+  v.off_x2y = 16 + align_up(v.Lr + v.Lc, 4);
+  v.off_carry = v.off_x2y + align_up(2 * v.Lr, 4);
+  v.off_region = align_up(v.off_carry + (v.ns > 1 ? 4 * (v.Lr + 1) : 0), 8);
+  const int region_bytes = max(v.ns * v.Lr * G, 8 * (v.Lr + v.Lc + 1) + 2 * (v.Lr + v.Lc));
+  v.valid = v.valid && (v.off_region + region_bytes <= a.slot_bytes);
+  return v;
+}
+
+// WV wavefronts per block: each runs the DP of its own 64/G windows; the per-window serial
+// stage (traceback + fusion) of ALL the block's windows is then run by the first lanes of
+// wave 0, so that an instruction of the serial stage serves WV * 64/G windows at once.
+template <int G, int WV>
+__global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NW = 64 / G, RS = 4 * G;     // windows per wave, rows per strip
-  const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
-  const int64_t li = NW * (int64_t)blockIdx.x + q;
-  bool valid = li < a.nlist;
-  const uint32_t w = valid ? a.list[li] : 0;
-  valid = valid && a.b.status[w] == 0;
-  int64_t o0 = 0;
-  int Lr = 0, Lc = 0;
-  if (valid) {
-    o0 = a.b.off[3 * (int64_t)w];
-    Lr = (int)(a.b.off[3 * (int64_t)w + 1] - o0);
-    Lc = (int)(a.b.off[3 * (int64_t)w + 2] - o0) - Lr;
-  }
-  // ---- slot layout: [ref+cor symbols][x2y u16][carry i32 (multi-strip only)][region]
-  // region = alignment #1 moves (1 byte per lane and column: 4 cells x 2 bits), reused
-  // after the traceback for the staged graph (xinfo int2[n1+1], then ring ids u16[n1]) ----
-  const int ns = (Lc + RS - 1) / RS;
-  const int off_x2y = align_up(Lr + Lc, 4);
-  const int off_carry = off_x2y + align_up(2 * Lr, 4);
-  const int off_region = align_up(off_carry + (ns > 1 ? 4 * (Lr + 1) : 0), 8);
-  const int region_bytes = max(ns * Lr * G, 8 * (Lr + Lc + 1) + 2 * (Lr + Lc));
-  valid = valid && (off_region + region_bytes <= a.slot_bytes);
-  uint8_t *slot = lds + q * a.slot_bytes;
-  uint8_t *xs = slot, *ys = slot + Lr;
-  uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + off_x2y);
-  int32_t *carry = reinterpret_cast<int32_t *>(slot + off_carry);
-  uint8_t *mv = slot + off_region;
-  int2 *xi_st = reinterpret_cast<int2 *>(slot + off_region);     // overlays the moves after traceback
-  uint16_t *ring_st = reinterpret_cast<uint16_t *>(slot + off_region + 8 * (Lr + Lc + 1));
+  const int sidx = wv * NW + q;               // this lane's window slot in the block
+  const WinA W = load_win_a<G>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
+  const bool valid = W.valid;
+  const int Lr = W.Lr, Lc = W.Lc, ns = W.ns;
+  uint8_t *slot = lds + sidx * a.slot_bytes;
+  uint8_t *xs = slot + 16, *ys = xs + Lr;
+  int32_t *carry = reinterpret_cast<int32_t *>(slot + W.off_carry);
+  uint8_t *mv = slot + W.off_region;
 
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
   if (valid) {
-    const uint8_t *src = a.b.sym + o0;
-    for (int i = g; i < Lr + Lc; i += G) slot[i] = src[i];
+    const uint8_t *src = a.b.sym + W.o0;
+    for (int i = g; i < Lr + Lc; i += G) xs[i] = src[i];
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   PHASE_STAMP(0);
 
   // wave-uniform loop bounds
@@ -189,88 +207,103 @@ __global__ void __launch_bounds__(64) k_fused_a(FusedArgs a)
       }
     }
     if (sv && s == ns - 1 && g == gstar) score = (kstar == 0) ? S[0] : (kstar == 1) ? S[1] : (kstar == 2) ? S[2] : S[3];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
+  if (valid && g == gstar) a.b.score1[W.w] = score;
+  __syncthreads();
 
   PHASE_STAMP(1);
-  // ---- traceback #1 + fusion #1: one lane per window ----
-  int n1 = 0, maxd = 1;
-  bool bad = false;
-  if (valid && g == gstar) a.b.score1[w] = score;
-  if (valid && g == 0 && !(a.debug & 2)) {
-    for (int j = 0; j < Lr; ++j) x2y[j] = (uint16_t)kNone16;
-    {
-      int x = Lr - 1, y = Lc - 1, guard = Lr + Lc + 2;
-      while (x >= 0 && y >= 0 && guard-- > 0) {
-        const int r = y % RS;
-        const uint32_t two = (mv[((y / RS) * Lr + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
-        const int xo = two & 1, yo = two >> 1;
-        if (xo && yo) x2y[x] = (uint16_t)y;
-        if (!xo && !yo) { bad = true; break; }
-        if (xo) --x;
-        if (yo) --y;
-      }
-    }
-    int n = 0, iy = 0, lastx = -1, lasty = -1;
-    auto emit = [&](int letter, int flags, int ring, int sa, int sb) {
-      int pp1, pp2 = (int)kNone16;
-      const int jj = n + 1;
-      if (sa < 0) pp1 = 0;
-      else if (flags & kFlagInitial) { pp1 = 0; pp2 = sa + 1; if (sb >= 0) bad = true; }
-      else { pp1 = sa + 1; if (sb >= 0) pp2 = sb + 1; }
-      if (pp1 > 0) maxd = max(maxd, jj - pp1);
-      if (pp2 != (int)kNone16 && pp2 > 0) maxd = max(maxd, jj - pp2);
-      xi_st[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
-      ring_st[n] = (uint16_t)ring;
-    };
-    for (int ix = 0; ix < Lr; ++ix) {
-      const int ay = x2y[ix];
-      const bool al = ay != (int)kNone16;
-      if (al)
-        while (iy < ay) {
-          emit(ys[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0), n, lasty, -1);
-          lasty = n; ++n; ++iy;
+  // ---- traceback #1 + fusion #1: lane l of wave 0 serves the block's window slot l ----
+  if (threadIdx.x < NW * WV && !(a.debug & 2)) {
+    const WinA V = load_win_a<G>(a, (int64_t)(NW * WV) * blockIdx.x + threadIdx.x);
+    if (V.valid) {
+      uint8_t *vs = lds + threadIdx.x * a.slot_bytes;
+      int32_t *hdr = reinterpret_cast<int32_t *>(vs);
+      const uint8_t *vx = vs + 16, *vy = vx + V.Lr;
+      uint16_t *x2y = reinterpret_cast<uint16_t *>(vs + V.off_x2y);
+      const uint8_t *vmv = vs + V.off_region;
+      int2 *xi_st = reinterpret_cast<int2 *>(vs + V.off_region);     // overlays the moves after traceback
+      uint16_t *ring_st = reinterpret_cast<uint16_t *>(vs + V.off_region + 8 * (V.Lr + V.Lc + 1));
+      const int vLr = V.Lr, vLc = V.Lc;
+      int maxd = 1;
+      bool bad = false;
+      for (int j = 0; j < vLr; ++j) x2y[j] = (uint16_t)kNone16;
+      {
+        int x = vLr - 1, y = vLc - 1, guard = vLr + vLc + 2;
+        while (x >= 0 && y >= 0 && guard-- > 0) {
+          const int r = y % RS;
+          const uint32_t two = (vmv[((y / RS) * vLr + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
+          const int xo = two & 1, yo = two >> 1;
+          if (xo && yo) x2y[x] = (uint16_t)y;
+          if (!xo && !yo) { bad = true; break; }
+          if (xo) --x;
+          if (yo) --y;
         }
-      int fl = kFlagHasRef | (ix == 0 ? kFlagInitial : 0) | (ix == Lr - 1 ? kFlagFinal : 0);
-      int sa = lastx, sb = -1, ring = n;
-      if (al && iy < Lc) {
-        const int fy = kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0);
-        if (xs[ix] == ys[iy]) {
-          fl |= fy;
-          if (lasty >= 0 && lasty != lastx) { if (sa < 0) sa = lasty; else sb = lasty; }
-          emit(xs[ix], fl, n, sa, sb);
-          lastx = lasty = n; ++n; ++iy;
-          continue;
-        }
-        emit(ys[iy], fy, n, lasty, -1);
-        ring = n; lasty = n; ++n; ++iy;
       }
-      emit(xs[ix], fl, ring, sa, sb);
-      lastx = n; ++n;
+      int n = 0, iy = 0, lastx = -1, lasty = -1;
+      auto emit = [&](int letter, int flags, int ring, int sa, int sb) {
+        int pp1, pp2 = (int)kNone16;
+        const int jj = n + 1;
+        if (sa < 0) pp1 = 0;
+        else if (flags & kFlagInitial) { pp1 = 0; pp2 = sa + 1; if (sb >= 0) bad = true; }
+        else { pp1 = sa + 1; if (sb >= 0) pp2 = sb + 1; }
+        if (pp1 > 0) maxd = max(maxd, jj - pp1);
+        if (pp2 != (int)kNone16 && pp2 > 0) maxd = max(maxd, jj - pp2);
+        xi_st[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
+        ring_st[n] = (uint16_t)ring;
+      };
+      for (int ix = 0; ix < vLr; ++ix) {
+        const int ay = x2y[ix];
+        const bool al = ay != (int)kNone16;
+        if (al)
+          while (iy < ay) {
+            emit(vy[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == vLc - 1 ? kFlagFinal : 0), n, lasty, -1);
+            lasty = n; ++n; ++iy;
+          }
+        int fl = kFlagHasRef | (ix == 0 ? kFlagInitial : 0) | (ix == vLr - 1 ? kFlagFinal : 0);
+        int sa = lastx, sb = -1, ring = n;
+        if (al && iy < vLc) {
+          const int fy = kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == vLc - 1 ? kFlagFinal : 0);
+          if (vx[ix] == vy[iy]) {
+            fl |= fy;
+            if (lasty >= 0 && lasty != lastx) { if (sa < 0) sa = lasty; else sb = lasty; }
+            emit(vx[ix], fl, n, sa, sb);
+            lastx = lasty = n; ++n; ++iy;
+            continue;
+          }
+          emit(vy[iy], fy, n, lasty, -1);
+          ring = n; lasty = n; ++n; ++iy;
+        }
+        emit(vx[ix], fl, ring, sa, sb);
+        lastx = n; ++n;
+      }
+      while (iy < vLc) {
+        emit(vy[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == vLc - 1 ? kFlagFinal : 0), n, lasty, -1);
+        lasty = n; ++n; ++iy;
+      }
+      hdr[0] = n; hdr[1] = maxd; hdr[2] = bad ? 1 : 0;
     }
-    while (iy < Lc) {
-      emit(ys[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0), n, lasty, -1);
-      lasty = n; ++n; ++iy;
-    }
-    n1 = n;
   }
   __syncthreads();
   PHASE_STAMP(2);
-  // ---- coalesced copy-out of the graph by the window's 16 lanes ----
-  n1 = __shfl(n1, lane & ~(G - 1));
+  // ---- coalesced copy-out of the graph by the window's own lanes ----
   if (valid) {
-    const int64_t nb = o0 + w;
+    const int32_t *hdr = reinterpret_cast<const int32_t *>(slot);
+    const int n1 = hdr[0];
+    const int2 *xi_st = reinterpret_cast<const int2 *>(slot + W.off_region);
+    const uint16_t *ring_st = reinterpret_cast<const uint16_t *>(slot + W.off_region + 8 * (Lr + Lc + 1));
+    const int64_t nb = W.o0 + W.w;
     int2 *gx = a.b.xinfo + nb;
     uint16_t *gr = a.b.ring1 + nb;
     for (int i = 1 + g; i <= n1; i += G) gx[i] = xi_st[i];
     for (int i = g; i < n1; i += G) gr[i] = ring_st[i];
     if (g == 0) {
-      a.b.n1[w] = n1;
-      const int need = maxd + 2;
-      a.b.cls[w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 16 ? 0x80 : 0));   // bit 7: too deep for k_fused_b's ring
-      if (need > 512) a.b.status[w] = 2;
-      if (bad) a.b.status[w] = 3;
-      a.done_a[w] = 1;
+      a.b.n1[W.w] = n1;
+      const int need = hdr[1] + 2;
+      a.b.cls[W.w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 8 ? 0x80 : 0));   // bit 7: too deep for k_fused_b's ring
+      if (need > 512) a.b.status[W.w] = 2;
+      if (hdr[2]) a.b.status[W.w] = 3;
+      a.done_a[W.w] = 1;
     }
   }
   PHASE_STAMP(3);
@@ -283,8 +316,8 @@ __global__ void __launch_bounds__(64) k_fused_a(FusedArgs a)
 // registers, everything else from a 16-deep LDS ring indexed by time that holds each
 // lane's four cells of the last 16 steps as 16-bit (score << 1 | came-from-match).
 
-constexpr int kRingDepth = 16;       // time slots
-constexpr int kRingSlots = 18;       // + slot 16: each lane's column -1 cells, slot 17: "no predecessor"
+constexpr int kRingDepth = 8;        // time slots
+constexpr int kRingSlots = 10;       // + slot 16: each lane's column -1 cells, slot 17: "no predecessor"
 constexpr int kNeg16 = -16383;       // score of the "no predecessor" cells (below any 16-bit-eligible score)
 
 __device__ __forceinline__ int cell16_S(int c) { return c >> 1; }
@@ -309,13 +342,14 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
     n1 = a.b.n1[w];
   }
   const int ns = (Lu + RS - 1) / RS;
-  // slot: [unc symbols][xinfo int2[n1+1]][ring1 u16[n1]][x2y u16[n1]][bnd0 i32[n1+1]][bnd1 i32[n1+1] if ns>1][region]
-  const int off_xi = align_up(Lu, 8);
-  const int off_r1 = off_xi + 8 * (n1 + 1);
+  // slot: [unc symbols][node info u32[n1+1]][ring1 u16[n1]][x2y u16[n1]][bnd0 i16[n1+1]][bnd1 i16[n1+1] if ns>1][region]
+  // node info = d1 (0 = virtual start) | d2 << 4 (0 = none, 15 = virtual) | letter << 8 | flags << 16
+  const int off_xi = align_up(Lu, 4);
+  const int off_r1 = off_xi + 4 * (n1 + 1);
   const int off_x2y = off_r1 + align_up(2 * n1, 4);
   const int off_b0 = off_x2y + align_up(2 * n1, 4);
-  const int off_b1 = off_b0 + 4 * (n1 + 1);
-  const int off_region = align_up(off_b1 + (ns > 1 ? 4 * (n1 + 1) : 0), 8);
+  const int off_b1 = off_b0 + align_up(2 * (n1 + 1), 4);
+  const int off_region = align_up(off_b1 + (ns > 1 ? 2 * (n1 + 1) : 0), 4);
   const int region_bytes = max(ns * n1 * 2 * G, 3 * (n1 + Lu) + 8);
   const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
   valid = valid && (off_region + region_bytes <= a.slot_bytes) && (maxpen * (n1 + Lu + 4) < 16000);
@@ -323,11 +357,11 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
   uint2 *ring = reinterpret_cast<uint2 *>(lds);                 // [kRingDepth][64] x 4 cells of 16 bits
   const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(lds);
   uint8_t *ys = slot;
-  int2 *xinfo = reinterpret_cast<int2 *>(slot + off_xi);
+  uint32_t *xinfo = reinterpret_cast<uint32_t *>(slot + off_xi);
   uint16_t *ring1 = reinterpret_cast<uint16_t *>(slot + off_r1);
   uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + off_x2y);
-  int32_t *bnd0 = reinterpret_cast<int32_t *>(slot + off_b0);
-  int32_t *bnd1 = reinterpret_cast<int32_t *>(slot + off_b1);
+  int16_t *bnd0 = reinterpret_cast<int16_t *>(slot + off_b0);
+  int16_t *bnd1 = reinterpret_cast<int16_t *>(slot + off_b1);
   uint16_t *mv = reinterpret_cast<uint16_t *>(slot + off_region);
   uint8_t *cols_st = slot + off_region;                          // overlays the moves after traceback
 
@@ -336,7 +370,13 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
     const int64_t nb = o0 + w;
     const uint8_t *sy = a.b.sym + o2;
     for (int i = g; i < Lu; i += G) ys[i] = sy[i];
-    for (int i = 1 + g; i <= n1; i += G) xinfo[i] = a.b.xinfo[nb + i];
+    for (int i = 1 + g; i <= n1; i += G) {
+      const int2 xi = a.b.xinfo[nb + i];
+      const int pp1 = xi.x & 0xFFFF, pp2 = (int)((uint32_t)xi.x >> 16);
+      const uint32_t d1 = pp1 == 0 ? 0u : (uint32_t)(i - pp1);                    // <= 6 (ring eligibility)
+      const uint32_t d2 = pp2 == (int)kNone16 ? 0u : pp2 == 0 ? 15u : (uint32_t)(i - pp2);
+      xinfo[i] = d1 | (d2 << 4) | ((uint32_t)(xi.y & 0xFF) << 8) | ((uint32_t)((xi.y >> 8) & 0xFF) << 16);
+    }
     for (int i = g; i < n1; i += G) ring1[i] = a.b.ring1[nb + i];
   }
   __syncthreads();
@@ -344,11 +384,15 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
   if (valid && g == 0) {
     bnd0[0] = 1;                                               // score 0, origin counts as "open"
     for (int jj = 1; jj <= n1; ++jj) {
-      const uint32_t pl = (uint32_t)xinfo[jj].x;
-      const int pp1 = pl & 0xFFFF, pp2 = pl >> 16;
+      const uint32_t inf = xinfo[jj];
+      const int d1 = inf & 15, d2 = (inf >> 4) & 15;
+      const int pp1 = d1 ? jj - d1 : 0;
       int r = cell16_S(bnd0[pp1]) - (pp1 == 0 ? kp.open_x : kp.ext_x);
-      if (pp2 != (int)kNone16) r = max(r, cell16_S(bnd0[pp2]) - (pp2 == 0 ? kp.open_x : kp.ext_x));
-      bnd0[jj] = r << 1;
+      if (d2) {
+        const int pp2 = d2 == 15 ? 0 : jj - d2;
+        r = max(r, cell16_S(bnd0[pp2]) - (pp2 == 0 ? kp.open_x : kp.ext_x));
+      }
+      bnd0[jj] = (int16_t)(r << 1);
     }
   }
   __syncthreads();
@@ -367,8 +411,8 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
   if (a.debug & 1) nsmax = 0;
   for (int s = 0; s < nsmax; ++s) {
     const bool sv = valid && s < ns;
-    const int32_t *bcur = (s & 1) ? bnd1 : bnd0;
-    int32_t *bnext = (s & 1) ? bnd0 : bnd1;
+    const int16_t *bcur = (s & 1) ? bnd1 : bnd0;
+    int16_t *bnext = (s & 1) ? bnd0 : bnd1;
     const int ii0 = RS * s + 4 * g + 1;
     int yl[4], S[4], M[4], Ey[4], colS[4];
 #pragma unroll
@@ -382,40 +426,41 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
     {
       const uint32_t p01 = (uint32_t)((colS[0] << 1) & 0xFFFF) | ((uint32_t)(colS[1] << 1) << 16);
       const uint32_t p23 = (uint32_t)((colS[2] << 1) & 0xFFFF) | ((uint32_t)(colS[3] << 1) << 16);
-      ring[16 * 64 + lane] = make_uint2(p01, p23);
+      ring[kRingDepth * 64 + lane] = make_uint2(p01, p23);
       const uint32_t ng = (uint32_t)((kNeg16 << 1) & 0xFFFF) | ((uint32_t)(kNeg16 << 1) << 16);
-      ring[17 * 64 + lane] = make_uint2(ng, ng);
+      ring[(kRingDepth + 1) * 64 + lane] = make_uint2(ng, ng);
     }
     const bool wr_carry = sv && (s + 1 < ns) && g == G - 1;
     const bool last_strip_row = sv && s == ns - 1 && g == gstar;
-    int2 xi_next = (sv && g == 0 && n1 >= 1) ? xinfo[1] : make_int2(0, 0);
+    uint32_t xi_next = (sv && g == 0 && n1 >= 1) ? xinfo[1] : 0u;
     for (int t = 1; t <= tmax; ++t) {
       const int bc = (sv && t <= n1) ? bcur[t] : 0;
       const int bS = bc >> 1, bEy = bS - ((bc & 1) ? kp.open_y : kp.ext_y);
       const int upEy = shift_in<G>(bEy, Ey[3], g);
       const int jj = t - g;
-      const int2 xi = xi_next;
-      xi_next = (sv && jj >= 0 && jj < n1) ? xinfo[jj + 1] : make_int2(0, 0);
+      const uint32_t xi = xi_next;
+      xi_next = (sv && jj >= 0 && jj < n1) ? xinfo[jj + 1] : 0u;
       const bool act = sv && jj >= 1 && jj <= n1;
-      const int pp1 = xi.x & 0xFFFF, pp2 = (int)((uint32_t)xi.x >> 16);
-      const bool has2 = act && pp2 != (int)kNone16;
+      const int d1i = xi & 15, d2i = (xi >> 4) & 15;
+      const int pp1 = d1i ? jj - d1i : 0, pp2 = d2i == 15 ? 0 : jj - d2i;
+      const bool has2 = act && d2i != 0;
       const int lm1 = (lane - 1) & 63;
       // ---- predecessor cells.  Own four cells at column pp: this lane's ring slot of
       // d = jj - pp steps ago; the cell above them: lane-1's slot one step earlier (the strip
       // border array for the group's first lane).  The virtual start column lives in slot 16,
       // a missing second predecessor reads the very negative cells of slot 17: no value selects. ----
       const int ppa = act ? pp1 : 0;
-      const int sa = (ppa == 0) ? 16 : ((t - (jj - ppa)) & (kRingDepth - 1));
-      const int sat = (ppa == 0) ? 16 : ((t - (jj - ppa) - 1) & (kRingDepth - 1));
-      const int sb = !has2 ? 17 : (pp2 == 0) ? 16 : ((t - (jj - pp2)) & (kRingDepth - 1));
-      const int sbt = !has2 ? 17 : (pp2 == 0) ? 16 : ((t - (jj - pp2) - 1) & (kRingDepth - 1));
+      const int sa = (ppa == 0) ? kRingDepth : ((t - (jj - ppa)) & (kRingDepth - 1));
+      const int sat = (ppa == 0) ? kRingDepth : ((t - (jj - ppa) - 1) & (kRingDepth - 1));
+      const int sb = !has2 ? kRingDepth + 1 : (pp2 == 0) ? kRingDepth : ((t - (jj - pp2)) & (kRingDepth - 1));
+      const int sbt = !has2 ? kRingDepth + 1 : (pp2 == 0) ? kRingDepth : ((t - (jj - pp2) - 1) & (kRingDepth - 1));
       const uint2 c1 = ring[sa * 64 + lane];
       const uint2 c2 = ring[sb * 64 + lane];
       const int r1 = (int16_t)ring16[(sat * 64 + lm1) * 4 + 3];
       const int r2 = (int16_t)ring16[(sbt * 64 + lm1) * 4 + 3];
       const int b1 = bcur[sv ? ppa : 0], b2 = bcur[has2 ? pp2 : 0];
       if (act) {
-        const int xl = xi.y & 0xFF;
+        const int xl = (xi >> 8) & 0xFF;
         const int d1top = ((g == 0) ? b1 : r1) >> 1;
         const int d2top = has2 ? (((g == 0) ? b2 : r2) >> 1) : kNeg16;
         int o1S[4], o1M[4], o2S[4], o2M[4];
@@ -460,15 +505,15 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
         const uint32_t p23 = (uint32_t)(((S[2] << 1) | M[2]) & 0xFFFF) | ((uint32_t)((S[3] << 1) | M[3]) << 16);
         ring[(t & (kRingDepth - 1)) * 64 + lane] = make_uint2(p01, p23);
         mv[(s * n1 + (jj - 1)) * G + g] = (uint16_t)mv16;
-        if (wr_carry) bnext[jj] = (S[3] << 1) | M[3];
-        if (last_strip_row && ((xi.y >> 8) & kFlagFinal)) {
+        if (wr_carry) bnext[jj] = (int16_t)((S[3] << 1) | M[3]);
+        if (last_strip_row && ((xi >> 16) & kFlagFinal)) {
           const int sv2 = (kstar == 0) ? S[0] : (kstar == 1) ? S[1] : (kstar == 2) ? S[2] : S[3];
           if (sv2 > best) { best = sv2; bestx = jj - 1; }      // ties keep the smaller column (:410-417)
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (wr_carry) bnext[0] = (-(kp.open_y + (RS * (s + 1) - 1) * kp.ext_y)) << 1;   // column -1 of the carried row
+    if (wr_carry) bnext[0] = (int16_t)((-(kp.open_y + (RS * (s + 1) - 1) * kp.ext_y)) * 2);   // column -1 of the carried row
     __syncthreads();
   }
 
@@ -489,8 +534,9 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
         if (xo && yo) x2y[x] = (uint16_t)y;
         if (!xo && !yo) { bad = true; break; }
         if (xo) {
-          const uint32_t pl = (uint32_t)xinfo[x + 1].x;
-          x = ((xo == 1) ? (int)(pl & 0xFFFF) : (int)(pl >> 16)) - 1;
+          const uint32_t inf = xinfo[x + 1];
+          const int dd = (xo == 1) ? (int)(inf & 15) : (int)((inf >> 4) & 15);
+          x = (dd == 0 || dd == 15) ? -1 : x - dd;
         }
         if (yo) --y;
       }
@@ -517,8 +563,8 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
           break;
         }
       }
-      const int xv = xinfo[ix + 1].y;
-      const int letter = xv & 0xFF, fl = xv >> 8;
+      const uint32_t xv = xinfo[ix + 1];
+      const int letter = (xv >> 8) & 0xFF, fl = (int)(xv >> 16);
       bool fused = false;
       if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
         if (letter == ys[iy]) fused = true;
@@ -557,18 +603,18 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
 
 // ---------------------------------------------------------------- launcher ---
 
-template <int G>
+template <int G, int WV>
 static int launch_a_t(const FusedArgs &a, hipStream_t st)
 {
-  constexpr int NW = 64 / G;
+  constexpr int NB = WV * 64 / G;     // windows per block
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_a<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_a<G, WV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
     attr = true;
   }
-  hipLaunchKernelGGL(k_fused_a<G>, dim3((unsigned)((a.nlist + NW - 1) / NW)), dim3(64), NW * a.slot_bytes, st, a);
+  hipLaunchKernelGGL((k_fused_a<G, WV>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64 * WV), NB * a.slot_bytes, st, a);
   return 0;
 }
 
@@ -591,7 +637,11 @@ static int launch_b_t(const FusedArgs &a, hipStream_t st)
 int launch_fused_a(const FusedArgs &a, int G, hipStream_t st)
 {
   if (a.nlist <= 0) return 0;
-  return G == 16 ? launch_a_t<16>(a, st) : G == 32 ? launch_a_t<32>(a, st) : launch_a_t<64>(a, st);
+  // several waves per block where the block's slots fit comfortably: the serial stage of all
+  // its windows is then shared by one wave
+  if (G == 16) return 16 * a.slot_bytes <= 72 * 1024 ? launch_a_t<16, 4>(a, st) : launch_a_t<16, 1>(a, st);
+  if (G == 32) return 8 * a.slot_bytes <= 72 * 1024 ? launch_a_t<32, 4>(a, st) : launch_a_t<32, 1>(a, st);
+  return launch_a_t<64, 1>(a, st);
 }
 
 int launch_fused_b(const FusedArgs &a, int G, hipStream_t st)

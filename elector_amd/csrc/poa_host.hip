@@ -381,9 +381,11 @@ static const int64_t kMovesBudgetDwords = (int64_t)3 << 28;   // 3 GiB
 static const int64_t kBumpBudgetDwords = (int64_t)1 << 28;    // 1 GiB
 
 // fused-kernel launch classes: (lanes per window, LDS slot bytes per window)
-static const int kBins = 20;
-static const int kBinG[kBins] = {16, 16, 16, 16, 16, 32, 32, 32, 32, 32, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64};
-static const int kSlot[kBins] = {2048, 3072, 4096, 6144, 8192, 4096, 6144, 8192, 12288, 16384, 24576,
+static const int kBins = 28;
+static const int kBinG[kBins] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32,
+                                 64, 64, 64, 64, 64, 64, 64, 64, 64};
+static const int kSlot[kBins] = {1536, 2048, 2560, 3072, 3584, 4096, 5120, 6144, 8192,
+                                 3072, 4096, 5120, 6144, 7168, 8192, 10240, 12288, 16384, 24576,
                                  8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072};
 
 // lane-per-window classes: reference length cap (columns of alignment #1) and node cap of
@@ -446,7 +448,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   std::vector<int8_t> lcls((size_t)n, -1);
   // lane-per-window kernels: experimental, slower than the fused kernels at present
   const bool use_lane = use_fused && std::getenv("ELECTOR_LANE") != nullptr;
-  int64_t key_cnt[NB + 1] = {0}, bin_cnt[kBins] = {0}, n_generic = 0, lane_cnt[kLaneClasses] = {0};
+  int64_t key_cnt[NB + 1] = {0}, bin_cnt[kBins] = {0}, n_generic = 0, lane_cnt[kLaneClasses] = {0}, bin_need_a[kBins] = {0};
   auto key = [&](int64_t w) {
     const int64_t m = std::max(off[3 * w + 1] - off[3 * w], off[3 * w + 3] - off[3 * w + 2]);
     int k = (int)(m >> 3);
@@ -464,7 +466,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   std::atomic<int> bad_offsets(0);
   {
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
-    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + kLaneClasses + 1, 0));
+    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + kLaneClasses + 1 + kBins, 0));
     auto work = [&](int t) {
       const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
       int64_t *cnt = tcnt[(size_t)t].data();
@@ -486,10 +488,15 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           const int rows = (int)std::max(lc, lu);
           for (int gi = rows <= 64 ? 0 : rows <= 128 ? 1 : 2; gi < 3 && bin[(size_t)w] < 0; ++gi) {
             const int G = 16 << gi;
-            const int need = std::max(fused_a_slot_need((int)lr, (int)lc, G),
-                                      fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G));
+            const int need_a = fused_a_slot_need((int)lr, (int)lc, G);
+            const int need = std::max(need_a, fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G));
             for (int b = g_first[gi]; b < g_end[gi]; ++b)
-              if (need <= kSlot[b]) { bin[(size_t)w] = (int8_t)b; break; }
+              if (need <= kSlot[b]) {
+                bin[(size_t)w] = (int8_t)b;
+                int64_t &mx = cnt[NB + kBins + kLaneClasses + 1 + b];      // alignment #1 needs less than the class slot
+                mx = std::max<int64_t>(mx, need_a);
+                break;
+              }
           }
         }
         if (bin[(size_t)w] >= 0) cnt[NB + bin[(size_t)w]]++;
@@ -510,6 +517,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       for (int b = 0; b < kBins; ++b) bin_cnt[b] += tcnt[(size_t)t][(size_t)(NB + b)];
       for (int k = 0; k < kLaneClasses; ++k) lane_cnt[k] += tcnt[(size_t)t][(size_t)(NB + kBins + k)];
       n_generic += tcnt[(size_t)t][(size_t)(NB + kBins + kLaneClasses)];
+      for (int b = 0; b < kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + kLaneClasses + 1 + b)]);
     }
   }
   if (bad_offsets.load()) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
@@ -690,9 +698,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     int used = 0;
     for (int k = kLaneClasses - 1; k >= 0; --k) {
       if (!lane_cnt[k]) continue;
-      hipStream_t sx = c->aux[used % elector_ctx::kAux];
-      if (used < elector_ctx::kAux) HIPCHK(c, hipStreamWaitEvent(sx, c->fork, 0));
-      ++used;
+      hipStream_t sx = c->aux[3];
       LaneArgs la;
       la.b = a;
       la.list = d_lists + lane_first[k];
@@ -711,11 +717,14 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       if (launch_lane_b(la, sx)) return fail(c, ELECTOR_E_HIP, "lane kernel attribute");
       timed_end(c, sx);
     }
-    for (int b = kBins - 1; b >= 0; --b) {          // long-running big-window classes first
+    // one stream per group size: the few long-running big-window launches (G = 64) form one
+    // chain that overlaps with the bulk classes on the other streams (the runtime maps streams
+    // to a handful of hardware queues, so more streams than this do not run concurrently)
+    used = std::max(used, 4);
+    for (int k = 0; k < 4; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
+    for (int b = kBins - 1; b >= 0; --b) {          // within a chain: big classes first
       if (!bin_cnt[b]) continue;
-      hipStream_t sx = c->aux[used % elector_ctx::kAux];
-      if (used < elector_ctx::kAux) HIPCHK(c, hipStreamWaitEvent(sx, c->fork, 0));
-      ++used;
+      hipStream_t sx = c->aux[kBinG[b] == 64 ? 0 : kBinG[b] == 32 ? 1 : 2];
       FusedArgs fa;
       fa.b = a;
       fa.list = d_lists + bin_first[b];
@@ -725,9 +734,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       fa.done_b = d_done_b;
       fa.rowinit = reinterpret_cast<int32_t *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b);   // phase stamps (debug)
       fa.debug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
+      fa.slot_bytes = (int)((bin_need_a[b] + 127) & ~(int64_t)127);   // alignment #1: the class's own maximum
       timed_begin(c, 0, sx);
       if (launch_fused_a(fa, kBinG[b], sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
       timed_end(c, sx);
+      fa.slot_bytes = kSlot[b];
       timed_begin(c, 1, sx);
       if (launch_fused_b(fa, kBinG[b], sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
       timed_end(c, sx);
