@@ -114,7 +114,8 @@ __host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G)
   o += (2 * (n1 + 1) + 3) & ~3;
   o += (ns > 1 ? 2 * (n1 + 1) : 0);
   o = (o + 3) & ~3;
-  const int mv = ns * n1 * 2 * G, st = 3 * (n1 + Lu) + 8;
+  // moves + ordinal bytes of the two-predecessor nodes (estimated: one node in six)
+  const int mv = ns * n1 * G + (4 + n1 / 6) * ns * G, st = 3 * (n1 + Lu) + 8;
   return o + (mv > st ? mv : st);
 }
 

@@ -350,9 +350,11 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
   const int off_b0 = off_x2y + align_up(2 * n1, 4);
   const int off_b1 = off_b0 + align_up(2 * (n1 + 1), 4);
   const int off_region = align_up(off_b1 + (ns > 1 ? 2 * (n1 + 1) : 0), 4);
-  const int region_bytes = max(ns * n1 * 2 * G, 3 * (n1 + Lu) + 8);
+  // region = moves (1 byte per lane and column: 4 cells x 2 bits) + predecessor-ordinal bytes of the
+  // K2 nodes that have two predecessors; reused after the traceback for the staged MSA columns
+  const int region_min = max(ns * n1 * G, 3 * (n1 + Lu) + 8);
   const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
-  valid = valid && (off_region + region_bytes <= a.slot_bytes) && (maxpen * (n1 + Lu + 4) < 16000);
+  valid = valid && (off_region + region_min <= a.slot_bytes) && (maxpen * (n1 + Lu + 4) < 16000);
   uint8_t *slot = lds + 64 * 8 * kRingSlots + q * a.slot_bytes;
   uint2 *ring = reinterpret_cast<uint2 *>(lds);                 // [kRingDepth][64] x 4 cells of 16 bits
   const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(lds);
@@ -362,7 +364,8 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
   uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + off_x2y);
   int16_t *bnd0 = reinterpret_cast<int16_t *>(slot + off_b0);
   int16_t *bnd1 = reinterpret_cast<int16_t *>(slot + off_b1);
-  uint16_t *mv = reinterpret_cast<uint16_t *>(slot + off_region);
+  uint8_t *mv = slot + off_region;
+  uint8_t *ordb = mv + ns * n1 * G;                              // [K2][ns][G]
   uint8_t *cols_st = slot + off_region;                          // overlays the moves after traceback
 
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
@@ -381,11 +384,13 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
   }
   __syncthreads();
   // virtual row -1 over the graph (align_lpo_po2.c:275-286): gaps along x from the origin
+  int k2n = 0;
   if (valid && g == 0) {
     bnd0[0] = 1;                                               // score 0, origin counts as "open"
     for (int jj = 1; jj <= n1; ++jj) {
-      const uint32_t inf = xinfo[jj];
+      uint32_t inf = xinfo[jj];
       const int d1 = inf & 15, d2 = (inf >> 4) & 15;
+      if (d2) { inf |= (uint32_t)min(k2n, 255) << 24; xinfo[jj] = inf; ++k2n; }   // index among the two-predecessor nodes
       const int pp1 = d1 ? jj - d1 : 0;
       int r = cell16_S(bnd0[pp1]) - (pp1 == 0 ? kp.open_x : kp.ext_x);
       if (d2) {
@@ -396,6 +401,9 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
     }
   }
   __syncthreads();
+  // the ordinal bytes must fit too (their count is only known now)
+  k2n = __shfl(k2n, lane & ~(G - 1));
+  valid = valid && k2n <= 255 && (off_region + max(ns * n1 * G + k2n * ns * G, 3 * (n1 + Lu) + 8) <= a.slot_bytes);
 
   PHASE_STAMP(8);
   int tmax = valid ? n1 + G - 1 : 0, nsmax = valid ? ns : 0;
@@ -476,7 +484,7 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
         }
         // ---- the four cells, top to bottom ----
         int insY = upEy, dt1 = d1top, dt2 = d2top;
-        uint32_t mv16 = 0;
+        uint32_t mv8 = 0, sec4 = 0;
         int nS[4], nM[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -491,9 +499,10 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
           const bool xw = insX > insY;
           const int Sn = max(mat, mx);
           // x-ordinal 1/2 (+ y-ordinal bit 2 on a match), or the lone y step
-          const uint32_t second = (m ? pm2 : px2) ? 1u : 0u;
-          const uint32_t nib = m ? (kMoveX1 | kMoveY) + second : (xw ? kMoveX1 + second : (uint32_t)kMoveY);
-          mv16 |= nib << (4 * k);
+          // 2 bits per cell: bit 0 = step along x, bit 1 = step along y; which of two predecessors
+          // was taken goes to the node's ordinal byte
+          mv8 |= (m ? 3u : (xw ? 1u : 2u)) << (2 * k);
+          sec4 |= ((m ? pm2 : px2) ? 1u : 0u) << k;
           nS[k] = Sn; nM[k] = m ? 1 : 0;
           insY = Sn - (m ? kp.open_y : kp.ext_y);
           dt1 = o1S[k]; dt2 = o2S[k];
@@ -504,7 +513,8 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
         const uint32_t p01 = (uint32_t)(((S[0] << 1) | M[0]) & 0xFFFF) | ((uint32_t)((S[1] << 1) | M[1]) << 16);
         const uint32_t p23 = (uint32_t)(((S[2] << 1) | M[2]) & 0xFFFF) | ((uint32_t)((S[3] << 1) | M[3]) << 16);
         ring[(t & (kRingDepth - 1)) * 64 + lane] = make_uint2(p01, p23);
-        mv[(s * n1 + (jj - 1)) * G + g] = (uint16_t)mv16;
+        mv[(s * n1 + (jj - 1)) * G + g] = (uint8_t)mv8;
+        if (has2) ordb[((xi >> 24) * ns + s) * G + g] = (uint8_t)sec4;
         if (wr_carry) bnext[jj] = (int16_t)((S[3] << 1) | M[3]);
         if (last_strip_row && ((xi >> 16) & kFlagFinal)) {
           const int sv2 = (kstar == 0) ? S[0] : (kstar == 1) ? S[1] : (kstar == 2) ? S[2] : S[3];
@@ -529,13 +539,15 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
       int x = bestx, y = Lu - 1, guard = n1 + Lu + 2;
       while (x >= 0 && y >= 0 && guard-- > 0) {
         const int r = y % RS;
-        const uint32_t nib = (mv[((y / RS) * n1 + x) * G + (r >> 2)] >> (4 * (r & 3))) & 15u;
-        const int xo = nib & 3, yo = nib >> 2;
+        const uint32_t two = (mv[((y / RS) * n1 + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
+        const int xo = two & 1, yo = two >> 1;
         if (xo && yo) x2y[x] = (uint16_t)y;
         if (!xo && !yo) { bad = true; break; }
         if (xo) {
           const uint32_t inf = xinfo[x + 1];
-          const int dd = (xo == 1) ? (int)(inf & 15) : (int)((inf >> 4) & 15);
+          const int d2v = (inf >> 4) & 15;
+          const int sec = d2v ? (ordb[((inf >> 24) * ns + (y / RS)) * G + (r >> 2)] >> (r & 3)) & 1 : 0;
+          const int dd = sec ? d2v : (int)(inf & 15);
           x = (dd == 0 || dd == 15) ? -1 : x - dd;
         }
         if (yo) --y;
