@@ -5,14 +5,15 @@
     (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
 A *step* is one pass of the hot path (symbolize -> alignment #1 -> fusion ->
-alignment #2 -> fusion + MSA columns) over one batch of window triples that is
+alignment #2 -> fusion + MSA columns -> merge of each read's windows -> per-read
+integer counters back on the host) over one batch of window triples that is
 already resident in HBM.  The batch is what ELECTOR's own batch protocol hands
 to its POA engine: the windows of `--reads` synthetic long reads
 (BASELINE.json configs[1] profile: E. coli 30X SimLord-like PacBio reads, 15 %
 error, LoRDEC-like 1 % corrected), cut by this repository's reference-compatible
 splitter on the host before the timed region.  Weak scaling: every rank
 processes its own shard of reads (independent triples, no data-path
-collective); rank 0 gathers the per-read column counters over RCCL at the end.
+collective); rank 0 gathers the per-read integer counters over RCCL once per step.
 
 Prints ONE JSON line (rank 0).  `value` = reference-read bases of all ranks per
 second of the slowest rank.  `roofline` prices the dominant kernel against HBM
@@ -138,12 +139,31 @@ def main():
     d_ncol = torch.empty(n, dtype=torch.int32, device=dev)
     d_status = torch.empty(n, dtype=torch.int32, device=dev)
     eng = PoaEngine(local)
+    # one msa.fa record (piece) per read, one piece per read: the synthetic corrected reads are not split
+    piece_first = win.read_first
+    read_first = np.arange(win.n_reads + 1, dtype=np.int64)
+    from elector_amd import distributed as edist
+    from elector_amd._capi import ES_NCOUNTERS
+
+    pending = []
+
+    def collect():
+        """per-read counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
+        counters, _ = eng.msa_stats_collect(pending.pop(0))
+        return edist.gather_rows(counters) if world > 1 else counters
 
     def step():
+        """Queue one step (windows in HBM -> POA kernels -> merge -> counters -> pinned host memory),
+        then hand out the counters of the step before it: the host prepares step i+1 while the GPU
+        still works on step i, as a run over many 10,001-read batches would."""
         eng.align_device(d_bases, off, d_cols, d_ncol, d_status)
+        pending.append(eng.msa_stats_enqueue(n, d_cols, d_ncol, d_status, piece_first, read_first))
+        return collect() if len(pending) > 1 else None
 
     for _ in range(args.warmup):
         step()
+    while pending:
+        collect()
     eng.sync()
     eng.timing_enable(True)
     eng.timing_reset()
@@ -156,6 +176,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    while pending:
+        counters = collect()                     # every step's counters are on the host before the clock stops
     eng.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -172,23 +194,12 @@ def main():
     t_dp1, k_dp1 = eng.timing_read(0)
     t_dp2, k_dp2 = eng.timing_read(1)
     t_oth, _ = eng.timing_read(2)
-    # per-read counters (column count per read) -> rank 0 over RCCL
-    read_cols = np.add.reduceat(ncol, win.read_first[:-1]) if n else np.zeros(0, dtype=np.int64)
+    t_st, _ = eng.timing_read(3)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([read_bases, n, cells1 + cells2], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        mine = torch.from_numpy(read_cols).to(dev)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([mine.numel()], dtype=torch.int64, device=dev))
-        cap = int(max(s.item() for s in sizes))
-        padded = torch.zeros(cap, dtype=torch.int64, device=dev)
-        padded[: mine.numel()] = mine
-        gathered = [torch.zeros(cap, dtype=torch.int64, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(padded, gathered, dst=0)
-        if rank == 0:
-            read_cols = np.concatenate([g[: int(s.item())].cpu().numpy() for g, s in zip(gathered, sizes)])
     dt_max = float(tmax.item())
     bases_all, windows_all, cells_all = (int(x) for x in tot.tolist())
 
@@ -219,13 +230,15 @@ def main():
             "kernel_ms_per_step": {"alignment1_stage": round(t_dp1 / args.steps, 3),
                                    "alignment2_stage": round(t_dp2 / args.steps, 3),
                                    "other": round(t_oth / args.steps, 3),
+                                   "merge_and_counters": round(t_st / args.steps, 3),
                                    "note": "sum of per-launch HIP-event times; size classes overlap on 8 streams"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": int(traffic) if traffic else None,
                          "launches": int(launches), "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch)},
-            "reads_gathered": int(len(read_cols)),
+            "reads_gathered": int(counters.shape[0]),
+            "counters_checksum": int(counters[:, :ES_NCOUNTERS - 1].sum()),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(win, lr, args.cpu_seconds)

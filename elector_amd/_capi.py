@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libelector_poa.so")
 ELECTOR_MAX_SYMBOL = 32
 ELECTOR_MAX_GAPTAB = 64
 ELECTOR_MAX_SEQ = 16384
+ES_NCOUNTERS = 25          # include/elector_stats.h
 
 E_WINDOW = -7
 W_OK, W_EMPTY, W_TOOLONG, W_INTERNAL = 0, 1, 2, 3
@@ -36,6 +37,9 @@ EXPORTS = [
     "elector_poa_batch", "elector_poa_batch_device", "elector_ctx_sync",
     "elector_ctx_timing_enable", "elector_ctx_timing_read", "elector_ctx_timing_reset",
     "elector_ctx_last_po_sizes",
+    "elector_stats_batch", "elector_msa_stats_device", "elector_msa_stats_enqueue", "elector_msa_stats_collect",
+    "elector_msa_rows_fetch", "elector_homopolymer_pairs",
+    "elector_split_reads", "elector_windows_free", "elector_merge_windows", "elector_msa_free",
 ]
 
 _lib = None
@@ -56,6 +60,13 @@ def lib():
         raise RuntimeError(
             "HIP library %s is missing: run `python -m elector_amd.build` "
             "(this package has no CPU fallback)" % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64, and a process that loads the
+    # system one first leaves torch without devices.  Let torch (when installed) load its copy first;
+    # the library then binds to that same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.elector_version.restype = C.c_char_p
@@ -77,5 +88,9 @@ def lib():
     L.elector_ctx_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]
     L.elector_ctx_timing_reset.argtypes = [vp]
     L.elector_ctx_last_po_sizes.argtypes = [vp, i64, vp]
+    L.elector_msa_stats_device.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64]
+    L.elector_msa_rows_fetch.argtypes = [vp, i64, vp, vp]
+    L.elector_msa_stats_enqueue.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp]
+    L.elector_msa_stats_collect.argtypes = [vp, i64, vp, vp, vp, vp, i64]
     _lib = L
     return L

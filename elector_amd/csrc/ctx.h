@@ -47,6 +47,21 @@ struct HostPinned {
 
 struct TimedSpan { hipEvent_t a, b; int kind; };
 
+// one merge + statistics job of the device pipeline (elector_msa_stats_enqueue / _collect)
+struct StatsSlot {
+  DevBuf rows, rowoff, cols, first, clips, cnt, mask, woff;
+  HostPinned h;                 // [overflow flag, pad to 16][counters][cols][inputs]
+  hipEvent_t done = nullptr;
+  int64_t n_pieces = 0, n_reads = 0, total = 0, last_piece = 0;
+  bool has_clips = false;
+  void release()
+  {
+    rows.release(); rowoff.release(); cols.release(); first.release(); clips.release(); cnt.release();
+    mask.release(); woff.release(); h.release();
+    if (done) { (void)hipEventDestroy(done); done = nullptr; }
+  }
+};
+
 }  // namespace elector
 
 struct elector_ctx {
@@ -72,13 +87,18 @@ struct elector_ctx {
   elector::DevBuf d_bases, d_cols, d_ncol, d_status, d_scores, d_rowoff, d_rows;
   elector::HostPinned h_meta;
   // statistics workspace
-  elector::DevBuf d_st_rows, d_st_rowoff, d_st_cols, d_st_first, d_st_clips, d_st_cnt, d_st_mask, d_st_scr, d_st_scroff;
+  elector::DevBuf d_st_rows, d_st_rowoff, d_st_cols, d_st_first, d_st_clips, d_st_cnt, d_st_mask, d_st_scr, d_st_dense, d_st_outoff;
+  static constexpr int kStatsSlots = 2;
+  elector::StatsSlot st_slot[kStatsSlots];
+  int st_head = 0, st_tail = 0, st_inflight = 0, st_last = -1;
   // timing
   bool timing = false;
   std::vector<elector::TimedSpan> spans;
-  double ms_acc[3] = {0, 0, 0};
-  int64_t launches_acc[3] = {0, 0, 0};
-  int64_t last_n = 0;
+  static constexpr int kTimedKinds = 4;   // alignment #1 stage, alignment #2 stage, other POA kernels, merge + statistics
+  double ms_acc[kTimedKinds] = {};
+  int64_t launches_acc[kTimedKinds] = {};
+  int64_t last_n = 0;          // windows of the last POA batch (their offsets stay in d_off)
+  int64_t last_total = 0;      // bases of that batch
 };
 
 inline int elector_fail(elector_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
@@ -88,6 +108,23 @@ inline int elector_fail(elector_ctx *c, int code, const char *what, hipError_t e
     if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
   }
   return code;
+}
+
+// HIP-event brackets around kernel launches, summed per kind by elector_ctx_timing_read
+inline void timed_begin(elector_ctx *c, int kind, hipStream_t st)
+{
+  if (!c->timing) return;
+  elector::TimedSpan s;
+  s.kind = kind;
+  if (hipEventCreate(&s.a) != hipSuccess) return;
+  if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
+  (void)hipEventRecord(s.a, st);
+  c->spans.push_back(s);
+}
+inline void timed_end(elector_ctx *c, hipStream_t st)
+{
+  if (!c->timing || c->spans.empty()) return;
+  (void)hipEventRecord(c->spans.back().b, st);
 }
 
 #define HIPCHK(ctx, call)                                                        \

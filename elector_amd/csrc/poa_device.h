@@ -107,7 +107,7 @@ __host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G)
 __host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G)
 {
   const int ns = (Lu + 4 * G - 1) / (4 * G);
-  int o = (Lu + 3) & ~3;
+  int o = 16 + ((Lu + 3) & ~3);
   o += 4 * (n1 + 1);
   o += (2 * n1 + 3) & ~3;
   o += (2 * n1 + 3) & ~3;

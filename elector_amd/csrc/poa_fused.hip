@@ -21,6 +21,7 @@
 // Reference behaviour restated: align_lpo_po2.c:178-433 (DP, tie-breaks),
 // :108-168 (traceback), lpo.c:413-463,602-656 (fusion), lpo_format.c:337-393 (rows).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "poa_device.h"
 
 namespace elector {
@@ -322,56 +323,77 @@ constexpr int kNeg16 = -16383;       // score of the "no predecessor" cells (bel
 
 __device__ __forceinline__ int cell16_S(int c) { return c >> 1; }
 
+// one window of k_fused_b and its LDS slot layout:
+// [header 16 B: k2 / ncol, ok, best, bestx][unc symbols][node info u32[n1+1]][ring1 u16[n1]][x2y u16[n1]]
+// [bnd0 i16[n1+1]][bnd1 i16[n1+1] if ns>1][region]
+// node info = d1 (0 = virtual start) | d2 << 4 (0 = none, 15 = virtual) | letter << 8 | flags << 16 | k2 << 24
+// region = moves (1 byte per lane and column: 4 cells x 2 bits) + predecessor-ordinal bytes of the
+// K2 nodes that have two predecessors; reused after the traceback for the staged MSA columns
+struct WinB {
+  bool valid;
+  uint32_t w;
+  int64_t o0, o2;
+  int n1, Lu, ns, off_xi, off_r1, off_x2y, off_b0, off_b1, off_region;
+};
+
 template <int G>
-__global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
+__device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
+{
+  constexpr int RS = 4 * G;
+  const KParams kp = a.b.kp;
+  WinB v;
+  v.valid = li < a.nlist;
+  v.w = v.valid ? a.list[li] : 0;
+  v.valid = v.valid && a.b.status[v.w] == 0 && a.done_a[v.w] != 0 && a.b.cls[v.w] == 0;
+  v.o0 = 0; v.o2 = 0; v.n1 = 0; v.Lu = 0;
+  if (v.valid) {
+    v.o0 = a.b.off[3 * (int64_t)v.w];
+    v.o2 = a.b.off[3 * (int64_t)v.w + 2];
+    v.Lu = (int)(a.b.off[3 * (int64_t)v.w + 3] - v.o2);
+    v.n1 = a.b.n1[v.w];
+  }
+  v.ns = (v.Lu + RS - 1) / RS;
+  v.off_xi = 16 + align_up(v.Lu, 4);
+  v.off_r1 = v.off_xi + 4 * (v.n1 + 1);
+  v.off_x2y = v.off_r1 + align_up(2 * v.n1, 4);
+  v.off_b0 = v.off_x2y + align_up(2 * v.n1, 4);
+  v.off_b1 = v.off_b0 + align_up(2 * (v.n1 + 1), 4);
+  v.off_region = align_up(v.off_b1 + (v.ns > 1 ? 2 * (v.n1 + 1) : 0), 4);
+  const int region_min = max(v.ns * v.n1 * G, 3 * (v.n1 + v.Lu) + 8);
+  const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
+  v.valid = v.valid && (v.off_region + region_min <= a.slot_bytes) && (maxpen * (v.n1 + v.Lu + 4) < 16000);
+  return v;
+}
+
+template <int G, int WV>
+__global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NW = 64 / G, RS = 4 * G;     // windows per wave, rows per strip
-  const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
-  const int64_t li = NW * (int64_t)blockIdx.x + q;
-  bool valid = li < a.nlist;
-  const uint32_t w = valid ? a.list[li] : 0;
-  valid = valid && a.b.status[w] == 0 && a.done_a[w] != 0 && a.b.cls[w] == 0;
-  int64_t o0 = 0, o2 = 0;
-  int n1 = 0, Lu = 0;
-  if (valid) {
-    o0 = a.b.off[3 * (int64_t)w];
-    o2 = a.b.off[3 * (int64_t)w + 2];
-    Lu = (int)(a.b.off[3 * (int64_t)w + 3] - o2);
-    n1 = a.b.n1[w];
-  }
-  const int ns = (Lu + RS - 1) / RS;
-  // slot: [unc symbols][node info u32[n1+1]][ring1 u16[n1]][x2y u16[n1]][bnd0 i16[n1+1]][bnd1 i16[n1+1] if ns>1][region]
-  // node info = d1 (0 = virtual start) | d2 << 4 (0 = none, 15 = virtual) | letter << 8 | flags << 16
-  const int off_xi = align_up(Lu, 4);
-  const int off_r1 = off_xi + 4 * (n1 + 1);
-  const int off_x2y = off_r1 + align_up(2 * n1, 4);
-  const int off_b0 = off_x2y + align_up(2 * n1, 4);
-  const int off_b1 = off_b0 + align_up(2 * (n1 + 1), 4);
-  const int off_region = align_up(off_b1 + (ns > 1 ? 2 * (n1 + 1) : 0), 4);
-  // region = moves (1 byte per lane and column: 4 cells x 2 bits) + predecessor-ordinal bytes of the
-  // K2 nodes that have two predecessors; reused after the traceback for the staged MSA columns
-  const int region_min = max(ns * n1 * G, 3 * (n1 + Lu) + 8);
-  const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
-  valid = valid && (off_region + region_min <= a.slot_bytes) && (maxpen * (n1 + Lu + 4) < 16000);
-  uint8_t *slot = lds + 64 * 8 * kRingSlots + q * a.slot_bytes;
-  uint2 *ring = reinterpret_cast<uint2 *>(lds);                 // [kRingDepth][64] x 4 cells of 16 bits
-  const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(lds);
-  uint8_t *ys = slot;
-  uint32_t *xinfo = reinterpret_cast<uint32_t *>(slot + off_xi);
-  uint16_t *ring1 = reinterpret_cast<uint16_t *>(slot + off_r1);
-  uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + off_x2y);
-  int16_t *bnd0 = reinterpret_cast<int16_t *>(slot + off_b0);
-  int16_t *bnd1 = reinterpret_cast<int16_t *>(slot + off_b1);
-  uint8_t *mv = slot + off_region;
+  const int sidx = wv * NW + q;
+  const WinB W = load_win_b<G>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
+  bool valid = W.valid;
+  const uint32_t w = W.w;
+  const int64_t o0 = W.o0;
+  const int n1 = W.n1, Lu = W.Lu, ns = W.ns;
+  uint8_t *slot = lds + WV * 64 * 8 * kRingSlots + sidx * a.slot_bytes;
+  uint2 *ring = reinterpret_cast<uint2 *>(lds + wv * 64 * 8 * kRingSlots);   // this wave's [kRingSlots][64] x 4 cells of 16 bits
+  const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(ring);
+  int32_t *hdr = reinterpret_cast<int32_t *>(slot);
+  uint8_t *ys = slot + 16;
+  uint32_t *xinfo = reinterpret_cast<uint32_t *>(slot + W.off_xi);
+  uint16_t *ring1 = reinterpret_cast<uint16_t *>(slot + W.off_r1);
+  int16_t *bnd0 = reinterpret_cast<int16_t *>(slot + W.off_b0);
+  int16_t *bnd1 = reinterpret_cast<int16_t *>(slot + W.off_b1);
+  uint8_t *mv = slot + W.off_region;
   uint8_t *ordb = mv + ns * n1 * G;                              // [K2][ns][G]
-  uint8_t *cols_st = slot + off_region;                          // overlays the moves after traceback
 
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
   if (valid) {
     const int64_t nb = o0 + w;
-    const uint8_t *sy = a.b.sym + o2;
+    const uint8_t *sy = a.b.sym + W.o2;
     for (int i = g; i < Lu; i += G) ys[i] = sy[i];
     for (int i = 1 + g; i <= n1; i += G) {
       const int2 xi = a.b.xinfo[nb + i];
@@ -383,27 +405,37 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
     for (int i = g; i < n1; i += G) ring1[i] = a.b.ring1[nb + i];
   }
   __syncthreads();
-  // virtual row -1 over the graph (align_lpo_po2.c:275-286): gaps along x from the origin
-  int k2n = 0;
-  if (valid && g == 0) {
-    bnd0[0] = 1;                                               // score 0, origin counts as "open"
-    for (int jj = 1; jj <= n1; ++jj) {
-      uint32_t inf = xinfo[jj];
-      const int d1 = inf & 15, d2 = (inf >> 4) & 15;
-      if (d2) { inf |= (uint32_t)min(k2n, 255) << 24; xinfo[jj] = inf; ++k2n; }   // index among the two-predecessor nodes
-      const int pp1 = d1 ? jj - d1 : 0;
-      int r = cell16_S(bnd0[pp1]) - (pp1 == 0 ? kp.open_x : kp.ext_x);
-      if (d2) {
-        const int pp2 = d2 == 15 ? 0 : jj - d2;
-        r = max(r, cell16_S(bnd0[pp2]) - (pp2 == 0 ? kp.open_x : kp.ext_x));
+  // ---- per-window prologue by the first lanes of wave 0: virtual row -1 over the graph
+  // (align_lpo_po2.c:275-286), index of the two-predecessor nodes, final fit check ----
+  if (threadIdx.x < NW * WV) {
+    const WinB V = load_win_b<G>(a, (int64_t)(NW * WV) * blockIdx.x + threadIdx.x);
+    uint8_t *vs = lds + WV * 64 * 8 * kRingSlots + threadIdx.x * a.slot_bytes;
+    int32_t *vh = reinterpret_cast<int32_t *>(vs);
+    int k2n = 0;
+    bool ok = V.valid;
+    if (ok) {
+      uint32_t *vxi = reinterpret_cast<uint32_t *>(vs + V.off_xi);
+      int16_t *vb0 = reinterpret_cast<int16_t *>(vs + V.off_b0);
+      vb0[0] = 1;                                              // score 0, origin counts as "open"
+      for (int jj = 1; jj <= V.n1; ++jj) {
+        uint32_t inf = vxi[jj];
+        const int d1 = inf & 15, d2 = (inf >> 4) & 15;
+        if (d2) { inf |= (uint32_t)min(k2n, 255) << 24; vxi[jj] = inf; ++k2n; }
+        const int pp1 = d1 ? jj - d1 : 0;
+        int r = cell16_S(vb0[pp1]) - (pp1 == 0 ? kp.open_x : kp.ext_x);
+        if (d2) {
+          const int pp2 = d2 == 15 ? 0 : jj - d2;
+          r = max(r, cell16_S(vb0[pp2]) - (pp2 == 0 ? kp.open_x : kp.ext_x));
+        }
+        vb0[jj] = (int16_t)(r << 1);
       }
-      bnd0[jj] = (int16_t)(r << 1);
+      ok = k2n <= 255 &&
+           (V.off_region + max(V.ns * V.n1 * G + k2n * V.ns * G, 3 * (V.n1 + V.Lu) + 8) <= a.slot_bytes);
     }
+    vh[0] = k2n; vh[1] = ok ? 1 : 0; vh[2] = kNeg; vh[3] = -1;
   }
   __syncthreads();
-  // the ordinal bytes must fit too (their count is only known now)
-  k2n = __shfl(k2n, lane & ~(G - 1));
-  valid = valid && k2n <= 255 && (off_region + max(ns * n1 * G + k2n * ns * G, 3 * (n1 + Lu) + 8) <= a.slot_bytes);
+  valid = valid && hdr[1] != 0;
 
   PHASE_STAMP(8);
   int tmax = valid ? n1 + G - 1 : 0, nsmax = valid ? ns : 0;
@@ -524,16 +556,30 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
       __builtin_amdgcn_wave_barrier();
     }
     if (wr_carry) bnext[0] = (int16_t)((-(kp.open_y + (RS * (s + 1) - 1) * kp.ext_y)) * 2);   // column -1 of the carried row
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
 
+  if (valid && g == gstar) { hdr[2] = best; hdr[3] = bestx; }
+  __syncthreads();
+
   PHASE_STAMP(9);
-  // ---- traceback #2 + fusion #2 + MSA columns: one lane per window ----
-  best = __shfl(best, (lane & ~(G - 1)) | gstar);
-  bestx = __shfl(bestx, (lane & ~(G - 1)) | gstar);
-  int ncol = 0;
-  bool bad = false;
-  if (valid && g == 0 && !(a.debug & 2)) {
+  // ---- traceback #2 + fusion #2 + MSA columns: lane l of wave 0 serves the block's window slot l ----
+  if (threadIdx.x < NW * WV && !(a.debug & 2)) {
+    const WinB V = load_win_b<G>(a, (int64_t)(NW * WV) * blockIdx.x + threadIdx.x);
+    uint8_t *vs = lds + WV * 64 * 8 * kRingSlots + threadIdx.x * a.slot_bytes;
+    int32_t *vh = reinterpret_cast<int32_t *>(vs);
+    if (V.valid && vh[1] != 0) {
+      const int n1 = V.n1, Lu = V.Lu, ns = V.ns;
+      const uint8_t *ys = vs + 16;
+      const uint32_t *xinfo = reinterpret_cast<const uint32_t *>(vs + V.off_xi);
+      const uint16_t *ring1 = reinterpret_cast<const uint16_t *>(vs + V.off_r1);
+      uint16_t *x2y = reinterpret_cast<uint16_t *>(vs + V.off_x2y);
+      const uint8_t *mv = vs + V.off_region;
+      const uint8_t *ordb = mv + ns * n1 * G;
+      uint8_t *cols_st = vs + V.off_region;                        // overlays the moves after traceback
+      const int bestx = vh[3];
+      bool bad = false;
+      int ncol = 0;
     for (int j = 0; j < n1; ++j) x2y[j] = (uint16_t)kNone16;
     {
       int x = bestx, y = Lu - 1, guard = n1 + Lu + 2;
@@ -594,18 +640,22 @@ __global__ void __launch_bounds__(64) k_fused_b(FusedArgs a)
     while (iy < Lu) { place(n, ys[iy], false, false, true); ++n; ++iy; }
     flush();
     ncol = col + 1;
+      vh[0] = ncol;
+      if (bad) vh[1] = 2;
+    }
   }
   __syncthreads();
   PHASE_STAMP(10);
-  ncol = __shfl(ncol, lane & ~(G - 1));
   if (valid) {
+    const int ncol = hdr[0];
+    const uint8_t *cols_st = slot + W.off_region;
     uint8_t *gc = a.b.cols + 3 * o0;
     for (int i = g; i < 3 * ncol; i += G) gc[i] = cols_st[i];
     if (g == 0) {
       a.b.ncol[w] = ncol;
-      a.b.score2[w] = best;
-      a.b.bx2[w] = bestx;
-      if (bad) a.b.status[w] = 3;
+      a.b.score2[w] = hdr[2];
+      a.b.bx2[w] = hdr[3];
+      if (hdr[1] == 2) a.b.status[w] = 3;
       a.done_b[w] = 1;
     }
   }
@@ -630,19 +680,19 @@ static int launch_a_t(const FusedArgs &a, hipStream_t st)
   return 0;
 }
 
-template <int G>
+template <int G, int WV>
 static int launch_b_t(const FusedArgs &a, hipStream_t st)
 {
-  constexpr int NW = 64 / G;
+  constexpr int NB = WV * 64 / G;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_b<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_b<G, WV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
     attr = true;
   }
-  hipLaunchKernelGGL(k_fused_b<G>, dim3((unsigned)((a.nlist + NW - 1) / NW)), dim3(64),
-                     NW * a.slot_bytes + 64 * 8 * kRingSlots, st, a);
+  hipLaunchKernelGGL((k_fused_b<G, WV>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64 * WV),
+                     NB * a.slot_bytes + WV * 64 * 8 * kRingSlots, st, a);
   return 0;
 }
 
@@ -659,7 +709,10 @@ int launch_fused_a(const FusedArgs &a, int G, hipStream_t st)
 int launch_fused_b(const FusedArgs &a, int G, hipStream_t st)
 {
   if (a.nlist <= 0) return 0;
-  return G == 16 ? launch_b_t<16>(a, st) : G == 32 ? launch_b_t<32>(a, st) : launch_b_t<64>(a, st);
+  const bool multi = std::getenv("ELECTOR_B_WV4") != nullptr;   // shared serial stage: measured no faster
+  if (G == 16) return multi && 16 * a.slot_bytes <= 60 * 1024 ? launch_b_t<16, 4>(a, st) : launch_b_t<16, 1>(a, st);
+  if (G == 32) return multi && 8 * a.slot_bytes <= 60 * 1024 ? launch_b_t<32, 4>(a, st) : launch_b_t<32, 1>(a, st);
+  return launch_b_t<64, 1>(a, st);
 }
 
 }  // namespace elector

@@ -298,9 +298,10 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_xinfo, &c->d_ring1, &c->d_map16, &c->d_carry, &c->d_moves, &c->d_n1, &c->d_cls,
                     &c->d_score1, &c->d_score2, &c->d_bx2, &c->d_bases, &c->d_cols, &c->d_ncol, &c->d_status,
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
-                    &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_scroff,
+                    &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit, &c->d_lanemeta};
   for (DevBuf *b : bufs) b->release();
+  for (auto &s : c->st_slot) s.release();
   c->h_meta.release();
   if (c->aux_ready) {
     for (int k = 0; k < elector_ctx::kAux; ++k) { (void)hipStreamDestroy(c->aux[k]); (void)hipEventDestroy(c->aux_done[k]); }
@@ -344,7 +345,7 @@ static void spans_collect(elector_ctx *c)
 
 extern "C" int elector_ctx_timing_read(elector_ctx *c, int kernel, double *ms, int64_t *launches)
 {
-  if (!c || kernel < 0 || kernel > 2) return ELECTOR_E_INVAL;
+  if (!c || kernel < 0 || kernel >= elector_ctx::kTimedKinds) return ELECTOR_E_INVAL;
   (void)hipSetDevice(c->device);
   spans_collect(c);
   if (ms) *ms = c->ms_acc[kernel];
@@ -357,7 +358,7 @@ extern "C" int elector_ctx_timing_reset(elector_ctx *c)
   if (!c) return ELECTOR_E_INVAL;
   (void)hipSetDevice(c->device);
   spans_collect(c);
-  for (int k = 0; k < 3; ++k) { c->ms_acc[k] = 0; c->launches_acc[k] = 0; }
+  for (int k = 0; k < elector_ctx::kTimedKinds; ++k) { c->ms_acc[k] = 0; c->launches_acc[k] = 0; }
   return ELECTOR_OK;
 }
 
@@ -406,26 +407,10 @@ static int ensure_streams(elector_ctx *c)
   return 0;
 }
 
-static void timed_begin(elector_ctx *c, int kind, hipStream_t st)
-{
-  if (!c->timing) return;
-  TimedSpan s;
-  s.kind = kind;
-  if (hipEventCreate(&s.a) != hipSuccess) return;
-  if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
-  (void)hipEventRecord(s.a, st);
-  c->spans.push_back(s);
-}
-static void timed_end(elector_ctx *c, hipStream_t st)
-{
-  if (!c->timing || c->spans.empty()) return;
-  (void)hipEventRecord(c->spans.back().b, st);
-}
-
 static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *off,
                             uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status, int32_t *d_scores)
 {
-  if (n == 0) return ELECTOR_OK;
+  if (n == 0) { c->last_n = 0; c->last_total = 0; return ELECTOR_OK; }
   const int64_t total = off[3 * n];
   if (off[0] != 0 || total < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
   const bool use_fused = !c->gen && !std::getenv("ELECTOR_NO_FUSED");
@@ -806,6 +791,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     HIPCHK(c, hipMemcpy2DAsync(d_scores + 1, 8, c->d_score2.p, 4, 4, (size_t)n, hipMemcpyDeviceToDevice, st));
   }
   c->last_n = n;
+  c->last_total = total;
   if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 4)) {
     (void)hipStreamSynchronize(st);
     int32_t hc[4];

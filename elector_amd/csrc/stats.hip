@@ -1,16 +1,29 @@
-// elector_amd/csrc/stats.hip -- per-read MSA statistics.
+// elector_amd/csrc/stats.hip -- the second half of the MSA stage on the device:
+// merging the windows of a read into one record (k_merge, SURVEY.md section 8(f)
+// row 2) and the per-read MSA statistics (k_stats, section 8 row a14).
 //
-// k_stats: one lane per READ walks the read's pieces and their columns and
-// produces the integer counters of include/elector_stats.h.  It replaces the
-// per-column Python loops of the reference (elector/computeStats.py:61-189,
-// 291-328, 371-440, 472-498, 712-752).  Byte-per-column work, HBM/latency bound;
-// rows are read three bytes per column, the per-column "takes part" mask is a
-// one-byte-per-column scratch array.  Floats never appear here.
+// k_merge: one 256-thread block per PIECE (one 6-line record of msa.fa: all
+// windows of a read, or of one part of a split read).  It replaces `Donatello`
+// (reference: src/split/Donatello.cpp:13-31 clean_msa, :48-93 concatenation): the
+// windows' column-interleaved MSAs (the output layout of elector_poa_batch_device)
+// are concatenated into three rows, dropping the columns whose corrected letter is
+// 'n'.  Pure byte movement: 3 bytes per column in, 3 out.
+//
+// k_stats: one 256-thread block per READ walks the read's pieces and produces the
+// integer counters of include/elector_stats.h.  It replaces the per-column Python
+// loops of the reference (elector/computeStats.py:61-189, 291-328, 371-440,
+// 472-498, 712-752).  The per-column work (counters, masks, the search for long
+// gap runs) is spread over the block; the few inherently sequential pieces (the
+// end-gap scans, which stop after a handful of columns, and the interval list
+// logic of findGapStretches, which sees one entry per run of >= 5 corrected gaps)
+// run on single lanes.  Byte-per-column work, HBM/latency bound.  Floats never
+// appear here.
 //
 // elector_homopolymer_pairs: host-side integer state machine for the one read
 // whose homopolymer ratio the reference reports (computeStats.py:671-674).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -21,19 +34,120 @@ namespace elector {
 
 constexpr int kThresh = 5;     // THRESH  computeStats.py:40
 constexpr int kThresh2 = 20;   // THRESH2 computeStats.py:41
+constexpr int kStatsThreads = 256;
+
+// --------------------------------------------------------------------- merge ---
+
+struct MergeArgs {
+  int64_t n_pieces;
+  const int64_t *piece_first;   // n_pieces + 1 window ids
+  const int64_t *off;           // [3n+1] window offsets of the POA batch
+  const uint8_t *cols_in;       // window w: 3 * ncol[w] bytes at 3 * off[3w], column-interleaved
+  const int32_t *ncol;
+  const int32_t *status;
+  uint8_t *rows;                // out: piece p's three rows at rows + row_off[p]
+  int64_t *row_off;             // out: 3 * off[3 * piece_first[p]]  (room for every column of its windows)
+  int64_t *cols;                // out: surviving columns per piece
+  int32_t *woff;                // scratch, one per window
+};
+
+__global__ void __launch_bounds__(kStatsThreads) k_merge(MergeArgs a)
+{
+  __shared__ int s_wave[kStatsThreads / 64];
+  __shared__ int64_t s_carry;
+  const int64_t p = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t w0 = a.piece_first[p], w1 = a.piece_first[p + 1];
+  // surviving columns per window (Donatello.cpp:13-31)
+  for (int64_t w = w0 + wave; w < w1; w += kStatsThreads / 64) {
+    const int nc = a.status[w] == 0 ? a.ncol[w] : 0;
+    const uint8_t *src = a.cols_in + 3 * a.off[3 * w];
+    int cnt = 0;
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+      const int c = c0 + lane;
+      const bool keep = c < nc && src[3 * c + 1] != 'n';
+      cnt += __popcll(__ballot(keep));
+    }
+    if (lane == 0) a.woff[w] = cnt;
+  }
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  // exclusive scan of the counts over the piece's windows
+  for (int64_t base = w0; base < w1; base += kStatsThreads) {
+    const int64_t w = base + tid;
+    const int v = w < w1 ? a.woff[w] : 0;
+    int inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int k = 0; k < kStatsThreads / 64; ++k) {
+      if (k < wave) before += s_wave[k];
+      total += s_wave[k];
+    }
+    const int64_t carry = s_carry;
+    if (w < w1) a.woff[w] = (int32_t)(carry + before + inc - v);
+    __syncthreads();
+    if (tid == 0) s_carry = carry + total;
+    __syncthreads();
+  }
+  const int64_t n = s_carry;
+  const int64_t rb = 3 * a.off[3 * w0];
+  if (tid == 0) { a.row_off[p] = rb; a.cols[p] = n; }
+  uint8_t *d0 = a.rows + rb, *d1 = d0 + n, *d2 = d1 + n;
+  for (int64_t w = w0 + wave; w < w1; w += kStatsThreads / 64) {
+    const int nc = a.status[w] == 0 ? a.ncol[w] : 0;
+    const uint8_t *src = a.cols_in + 3 * a.off[3 * w];
+    int64_t k = a.woff[w];
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+      const int c = c0 + lane;
+      uint8_t x = 0, y = 'n', z = 0;
+      if (c < nc) { x = src[3 * c]; y = src[3 * c + 1]; z = src[3 * c + 2]; }
+      const bool keep = c < nc && y != 'n';
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int64_t at = k + __popcll(m & ((1ull << lane) - 1ull));
+        d0[at] = x; d1[at] = y; d2[at] = z;
+      }
+      k += __popcll(m);
+    }
+  }
+}
+
+// copy the pieces' rows from their roomy device layout to a dense one (out_off[p] = 3 * sum of cols before p)
+struct CompactArgs {
+  const uint8_t *rows;
+  const int64_t *row_off, *cols, *out_off;
+  uint8_t *out;
+};
+
+__global__ void __launch_bounds__(kStatsThreads) k_compact(CompactArgs a)
+{
+  const int64_t p = blockIdx.x;
+  const uint8_t *src = a.rows + a.row_off[p];
+  uint8_t *dst = a.out + a.out_off[p];
+  const int64_t nb = 3 * a.cols[p];
+  for (int64_t i = threadIdx.x; i < nb; i += kStatsThreads) dst[i] = src[i];
+}
+
+// --------------------------------------------------------------------- stats ---
 
 struct StatsArgs {
   int64_t n_reads;
-  const int64_t *read_first;
+  const int64_t *read_first;   // n_reads + 1 piece ids
   const uint8_t *rows;
-  const int64_t *row_off;
-  const int64_t *cols;
-  const int32_t *clips;      // may be null
+  const int64_t *row_off;      // per piece: start of its three rows
+  const int64_t *cols;         // per piece
+  const int32_t *clips;        // may be null
   int64_t *counters;
-  uint8_t *mask;             // 1 byte per column, indexed like one row: mask_off[p]
-  const int64_t *mask_off;   // n_pieces + 1
-  int32_t *scratch;          // per read: interval lists + union bytes
-  const int64_t *scr_off;    // n_reads + 1 (in int32 units)
+  uint8_t *mask;               // 1 byte per column; piece p at mask + row_off[p] / 3
+  int32_t *pool;               // bump-allocated scratch: interval lists, union bytes of split reads
+  unsigned long long pool_cap; // in int32 units
+  unsigned long long *pool_used;
+  int32_t *overflow;           // set when the pool ran out: the host grows it and runs again
 };
 
 // computeStats.py:61-77
@@ -60,38 +174,41 @@ __device__ int right_gaps(const uint8_t *row, int n)
   return total;
 }
 
-// findGapStretches (computeStats.py:104-189).  Interval lists live in `scr`
-// (pairs of ints): runs | tmp | merged | dict.  Returns the number of kept
-// intervals, written as pairs to dict_out.
-__device__ int gap_stretches(const uint8_t *cor, const uint8_t *ref, int n, int32_t *scr, int cap_pairs,
-                             int32_t **dict_out)
+// findGapStretches (computeStats.py:104-189), its per-column state machine:
+//   countGapsCor  (cg)  = k for the k-th column of a run of corrected gaps, except 0 on the run's first
+//                         column unless the run starts the record (:113-127)
+//   countGapsRef  (cgr) is advanced on a reference gap only when the PREVIOUS corrected column was a gap,
+//                         from 0 to 2 and then by one (from 0 to 1 on the record's first column), and is
+//                         cleared by a reference letter
+// A column is a "hit" when cg >= THRESH and cgr < THRESH2 (:133); hits exist only inside runs of at least
+// THRESH corrected gaps.  One lane walks one such run and reports its first and last hit.
+__device__ void walk_gap_run(const uint8_t *cor, const uint8_t *ref, int n, int s, int *first_hit, int *last_hit)
 {
-  int32_t *runs = scr, *tmp = runs + 2 * cap_pairs, *mrg = tmp + 4 * cap_pairs, *dict = mrg + 4 * cap_pairs;
-  int n_total = 0, n_ne = 0;      // list length incl. empty entries / non-empty entries
-  bool last_empty = false, have_prev = false, prev_gap = false;
-  int cg = 0, cgr = 0;
-  for (int pos = 0; pos < n; ++pos) {
-    const bool cgap = cor[pos] == '.', rgap = ref[pos] == '.';
-    if (have_prev && prev_gap) {
-      if (cgap) cg = (cg > 0) ? cg + 1 : 2;
-      if (rgap) cgr = (cgr > 0) ? cgr + 1 : 2;
-    }
-    if (!have_prev) { if (cgap) ++cg; if (rgap) ++cgr; }
-    if (!cgap) { if (cg > 0) { ++n_total; last_empty = true; } cg = 0; }
+  // reference-gap count on entry: replay the reference gap run that reaches column s - 1
+  int rb = s;
+  while (rb > 0 && ref[rb - 1] == '.') --rb;
+  int cgr = 0;
+  auto step = [&](int x) {
+    const bool rgap = ref[x] == '.';
+    if (x == 0) { if (rgap) cgr = 1; }
+    else if (cor[x - 1] == '.' && rgap) cgr = cgr > 0 ? cgr + 1 : 2;
     if (!rgap) cgr = 0;
-    if (cg >= kThresh && cgr < kThresh2) {
-      if (n_total == 0) { runs[0] = pos - kThresh + 1; runs[1] = pos; n_total = 1; n_ne = 1; last_empty = false; }
-      else {
-        if (last_empty) {
-          if (n_ne < cap_pairs) { runs[2 * n_ne] = pos - kThresh + 1; runs[2 * n_ne + 1] = pos; ++n_ne; }
-          last_empty = false;
-        }
-        runs[2 * (n_ne - 1) + 1] = pos;
-      }
-    }
-    have_prev = true;
-    prev_gap = cgap;
+  };
+  for (int x = rb; x < s; ++x) step(x);
+  int fh = -1, lh = -1;
+  for (int x = s; x < n && cor[x] == '.'; ++x) {
+    step(x);
+    if (x - s + 1 >= kThresh && cgr < kThresh2) { if (fh < 0) fh = x; lh = x; }
   }
+  *first_hit = fh;
+  *last_hit = lh;
+}
+
+// the interval-list part of findGapStretches (:146-188) on the runs that had hits: pairs in `runs`
+// (n_ne of them), n_total = length of the reference's position list including its empty entries.
+// Returns the number of kept stretches, written as pairs to dict.
+__device__ int stretch_intervals(int32_t *runs, int n_ne, int n_total, int n, int32_t *tmp, int32_t *mrg, int32_t *dict)
+{
   // borders (:146-162)
   int nt = 0;
   for (int k = 0; k < n_ne; ++k) {
@@ -126,111 +243,230 @@ __device__ int gap_stretches(const uint8_t *cor, const uint8_t *ref, int n, int3
       if (j == nd) ++nd;
     }
   }
-  *dict_out = dict;
   return nd;
 }
 
 __device__ inline bool is_gc(uint8_t c) { return c == 'g' || c == 'c' || c == 'G' || c == 'C'; }
 
-__global__ void __launch_bounds__(64) k_stats(StatsArgs a)
+__device__ inline int32_t *pool_take(const StatsArgs &a, unsigned long long ints)
 {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= a.n_reads) return;
+  const unsigned long long at = atomicAdd(a.pool_used, ints);
+  if (at + ints > a.pool_cap) { *a.overflow = 1; return nullptr; }
+  return a.pool + at;
+}
+
+// sum over the block; every thread gets the result
+__device__ inline int block_sum(int v, int *red)
+{
+  for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+  for (int k = 0; k < kStatsThreads / 64; ++k) t += red[k];
+  return t;
+}
+
+enum { kAccN = 18 };
+
+__global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
+{
+  __shared__ int s_red[kStatsThreads / 64];
+  __shared__ int s_end[4];                 // end-gap scans: left ref, left unc, right ref, right unc
+  __shared__ int s_acc[kAccN];
+  __shared__ int s_n[8];                   // 0: long-run fill  1: stretches kept  2: clip left  3: clip right  4: earliest qualifying run end
+  __shared__ int32_t *s_lists;
+  __shared__ uint8_t *s_uni;
+  const int64_t r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int64_t p0 = a.read_first[r], p1 = a.read_first[r + 1];
   const int nfrag = (int)(p1 - p0);
-  int32_t *scr = a.scratch + a.scr_off[r];
-  const int64_t scr_len = a.scr_off[r + 1] - a.scr_off[r];
-  // scratch layout: [union bytes: ucap] [interval lists: 14*cap_pairs ints]
-  int64_t maxc = 0;
-  for (int64_t p = p0; p < p1; ++p) maxc = a.cols[p] > maxc ? a.cols[p] : maxc;
-  const int ucap = (int)maxc;
-  uint8_t *uni = reinterpret_cast<uint8_t *>(scr);
-  int32_t *lists = scr + (ucap + 3) / 4;
-  const int cap_pairs = (int)((scr_len - (ucap + 3) / 4) / 14) - 1;
-  if (nfrag > 1) for (int i = 0; i < ucap; ++i) uni[i] = 0;
+
+  // realNotMissing of a split read (:589-591): one byte per column of its longest piece
+  int ucap = 0;
+  if (nfrag > 1) {
+    if (tid == 0) {
+      int64_t maxc = 0;
+      for (int64_t p = p0; p < p1; ++p) maxc = a.cols[p] > maxc ? a.cols[p] : maxc;
+      s_n[5] = (int)maxc;
+      s_uni = reinterpret_cast<uint8_t *>(pool_take(a, (unsigned long long)(maxc + 3) / 4 + 1));
+    }
+    __syncthreads();
+    ucap = s_n[5];
+    if (!s_uni) return;
+    for (int i = tid; i < ucap; i += kStatsThreads) s_uni[i] = 0;
+  }
+  uint8_t *uni = nfrag > 1 ? s_uni : nullptr;
 
   int64_t missing = 0;
   for (int64_t p = p0; p < p1; ++p) {
     int64_t *out = a.counters + p * ES_NCOUNTERS;
-    for (int k = 0; k < ES_NCOUNTERS; ++k) out[k] = 0;
-    out[ES_EXT_LEFT] = out[ES_EXT_RIGHT] = -1;
-    out[ES_MISSING_LAST] = -1;
     const int n = (int)a.cols[p];
-    if (n <= 10) { out[ES_MISSING] = missing; continue; }          // computeStats.py:577,624
+    __syncthreads();
+    if (n <= 10) {                                                   // computeStats.py:577,624
+      if (tid == 0) {
+        for (int k = 0; k < ES_NCOUNTERS; ++k) out[k] = 0;
+        out[ES_EXT_LEFT] = out[ES_EXT_RIGHT] = -1;
+        out[ES_MISSING_LAST] = -1;
+        out[ES_MISSING] = missing;
+      }
+      continue;
+    }
     const uint8_t *ref = a.rows + a.row_off[p], *cor = ref + n, *unc = cor + n;
-    uint8_t *mask = a.mask + a.mask_off[p];
-    out[ES_PROCESSED] = 1;
+    uint8_t *mask = a.mask + a.row_off[p] / 3;
 
-    // gapsAndExtensions (:472-498)
-    const int gl = min(left_gaps(ref, n), left_gaps(unc, n));
-    const int gr = min(right_gaps(ref, n), right_gaps(unc, n));
+    // ---- gapsAndExtensions (:472-498): the four end scans on four lanes ----
+    if (tid == 0) s_end[0] = left_gaps(ref, n);
+    if (tid == 64) s_end[1] = left_gaps(unc, n);
+    if (tid == 128) s_end[2] = right_gaps(ref, n);
+    if (tid == 192) s_end[3] = right_gaps(unc, n);
+    if (tid < kAccN) s_acc[tid] = 0;
+    if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = n - 1; s_n[4] = 0x7fffffff; s_lists = nullptr; }
+    __syncthreads();
+    const int gl = min(s_end[0], s_end[1]), gr = min(s_end[2], s_end[3]);
+    int64_t ext_left = -1, ext_right = -1;
     if (gl >= kThresh && gl >= kThresh2) {
       int dots = 0;
-      for (int i = 0; i < gl; ++i) dots += cor[i] == '.';
-      out[ES_EXT_LEFT] = gl - dots;
+      for (int i = tid; i < gl; i += kStatsThreads) dots += cor[i] == '.';
+      ext_left = gl - block_sum(dots, s_red);
     }
     if (gr >= kThresh && gr >= kThresh2) {
       int dots = 0;
-      for (int i = n - gr + 1; i < n; ++i) dots += cor[i] == '.';
-      out[ES_EXT_RIGHT] = gr - dots;
+      for (int i = n - gr + 1 + tid; i < n; i += kStatsThreads) dots += cor[i] == '.';
+      ext_right = gr - block_sum(dots, s_red);
     }
+
+    // ---- findGapStretches (:104-189) ----
+    // pass 1: runs of >= THRESH corrected gaps, and the ends of runs that leave countGapsCor > 0
+    int nlong = 0, nq = 0, qmin = 0x7fffffff;
+    for (int i = tid; i < n; i += kStatsThreads) {
+      if (cor[i] != '.') continue;
+      const bool first = i == 0 || cor[i - 1] != '.';
+      if (first && i + kThresh - 1 < n) {
+        bool all = true;
+        for (int k = 1; k < kThresh; ++k) all = all && cor[i + k] == '.';
+        nlong += all;
+      }
+      if (i + 1 < n && cor[i + 1] != '.' && (i == 0 || !first)) { ++nq; qmin = min(qmin, i + 1); }
+    }
+    const int m = block_sum(nlong, s_red);
+    nq = block_sum(nq, s_red);
+    int nd = 0;
     int32_t *dict = nullptr;
-    const int nd = gap_stretches(cor, ref, n, lists, cap_pairs, &dict);
+    if (m > 0) {
+      atomicMin(&s_n[4], qmin);
+      if (tid == 0) s_lists = pool_take(a, 14ull * (unsigned long long)(m + 2));
+      __syncthreads();
+      int32_t *lists = s_lists;
+      if (!lists) return;                                             // uniform: the host runs again with a larger pool
+      int32_t *runs = lists, *tmp = runs + 2 * (m + 2), *mrg = tmp + 4 * (m + 2);
+      dict = mrg + 4 * (m + 2);
+      // pass 2: the run starts, in any order, then sorted by rank
+      for (int i = tid; i < n; i += kStatsThreads) {
+        if (cor[i] != '.' || !(i == 0 || cor[i - 1] != '.') || i + kThresh - 1 >= n) continue;
+        bool all = true;
+        for (int k = 1; k < kThresh; ++k) all = all && cor[i + k] == '.';
+        if (all) tmp[atomicAdd(&s_n[0], 1)] = i;
+      }
+      __syncthreads();
+      for (int e = tid; e < m; e += kStatsThreads) {
+        const int v = tmp[e];
+        int rank = 0;
+        for (int x = 0; x < m; ++x) rank += tmp[x] < v;
+        runs[rank] = v;
+      }
+      __syncthreads();
+      for (int e = tid; e < m; e += kStatsThreads) walk_gap_run(cor, ref, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1]);
+      __syncthreads();
+      if (tid == 0) {
+        int n_ne = 0, first_hit = 0x7fffffff;
+        for (int e = 0; e < m; ++e) {
+          const int fh = mrg[2 * e], lh = mrg[2 * e + 1];
+          if (fh < 0) continue;
+          if (n_ne == 0) first_hit = fh;
+          runs[2 * n_ne] = fh - kThresh + 1;
+          runs[2 * n_ne + 1] = lh;
+          ++n_ne;
+        }
+        // the reference's list also holds one empty entry per ended run; the very first hit opens the
+        // list itself when no run has ended before it (:134-137)
+        const int n_total = nq + ((n_ne > 0 && s_n[4] > first_hit) ? 1 : 0);
+        s_n[1] = stretch_intervals(runs, n_ne, n_total, n, tmp, mrg, dict);
+      }
+      __syncthreads();
+      nd = s_n[1];
+    }
     for (int k = 0; k < nd; ++k) {
       const int s0 = dict[2 * k], s1 = dict[2 * k + 1];
       int dots = 0;
-      for (int i = s0; i <= s1; ++i) dots += ref[i] == '.';
-      missing += s1 - s0 - dots;
+      for (int i = s0 + tid; i <= s1; i += kStatsThreads) dots += ref[i] == '.';
+      missing += s1 - s0 - block_sum(dots, s_red);
     }
     missing -= gl + gr;
     if (missing < 0) missing = 0;
-    out[ES_MISSING] = missing;
-    out[ES_GAPS_LEFT] = gl;
-    out[ES_GAPS_RIGHT] = gr;
 
-    // getCorrectedPositions (:712-752)
-    for (int i = 0; i < n; ++i) mask[i] = 1;
-    if (a.clips) {
+    // ---- getCorrectedPositions (:712-752): soft clips walk the corrected row from both ends ----
+    if (a.clips && tid == 0) {
       const int lc = a.clips[2 * p], rc = a.clips[2 * p + 1];
       int i = 0, j = 0;
-      while (j < lc && i < n) { if (cor[i] != '.') ++j; mask[i] = 0; ++i; }
+      while (j < lc && i < n) { if (cor[i] != '.') ++j; ++i; }
+      s_n[2] = i;                                                     // columns < i are clipped
       if (lc != 0 || rc != 0) {
         const int right_clip = n - rc;
         i = n - 1; j = n - 1;
-        while (j >= right_clip && i >= 0) { if (cor[i] != '.') --j; mask[i] = 0; --i; }
+        while (j >= right_clip && i >= 0) { if (cor[i] != '.') --j; --i; }
+        s_n[3] = i;                                                   // columns > i are clipped
       }
     }
-    for (int k = 0; k < nd; ++k)
-      for (int i = dict[2 * k]; i <= dict[2 * k + 1]; ++i) mask[i] = 0;
-    if (gl >= kThresh) for (int i = 0; i < gl; ++i) mask[i] = 0;
-    if (gr >= kThresh) for (int i = n - 1; i > n - gr; --i) mask[i] = 0;
+    __syncthreads();
+    const int clip_l = s_n[2], clip_r = s_n[3];
 
-    // per-column counters (:399-440 with :291-328 and :371-393)
-    int64_t tp = 0, fp = 0, fn = 0, cb = 0, ub = 0, ucb = 0, uub = 0, gcr = 0, gcc = 0;
-    int64_t insu = 0, delu = 0, subu = 0, insc = 0, delc = 0, subc = 0, lr = 0, lcn = 0, lu = 0;
-    for (int i = 0; i < n; ++i) {
+    // ---- per-column counters (:399-440 with :291-328 and :371-393) ----
+    int acc[kAccN];
+#pragma unroll
+    for (int k = 0; k < kAccN; ++k) acc[k] = 0;
+    for (int i = tid; i < n; i += kStatsThreads) {
       const uint8_t x = ref[i], c = cor[i], u = unc[i];
-      gcr += is_gc(x); gcc += is_gc(c);
-      lr += x != '.'; lcn += c != '.'; lu += u != '.';
-      if (!mask[i]) continue;
-      if (c != x) { if (x == '.') ++insc; else if (c != '.') ++subc; else ++delc; }
-      if (u != x) { if (x == '.') ++insu; else if (u != '.') ++subu; else ++delu; }
-      if (x == u) { if (u != c) { ++fp; ++ub; } else { ++tp; ++cb; } ++ucb; }
-      else { if (x == c) { ++tp; ++cb; } else { if (u == c) { ++fn; ++fp; } ++ub; } ++uub; }
+      bool mk = i >= clip_l && i <= clip_r;
+      if (gl >= kThresh && i < gl) mk = false;
+      if (gr >= kThresh && i > n - gr) mk = false;
+      for (int k = 0; k < nd; ++k) if (i >= dict[2 * k] && i <= dict[2 * k + 1]) mk = false;
+      mask[i] = mk ? 1 : 0;
+      acc[7] += is_gc(x); acc[8] += is_gc(c);
+      acc[15] += x != '.'; acc[16] += c != '.'; acc[17] += u != '.';
+      if (!mk) continue;
+      if (c != x) { if (x == '.') ++acc[12]; else if (c != '.') ++acc[14]; else ++acc[13]; }
+      if (u != x) { if (x == '.') ++acc[9]; else if (u != '.') ++acc[11]; else ++acc[10]; }
+      if (x == u) { if (u != c) { ++acc[1]; ++acc[4]; } else { ++acc[0]; ++acc[3]; } ++acc[5]; }
+      else { if (x == c) { ++acc[0]; ++acc[3]; } else { if (u == c) { ++acc[2]; ++acc[1]; } ++acc[4]; } ++acc[6]; }
     }
-    out[ES_TP] = tp; out[ES_FP] = fp; out[ES_FN] = fn; out[ES_COR] = cb; out[ES_UNC] = ub;
-    out[ES_UCOR] = ucb; out[ES_UUNC] = uub; out[ES_GC_REF] = gcr; out[ES_GC_COR] = gcc;
-    out[ES_INS_U] = insu; out[ES_DEL_U] = delu; out[ES_SUB_U] = subu;
-    out[ES_INS_C] = insc; out[ES_DEL_C] = delc; out[ES_SUB_C] = subc;
-    out[ES_LEN_REF] = lr; out[ES_LEN_COR] = lcn; out[ES_LEN_UNC] = lu;
-
+#pragma unroll
+    for (int k = 0; k < kAccN; ++k) {
+      int v = acc[k];
+      for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+      if (lane == 0 && v) atomicAdd(&s_acc[k], v);
+    }
+    __syncthreads();
+    int64_t missing_last = -1;
     if (nfrag > 1) {
-      for (int i = 0; i < n; ++i) uni[i] |= mask[i];               // realNotMissing (:589-591)
-      if (p == p1 - 1) {                                            // last piece (:595-599)
-        int64_t miss = 0;
-        for (int i = 0; i < n; ++i) miss += (!uni[i] && ref[i] != '.');
-        out[ES_MISSING_LAST] = miss;
+      for (int i = tid; i < n; i += kStatsThreads) uni[i] |= mask[i];      // realNotMissing (:589-591)
+      if (p == p1 - 1) {                                                    // last piece (:595-599)
+        __syncthreads();
+        int miss = 0;
+        for (int i = tid; i < n; i += kStatsThreads) miss += (!uni[i] && ref[i] != '.');
+        missing_last = block_sum(miss, s_red);
       }
+    }
+    if (tid == 0) {
+      // s_acc order = ES_TP .. ES_LEN_UNC
+      for (int k = 0; k < kAccN; ++k) out[k] = s_acc[k];
+      out[ES_GAPS_LEFT] = gl;
+      out[ES_GAPS_RIGHT] = gr;
+      out[ES_EXT_LEFT] = ext_left;
+      out[ES_EXT_RIGHT] = ext_right;
+      out[ES_MISSING] = missing;
+      out[ES_MISSING_LAST] = missing_last;
+      out[ES_PROCESSED] = 1;
     }
   }
 }
@@ -238,6 +474,50 @@ __global__ void __launch_bounds__(64) k_stats(StatsArgs a)
 }  // namespace elector
 
 using namespace elector;
+
+namespace {
+
+// scratch pool of k_stats: [used counter u64][overflow i32][pad][ints...]
+struct PoolView { unsigned long long *used; int32_t *overflow; int32_t *ints; unsigned long long cap; };
+
+int pool_prepare(elector_ctx *c, unsigned long long ints, PoolView *v)
+{
+  if (c->d_st_scr.ensure((size_t)ints * 4 + 64)) return ELECTOR_E_NOMEM;
+  uint8_t *base = c->d_st_scr.as<uint8_t>();
+  v->used = reinterpret_cast<unsigned long long *>(base);
+  v->overflow = reinterpret_cast<int32_t *>(base + 8);
+  v->ints = reinterpret_cast<int32_t *>(base + 16);
+  v->cap = (c->d_st_scr.cap - 16) / 4;
+  return 0;
+}
+
+// runs k_stats, growing the pool to the worst case once if the first size was too small;
+// total_cols bounds the sum of the pieces' columns
+int run_stats(elector_ctx *c, StatsArgs a, int64_t n_pieces, int64_t total_cols)
+{
+  hipStream_t st = c->stream;
+  unsigned long long want = std::max<unsigned long long>(1ull << 20, (unsigned long long)total_cols / 4);   // pool_first_size
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    PoolView pv;
+    if (pool_prepare(c, want, &pv)) return elector_fail(c, ELECTOR_E_NOMEM, "statistics scratch pool");
+    HIPCHK(c, hipMemsetAsync(c->d_st_scr.p, 0, 16, st));
+    a.pool = pv.ints; a.pool_cap = pv.cap; a.pool_used = pv.used; a.overflow = pv.overflow;
+    timed_begin(c, 3, st);
+    hipLaunchKernelGGL(k_stats, dim3((unsigned)a.n_reads), dim3(kStatsThreads), 0, st, a);
+    timed_end(c, st);
+    HIPCHK(c, hipGetLastError());
+    int32_t over = 0;
+    HIPCHK(c, hipMemcpyAsync(&over, pv.overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (!over) return ELECTOR_OK;
+    // worst case: a run list entry per THRESH columns (14 ints each) + a union byte per column
+    want = 14ull * ((unsigned long long)total_cols / kThresh + 3ull * (unsigned long long)n_pieces) +
+           (unsigned long long)total_cols / 4 + 2ull * (unsigned long long)a.n_reads + 1024;
+  }
+  return elector_fail(c, ELECTOR_E_NOMEM, "statistics scratch pool overflow");
+}
+
+}  // namespace
 
 extern "C" int elector_stats_batch(elector_ctx *c, int64_t n_reads, const int64_t *read_first, int64_t n_pieces,
                                    const uint8_t *rows, const int64_t *row_off, const int64_t *cols,
@@ -247,44 +527,34 @@ extern "C" int elector_stats_batch(elector_ctx *c, int64_t n_reads, const int64_
   if (n_reads < 0 || n_pieces < 0 || !read_first || (n_pieces > 0 && (!rows || !row_off || !cols || !counters)))
     return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
   if (n_reads == 0 || n_pieces == 0) return ELECTOR_OK;
+  if (n_reads > 0x7fffffff) return elector_fail(c, ELECTOR_E_INVAL, "too many reads in one call");
   if (read_first[0] != 0 || read_first[n_reads] != n_pieces) return elector_fail(c, ELECTOR_E_INVAL, "read_first must cover all pieces");
   std::lock_guard<std::mutex> lock(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  // host metadata: mask offsets (one byte per column) and per-read scratch offsets
-  std::vector<int64_t> mask_off((size_t)n_pieces + 1), scr_off((size_t)n_reads + 1);
-  mask_off[0] = 0;
+  int64_t total_cols = 0;
   for (int64_t p = 0; p < n_pieces; ++p) {
     if (cols[p] < 0 || cols[p] > 0x3fffffff || row_off[p + 1] - row_off[p] != 3 * cols[p])
       return elector_fail(c, ELECTOR_E_INVAL, "row_off/cols mismatch");
-    mask_off[p + 1] = mask_off[p] + cols[p];
+    total_cols += cols[p];
   }
-  scr_off[0] = 0;
-  for (int64_t r = 0; r < n_reads; ++r) {
+  for (int64_t r = 0; r < n_reads; ++r)
     if (read_first[r + 1] < read_first[r]) return elector_fail(c, ELECTOR_E_INVAL, "read_first must be non-decreasing");
-    int64_t maxc = 0;
-    for (int64_t p = read_first[r]; p < read_first[r + 1]; ++p) maxc = std::max(maxc, cols[p]);
-    const int64_t pairs = maxc / kThresh + 4;                       // a run needs >= 5 gap columns
-    scr_off[r + 1] = scr_off[r] + (maxc + 3) / 4 + 14 * (pairs + 2) + 8;
-  }
-  const int64_t total_rows = row_off[n_pieces];
-  int rc = c->d_st_rows.ensure((size_t)total_rows + 64) | c->d_st_rowoff.ensure((size_t)(n_pieces + 1) * 8) |
+  const int64_t r0 = row_off[0], total_rows = row_off[n_pieces] - r0;
+  int rc = c->d_st_rows.ensure((size_t)total_rows + r0 % 3 + 64) | c->d_st_rowoff.ensure((size_t)(n_pieces + 1) * 8) |
            c->d_st_cols.ensure((size_t)n_pieces * 8) | c->d_st_first.ensure((size_t)(n_reads + 1) * 8) |
-           c->d_st_cnt.ensure((size_t)n_pieces * ES_NCOUNTERS * 8) | c->d_st_mask.ensure((size_t)mask_off[n_pieces] + 64) |
-           c->d_st_scr.ensure((size_t)scr_off[n_reads] * 4 + 64) |
-           c->d_st_scroff.ensure((size_t)(n_reads + 1 + n_pieces + 1) * 8) |
+           c->d_st_cnt.ensure((size_t)n_pieces * ES_NCOUNTERS * 8) | c->d_st_mask.ensure((size_t)total_cols + 64) |
            (clips ? c->d_st_clips.ensure((size_t)n_pieces * 8) : 0);
   if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "statistics workspace");
   hipStream_t st = c->stream;
-  int64_t *d_scroff = c->d_st_scroff.as<int64_t>();
-  int64_t *d_maskoff = d_scroff + (n_reads + 1);
-  HIPCHK(c, hipMemcpyAsync(c->d_st_rows.p, rows, (size_t)total_rows, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_st_rowoff.p, row_off, (size_t)(n_pieces + 1) * 8, hipMemcpyHostToDevice, st));
+  // device offsets are relative to the first piece
+  std::vector<int64_t> rel((size_t)n_pieces + 1);
+  for (int64_t p = 0; p <= n_pieces; ++p) rel[(size_t)p] = row_off[p] - r0;
+  HIPCHK(c, hipMemcpyAsync(c->d_st_rows.p, rows + r0, (size_t)total_rows, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_st_rowoff.p, rel.data(), (size_t)(n_pieces + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_st_cols.p, cols, (size_t)n_pieces * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_st_first.p, read_first, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_scroff, scr_off.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_maskoff, mask_off.data(), (size_t)(n_pieces + 1) * 8, hipMemcpyHostToDevice, st));
   if (clips) HIPCHK(c, hipMemcpyAsync(c->d_st_clips.p, clips, (size_t)n_pieces * 8, hipMemcpyHostToDevice, st));
-  StatsArgs a;
+  StatsArgs a{};
   a.n_reads = n_reads;
   a.read_first = c->d_st_first.as<int64_t>();
   a.rows = c->d_st_rows.as<uint8_t>();
@@ -293,18 +563,226 @@ extern "C" int elector_stats_batch(elector_ctx *c, int64_t n_reads, const int64_
   a.clips = clips ? c->d_st_clips.as<int32_t>() : nullptr;
   a.counters = c->d_st_cnt.as<int64_t>();
   a.mask = c->d_st_mask.as<uint8_t>();
-  a.mask_off = d_maskoff;
-  a.scratch = c->d_st_scr.as<int32_t>();
-  a.scr_off = d_scroff;
-  hipLaunchKernelGGL(k_stats, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, a);
-  HIPCHK(c, hipGetLastError());
+  rc = run_stats(c, a, n_pieces, total_cols);
+  if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(counters, c->d_st_cnt.p, (size_t)n_pieces * ES_NCOUNTERS * 8, hipMemcpyDeviceToHost, st));
   if (last_mask) {
     const int64_t pl = read_first[n_reads - 1];
-    const int64_t nb = mask_off[n_pieces] - mask_off[pl];
+    const int64_t nb = (rel[(size_t)n_pieces] - rel[(size_t)pl]) / 3;
     if (nb > 0)
-      HIPCHK(c, hipMemcpyAsync(last_mask, c->d_st_mask.as<uint8_t>() + mask_off[pl], (size_t)nb, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(last_mask, c->d_st_mask.as<uint8_t>() + rel[(size_t)pl] / 3, (size_t)nb, hipMemcpyDeviceToHost, st));
   }
+  HIPCHK(c, hipStreamSynchronize(st));
+  return ELECTOR_OK;
+}
+
+namespace {
+
+unsigned long long pool_first_size(int64_t total_cols) { return std::max<unsigned long long>(1ull << 20, (unsigned long long)total_cols / 4); }
+
+// worst case: a run list entry per THRESH columns (14 ints each) + a union byte per column
+unsigned long long pool_worst_size(int64_t total_cols, int64_t n_pieces, int64_t n_reads)
+{
+  return 14ull * ((unsigned long long)total_cols / kThresh + 3ull * (unsigned long long)n_pieces) +
+         (unsigned long long)total_cols / 4 + 2ull * (unsigned long long)n_reads + 1024;
+}
+
+StatsArgs slot_args(const elector::StatsSlot &s)
+{
+  StatsArgs a{};
+  a.n_reads = s.n_reads;
+  a.read_first = s.first.as<int64_t>();
+  a.rows = s.rows.as<uint8_t>();
+  a.row_off = s.rowoff.as<int64_t>();
+  a.cols = s.cols.as<int64_t>();
+  a.clips = s.has_clips ? s.clips.as<int32_t>() : nullptr;
+  a.counters = s.cnt.as<int64_t>();
+  a.mask = s.mask.as<uint8_t>();
+  return a;
+}
+
+// k_stats of a slot on the context's stream with a pool of `ints`, then its results to the slot's
+// pinned staging: [overflow i32, pad][counters][cols]
+int enqueue_stats(elector_ctx *c, elector::StatsSlot &s, unsigned long long ints)
+{
+  hipStream_t st = c->stream;
+  PoolView pv;
+  if (pool_prepare(c, ints, &pv)) return elector_fail(c, ELECTOR_E_NOMEM, "statistics scratch pool");
+  HIPCHK(c, hipMemsetAsync(c->d_st_scr.p, 0, 16, st));
+  StatsArgs a = slot_args(s);
+  a.pool = pv.ints; a.pool_cap = pv.cap; a.pool_used = pv.used; a.overflow = pv.overflow;
+  timed_begin(c, 3, st);
+  hipLaunchKernelGGL(k_stats, dim3((unsigned)a.n_reads), dim3(kStatsThreads), 0, st, a);
+  timed_end(c, st);
+  HIPCHK(c, hipGetLastError());
+  uint8_t *h = s.h.as<uint8_t>();
+  HIPCHK(c, hipMemcpyAsync(h, pv.overflow, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(h + 16, s.cnt.p, (size_t)s.n_pieces * ES_NCOUNTERS * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(h + 16 + (size_t)s.n_pieces * ES_NCOUNTERS * 8, s.cols.p, (size_t)s.n_pieces * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(s.done, st));
+  return ELECTOR_OK;
+}
+
+}  // namespace
+
+extern "C" int elector_msa_stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
+                                         const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
+                                         int64_t n_reads, const int64_t *read_first, const int32_t *clips)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n_windows < 0 || n_pieces < 0 || n_reads < 0 || !piece_first || !read_first ||
+      (n_windows > 0 && (!d_cols || !d_ncol || !d_status)))
+    return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  if (n_windows != c->last_n) return elector_fail(c, ELECTOR_E_INVAL, "the windows must be those of the context's last elector_poa_batch_device call");
+  if (n_reads > 0x7fffffff || n_pieces > 0x7fffffff) return elector_fail(c, ELECTOR_E_INVAL, "too many reads in one call");
+  if (piece_first[0] != 0 || piece_first[n_pieces] != n_windows) return elector_fail(c, ELECTOR_E_INVAL, "piece_first must cover all windows");
+  if (read_first[0] != 0 || read_first[n_reads] != n_pieces) return elector_fail(c, ELECTOR_E_INVAL, "read_first must cover all pieces");
+  for (int64_t p = 0; p < n_pieces; ++p)
+    if (piece_first[p + 1] < piece_first[p]) return elector_fail(c, ELECTOR_E_INVAL, "piece_first must be non-decreasing");
+  for (int64_t r = 0; r < n_reads; ++r)
+    if (read_first[r + 1] < read_first[r]) return elector_fail(c, ELECTOR_E_INVAL, "read_first must be non-decreasing");
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (c->st_inflight >= elector_ctx::kStatsSlots) return elector_fail(c, ELECTOR_E_INVAL, "two statistics jobs in flight: collect one first");
+  HIPCHK(c, hipSetDevice(c->device));
+  elector::StatsSlot &s = c->st_slot[c->st_head];
+  if (!s.done) HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  s.n_pieces = n_pieces; s.n_reads = n_reads; s.total = c->last_total; s.has_clips = clips != nullptr;
+  s.last_piece = n_reads > 0 ? read_first[n_reads - 1] : 0;
+  const int64_t total = s.total;            // bases of the batch: an upper bound of its MSA columns
+  if (n_pieces > 0 && n_reads > 0) {
+    int rc = s.rows.ensure((size_t)3 * total + 64) | s.rowoff.ensure((size_t)(n_pieces + 1) * 8) |
+             s.cols.ensure((size_t)n_pieces * 8) | s.first.ensure((size_t)(n_reads + 1 + n_pieces + 1) * 8) |
+             s.cnt.ensure((size_t)n_pieces * ES_NCOUNTERS * 8) | s.mask.ensure((size_t)total + 64) |
+             s.woff.ensure((size_t)(n_windows + 1) * 4) | (clips ? s.clips.ensure((size_t)n_pieces * 8) : 0) |
+             s.h.ensure(16 + (size_t)n_pieces * (ES_NCOUNTERS + 1) * 8 + (size_t)(n_reads + n_pieces + 2) * 8 +
+                        (clips ? (size_t)n_pieces * 8 : 0));
+    if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "statistics workspace");
+    hipStream_t st = c->stream;
+    // inputs go through the slot's pinned block so that the uploads do not wait for the device
+    uint8_t *hin = s.h.as<uint8_t>() + 16 + (size_t)n_pieces * (ES_NCOUNTERS + 1) * 8;
+    std::memcpy(hin, read_first, (size_t)(n_reads + 1) * 8);
+    std::memcpy(hin + (size_t)(n_reads + 1) * 8, piece_first, (size_t)(n_pieces + 1) * 8);
+    int64_t *d_read_first = s.first.as<int64_t>(), *d_piece_first = d_read_first + (n_reads + 1);
+    HIPCHK(c, hipMemcpyAsync(d_read_first, hin, (size_t)(n_reads + n_pieces + 2) * 8, hipMemcpyHostToDevice, st));
+    if (clips) {
+      uint8_t *hc = hin + (size_t)(n_reads + n_pieces + 2) * 8;
+      std::memcpy(hc, clips, (size_t)n_pieces * 8);
+      HIPCHK(c, hipMemcpyAsync(s.clips.p, hc, (size_t)n_pieces * 8, hipMemcpyHostToDevice, st));
+    }
+    MergeArgs m{};
+    m.n_pieces = n_pieces;
+    m.piece_first = d_piece_first;
+    m.off = c->d_off.as<int64_t>();
+    m.cols_in = d_cols;
+    m.ncol = d_ncol;
+    m.status = d_status;
+    m.rows = s.rows.as<uint8_t>();
+    m.row_off = s.rowoff.as<int64_t>();
+    m.cols = s.cols.as<int64_t>();
+    m.woff = s.woff.as<int32_t>();
+    timed_begin(c, 3, st);
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, m);
+    timed_end(c, st);
+    HIPCHK(c, hipGetLastError());
+    const int rc2 = enqueue_stats(c, s, pool_first_size(total));
+    if (rc2) return rc2;
+  }
+  c->st_head = (c->st_head + 1) % elector_ctx::kStatsSlots;
+  ++c->st_inflight;
+  return ELECTOR_OK;
+}
+
+extern "C" int elector_msa_stats_collect(elector_ctx *c, int64_t n_pieces, int64_t *counters, int64_t *piece_cols,
+                                         uint8_t *last_rows, uint8_t *last_mask, int64_t last_cap)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (c->st_inflight <= 0) return elector_fail(c, ELECTOR_E_INVAL, "no statistics job in flight");
+  elector::StatsSlot &s = c->st_slot[c->st_tail];
+  if (n_pieces != s.n_pieces || (n_pieces > 0 && !counters)) return elector_fail(c, ELECTOR_E_INVAL, "n_pieces differs from the job's");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->st_last = c->st_tail;
+  c->st_tail = (c->st_tail + 1) % elector_ctx::kStatsSlots;
+  --c->st_inflight;
+  if (s.n_pieces == 0 || s.n_reads == 0) return ELECTOR_OK;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipEventSynchronize(s.done));
+  const uint8_t *h = s.h.as<uint8_t>();
+  if (*reinterpret_cast<const int32_t *>(h) != 0) {
+    // the interval scratch ran out: run the statistics kernel again with the worst-case pool
+    const int rc = enqueue_stats(c, s, pool_worst_size(s.total, s.n_pieces, s.n_reads));
+    if (rc) return rc;
+    HIPCHK(c, hipEventSynchronize(s.done));
+    if (*reinterpret_cast<const int32_t *>(h) != 0) return elector_fail(c, ELECTOR_E_NOMEM, "statistics scratch pool overflow");
+  }
+  std::memcpy(counters, h + 16, (size_t)n_pieces * ES_NCOUNTERS * 8);
+  const int64_t *hcols = reinterpret_cast<const int64_t *>(h + 16 + (size_t)n_pieces * ES_NCOUNTERS * 8);
+  if (piece_cols) std::memcpy(piece_cols, hcols, (size_t)n_pieces * 8);
+  const int64_t pl = s.last_piece, npl = n_pieces - pl;
+  if ((last_rows || last_mask) && npl > 0) {
+    int64_t need = 0;
+    for (int64_t k = 0; k < npl; ++k) need += hcols[pl + k];
+    if (need > last_cap) return elector_fail(c, ELECTOR_E_INVAL, "last_cap is smaller than the last read's columns");
+    std::vector<int64_t> loff((size_t)npl);
+    HIPCHK(c, hipMemcpyAsync(loff.data(), s.rowoff.as<int64_t>() + pl, (size_t)npl * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    int64_t at = 0;
+    for (int64_t k = 0; k < npl; ++k) {
+      const int64_t nc = hcols[pl + k];
+      if (nc > 0 && last_rows)
+        HIPCHK(c, hipMemcpyAsync(last_rows + 3 * at, s.rows.as<uint8_t>() + loff[(size_t)k], (size_t)3 * nc, hipMemcpyDeviceToHost, st));
+      if (nc > 0 && last_mask)
+        HIPCHK(c, hipMemcpyAsync(last_mask + at, s.mask.as<uint8_t>() + loff[(size_t)k] / 3, (size_t)nc, hipMemcpyDeviceToHost, st));
+      at += nc;
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  return ELECTOR_OK;
+}
+
+extern "C" int elector_msa_stats_device(elector_ctx *c, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
+                                        const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
+                                        int64_t n_reads, const int64_t *read_first, const int32_t *clips,
+                                        int64_t *counters, int64_t *piece_cols, uint8_t *last_rows, uint8_t *last_mask,
+                                        int64_t last_cap)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (c->st_inflight != 0) return elector_fail(c, ELECTOR_E_INVAL, "statistics jobs in flight: collect them first");
+  if (n_pieces > 0 && !counters) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  const int rc = elector_msa_stats_enqueue(c, n_windows, d_cols, d_ncol, d_status, n_pieces, piece_first, n_reads, read_first, clips);
+  if (rc) return rc;
+  return elector_msa_stats_collect(c, n_pieces, counters, piece_cols, last_rows, last_mask, last_cap);
+}
+
+extern "C" int elector_msa_rows_fetch(elector_ctx *c, int64_t n_pieces, const int64_t *piece_cols, uint8_t *rows)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n_pieces < 0 || (n_pieces > 0 && (!piece_cols || !rows))) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (c->st_last < 0 || n_pieces != c->st_slot[c->st_last].n_pieces)
+    return elector_fail(c, ELECTOR_E_INVAL, "the pieces must be those of the context's last collected statistics job");
+  if (n_pieces == 0) return ELECTOR_OK;
+  elector::StatsSlot &s = c->st_slot[c->st_last];
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<int64_t> out_off((size_t)n_pieces + 1);
+  out_off[0] = 0;
+  for (int64_t p = 0; p < n_pieces; ++p) {
+    if (piece_cols[p] < 0) return elector_fail(c, ELECTOR_E_INVAL, "negative column count");
+    out_off[(size_t)p + 1] = out_off[(size_t)p] + 3 * piece_cols[p];
+  }
+  const int64_t total = out_off[(size_t)n_pieces];
+  if (total == 0) return ELECTOR_OK;
+  if (total > 3 * s.total) return elector_fail(c, ELECTOR_E_INVAL, "piece_cols exceed the job's columns");
+  if (c->d_st_dense.ensure((size_t)total + 64) | c->d_st_outoff.ensure((size_t)(n_pieces + 1) * 8))
+    return elector_fail(c, ELECTOR_E_NOMEM, "row staging");
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->d_st_outoff.p, out_off.data(), (size_t)(n_pieces + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  CompactArgs a{s.rows.as<uint8_t>(), s.rowoff.as<int64_t>(), s.cols.as<int64_t>(), c->d_st_outoff.as<int64_t>(),
+                c->d_st_dense.as<uint8_t>()};
+  hipLaunchKernelGGL(k_compact, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(rows, c->d_st_dense.p, (size_t)total, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   return ELECTOR_OK;
 }

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import ElectorError, ElectorParams
+from ._capi import ElectorError, ElectorParams, ES_NCOUNTERS
 
 
 def default_params():
@@ -109,6 +109,63 @@ class PoaEngine:
             d_ncol.data_ptr(), d_status.data_ptr(),
             d_scores.data_ptr() if d_scores is not None else None)
         self._check(rc)
+
+    def msa_stats_device(self, n_windows, d_cols, d_ncol, d_status, piece_first, read_first, clips=None,
+                         last_cap=0):
+        """Second half of the MSA stage on the windows of the last align_device call:
+        merge them into one record per piece and count (include/elector_stats.h).
+        -> (counters int64[n_pieces, ES_NCOUNTERS], piece_cols int64[n_pieces],
+            last_rows, last_mask)   -- the last two are None unless last_cap > 0."""
+        piece_first = np.ascontiguousarray(piece_first, dtype=np.int64)
+        read_first = np.ascontiguousarray(read_first, dtype=np.int64)
+        n_pieces, n_reads = len(piece_first) - 1, len(read_first) - 1
+        counters = np.zeros((n_pieces, ES_NCOUNTERS), dtype=np.int64)
+        piece_cols = np.zeros(n_pieces, dtype=np.int64)
+        if clips is not None:
+            clips = np.ascontiguousarray(clips, dtype=np.int32)
+        last_rows = np.zeros(3 * last_cap + 1, dtype=np.uint8) if last_cap > 0 else None
+        last_mask = np.zeros(last_cap + 1, dtype=np.uint8) if last_cap > 0 else None
+        rc = self._lib.elector_msa_stats_device(
+            self._h, n_windows, d_cols.data_ptr(), d_ncol.data_ptr(), d_status.data_ptr(),
+            n_pieces, piece_first.ctypes.data, n_reads, read_first.ctypes.data,
+            clips.ctypes.data if clips is not None else None, counters.ctypes.data, piece_cols.ctypes.data,
+            last_rows.ctypes.data if last_rows is not None else None,
+            last_mask.ctypes.data if last_mask is not None else None, last_cap)
+        self._check(rc)
+        if last_cap > 0 and n_reads > 0:
+            nl = int(piece_cols[int(read_first[-2]):].sum())
+            last_rows, last_mask = last_rows[:3 * nl], last_mask[:nl]
+        return counters, piece_cols, last_rows, last_mask
+
+    def msa_stats_enqueue(self, n_windows, d_cols, d_ncol, d_status, piece_first, read_first, clips=None):
+        """First half of msa_stats_device: queue merge + counters behind the POA kernels and
+        return at once (at most two jobs in flight).  -> n_pieces, to pass to msa_stats_collect."""
+        piece_first = np.ascontiguousarray(piece_first, dtype=np.int64)
+        read_first = np.ascontiguousarray(read_first, dtype=np.int64)
+        if clips is not None:
+            clips = np.ascontiguousarray(clips, dtype=np.int32)
+        self._check(self._lib.elector_msa_stats_enqueue(
+            self._h, n_windows, d_cols.data_ptr(), d_ncol.data_ptr(), d_status.data_ptr(),
+            len(piece_first) - 1, piece_first.ctypes.data, len(read_first) - 1, read_first.ctypes.data,
+            clips.ctypes.data if clips is not None else None))
+        return len(piece_first) - 1
+
+    def msa_stats_collect(self, n_pieces):
+        """Wait for the oldest queued job -> (counters int64[n_pieces, ES_NCOUNTERS], piece_cols)."""
+        counters = np.zeros((n_pieces, ES_NCOUNTERS), dtype=np.int64)
+        piece_cols = np.zeros(n_pieces, dtype=np.int64)
+        self._check(self._lib.elector_msa_stats_collect(self._h, n_pieces, counters.ctypes.data,
+                                                        piece_cols.ctypes.data, None, None, 0))
+        return counters, piece_cols
+
+    def msa_rows_fetch(self, piece_cols):
+        """Merged records of the last msa_stats_device call: uint8[3 * sum(piece_cols)],
+        per piece the reference, corrected and uncorrected row back to back."""
+        piece_cols = np.ascontiguousarray(piece_cols, dtype=np.int64)
+        rows = np.zeros(3 * int(piece_cols.sum()) + 1, dtype=np.uint8)
+        self._check(self._lib.elector_msa_rows_fetch(self._h, len(piece_cols), piece_cols.ctypes.data,
+                                                     rows.ctypes.data))
+        return rows[:-1]
 
     def sync(self):
         self._check(self._lib.elector_ctx_sync(self._h))

@@ -53,6 +53,50 @@ int elector_stats_batch(elector_ctx *ctx, int64_t n_reads, const int64_t *read_f
                         int64_t n_pieces, const uint8_t *rows, const int64_t *row_off, const int64_t *cols,
                         const int32_t *clips, int64_t *counters, uint8_t *last_mask);
 
+/* The same statistics computed where the MSAs already are: merges the windows of
+ * the context's LAST elector_poa_batch_device call into one record per piece on
+ * the device (what `Donatello` does on files: src/split/Donatello.cpp:13-31
+ * drops the columns whose corrected letter is 'n', :48-93 concatenates the
+ * windows of a read; spawned from elector/alignment.py:120-122) and counts.
+ * Nothing but the integer counters crosses PCIe.
+ *
+ * n_windows, d_cols, d_ncol, d_status: the arguments/outputs of that POA call
+ * (device pointers).  Piece p owns windows [piece_first[p], piece_first[p+1]),
+ * read r owns pieces [read_first[r], read_first[r+1]) (host arrays); a window
+ * whose status is not 0 contributes no column.
+ * counters: out (host), n_pieces * ES_NCOUNTERS.  piece_cols: optional out
+ * (host), surviving columns per piece.  last_rows / last_mask: optional out
+ * (host), the LAST read's pieces back to back: per piece 3 * cols bytes
+ * (reference, corrected, uncorrected row) resp. cols mask bytes; last_cap =
+ * room in columns (the call fails with ELECTOR_E_INVAL when it is too small). */
+int elector_msa_stats_device(elector_ctx *ctx, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
+                             const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
+                             int64_t n_reads, const int64_t *read_first, const int32_t *clips,
+                             int64_t *counters, int64_t *piece_cols, uint8_t *last_rows, uint8_t *last_mask,
+                             int64_t last_cap);
+
+/* The same call in two halves, for callers that keep the GPU busy across batches:
+ * _enqueue validates, uploads the two small index arrays and queues the merge
+ * and statistics kernels and the copy of their results behind the POA kernels
+ * on the context's stream, without waiting; _collect waits for the OLDEST
+ * queued job and hands out its results (arguments as above; n_pieces must be
+ * the job's).  At most two jobs may be in flight per context, so a caller can
+ * prepare and queue batch i+1 (elector_poa_batch_device + _enqueue) while the
+ * device still works on batch i, then collect batch i.  d_cols/d_ncol/d_status
+ * are read by the queued kernels in stream order: a later POA call on the same
+ * context may reuse them. */
+int elector_msa_stats_enqueue(elector_ctx *ctx, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
+                              const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
+                              int64_t n_reads, const int64_t *read_first, const int32_t *clips);
+int elector_msa_stats_collect(elector_ctx *ctx, int64_t n_pieces, int64_t *counters, int64_t *piece_cols,
+                              uint8_t *last_rows, uint8_t *last_mask, int64_t last_cap);
+
+/* The merged records of the context's last COLLECTED statistics job, copied
+ * to the host (elector_msa_stats_device collects its own job): piece p's three rows (3 * piece_cols[p] bytes) back to back in
+ * piece order -- the body of msa.fa (Donatello.cpp:86-91).  piece_cols as
+ * returned by that call. */
+int elector_msa_rows_fetch(elector_ctx *ctx, int64_t n_pieces, const int64_t *piece_cols, uint8_t *rows);
+
 /* Homopolymer size pairs of ONE read (host side, integer output): walks the
  * pieces' columns with the reference's state machine (computeStats.py:291-365,
  * :427-432) and writes (corrected_size, reference_size) pairs.
