@@ -104,6 +104,9 @@ __host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G)
   return o + (mv > st ? mv : st);
 }
 
+// bytes of k_fused_b's staged MSA columns (3 per column) + the column of every uncorrected letter
+__host__ __device__ inline int fused_b_cols_bytes(int n1, int Lu) { return ((3 * (n1 + Lu) + 8 + 3) & ~3) + 2 * Lu + 4; }
+
 __host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G)
 {
   const int ns = (Lu + 4 * G - 1) / (4 * G);
@@ -115,7 +118,7 @@ __host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G)
   o += (ns > 1 ? 2 * (n1 + 1) : 0);
   o = (o + 3) & ~3;
   // moves + ordinal bytes of the two-predecessor nodes (estimated: one node in six)
-  const int mv = ns * n1 * G + (4 + n1 / 6) * ns * G, st = 3 * (n1 + Lu) + 8;
+  const int mv = ns * n1 * G + (4 + n1 / 6) * ns * G, st = fused_b_cols_bytes(n1, Lu);
   return o + (mv > st ? mv : st);
 }
 

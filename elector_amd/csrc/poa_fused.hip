@@ -241,7 +241,9 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
           if (yo) --y;
         }
       }
+      PHASE_STAMP(5);
       int n = 0, iy = 0, lastx = -1, lasty = -1;
+      const int vLrF = (a.debug & 16) ? 0 : vLr, vLcF = (a.debug & 16) ? 0 : vLc;   // timing experiment: traceback only
       auto emit = [&](int letter, int flags, int ring, int sa, int sb) {
         int pp1, pp2 = (int)kNone16;
         const int jj = n + 1;
@@ -253,7 +255,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
         xi_st[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
         ring_st[n] = (uint16_t)ring;
       };
-      for (int ix = 0; ix < vLr; ++ix) {
+      for (int ix = 0; ix < vLrF; ++ix) {
         const int ay = x2y[ix];
         const bool al = ay != (int)kNone16;
         if (al)
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
         emit(vx[ix], fl, ring, sa, sb);
         lastx = n; ++n;
       }
-      while (iy < vLc) {
+      while (iy < vLcF) {
         emit(vy[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == vLc - 1 ? kFlagFinal : 0), n, lasty, -1);
         lasty = n; ++n; ++iy;
       }
@@ -323,6 +325,53 @@ constexpr int kNeg16 = -16383;       // score of the "no predecessor" cells (bel
 
 __device__ __forceinline__ int cell16_S(int c) { return c >> 1; }
 
+// the column layout rule in its plain serial form (one lane): the fallback of k_fused_b's parallel version
+__device__ __noinline__ int fuse2_columns_serial(int n1, int Lu, const uint32_t *xinfo, const uint16_t *ring1,
+                                                 const uint16_t *x2y, const uint8_t *ys, const uint8_t *chr,
+                                                 uint8_t *cols_st)
+{
+  int col = 0, prev_ring = 0;
+  uint8_t c0 = '.', c1 = '.', c2 = '.';
+  auto flush = [&]() { cols_st[3 * col] = c0; cols_st[3 * col + 1] = c1; cols_st[3 * col + 2] = c2; };
+  auto place = [&](int ring_id, int letter, bool r, bool c, bool u) {
+    if (ring_id != prev_ring) { flush(); ++col; c0 = c1 = c2 = '.'; prev_ring = ring_id; }
+    const uint8_t ch = chr[letter & 31];
+    if (r) c0 = ch;
+    if (c) c1 = ch;
+    if (u) c2 = ch;
+  };
+  int n = 0, iy = 0, blk_old = -1, blk_new = -1;
+  for (int ix = 0; ix < n1; ++ix) {
+    const int r0 = ring1[ix];
+    if (r0 != blk_old) { blk_old = r0; blk_new = -1; }
+    for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
+      const int ay = x2y[k];
+      if (ay != (int)kNone16) {
+        while (iy < ay) { place(n, ys[iy], false, false, true); ++n; ++iy; }
+        break;
+      }
+    }
+    const uint32_t xv = xinfo[ix + 1];
+    const int letter = (xv >> 8) & 0xFF, fl = (int)(xv >> 16);
+    bool fused = false;
+    if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
+      if (letter == ys[iy]) fused = true;
+      else {
+        if (blk_new < 0) blk_new = n;
+        place(blk_new, ys[iy], false, false, true);
+        ++n;
+      }
+      ++iy;
+    }
+    if (blk_new < 0) blk_new = n;
+    place(blk_new, letter, (fl & kFlagHasRef) != 0, (fl & kFlagHasCor) != 0, fused);
+    ++n;
+  }
+  while (iy < Lu) { place(n, ys[iy], false, false, true); ++n; ++iy; }
+  flush();
+  return col + 1;
+}
+
 // one window of k_fused_b and its LDS slot layout:
 // [header 16 B: k2 / ncol, ok, best, bestx][unc symbols][node info u32[n1+1]][ring1 u16[n1]][x2y u16[n1]]
 // [bnd0 i16[n1+1]][bnd1 i16[n1+1] if ns>1][region]
@@ -359,7 +408,7 @@ __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
   v.off_b0 = v.off_x2y + align_up(2 * v.n1, 4);
   v.off_b1 = v.off_b0 + align_up(2 * (v.n1 + 1), 4);
   v.off_region = align_up(v.off_b1 + (v.ns > 1 ? 2 * (v.n1 + 1) : 0), 4);
-  const int region_min = max(v.ns * v.n1 * G, 3 * (v.n1 + v.Lu) + 8);
+  const int region_min = max(v.ns * v.n1 * G, fused_b_cols_bytes(v.n1, v.Lu));
   const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
   v.valid = v.valid && (v.off_region + region_min <= a.slot_bytes) && (maxpen * (v.n1 + v.Lu + 4) < 16000);
   return v;
@@ -378,8 +427,10 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   const uint32_t w = W.w;
   const int64_t o0 = W.o0;
   const int n1 = W.n1, Lu = W.Lu, ns = W.ns;
-  uint8_t *slot = lds + WV * 64 * 8 * kRingSlots + sidx * a.slot_bytes;
-  uint2 *ring = reinterpret_cast<uint2 *>(lds + wv * 64 * 8 * kRingSlots);   // this wave's [kRingSlots][64] x 4 cells of 16 bits
+  // LDS: [output characters 64 B][one score ring per wave][window slots]
+  uint8_t *chr = lds;
+  uint8_t *slot = lds + 64 + WV * 64 * 8 * kRingSlots + sidx * a.slot_bytes;
+  uint2 *ring = reinterpret_cast<uint2 *>(lds + 64 + wv * 64 * 8 * kRingSlots);   // this wave's [kRingSlots][64] x 4 cells of 16 bits
   const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(ring);
   int32_t *hdr = reinterpret_cast<int32_t *>(slot);
   uint8_t *ys = slot + 16;
@@ -391,6 +442,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   uint8_t *ordb = mv + ns * n1 * G;                              // [K2][ns][G]
 
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
+  if (threadIdx.x < 32) chr[threadIdx.x] = a.b.tab->chr[threadIdx.x];
   if (valid) {
     const int64_t nb = o0 + w;
     const uint8_t *sy = a.b.sym + W.o2;
@@ -409,7 +461,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   // (align_lpo_po2.c:275-286), index of the two-predecessor nodes, final fit check ----
   if (threadIdx.x < NW * WV) {
     const WinB V = load_win_b<G>(a, (int64_t)(NW * WV) * blockIdx.x + threadIdx.x);
-    uint8_t *vs = lds + WV * 64 * 8 * kRingSlots + threadIdx.x * a.slot_bytes;
+    uint8_t *vs = lds + 64 + WV * 64 * 8 * kRingSlots + threadIdx.x * a.slot_bytes;
     int32_t *vh = reinterpret_cast<int32_t *>(vs);
     int k2n = 0;
     bool ok = V.valid;
@@ -430,7 +482,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
         vb0[jj] = (int16_t)(r << 1);
       }
       ok = k2n <= 255 &&
-           (V.off_region + max(V.ns * V.n1 * G + k2n * V.ns * G, 3 * (V.n1 + V.Lu) + 8) <= a.slot_bytes);
+           (V.off_region + max(V.ns * V.n1 * G + k2n * V.ns * G, fused_b_cols_bytes(V.n1, V.Lu)) <= a.slot_bytes);
     }
     vh[0] = k2n; vh[1] = ok ? 1 : 0; vh[2] = kNeg; vh[3] = -1;
   }
@@ -560,102 +612,163 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   }
 
   if (valid && g == gstar) { hdr[2] = best; hdr[3] = bestx; }
+  if (valid) {
+    uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + W.off_x2y);
+    for (int i = g; i < n1; i += G) x2y[i] = (uint16_t)kNone16;
+  }
   __syncthreads();
 
   PHASE_STAMP(9);
-  // ---- traceback #2 + fusion #2 + MSA columns: lane l of wave 0 serves the block's window slot l ----
-  if (threadIdx.x < NW * WV && !(a.debug & 2)) {
-    const WinB V = load_win_b<G>(a, (int64_t)(NW * WV) * blockIdx.x + threadIdx.x);
-    uint8_t *vs = lds + WV * 64 * 8 * kRingSlots + threadIdx.x * a.slot_bytes;
-    int32_t *vh = reinterpret_cast<int32_t *>(vs);
-    if (V.valid && vh[1] != 0) {
-      const int n1 = V.n1, Lu = V.Lu, ns = V.ns;
-      const uint8_t *ys = vs + 16;
-      const uint32_t *xinfo = reinterpret_cast<const uint32_t *>(vs + V.off_xi);
-      const uint16_t *ring1 = reinterpret_cast<const uint16_t *>(vs + V.off_r1);
-      uint16_t *x2y = reinterpret_cast<uint16_t *>(vs + V.off_x2y);
-      const uint8_t *mv = vs + V.off_region;
-      const uint8_t *ordb = mv + ns * n1 * G;
-      uint8_t *cols_st = vs + V.off_region;                        // overlays the moves after traceback
-      const int bestx = vh[3];
-      bool bad = false;
-      int ncol = 0;
-    for (int j = 0; j < n1; ++j) x2y[j] = (uint16_t)kNone16;
-    {
-      int x = bestx, y = Lu - 1, guard = n1 + Lu + 2;
-      while (x >= 0 && y >= 0 && guard-- > 0) {
-        const int r = y % RS;
-        const uint32_t two = (mv[((y / RS) * n1 + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
-        const int xo = two & 1, yo = two >> 1;
-        if (xo && yo) x2y[x] = (uint16_t)y;
-        if (!xo && !yo) { bad = true; break; }
-        if (xo) {
-          const uint32_t inf = xinfo[x + 1];
-          const int d2v = (inf >> 4) & 15;
-          const int sec = d2v ? (ordb[((inf >> 24) * ns + (y / RS)) * G + (r >> 2)] >> (r & 3)) & 1 : 0;
-          const int dd = sec ? d2v : (int)(inf & 15);
-          x = (dd == 0 || dd == 15) ? -1 : x - dd;
-        }
-        if (yo) --y;
+  uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + W.off_x2y);
+  uint8_t *cols_st = slot + W.off_region;                               // overlays the moves after the traceback
+  uint16_t *col_y = reinterpret_cast<uint16_t *>(slot + W.off_region + align_up(3 * (n1 + Lu) + 8, 4));
+  bool bad = false;
+  // ---- traceback #2 (align_lpo_po2.c:108-168): the first lane of the window's group ----
+  if (valid && g == 0 && !(a.debug & 2)) {
+    int x = hdr[3], y = Lu - 1, guard = n1 + Lu + 2;
+    while (x >= 0 && y >= 0 && guard-- > 0) {
+      const int r = y % RS;
+      const uint32_t inf = xinfo[x + 1];
+      const uint32_t two = (mv[((y / RS) * n1 + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
+      const int xo = two & 1, yo = two >> 1;
+      if (xo && yo) x2y[x] = (uint16_t)y;
+      if (!xo && !yo) { bad = true; break; }
+      if (xo) {
+        const int d2v = (inf >> 4) & 15;
+        const int sec = d2v ? (ordb[((inf >> 24) * ns + (y / RS)) * G + (r >> 2)] >> (r & 3)) & 1 : 0;
+        const int dd = sec ? d2v : (int)(inf & 15);
+        x = (dd == 0 || dd == 15) ? -1 : x - dd;
       }
-    }
-    const uint8_t *chr = a.b.tab->chr;
-    int col = 0, prev_ring = 0;
-    uint8_t c0 = '.', c1 = '.', c2 = '.';
-    auto flush = [&]() { cols_st[3 * col] = c0; cols_st[3 * col + 1] = c1; cols_st[3 * col + 2] = c2; };
-    auto place = [&](int ring_id, int letter, bool r, bool c, bool u) {
-      if (ring_id != prev_ring) { flush(); ++col; c0 = c1 = c2 = '.'; prev_ring = ring_id; }
-      const uint8_t ch = chr[letter];
-      if (r) c0 = ch;
-      if (c) c1 = ch;
-      if (u) c2 = ch;
-    };
-    int n = 0, iy = 0, blk_old = -1, blk_new = -1;
-    for (int ix = 0; ix < n1; ++ix) {
-      const int r0 = ring1[ix];
-      if (r0 != blk_old) { blk_old = r0; blk_new = -1; }
-      for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
-        const int ay = x2y[k];
-        if (ay != (int)kNone16) {
-          while (iy < ay) { place(n, ys[iy], false, false, true); ++n; ++iy; }
-          break;
-        }
-      }
-      const uint32_t xv = xinfo[ix + 1];
-      const int letter = (xv >> 8) & 0xFF, fl = (int)(xv >> 16);
-      bool fused = false;
-      if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
-        if (letter == ys[iy]) fused = true;
-        else {
-          if (blk_new < 0) blk_new = n;
-          place(blk_new, ys[iy], false, false, true);
-          ++n;
-        }
-        ++iy;
-      }
-      if (blk_new < 0) blk_new = n;
-      place(blk_new, letter, (fl & kFlagHasRef) != 0, (fl & kFlagHasCor) != 0, fused);
-      ++n;
-    }
-    while (iy < Lu) { place(n, ys[iy], false, false, true); ++n; ++iy; }
-    flush();
-    ncol = col + 1;
-      vh[0] = ncol;
-      if (bad) vh[1] = 2;
+      if (yo) --y;
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
+  PHASE_STAMP(13);
+  // ---- fusion #2 and the MSA columns (lpo.c:602-668 column layout rule, lpo_format.c:337-393), spread
+  // over the window's G lanes.  Only the columns are needed, not the fused graph: every ring of the
+  // (ref + cor) graph is one column, an uncorrected letter aligned to one of the ring's nodes joins it,
+  // every other uncorrected letter gets a column of its own just before the next ring that holds an
+  // aligned letter (at the end when there is none).  Column of ring k = k + (aligned letter of the last
+  // aligned ring <= k) - (aligned rings before that one); scans over nodes give those terms.
+  int ncol = 0;
+  {
+    const int cn = (n1 + G - 1) / G, cy = (Lu + G - 1) / G;                // nodes / letters per lane
+    int cnmax = valid ? cn : 0, cymax = valid ? cy : 0;
+    for (int d = G; d < 64; d <<= 1) {
+      cnmax = max(cnmax, __shfl_xor(cnmax, d));
+      cymax = max(cymax, __shfl_xor(cymax, d));
+    }
+    cnmax = __builtin_amdgcn_readfirstlane(cnmax);
+    cymax = __builtin_amdgcn_readfirstlane(cymax);
+    if (a.debug & 2) { cnmax = 0; cymax = 0; }
+    if (valid) for (int i = g; i < Lu; i += G) col_y[i] = (uint16_t)kNone16;
+    const int i0 = g * cn, i1 = valid ? min(n1, i0 + cn) : 0;
+    // the aligned letter of the ring that starts at node ix (-1: none); cnt > 1 cannot come from a path
+    auto ring_aligned = [&](int ix, int r0, bool *odd) {
+      int ay = -1, cnt = 0;
+      for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
+        const int v = x2y[k];
+        if (v != (int)kNone16) { if (!cnt) ay = v; ++cnt; }
+      }
+      if (cnt > 1) *odd = true;
+      return ay;
+    };
+    bool odd = false;
+    int ngs = 0, nal = 0, last_ay = -1;
+    for (int it = 0; it < cnmax; ++it) {
+      const int ix = i0 + it;
+      if (ix < i1) {
+        const int r0 = ring1[ix];
+        if (ix == 0 || ring1[ix - 1] != r0) {
+          ++ngs;
+          const int ay = ring_aligned(ix, r0, &odd);
+          if (ay >= 0) { ++nal; if (ay <= last_ay) odd = true; last_ay = ay; }
+        }
+      }
+    }
+    int sg = ngs, sa = nal, sy = last_ay;                                  // inclusive scans over the group's lanes
+    for (int d = 1; d < G; d <<= 1) {
+      const int tg = __shfl_up(sg, d, G), ta = __shfl_up(sa, d, G), ty = __shfl_up(sy, d, G);
+      if (g >= d) { sg += tg; sa += ta; sy = max(sy, ty); }
+    }
+    const int prev_ay = __shfl_up(sy, 1, G);
+    int gcount = sg - ngs, alc = sa - nal, A = g > 0 ? prev_ay : -1;
+    const int ngroups = __shfl(sg, G - 1, G), nal_all = __shfl(sa, G - 1, G);
+    ncol = ngroups + Lu - nal_all;
+    __builtin_amdgcn_wave_barrier();
+    for (int it = 0; it < cnmax; ++it) {
+      const int ix = i0 + it;
+      if (ix < i1) {
+        const int r0 = ring1[ix];
+        if (ix == 0 || ring1[ix - 1] != r0) {
+          int ay = -1;
+          uint8_t c0 = '.', c1 = '.';
+          for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
+            const uint32_t xv = xinfo[k + 1];
+            const uint8_t ch = chr[(xv >> 8) & 31];
+            if ((xv >> 16) & kFlagHasRef) c0 = ch;
+            if ((xv >> 16) & kFlagHasCor) c1 = ch;
+            const int v = x2y[k];
+            if (v != (int)kNone16 && ay < 0) ay = v;
+          }
+          if (ay >= 0) { if (ay <= A) odd = true; ++alc; A = ay; }
+          const int col = gcount + (alc >= 1 ? A - (alc - 1) : 0);
+          if (col >= 0 && col < n1 + Lu) {
+            cols_st[3 * col] = c0;
+            cols_st[3 * col + 1] = c1;
+            cols_st[3 * col + 2] = ay >= 0 ? chr[ys[ay] & 31] : (uint8_t)'.';
+          } else odd = true;
+          if (ay >= 0) col_y[ay] = (uint16_t)col;
+          ++gcount;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // letters without a partner: column = K + y with K = (column - letter) of the next aligned letter
+    constexpr int kUndef = -0x40000000;
+    const int y0 = g * cy, y1 = valid ? min(Lu, y0 + cy) : 0;
+    int klow = kUndef;
+    for (int it = 0; it < cymax; ++it) {
+      const int y = y1 - 1 - it;
+      if (y >= y0) { const int c = col_y[y]; if (c != (int)kNone16) klow = c - y; }
+    }
+    int sfx = klow;                                                        // nearest defined value at or after this lane
+    for (int d = 1; d < G; d <<= 1) {
+      const int t = __shfl_down(sfx, d, G);
+      if (g + d < G && sfx == kUndef) sfx = t;
+    }
+    int K = __shfl_down(sfx, 1, G);
+    if (g == G - 1 || K == kUndef) K = ncol - Lu;
+    for (int it = 0; it < cymax; ++it) {
+      const int y = y1 - 1 - it;
+      if (y >= y0) {
+        const int c = col_y[y];
+        if (c != (int)kNone16) K = c - y;
+        else {
+          const int col = K + y;
+          if (col >= 0 && col < n1 + Lu) {
+            cols_st[3 * col] = '.'; cols_st[3 * col + 1] = '.'; cols_st[3 * col + 2] = chr[ys[y] & 31];
+          } else odd = true;
+        }
+      }
+    }
+    for (int d = 1; d < G; d <<= 1) odd = odd || __shfl_xor(odd ? 1 : 0, d, G) != 0;
+    __builtin_amdgcn_wave_barrier();
+    // an alignment that is not a monotone path through the rings cannot happen; if it ever does,
+    // the plain serial form of the rule decides
+    if (valid && odd && g == 0 && !bad) ncol = fuse2_columns_serial(n1, Lu, xinfo, ring1, x2y, ys, chr, cols_st);
+    ncol = __shfl(ncol, 0, G);
+  }
+  __builtin_amdgcn_wave_barrier();
   PHASE_STAMP(10);
   if (valid) {
-    const int ncol = hdr[0];
-    const uint8_t *cols_st = slot + W.off_region;
     uint8_t *gc = a.b.cols + 3 * o0;
     for (int i = g; i < 3 * ncol; i += G) gc[i] = cols_st[i];
     if (g == 0) {
       a.b.ncol[w] = ncol;
       a.b.score2[w] = hdr[2];
       a.b.bx2[w] = hdr[3];
-      if (hdr[1] == 2) a.b.status[w] = 3;
+      if (bad) a.b.status[w] = 3;
       a.done_b[w] = 1;
     }
   }
@@ -692,7 +805,7 @@ static int launch_b_t(const FusedArgs &a, hipStream_t st)
     attr = true;
   }
   hipLaunchKernelGGL((k_fused_b<G, WV>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64 * WV),
-                     NB * a.slot_bytes + WV * 64 * 8 * kRingSlots, st, a);
+                     64 + NB * a.slot_bytes + WV * 64 * 8 * kRingSlots, st, a);
   return 0;
 }
 
@@ -709,10 +822,7 @@ int launch_fused_a(const FusedArgs &a, int G, hipStream_t st)
 int launch_fused_b(const FusedArgs &a, int G, hipStream_t st)
 {
   if (a.nlist <= 0) return 0;
-  const bool multi = std::getenv("ELECTOR_B_WV4") != nullptr;   // shared serial stage: measured no faster
-  if (G == 16) return multi && 16 * a.slot_bytes <= 60 * 1024 ? launch_b_t<16, 4>(a, st) : launch_b_t<16, 1>(a, st);
-  if (G == 32) return multi && 8 * a.slot_bytes <= 60 * 1024 ? launch_b_t<32, 4>(a, st) : launch_b_t<32, 1>(a, st);
-  return launch_b_t<64, 1>(a, st);
+  return G == 16 ? launch_b_t<16, 1>(a, st) : G == 32 ? launch_b_t<32, 1>(a, st) : launch_b_t<64, 1>(a, st);
 }
 
 }  // namespace elector

@@ -802,10 +802,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     for (int b = 0; b < 12; ++b) {
       const unsigned long long *p = hs + 32 * b;
       if (!p[4]) continue;
-      std::fprintf(stderr, "[elector] class %d G%d/%d  A waves %llu: stage %.0f dp %.0f serial %.0f out %.0f | B waves %llu: stage %.0f dp %.0f serial %.0f out %.0f  (cycles per wave)\n",
-                   b, kBinG[b], kSlot[b], p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],
-                   p[12], p[12] ? (double)p[8] / p[12] : 0, p[12] ? (double)p[9] / p[12] : 0, p[12] ? (double)p[10] / p[12] : 0,
-                   p[12] ? (double)p[11] / p[12] : 0);
+      std::fprintf(stderr, "[elector] class %d G%d/%d  A waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f | B waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f  (cycles per wave)\n",
+                   b, kBinG[b], kSlot[b], p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[5] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],
+                   p[12], p[12] ? (double)p[8] / p[12] : 0, p[12] ? (double)p[9] / p[12] : 0, p[12] ? (double)p[13] / p[12] : 0,
+                   p[12] ? (double)p[10] / p[12] : 0, p[12] ? (double)p[11] / p[12] : 0);
     }
   }
   return ELECTOR_OK;

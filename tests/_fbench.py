@@ -13,8 +13,13 @@ for dbg in [int(x) for x in os.environ.get("FB_DEBUGS","0,1,2,3").split(",")]:
     os.environ["ELECTOR_DEBUG_FUSED"] = str(dbg)
     eng = PoaEngine(0)
     for _ in range(2): eng.align_device(d_bases, win.off, d_cols, d_ncol, d_status)
-    eng.sync(); eng.timing_enable(True); eng.timing_reset()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(5): eng.align_device(d_bases, win.off, d_cols, d_ncol, d_status)
+    eng.sync()
+    wall = (time.perf_counter() - t0) / 5 * 1e3
+    eng.timing_enable(True); eng.timing_reset()
     for _ in range(3): eng.align_device(d_bases, win.off, d_cols, d_ncol, d_status)
     eng.sync()
-    print("debug", dbg, "k_a %.3f ms/step" % (eng.timing_read(0)[0]/3), "dp2 %.3f" % (eng.timing_read(1)[0]/3), "other %.3f" % (eng.timing_read(2)[0]/3), flush=True)
+    print("debug", dbg, "wall %.3f ms/step" % wall, "k_a %.3f ms/step" % (eng.timing_read(0)[0]/3), "dp2 %.3f" % (eng.timing_read(1)[0]/3), "other %.3f" % (eng.timing_read(2)[0]/3), flush=True)
     eng.close()
