@@ -444,50 +444,78 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
   if (threadIdx.x < 32) chr[threadIdx.x] = a.b.tab->chr[threadIdx.x];
   if (valid) {
+    // staging: loads of four rounds are issued before their values are used
     const int64_t nb = o0 + w;
     const uint8_t *sy = a.b.sym + W.o2;
-    for (int i = g; i < Lu; i += G) ys[i] = sy[i];
-    for (int i = 1 + g; i <= n1; i += G) {
-      const int2 xi = a.b.xinfo[nb + i];
-      const int pp1 = xi.x & 0xFFFF, pp2 = (int)((uint32_t)xi.x >> 16);
-      const uint32_t d1 = pp1 == 0 ? 0u : (uint32_t)(i - pp1);                    // <= 6 (ring eligibility)
-      const uint32_t d2 = pp2 == (int)kNone16 ? 0u : pp2 == 0 ? 15u : (uint32_t)(i - pp2);
-      xinfo[i] = d1 | (d2 << 4) | ((uint32_t)(xi.y & 0xFF) << 8) | ((uint32_t)((xi.y >> 8) & 0xFF) << 16);
-    }
-    for (int i = g; i < n1; i += G) ring1[i] = a.b.ring1[nb + i];
-  }
-  __syncthreads();
-  // ---- per-window prologue by the first lanes of wave 0: virtual row -1 over the graph
-  // (align_lpo_po2.c:275-286), index of the two-predecessor nodes, final fit check ----
-  if (threadIdx.x < NW * WV) {
-    const WinB V = load_win_b<G>(a, (int64_t)(NW * WV) * blockIdx.x + threadIdx.x);
-    uint8_t *vs = lds + 64 + WV * 64 * 8 * kRingSlots + threadIdx.x * a.slot_bytes;
-    int32_t *vh = reinterpret_cast<int32_t *>(vs);
-    int k2n = 0;
-    bool ok = V.valid;
-    if (ok) {
-      uint32_t *vxi = reinterpret_cast<uint32_t *>(vs + V.off_xi);
-      int16_t *vb0 = reinterpret_cast<int16_t *>(vs + V.off_b0);
-      vb0[0] = 1;                                              // score 0, origin counts as "open"
-      for (int jj = 1; jj <= V.n1; ++jj) {
-        uint32_t inf = vxi[jj];
-        const int d1 = inf & 15, d2 = (inf >> 4) & 15;
-        if (d2) { inf |= (uint32_t)min(k2n, 255) << 24; vxi[jj] = inf; ++k2n; }
-        const int pp1 = d1 ? jj - d1 : 0;
-        int r = cell16_S(vb0[pp1]) - (pp1 == 0 ? kp.open_x : kp.ext_x);
-        if (d2) {
-          const int pp2 = d2 == 15 ? 0 : jj - d2;
-          r = max(r, cell16_S(vb0[pp2]) - (pp2 == 0 ? kp.open_x : kp.ext_x));
+    const int2 *gx = a.b.xinfo + nb;
+    const uint16_t *gr = a.b.ring1 + nb;
+    for (int ib = 1 + g; ib <= n1; ib += 4 * G) {
+      int2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = ib + u * G; v[u] = i <= n1 ? gx[i] : make_int2(0, 0); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = ib + u * G;
+        if (i <= n1) {
+          const int pp1 = v[u].x & 0xFFFF, pp2 = (int)((uint32_t)v[u].x >> 16);
+          const uint32_t d1 = pp1 == 0 ? 0u : (uint32_t)(i - pp1);                    // <= 6 (ring eligibility)
+          const uint32_t d2 = pp2 == (int)kNone16 ? 0u : pp2 == 0 ? 15u : (uint32_t)(i - pp2);
+          xinfo[i] = d1 | (d2 << 4) | ((uint32_t)(v[u].y & 0xFF) << 8) | ((uint32_t)((v[u].y >> 8) & 0xFF) << 16);
         }
-        vb0[jj] = (int16_t)(r << 1);
       }
-      ok = k2n <= 255 &&
-           (V.off_region + max(V.ns * V.n1 * G + k2n * V.ns * G, fused_b_cols_bytes(V.n1, V.Lu)) <= a.slot_bytes);
     }
-    vh[0] = k2n; vh[1] = ok ? 1 : 0; vh[2] = kNeg; vh[3] = -1;
+    for (int ib = g; ib < n1; ib += 4 * G) {
+      uint16_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = ib + u * G; v[u] = i < n1 ? gr[i] : (uint16_t)0; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = ib + u * G; if (i < n1) ring1[i] = v[u]; }
+    }
+    for (int ib = g; ib < Lu; ib += 4 * G) {
+      uint8_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = ib + u * G; v[u] = i < Lu ? sy[i] : (uint8_t)0; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = ib + u * G; if (i < Lu) ys[i] = v[u]; }
+    }
+    if (g == 0) { bnd0[0] = 1; hdr[2] = kNeg; hdr[3] = -1; }      // border origin: score 0, counts as "open"
   }
   __syncthreads();
-  valid = valid && hdr[1] != 0;
+  // nodes / letters per lane for the passes that walk them in contiguous chunks
+  const int cn = (n1 + G - 1) / G, cy = (Lu + G - 1) / G;
+  int cnmax = valid ? cn : 0, cymax = valid ? cy : 0;
+  for (int d = G; d < 64; d <<= 1) {
+    cnmax = max(cnmax, __shfl_xor(cnmax, d));
+    cymax = max(cymax, __shfl_xor(cymax, d));
+  }
+  cnmax = __builtin_amdgcn_readfirstlane(cnmax);
+  cymax = __builtin_amdgcn_readfirstlane(cymax);
+  // ---- index of the nodes with two predecessors (they own a row of ordinal bytes), final fit check ----
+  {
+    const int j0 = 1 + g * cn, j1 = valid ? min(n1 + 1, j0 + cn) : 0;
+    int cnt = 0;
+    for (int it = 0; it < cnmax; ++it) {
+      const int jj = j0 + it;
+      if (jj < j1) cnt += ((xinfo[jj] >> 4) & 15u) != 0;
+    }
+    int sc = cnt;
+    for (int d = 1; d < G; d <<= 1) {
+      const int t = __shfl_up(sc, d, G);
+      if (g >= d) sc += t;
+    }
+    const int k2n = __shfl(sc, G - 1, G);
+    int k = sc - cnt;
+    for (int it = 0; it < cnmax; ++it) {
+      const int jj = j0 + it;
+      if (jj < j1) {
+        const uint32_t inf = xinfo[jj];
+        if ((inf >> 4) & 15u) { xinfo[jj] = inf | ((uint32_t)min(k, 255) << 24); ++k; }
+      }
+    }
+    valid = valid && k2n <= 255 &&
+            (W.off_region + max(ns * n1 * G + k2n * ns * G, fused_b_cols_bytes(n1, Lu)) <= a.slot_bytes);
+  }
+  __syncthreads();
 
   PHASE_STAMP(8);
   int tmax = valid ? n1 + G - 1 : 0, nsmax = valid ? ns : 0;
@@ -526,9 +554,6 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
     const bool last_strip_row = sv && s == ns - 1 && g == gstar;
     uint32_t xi_next = (sv && g == 0 && n1 >= 1) ? xinfo[1] : 0u;
     for (int t = 1; t <= tmax; ++t) {
-      const int bc = (sv && t <= n1) ? bcur[t] : 0;
-      const int bS = bc >> 1, bEy = bS - ((bc & 1) ? kp.open_y : kp.ext_y);
-      const int upEy = shift_in<G>(bEy, Ey[3], g);
       const int jj = t - g;
       const uint32_t xi = xi_next;
       xi_next = (sv && jj >= 0 && jj < n1) ? xinfo[jj + 1] : 0u;
@@ -536,12 +561,23 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
       const int d1i = xi & 15, d2i = (xi >> 4) & 15;
       const int pp1 = d1i ? jj - d1i : 0, pp2 = d2i == 15 ? 0 : jj - d2i;
       const bool has2 = act && d2i != 0;
+      const int ppa = act ? pp1 : 0;
+      const int b1 = bcur[sv ? ppa : 0], b2 = bcur[has2 ? pp2 : 0];
+      int bc = (sv && t <= n1) ? bcur[t] : 0;
+      if (s == 0 && g == 0 && act) {
+        // the virtual row -1 over the graph (align_lpo_po2.c:275-286): column t, one step ahead of its use
+        int r = (b1 >> 1) - ((b1 & 1) ? kp.open_x : kp.ext_x);
+        if (has2) r = max(r, (b2 >> 1) - ((b2 & 1) ? kp.open_x : kp.ext_x));
+        bc = r << 1;
+        bnd0[t] = (int16_t)bc;
+      }
+      const int bS = bc >> 1, bEy = bS - ((bc & 1) ? kp.open_y : kp.ext_y);
+      const int upEy = shift_in<G>(bEy, Ey[3], g);
       const int lm1 = (lane - 1) & 63;
       // ---- predecessor cells.  Own four cells at column pp: this lane's ring slot of
       // d = jj - pp steps ago; the cell above them: lane-1's slot one step earlier (the strip
       // border array for the group's first lane).  The virtual start column lives in slot 16,
       // a missing second predecessor reads the very negative cells of slot 17: no value selects. ----
-      const int ppa = act ? pp1 : 0;
       const int sa = (ppa == 0) ? kRingDepth : ((t - (jj - ppa)) & (kRingDepth - 1));
       const int sat = (ppa == 0) ? kRingDepth : ((t - (jj - ppa) - 1) & (kRingDepth - 1));
       const int sb = !has2 ? kRingDepth + 1 : (pp2 == 0) ? kRingDepth : ((t - (jj - pp2)) & (kRingDepth - 1));
@@ -550,7 +586,6 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
       const uint2 c2 = ring[sb * 64 + lane];
       const int r1 = (int16_t)ring16[(sat * 64 + lm1) * 4 + 3];
       const int r2 = (int16_t)ring16[(sbt * 64 + lm1) * 4 + 3];
-      const int b1 = bcur[sv ? ppa : 0], b2 = bcur[has2 ? pp2 : 0];
       if (act) {
         const int xl = (xi >> 8) & 0xFF;
         const int d1top = ((g == 0) ? b1 : r1) >> 1;
@@ -652,14 +687,6 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   // aligned ring <= k) - (aligned rings before that one); scans over nodes give those terms.
   int ncol = 0;
   {
-    const int cn = (n1 + G - 1) / G, cy = (Lu + G - 1) / G;                // nodes / letters per lane
-    int cnmax = valid ? cn : 0, cymax = valid ? cy : 0;
-    for (int d = G; d < 64; d <<= 1) {
-      cnmax = max(cnmax, __shfl_xor(cnmax, d));
-      cymax = max(cymax, __shfl_xor(cymax, d));
-    }
-    cnmax = __builtin_amdgcn_readfirstlane(cnmax);
-    cymax = __builtin_amdgcn_readfirstlane(cymax);
     if (a.debug & 2) { cnmax = 0; cymax = 0; }
     if (valid) for (int i = g; i < Lu; i += G) col_y[i] = (uint16_t)kNone16;
     const int i0 = g * cn, i1 = valid ? min(n1, i0 + cn) : 0;
