@@ -93,6 +93,9 @@ struct BatchArgs {
 
 // LDS bytes the fused kernels need for a window in a group of G lanes (4G rows per
 // strip); must mirror the slot layouts in poa_fused.hip
+// bytes of k_fused_a's node maps (u16 per ref letter, 2 x u16 per cor letter)
+__host__ __device__ inline int fused_a_maps_bytes(int Lr, int Lc) { return 2 * ((Lr + 1) & ~1) + 4 * ((Lc + 1) & ~1) + 8; }
+
 __host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G)
 {
   const int ns = (Lc + 4 * G - 1) / (4 * G);
@@ -100,7 +103,7 @@ __host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G)
   o += (2 * Lr + 3) & ~3;
   o += (ns > 1 ? 4 * (Lr + 1) : 0);
   o = (o + 7) & ~7;
-  const int mv = ns * Lr * G, st = 8 * (Lr + Lc + 1) + 2 * (Lr + Lc);
+  const int mv = ns * Lr * G, st = fused_a_maps_bytes(Lr, Lc);
   return o + (mv > st ? mv : st);
 }
 

@@ -88,9 +88,9 @@ __device__ __forceinline__ CellOut cell_1pred(int diag, int insX, int insY, int 
 // ---------------------------------------------------------------- k_fused_a ---
 
 // one window of k_fused_a: ids, lengths and its LDS slot layout
-// slot: [header 16 B: n1, maxd, bad][ref+cor symbols][x2y u16][carry i32 (multi-strip only)][region]
+// slot: [header 16 B, unused][ref+cor symbols][x2y u16][carry i32 (multi-strip only)][region]
 // region = alignment #1 moves (1 byte per lane and column: 4 cells x 2 bits), reused after the
-// traceback for the staged graph (xinfo int2[n1+1], then ring ids u16[n1])
+// traceback for the node maps of the fusion (node of every ref / cor letter, cor -> ref map, u16 each)
 struct WinA {
   bool valid;
   uint32_t w;
@@ -116,14 +116,12 @@ __device__ __forceinline__ WinA load_win_a(const FusedArgs &a, int64_t li)
   v.off_x2y = 16 + align_up(v.Lr + v.Lc, 4);
   v.off_carry = v.off_x2y + align_up(2 * v.Lr, 4);
   v.off_region = align_up(v.off_carry + (v.ns > 1 ? 4 * (v.Lr + 1) : 0), 8);
-  const int region_bytes = max(v.ns * v.Lr * G, 8 * (v.Lr + v.Lc + 1) + 2 * (v.Lr + v.Lc));
+  const int region_bytes = max(v.ns * v.Lr * G, fused_a_maps_bytes(v.Lr, v.Lc));
   v.valid = v.valid && (v.off_region + region_bytes <= a.slot_bytes);
   return v;
 }
 
-// WV wavefronts per block: each runs the DP of its own 64/G windows; the per-window serial
-// stage (traceback + fusion) of ALL the block's windows is then run by the first lanes of
-// wave 0, so that an instruction of the serial stage serves WV * 64/G windows at once.
+// WV wavefronts per block, each owning 64/G windows from staging to the fused graph.
 template <int G, int WV>
 __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
 {
@@ -211,103 +209,176 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
     __builtin_amdgcn_wave_barrier();
   }
   if (valid && g == gstar) a.b.score1[W.w] = score;
+  uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + W.off_x2y);
+  if (valid) for (int i = g; i < Lr; i += G) x2y[i] = (uint16_t)kNone16;
   __syncthreads();
 
   PHASE_STAMP(1);
-  // ---- traceback #1 + fusion #1: lane l of wave 0 serves the block's window slot l ----
-  if (threadIdx.x < NW * WV && !(a.debug & 2)) {
-    const WinA V = load_win_a<G>(a, (int64_t)(NW * WV) * blockIdx.x + threadIdx.x);
-    if (V.valid) {
-      uint8_t *vs = lds + threadIdx.x * a.slot_bytes;
-      int32_t *hdr = reinterpret_cast<int32_t *>(vs);
-      const uint8_t *vx = vs + 16, *vy = vx + V.Lr;
-      uint16_t *x2y = reinterpret_cast<uint16_t *>(vs + V.off_x2y);
-      const uint8_t *vmv = vs + V.off_region;
-      int2 *xi_st = reinterpret_cast<int2 *>(vs + V.off_region);     // overlays the moves after traceback
-      uint16_t *ring_st = reinterpret_cast<uint16_t *>(vs + V.off_region + 8 * (V.Lr + V.Lc + 1));
-      const int vLr = V.Lr, vLc = V.Lc;
-      int maxd = 1;
-      bool bad = false;
-      for (int j = 0; j < vLr; ++j) x2y[j] = (uint16_t)kNone16;
-      {
-        int x = vLr - 1, y = vLc - 1, guard = vLr + vLc + 2;
-        while (x >= 0 && y >= 0 && guard-- > 0) {
-          const int r = y % RS;
-          const uint32_t two = (vmv[((y / RS) * vLr + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
-          const int xo = two & 1, yo = two >> 1;
-          if (xo && yo) x2y[x] = (uint16_t)y;
-          if (!xo && !yo) { bad = true; break; }
-          if (xo) --x;
-          if (yo) --y;
-        }
-      }
-      PHASE_STAMP(5);
-      int n = 0, iy = 0, lastx = -1, lasty = -1;
-      const int vLrF = (a.debug & 16) ? 0 : vLr, vLcF = (a.debug & 16) ? 0 : vLc;   // timing experiment: traceback only
-      auto emit = [&](int letter, int flags, int ring, int sa, int sb) {
-        int pp1, pp2 = (int)kNone16;
-        const int jj = n + 1;
-        if (sa < 0) pp1 = 0;
-        else if (flags & kFlagInitial) { pp1 = 0; pp2 = sa + 1; if (sb >= 0) bad = true; }
-        else { pp1 = sa + 1; if (sb >= 0) pp2 = sb + 1; }
-        if (pp1 > 0) maxd = max(maxd, jj - pp1);
-        if (pp2 != (int)kNone16 && pp2 > 0) maxd = max(maxd, jj - pp2);
-        xi_st[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
-        ring_st[n] = (uint16_t)ring;
-      };
-      for (int ix = 0; ix < vLrF; ++ix) {
-        const int ay = x2y[ix];
-        const bool al = ay != (int)kNone16;
-        if (al)
-          while (iy < ay) {
-            emit(vy[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == vLc - 1 ? kFlagFinal : 0), n, lasty, -1);
-            lasty = n; ++n; ++iy;
-          }
-        int fl = kFlagHasRef | (ix == 0 ? kFlagInitial : 0) | (ix == vLr - 1 ? kFlagFinal : 0);
-        int sa = lastx, sb = -1, ring = n;
-        if (al && iy < vLc) {
-          const int fy = kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == vLc - 1 ? kFlagFinal : 0);
-          if (vx[ix] == vy[iy]) {
-            fl |= fy;
-            if (lasty >= 0 && lasty != lastx) { if (sa < 0) sa = lasty; else sb = lasty; }
-            emit(vx[ix], fl, n, sa, sb);
-            lastx = lasty = n; ++n; ++iy;
-            continue;
-          }
-          emit(vy[iy], fy, n, lasty, -1);
-          ring = n; lasty = n; ++n; ++iy;
-        }
-        emit(vx[ix], fl, ring, sa, sb);
-        lastx = n; ++n;
-      }
-      while (iy < vLcF) {
-        emit(vy[iy], kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == vLc - 1 ? kFlagFinal : 0), n, lasty, -1);
-        lasty = n; ++n; ++iy;
-      }
-      hdr[0] = n; hdr[1] = maxd; hdr[2] = bad ? 1 : 0;
+  bool bad = false;
+  // ---- traceback #1 (align_lpo_po2.c:108-168): the first lane of the window's group ----
+  if (valid && g == 0 && !(a.debug & 2)) {
+    int x = Lr - 1, y = Lc - 1, guard = Lr + Lc + 2;
+    while (x >= 0 && y >= 0 && guard-- > 0) {
+      const int r = y % RS;
+      const uint32_t two = (mv[((y / RS) * Lr + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
+      const int xo = two & 1, yo = two >> 1;
+      if (xo && yo) x2y[x] = (uint16_t)y;
+      if (!xo && !yo) { bad = true; break; }
+      x -= xo;
+      y -= yo;
     }
   }
-  __syncthreads();
-  PHASE_STAMP(2);
-  // ---- coalesced copy-out of the graph by the window's own lanes ----
-  if (valid) {
-    const int32_t *hdr = reinterpret_cast<const int32_t *>(slot);
-    const int n1 = hdr[0];
-    const int2 *xi_st = reinterpret_cast<const int2 *>(slot + W.off_region);
-    const uint16_t *ring_st = reinterpret_cast<const uint16_t *>(slot + W.off_region + 8 * (Lr + Lc + 1));
+  __builtin_amdgcn_wave_barrier();
+  PHASE_STAMP(5);
+  // ---- fusion #1 (lpo.c:602-668 fuse_lpo_remap on two linear sequences), spread over the window's
+  // G lanes.  Node order of the fused graph: walking the reference, every pending corrected letter up
+  // to the aligned one comes first (an aligned but different letter directly before its reference
+  // letter, sharing its ring), identical aligned letters are one node.  So
+  //   node(ref i) = i + (corrected letters consumed up to i) - (fused pairs up to i)
+  //   node(cor j) = j - (fused pairs before j) + (reference letters before the next aligned pair)
+  // and the predecessors are the nodes of ref i-1 / cor j-1.  Scans over the letters give the terms;
+  // every lane then writes its nodes straight to the graph arrays in HBM. ----
+  int n1 = 0, maxd = 1;
+  {
+    uint16_t *node_ref = reinterpret_cast<uint16_t *>(slot + W.off_region);
+    uint16_t *node_cor = node_ref + ((Lr + 1) & ~1);
+    uint16_t *y2x = node_cor + ((Lc + 1) & ~1);
+    const int cx = (Lr + G - 1) / G, cy = (Lc + G - 1) / G;               // letters per lane
+    int cxmax = valid ? cx : 0, cymax = valid ? cy : 0;
+    for (int d = G; d < 64; d <<= 1) {
+      cxmax = max(cxmax, __shfl_xor(cxmax, d));
+      cymax = max(cymax, __shfl_xor(cymax, d));
+    }
+    cxmax = __builtin_amdgcn_readfirstlane(cxmax);
+    cymax = __builtin_amdgcn_readfirstlane(cymax);
+    if (a.debug & (2 | 16)) { cxmax = 0; cymax = 0; }
+    if (valid) for (int i = g; i < Lc; i += G) y2x[i] = (uint16_t)kNone16;
+    __builtin_amdgcn_wave_barrier();
+    const int x0 = g * cx, x1 = valid ? min(Lr, x0 + cx) : 0;
+    const int y0 = g * cy, y1 = valid ? min(Lc, y0 + cy) : 0;
+    // reference letters: corrected letters consumed (P) and fused pairs (F) up to each of them
+    int pmax = 0, fcnt = 0;
+    for (int it = 0; it < cxmax; ++it) {
+      const int ix = x0 + it;
+      if (ix < x1) {
+        const int ay = x2y[ix];
+        if (ay != (int)kNone16) {
+          if (ay < Lc) y2x[ay] = (uint16_t)ix; else bad = true;
+          if (ay + 1 <= pmax) bad = true;                                // a path is monotone
+          pmax = ay + 1;
+          fcnt += (ay < Lc && xs[ix] == ys[ay]);
+        }
+      }
+    }
+    int sp = pmax, sf = fcnt;
+    for (int d = 1; d < G; d <<= 1) {
+      const int tp = __shfl_up(sp, d, G), tf = __shfl_up(sf, d, G);
+      if (g >= d) { sp = max(sp, tp); sf += tf; }
+    }
+    const int fused_all = __shfl(sf, G - 1, G);
+    int P = __shfl_up(sp, 1, G), F = sf - fcnt;
+    if (g == 0) P = 0;
+    if (pmax > 0 && x1 > x0) {
+      // first aligned letter of this lane's chunk must lie beyond everything before it
+      int first = 0;
+      for (int ix = x0; ix < x1; ++ix) { const int ay = x2y[ix]; if (ay != (int)kNone16) { first = ay + 1; break; } }
+      if (first <= P) bad = true;
+    }
+    for (int it = 0; it < cxmax; ++it) {
+      const int ix = x0 + it;
+      if (ix < x1) {
+        const int ay = x2y[ix];
+        if (ay != (int)kNone16) { P = ay + 1; F += (ay < Lc && xs[ix] == ys[ay]); }
+        node_ref[ix] = (uint16_t)(ix + P - F);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // corrected letters: fused pairs before each of them, reference letters before the next aligned pair
+    constexpr int kUndef = -1;
+    int fy = 0, klow = kUndef;
+    for (int it = 0; it < cymax; ++it) {
+      const int y = y1 - 1 - it;
+      if (y >= y0) {
+        const int x = y2x[y];
+        if (x != (int)kNone16) { klow = x; fy += xs[x] == ys[y]; }
+      }
+    }
+    int sfy = fy, sfx = klow;
+    for (int d = 1; d < G; d <<= 1) {
+      const int tf = __shfl_up(sfy, d, G), tk = __shfl_down(sfx, d, G);
+      if (g >= d) sfy += tf;
+      if (g + d < G && sfx == kUndef) sfx = tk;
+    }
+    int K = __shfl_down(sfx, 1, G), fy_run = sfy;                          // fused pairs below the end of this chunk
+    if (g == G - 1 || K == kUndef) K = Lr;
+    for (int it = 0; it < cymax; ++it) {
+      const int y = y1 - 1 - it;
+      if (y >= y0) {
+        const int x = y2x[y];
+        const bool al = x != (int)kNone16, fu = al && xs[x] == ys[y];
+        if (fu) --fy_run;
+        if (al) K = x;
+        node_cor[y] = fu ? node_ref[x] : (uint16_t)(y - fy_run + K);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    n1 = Lr + Lc - fused_all;
+    // emit: predecessor list, letter, flags and ring of every node (lpo.c:413-463 reindexing, :227-241 links)
     const int64_t nb = W.o0 + W.w;
     int2 *gx = a.b.xinfo + nb;
     uint16_t *gr = a.b.ring1 + nb;
-    for (int i = 1 + g; i <= n1; i += G) gx[i] = xi_st[i];
-    for (int i = g; i < n1; i += G) gr[i] = ring_st[i];
-    if (g == 0) {
-      a.b.n1[W.w] = n1;
-      const int need = hdr[1] + 2;
-      a.b.cls[W.w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 8 ? 0x80 : 0));   // bit 7: too deep for k_fused_b's ring
-      if (need > 512) a.b.status[W.w] = 2;
-      if (hdr[2]) a.b.status[W.w] = 3;
-      a.done_a[W.w] = 1;
+    auto emit = [&](int n, int letter, int flags, int ring, int sa, int sb) {
+      int pp1, pp2 = (int)kNone16;
+      const int jj = n + 1;
+      if (sa < 0) pp1 = 0;
+      else if (flags & kFlagInitial) { pp1 = 0; pp2 = sa + 1; if (sb >= 0) bad = true; }
+      else { pp1 = sa + 1; if (sb >= 0) pp2 = sb + 1; }
+      if (pp1 > 0) maxd = max(maxd, jj - pp1);
+      if (pp2 != (int)kNone16 && pp2 > 0) maxd = max(maxd, jj - pp2);
+      if (n >= 0 && n < Lr + Lc) {
+        gx[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
+        gr[n] = (uint16_t)ring;
+      } else bad = true;
+    };
+    for (int it = 0; it < cxmax; ++it) {
+      const int ix = x0 + it;
+      if (ix < x1) {
+        const int ay = x2y[ix], n = node_ref[ix];
+        const bool al = ay != (int)kNone16 && ay < Lc, fu = al && xs[ix] == ys[ay];
+        int fl = kFlagHasRef | (ix == 0 ? kFlagInitial : 0) | (ix == Lr - 1 ? kFlagFinal : 0);
+        int sa = ix > 0 ? (int)node_ref[ix - 1] : -1, sb = -1, ring = n;
+        if (fu) {
+          fl |= kFlagHasCor | (ay == 0 ? kFlagInitial : 0) | (ay == Lc - 1 ? kFlagFinal : 0);
+          const int lasty = ay > 0 ? (int)node_cor[ay - 1] : -1;
+          if (lasty >= 0 && lasty != sa) { if (sa < 0) sa = lasty; else sb = lasty; }
+        } else if (al) ring = n - 1;                                       // joins the ring of its corrected partner
+        emit(n, xs[ix], fl, ring, sa, sb);
+      }
     }
+    for (int it = 0; it < cymax; ++it) {
+      const int y = y0 + it;
+      if (y < y1) {
+        const int x = y2x[y];
+        if (!(x != (int)kNone16 && xs[x] == ys[y])) {
+          const int n = node_cor[y];
+          emit(n, ys[y], kFlagHasCor | (y == 0 ? kFlagInitial : 0) | (y == Lc - 1 ? kFlagFinal : 0), n,
+               y > 0 ? (int)node_cor[y - 1] : -1, -1);
+        }
+      }
+    }
+    for (int d = 1; d < G; d <<= 1) {
+      maxd = max(maxd, __shfl_xor(maxd, d, G));
+      bad = bad || __shfl_xor(bad ? 1 : 0, d, G) != 0;
+    }
+  }
+  PHASE_STAMP(2);
+  if (valid && g == 0) {
+    a.b.n1[W.w] = n1;
+    const int need = maxd + 2;
+    a.b.cls[W.w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 8 ? 0x80 : 0));   // bit 7: too deep for k_fused_b's ring
+    if (need > 512) a.b.status[W.w] = 2;
+    if (bad) a.b.status[W.w] = 3;
+    a.done_a[W.w] = 1;
   }
   PHASE_STAMP(3);
   if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 4, 1ull);
@@ -841,9 +912,7 @@ int launch_fused_a(const FusedArgs &a, int G, hipStream_t st)
   if (a.nlist <= 0) return 0;
   // several waves per block where the block's slots fit comfortably: the serial stage of all
   // its windows is then shared by one wave
-  if (G == 16) return 16 * a.slot_bytes <= 72 * 1024 ? launch_a_t<16, 4>(a, st) : launch_a_t<16, 1>(a, st);
-  if (G == 32) return 8 * a.slot_bytes <= 72 * 1024 ? launch_a_t<32, 4>(a, st) : launch_a_t<32, 1>(a, st);
-  return launch_a_t<64, 1>(a, st);
+  return G == 16 ? launch_a_t<16, 1>(a, st) : G == 32 ? launch_a_t<32, 1>(a, st) : launch_a_t<64, 1>(a, st);
 }
 
 int launch_fused_b(const FusedArgs &a, int G, hipStream_t st)
