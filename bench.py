@@ -106,6 +106,20 @@ def cpu_baseline(windows, ref_bases_per_window, seconds):
             "sample": "%d windows (%d reference bases), oracle/poa_oracle.c single thread, wall %.2f s" % (ns, int(nb), dt)}
 
 
+def pmc_traffic(kernel, reads):
+    """HBM bytes per launch of `kernel` from the committed PMC passes over this very command
+    (profiles/pmc_traffic.json, written from tests/_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 passes, gfx950 correction applied); None when the workload differs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        if int(t["reads_per_gpu"]) != int(reads):
+            return None
+        return int(t["kernels"][kernel]["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -215,7 +229,7 @@ def main():
         avg_ms = dom[1] / launches
         bytes_per_launch = alg_bytes * args.steps / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = os.environ.get("ELECTOR_BENCH_TRAFFIC_BYTES")
+        traffic = pmc_traffic(dom[0], args.reads)
         out = {
             "metric": "triplet-MSA Mbases/s", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,7 +248,7 @@ def main():
                                    "note": "sum of per-launch HIP-event times; size classes overlap on 8 streams"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": int(traffic) if traffic else None,
+                         "traffic": traffic,
                          "launches": int(launches), "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch)},
             "reads_gathered": int(counters.shape[0]),
