@@ -1,0 +1,297 @@
+// elector_amd/csrc/bundle.hip -- a12: heaviest-bundle consensus of every window
+// (optional output; the reference compiles it but never calls it, main.c:345-347).
+//
+// Reference behaviour restated: heaviest_bundle (heaviest_bundle.c:16-78),
+// assign_sequence_bundle_id (:80-110), generate_lpo_bundles (:144-172) on the
+// graph that fuse_lpo leaves after both fusions (lpo.c:413-463,602-656).
+//
+// The POA kernels never materialise the graph of (ref + cor + unc): they emit the
+// MSA columns directly.  k_bundle rebuilds exactly the part of it that the bundle
+// search looks at, from what the batch left in HBM (the graph after fusion #1:
+// xinfo, ring1; the x -> y map of alignment #2: map16; the uncorrected symbols):
+//
+//   node record (16 B, node space of the window, in final node order)
+//     pos[3]   position of the node's letter in ref / cor / unc (0xFFFF = absent)
+//     nxt[3]   node that holds the next letter of ref / cor / unc  (0xFFFF = last)
+//     col      MSA column (lpo_format.c:346-371: a new column at every ring change)
+//     letter, cons   symbol index; bit k set = node lies on consensus path k
+//
+// The right-link list of a node, in the order the reference's add_lpo_link calls
+// leave it (lpo.c:227-241: x's links first, then y's if new), is nxt[0], nxt[1],
+// nxt[2] with duplicates dropped, because the graph is built ref <- cor <- unc.
+//
+// One lane = one window: the search is a right-to-left dynamic program over a
+// chain-like graph with order-dependent tie-breaks (first best link wins, highest
+// node index wins among equal path scores); the windows are what is parallel.
+// Latency / L2 bound; integer only except the one float comparison of :96.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "ctx.h"
+#include "elector_poa.h"
+#include "poa_device.h"
+
+namespace elector {
+
+constexpr int kMaxBundles = 3;     // three source sequences: each productive pass bundles >= 1 of them
+
+struct BundleArgs {
+  int64_t n;
+  const int64_t *off;
+  const uint8_t *sym;
+  const int2 *xinfo;
+  const uint16_t *ring1;
+  const uint16_t *map16;      // x_to_y of alignment #2 per node of the graph after fusion #1
+  const int32_t *n1;
+  const int32_t *ncol;        // from the POA kernels (cross-check)
+  int32_t *status;
+  const DevTables *tab;
+  float min_fraction;
+  uint4 *node;                // node space: 16-byte records
+  int32_t *score;             // node space
+  uint16_t *path;             // node space: best right link
+  uint8_t *cons;              // out: window w, bundle k: ncol bytes at cons + 3*off[3w] + k*ncol
+  int32_t *info;              // out: 8 per window: nbundle, count[3], bundle id of ref/cor/unc, ncol
+};
+
+struct NodeRec {
+  uint16_t pos[3], nxt[3], col;
+  uint8_t letter, cons;
+};
+static_assert(sizeof(NodeRec) == 16, "node record is one 16-byte load");
+
+__device__ __forceinline__ NodeRec load_node(const uint4 *p)
+{
+  const uint4 v = *p;
+  NodeRec r;
+  r.pos[0] = (uint16_t)(v.x & 0xFFFF); r.pos[1] = (uint16_t)(v.x >> 16); r.pos[2] = (uint16_t)(v.y & 0xFFFF);
+  r.nxt[0] = (uint16_t)(v.y >> 16); r.nxt[1] = (uint16_t)(v.z & 0xFFFF); r.nxt[2] = (uint16_t)(v.z >> 16);
+  r.col = (uint16_t)(v.w & 0xFFFF); r.letter = (uint8_t)((v.w >> 16) & 0xFF); r.cons = (uint8_t)(v.w >> 24);
+  return r;
+}
+
+__device__ __forceinline__ void store_node(uint4 *p, const NodeRec &r)
+{
+  uint4 v;
+  v.x = (uint32_t)r.pos[0] | ((uint32_t)r.pos[1] << 16);
+  v.y = (uint32_t)r.pos[2] | ((uint32_t)r.nxt[0] << 16);
+  v.z = (uint32_t)r.nxt[1] | ((uint32_t)r.nxt[2] << 16);
+  v.w = (uint32_t)r.col | ((uint32_t)r.letter << 16) | ((uint32_t)r.cons << 24);
+  *p = v;
+}
+
+__global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
+{
+  const int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (w >= a.n) return;
+  int32_t *info = a.info + 8 * w;
+  for (int k = 0; k < 8; ++k) info[k] = k >= 4 && k <= 6 ? -1 : 0;
+  if (a.status[w]) return;
+  const int64_t o0 = a.off[3 * w], o1 = a.off[3 * w + 1], o2 = a.off[3 * w + 2], o3 = a.off[3 * w + 3];
+  const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1), Lu = (int)(o3 - o2), n1 = a.n1[w];
+  const int64_t nb = o0 + w;
+  const int2 *xinfo = a.xinfo + nb;
+  const uint16_t *ring1 = a.ring1 + nb, *x2y = a.map16 + nb;
+  const uint8_t *ys = a.sym + o2;
+  uint4 *node = a.node + nb;
+  uint16_t *nodeh = reinterpret_cast<uint16_t *>(node);
+  int32_t *score = a.score + nb;
+  uint16_t *path = a.path + nb;
+
+  // ---- the graph after fusion #2 (lpo.c:431-459 node order), as node records ----
+  int n = 0, col = 0, prev_ring = 0, posr = 0, posc = 0;
+  int last[3] = {-1, -1, -1};
+  auto add = [&](int ring, int letter, bool r, bool c, int upos) {
+    if (ring != prev_ring) { ++col; prev_ring = ring; }
+    NodeRec rec;
+    rec.pos[0] = r ? (uint16_t)posr : (uint16_t)kNone16;
+    rec.pos[1] = c ? (uint16_t)posc : (uint16_t)kNone16;
+    rec.pos[2] = upos >= 0 ? (uint16_t)upos : (uint16_t)kNone16;
+    rec.nxt[0] = rec.nxt[1] = rec.nxt[2] = (uint16_t)kNone16;
+    rec.col = (uint16_t)col; rec.letter = (uint8_t)letter; rec.cons = 0;
+    store_node(node + n, rec);
+    // the previous letter of each source now knows its right neighbour
+    if (r) { if (last[0] >= 0) nodeh[8 * last[0] + 3] = (uint16_t)n; last[0] = n; ++posr; }
+    if (c) { if (last[1] >= 0) nodeh[8 * last[1] + 4] = (uint16_t)n; last[1] = n; ++posc; }
+    if (upos >= 0) { if (last[2] >= 0) nodeh[8 * last[2] + 5] = (uint16_t)n; last[2] = n; }
+    ++n;
+  };
+  int iy = 0, blk_old = -1, blk_new = -1;
+  for (int ix = 0; ix < n1; ++ix) {
+    const int r0 = ring1[ix];
+    if (r0 != blk_old) { blk_old = r0; blk_new = -1; }
+    for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
+      const int ay = x2y[k];
+      if (ay != (int)kNone16) {
+        while (iy < ay && iy < Lu) { add(n, ys[iy], false, false, iy); ++iy; }
+        break;
+      }
+    }
+    const int xi = xinfo[ix + 1].y;
+    const int letter = xi & 0xFF, fl = xi >> 8;
+    int fused_pos = -1;
+    if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
+      if (letter == ys[iy]) fused_pos = iy;
+      else {
+        if (blk_new < 0) blk_new = n;
+        add(blk_new, ys[iy], false, false, iy);
+      }
+      ++iy;
+    }
+    if (blk_new < 0) blk_new = n;
+    add(blk_new, letter, (fl & kFlagHasRef) != 0, (fl & kFlagHasCor) != 0, fused_pos);
+  }
+  while (iy < Lu) { add(n, ys[iy], false, false, iy); ++iy; }
+  const int n2 = n, ncol = col + 1;
+  info[7] = ncol;
+  if (ncol != a.ncol[w] || posr != Lr || posc != Lc || n2 > Lr + Lc + Lu) { a.status[w] = 3; return; }
+
+  // ---- generate_lpo_bundles (heaviest_bundle.c:144-172) ----
+  int wt[3] = {1, 1, 1}, bid[3] = {-1, -1, -1};
+  const int slen[3] = {Lr, Lc, Lu};
+  int nbundled = 0, nseq = 3, ib = 0;
+  uint8_t *cons = a.cons + 3 * o0;
+  while (nbundled < nseq && ib < kMaxBundles) {
+    // heaviest_bundle (:16-78): right-to-left over the nodes
+    int best = kNeg, ibest = -1;
+    for (int i = n2 - 1; i >= 0; --i) {
+      const NodeRec me = load_node(node + i);
+      int right_score = 0, right_overlap = 0, best_right = -1;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int rn = me.nxt[s];
+        if (rn == (int)kNone16) continue;
+        if ((s >= 1 && rn == me.nxt[0]) || (s == 2 && rn == me.nxt[1])) continue;   // add_lpo_link keeps one copy
+        const NodeRec rt = load_node(node + rn);
+        int ov = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          // contains_pos[q] = pos + 1 for weighted sources of this node, 0 otherwise (:35-39); a right
+          // node counts source q when contains_pos[q] == its position (:46-48) -- so a node holding the
+          // FIRST letter of a source this node lacks also counts
+          if (!wt[q] || rt.pos[q] == (uint16_t)kNone16) continue;
+          const int cp = me.pos[q] != (uint16_t)kNone16 ? me.pos[q] + 1 : 0;
+          if (cp == (int)rt.pos[q]) ov += wt[q];
+        }
+        const int sr = score[rn];
+        if (ov > right_overlap || (ov == right_overlap && sr > right_score)) {
+          right_overlap = ov; right_score = sr; best_right = rn;
+        }
+      }
+      path[i] = (uint16_t)(best_right < 0 ? (int)kNone16 : best_right);
+      const int sc = right_score + right_overlap;
+      score[i] = sc;
+      if (sc > best) { best = sc; ibest = i; }
+    }
+    // the path, its length, how many letters of each source lie on it
+    int plen = 0, cnt[3] = {0, 0, 0};
+    for (int i = ibest; i >= 0;) {
+      const NodeRec me = load_node(node + i);
+      ++plen;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) cnt[q] += me.pos[q] != (uint16_t)kNone16;
+      const int nx = path[i];
+      i = nx == (int)kNone16 ? -1 : nx;
+    }
+    if (plen < 10) break;                                                   // :152
+    int count = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (bid[q] < 0 && (float)slen[q] * a.min_fraction <= (float)cnt[q]) { bid[q] = ib; wt[q] = 0; ++count; }   // :95-100
+    // add_path_sequence: the consensus row of this bundle
+    uint8_t *row = cons + (int64_t)ib * ncol;
+    for (int c = 0; c < ncol; ++c) row[c] = '.';
+    for (int i = ibest; i >= 0;) {
+      const NodeRec me = load_node(node + i);
+      row[me.col] = a.tab->chr[me.letter & 31];
+      const int nx = path[i];
+      i = nx == (int)kNone16 ? -1 : nx;
+    }
+    info[1 + ib] = count;
+    ++ib; ++nseq;
+    nbundled += count;
+    if (count < 1) break;                                                   // :166
+  }
+  info[0] = ib;
+  info[4] = bid[0]; info[5] = bid[1]; info[6] = bid[2];
+}
+
+// consensus rows of all windows, packed: window w's nbundle[w] rows at out + cons_off[w]
+__global__ void __launch_bounds__(256) k_cons_pack(const uint8_t *__restrict__ cons, const int64_t *__restrict__ off,
+                                                    const int32_t *__restrict__ info, const int64_t *__restrict__ cons_off,
+                                                    uint8_t *__restrict__ out, int64_t n)
+{
+  const int64_t w = blockIdx.x;
+  if (w >= n) return;
+  const int64_t bytes = (int64_t)info[8 * w] * info[8 * w + 7];
+  const uint8_t *src = cons + 3 * off[3 * w];
+  uint8_t *dst = out + cons_off[w];
+  for (int64_t i = threadIdx.x; i < bytes; i += blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace elector
+
+using namespace elector;
+
+extern "C" int elector_ctx_keep_graph(elector_ctx *c, int on)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->keep_graph = on != 0;
+  return ELECTOR_OK;
+}
+
+extern "C" int elector_poa_bundles(elector_ctx *c, int64_t n, float minimum_fraction, uint8_t *cons_rows,
+                                   int64_t cons_cap, int64_t *cons_off, int32_t *info)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n < 0 || !cons_off || (n > 0 && !info)) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(c->mu);
+  cons_off[0] = 0;
+  if (n == 0) return ELECTOR_OK;
+  if (!c->keep_graph || !c->graph_valid || n != c->last_n)
+    return elector_fail(c, ELECTOR_E_INVAL, "no graph kept: call elector_ctx_keep_graph(ctx, 1) before the POA batch");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nodes = (size_t)c->last_total + (size_t)n + 8;
+  int rc = c->d_bnode.ensure(nodes * 16) | c->d_bscore.ensure(nodes * 4) | c->d_bpath.ensure(nodes * 2) |
+           c->d_bcons.ensure((size_t)3 * c->last_total + 64) | c->d_binfo.ensure((size_t)n * 32) |
+           c->d_rowoff.ensure((size_t)(n + 1) * 8);
+  if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "bundle workspace");
+  hipStream_t st = c->stream;
+  BundleArgs a;
+  a.n = n;
+  a.off = c->d_off.as<int64_t>();
+  a.sym = c->d_sym.as<uint8_t>();
+  a.xinfo = c->d_xinfo.as<int2>();
+  a.ring1 = c->d_ring1.as<uint16_t>();
+  a.map16 = c->d_map16.as<uint16_t>();
+  a.n1 = c->d_n1.as<int32_t>();
+  a.ncol = c->last_ncol;
+  a.status = c->last_status;
+  a.tab = c->d_tab.as<DevTables>();
+  a.min_fraction = minimum_fraction;
+  a.node = c->d_bnode.as<uint4>();
+  a.score = c->d_bscore.as<int32_t>();
+  a.path = c->d_bpath.as<uint16_t>();
+  a.cons = c->d_bcons.as<uint8_t>();
+  a.info = c->d_binfo.as<int32_t>();
+  hipLaunchKernelGGL(k_bundle, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(info, c->d_binfo.p, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  for (int64_t w = 0; w < n; ++w) cons_off[w + 1] = cons_off[w] + (int64_t)info[8 * w] * info[8 * w + 7];
+  if (cons_off[n] > cons_cap || (cons_off[n] > 0 && !cons_rows)) return elector_fail(c, ELECTOR_E_INVAL, "consensus buffer too small");
+  if (cons_off[n] > 0) {
+    rc = c->d_rows.ensure((size_t)cons_off[n] + 64);
+    if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "consensus rows");
+    HIPCHK(c, hipMemcpyAsync(c->d_rowoff.p, cons_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_cons_pack, dim3((unsigned)n), dim3(256), 0, st, c->d_bcons.as<uint8_t>(), c->d_off.as<int64_t>(),
+                       c->d_binfo.as<int32_t>(), c->d_rowoff.as<int64_t>(), c->d_rows.as<uint8_t>(), n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(cons_rows, c->d_rows.p, (size_t)cons_off[n], hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  return ELECTOR_OK;
+}

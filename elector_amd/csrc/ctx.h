@@ -99,6 +99,12 @@ struct elector_ctx {
   int64_t launches_acc[kTimedKinds] = {};
   int64_t last_n = 0;          // windows of the last POA batch (their offsets stay in d_off)
   int64_t last_total = 0;      // bases of that batch
+  // a12: heaviest-bundle consensus (bundle.hip) works on the graph data of the last batch
+  bool keep_graph = false;     // POA kernels also leave the x -> y map of alignment #2 in d_map16
+  bool graph_valid = false;    // the last batch ran with keep_graph
+  const int32_t *last_ncol = nullptr;   // device arrays of the last batch (caller's or the staging ones)
+  int32_t *last_status = nullptr;
+  elector::DevBuf d_bnode, d_bscore, d_bpath, d_bcons, d_binfo;
 };
 
 inline int elector_fail(elector_ctx *c, int code, const char *what, hipError_t e = hipSuccess)

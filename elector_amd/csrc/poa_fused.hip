@@ -35,6 +35,7 @@ struct FusedArgs {
   uint8_t *done_b;          // 1 = alignment #2 + fusion #2 done by k_fused_b
   int32_t *rowinit;         // node space: score of the virtual row -1 at node jj
   int debug;                // timing experiments only (bit0: skip DP, bit1: skip serial stage)
+  int keep_map;             // k_fused_b also leaves the x -> y map of alignment #2 in HBM (a12 needs it)
 };
 
 __device__ __forceinline__ int row_shr1(int old, int v)
@@ -749,6 +750,10 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
     }
   }
   __builtin_amdgcn_wave_barrier();
+  if (a.keep_map && valid) {
+    uint16_t *gm = a.b.map16 + o0 + w;
+    for (int i = g; i < n1; i += G) gm[i] = x2y[i];
+  }
   PHASE_STAMP(13);
   // ---- fusion #2 and the MSA columns (lpo.c:602-668 column layout rule, lpo_format.c:337-393), spread
   // over the window's G lanes.  Only the columns are needed, not the fused graph: every ring of the

@@ -39,6 +39,7 @@ struct FusedArgs {
   uint8_t *done_b;
   int32_t *rowinit;
   int debug;
+  int keep_map;
 };
 int launch_fused_a(const FusedArgs &a, int G, hipStream_t st);
 int launch_fused_b(const FusedArgs &a, int G, hipStream_t st);
@@ -299,7 +300,8 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_score1, &c->d_score2, &c->d_bx2, &c->d_bases, &c->d_cols, &c->d_ncol, &c->d_status,
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
-                    &c->d_list, &c->d_done, &c->d_rowinit, &c->d_lanemeta};
+                    &c->d_list, &c->d_done, &c->d_rowinit, &c->d_lanemeta,
+                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo};
   for (DevBuf *b : bufs) b->release();
   for (auto &s : c->st_slot) s.release();
   c->h_meta.release();
@@ -410,7 +412,7 @@ static int ensure_streams(elector_ctx *c)
 static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *off,
                             uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status, int32_t *d_scores)
 {
-  if (n == 0) { c->last_n = 0; c->last_total = 0; return ELECTOR_OK; }
+  if (n == 0) { c->last_n = 0; c->last_total = 0; c->graph_valid = false; return ELECTOR_OK; }
   const int64_t total = off[3 * n];
   if (off[0] != 0 || total < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
   const bool use_fused = !c->gen && !std::getenv("ELECTOR_NO_FUSED");
@@ -432,7 +434,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   std::vector<int8_t> bin((size_t)n, -1);
   std::vector<int8_t> lcls((size_t)n, -1);
   // lane-per-window kernels: experimental, slower than the fused kernels at present
-  const bool use_lane = use_fused && std::getenv("ELECTOR_LANE") != nullptr;
+  const bool use_lane = use_fused && !c->keep_graph && std::getenv("ELECTOR_LANE") != nullptr;
   int64_t key_cnt[NB + 1] = {0}, bin_cnt[kBins] = {0}, n_generic = 0, lane_cnt[kLaneClasses] = {0}, bin_need_a[kBins] = {0};
   auto key = [&](int64_t w) {
     const int64_t m = std::max(off[3 * w + 1] - off[3 * w], off[3 * w + 3] - off[3 * w + 2]);
@@ -719,6 +721,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       fa.done_b = d_done_b;
       fa.rowinit = reinterpret_cast<int32_t *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b);   // phase stamps (debug)
       fa.debug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
+      fa.keep_map = c->keep_graph ? 1 : 0;
       fa.slot_bytes = (int)((bin_need_a[b] + 127) & ~(int64_t)127);   // alignment #1: the class's own maximum
       timed_begin(c, 0, sx);
       if (launch_fused_a(fa, kBinG[b], sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
@@ -792,6 +795,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   }
   c->last_n = n;
   c->last_total = total;
+  c->graph_valid = c->keep_graph;
+  c->last_ncol = d_ncol;
+  c->last_status = d_status;
   if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 4)) {
     (void)hipStreamSynchronize(st);
     int32_t hc[4];

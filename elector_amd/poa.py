@@ -167,6 +167,38 @@ class PoaEngine:
                                                      rows.ctypes.data))
         return rows[:-1]
 
+    # ---- a12: heaviest-bundle consensus (optional output) -------------------
+    def keep_graph(self, on=True):
+        """Make the following batches keep the graph data the bundle search needs."""
+        self._check(self._lib.elector_ctx_keep_graph(self._h, 1 if on else 0))
+
+    def bundles(self, n, total_bases, minimum_fraction=0.9):
+        """generate_lpo_bundles(lpo, minimum_fraction) (heaviest_bundle.c:144-172) on every window of
+        the last batch -> list of (consensus rows [bytes], counts [int], bundle ids (ref, cor, unc))."""
+        cap = 3 * int(total_bases) + 16
+        cons = np.zeros(cap, dtype=np.uint8)
+        cons_off = np.zeros(n + 1, dtype=np.int64)
+        info = np.zeros((n, 8), dtype=np.int32)
+        self._check(self._lib.elector_poa_bundles(self._h, n, float(minimum_fraction), cons.ctypes.data, cap,
+                                                  cons_off.ctypes.data, info.ctypes.data))
+        buf = cons.tobytes()
+        out = []
+        for w in range(n):
+            k, nc, a = int(info[w, 0]), int(info[w, 7]), int(cons_off[w])
+            out.append(([buf[a + i * nc:a + (i + 1) * nc] for i in range(k)],
+                        [int(x) for x in info[w, 1:1 + k]], tuple(int(x) for x in info[w, 4:7])))
+        return out
+
+    def align_with_bundles(self, triples, minimum_fraction=0.9):
+        """[(ref, cor, unc)] -> (rows as align(), bundles as bundles())"""
+        self.keep_graph(True)
+        try:
+            bases, off = pack_windows(triples)
+            rows = self.align(triples, strict=False)
+            return rows, self.bundles(len(triples), int(off[-1]), minimum_fraction)
+        finally:
+            self.keep_graph(False)
+
     def sync(self):
         self._check(self._lib.elector_ctx_sync(self._h))
 

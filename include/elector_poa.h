@@ -123,6 +123,32 @@ int elector_ctx_timing_reset(elector_ctx *ctx);
  * batch, so callers can count the DP cells of alignment #2 (|PO| x Lu). */
 int elector_ctx_last_po_sizes(elector_ctx *ctx, int64_t n, int32_t *po_nodes);
 
+/* a12 -- heaviest-bundle consensus (OPTIONAL output: the reference compiles
+ * generate_lpo_bundles but its main() never calls it, src/poa-graph/main.c:345-347;
+ * heaviest_bundle.c:16-78 heaviest_bundle, :80-110 assign_sequence_bundle_id,
+ * :144-172 generate_lpo_bundles, lpo.c:762-781 add_path_sequence).
+ *
+ * elector_ctx_keep_graph(ctx, 1) makes the following POA batches keep what the
+ * search needs in device memory (the x -> y map of the second alignment; the
+ * fused kernels otherwise drop it).  elector_poa_bundles then runs the bundle
+ * search on every window of the LAST batch of this context (n must equal that
+ * batch's n; its ncol / status device arrays must still be alive) exactly as
+ * generate_lpo_bundles(lpo, minimum_fraction) would on the window's final graph:
+ *   info      : out, 8 x int32 per window: [0] number of consensus sequences
+ *               CONSENS0.. (0..3), [1..3] the "containing %d seqs" count of each,
+ *               [4..6] bundle id assigned to the reference / corrected /
+ *               uncorrected sequence (-1 = none), [7] ncol
+ *   cons_rows : out, window w's info[8w] consensus rows of ncol[w] bytes each at
+ *               cons_rows[cons_off[w] ..), as write_lpo_bundle_as_fasta would
+ *               print them after the three sequences ('.' = not on the path)
+ *   cons_off  : out, n+1 entries;  cons_cap: capacity of cons_rows in bytes
+ *               (3 * off[3n] always suffices)
+ * The reference's default minimum_fraction is 0.9 (main.c:30). */
+int elector_ctx_keep_graph(elector_ctx *ctx, int on);
+int elector_poa_bundles(elector_ctx *ctx, int64_t n, float minimum_fraction,
+                        uint8_t *cons_rows, int64_t cons_cap, int64_t *cons_off,
+                        int32_t *info);
+
 #ifdef __cplusplus
 }
 #endif

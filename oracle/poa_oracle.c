@@ -550,6 +550,14 @@ int po_generate_bundles(po_graph *g, float minimum_fraction, int *bundle_counts)
 
 /* -------------------------------------------------------------- a9 a11 --- */
 
+static int window_triple_ex(const po_params *m,
+                            const unsigned char *ref, int lr,
+                            const unsigned char *cor, int lc,
+                            const unsigned char *unc, int lu,
+                            int with_bundles, float minimum_fraction,
+                            char *rows_out, int rows_cap, int *ncol, int *nrows,
+                            int *dbg, int64_t *ncells, int *bundle_counts, int *seq_bundle);
+
 int po_window_triple(const po_params *m,
                      const unsigned char *ref, int lr,
                      const unsigned char *cor, int lc,
@@ -557,6 +565,19 @@ int po_window_triple(const po_params *m,
                      int with_bundles,
                      char *rows_out, int rows_cap, int *ncol, int *nrows,
                      int *dbg, int64_t *ncells, int *bundle_counts)
+{
+  /* 0.9 = the reference's default bundling_threshold (main.c:30) */
+  return window_triple_ex(m, ref, lr, cor, lc, unc, lu, with_bundles, 0.9f, rows_out, rows_cap, ncol, nrows,
+                          dbg, ncells, bundle_counts, NULL);
+}
+
+static int window_triple_ex(const po_params *m,
+                            const unsigned char *ref, int lr,
+                            const unsigned char *cor, int lc,
+                            const unsigned char *unc, int lu,
+                            int with_bundles, float minimum_fraction,
+                            char *rows_out, int rows_cap, int *ncol, int *nrows,
+                            int *dbg, int64_t *ncells, int *bundle_counts, int *seq_bundle)
 {
   /* buildup_lpo.c:381-401,481-534: merge order is fixed: ref <- cor, then
    * (ref+cor) <- unc; x is always the growing graph (cluster 0). */
@@ -581,7 +602,8 @@ int po_window_triple(const po_params *m,
   po_fuse(g, y, x2y, y2x);
   if (dbg) dbg[7] = g->n;
 
-  if (with_bundles) po_generate_bundles(g, 0.9f, bundle_counts);
+  if (with_bundles) po_generate_bundles(g, minimum_fraction, bundle_counts);
+  if (seq_bundle) { seq_bundle[0] = g->seq_bundle[0]; seq_bundle[1] = g->seq_bundle[1]; seq_bundle[2] = g->seq_bundle[2]; }
   nc = po_msa_rows(g, m, rows_out, rows_cap);
   if (nc < 0) rc = -28;
   else { if (ncol) *ncol = nc; if (nrows) *nrows = g->nseq; }
@@ -710,4 +732,35 @@ int64_t po_batch(const po_params *m, int n, const char *bases, const int64_t *of
   }
   free(buf);
   return cells;
+}
+
+int po_batch_bundles(const po_params *m, int n, const char *bases, const int64_t *off, float minimum_fraction,
+                     char *cons, int64_t cons_cap, int64_t *cons_off, int *info)
+{
+  /* per window: generate_lpo_bundles on the final graph; info[8w..] = nbundle, count[3], bundle id of
+   * ref / cor / unc, ncol; cons = the CONSENS rows (rows 3.. of write_lpo_bundle_as_fasta) */
+  int w;
+  int64_t used = 0;
+  cons_off[0] = 0;
+  for (w = 0; w < n; w++) {
+    int64_t a = off[3 * w], b = off[3 * w + 1], c = off[3 * w + 2], d = off[3 * w + 3];
+    int cap = (int)(d - a + 2) * PO_MAXS, nc = 0, nrows = 0, lr, lc, lu, k;
+    int counts[PO_MAXS] = {0}, sb[3] = {-1, -1, -1};
+    unsigned char *buf = (unsigned char *)malloc((size_t)(d - a) + 3);
+    char *rows = (char *)malloc((size_t)cap);
+    lr = po_symbolize(m, bases + a, (int)(b - a), buf);
+    lc = po_symbolize(m, bases + b, (int)(c - b), buf + lr);
+    lu = po_symbolize(m, bases + c, (int)(d - c), buf + lr + lc);
+    if (window_triple_ex(m, buf, lr, buf + lr, lc, buf + lr + lc, lu, 1, minimum_fraction, rows, cap, &nc, &nrows,
+                         NULL, NULL, counts, sb)) { free(buf); free(rows); return -1; }
+    if (used + (int64_t)(nrows - 3) * nc > cons_cap) { free(buf); free(rows); return -2; }
+    memcpy(cons + used, rows + (size_t)3 * nc, (size_t)(nrows - 3) * nc);
+    used += (int64_t)(nrows - 3) * nc;
+    cons_off[w + 1] = used;
+    info[8 * w] = nrows - 3;
+    for (k = 0; k < 3; k++) { info[8 * w + 1 + k] = k < nrows - 3 ? counts[k] : 0; info[8 * w + 4 + k] = sb[k]; }
+    info[8 * w + 7] = nc;
+    free(buf); free(rows);
+  }
+  return 0;
 }

@@ -29,6 +29,16 @@ def bundles():
     return out
 
 
+def bundle_expectation(recs):
+    """records of one window in bundles.tsv -> (consensus rows, 'containing N seqs' counts)"""
+    rows, counts = [], []
+    for h, r in recs[3:]:
+        assert h.startswith(b">CONSENS")
+        rows.append(r)
+        counts.append(int(h.split(b"containing ")[1].split()[0]))
+    return rows, counts
+
+
 def splitter():
     """-> reads [(header, (ref, cor, unc))], windows [(header, (ref, cor, unc))], small, wrong"""
     reads, wins, small, wrong = [], [], 0, 0

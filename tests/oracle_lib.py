@@ -32,6 +32,8 @@ def lib():
         L.po_batch.restype = C.c_int64
         L.po_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_batch_bundles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -78,6 +80,29 @@ def batch(bases, off, params=None):
         a, nc = int(row_off[w]), int(ncol[w])
         out.append((buf[a:a + nc], buf[a + nc:a + 2 * nc], buf[a + 2 * nc:a + 3 * nc]))
     return out, ncol, scores, int(cells)
+
+
+def batch_bundles(bases, off, minimum_fraction=0.9, params=None):
+    """a12 -> list of (consensus rows [bytes], counts [int], bundle ids (ref, cor, unc)) per window"""
+    params = params or default_params()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    n = (len(off) - 1) // 3
+    cap = 4 * int(off[-1]) + 64
+    cons = np.zeros(cap, dtype=np.uint8)
+    cons_off = np.zeros(n + 1, dtype=np.int64)
+    info = np.zeros((n, 8), dtype=np.int32)
+    rc = lib().po_batch_bundles(params, n, bases.ctypes.data, off.ctypes.data, float(minimum_fraction),
+                                cons.ctypes.data, cap, cons_off.ctypes.data, info.ctypes.data)
+    if rc:
+        raise RuntimeError("oracle bundles failed (%d)" % rc)
+    buf = cons.tobytes()
+    out = []
+    for w in range(n):
+        k, nc, a = int(info[w, 0]), int(info[w, 7]), int(cons_off[w])
+        out.append(([buf[a + i * nc:a + (i + 1) * nc] for i in range(k)],
+                    [int(x) for x in info[w, 1:1 + k]], tuple(int(x) for x in info[w, 4:7])))
+    return out
 
 
 def run_files(matrix, ref_fa, cor_fa, unc_fa, out_path, with_bundles=False):

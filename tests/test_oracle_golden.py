@@ -39,6 +39,17 @@ def test_heaviest_bundle_rows(tmp_path):
     assert lines[k:] == [b""]
 
 
+def test_heaviest_bundle_batch_entry():
+    """the in-memory batch entry the GPU parity tests compare against gives the golden rows too"""
+    gold = golden_io.bundles()
+    bases, off = synth.pack_windows([g[0] for g in gold])
+    got = oracle_lib.batch_bundles(np.frombuffer(bases, dtype=np.uint8), off)
+    for (t, recs), (rows, counts, ids) in zip(gold, got):
+        exp_rows, exp_counts = golden_io.bundle_expectation(recs)
+        assert rows == exp_rows and counts == exp_counts, t
+        assert sum(1 for i in ids if i >= 0) == sum(counts)
+
+
 def test_matrix_parameters(tmp_path):
     g = golden_io.params()
 
