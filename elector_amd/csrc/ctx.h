@@ -82,10 +82,15 @@ struct elector_ctx {
   elector::DevBuf d_tab, d_linx, d_liny;
   // per-batch workspace
   elector::DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
-      d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_lanemeta;
+      d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_lanemeta, d_fmv;
   // host API staging
   elector::DevBuf d_bases, d_cols, d_ncol, d_status, d_scores, d_rowoff, d_rows;
-  elector::HostPinned h_meta;
+  // pinned upload staging of the per-batch metadata, double-buffered: a batch's host-to-device copies
+  // are queued behind the previous batch's kernels, so the host may already prepare the next batch
+  // while they are pending; a buffer is rewritten only after its copies have run (h_meta_done)
+  elector::HostPinned h_meta_buf[2];
+  hipEvent_t h_meta_done[2] = {nullptr, nullptr};
+  int h_meta_cur = 0;
   // statistics workspace
   elector::DevBuf d_st_rows, d_st_rowoff, d_st_cols, d_st_first, d_st_clips, d_st_cnt, d_st_mask, d_st_scr, d_st_dense, d_st_outoff;
   static constexpr int kStatsSlots = 2;

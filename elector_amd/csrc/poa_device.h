@@ -91,28 +91,42 @@ struct BatchArgs {
   uint8_t *mark_b;              // when set, k_fuse2 marks the windows it finishes
 };
 
-// LDS bytes the fused kernels need for a window in a group of G lanes (4G rows per
-// strip); must mirror the slot layouts in poa_fused.hip
+// LDS bytes the fused kernels need for a window worked on by a group of G lanes with R rows
+// per lane (a strip has G*R rows); must mirror the slot layouts in poa_fused.hip.
+// moves: 2 bits per cell, one byte (R <= 4) or two (R <= 8) per lane and step.  They live in HBM
+// (written once, coalesced: one word per lane and anti-diagonal step; read back by the traceback
+// while still in L2), indexed [block][strip][step][lane].
+__host__ __device__ inline int fused_mv_bytes(int R) { return R <= 4 ? 1 : 2; }
+
+// Alignment #1 may keep its moves in LDS for the classes up to this many lanes per window.  Measured
+// on the bench batch: 0 (all moves in HBM) wins -- the traceback of alignment #1 gets slower (its many
+// resident waves' moves fall out of L2), but the LDS it frees goes to the concurrently running
+// alignment #2 kernels, whose occupancy is LDS-bound.
+#ifndef ELECTOR_A_LDS_MAXG
+#define ELECTOR_A_LDS_MAXG 0
+#endif
+__host__ __device__ constexpr bool fused_a_moves_in_lds(int G) { return G <= ELECTOR_A_LDS_MAXG; }
+
 // bytes of k_fused_a's node maps (u16 per ref letter, 2 x u16 per cor letter)
 __host__ __device__ inline int fused_a_maps_bytes(int Lr, int Lc) { return 2 * ((Lr + 1) & ~1) + 4 * ((Lc + 1) & ~1) + 8; }
 
-__host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G)
+__host__ __device__ inline int fused_a_slot_need(int Lr, int Lc, int G, int R)
 {
-  const int ns = (Lc + 4 * G - 1) / (4 * G);
+  const int ns = (Lc + R * G - 1) / (R * G);
   int o = 16 + ((Lr + Lc + 3) & ~3);
   o += (2 * Lr + 3) & ~3;
   o += (ns > 1 ? 4 * (Lr + 1) : 0);
   o = (o + 7) & ~7;
-  const int mv = ns * Lr * G, st = fused_a_maps_bytes(Lr, Lc);
+  const int mv = fused_a_moves_in_lds(G) ? ns * Lr * G * fused_mv_bytes(R) : 0, st = fused_a_maps_bytes(Lr, Lc);
   return o + (mv > st ? mv : st);
 }
 
 // bytes of k_fused_b's staged MSA columns (3 per column) + the column of every uncorrected letter
 __host__ __device__ inline int fused_b_cols_bytes(int n1, int Lu) { return ((3 * (n1 + Lu) + 8 + 3) & ~3) + 2 * Lu + 4; }
 
-__host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G)
+__host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G, int R)
 {
-  const int ns = (Lu + 4 * G - 1) / (4 * G);
+  const int ns = (Lu + R * G - 1) / (R * G);
   int o = 16 + ((Lu + 3) & ~3);
   o += 4 * (n1 + 1);
   o += (2 * n1 + 3) & ~3;
@@ -120,9 +134,14 @@ __host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G)
   o += (2 * (n1 + 1) + 3) & ~3;
   o += (ns > 1 ? 2 * (n1 + 1) : 0);
   o = (o + 3) & ~3;
-  // moves + ordinal bytes of the two-predecessor nodes (estimated: one node in six)
-  const int mv = ns * n1 * G + (4 + n1 / 6) * ns * G, st = fused_b_cols_bytes(n1, Lu);
-  return o + (mv > st ? mv : st);
+  // ordinal bytes of the two-predecessor nodes (estimated: one node in six), overlaid by the staged columns
+  const int ob = (4 + n1 / 6) * ns * G, st = fused_b_cols_bytes(n1, Lu);
+  return o + (ob > st ? ob : st);
 }
+
+// bytes of one wave's score ring in k_fused_b: kFusedRingSlots time slots x 64 lanes x R 16-bit cells
+constexpr int kFusedRingDepth = 8;        // time slots
+constexpr int kFusedRingSlots = 8;
+__host__ __device__ inline int fused_ring_bytes(int R) { return kFusedRingSlots * 64 * 4 * ((R + 1) / 2); }
 
 }  // namespace elector

@@ -1,13 +1,14 @@
 // elector_amd/csrc/poa_fused.hip -- LDS-resident, row-blocked kernels for the
 // windows that fit on chip (the bulk: the splitter's windows are 27-400 bases).
 //
-// Geometry: one wavefront works on FOUR windows; each window owns 16 lanes and a
-// slot of LDS.  A lane holds FOUR consecutive rows of the linear read y in
-// registers, so a 64-row strip needs only 16 anti-diagonal steps of skew instead
-// of 64: steps per strip = Lx + 15, lane g computes column jj = t - g for its 4
-// rows top to bottom (the vertical dependence stays inside the lane).  The row
-// above a lane's block arrives by DPP row_shr:1 inside the 16-lane row; lane 0
-// receives the strip's top border through the DPP `old` operand.
+// Geometry: one wavefront works on 64/G windows; each window owns G lanes
+// (G = 8, 16, 32 or 64) and a slot of LDS.  A lane holds R consecutive rows of the
+// linear read y in registers (R = 4..8, chosen with G so that one strip of G*R
+// rows is just as tall as the window), so a strip costs Lx + G - 1 anti-diagonal
+// steps: lane g computes column jj = t - g for its R rows top to bottom (the
+// vertical dependence stays inside the lane).  The row above a lane's block
+// arrives by DPP row_shr:1 (wave_shr:1 for G > 16); the group's first lane
+// receives the strip's top border.
 //
 //   k_fused_a  alignment #1 (linear x linear) -> moves in LDS -> traceback ->
 //              fusion #1 -> PO graph (xinfo, ring1, virtual-row scores) to HBM.
@@ -36,6 +37,8 @@ struct FusedArgs {
   int32_t *rowinit;         // node space: score of the virtual row -1 at node jj
   int debug;                // timing experiments only (bit0: skip DP, bit1: skip serial stage)
   int keep_map;             // k_fused_b also leaves the x -> y map of alignment #2 in HBM (a12 needs it)
+  uint8_t *mv_pool;         // moves scratch of this launch: [block][mv_ns strips][mv_tw steps][64 lanes] words
+  int mv_tw, mv_ns;
 };
 
 __device__ __forceinline__ int row_shr1(int old, int v)
@@ -55,6 +58,7 @@ template <int G>
 __device__ __forceinline__ int shift_in(int border, int v, int g)
 {
   if (G == 16) return row_shr1(border, v);
+  if (G == 8) { const int r = row_shr1(border, v); return g == 0 ? border : r; }
   const int r = wave_shr1_old(border, v);
   return (G < 64 && g == 0) ? border : r;
 }
@@ -71,6 +75,13 @@ __device__ __forceinline__ int align_up(int x, int a) { return (x + a - 1) & ~(a
       stamp_ = now_;                                                                              \
     }                                                                                             \
   } while (0)
+
+// a lane's move pairs of one column: 2 bits per cell, R cells
+template <int R> struct MvWord { using type = uint16_t; };
+template <> struct MvWord<1> { using type = uint8_t; };
+template <> struct MvWord<2> { using type = uint8_t; };
+template <> struct MvWord<3> { using type = uint8_t; };
+template <> struct MvWord<4> { using type = uint8_t; };
 
 // one DP cell with uniform scoring: returns new score, sets match flag / move nibble
 struct CellOut { int S; bool m; uint32_t nib; };
@@ -90,8 +101,8 @@ __device__ __forceinline__ CellOut cell_1pred(int diag, int insX, int insY, int 
 
 // one window of k_fused_a: ids, lengths and its LDS slot layout
 // slot: [header 16 B, unused][ref+cor symbols][x2y u16][carry i32 (multi-strip only)][region]
-// region = alignment #1 moves (1 byte per lane and column: 4 cells x 2 bits), reused after the
-// traceback for the node maps of the fusion (node of every ref / cor letter, cor -> ref map, u16 each)
+// region = the node maps of the fusion (node of every ref / cor letter, cor -> ref map, u16 each).
+// The moves (R cells x 2 bits per lane and step, in 1 or 2 bytes) go to the launch's HBM scratch.
 struct WinA {
   bool valid;
   uint32_t w;
@@ -99,10 +110,10 @@ struct WinA {
   int Lr, Lc, ns, off_x2y, off_carry, off_region;
 };
 
-template <int G>
+template <int G, int R>
 __device__ __forceinline__ WinA load_win_a(const FusedArgs &a, int64_t li)
 {
-  constexpr int RS = 4 * G;
+  constexpr int RS = R * G;
   WinA v;
   v.valid = li < a.nlist;
   v.w = v.valid ? a.list[li] : 0;
@@ -117,27 +128,35 @@ __device__ __forceinline__ WinA load_win_a(const FusedArgs &a, int64_t li)
   v.off_x2y = 16 + align_up(v.Lr + v.Lc, 4);
   v.off_carry = v.off_x2y + align_up(2 * v.Lr, 4);
   v.off_region = align_up(v.off_carry + (v.ns > 1 ? 4 * (v.Lr + 1) : 0), 8);
-  const int region_bytes = max(v.ns * v.Lr * G, fused_a_maps_bytes(v.Lr, v.Lc));
-  v.valid = v.valid && (v.off_region + region_bytes <= a.slot_bytes);
+  constexpr int MVB = R <= 4 ? 1 : 2;
+  const int region_bytes = max(fused_a_moves_in_lds(G) ? v.ns * v.Lr * G * MVB : 0, fused_a_maps_bytes(v.Lr, v.Lc));
+  v.valid = v.valid && (v.off_region + region_bytes <= a.slot_bytes) &&
+            (fused_a_moves_in_lds(G) || (v.ns <= a.mv_ns && v.Lr + G <= a.mv_tw));
   return v;
 }
 
 // WV wavefronts per block, each owning 64/G windows from staging to the fused graph.
-template <int G, int WV>
+template <int G, int R, int WV>
 __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
-  constexpr int NW = 64 / G, RS = 4 * G;     // windows per wave, rows per strip
+  constexpr int NW = 64 / G, RS = R * G;     // windows per wave, rows per strip
+  using mv_t = typename MvWord<R>::type;     // a lane's R move pairs of one column
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
   const int sidx = wv * NW + q;               // this lane's window slot in the block
-  const WinA W = load_win_a<G>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
+  const WinA W = load_win_a<G, R>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
   const bool valid = W.valid;
   const int Lr = W.Lr, Lc = W.Lc, ns = W.ns;
   uint8_t *slot = lds + sidx * a.slot_bytes;
   uint8_t *xs = slot + 16, *ys = xs + Lr;
   int32_t *carry = reinterpret_cast<int32_t *>(slot + W.off_carry);
-  uint8_t *mv = slot + W.off_region;
+  // moves: LDS (region, [strip][column][lane of the group]) for the small classes, else the launch's
+  // HBM scratch ([strip][step][lane of the wave])
+  constexpr bool kMvLds = fused_a_moves_in_lds(G);
+  mv_t *mvl = reinterpret_cast<mv_t *>(slot + W.off_region);
+  mv_t *mvg = reinterpret_cast<mv_t *>(a.mv_pool) + ((int64_t)blockIdx.x * WV + wv) * a.mv_ns * a.mv_tw * 64;
+  const int mvtw = a.mv_tw;
 
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
   if (valid) {
@@ -157,14 +176,14 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
   nsmax = __builtin_amdgcn_readfirstlane(nsmax);
 
   int score = kNeg;
-  const int gstar = ((Lc - 1) % RS) >> 2, kstar = (Lc - 1) & 3;
+  const int gstar = ((Lc - 1) % RS) / R, kstar = ((Lc - 1) % RS) % R;
   if (a.debug & 1) nsmax = 0;
   for (int s = 0; s < nsmax; ++s) {
     const bool sv = valid && s < ns;
-    const int ii0 = RS * s + 4 * g + 1;                    // first of this lane's 4 rows (1-based)
-    int yl[4], S[4], Ex[4], Ey[4];
+    const int ii0 = RS * s + R * g + 1;                    // first of this lane's R rows (1-based)
+    int yl[R], S[R], Ex[R], Ey[R];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < R; ++k) {
       const int ii = ii0 + k;
       yl[k] = (sv && ii <= Lc) ? ys[ii - 1] : 255;
       S[k] = -(kp.open_y + (ii - 1) * kp.ext_y);           // column -1: ii gap steps from the origin
@@ -182,8 +201,8 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
         const int c = (sv && t <= Lr) ? carry[t] : 0;
         bS = c >> 1; bEy = bS - ((c & 1) ? kp.open_y : kp.ext_y);
       }
-      const int upS = shift_in<G>(bS, S[3], g);
-      const int upEy = shift_in<G>(bEy, Ey[3], g);
+      const int upS = shift_in<G>(bS, S[R - 1], g);
+      const int upEy = shift_in<G>(bEy, Ey[R - 1], g);
       const int jj = t - g;
       const int xl = xl_next;
       xl_next = (sv && jj >= 0 && jj < Lr) ? xs[jj] : 0;
@@ -192,7 +211,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
         uint32_t mv8 = 0;
         bool mlast = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < R; ++k) {
           const int oldS = S[k];
           const CellOut c = cell_1pred(diag, Ex[k], insY, xl == yl[k] ? kp.match : kp.mismatch);
           S[k] = c.S;
@@ -202,11 +221,15 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
           diag = oldS; insY = Ey[k]; mlast = c.m;
         }
         dg0 = upS;
-        mv[(s * Lr + (jj - 1)) * G + g] = (uint8_t)mv8;
-        if (wr_carry) carry[jj] = (S[3] << 1) | (mlast ? 1 : 0);
+        if (kMvLds) mvl[(s * Lr + (jj - 1)) * G + g] = (mv_t)mv8;
+        else mvg[(s * mvtw + t) * 64 + lane] = (mv_t)mv8;
+        if (wr_carry) carry[jj] = (S[R - 1] << 1) | (mlast ? 1 : 0);
       }
     }
-    if (sv && s == ns - 1 && g == gstar) score = (kstar == 0) ? S[0] : (kstar == 1) ? S[1] : (kstar == 2) ? S[2] : S[3];
+    if (sv && s == ns - 1 && g == gstar) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) if (k == kstar) score = S[k];
+    }
     __builtin_amdgcn_wave_barrier();
   }
   if (valid && g == gstar) a.b.score1[W.w] = score;
@@ -220,8 +243,10 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
   if (valid && g == 0 && !(a.debug & 2)) {
     int x = Lr - 1, y = Lc - 1, guard = Lr + Lc + 2;
     while (x >= 0 && y >= 0 && guard-- > 0) {
-      const int r = y % RS;
-      const uint32_t two = (mv[((y / RS) * Lr + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
+      const int r = y % RS, rl = r / R, rk = r - rl * R;
+      const uint32_t word = kMvLds ? (uint32_t)mvl[((y / RS) * Lr + x) * G + rl]
+                                   : (uint32_t)mvg[((y / RS) * mvtw + (x + 1 + rl)) * 64 + q * G + rl];
+      const uint32_t two = (word >> (2 * rk)) & 3u;
       const int xo = two & 1, yo = two >> 1;
       if (xo && yo) x2y[x] = (uint16_t)y;
       if (!xo && !yo) { bad = true; break; }
@@ -388,11 +413,12 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
 // ---------------------------------------------------------------- k_fused_b ---
 // Alignment #2 on the PO graph of (ref + cor).  A node has <= 2 DP predecessors at
 // any distance; the common case (one predecessor, the previous node) is served from
-// registers, everything else from a 16-deep LDS ring indexed by time that holds each
-// lane's four cells of the last 16 steps as 16-bit (score << 1 | came-from-match).
+// registers, everything else from an 8-deep LDS ring indexed by time that holds each
+// lane's R cells of the last 8 steps as 16-bit (score << 1 | came-from-match), laid out
+// [slot][dword][lane] so that every access is bank-conflict free.
 
-constexpr int kRingDepth = 8;        // time slots
-constexpr int kRingSlots = 10;       // + slot 16: each lane's column -1 cells, slot 17: "no predecessor"
+constexpr int kRingDepth = kFusedRingDepth;   // time slots
+constexpr int kRingSlots = kFusedRingSlots;   // the virtual start column and "no predecessor" are computed, not stored
 constexpr int kNeg16 = -16383;       // score of the "no predecessor" cells (below any 16-bit-eligible score)
 
 __device__ __forceinline__ int cell16_S(int c) { return c >> 1; }
@@ -448,8 +474,9 @@ __device__ __noinline__ int fuse2_columns_serial(int n1, int Lu, const uint32_t 
 // [header 16 B: k2 / ncol, ok, best, bestx][unc symbols][node info u32[n1+1]][ring1 u16[n1]][x2y u16[n1]]
 // [bnd0 i16[n1+1]][bnd1 i16[n1+1] if ns>1][region]
 // node info = d1 (0 = virtual start) | d2 << 4 (0 = none, 15 = virtual) | letter << 8 | flags << 16 | k2 << 24
-// region = moves (1 byte per lane and column: 4 cells x 2 bits) + predecessor-ordinal bytes of the
-// K2 nodes that have two predecessors; reused after the traceback for the staged MSA columns
+// region = predecessor-ordinal bytes of the K2 nodes that have two predecessors; reused after the
+// traceback for the staged MSA columns.  The moves (R cells x 2 bits per lane and step, in 1 or 2
+// bytes) go to the launch's HBM scratch.
 struct WinB {
   bool valid;
   uint32_t w;
@@ -457,10 +484,10 @@ struct WinB {
   int n1, Lu, ns, off_xi, off_r1, off_x2y, off_b0, off_b1, off_region;
 };
 
-template <int G>
+template <int G, int R>
 __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
 {
-  constexpr int RS = 4 * G;
+  constexpr int RS = R * G;
   const KParams kp = a.b.kp;
   WinB v;
   v.valid = li < a.nlist;
@@ -480,29 +507,33 @@ __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
   v.off_b0 = v.off_x2y + align_up(2 * v.n1, 4);
   v.off_b1 = v.off_b0 + align_up(2 * (v.n1 + 1), 4);
   v.off_region = align_up(v.off_b1 + (v.ns > 1 ? 2 * (v.n1 + 1) : 0), 4);
-  const int region_min = max(v.ns * v.n1 * G, fused_b_cols_bytes(v.n1, v.Lu));
+  const int region_min = fused_b_cols_bytes(v.n1, v.Lu);
   const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
-  v.valid = v.valid && (v.off_region + region_min <= a.slot_bytes) && (maxpen * (v.n1 + v.Lu + 4) < 16000);
+  v.valid = v.valid && (v.off_region + region_min <= a.slot_bytes) && (maxpen * (v.n1 + v.Lu + 4) < 16000) &&
+            v.ns <= a.mv_ns && v.n1 + G <= a.mv_tw;
   return v;
 }
 
-template <int G, int WV>
+template <int G, int R, int WV>
 __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
-  constexpr int NW = 64 / G, RS = 4 * G;     // windows per wave, rows per strip
+  constexpr int NW = 64 / G, RS = R * G;     // windows per wave, rows per strip
+  constexpr int RW = (R + 1) / 2;                         // ring dwords per lane and slot
+  constexpr int kRingBytes = kRingSlots * 64 * 4 * RW;
+  using mv_t = typename MvWord<R>::type;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
   const int sidx = wv * NW + q;
-  const WinB W = load_win_b<G>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
+  const WinB W = load_win_b<G, R>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
   bool valid = W.valid;
   const uint32_t w = W.w;
   const int64_t o0 = W.o0;
   const int n1 = W.n1, Lu = W.Lu, ns = W.ns;
   // LDS: [output characters 64 B][one score ring per wave][window slots]
   uint8_t *chr = lds;
-  uint8_t *slot = lds + 64 + WV * 64 * 8 * kRingSlots + sidx * a.slot_bytes;
-  uint2 *ring = reinterpret_cast<uint2 *>(lds + 64 + wv * 64 * 8 * kRingSlots);   // this wave's [kRingSlots][64] x 4 cells of 16 bits
+  uint8_t *slot = lds + 64 + WV * kRingBytes + sidx * a.slot_bytes;
+  uint32_t *ring = reinterpret_cast<uint32_t *>(lds + 64 + wv * kRingBytes);   // this wave's [kRingSlots][RW][64] dwords = 2 cells of 16 bits
   const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(ring);
   int32_t *hdr = reinterpret_cast<int32_t *>(slot);
   uint8_t *ys = slot + 16;
@@ -510,8 +541,9 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   uint16_t *ring1 = reinterpret_cast<uint16_t *>(slot + W.off_r1);
   int16_t *bnd0 = reinterpret_cast<int16_t *>(slot + W.off_b0);
   int16_t *bnd1 = reinterpret_cast<int16_t *>(slot + W.off_b1);
-  uint8_t *mv = slot + W.off_region;
-  uint8_t *ordb = mv + ns * n1 * G;                              // [K2][ns][G]
+  mv_t *mv = reinterpret_cast<mv_t *>(a.mv_pool) + ((int64_t)blockIdx.x * WV + wv) * a.mv_ns * a.mv_tw * 64;
+  const int mvtw = a.mv_tw;
+  uint8_t *ordb = slot + W.off_region;                           // [K2][ns][G]
 
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
   if (threadIdx.x < 32) chr[threadIdx.x] = a.b.tab->chr[threadIdx.x];
@@ -585,7 +617,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
       }
     }
     valid = valid && k2n <= 255 &&
-            (W.off_region + max(ns * n1 * G + k2n * ns * G, fused_b_cols_bytes(n1, Lu)) <= a.slot_bytes);
+            (W.off_region + max(k2n * ns * G, fused_b_cols_bytes(n1, Lu)) <= a.slot_bytes);
   }
   __syncthreads();
 
@@ -599,28 +631,21 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   nsmax = __builtin_amdgcn_readfirstlane(nsmax);
 
   int best = kNeg, bestx = -1;
-  const int gstar = ((Lu - 1) % RS) >> 2, kstar = (Lu - 1) & 3;
+  const int gstar = ((Lu - 1) % RS) / R, kstar = ((Lu - 1) % RS) % R;
   if (a.debug & 1) nsmax = 0;
   for (int s = 0; s < nsmax; ++s) {
     const bool sv = valid && s < ns;
     const int16_t *bcur = (s & 1) ? bnd1 : bnd0;
     int16_t *bnext = (s & 1) ? bnd0 : bnd1;
-    const int ii0 = RS * s + 4 * g + 1;
-    int yl[4], S[4], M[4], Ey[4], colS[4];
+    const int ii0 = RS * s + R * g + 1;
+    int yl[R], S[R], M[R], Ey[R], colS[R];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < R; ++k) {
       const int ii = ii0 + k;
       yl[k] = (sv && ii <= Lu) ? ys[ii - 1] : 255;
       colS[k] = -(kp.open_y + (ii - 1) * kp.ext_y);
       S[k] = colS[k]; M[k] = 0;
       Ey[k] = S[k] - kp.ext_y;
-    }
-    {
-      const uint32_t p01 = (uint32_t)((colS[0] << 1) & 0xFFFF) | ((uint32_t)(colS[1] << 1) << 16);
-      const uint32_t p23 = (uint32_t)((colS[2] << 1) & 0xFFFF) | ((uint32_t)(colS[3] << 1) << 16);
-      ring[kRingDepth * 64 + lane] = make_uint2(p01, p23);
-      const uint32_t ng = (uint32_t)((kNeg16 << 1) & 0xFFFF) | ((uint32_t)(kNeg16 << 1) << 16);
-      ring[(kRingDepth + 1) * 64 + lane] = make_uint2(ng, ng);
     }
     const bool wr_carry = sv && (s + 1 < ns) && g == G - 1;
     const bool last_strip_row = sv && s == ns - 1 && g == gstar;
@@ -644,41 +669,58 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
         bnd0[t] = (int16_t)bc;
       }
       const int bS = bc >> 1, bEy = bS - ((bc & 1) ? kp.open_y : kp.ext_y);
-      const int upEy = shift_in<G>(bEy, Ey[3], g);
+      const int upEy = shift_in<G>(bEy, Ey[R - 1], g);
       const int lm1 = (lane - 1) & 63;
-      // ---- predecessor cells.  Own four cells at column pp: this lane's ring slot of
+      // ---- predecessor cells.  Own R cells at column pp: this lane's ring slot of
       // d = jj - pp steps ago; the cell above them: lane-1's slot one step earlier (the strip
-      // border array for the group's first lane).  The virtual start column lives in slot 16,
-      // a missing second predecessor reads the very negative cells of slot 17: no value selects. ----
-      const int sa = (ppa == 0) ? kRingDepth : ((t - (jj - ppa)) & (kRingDepth - 1));
-      const int sat = (ppa == 0) ? kRingDepth : ((t - (jj - ppa) - 1) & (kRingDepth - 1));
-      const int sb = !has2 ? kRingDepth + 1 : (pp2 == 0) ? kRingDepth : ((t - (jj - pp2)) & (kRingDepth - 1));
-      const int sbt = !has2 ? kRingDepth + 1 : (pp2 == 0) ? kRingDepth : ((t - (jj - pp2) - 1) & (kRingDepth - 1));
-      const uint2 c1 = ring[sa * 64 + lane];
-      const uint2 c2 = ring[sb * 64 + lane];
-      const int r1 = (int16_t)ring16[(sat * 64 + lm1) * 4 + 3];
-      const int r2 = (int16_t)ring16[(sbt * 64 + lm1) * 4 + 3];
+      // border array for the group's first lane).  The cells of the virtual start column are a
+      // function of the row (patched in below, rare); a missing second predecessor gets very
+      // negative cells: no value selects. ----
+      const bool virt1 = act && ppa == 0, virt2 = has2 && pp2 == 0;
+      const int sa = (t - (jj - ppa)) & (kRingDepth - 1);
+      const int sat = (t - (jj - ppa) - 1) & (kRingDepth - 1);
+      const int sb = (t - (jj - pp2)) & (kRingDepth - 1);
+      const int sbt = (t - (jj - pp2) - 1) & (kRingDepth - 1);
+      uint32_t c1[RW], c2[RW];
+#pragma unroll
+      for (int d = 0; d < RW; ++d) {
+        c1[d] = ring[(sa * RW + d) * 64 + lane];
+        c2[d] = ring[(sb * RW + d) * 64 + lane];
+      }
+      // the last cell of the lane above: dword (R-1)/2, half (R-1)&1 of its slot one step earlier
+      int r1 = (int16_t)ring16[((sat * RW + ((R - 1) >> 1)) * 64 + lm1) * 2 + ((R - 1) & 1)];
+      int r2 = (int16_t)ring16[((sbt * RW + ((R - 1) >> 1)) * 64 + lm1) * 2 + ((R - 1) & 1)];
+      if (__builtin_amdgcn_ballot_w64(virt1 || virt2) != 0) {
+        // column -1: row ii holds -(open_y + (ii - 1) ext_y), not a match; the row above this lane's first is ii0 - 1
+        const int above = (colS[0] + kp.ext_y) * 2;
+#pragma unroll
+        for (int d = 0; d < RW; ++d) {
+          const uint32_t lo = (uint32_t)((colS[2 * d] * 2) & 0xFFFF);
+          const uint32_t hi = (2 * d + 1 < R) ? (uint32_t)((colS[(2 * d + 1 < R) ? 2 * d + 1 : 0] * 2) & 0xFFFF) : 0u;
+          if (virt1) c1[d] = lo | (hi << 16);
+          if (virt2) c2[d] = lo | (hi << 16);
+        }
+        if (virt1) r1 = above;
+        if (virt2) r2 = above;
+      }
       if (act) {
         const int xl = (xi >> 8) & 0xFF;
         const int d1top = ((g == 0) ? b1 : r1) >> 1;
         const int d2top = has2 ? (((g == 0) ? b2 : r2) >> 1) : kNeg16;
-        int o1S[4], o1M[4], o2S[4], o2M[4];
-        {
-          const int e0 = (int16_t)(c1.x & 0xFFFF), e1 = (int16_t)(c1.x >> 16), e2 = (int16_t)(c1.y & 0xFFFF), e3 = (int16_t)(c1.y >> 16);
-          o1S[0] = e0 >> 1; o1S[1] = e1 >> 1; o1S[2] = e2 >> 1; o1S[3] = e3 >> 1;
-          o1M[0] = e0 & 1; o1M[1] = e1 & 1; o1M[2] = e2 & 1; o1M[3] = e3 & 1;
+        int o1S[R], o1M[R], o2S[R], o2M[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const int e1 = (k & 1) ? (int)((int32_t)c1[k >> 1] >> 16) : (int)(int16_t)(c1[k >> 1] & 0xFFFF);
+          const int e2 = (k & 1) ? (int)((int32_t)c2[k >> 1] >> 16) : (int)(int16_t)(c2[k >> 1] & 0xFFFF);
+          o1S[k] = e1 >> 1; o1M[k] = e1 & 1;
+          o2S[k] = has2 ? e2 >> 1 : kNeg16; o2M[k] = has2 ? e2 & 1 : 0;
         }
-        {
-          const int e0 = (int16_t)(c2.x & 0xFFFF), e1 = (int16_t)(c2.x >> 16), e2 = (int16_t)(c2.y & 0xFFFF), e3 = (int16_t)(c2.y >> 16);
-          o2S[0] = e0 >> 1; o2S[1] = e1 >> 1; o2S[2] = e2 >> 1; o2S[3] = e3 >> 1;
-          o2M[0] = e0 & 1; o2M[1] = e1 & 1; o2M[2] = e2 & 1; o2M[3] = e3 & 1;
-        }
-        // ---- the four cells, top to bottom ----
+        // ---- the lane's R cells, top to bottom ----
         int insY = upEy, dt1 = d1top, dt2 = d2top;
         uint32_t mv8 = 0, sec4 = 0;
-        int nS[4], nM[4];
+        int nS[R], nM[R];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < R; ++k) {
           const int cx1 = o1S[k] - (o1M[k] ? kp.open_x : kp.ext_x);
           const int cx2 = o2S[k] - (o2M[k] ? kp.open_x : kp.ext_x);
           const bool px2 = cx2 > cx1;                         // first maximum wins (:361-371)
@@ -700,15 +742,20 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
           Ey[k] = insY;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { S[k] = nS[k]; M[k] = nM[k]; }
-        const uint32_t p01 = (uint32_t)(((S[0] << 1) | M[0]) & 0xFFFF) | ((uint32_t)((S[1] << 1) | M[1]) << 16);
-        const uint32_t p23 = (uint32_t)(((S[2] << 1) | M[2]) & 0xFFFF) | ((uint32_t)((S[3] << 1) | M[3]) << 16);
-        ring[(t & (kRingDepth - 1)) * 64 + lane] = make_uint2(p01, p23);
-        mv[(s * n1 + (jj - 1)) * G + g] = (uint8_t)mv8;
+        for (int k = 0; k < R; ++k) { S[k] = nS[k]; M[k] = nM[k]; }
+#pragma unroll
+        for (int d = 0; d < RW; ++d) {
+          const uint32_t lo = (uint32_t)(((S[2 * d] << 1) | M[2 * d]) & 0xFFFF);
+          const uint32_t hi = (2 * d + 1 < R) ? (uint32_t)((S[(2 * d + 1 < R) ? 2 * d + 1 : 0] << 1) | M[(2 * d + 1 < R) ? 2 * d + 1 : 0]) : 0u;
+          ring[((t & (kRingDepth - 1)) * RW + d) * 64 + lane] = lo | (hi << 16);
+        }
+        mv[(s * mvtw + t) * 64 + lane] = (mv_t)mv8;
         if (has2) ordb[((xi >> 24) * ns + s) * G + g] = (uint8_t)sec4;
-        if (wr_carry) bnext[jj] = (int16_t)((S[3] << 1) | M[3]);
+        if (wr_carry) bnext[jj] = (int16_t)((S[R - 1] << 1) | M[R - 1]);
         if (last_strip_row && ((xi >> 16) & kFlagFinal)) {
-          const int sv2 = (kstar == 0) ? S[0] : (kstar == 1) ? S[1] : (kstar == 2) ? S[2] : S[3];
+          int sv2 = S[0];
+#pragma unroll
+          for (int k = 1; k < R; ++k) if (k == kstar) sv2 = S[k];
           if (sv2 > best) { best = sv2; bestx = jj - 1; }      // ties keep the smaller column (:410-417)
         }
       }
@@ -734,15 +781,15 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   if (valid && g == 0 && !(a.debug & 2)) {
     int x = hdr[3], y = Lu - 1, guard = n1 + Lu + 2;
     while (x >= 0 && y >= 0 && guard-- > 0) {
-      const int r = y % RS;
+      const int r = y % RS, rl = r / R, rk = r - rl * R;
       const uint32_t inf = xinfo[x + 1];
-      const uint32_t two = (mv[((y / RS) * n1 + x) * G + (r >> 2)] >> (2 * (r & 3))) & 3u;
+      const uint32_t two = ((uint32_t)mv[((y / RS) * mvtw + (x + 1 + rl)) * 64 + q * G + rl] >> (2 * rk)) & 3u;
       const int xo = two & 1, yo = two >> 1;
       if (xo && yo) x2y[x] = (uint16_t)y;
       if (!xo && !yo) { bad = true; break; }
       if (xo) {
         const int d2v = (inf >> 4) & 15;
-        const int sec = d2v ? (ordb[((inf >> 24) * ns + (y / RS)) * G + (r >> 2)] >> (r & 3)) & 1 : 0;
+        const int sec = d2v ? (ordb[((inf >> 24) * ns + (y / RS)) * G + rl] >> rk) & 1 : 0;
         const int dd = sec ? d2v : (int)(inf & 15);
         x = (dd == 0 || dd == 15) ? -1 : x - dd;
       }
@@ -881,49 +928,58 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
 
 // ---------------------------------------------------------------- launcher ---
 
-template <int G, int WV>
+template <int G, int R>
 static int launch_a_t(const FusedArgs &a, hipStream_t st)
 {
-  constexpr int NB = WV * 64 / G;     // windows per block
+  constexpr int NB = 64 / G;     // windows per block (one wave)
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_a<G, WV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_a<G, R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
     attr = true;
   }
-  hipLaunchKernelGGL((k_fused_a<G, WV>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64 * WV), NB * a.slot_bytes, st, a);
+  hipLaunchKernelGGL((k_fused_a<G, R, 1>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64), NB * a.slot_bytes, st, a);
   return 0;
 }
 
-template <int G, int WV>
+template <int G, int R>
 static int launch_b_t(const FusedArgs &a, hipStream_t st)
 {
-  constexpr int NB = WV * 64 / G;
+  constexpr int NB = 64 / G;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_b<G, WV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_b<G, R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
     attr = true;
   }
-  hipLaunchKernelGGL((k_fused_b<G, WV>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64 * WV),
-                     64 + NB * a.slot_bytes + WV * 64 * 8 * kRingSlots, st, a);
+  hipLaunchKernelGGL((k_fused_b<G, R, 1>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64),
+                     64 + NB * a.slot_bytes + fused_ring_bytes(R), st, a);
   return 0;
 }
 
-int launch_fused_a(const FusedArgs &a, int G, hipStream_t st)
+// the geometry classes the host may ask for (poa_host.hip kFusedClasses)
+#define ELECTOR_FUSED_CLASSES(X) \
+  X(8, 4) X(8, 5) X(8, 6) X(8, 7) X(8, 8) X(16, 5) X(16, 6) X(16, 7) X(16, 8) \
+  X(32, 5) X(32, 6) X(32, 7) X(32, 8) X(64, 5) X(64, 6) X(64, 7) X(64, 8)
+
+int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st)
 {
   if (a.nlist <= 0) return 0;
-  // several waves per block where the block's slots fit comfortably: the serial stage of all
-  // its windows is then shared by one wave
-  return G == 16 ? launch_a_t<16, 1>(a, st) : G == 32 ? launch_a_t<32, 1>(a, st) : launch_a_t<64, 1>(a, st);
+#define X(g, r) if (G == g && R == r) return launch_a_t<g, r>(a, st);
+  ELECTOR_FUSED_CLASSES(X)
+#undef X
+  return -2;
 }
 
-int launch_fused_b(const FusedArgs &a, int G, hipStream_t st)
+int launch_fused_b(const FusedArgs &a, int G, int R, hipStream_t st)
 {
   if (a.nlist <= 0) return 0;
-  return G == 16 ? launch_b_t<16, 1>(a, st) : G == 32 ? launch_b_t<32, 1>(a, st) : launch_b_t<64, 1>(a, st);
+#define X(g, r) if (G == g && R == r) return launch_b_t<g, r>(a, st);
+  ELECTOR_FUSED_CLASSES(X)
+#undef X
+  return -2;
 }
 
 }  // namespace elector

@@ -40,9 +40,11 @@ struct FusedArgs {
   int32_t *rowinit;
   int debug;
   int keep_map;
+  uint8_t *mv_pool;
+  int mv_tw, mv_ns;
 };
-int launch_fused_a(const FusedArgs &a, int G, hipStream_t st);
-int launch_fused_b(const FusedArgs &a, int G, hipStream_t st);
+int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
+int launch_fused_b(const FusedArgs &a, int G, int R, hipStream_t st);
 struct LaneArgs {
   BatchArgs b;
   const uint32_t *list;
@@ -301,10 +303,13 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit, &c->d_lanemeta,
-                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo};
+                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv};
   for (DevBuf *b : bufs) b->release();
   for (auto &s : c->st_slot) s.release();
-  c->h_meta.release();
+  for (int k = 0; k < 2; ++k) {
+    c->h_meta_buf[k].release();
+    if (c->h_meta_done[k]) (void)hipEventDestroy(c->h_meta_done[k]);
+  }
   if (c->aux_ready) {
     for (int k = 0; k < elector_ctx::kAux; ++k) { (void)hipStreamDestroy(c->aux[k]); (void)hipEventDestroy(c->aux_done[k]); }
     (void)hipEventDestroy(c->fork);
@@ -383,13 +388,33 @@ extern "C" int elector_ctx_last_po_sizes(elector_ctx *c, int64_t n, int32_t *po_
 static const int64_t kMovesBudgetDwords = (int64_t)3 << 28;   // 3 GiB
 static const int64_t kBumpBudgetDwords = (int64_t)1 << 28;    // 1 GiB
 
-// fused-kernel launch classes: (lanes per window, LDS slot bytes per window)
-static const int kBins = 28;
-static const int kBinG[kBins] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32,
-                                 64, 64, 64, 64, 64, 64, 64, 64, 64};
-static const int kSlot[kBins] = {1536, 2048, 2560, 3072, 3584, 4096, 5120, 6144, 8192,
-                                 3072, 4096, 5120, 6144, 7168, 8192, 10240, 12288, 16384, 24576,
-                                 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 131072};
+// fused-kernel geometry classes: G lanes per window x R rows per lane, ordered by the rows one
+// strip holds (must match ELECTOR_FUSED_CLASSES in poa_fused.hip).  A window goes to the first
+// class whose strip is at least as tall as its longer read, so few lanes idle.
+static const int kNC = 17;
+static const int kClsG[kNC] = {8, 8, 8, 8, 8, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64};
+static const int kClsR[kNC] = {4, 5, 6, 7, 8, 5, 6, 7, 8, 5, 6, 7, 8, 5, 6, 7, 8};
+// LDS slot sizes (bytes per window): a launch bin is (geometry class, slot tier)
+static const int kNT = 61;
+static int g_tier_bytes[kNT];
+static void build_tiers()
+{
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int k = 0, v = 512;
+    auto run = [&](int step, int upto) { for (; v <= upto; v += step) g_tier_bytes[k++] = v; };
+    run(128, 2048); run(256, 4096); run(512, 8192); run(1024, 16384); run(2048, 32768); run(4096, 65536); run(8192, 131072);
+  });
+}
+static const int kBins = kNC * kNT;
+// a bin with fewer windows than this joins the next larger populated slot tier of its class
+static const int64_t kMinBinWindows = 4096;
+// largest slot a class can give each of its 64/G windows (k_fused_b: 64 B table + one score ring per wave)
+static int class_max_slot(int ci)
+{
+  const int nw = 64 / kClsG[ci];
+  return ((160 * 1024 - 256 - 64 - fused_ring_bytes(kClsR[ci])) / nw) & ~127;
+}
 
 // lane-per-window classes: reference length cap (columns of alignment #1) and node cap of
 // alignment #2 (|PO| is usually a few percent above Lr; larger graphs are handed back)
@@ -421,9 +446,15 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const bool host_prof = std::getenv("ELECTOR_DEBUG_HOST") != nullptr;
   auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
   const double tp0 = now_ms();
-  int rc = c->h_meta.ensure((size_t)n * (4 + 8 + 8 + 4 + 4) + 64);
+  c->h_meta_cur ^= 1;
+  elector::HostPinned &h_meta = c->h_meta_buf[c->h_meta_cur];
+  hipEvent_t &h_done = c->h_meta_done[c->h_meta_cur];
+  if (!h_done) HIPCHK(c, hipEventCreateWithFlags(&h_done, hipEventDisableTiming));
+  else HIPCHK(c, hipEventSynchronize(h_done));                     // the copies of the batch before last have run
+  int rc = h_meta.ensure((size_t)n * (4 + 8 + 8 + 4 + 4) + (size_t)(3 * n + 1) * 8 + 64);
   if (rc) return fail(c, rc, "pinned metadata");
-  int32_t *h_status = c->h_meta.as<int32_t>();
+  int64_t *h_off = h_meta.as<int64_t>();                           // copy of off[]: the caller's array may be pageable
+  int32_t *h_status = reinterpret_cast<int32_t *>(h_off + 3 * n + 1);
   int64_t *h_mv1 = reinterpret_cast<int64_t *>(h_status + n + (n & 1));
   int64_t *h_mv2 = h_mv1 + n;
   uint32_t *h_generic = reinterpret_cast<uint32_t *>(h_mv2 + n);   // generic-path windows, processing order
@@ -431,32 +462,38 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
 
   // window sizes -> status, coarse size key (counting sort, largest first), launch class
   constexpr int NB = 256;
-  std::vector<int8_t> bin((size_t)n, -1);
+  build_tiers();
+  std::vector<int16_t> bin((size_t)n, -1);
   std::vector<int8_t> lcls((size_t)n, -1);
   // lane-per-window kernels: experimental, slower than the fused kernels at present
   const bool use_lane = use_fused && !c->keep_graph && std::getenv("ELECTOR_LANE") != nullptr;
-  int64_t key_cnt[NB + 1] = {0}, bin_cnt[kBins] = {0}, n_generic = 0, lane_cnt[kLaneClasses] = {0}, bin_need_a[kBins] = {0};
+  int64_t key_cnt[NB + 1] = {0}, n_generic = 0, lane_cnt[kLaneClasses] = {0};
+  std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)5 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc
+  int64_t *bin_max_lr = bin_need_a.data() + kBins, *bin_max_lc = bin_max_lr + kBins, *bin_max_lu = bin_max_lc + kBins,
+          *bin_max_po = bin_max_lu + kBins;
+  const int maxpen = std::max(std::max(std::abs(c->kp.mismatch), std::abs(c->kp.match)),
+                              std::max(std::max(c->kp.open_x, c->kp.open_y), std::max(c->kp.ext_x, c->kp.ext_y)));
+  int cls_max_slot[kNC];
+  for (int ci = 0; ci < kNC; ++ci) cls_max_slot[ci] = class_max_slot(ci);
+  // testing knob: every window into one geometry class (multi-strip paths of the small classes)
+  const int force_cls = std::getenv("ELECTOR_FORCE_CLASS") ? std::atoi(std::getenv("ELECTOR_FORCE_CLASS")) : -1;
   auto key = [&](int64_t w) {
     const int64_t m = std::max(off[3 * w + 1] - off[3 * w], off[3 * w + 3] - off[3 * w + 2]);
     int k = (int)(m >> 3);
     if (k >= NB) k = NB - 1;
     return NB - 1 - k;
   };
-  // first slot class of each group size in kBinG/kSlot
-  int g_first[3] = {kBins, kBins, kBins}, g_end[3] = {0, 0, 0};
-  for (int b = 0; b < kBins; ++b) {
-    const int gi = kBinG[b] == 16 ? 0 : kBinG[b] == 32 ? 1 : 2;
-    g_first[gi] = std::min(g_first[gi], b);
-    g_end[gi] = b + 1;
-  }
   std::vector<uint8_t> wkey((size_t)n);
   std::atomic<int> bad_offsets(0);
   {
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
-    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + kLaneClasses + 1 + kBins, 0));
+    // per thread: size keys, bin counts, lane classes, generic count, then per bin the maxima of
+    // alignment #1's slot need, Lr, Lc, Lu and Lr + Lc (the bound on |PO|)
+    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + kLaneClasses + 1 + 5 * kBins, 0));
     auto work = [&](int t) {
       const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
       int64_t *cnt = tcnt[(size_t)t].data();
+      std::memcpy(h_off + 3 * w0, off + 3 * w0, (size_t)(3 * (w1 - w0) + (w1 == n ? 1 : 0)) * 8);
       for (int64_t w = w0; w < w1; ++w) {
         const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
                       lu = off[3 * w + 3] - off[3 * w + 2];
@@ -473,17 +510,33 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           // one class for both fused kernels; |PO| is not known yet: typical growth estimate, windows
           // whose graph turns out larger are handed back by the device (k_left_b)
           const int rows = (int)std::max(lc, lu);
-          for (int gi = rows <= 64 ? 0 : rows <= 128 ? 1 : 2; gi < 3 && bin[(size_t)w] < 0; ++gi) {
-            const int G = 16 << gi;
-            const int need_a = fused_a_slot_need((int)lr, (int)lc, G);
-            const int need = std::max(need_a, fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G));
-            for (int b = g_first[gi]; b < g_end[gi]; ++b)
-              if (need <= kSlot[b]) {
-                bin[(size_t)w] = (int8_t)b;
-                int64_t &mx = cnt[NB + kBins + kLaneClasses + 1 + b];      // alignment #1 needs less than the class slot
-                mx = std::max<int64_t>(mx, need_a);
-                break;
-              }
+          int c0 = 0;
+          while (c0 < kNC - 1 && kClsG[c0] * kClsR[c0] < rows) ++c0;
+          if (force_cls >= 0 && force_cls < kNC) c0 = force_cls;
+          for (int ci = c0; ci < kNC && bin[(size_t)w] < 0; ++ci) {
+            const int G = kClsG[ci], R = kClsR[ci];
+            // k_fused_b's 16-bit ring cells hold scores up to about +-16000 (it hands larger windows back)
+            if ((int64_t)maxpen * (lr + lr / 16 + 6 + lu + 4) >= 16000) break;
+            const int need_a = fused_a_slot_need((int)lr, (int)lc, G, R);
+            const int need = std::max(need_a, fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G, R));
+            if (need > cls_max_slot[ci]) {
+              if (force_cls >= 0) break;
+              continue;                                                    // a class with fewer windows per wave has larger slots
+            }
+            const int t = (int)(std::lower_bound(g_tier_bytes, g_tier_bytes + kNT, need) - g_tier_bytes);
+            if (t >= kNT) break;
+            if (g_tier_bytes[t] > cls_max_slot[ci]) {
+              if (force_cls >= 0) break;
+              continue;
+            }
+            const int b = ci * kNT + t;
+            bin[(size_t)w] = (int16_t)b;
+            int64_t *mx = cnt + NB + kBins + kLaneClasses + 1 + b;         // alignment #1 needs less than the class slot
+            mx[0] = std::max<int64_t>(mx[0], need_a);
+            mx[kBins] = std::max<int64_t>(mx[kBins], lr);
+            mx[2 * kBins] = std::max<int64_t>(mx[2 * kBins], lc);
+            mx[3 * kBins] = std::max<int64_t>(mx[3 * kBins], lu);
+            mx[4 * kBins] = std::max<int64_t>(mx[4 * kBins], lr + lc);
           }
         }
         if (bin[(size_t)w] >= 0) cnt[NB + bin[(size_t)w]]++;
@@ -504,25 +557,43 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       for (int b = 0; b < kBins; ++b) bin_cnt[b] += tcnt[(size_t)t][(size_t)(NB + b)];
       for (int k = 0; k < kLaneClasses; ++k) lane_cnt[k] += tcnt[(size_t)t][(size_t)(NB + kBins + k)];
       n_generic += tcnt[(size_t)t][(size_t)(NB + kBins + kLaneClasses)];
-      for (int b = 0; b < kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + kLaneClasses + 1 + b)]);
+      for (int b = 0; b < 5 * kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + kLaneClasses + 1 + b)]);
     }
   }
   if (bad_offsets.load()) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
   const double tp1 = now_ms();
   for (int k = 0; k < NB; ++k) key_cnt[k + 1] += key_cnt[k];
   // stable placement in descending size order, per destination list
-  int64_t bin_first[kBins + 1];
+  // sparse bins join the next larger populated slot tier of their class (a larger slot always fits);
+  // the class's largest populated tier keeps whatever it has
+  std::vector<int16_t> bin_final((size_t)kBins);
+  for (int ci = 0; ci < kNC; ++ci) {
+    int into = -1;                                     // nearest larger tier that stays a launch
+    for (int t = kNT - 1; t >= 0; --t) {
+      const int b = ci * kNT + t;
+      bin_final[(size_t)b] = (int16_t)b;
+      if (!bin_cnt[(size_t)b]) continue;
+      if (into >= 0 && bin_cnt[(size_t)b] < kMinBinWindows && g_tier_bytes[into % kNT] <= cls_max_slot[ci]) {
+        bin_cnt[(size_t)into] += bin_cnt[(size_t)b];
+        for (int q = 0; q < 5; ++q)
+          bin_need_a[(size_t)(q * kBins + into)] = std::max(bin_need_a[(size_t)(q * kBins + into)], bin_need_a[(size_t)(q * kBins + b)]);
+        bin_cnt[(size_t)b] = 0;
+        bin_final[(size_t)b] = (int16_t)into;
+      } else into = b;
+    }
+  }
+  std::vector<int64_t> bin_first((size_t)kBins + 1);
   bin_first[0] = 0;
-  for (int b = 0; b < kBins; ++b) bin_first[b + 1] = bin_first[b] + bin_cnt[b];
+  for (int b = 0; b < kBins; ++b) bin_first[(size_t)b + 1] = bin_first[(size_t)b] + bin_cnt[(size_t)b];
   {
     std::vector<uint32_t> order((size_t)n);
     for (int64_t w = 0; w < n; ++w) order[(size_t)key_cnt[wkey[(size_t)w]]++] = (uint32_t)w;
-    int64_t pos[kBins], gpos = 0;
-    for (int b = 0; b < kBins; ++b) pos[b] = bin_first[b];
+    std::vector<int64_t> pos(bin_first.begin(), bin_first.end() - 1);
+    int64_t gpos = 0;
     for (int64_t k = 0; k < n; ++k) {
       const uint32_t w = order[(size_t)k];
       const int b = bin[w];
-      if (b >= 0) h_list[pos[b]++] = w;
+      if (b >= 0) h_list[pos[(size_t)bin_final[(size_t)b]]++] = w;
       else if (lcls[w] < 0) h_generic[gpos++] = w;
     }
   }
@@ -572,7 +643,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   }
   if (std::getenv("ELECTOR_DEBUG_BINS")) {
     std::fprintf(stderr, "[elector] n=%lld generic=%lld classes:", (long long)n, (long long)n_generic);
-    for (int b = 0; b < kBins; ++b) std::fprintf(stderr, " G%d/%d:%lld", kBinG[b], kSlot[b], (long long)bin_cnt[b]);
+    for (int b = 0; b < kBins; ++b)
+      if (bin_cnt[(size_t)b])
+        std::fprintf(stderr, " G%dxR%d/%d:%lld", kClsG[b / kNT], kClsR[b / kNT], g_tier_bytes[b % kNT], (long long)bin_cnt[(size_t)b]);
     for (int k = 0; k < kLaneClasses; ++k) std::fprintf(stderr, " L%d:%lld", kLaneCapA[k], (long long)lane_cnt[k]);
     std::fprintf(stderr, " lane scratch %.1f MB\n", lane_dwords * 4e-6);
   }
@@ -599,7 +672,28 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   }
   int64_t max_dwords = 0;
   for (auto &ch : chunks) max_dwords = std::max(max_dwords, ch.dwords);
-  const int64_t bump_dwords = use_fused ? std::min<int64_t>(kBumpBudgetDwords, 64 + 16 * (total + 64 * n)) : 0;
+  const int64_t bump_dwords = use_fused ? std::min<int64_t>(kBumpBudgetDwords, ((int64_t)1 << 24) + 16 * (total + 64 * n)) : 0;
+
+  // moves scratch of the fused kernels: launches on one stream run one after the other and the moves
+  // of a launch die with it, so every stream owns one region as large as its largest launch needs
+  // ([block][strips][steps][64 lanes] words; strips and steps from the bin's maxima)
+  int64_t fmv_stream[4] = {0, 0, 0, 0};
+  auto fmv_geom = [&](int b, bool second, int *tw, int *ns) {
+    const int G = kClsG[b / kNT], R = kClsR[b / kNT];
+    *tw = (int)(second ? bin_max_po[b] : bin_max_lr[b]) + G;
+    *ns = (int)(((second ? bin_max_lu[b] : bin_max_lc[b]) + G * R - 1) / (G * R));
+    const int64_t blocks = (bin_cnt[(size_t)b] + 64 / G - 1) / (64 / G);
+    return blocks * *ns * *tw * 64 * fused_mv_bytes(R);
+  };
+  auto stream_of = [&](int b) { const int G = kClsG[b / kNT]; return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };
+  if (use_fused)
+    for (int b = 0; b < kBins; ++b) {
+      if (!bin_cnt[(size_t)b]) continue;
+      int tw, ns;
+      int64_t &r = fmv_stream[stream_of(b)];
+      r = std::max(r, std::max(fmv_geom(b, false, &tw, &ns), fmv_geom(b, true, &tw, &ns)));
+    }
+  for (int k = 0; k < 4; ++k) fmv_stream[k] = (fmv_stream[k] + 255) & ~(int64_t)255;
 
   // ---- workspace ----
   const size_t nodes = (size_t)total + (size_t)n + 8;
@@ -610,7 +704,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
        c->d_lanemeta.ensure(lane_dims.size() * 4 + lane_mvoff_a.size() * 16 + 64) | c->d_n1.ensure((size_t)n * 4) |
        c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
        c->d_bx2.ensure((size_t)n * 4) | c->d_list.ensure((size_t)2 * n * 4 + 64) | c->d_done.ensure((size_t)2 * n + 64) |
-       c->d_rowinit.ensure(4096);
+       c->d_rowinit.ensure(1024 + 256 * (size_t)kBins) |
+       c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256);
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
   if (use_fused && (rc = ensure_streams(c))) return fail(c, rc, "auxiliary streams");
 
@@ -622,7 +717,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n;
   // device counters: [0] = leftover count (int32), [2..3] = bump allocator (u64)
   int32_t *d_counters = reinterpret_cast<int32_t *>(c->d_rowinit.p);
-  HIPCHK(c, hipMemcpyAsync(c->d_off.p, off, (size_t)(3 * n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_off.p, h_off, (size_t)(3 * n + 1) * 8, hipMemcpyHostToDevice, st));
   if (n_generic) HIPCHK(c, hipMemcpyAsync(d_generic, h_generic, (size_t)n_generic * 4, hipMemcpyHostToDevice, st));
   if (n - n_generic) HIPCHK(c, hipMemcpyAsync(d_lists, h_list, (size_t)(n - n_generic) * 4, hipMemcpyHostToDevice, st));
   const size_t nblk = lane_mvoff_a.size();
@@ -640,9 +735,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemcpyAsync(c->d_mv1.p, h_mv1, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipEventRecord(h_done, st));
   HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)2 * n, st));
   HIPCHK(c, hipMemsetAsync(d_counters, 0, 16, st));
-  if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 3072, st));
+  if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 256 * (size_t)kBins, st));
 
   const double tp4 = now_ms();
   if (host_prof)
@@ -710,25 +806,31 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     used = std::max(used, 4);
     for (int k = 0; k < 4; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
     for (int b = kBins - 1; b >= 0; --b) {          // within a chain: big classes first
-      if (!bin_cnt[b]) continue;
-      hipStream_t sx = c->aux[kBinG[b] == 64 ? 0 : kBinG[b] == 32 ? 1 : 2];
+      if (!bin_cnt[(size_t)b]) continue;
+      const int bG = kClsG[b / kNT], bR = kClsR[b / kNT], bslot = g_tier_bytes[b % kNT];
+      const int sk = stream_of(b);
+      hipStream_t sx = c->aux[sk];
       FusedArgs fa;
       fa.b = a;
-      fa.list = d_lists + bin_first[b];
-      fa.nlist = bin_cnt[b];
-      fa.slot_bytes = kSlot[b];
+      fa.list = d_lists + bin_first[(size_t)b];
+      fa.nlist = bin_cnt[(size_t)b];
+      fa.slot_bytes = bslot;
       fa.done_a = d_done_a;
       fa.done_b = d_done_b;
       fa.rowinit = reinterpret_cast<int32_t *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b);   // phase stamps (debug)
       fa.debug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
       fa.keep_map = c->keep_graph ? 1 : 0;
-      fa.slot_bytes = (int)((bin_need_a[b] + 127) & ~(int64_t)127);   // alignment #1: the class's own maximum
+      fa.slot_bytes = (int)((bin_need_a[(size_t)b] + 127) & ~(int64_t)127);   // alignment #1: the bin's own maximum
+      fa.mv_pool = c->d_fmv.as<uint8_t>();
+      for (int k = 0; k < sk; ++k) fa.mv_pool += fmv_stream[k];
+      (void)fmv_geom(b, false, &fa.mv_tw, &fa.mv_ns);
       timed_begin(c, 0, sx);
-      if (launch_fused_a(fa, kBinG[b], sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+      if (launch_fused_a(fa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
       timed_end(c, sx);
-      fa.slot_bytes = kSlot[b];
+      fa.slot_bytes = bslot;
+      (void)fmv_geom(b, true, &fa.mv_tw, &fa.mv_ns);
       timed_begin(c, 1, sx);
-      if (launch_fused_b(fa, kBinG[b], sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+      if (launch_fused_b(fa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
       timed_end(c, sx);
     }
     for (int k = 0; k < std::min(used, (int)elector_ctx::kAux); ++k) {
@@ -803,13 +905,13 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     int32_t hc[4];
     (void)hipMemcpy(hc, c->d_rowinit.p, sizeof hc, hipMemcpyDeviceToHost);
     std::fprintf(stderr, "[elector] windows handed back to the generic alignment #2: %d\n", hc[0]);
-    unsigned long long hs[384];
-    (void)hipMemcpy(hs, c->d_rowinit.as<uint8_t>() + 1024, sizeof hs, hipMemcpyDeviceToHost);
-    for (int b = 0; b < 12; ++b) {
-      const unsigned long long *p = hs + 32 * b;
+    std::vector<unsigned long long> hs((size_t)32 * kBins);
+    (void)hipMemcpy(hs.data(), c->d_rowinit.as<uint8_t>() + 1024, hs.size() * 8, hipMemcpyDeviceToHost);
+    for (int b = 0; b < kBins; ++b) {
+      const unsigned long long *p = hs.data() + 32 * (size_t)b;
       if (!p[4]) continue;
-      std::fprintf(stderr, "[elector] class %d G%d/%d  A waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f | B waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f  (cycles per wave)\n",
-                   b, kBinG[b], kSlot[b], p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[5] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],
+      std::fprintf(stderr, "[elector] bin G%dxR%d/%d  A waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f | B waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f  (cycles per wave)\n",
+                   kClsG[b / kNT], kClsR[b / kNT], g_tier_bytes[b % kNT], p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[5] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],
                    p[12], p[12] ? (double)p[8] / p[12] : 0, p[12] ? (double)p[9] / p[12] : 0, p[12] ? (double)p[13] / p[12] : 0,
                    p[12] ? (double)p[10] / p[12] : 0, p[12] ? (double)p[11] / p[12] : 0);
     }

@@ -1,0 +1,13 @@
+TAG=${1:-pmcsq}
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/$TAG
+CMD="python3 bench.py --no-cpu-baseline --steps 3 --warmup 1"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/$TAG/p3 -- $CMD > gpurun_out/$TAG/p3.log 2>&1
+python3 tests/_pmc_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.json
+python3 - gpurun_out/$TAG/summary.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k in ("k_fused_a","k_fused_b"):
+    v=d[k]; print(k, {c: "%.4g"%x["total"] for c,x in v.items()}, "launches", v["SQ_WAVES"]["launches"])
+PY
+find gpurun_out/$TAG -name "*kernel_trace.csv" -delete; find gpurun_out/$TAG -name "*counter_collection.csv" -size +20M -delete

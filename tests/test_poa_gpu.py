@@ -116,3 +116,12 @@ def test_round_trip_property_large(engine):
         assert r1.replace(b".", b"") == b[off[3 * w + 1]:off[3 * w + 2]]
         assert r2.replace(b".", b"") == b[off[3 * w + 2]:off[3 * w + 3]]
         assert all(not (x == 46 and y == 46 and z == 46) for x, y, z in zip(r0, r1, r2))
+
+
+@pytest.mark.parametrize("cls", list(range(17)))
+def test_every_geometry_class(engine, cls, monkeypatch):
+    """Each (lanes per window, rows per lane) instantiation of the fused kernels on windows of every
+    size (ELECTOR_FORCE_CLASS routes all windows that fit its LDS slots to one class): the small
+    classes then run many strips per window, the big ones mostly idle lanes."""
+    monkeypatch.setenv("ELECTOR_FORCE_CLASS", str(cls))
+    check(engine, synth.window_triples(100 + cls, 500, 5, 420) + synth.adversarial_triples(200 + cls, 300))
