@@ -139,9 +139,7 @@ __host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G, int R)
   return o + (ob > st ? ob : st);
 }
 
-// bytes of one wave's score ring in k_fused_b: kFusedRingSlots time slots x 64 lanes x R 16-bit cells
-constexpr int kFusedRingDepth = 8;        // time slots
-constexpr int kFusedRingSlots = 8;
-__host__ __device__ inline int fused_ring_bytes(int R) { return kFusedRingSlots * 64 * 4 * ((R + 1) / 2); }
+// bytes of one wave's score ring in k_fused_b: D time slots x 64 lanes x R 16-bit cells
+__host__ __device__ inline int fused_ring_bytes(int R, int D) { return D * 64 * 4 * ((R + 1) / 2); }
 
 }  // namespace elector

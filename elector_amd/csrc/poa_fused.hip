@@ -65,6 +65,16 @@ __device__ __forceinline__ int shift_in(int border, int v, int g)
 
 __device__ __forceinline__ int align_up(int x, int a) { return (x + a - 1) & ~(a - 1); }
 
+// number of leading lanes of this lane's group of G (group index q) whose flag is set
+template <int G>
+__device__ __forceinline__ int diag_run(bool flag, int q)
+{
+  const unsigned long long bm = __builtin_amdgcn_ballot_w64(flag);
+  if (G == 64) return ~bm == 0ull ? 64 : __builtin_ctzll(~bm);
+  const unsigned long long gm = (bm >> (q * G)) & ((1ull << (G & 63)) - 1);
+  return __builtin_ctzll(~gm | (1ull << (G & 63)));
+}
+
 // phase stamps for the timing-experiment build path (debug bit 2): cycles per phase
 // summed over waves into a scratch array that nothing else reads
 #define PHASE_STAMP(idx)                                                                          \
@@ -239,19 +249,37 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
 
   PHASE_STAMP(1);
   bool bad = false;
-  // ---- traceback #1 (align_lpo_po2.c:108-168): the first lane of the window's group ----
-  if (valid && g == 0 && !(a.debug & 2)) {
+  // ---- traceback #1 (align_lpo_po2.c:108-168), G cells per round: lane g fetches the move of cell
+  // (x - g, y - g); as long as those are matches the walk stays on this diagonal and the lanes record
+  // their aligned pairs together; the first cell off the diagonal decides where the next round starts.
+  // The moves come from HBM: one memory latency per round instead of one per cell. ----
+  {
     int x = Lr - 1, y = Lc - 1, guard = Lr + Lc + 2;
-    while (x >= 0 && y >= 0 && guard-- > 0) {
-      const int r = y % RS, rl = r / R, rk = r - rl * R;
-      const uint32_t word = kMvLds ? (uint32_t)mvl[((y / RS) * Lr + x) * G + rl]
-                                   : (uint32_t)mvg[((y / RS) * mvtw + (x + 1 + rl)) * 64 + q * G + rl];
-      const uint32_t two = (word >> (2 * rk)) & 3u;
+    bool alive = valid && !(a.debug & 2);
+    while (__builtin_amdgcn_ballot_w64(alive) != 0) {
+      const int cx = x - g, cy = y - g;
+      const bool inb = alive && cx >= 0 && cy >= 0;
+      uint32_t two = 0;
+      if (inb) {
+        const int r = cy % RS, rl = r / R, rk = r - rl * R;
+        const uint32_t word = kMvLds ? (uint32_t)mvl[((cy / RS) * Lr + cx) * G + rl]
+                                     : (uint32_t)mvg[((cy / RS) * mvtw + (cx + 1 + rl)) * 64 + q * G + rl];
+        two = (word >> (2 * rk)) & 3u;
+      }
       const int xo = two & 1, yo = two >> 1;
-      if (xo && yo) x2y[x] = (uint16_t)y;
-      if (!xo && !yo) { bad = true; break; }
-      x -= xo;
-      y -= yo;
+      const int run = diag_run<G>(inb && xo && yo, q);
+      if (g < run) x2y[cx] = (uint16_t)cy;
+      // what this lane's cell would do to the walk if it is the first one off the diagonal
+      const bool stop = !inb || (!xo && !yo);
+      int nx = cx - xo, ny = cy - yo, fl = (stop ? 1 : 0) | ((inb && !xo && !yo) ? 2 : 0);
+      const int src = min(run, G - 1);
+      nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
+      if (run >= G) { nx = x - G; ny = y - G; fl = 0; }
+      if (alive) {
+        x = nx; y = ny;
+        if (fl & 2) bad = true;
+        if ((fl & 1) || --guard <= 0) alive = false;
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -401,7 +429,9 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
   if (valid && g == 0) {
     a.b.n1[W.w] = n1;
     const int need = maxd + 2;
-    a.b.cls[W.w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 8 ? 0x80 : 0));   // bit 7: too deep for k_fused_b's ring
+    if (a.debug & 32) atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 16 + min(need, 15), 1ull);   // histogram (diagnostics)
+    // bits 0-1: ring class of the generic k_dp2; bit 6 / bit 7: too deep for k_fused_b's 4- / 8-deep ring
+    a.b.cls[W.w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 4 ? 0x40 : 0) | (need > 8 ? 0x80 : 0));
     if (need > 512) a.b.status[W.w] = 2;
     if (bad) a.b.status[W.w] = 3;
     a.done_a[W.w] = 1;
@@ -417,8 +447,9 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
 // lane's R cells of the last 8 steps as 16-bit (score << 1 | came-from-match), laid out
 // [slot][dword][lane] so that every access is bank-conflict free.
 
-constexpr int kRingDepth = kFusedRingDepth;   // time slots
-constexpr int kRingSlots = kFusedRingSlots;   // the virtual start column and "no predecessor" are computed, not stored
+// The ring depth D (time slots, a power of two) is a template parameter: a node's predecessors must
+// lie at most D - 2 nodes back.  Only D = 8 is instantiated: on well-corrected reads 99.8 % of the
+// windows would do with D = 4, but the smaller ring did not pay (see poa_host.hip).
 constexpr int kNeg16 = -16383;       // score of the "no predecessor" cells (below any 16-bit-eligible score)
 
 __device__ __forceinline__ int cell16_S(int c) { return c >> 1; }
@@ -484,7 +515,7 @@ struct WinB {
   int n1, Lu, ns, off_xi, off_r1, off_x2y, off_b0, off_b1, off_region;
 };
 
-template <int G, int R>
+template <int G, int R, int D>
 __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
 {
   constexpr int RS = R * G;
@@ -492,7 +523,8 @@ __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
   WinB v;
   v.valid = li < a.nlist;
   v.w = v.valid ? a.list[li] : 0;
-  v.valid = v.valid && a.b.status[v.w] == 0 && a.done_a[v.w] != 0 && a.b.cls[v.w] == 0;
+  v.valid = v.valid && a.b.status[v.w] == 0 && a.done_a[v.w] != 0 && a.done_b[v.w] == 0 &&
+            (a.b.cls[v.w] & (D >= 8 ? 0x83 : 0xC3)) == 0;
   v.o0 = 0; v.o2 = 0; v.n1 = 0; v.Lu = 0;
   if (v.valid) {
     v.o0 = a.b.off[3 * (int64_t)v.w];
@@ -514,26 +546,28 @@ __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
   return v;
 }
 
-template <int G, int R, int WV>
+template <int G, int R, int D, int WV>
 __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NW = 64 / G, RS = R * G;     // windows per wave, rows per strip
   constexpr int RW = (R + 1) / 2;                         // ring dwords per lane and slot
-  constexpr int kRingBytes = kRingSlots * 64 * 4 * RW;
+  constexpr int kRingDepth = D;
+  constexpr int kRingBytes = D * 64 * 4 * RW;
   using mv_t = typename MvWord<R>::type;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
   const int sidx = wv * NW + q;
-  const WinB W = load_win_b<G, R>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
+  const WinB W = load_win_b<G, R, D>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
   bool valid = W.valid;
+  if (WV == 1 && __builtin_amdgcn_ballot_w64(valid) == 0) return;       // nothing left for this wave
   const uint32_t w = W.w;
   const int64_t o0 = W.o0;
   const int n1 = W.n1, Lu = W.Lu, ns = W.ns;
   // LDS: [output characters 64 B][one score ring per wave][window slots]
   uint8_t *chr = lds;
   uint8_t *slot = lds + 64 + WV * kRingBytes + sidx * a.slot_bytes;
-  uint32_t *ring = reinterpret_cast<uint32_t *>(lds + 64 + wv * kRingBytes);   // this wave's [kRingSlots][RW][64] dwords = 2 cells of 16 bits
+  uint32_t *ring = reinterpret_cast<uint32_t *>(lds + 64 + wv * kRingBytes);   // this wave's [D][RW][64] dwords = 2 cells of 16 bits
   const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(ring);
   int32_t *hdr = reinterpret_cast<int32_t *>(slot);
   uint8_t *ys = slot + 16;
@@ -777,23 +811,39 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   uint8_t *cols_st = slot + W.off_region;                               // overlays the moves after the traceback
   uint16_t *col_y = reinterpret_cast<uint16_t *>(slot + W.off_region + align_up(3 * (n1 + Lu) + 8, 4));
   bool bad = false;
-  // ---- traceback #2 (align_lpo_po2.c:108-168): the first lane of the window's group ----
-  if (valid && g == 0 && !(a.debug & 2)) {
-    int x = hdr[3], y = Lu - 1, guard = n1 + Lu + 2;
-    while (x >= 0 && y >= 0 && guard-- > 0) {
-      const int r = y % RS, rl = r / R, rk = r - rl * R;
-      const uint32_t inf = xinfo[x + 1];
-      const uint32_t two = ((uint32_t)mv[((y / RS) * mvtw + (x + 1 + rl)) * 64 + q * G + rl] >> (2 * rk)) & 3u;
-      const int xo = two & 1, yo = two >> 1;
-      if (xo && yo) x2y[x] = (uint16_t)y;
-      if (!xo && !yo) { bad = true; break; }
-      if (xo) {
-        const int d2v = (inf >> 4) & 15;
-        const int sec = d2v ? (ordb[((inf >> 24) * ns + (y / RS)) * G + rl] >> rk) & 1 : 0;
-        const int dd = sec ? d2v : (int)(inf & 15);
-        x = (dd == 0 || dd == 15) ? -1 : x - dd;
+  // ---- traceback #2 (align_lpo_po2.c:108-168), G cells per round as in k_fused_a: a cell keeps the walk
+  // on its diagonal when it is a match whose chosen predecessor is the node right before it ----
+  {
+    int x = valid ? hdr[3] : -1, y = Lu - 1, guard = n1 + Lu + 2;
+    bool alive = valid && !(a.debug & 2);
+    while (__builtin_amdgcn_ballot_w64(alive) != 0) {
+      const int cx = x - g, cy = y - g;
+      const bool inb = alive && cx >= 0 && cy >= 0;
+      int xo = 0, yo = 0, px = cx;
+      if (inb) {
+        const int r = cy % RS, rl = r / R, rk = r - rl * R;
+        const uint32_t inf = xinfo[cx + 1];
+        const uint32_t two = ((uint32_t)mv[((cy / RS) * mvtw + (cx + 1 + rl)) * 64 + q * G + rl] >> (2 * rk)) & 3u;
+        xo = two & 1; yo = two >> 1;
+        if (xo) {
+          const int d2v = (inf >> 4) & 15;
+          const int sec = d2v ? (ordb[((inf >> 24) * ns + (cy / RS)) * G + rl] >> rk) & 1 : 0;
+          const int dd = sec ? d2v : (int)(inf & 15);
+          px = (dd == 0 || dd == 15) ? -1 : cx - dd;
+        }
       }
-      if (yo) --y;
+      const int run = diag_run<G>(inb && xo && yo && px == cx - 1, q);
+      if (inb && xo && yo && g <= run) x2y[cx] = (uint16_t)cy;      // the run's pairs, and the breaker's if it is a match
+      const bool stop = !inb || (!xo && !yo);
+      int nx = px, ny = cy - yo, fl = (stop ? 1 : 0) | ((inb && !xo && !yo) ? 2 : 0);
+      const int src = min(run, G - 1);
+      nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
+      if (run >= G) { nx = x - G; ny = y - G; fl = 0; }
+      if (alive) {
+        x = nx; y = ny;
+        if (fl & 2) bad = true;
+        if ((fl & 1) || --guard <= 0) alive = false;
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -943,19 +993,19 @@ static int launch_a_t(const FusedArgs &a, hipStream_t st)
   return 0;
 }
 
-template <int G, int R>
+template <int G, int R, int D>
 static int launch_b_t(const FusedArgs &a, hipStream_t st)
 {
   constexpr int NB = 64 / G;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_b<G, R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_b<G, R, D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
     attr = true;
   }
-  hipLaunchKernelGGL((k_fused_b<G, R, 1>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64),
-                     64 + NB * a.slot_bytes + fused_ring_bytes(R), st, a);
+  hipLaunchKernelGGL((k_fused_b<G, R, D, 1>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64),
+                     64 + NB * a.slot_bytes + fused_ring_bytes(R, D), st, a);
   return 0;
 }
 
@@ -973,10 +1023,10 @@ int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st)
   return -2;
 }
 
-int launch_fused_b(const FusedArgs &a, int G, int R, hipStream_t st)
+int launch_fused_b(const FusedArgs &a, int G, int R, int D, hipStream_t st)
 {
   if (a.nlist <= 0) return 0;
-#define X(g, r) if (G == g && R == r) return launch_b_t<g, r>(a, st);
+#define X(g, r) if (G == g && R == r && D == 8) return launch_b_t<g, r, 8>(a, st);
   ELECTOR_FUSED_CLASSES(X)
 #undef X
   return -2;

@@ -44,7 +44,7 @@ struct FusedArgs {
   int mv_tw, mv_ns;
 };
 int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
-int launch_fused_b(const FusedArgs &a, int G, int R, hipStream_t st);
+int launch_fused_b(const FusedArgs &a, int G, int R, int D, hipStream_t st);
 struct LaneArgs {
   BatchArgs b;
   const uint32_t *list;
@@ -413,7 +413,7 @@ static const int64_t kMinBinWindows = 4096;
 static int class_max_slot(int ci)
 {
   const int nw = 64 / kClsG[ci];
-  return ((160 * 1024 - 256 - 64 - fused_ring_bytes(kClsR[ci])) / nw) & ~127;
+  return ((160 * 1024 - 256 - 64 - fused_ring_bytes(kClsR[ci], 8)) / nw) & ~127;
 }
 
 // lane-per-window classes: reference length cap (columns of alignment #1) and node cap of
@@ -830,7 +830,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       fa.slot_bytes = bslot;
       (void)fmv_geom(b, true, &fa.mv_tw, &fa.mv_ns);
       timed_begin(c, 1, sx);
-      if (launch_fused_b(fa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+      // Ring depth 8.  (Measured: a 4-deep ring for the 99.8 % of windows that need no more, followed by
+      // a second launch for the rest, raises the occupancy but not the throughput, and the second launch
+      // costs more than it saves.)
+      if (launch_fused_b(fa, bG, bR, 8, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
       timed_end(c, sx);
     }
     for (int k = 0; k < std::min(used, (int)elector_ctx::kAux); ++k) {
@@ -907,6 +910,13 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     std::fprintf(stderr, "[elector] windows handed back to the generic alignment #2: %d\n", hc[0]);
     std::vector<unsigned long long> hs((size_t)32 * kBins);
     (void)hipMemcpy(hs.data(), c->d_rowinit.as<uint8_t>() + 1024, hs.size() * 8, hipMemcpyDeviceToHost);
+    {
+      unsigned long long hist[16] = {0};
+      for (int b = 0; b < kBins; ++b) for (int k = 0; k < 16; ++k) hist[k] += hs[32 * (size_t)b + 16 + k];
+      std::fprintf(stderr, "[elector] ring depth needed (max predecessor distance + 2), windows:");
+      for (int k = 0; k < 16; ++k) std::fprintf(stderr, " %d:%llu", k, hist[k]);
+      std::fprintf(stderr, "\n");
+    }
     for (int b = 0; b < kBins; ++b) {
       const unsigned long long *p = hs.data() + 32 * (size_t)b;
       if (!p[4]) continue;

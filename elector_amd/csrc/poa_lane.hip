@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) k_lane_b(LaneArgs a)
   const int64_t li = 64 * (int64_t)blockIdx.x + lane;
   bool valid = li < a.nlist;
   const uint32_t w = valid ? a.list[li] : 0;
-  valid = valid && a.b.status[w] == 0 && a.done_a[w] != 0 && a.b.cls[w] == 0;   // cls bit 7: deeper than 14 nodes
+  valid = valid && a.b.status[w] == 0 && a.done_a[w] != 0 && (a.b.cls[w] & 0x83) == 0;   // cls bit 7: deeper than the ring
   int64_t o0 = 0, o2 = 0;
   int n1 = 0, Lu = 0;
   if (valid) {

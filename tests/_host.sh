@@ -1,3 +1,2 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python3 tests/_hostbench.py > gpurun_out/host.log 2>&1; tail -1 gpurun_out/host.log | cut -c1-300
-timeout -k 10 300 python3 tests/_hostbench.py > gpurun_out/host.log 2>&1; tail -1 gpurun_out/host.log | cut -c1-300
+for i in 1 2; do timeout -k 10 300 python3 tests/_hostbench.py > gpurun_out/host.log 2>&1; tail -1 gpurun_out/host.log | cut -c1-300; done
