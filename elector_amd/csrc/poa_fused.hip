@@ -23,6 +23,7 @@
 // :108-168 (traceback), lpo.c:413-463,602-656 (fusion), lpo_format.c:337-393 (rows).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "poa_device.h"
 
 namespace elector {
@@ -711,70 +712,81 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
       // function of the row (patched in below, rare); a missing second predecessor gets very
       // negative cells: no value selects. ----
       const bool virt1 = act && ppa == 0, virt2 = has2 && pp2 == 0;
-      const int sa = (t - (jj - ppa)) & (kRingDepth - 1);
-      const int sat = (t - (jj - ppa) - 1) & (kRingDepth - 1);
-      const int sb = (t - (jj - pp2)) & (kRingDepth - 1);
-      const int sbt = (t - (jj - pp2) - 1) & (kRingDepth - 1);
-      uint32_t c1[RW], c2[RW];
-#pragma unroll
-      for (int d = 0; d < RW; ++d) {
-        c1[d] = ring[(sa * RW + d) * 64 + lane];
-        c2[d] = ring[(sb * RW + d) * 64 + lane];
-      }
-      // the last cell of the lane above: dword (R-1)/2, half (R-1)&1 of its slot one step earlier
-      int r1 = (int16_t)ring16[((sat * RW + ((R - 1) >> 1)) * 64 + lm1) * 2 + ((R - 1) & 1)];
-      int r2 = (int16_t)ring16[((sbt * RW + ((R - 1) >> 1)) * 64 + lm1) * 2 + ((R - 1) & 1)];
-      if (__builtin_amdgcn_ballot_w64(virt1 || virt2) != 0) {
-        // column -1: row ii holds -(open_y + (ii - 1) ext_y), not a match; the row above this lane's first is ii0 - 1
-        const int above = (colS[0] + kp.ext_y) * 2;
+      const int xl = (xi >> 8) & 0xFF;
+      uint32_t mv8 = 0, sec4 = 0;
+      int nS[R], nM[R];
+      // One step of the lane's R cells.  TWO = some lane of the wave is at a node with two predecessors
+      // (about half of the steps on well-corrected reads); otherwise the second predecessor's loads,
+      // unpacking and comparisons are not even issued.
+      auto cells = [&](auto two_tag) {
+        constexpr bool TWO = decltype(two_tag)::value;
+        const int sa = (t - (jj - ppa)) & (kRingDepth - 1);
+        const int sat = (t - (jj - ppa) - 1) & (kRingDepth - 1);
+        const int sb = (t - (jj - pp2)) & (kRingDepth - 1);
+        const int sbt = (t - (jj - pp2) - 1) & (kRingDepth - 1);
+        uint32_t c1[RW], c2[RW];
 #pragma unroll
         for (int d = 0; d < RW; ++d) {
-          const uint32_t lo = (uint32_t)((colS[2 * d] * 2) & 0xFFFF);
-          const uint32_t hi = (2 * d + 1 < R) ? (uint32_t)((colS[(2 * d + 1 < R) ? 2 * d + 1 : 0] * 2) & 0xFFFF) : 0u;
-          if (virt1) c1[d] = lo | (hi << 16);
-          if (virt2) c2[d] = lo | (hi << 16);
+          c1[d] = ring[(sa * RW + d) * 64 + lane];
+          c2[d] = TWO ? ring[(sb * RW + d) * 64 + lane] : 0u;
         }
-        if (virt1) r1 = above;
-        if (virt2) r2 = above;
-      }
+        // the last cell of the lane above: dword (R-1)/2, half (R-1)&1 of its slot one step earlier
+        int r1 = (int16_t)ring16[((sat * RW + ((R - 1) >> 1)) * 64 + lm1) * 2 + ((R - 1) & 1)];
+        int r2 = TWO ? (int)(int16_t)ring16[((sbt * RW + ((R - 1) >> 1)) * 64 + lm1) * 2 + ((R - 1) & 1)] : 0;
+        if (__builtin_amdgcn_ballot_w64(virt1 || (TWO && virt2)) != 0) {
+          // column -1: row ii holds -(open_y + (ii - 1) ext_y), not a match; the row above this lane's first is ii0 - 1
+          const int above = (colS[0] + kp.ext_y) * 2;
+#pragma unroll
+          for (int d = 0; d < RW; ++d) {
+            const uint32_t lo = (uint32_t)((colS[2 * d] * 2) & 0xFFFF);
+            const uint32_t hi = (2 * d + 1 < R) ? (uint32_t)((colS[(2 * d + 1 < R) ? 2 * d + 1 : 0] * 2) & 0xFFFF) : 0u;
+            if (virt1) c1[d] = lo | (hi << 16);
+            if (TWO && virt2) c2[d] = lo | (hi << 16);
+          }
+          if (virt1) r1 = above;
+          if (TWO && virt2) r2 = above;
+        }
+        if (act) {
+          const int d1top = ((g == 0) ? b1 : r1) >> 1;
+          const int d2top = (TWO && has2) ? (((g == 0) ? b2 : r2) >> 1) : kNeg16;
+          int o1S[R], o1M[R], o2S[R], o2M[R];
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            const int e1 = (k & 1) ? (int)((int32_t)c1[k >> 1] >> 16) : (int)(int16_t)(c1[k >> 1] & 0xFFFF);
+            o1S[k] = e1 >> 1; o1M[k] = e1 & 1;
+            if (TWO) {
+              const int e2 = (k & 1) ? (int)((int32_t)c2[k >> 1] >> 16) : (int)(int16_t)(c2[k >> 1] & 0xFFFF);
+              o2S[k] = has2 ? e2 >> 1 : kNeg16; o2M[k] = has2 ? e2 & 1 : 0;
+            } else { o2S[k] = kNeg16; o2M[k] = 0; }
+          }
+          // ---- the lane's R cells, top to bottom ----
+          int insY = upEy, dt1 = d1top, dt2 = d2top;
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            const int cx1 = o1S[k] - (o1M[k] ? kp.open_x : kp.ext_x);
+            const int cx2 = TWO ? o2S[k] - (o2M[k] ? kp.open_x : kp.ext_x) : kNeg16;
+            const bool px2 = TWO && cx2 > cx1;                  // first maximum wins (:361-371)
+            const int insX = TWO ? max(cx1, cx2) : cx1;
+            const bool pm2 = TWO && dt2 > dt1;                  // (:348-357)
+            const int mat = (TWO ? max(dt1, dt2) : dt1) + (xl == yl[k] ? kp.match : kp.mismatch);
+            const int mx = max(insX, insY);
+            const bool m = mat > mx;
+            const bool xw = insX > insY;
+            const int Sn = max(mat, mx);
+            // 2 bits per cell: bit 0 = step along x, bit 1 = step along y; which of two predecessors
+            // was taken goes to the node's ordinal byte
+            mv8 |= (m ? 3u : (xw ? 1u : 2u)) << (2 * k);
+            if (TWO) sec4 |= ((m ? pm2 : px2) ? 1u : 0u) << k;
+            nS[k] = Sn; nM[k] = m ? 1 : 0;
+            insY = Sn - (m ? kp.open_y : kp.ext_y);
+            dt1 = o1S[k]; dt2 = o2S[k];
+            Ey[k] = insY;
+          }
+        }
+      };
+      if (__builtin_amdgcn_ballot_w64(has2) != 0) cells(std::true_type{});
+      else cells(std::false_type{});
       if (act) {
-        const int xl = (xi >> 8) & 0xFF;
-        const int d1top = ((g == 0) ? b1 : r1) >> 1;
-        const int d2top = has2 ? (((g == 0) ? b2 : r2) >> 1) : kNeg16;
-        int o1S[R], o1M[R], o2S[R], o2M[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          const int e1 = (k & 1) ? (int)((int32_t)c1[k >> 1] >> 16) : (int)(int16_t)(c1[k >> 1] & 0xFFFF);
-          const int e2 = (k & 1) ? (int)((int32_t)c2[k >> 1] >> 16) : (int)(int16_t)(c2[k >> 1] & 0xFFFF);
-          o1S[k] = e1 >> 1; o1M[k] = e1 & 1;
-          o2S[k] = has2 ? e2 >> 1 : kNeg16; o2M[k] = has2 ? e2 & 1 : 0;
-        }
-        // ---- the lane's R cells, top to bottom ----
-        int insY = upEy, dt1 = d1top, dt2 = d2top;
-        uint32_t mv8 = 0, sec4 = 0;
-        int nS[R], nM[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          const int cx1 = o1S[k] - (o1M[k] ? kp.open_x : kp.ext_x);
-          const int cx2 = o2S[k] - (o2M[k] ? kp.open_x : kp.ext_x);
-          const bool px2 = cx2 > cx1;                         // first maximum wins (:361-371)
-          const int insX = max(cx1, cx2);
-          const bool pm2 = dt2 > dt1;                         // (:348-357)
-          const int mat = max(dt1, dt2) + (xl == yl[k] ? kp.match : kp.mismatch);
-          const int mx = max(insX, insY);
-          const bool m = mat > mx;
-          const bool xw = insX > insY;
-          const int Sn = max(mat, mx);
-          // x-ordinal 1/2 (+ y-ordinal bit 2 on a match), or the lone y step
-          // 2 bits per cell: bit 0 = step along x, bit 1 = step along y; which of two predecessors
-          // was taken goes to the node's ordinal byte
-          mv8 |= (m ? 3u : (xw ? 1u : 2u)) << (2 * k);
-          sec4 |= ((m ? pm2 : px2) ? 1u : 0u) << k;
-          nS[k] = Sn; nM[k] = m ? 1 : 0;
-          insY = Sn - (m ? kp.open_y : kp.ext_y);
-          dt1 = o1S[k]; dt2 = o2S[k];
-          Ey[k] = insY;
-        }
 #pragma unroll
         for (int k = 0; k < R; ++k) { S[k] = nS[k]; M[k] = nM[k]; }
 #pragma unroll

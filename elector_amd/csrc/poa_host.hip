@@ -451,7 +451,14 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   hipEvent_t &h_done = c->h_meta_done[c->h_meta_cur];
   if (!h_done) HIPCHK(c, hipEventCreateWithFlags(&h_done, hipEventDisableTiming));
   else HIPCHK(c, hipEventSynchronize(h_done));                     // the copies of the batch before last have run
-  int rc = h_meta.ensure((size_t)n * (4 + 8 + 8 + 4 + 4) + (size_t)(3 * n + 1) * 8 + 64);
+  const size_t meta_bytes = (size_t)n * (4 + 8 + 8 + 4 + 4) + (size_t)(3 * n + 1) * 8 + 64;
+  int rc = h_meta.ensure(meta_bytes);
+  if (!rc && c->h_meta_buf[c->h_meta_cur ^ 1].cap < meta_bytes) {
+    // grow the other buffer now too (a pipelined caller's next batch must not pay for it); it may
+    // still feed pending copies, so wait for them first
+    if (c->h_meta_done[c->h_meta_cur ^ 1]) HIPCHK(c, hipEventSynchronize(c->h_meta_done[c->h_meta_cur ^ 1]));
+    rc = c->h_meta_buf[c->h_meta_cur ^ 1].ensure(meta_bytes);
+  }
   if (rc) return fail(c, rc, "pinned metadata");
   int64_t *h_off = h_meta.as<int64_t>();                           // copy of off[]: the caller's array may be pageable
   int32_t *h_status = reinterpret_cast<int32_t *>(h_off + 3 * n + 1);

@@ -650,12 +650,17 @@ extern "C" int elector_msa_stats_enqueue(elector_ctx *c, int64_t n_windows, cons
   s.last_piece = n_reads > 0 ? read_first[n_reads - 1] : 0;
   const int64_t total = s.total;            // bases of the batch: an upper bound of its MSA columns
   if (n_pieces > 0 && n_reads > 0) {
-    int rc = s.rows.ensure((size_t)3 * total + 64) | s.rowoff.ensure((size_t)(n_pieces + 1) * 8) |
-             s.cols.ensure((size_t)n_pieces * 8) | s.first.ensure((size_t)(n_reads + 1 + n_pieces + 1) * 8) |
-             s.cnt.ensure((size_t)n_pieces * ES_NCOUNTERS * 8) | s.mask.ensure((size_t)total + 64) |
-             s.woff.ensure((size_t)(n_windows + 1) * 4) | (clips ? s.clips.ensure((size_t)n_pieces * 8) : 0) |
-             s.h.ensure(16 + (size_t)n_pieces * (ES_NCOUNTERS + 1) * 8 + (size_t)(n_reads + n_pieces + 2) * 8 +
-                        (clips ? (size_t)n_pieces * 8 : 0));
+    // both slots grow together: the second job of a pipelined caller must not pay for allocations
+    int rc = 0;
+    for (int k = 0; k < elector_ctx::kStatsSlots; ++k) {
+      elector::StatsSlot &z = c->st_slot[k];
+      rc |= z.rows.ensure((size_t)3 * total + 64) | z.rowoff.ensure((size_t)(n_pieces + 1) * 8) |
+            z.cols.ensure((size_t)n_pieces * 8) | z.first.ensure((size_t)(n_reads + 1 + n_pieces + 1) * 8) |
+            z.cnt.ensure((size_t)n_pieces * ES_NCOUNTERS * 8) | z.mask.ensure((size_t)total + 64) |
+            z.woff.ensure((size_t)(n_windows + 1) * 4) | (clips ? z.clips.ensure((size_t)n_pieces * 8) : 0) |
+            z.h.ensure(16 + (size_t)n_pieces * (ES_NCOUNTERS + 1) * 8 + (size_t)(n_reads + n_pieces + 2) * 8 +
+                       (clips ? (size_t)n_pieces * 8 : 0));
+    }
     if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "statistics workspace");
     hipStream_t st = c->stream;
     // inputs go through the slot's pinned block so that the uploads do not wait for the device
