@@ -229,7 +229,7 @@ def main():
         # roofline of the dominant kernel: algorithmic bytes = 8-bit inputs + 8-bit MSA out + descriptors
         alg_bytes = int((lr + lc + lu).sum() + 3 * ncol.sum() + 28 * n)
         # kernel classes: 0 = alignment #1 stage (k_fused_a<G>, or k_dp1 on the generic path),
-        # 1 = alignment #2 stage (k_fused_b<G> / k_dp2); launches of the size classes run
+        # 1 = alignment #2 stage (k_fused_b<G> / k_dp2); launches of the geometry classes run
         # concurrently on separate streams, so their event times overlap in wall time
         dom = ("k_fused_b", t_dp2, k_dp2) if t_dp2 >= t_dp1 else ("k_fused_a", t_dp1, k_dp1)
         launches = max(1, dom[2])
@@ -252,7 +252,7 @@ def main():
                                    "alignment2_stage": round(t_dp2 / args.steps, 3),
                                    "other": round(t_oth / args.steps, 3),
                                    "merge_and_counters": round(t_st / args.steps, 3),
-                                   "note": "sum of per-launch HIP-event times; size classes overlap on 8 streams"},
+                                   "note": "sum of per-launch HIP-event times; size classes overlap on 4 streams"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic,
