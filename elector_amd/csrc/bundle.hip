@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
   for (int k = 0; k < 8; ++k) info[k] = k >= 4 && k <= 6 ? -1 : 0;
   if (a.status[w]) return;
   const int64_t o0 = a.off[3 * w], o1 = a.off[3 * w + 1], o2 = a.off[3 * w + 2], o3 = a.off[3 * w + 3];
+  if (o3 - o0 >= 65535) return;             // node records hold 16-bit node ids: no bundles for such windows
   const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1), Lu = (int)(o3 - o2), n1 = a.n1[w];
   const int64_t nb = o0 + w;
   const int2 *xinfo = a.xinfo + nb;

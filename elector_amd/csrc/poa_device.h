@@ -8,10 +8,12 @@
 //                 i.e. one more slot than it has bases, so that 1-based node
 //                 indices jj = 1..|PO| and the virtual start node jj = 0 fit.
 //       xinfo[nb+jj]  int2  DP view of node jj of the graph after fusion #1:
-//                             .x = pp1 | pp2<<16   (DP predecessor list, 1-based,
-//                                                   0 = virtual start, 0xFFFF = none)
+//                             .x = d1 | d2<<16     (DP predecessor list as distances back,
+//                                                   node jj - d; d1 = 0: the virtual start,
+//                                                   d2 = 0: no second predecessor)
 //                             .y = letter | flags<<8
-//       ring1[nb+j]   u16   ring id (column id) of node j
+//       ring1[nb+j]   u16   ring id (column id) of node j, low 16 bits (only ever compared
+//                           between neighbouring nodes)
 //       map16[nb+j]   u16   x_to_y of the alignment being traced (0xFFFF = unaligned)
 //       carry[nb+jj]  i32   packed (score, tag) of the last row of a DP strip
 //   moves         u32     per window and alignment: [strip][t>>3][lane] dwords,

@@ -383,15 +383,14 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
     int2 *gx = a.b.xinfo + nb;
     uint16_t *gr = a.b.ring1 + nb;
     auto emit = [&](int n, int letter, int flags, int ring, int sa, int sb) {
-      int pp1, pp2 = (int)kNone16;
+      int d1, d2 = 0;                                      // distances back; d1 0 = virtual start, d2 0 = none
       const int jj = n + 1;
-      if (sa < 0) pp1 = 0;
-      else if (flags & kFlagInitial) { pp1 = 0; pp2 = sa + 1; if (sb >= 0) bad = true; }
-      else { pp1 = sa + 1; if (sb >= 0) pp2 = sb + 1; }
-      if (pp1 > 0) maxd = max(maxd, jj - pp1);
-      if (pp2 != (int)kNone16 && pp2 > 0) maxd = max(maxd, jj - pp2);
+      if (sa < 0) d1 = 0;
+      else if (flags & kFlagInitial) { d1 = 0; d2 = n - sa; if (sb >= 0) bad = true; }
+      else { d1 = n - sa; if (sb >= 0) d2 = n - sb; }
+      maxd = max(maxd, max(d1, d2));
       if (n >= 0 && n < Lr + Lc) {
-        gx[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
+        gx[jj] = make_int2(d1 | (d2 << 16), letter | (flags << 8));
         gr[n] = (uint16_t)ring;
       } else bad = true;
     };
@@ -596,9 +595,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
       for (int u = 0; u < 4; ++u) {
         const int i = ib + u * G;
         if (i <= n1) {
-          const int pp1 = v[u].x & 0xFFFF, pp2 = (int)((uint32_t)v[u].x >> 16);
-          const uint32_t d1 = pp1 == 0 ? 0u : (uint32_t)(i - pp1);                    // <= 6 (ring eligibility)
-          const uint32_t d2 = pp2 == (int)kNone16 ? 0u : pp2 == 0 ? 15u : (uint32_t)(i - pp2);
+          const uint32_t d1 = (uint32_t)v[u].x & 0xFFFFu, d2 = (uint32_t)v[u].x >> 16;   // <= 6 (ring eligibility)
           xinfo[i] = d1 | (d2 << 4) | ((uint32_t)(v[u].y & 0xFF) << 8) | ((uint32_t)((v[u].y >> 8) & 0xFF) << 16);
         }
       }

@@ -204,7 +204,8 @@ static int validate_params(const elector_params *p)
 {
   if (p->nsymbol < 1 || p->nsymbol > ELECTOR_MAX_SYMBOL) return ELECTOR_E_PARAMS;
   if (p->max_gap_length < 0 || p->max_gap_length + 2 > ELECTOR_MAX_GAPTAB) return ELECTOR_E_PARAMS;
-  // scores must stay far from the packed-cell range: |score| * (2*MAX_SEQ) < 2^25
+  // packed DP cell = score << 6 | tag in 32 bits; the per-window check in run_device_batch keeps
+  // |score| * (cells on a path) below 2^24
   for (int i = 0; i < p->nsymbol; ++i)
     for (int j = 0; j < p->nsymbol; ++j)
       if (std::abs(p->score[i][j]) > 500) return ELECTOR_E_PARAMS;
@@ -480,6 +481,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           *bin_max_po = bin_max_lu + kBins;
   const int maxpen = std::max(std::max(std::abs(c->kp.mismatch), std::abs(c->kp.match)),
                               std::max(std::max(c->kp.open_x, c->kp.open_y), std::max(c->kp.ext_x, c->kp.ext_y)));
+  int pen_abs_max = 1;                       // largest |score| or gap penalty of the parameter set
+  for (int i = 0; i < c->params.nsymbol; ++i)
+    for (int j = 0; j < c->params.nsymbol; ++j) pen_abs_max = std::max(pen_abs_max, std::abs(c->params.score[i][j]));
+  for (int g = 0; g <= c->params.max_gap_length + 1; ++g)
+    pen_abs_max = std::max(pen_abs_max, std::max(std::abs(c->params.gap_penalty_x[g]), std::abs(c->params.gap_penalty_y[g])));
   int cls_max_slot[kNC];
   for (int ci = 0; ci < kNC; ++ci) cls_max_slot[ci] = class_max_slot(ci);
   // testing knob: every window into one geometry class (multi-strip paths of the small classes)
@@ -507,7 +513,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         int st = ELECTOR_W_OK;
         if (lr < 0 || lc < 0 || lu < 0) { bad_offsets.store(1); continue; }
         if (lr == 0 || lc == 0 || lu == 0) st = ELECTOR_W_EMPTY;
-        else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ) st = ELECTOR_W_TOOLONG;
+        else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ ||
+                 (int64_t)pen_abs_max * (lr + lc + lu + 4) >= ((int64_t)1 << 24))
+          st = ELECTOR_W_TOOLONG;
         h_status[w] = st;
         h_mv1[w] = h_mv2[w] = -1;
         if (!st && use_lane && lr <= kLaneCapA[kLaneClasses - 1] && lc <= 1023 && lu <= 1023) {

@@ -197,7 +197,7 @@ __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring
   int32_t *carry = a.carry + (o0 + w);
   const int tw = mv_tw(Lx), ns = n_strips(Ly);
   constexpr int MASK = D - 1;
-  constexpr int kNoPred = (int)(kNone16 << 16);   // pp1 = 0 (virtual), pp2 = none
+  constexpr int kNoPred = 0;                      // d1 = 0 (virtual start), d2 = 0 (none)
 
   int best = kNeg, bestx = -1;
   for (int s = 0; s < ns; ++s) {
@@ -227,21 +227,21 @@ __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring
       if (lane == 0) { xlo = x0lo; xhi = x0hi; }
       const int jj = t - lane;
       const bool incol = jj >= 1 && jj <= Lx;
-      const int pp1 = xlo & 0xFFFF, pp2 = (int)((uint32_t)xlo >> 16);
+      const int d1 = xlo & 0xFFFF, d2 = (int)((uint32_t)xlo >> 16);   // distances back to the predecessors
       const int xl = xhi & 0xFF;
-      const bool has2 = incol && (pp2 != (int)kNone16);
-      const bool virt1 = !incol || pp1 == 0;
+      const bool has2 = incol && d2 != 0;
+      const bool virt1 = !incol || d1 == 0;
       const int lm1 = max(lane - 1, 0);
 
       // predecessor cells: own row from this lane's ring, row above from lane-1's
       int own1 = col_own, dg1 = col_dg, own2 = 0, dg2 = 0;
       if (!virt1) {
-        const int d = jj - pp1;
+        const int d = d1;
         own1 = ring[((t - d) & MASK) * 64 + lane];
         dg1 = ring[((t - d - 1) & MASK) * 64 + lm1];
       }
       if (has2) {
-        const int d = jj - pp2;
+        const int d = d2;
         own2 = ring[((t - d) & MASK) * 64 + lane];
         dg2 = ring[((t - d - 1) & MASK) * 64 + lm1];
       }

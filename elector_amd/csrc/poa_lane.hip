@@ -171,9 +171,8 @@ __global__ void __launch_bounds__(64) k_lane_b(LaneArgs a)
     int r = 0;
     if (jj <= n1) {
       const int2 xi = xinfo[jj];
-      const int pp1 = xi.x & 0xFFFF, pp2 = (int)((uint32_t)xi.x >> 16);
-      const int d1 = pp1 == 0 ? 0 : jj - pp1;
-      const int d2 = pp2 == (int)kNone16 ? 0 : (pp2 == 0 ? 255 : jj - pp2);
+      const int d1 = xi.x & 0xFFFF, d2 = (int)((uint32_t)xi.x >> 16);
+      const int pp1 = d1 ? jj - d1 : 0, pp2 = d2 ? jj - d2 : 0;
       inf = (uint32_t)d1 | ((uint32_t)d2 << 8) | ((uint32_t)(xi.y & 0xFF) << 16) |
             ((uint32_t)((xi.y >> 8) & kFlagFinal) << 24);
       r = ((int)R[pp1 * 64 + lane] >> 1) - (pp1 == 0 ? kp.open_x : kp.ext_x);

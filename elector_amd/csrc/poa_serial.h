@@ -29,14 +29,13 @@ struct NodeWriter {
   // sa, sb: stored predecessors (new indices) in stored order, -1 = none
   __device__ __forceinline__ void emit(int n, int letter, int flags, int ring, int sa, int sb)
   {
-    int pp1, pp2 = (int)kNone16;
+    int d1, d2 = 0;                                            // distances back; d1 0 = virtual start, d2 0 = none
+    if (sa < 0) { d1 = 0; }                                    // no stored link: [-1]
+    else if (flags & kFlagInitial) { d1 = 0; d2 = n - sa; if (sb >= 0) bad = true; }   // virtual -1 first (:69-79)
+    else { d1 = n - sa; if (sb >= 0) d2 = n - sb; }
+    maxd = max(maxd, max(d1, d2));
     const int jj = n + 1;
-    if (sa < 0) { pp1 = 0; }                                   // no stored link: [-1]
-    else if (flags & kFlagInitial) { pp1 = 0; pp2 = sa + 1; if (sb >= 0) bad = true; }   // virtual -1 first (:69-79)
-    else { pp1 = sa + 1; if (sb >= 0) pp2 = sb + 1; }
-    if (pp1 > 0) maxd = max(maxd, jj - pp1);
-    if (pp2 != (int)kNone16 && pp2 > 0) maxd = max(maxd, jj - pp2);
-    xinfo[jj] = make_int2(pp1 | (pp2 << 16), letter | (flags << 8));
+    xinfo[jj] = make_int2(d1 | (d2 << 16), letter | (flags << 8));
     ring1[n] = (uint16_t)ring;
   }
 };
@@ -139,8 +138,8 @@ __device__ void fuse2_window(const BatchArgs &a, const uint32_t w, const MV getm
       if (!xo && !yo) { bad = true; break; }
       if (xo) {
         const uint32_t pl = (uint32_t)xinfo[x + 1].x;
-        const int pp = (xo == 1) ? (int)(pl & 0xFFFF) : (int)(pl >> 16);
-        x = pp - 1;
+        const int d = (xo == 1) ? (int)(pl & 0xFFFF) : (int)(pl >> 16);
+        x = d ? x - d : -1;                                       // 0 = the virtual start
       }
       if (yo) --y;
     }

@@ -31,7 +31,7 @@ extern "C" {
 
 #define ELECTOR_MAX_SYMBOL 32     /* device alphabet limit (shipped matrix: 31) */
 #define ELECTOR_MAX_GAPTAB 64     /* max_gap_length + 2 must fit               */
-#define ELECTOR_MAX_SEQ    16384  /* longest sequence of a window (bases)      */
+#define ELECTOR_MAX_SEQ    65520  /* longest sequence of a window (bases): 16-bit row indices */
 
 /* error codes (negative) */
 #define ELECTOR_OK            0
@@ -45,7 +45,7 @@ extern "C" {
 /* per-window status values */
 #define ELECTOR_W_OK          0
 #define ELECTOR_W_EMPTY       1     /* a sequence of the window is empty           */
-#define ELECTOR_W_TOOLONG     2     /* a sequence exceeds ELECTOR_MAX_SEQ          */
+#define ELECTOR_W_TOOLONG     2     /* a sequence exceeds ELECTOR_MAX_SEQ, or scores could leave the packed-cell range */
 #define ELECTOR_W_INTERNAL    3     /* graph invariant violated on device          */
 
 /* Scoring parameters = what the reference's read_score_matrix() leaves behind

@@ -125,3 +125,18 @@ def test_every_geometry_class(engine, cls, monkeypatch):
     classes then run many strips per window, the big ones mostly idle lanes."""
     monkeypatch.setenv("ELECTOR_FORCE_CLASS", str(cls))
     check(engine, synth.window_triples(100 + cls, 500, 5, 420) + synth.adversarial_triples(200 + cls, 300))
+
+
+def test_windows_beyond_16k(engine):
+    """The reference's un-anchored whole-read fallback hands poa very long triples: windows longer than
+    16,384 bases take the generic kernels (moves in HBM, node distances instead of 16-bit node ids)."""
+    check(engine, synth.window_triples(31, 2, 16500, 17500, err_unc=0.12, err_cor=0.01))
+
+
+def test_too_long_is_reported(engine):
+    from elector_amd._capi import ELECTOR_MAX_SEQ
+    big = b"A" * (ELECTOR_MAX_SEQ + 1)
+    got = engine.align([(big, b"ACGT", b"ACGT"), (b"ACGT", b"ACGT", b"ACGT")], strict=False)
+    assert got[0] is None and got[1] == (b"acgt", b"acgt", b"acgt")
+    with pytest.raises(Exception):
+        engine.align([(big, b"ACGT", b"ACGT")])
