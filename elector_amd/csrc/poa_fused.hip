@@ -40,6 +40,7 @@ struct FusedArgs {
   int keep_map;             // k_fused_b also leaves the x -> y map of alignment #2 in HBM (a12 needs it)
   uint8_t *mv_pool;         // moves scratch of this launch: [block][mv_ns strips][mv_tw steps][64 lanes] words
   int mv_tw, mv_ns;
+  const int32_t *nlist_dev; // k_fused_a: when set, only the first *nlist_dev windows of the list still need it
 };
 
 __device__ __forceinline__ int row_shr1(int old, int v)
@@ -126,9 +127,9 @@ __device__ __forceinline__ WinA load_win_a(const FusedArgs &a, int64_t li)
 {
   constexpr int RS = R * G;
   WinA v;
-  v.valid = li < a.nlist;
+  v.valid = li < (a.nlist_dev ? (int64_t)*a.nlist_dev : a.nlist);
   v.w = v.valid ? a.list[li] : 0;
-  v.valid = v.valid && a.b.status[v.w] == 0;
+  v.valid = v.valid && a.b.status[v.w] == 0 && a.done_a[v.w] == 0;
   v.o0 = 0; v.Lr = 0; v.Lc = 0;
   if (v.valid) {
     v.o0 = a.b.off[3 * (int64_t)v.w];
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
   const int sidx = wv * NW + q;               // this lane's window slot in the block
+  if (a.nlist_dev && (int64_t)(NW * WV) * blockIdx.x >= (int64_t)*a.nlist_dev) return;   // the rest of the list is done already
   const WinA W = load_win_a<G, R>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
   const bool valid = W.valid;
   const int Lr = W.Lr, Lc = W.Lc, ns = W.ns;

@@ -30,6 +30,9 @@ void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uin
                    unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, hipStream_t st);
 void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
                  uint8_t *rows, int64_t n, hipStream_t st);
+void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, hipStream_t st);
+void launch_partition(const uint32_t *in, uint32_t *out, const int64_t *bins, int nbins, const void *chunks, int nchunks,
+                      const int32_t *bin_chunks, const uint8_t *triv, int32_t *chunk_need, int32_t *count, hipStream_t st);
 struct FusedArgs {
   BatchArgs b;
   const uint32_t *list;
@@ -42,6 +45,7 @@ struct FusedArgs {
   int keep_map;
   uint8_t *mv_pool;
   int mv_tw, mv_ns;
+  const int32_t *nlist_dev;
 };
 int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
 int launch_fused_b(const FusedArgs &a, int G, int R, int D, hipStream_t st);
@@ -408,6 +412,7 @@ static void build_tiers()
   });
 }
 static const int kBins = kNC * kNT;
+static const int kPartChunk = 2048;     // list entries per block of the trivial-window partition
 // a bin with fewer windows than this joins the next larger populated slot tier of its class
 static const int64_t kMinBinWindows = 4096;
 // largest slot a class can give each of its 64/G windows (k_fused_b: 64 B table + one score ring per wave)
@@ -452,7 +457,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   hipEvent_t &h_done = c->h_meta_done[c->h_meta_cur];
   if (!h_done) HIPCHK(c, hipEventCreateWithFlags(&h_done, hipEventDisableTiming));
   else HIPCHK(c, hipEventSynchronize(h_done));                     // the copies of the batch before last have run
-  const size_t meta_bytes = (size_t)n * (4 + 8 + 8 + 4 + 4) + (size_t)(3 * n + 1) * 8 + 64;
+  const size_t part_chunks_max = (size_t)n / kPartChunk + kBins + 1;
+  const size_t meta_bytes = (size_t)n * (4 + 8 + 8 + 4 + 4) + (size_t)(3 * n + 1) * 8 + (size_t)kBins * 24 +
+                            part_chunks_max * 16 + 64;
   int rc = h_meta.ensure(meta_bytes);
   if (!rc && c->h_meta_buf[c->h_meta_cur ^ 1].cap < meta_bytes) {
     // grow the other buffer now too (a pipelined caller's next batch must not pay for it); it may
@@ -467,6 +474,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   int64_t *h_mv2 = h_mv1 + n;
   uint32_t *h_generic = reinterpret_cast<uint32_t *>(h_mv2 + n);   // generic-path windows, processing order
   uint32_t *h_list = h_generic + n;                                // fused classes, concatenated
+  int64_t *h_bins = reinterpret_cast<int64_t *>(h_list + n);   // (first, count) of every occupied fused bin
+  int64_t *h_chunks = h_bins + 2 * kBins;                      // partition chunks: first, (len | bin << 32)
+  int32_t *h_bin_chunks = reinterpret_cast<int32_t *>(h_chunks + 2 * part_chunks_max);   // first chunk, #chunks per bin
 
   // window sizes -> status, coarse size key (counting sort, largest first), launch class
   constexpr int NB = 256;
@@ -700,7 +710,32 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     const int64_t blocks = (bin_cnt[(size_t)b] + 64 / G - 1) / (64 / G);
     return blocks * *ns * *tw * 64 * fused_mv_bytes(R);
   };
-  auto stream_of = [&](int b) { const int G = kClsG[b / kNT]; return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };
+  // launch chains: one stream per group size G, big classes first, alignment #1 then #2 of each bin.
+  // (ELECTOR_STREAMS_LPT deals the bins longest-first onto the least loaded stream instead, by a work
+  // estimate of windows x columns x rows; measured 4 % slower: kernels of unlike geometry co-run worse.)
+  std::vector<int> bin_stream((size_t)kBins, 0), bin_order;
+  {
+    std::vector<std::pair<int64_t, int>> work;
+    for (int b = 0; b < kBins; ++b)
+      if (bin_cnt[(size_t)b]) work.push_back({bin_cnt[(size_t)b] * (bin_max_lr[b] + 8) * (bin_max_lu[b] + 8), b});
+    std::sort(work.begin(), work.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) {
+      return x.first != y.first ? x.first > y.first : x.second > y.second;
+    });
+    int64_t load[4] = {0, 0, 0, 0};
+    const bool by_size = std::getenv("ELECTOR_STREAMS_LPT") == nullptr;
+    if (by_size) std::sort(work.begin(), work.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) {
+      return x.second > y.second;
+    });
+    for (auto &wb : work) {
+      int k = 0;
+      if (by_size) { const int G = kClsG[wb.second / kNT]; k = G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; }
+      else for (int q = 1; q < 4; ++q) if (load[q] < load[k]) k = q;
+      load[k] += wb.first;
+      bin_stream[(size_t)wb.second] = k;
+      bin_order.push_back(wb.second);
+    }
+  }
+  auto stream_of = [&](int b) { return bin_stream[(size_t)b]; };
   if (use_fused)
     for (int b = 0; b < kBins; ++b) {
       if (!bin_cnt[(size_t)b]) continue;
@@ -718,7 +753,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
        c->d_moves.ensure((size_t)(max_dwords + bump_dwords + lane_dwords) * 4 + 1024) |
        c->d_lanemeta.ensure(lane_dims.size() * 4 + lane_mvoff_a.size() * 16 + 64) | c->d_n1.ensure((size_t)n * 4) |
        c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
-       c->d_bx2.ensure((size_t)n * 4) | c->d_list.ensure((size_t)2 * n * 4 + 64) | c->d_done.ensure((size_t)2 * n + 64) |
+       c->d_bx2.ensure((size_t)n * 4) |
+       c->d_list.ensure((size_t)3 * n * 4 + (size_t)kBins * 32 + part_chunks_max * 20 + 64) |
+       c->d_done.ensure((size_t)3 * n + 64) |
        c->d_rowinit.ensure(1024 + 256 * (size_t)kBins) |
        c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256);
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
@@ -729,7 +766,39 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   uint32_t *d_generic = c->d_perm.as<uint32_t>();
   uint32_t *d_lists = c->d_list.as<uint32_t>();
   uint32_t *d_leftb = d_lists + n;                 // device-built list for alignment #2 leftovers
-  uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n;
+  uint32_t *d_lists2 = d_lists + 2 * n;            // the fused bins' lists, windows that need alignment #1 first
+  int64_t *d_bins = reinterpret_cast<int64_t *>(d_lists2 + n + (n & 1));
+  int64_t *d_chunks = d_bins + 2 * kBins;
+  int32_t *d_bin_need = reinterpret_cast<int32_t *>(d_chunks + 2 * part_chunks_max);
+  int32_t *d_bin_chunks = d_bin_need + kBins, *d_chunk_need = d_bin_chunks + 2 * kBins;
+  uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n, *d_triv = d_done_b + n;
+  // alignment #1 without a dynamic program for windows whose corrected sequence equals the reference:
+  // valid when the diagonal is strictly best (see k_trivial)
+  const bool use_trivial = use_fused && !std::getenv("ELECTOR_NO_TRIVIAL") && c->kp.match >= 0 &&
+                           c->kp.mismatch <= c->kp.match && c->kp.open_x > 0 && c->kp.ext_x > 0 && c->kp.open_y > 0 &&
+                           c->kp.ext_y > 0;
+  int nbins_used = 0, nchunks = 0;
+  std::vector<int> bin_slot((size_t)kBins, -1);
+  if (use_trivial)
+    for (int b = 0; b < kBins; ++b)
+      if (bin_cnt[(size_t)b]) {
+        h_bins[2 * nbins_used] = bin_first[(size_t)b];
+        h_bins[2 * nbins_used + 1] = bin_cnt[(size_t)b];
+        h_bin_chunks[2 * nbins_used] = nchunks;
+        for (int64_t i = 0; i < bin_cnt[(size_t)b]; i += kPartChunk) {
+          h_chunks[2 * nchunks] = bin_first[(size_t)b] + i;
+          const int32_t len = (int32_t)std::min<int64_t>(kPartChunk, bin_cnt[(size_t)b] - i);
+          h_chunks[2 * nchunks + 1] = (int64_t)(uint32_t)len | ((int64_t)nbins_used << 32);
+          ++nchunks;
+        }
+        h_bin_chunks[2 * nbins_used + 1] = nchunks - h_bin_chunks[2 * nbins_used];
+        bin_slot[(size_t)b] = nbins_used++;
+      }
+  if (nbins_used) {
+    HIPCHK(c, hipMemcpyAsync(d_bins, h_bins, (size_t)nbins_used * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_chunks, h_chunks, (size_t)nchunks * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_bin_chunks, h_bin_chunks, (size_t)nbins_used * 8, hipMemcpyHostToDevice, st));
+  }
   // device counters: [0] = leftover count (int32), [2..3] = bump allocator (u64)
   int32_t *d_counters = reinterpret_cast<int32_t *>(c->d_rowinit.p);
   HIPCHK(c, hipMemcpyAsync(c->d_off.p, h_off, (size_t)(3 * n + 1) * 8, hipMemcpyHostToDevice, st));
@@ -751,7 +820,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipEventRecord(h_done, st));
-  HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)2 * n, st));
+  HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)3 * n, st));
   HIPCHK(c, hipMemsetAsync(d_counters, 0, 16, st));
   if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 256 * (size_t)kBins, st));
 
@@ -790,6 +859,15 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   a.skip_a = d_done_a;
   a.skip_b = d_done_b;
 
+  if (use_trivial) {
+    a.n = n;
+    timed_begin(c, 2, st);
+    launch_trivial(a, d_done_a, d_triv, st);
+    launch_partition(d_lists, d_lists2, d_bins, nbins_used, d_chunks, nchunks, d_bin_chunks, d_triv, d_chunk_need, d_bin_need, st);
+    timed_end(c, st);
+  }
+  const uint32_t *d_fused_lists = use_trivial ? d_lists2 : d_lists;
+
   // ---- fused classes: one stream per class chain (A then B), all concurrent ----
   if (use_fused && n > n_generic) {
     HIPCHK(c, hipEventRecord(c->fork, st));
@@ -820,14 +898,15 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     // to a handful of hardware queues, so more streams than this do not run concurrently)
     used = std::max(used, 4);
     for (int k = 0; k < 4; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
-    for (int b = kBins - 1; b >= 0; --b) {          // within a chain: big classes first
+    for (int b : bin_order) {                       // within a chain: most work first
       if (!bin_cnt[(size_t)b]) continue;
       const int bG = kClsG[b / kNT], bR = kClsR[b / kNT], bslot = g_tier_bytes[b % kNT];
       const int sk = stream_of(b);
       hipStream_t sx = c->aux[sk];
       FusedArgs fa;
       fa.b = a;
-      fa.list = d_lists + bin_first[(size_t)b];
+      fa.list = d_fused_lists + bin_first[(size_t)b];
+      fa.nlist_dev = use_trivial ? d_bin_need + bin_slot[(size_t)b] : nullptr;
       fa.nlist = bin_cnt[(size_t)b];
       fa.slot_bytes = bslot;
       fa.done_a = d_done_a;
@@ -843,6 +922,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       if (launch_fused_a(fa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
       timed_end(c, sx);
       fa.slot_bytes = bslot;
+      fa.nlist_dev = nullptr;
       (void)fmv_geom(b, true, &fa.mv_tw, &fa.mv_ns);
       timed_begin(c, 1, sx);
       // Ring depth 8.  (Measured: a 4-deep ring for the 99.8 % of windows that need no more, followed by

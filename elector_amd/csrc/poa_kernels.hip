@@ -353,6 +353,113 @@ __global__ void __launch_bounds__(256) k_left_b(BatchArgs a, uint32_t *list, int
   list[atomicAdd(count, 1)] = (uint32_t)w;
 }
 
+// -------------------------------------------------------------- k_trivial ---
+// Alignment #1 of a window whose corrected sequence EQUALS its reference (most windows of
+// well-corrected reads) needs no dynamic program: with uniform scoring, match >= 0, mismatch <=
+// match and positive gap penalties the diagonal is the strictly best predecessor of every diagonal
+// cell (a cell left of or above it has at least one gap step less than it has letters), so the
+// traceback (align_lpo_po2.c:108-168) pairs letter i with letter i and the fusion (lpo.c:602-656)
+// gives the plain chain with every node holding both letters.  8 lanes per window compare the two
+// symbol strings and, when equal, write that chain; the window is then marked done for alignment #1.
+__global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv)
+{
+  const int64_t w = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+  const int g = threadIdx.x & 7;
+  if (w >= a.n) return;
+  const int64_t o0 = a.off[3 * w], o1 = a.off[3 * w + 1], o2 = a.off[3 * w + 2];
+  const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1);
+  bool eq = a.status[w] == 0 && Lr == Lc;
+  const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
+  if (eq)
+    for (int i = g; i < Lr; i += 8) eq = eq && xs[i] == ys[i];
+  for (int d = 1; d < 8; d <<= 1) eq = __shfl_xor(eq ? 1 : 0, d, 8) != 0 && eq;
+  if (g == 0) triv[w] = eq ? 1 : 0;
+  if (!eq) return;
+  const int64_t nb = o0 + w;
+  for (int n = g; n < Lr; n += 8) {
+    const int fl = kFlagHasRef | kFlagHasCor | (n == 0 ? kFlagInitial : 0) | (n == Lr - 1 ? kFlagFinal : 0);
+    a.xinfo[nb + n + 1] = make_int2(n == 0 ? 0 : 1, xs[n] | (fl << 8));     // d1 = 1 (0: virtual start), no second predecessor
+    a.ring1[nb + n] = (uint16_t)n;
+  }
+  if (g == 0) {
+    a.n1[w] = Lr;
+    a.cls[w] = 0;                       // max predecessor distance 1
+    a.score1[w] = Lr * a.kp.match;
+    done_a[w] = 1;
+  }
+}
+
+// Stable partition of every launch bin's window list: windows that still need alignment #1 first,
+// the trivial ones after them; count[bin] = how many need it.  Three small launches over chunks of
+// kPartChunk list entries: per-chunk counts, a scan over each bin's chunks, the scatter.
+// chunk table (host-built): first list index, length, bin slot, index of the bin's first chunk
+struct PartChunk { int64_t first; int32_t len, bin; };
+
+__global__ void __launch_bounds__(256) k_part_count(const uint32_t *__restrict__ in, const PartChunk *__restrict__ chunks,
+                                                    const uint8_t *__restrict__ triv, int32_t *__restrict__ chunk_need)
+{
+  __shared__ int s_wave[4];
+  const PartChunk ch = chunks[blockIdx.x];
+  int mine = 0;
+  for (int i = threadIdx.x; i < ch.len; i += 256) mine += triv[in[ch.first + i]] ? 0 : 1;
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_need[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+// one wave per bin: exclusive scan of its chunks' counts (in place), total to count[bin]
+__global__ void __launch_bounds__(64) k_part_scan(const int32_t *__restrict__ bin_chunks /* first chunk, #chunks per bin */,
+                                                  int32_t *__restrict__ chunk_need, int32_t *__restrict__ count)
+{
+  const int c0 = bin_chunks[2 * blockIdx.x], nc = bin_chunks[2 * blockIdx.x + 1], lane = threadIdx.x;
+  int run = 0;
+  for (int base = 0; base < nc; base += 64) {
+    const int i = base + lane;
+    const int v = i < nc ? chunk_need[c0 + i] : 0;
+    int inc = v;
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (i < nc) chunk_need[c0 + i] = run + inc - v;
+    run += __shfl(inc, 63);
+  }
+  if (lane == 0) count[blockIdx.x] = run;
+}
+
+__global__ void __launch_bounds__(256) k_part_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                      const PartChunk *__restrict__ chunks, const int64_t *__restrict__ bins,
+                                                      const uint8_t *__restrict__ triv, const int32_t *__restrict__ chunk_need,
+                                                      const int32_t *__restrict__ count)
+{
+  __shared__ int s_wave[4], s_base;
+  const PartChunk ch = chunks[blockIdx.x];
+  const int64_t bin_first = bins[2 * ch.bin];
+  const int n_need = count[ch.bin], need_before = chunk_need[blockIdx.x];
+  const int idx0 = (int)(ch.first - bin_first);                 // entries of the bin before this chunk
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < ch.len; i0 += 256) {
+    const int i = i0 + tid;
+    const bool in_range = i < ch.len;
+    const uint32_t w = in_range ? in[ch.first + i] : 0u;
+    const bool need = in_range && !triv[w];
+    const unsigned long long bm = __builtin_amdgcn_ballot_w64(need);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (lane == 0) s_wave[wave] = __builtin_popcountll(bm);
+    __syncthreads();
+    int rank = s_base + __builtin_popcountll(bm & below), round = 0;
+    for (int k = 0; k < 4; ++k) { if (k < wave) rank += s_wave[k]; round += s_wave[k]; }
+    if (in_range) {
+      const int64_t pos = need ? (int64_t)need_before + rank
+                               : (int64_t)n_need + (idx0 + i - (need_before + rank));   // trivial entries before this one
+      out[bin_first + pos] = w;
+    }
+    __syncthreads();
+    if (tid == 0) s_base += round;
+    __syncthreads();
+  }
+}
+
 // ----------------------------------------------------------------- k_rows ---
 // column-interleaved MSA -> three contiguous rows per window (host-buffer API)
 
@@ -428,6 +535,22 @@ void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st)
 void launch_fuse2(const BatchArgs &a, hipStream_t st)
 {
   hipLaunchKernelGGL(k_fuse2, dim3(list_grid(a, 64, 256)), dim3(64), 0, st, a);
+}
+
+void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, hipStream_t st)
+{
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv);
+}
+
+void launch_partition(const uint32_t *in, uint32_t *out, const int64_t *bins, int nbins, const void *chunks, int nchunks,
+                      const int32_t *bin_chunks, const uint8_t *triv, int32_t *chunk_need, int32_t *count, hipStream_t st)
+{
+  if (nbins <= 0 || nchunks <= 0) return;
+  const PartChunk *ch = reinterpret_cast<const PartChunk *>(chunks);
+  hipLaunchKernelGGL(k_part_count, dim3((unsigned)nchunks), dim3(256), 0, st, in, ch, triv, chunk_need);
+  hipLaunchKernelGGL(k_part_scan, dim3((unsigned)nbins), dim3(64), 0, st, bin_chunks, chunk_need, count);
+  hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)nchunks), dim3(256), 0, st, in, out, ch, bins, triv, chunk_need, count);
 }
 
 void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
