@@ -414,7 +414,7 @@ static void build_tiers()
 static const int kBins = kNC * kNT;
 static const int kPartChunk = 2048;     // list entries per block of the trivial-window partition
 // a bin with fewer windows than this joins the next larger populated slot tier of its class
-static const int64_t kMinBinWindows = 4096;
+static const int64_t kMinBinWindows = std::getenv("ELECTOR_MIN_BIN") ? std::atoll(std::getenv("ELECTOR_MIN_BIN")) : 4096;
 // largest slot a class can give each of its 64/G windows (k_fused_b: 64 B table + one score ring per wave)
 static int class_max_slot(int ci)
 {
@@ -589,23 +589,50 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const double tp1 = now_ms();
   for (int k = 0; k < NB; ++k) key_cnt[k + 1] += key_cnt[k];
   // stable placement in descending size order, per destination list
-  // sparse bins join the next larger populated slot tier of their class (a larger slot always fits);
-  // the class's largest populated tier keeps whatever it has
+  // Launches are expensive in tails and ramps (measured: one launch per geometry class is 7 % faster
+  // than one per 4096-window slot tier, and a handful of tiny extra launches costs 8 %), so:
+  //  * a geometry class with few windows joins the next class of its group size (more rows per lane
+  //    never hurts correctness or the slot need);
+  //  * a class becomes ONE bin with its largest needed slot (a larger slot always fits the smaller
+  //    needs) unless that is more than 1.5x what 98 % of its windows need -- then those 98 % form the
+  //    main bin and the outliers keep their own tiers, sparse ones joining the next larger populated one.
   std::vector<int16_t> bin_final((size_t)kBins);
+  for (int b = 0; b < kBins; ++b) bin_final[(size_t)b] = (int16_t)b;
+  auto merge_into = [&](int b, int into) {
+    bin_cnt[(size_t)into] += bin_cnt[(size_t)b];
+    for (int q = 0; q < 5; ++q)
+      bin_need_a[(size_t)(q * kBins + into)] = std::max(bin_need_a[(size_t)(q * kBins + into)], bin_need_a[(size_t)(q * kBins + b)]);
+    bin_cnt[(size_t)b] = 0;
+    for (int x = 0; x < kBins; ++x) if (bin_final[(size_t)x] == b) bin_final[(size_t)x] = (int16_t)into;
+  };
+  for (int ci = 0; ci + 1 < kNC; ++ci) {
+    if (kClsG[ci + 1] != kClsG[ci]) continue;
+    int64_t total = 0;
+    for (int t = 0; t < kNT; ++t) total += bin_cnt[(size_t)(ci * kNT + t)];
+    if (!total || total >= kMinBinWindows / 2) continue;
+    for (int t = 0; t < kNT; ++t)
+      if (bin_cnt[(size_t)(ci * kNT + t)] && g_tier_bytes[t] <= cls_max_slot[ci + 1]) merge_into(ci * kNT + t, (ci + 1) * kNT + t);
+  }
   for (int ci = 0; ci < kNC; ++ci) {
-    int into = -1;                                     // nearest larger tier that stays a launch
-    for (int t = kNT - 1; t >= 0; --t) {
-      const int b = ci * kNT + t;
-      bin_final[(size_t)b] = (int16_t)b;
-      if (!bin_cnt[(size_t)b]) continue;
-      if (into >= 0 && bin_cnt[(size_t)b] < kMinBinWindows && g_tier_bytes[into % kNT] <= cls_max_slot[ci]) {
-        bin_cnt[(size_t)into] += bin_cnt[(size_t)b];
-        for (int q = 0; q < 5; ++q)
-          bin_need_a[(size_t)(q * kBins + into)] = std::max(bin_need_a[(size_t)(q * kBins + into)], bin_need_a[(size_t)(q * kBins + b)]);
-        bin_cnt[(size_t)b] = 0;
-        bin_final[(size_t)b] = (int16_t)into;
-      } else into = b;
+    int64_t total = 0, acc = 0;
+    int t_max = -1;
+    for (int t = 0; t < kNT; ++t) { total += bin_cnt[(size_t)(ci * kNT + t)]; if (bin_cnt[(size_t)(ci * kNT + t)]) t_max = t; }
+    if (!total) continue;
+    int t_main = t_max;
+    for (int t = 0; t < kNT; ++t) {
+      acc += bin_cnt[(size_t)(ci * kNT + t)];
+      if (acc * 50 >= total * 49) { t_main = t; break; }
     }
+    if (2 * g_tier_bytes[t_max] <= 3 * g_tier_bytes[t_main]) t_main = t_max;
+    int into = -1;                                     // nearest larger tier that stays a launch
+    for (int t = kNT - 1; t > t_main; --t) {
+      const int b = ci * kNT + t;
+      if (!bin_cnt[(size_t)b]) continue;
+      if (into >= 0 && bin_cnt[(size_t)b] < kMinBinWindows) merge_into(b, into);
+      else into = b;
+    }
+    for (int t = 0; t < t_main; ++t)
+      if (bin_cnt[(size_t)(ci * kNT + t)]) merge_into(ci * kNT + t, ci * kNT + t_main);
   }
   std::vector<int64_t> bin_first((size_t)kBins + 1);
   bin_first[0] = 0;
