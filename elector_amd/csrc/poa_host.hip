@@ -737,30 +737,45 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     const int64_t blocks = (bin_cnt[(size_t)b] + 64 / G - 1) / (64 / G);
     return blocks * *ns * *tw * 64 * fused_mv_bytes(R);
   };
-  // launch chains: one stream per group size G, big classes first, alignment #1 then #2 of each bin.
-  // (ELECTOR_STREAMS_LPT deals the bins longest-first onto the least loaded stream instead, by a work
-  // estimate of windows x columns x rows; measured 4 % slower: kernels of unlike geometry co-run worse.)
+  // Launch chains.  Two kernels side by side use the chip best (measured on the bench batch: 8.1 ms
+  // per step with two concurrent launch chains, 9.9 ms with four or more -- kernels of unlike
+  // geometry compete for LDS and L2 -- and a single chain pays every kernel's tail), so the four
+  // launches go to TWO streams; within a chain big classes first, alignment #1 then #2 of each bin.
+  // ELECTOR_CHAINS=1|4 are the alternatives for experiments (4 = one stream per group size).
+  static const int n_chains = std::getenv("ELECTOR_CHAINS") ? std::max(1, std::min(4, std::atoi(std::getenv("ELECTOR_CHAINS")))) : 2;
   std::vector<int> bin_stream((size_t)kBins, 0), bin_order;
   {
-    std::vector<std::pair<int64_t, int>> work;
+    auto group_of = [&](int b) { const int G = kClsG[b / kNT]; return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };
+    int64_t gwork[4] = {0, 0, 0, 0};
     for (int b = 0; b < kBins; ++b)
-      if (bin_cnt[(size_t)b]) work.push_back({bin_cnt[(size_t)b] * (bin_max_lr[b] + 8) * (bin_max_lu[b] + 8), b});
-    std::sort(work.begin(), work.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) {
-      return x.first != y.first ? x.first > y.first : x.second > y.second;
-    });
-    int64_t load[4] = {0, 0, 0, 0};
-    const bool by_size = std::getenv("ELECTOR_STREAMS_LPT") == nullptr;
-    if (by_size) std::sort(work.begin(), work.end(), [](const std::pair<int64_t, int> &x, const std::pair<int64_t, int> &y) {
-      return x.second > y.second;
-    });
-    for (auto &wb : work) {
-      int k = 0;
-      if (by_size) { const int G = kClsG[wb.second / kNT]; k = G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; }
-      else for (int q = 1; q < 4; ++q) if (load[q] < load[k]) k = q;
-      load[k] += wb.first;
-      bin_stream[(size_t)wb.second] = k;
-      bin_order.push_back(wb.second);
+      if (bin_cnt[(size_t)b]) gwork[group_of(b)] += bin_cnt[(size_t)b] * (bin_max_lr[b] + 8) * (bin_max_lu[b] + 8);
+    int chain_of_group[4] = {0, 1, 2, 3};
+    if (n_chains == 1) chain_of_group[1] = chain_of_group[2] = chain_of_group[3] = 0;
+    else if (n_chains < 4) {
+      int64_t best = -1;
+      for (int m = 0; m < 8; ++m) {                      // group 0 on chain 0; the others either way
+        int64_t load[2] = {gwork[0], 0};
+        for (int gi = 1; gi < 4; ++gi) load[(m >> (gi - 1)) & 1] += gwork[gi];
+        const int64_t mx = std::max(load[0], load[1]);
+        if (best < 0 || mx < best) { best = mx; for (int gi = 1; gi < 4; ++gi) chain_of_group[gi] = (m >> (gi - 1)) & 1; }
+      }
+      chain_of_group[0] = 0;
     }
+    // two chains: the bins, in class order, are dealt alternately -- both chains then hold about half
+    // of every group's work whatever the window distribution (as fast as the best hand-picked split of
+    // the groups; a split by the work estimate above was 4 % slower), and the kernels that run side
+    // by side are of neighbouring classes.  ELECTOR_CHAINS_BY_GROUP keeps whole groups together.
+    static const bool deal = std::getenv("ELECTOR_CHAINS_BY_GROUP") == nullptr;
+    int turn = 0;
+    for (int b = kBins - 1; b >= 0; --b)
+      if (bin_cnt[(size_t)b]) {
+        bin_stream[(size_t)b] = (deal && n_chains == 2) ? (turn++ & 1) : chain_of_group[group_of(b)];
+        bin_order.push_back(b);
+      }
+    if (std::getenv("ELECTOR_DEBUG_BINS"))
+      std::fprintf(stderr, "[elector] chains: G64->%d G32->%d G16->%d G8->%d (work %lld %lld %lld %lld)\n", chain_of_group[0],
+                   chain_of_group[1], chain_of_group[2], chain_of_group[3], (long long)gwork[0], (long long)gwork[1],
+                   (long long)gwork[2], (long long)gwork[3]);
   }
   auto stream_of = [&](int b) { return bin_stream[(size_t)b]; };
   if (use_fused)
@@ -925,6 +940,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     // to a handful of hardware queues, so more streams than this do not run concurrently)
     used = std::max(used, 4);
     for (int k = 0; k < 4; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
+    // ELECTOR_LAUNCH_ORDER=ab (experiment): per stream all alignment #1 launches first, then all #2
+    static const bool split_ab = std::getenv("ELECTOR_LAUNCH_ORDER") && std::string(std::getenv("ELECTOR_LAUNCH_ORDER")) == "ab";
+    for (int pass = 0; pass < (split_ab ? 2 : 1); ++pass)
     for (int b : bin_order) {                       // within a chain: most work first
       if (!bin_cnt[(size_t)b]) continue;
       const int bG = kClsG[b / kNT], bR = kClsR[b / kNT], bslot = g_tier_bytes[b % kNT];
@@ -945,9 +963,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       fa.mv_pool = c->d_fmv.as<uint8_t>();
       for (int k = 0; k < sk; ++k) fa.mv_pool += fmv_stream[k];
       (void)fmv_geom(b, false, &fa.mv_tw, &fa.mv_ns);
-      timed_begin(c, 0, sx);
-      if (launch_fused_a(fa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
-      timed_end(c, sx);
+      if (!split_ab || pass == 0) {
+        timed_begin(c, 0, sx);
+        if (launch_fused_a(fa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+        timed_end(c, sx);
+      }
+      if (split_ab && pass == 0) continue;
       fa.slot_bytes = bslot;
       fa.nlist_dev = nullptr;
       (void)fmv_geom(b, true, &fa.mv_tw, &fa.mv_ns);
