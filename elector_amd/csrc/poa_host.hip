@@ -49,18 +49,6 @@ struct FusedArgs {
 };
 int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
 int launch_fused_b(const FusedArgs &a, int G, int R, int D, hipStream_t st);
-struct LaneArgs {
-  BatchArgs b;
-  const uint32_t *list;
-  int64_t nlist;
-  const int64_t *mv_off;
-  const int32_t *dims;
-  int cap;
-  uint8_t *done_a;
-  uint8_t *done_b;
-};
-int launch_lane_a(const LaneArgs &a, hipStream_t st);
-int launch_lane_b(const LaneArgs &a, hipStream_t st);
 }  // namespace elector
 
 using namespace elector;
@@ -307,7 +295,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_score1, &c->d_score2, &c->d_bx2, &c->d_bases, &c->d_cols, &c->d_ncol, &c->d_status,
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
-                    &c->d_list, &c->d_done, &c->d_rowinit, &c->d_lanemeta,
+                    &c->d_list, &c->d_done, &c->d_rowinit,
                     &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv};
   for (DevBuf *b : bufs) b->release();
   for (auto &s : c->st_slot) s.release();
@@ -422,12 +410,6 @@ static int class_max_slot(int ci)
   return ((160 * 1024 - 256 - 64 - fused_ring_bytes(kClsR[ci], 8)) / nw) & ~127;
 }
 
-// lane-per-window classes: reference length cap (columns of alignment #1) and node cap of
-// alignment #2 (|PO| is usually a few percent above Lr; larger graphs are handed back)
-static const int kLaneClasses = 6;
-static const int kLaneCapA[kLaneClasses] = {32, 48, 64, 80, 96, 128};
-static const int kLaneCapB[kLaneClasses] = {42, 60, 78, 96, 114, 150};
-
 static int ensure_streams(elector_ctx *c)
 {
   if (c->aux_ready) return 0;
@@ -482,10 +464,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   constexpr int NB = 256;
   build_tiers();
   std::vector<int16_t> bin((size_t)n, -1);
-  std::vector<int8_t> lcls((size_t)n, -1);
-  // lane-per-window kernels: experimental, slower than the fused kernels at present
-  const bool use_lane = use_fused && !c->keep_graph && std::getenv("ELECTOR_LANE") != nullptr;
-  int64_t key_cnt[NB + 1] = {0}, n_generic = 0, lane_cnt[kLaneClasses] = {0};
+  int64_t key_cnt[NB + 1] = {0}, n_generic = 0;
   std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)5 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc
   int64_t *bin_max_lr = bin_need_a.data() + kBins, *bin_max_lc = bin_max_lr + kBins, *bin_max_lu = bin_max_lc + kBins,
           *bin_max_po = bin_max_lu + kBins;
@@ -510,9 +489,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   std::atomic<int> bad_offsets(0);
   {
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
-    // per thread: size keys, bin counts, lane classes, generic count, then per bin the maxima of
+    // per thread: size keys, bin counts, generic count, then per bin the maxima of
     // alignment #1's slot need, Lr, Lc, Lu and Lr + Lc (the bound on |PO|)
-    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + kLaneClasses + 1 + 5 * kBins, 0));
+    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + 1 + 5 * kBins, 0));
     auto work = [&](int t) {
       const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
       int64_t *cnt = tcnt[(size_t)t].data();
@@ -528,10 +507,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           st = ELECTOR_W_TOOLONG;
         h_status[w] = st;
         h_mv1[w] = h_mv2[w] = -1;
-        if (!st && use_lane && lr <= kLaneCapA[kLaneClasses - 1] && lc <= 1023 && lu <= 1023) {
-          for (int k = 0; k < kLaneClasses; ++k)
-            if (lr <= kLaneCapA[k]) { lcls[(size_t)w] = (int8_t)k; cnt[NB + kBins + k]++; break; }
-        } else if (!st && use_fused) {
+        if (!st && use_fused) {
           // one class for both fused kernels; |PO| is not known yet: typical growth estimate, windows
           // whose graph turns out larger are handed back by the device (k_left_b)
           const int rows = (int)std::max(lc, lu);
@@ -556,7 +532,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
             }
             const int b = ci * kNT + t;
             bin[(size_t)w] = (int16_t)b;
-            int64_t *mx = cnt + NB + kBins + kLaneClasses + 1 + b;         // alignment #1 needs less than the class slot
+            int64_t *mx = cnt + NB + kBins + 1 + b;         // alignment #1 needs less than the class slot
             mx[0] = std::max<int64_t>(mx[0], need_a);
             mx[kBins] = std::max<int64_t>(mx[kBins], lr);
             mx[2 * kBins] = std::max<int64_t>(mx[2 * kBins], lc);
@@ -565,7 +541,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           }
         }
         if (bin[(size_t)w] >= 0) cnt[NB + bin[(size_t)w]]++;
-        else if (lcls[(size_t)w] < 0) cnt[NB + kBins + kLaneClasses]++;   // generic (incl. failed windows)
+        else cnt[NB + kBins]++;                           // generic (incl. failed windows)
         const int64_t mlen = std::max(lr, lu);
         int k = (int)(mlen >> 3);
         if (k >= NB) k = NB - 1;
@@ -580,9 +556,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     for (int t = 0; t < T; ++t) {
       for (int k = 0; k < NB; ++k) key_cnt[k + 1] += tcnt[(size_t)t][(size_t)k];
       for (int b = 0; b < kBins; ++b) bin_cnt[b] += tcnt[(size_t)t][(size_t)(NB + b)];
-      for (int k = 0; k < kLaneClasses; ++k) lane_cnt[k] += tcnt[(size_t)t][(size_t)(NB + kBins + k)];
-      n_generic += tcnt[(size_t)t][(size_t)(NB + kBins + kLaneClasses)];
-      for (int b = 0; b < 5 * kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + kLaneClasses + 1 + b)]);
+      n_generic += tcnt[(size_t)t][(size_t)(NB + kBins)];
+      for (int b = 0; b < 5 * kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + 1 + b)]);
     }
   }
   if (bad_offsets.load()) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
@@ -646,51 +621,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       const uint32_t w = order[(size_t)k];
       const int b = bin[w];
       if (b >= 0) h_list[pos[(size_t)bin_final[(size_t)b]]++] = w;
-      else if (lcls[w] < 0) h_generic[gpos++] = w;
-    }
-  }
-  // lane-per-window classes: 64 windows per wave, sorted so that a wave's windows have nearly
-  // the same reference and uncorrected lengths (counting sort on (Lr, Lu/4), longest first)
-  int64_t lane_first[kLaneClasses + 1];
-  lane_first[0] = bin_first[kBins];
-  for (int k = 0; k < kLaneClasses; ++k) lane_first[k + 1] = lane_first[k] + lane_cnt[k];
-  const int64_t n_lane = lane_first[kLaneClasses] - lane_first[0];
-  std::vector<int64_t> lane_mvoff_a, lane_mvoff_b;
-  std::vector<int32_t> lane_dims;
-  int64_t lane_blk_first[kLaneClasses + 1] = {0};
-  int64_t lane_dwords = 0;
-  if (n_lane) {
-    constexpr int KB = (128 + 1) * 256;
-    std::vector<int64_t> kc((size_t)KB + 1, 0);
-    auto lkey = [&](int64_t w) {
-      const int lr = (int)(off[3 * w + 1] - off[3 * w]);
-      const int lu4 = (int)std::min<int64_t>((off[3 * w + 3] - off[3 * w + 2]) >> 2, 255);
-      return (KB - 1) - (lr * 256 + lu4);               // descending
-    };
-    for (int64_t w = 0; w < n; ++w) if (lcls[(size_t)w] >= 0) kc[(size_t)lkey(w) + 1]++;
-    for (int k = 0; k < KB; ++k) kc[(size_t)k + 1] += kc[(size_t)k];
-    // classes are contiguous Lr ranges, so one global sort keeps them contiguous too (largest class first)
-    std::vector<uint32_t> tmp((size_t)n_lane);
-    for (int64_t w = 0; w < n; ++w) if (lcls[(size_t)w] >= 0) tmp[(size_t)kc[(size_t)lkey(w)]++] = (uint32_t)w;
-    // place per class (descending within class)
-    int64_t pos[kLaneClasses];
-    for (int k = 0; k < kLaneClasses; ++k) pos[k] = lane_first[k];
-    for (int64_t i = 0; i < n_lane; ++i) { const uint32_t w = tmp[(size_t)i]; h_list[pos[lcls[w]]++] = w; }
-    // per wave: maxima and moves tiles
-    for (int k = 0; k < kLaneClasses; ++k) {
-      lane_blk_first[k + 1] = lane_blk_first[k] + (lane_cnt[k] + 63) / 64;
-      for (int64_t b0 = lane_first[k]; b0 < lane_first[k + 1]; b0 += 64) {
-        int32_t mr = 0, mc = 0, mu = 0, mb = 0;
-        for (int64_t i = b0; i < std::min(b0 + 64, lane_first[k + 1]); ++i) {
-          const int64_t w = h_list[i];
-          const int32_t lr = (int32_t)(off[3 * w + 1] - off[3 * w]), lc = (int32_t)(off[3 * w + 2] - off[3 * w + 1]),
-                        lu = (int32_t)(off[3 * w + 3] - off[3 * w + 2]);
-          mr = std::max(mr, lr); mc = std::max(mc, lc); mu = std::max(mu, lu); mb = std::max(mb, lr + lc);
-        }
-        lane_dims.push_back(mr); lane_dims.push_back(mc); lane_dims.push_back(mu); lane_dims.push_back(mb);
-        lane_mvoff_a.push_back(lane_dwords); lane_dwords += (int64_t)mc * ((mr + 7) / 8) * 64;
-        lane_mvoff_b.push_back(lane_dwords); lane_dwords += (int64_t)mu * ((mb + 7) / 8) * 64;
-      }
+      else h_generic[gpos++] = w;
     }
   }
   if (std::getenv("ELECTOR_DEBUG_BINS")) {
@@ -698,8 +629,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     for (int b = 0; b < kBins; ++b)
       if (bin_cnt[(size_t)b])
         std::fprintf(stderr, " G%dxR%d/%d:%lld", kClsG[b / kNT], kClsR[b / kNT], g_tier_bytes[b % kNT], (long long)bin_cnt[(size_t)b]);
-    for (int k = 0; k < kLaneClasses; ++k) std::fprintf(stderr, " L%d:%lld", kLaneCapA[k], (long long)lane_cnt[k]);
-    std::fprintf(stderr, " lane scratch %.1f MB\n", lane_dwords * 4e-6);
+    std::fprintf(stderr, "\n");
   }
   const double tp2 = now_ms();
   // moves scratch of the generic-path windows, in chunks
@@ -792,8 +722,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_perm.ensure((size_t)n * 4 + 64) | c->d_mv1.ensure((size_t)n * 8) |
        c->d_mv2.ensure((size_t)n * 8) | c->d_sym.ensure((size_t)total + 64) | c->d_xinfo.ensure(nodes * 8) |
        c->d_ring1.ensure(nodes * 2) | c->d_map16.ensure(nodes * 2) | c->d_carry.ensure(nodes * 4) |
-       c->d_moves.ensure((size_t)(max_dwords + bump_dwords + lane_dwords) * 4 + 1024) |
-       c->d_lanemeta.ensure(lane_dims.size() * 4 + lane_mvoff_a.size() * 16 + 64) | c->d_n1.ensure((size_t)n * 4) |
+       c->d_moves.ensure((size_t)(max_dwords + bump_dwords) * 4 + 1024) | c->d_n1.ensure((size_t)n * 4) |
        c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
        c->d_bx2.ensure((size_t)n * 4) |
        c->d_list.ensure((size_t)3 * n * 4 + (size_t)kBins * 32 + part_chunks_max * 20 + 64) |
@@ -846,18 +775,6 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemcpyAsync(c->d_off.p, h_off, (size_t)(3 * n + 1) * 8, hipMemcpyHostToDevice, st));
   if (n_generic) HIPCHK(c, hipMemcpyAsync(d_generic, h_generic, (size_t)n_generic * 4, hipMemcpyHostToDevice, st));
   if (n - n_generic) HIPCHK(c, hipMemcpyAsync(d_lists, h_list, (size_t)(n - n_generic) * 4, hipMemcpyHostToDevice, st));
-  const size_t nblk = lane_mvoff_a.size();
-  int64_t *d_lane_mva = c->d_lanemeta.as<int64_t>(), *d_lane_mvb = d_lane_mva + nblk;
-  int32_t *d_lane_dims = reinterpret_cast<int32_t *>(d_lane_mvb + nblk);
-  if (nblk) {
-    // tiles live after the generic chunk scratch and the bump region
-    for (auto &v : lane_mvoff_a) v += max_dwords + bump_dwords;
-    for (auto &v : lane_mvoff_b) v += max_dwords + bump_dwords;
-    HIPCHK(c, hipMemcpyAsync(d_lane_mva, lane_mvoff_a.data(), nblk * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_lane_mvb, lane_mvoff_b.data(), nblk * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_lane_dims, lane_dims.data(), nblk * 16, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));      // the host vectors go out of scope before the copies would run
-  }
   HIPCHK(c, hipMemcpyAsync(c->d_mv1.p, h_mv1, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -910,36 +827,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   }
   const uint32_t *d_fused_lists = use_trivial ? d_lists2 : d_lists;
 
-  // ---- fused classes: one stream per class chain (A then B), all concurrent ----
+  // ---- fused classes: launch chains on the auxiliary streams (A then B of each bin) ----
   if (use_fused && n > n_generic) {
     HIPCHK(c, hipEventRecord(c->fork, st));
-    int used = 0;
-    for (int k = kLaneClasses - 1; k >= 0; --k) {
-      if (!lane_cnt[k]) continue;
-      hipStream_t sx = c->aux[3];
-      LaneArgs la;
-      la.b = a;
-      la.list = d_lists + lane_first[k];
-      la.nlist = lane_cnt[k];
-      la.dims = d_lane_dims + 4 * lane_blk_first[k];
-      la.done_a = d_done_a;
-      la.done_b = d_done_b;
-      la.mv_off = d_lane_mva + lane_blk_first[k];
-      la.cap = kLaneCapA[k];
-      timed_begin(c, 0, sx);
-      if (launch_lane_a(la, sx)) return fail(c, ELECTOR_E_HIP, "lane kernel attribute");
-      timed_end(c, sx);
-      la.mv_off = d_lane_mvb + lane_blk_first[k];
-      la.cap = kLaneCapB[k];
-      timed_begin(c, 1, sx);
-      if (launch_lane_b(la, sx)) return fail(c, ELECTOR_E_HIP, "lane kernel attribute");
-      timed_end(c, sx);
-    }
-    // one stream per group size: the few long-running big-window launches (G = 64) form one
-    // chain that overlaps with the bulk classes on the other streams (the runtime maps streams
-    // to a handful of hardware queues, so more streams than this do not run concurrently)
-    used = std::max(used, 4);
-    for (int k = 0; k < 4; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
+    const int used = n_chains;                         // launch chains = auxiliary streams in use
+    for (int k = 0; k < used; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
     // ELECTOR_LAUNCH_ORDER=ab (experiment): per stream all alignment #1 launches first, then all #2
     static const bool split_ab = std::getenv("ELECTOR_LAUNCH_ORDER") && std::string(std::getenv("ELECTOR_LAUNCH_ORDER")) == "ab";
     for (int pass = 0; pass < (split_ab ? 2 : 1); ++pass)

@@ -1,5 +1,5 @@
 // elector_amd/csrc/poa_serial.h -- the per-window serial stages shared by the
-// generic kernels (poa_kernels.hip) and the lane-per-window kernels (poa_lane.hip):
+// generic kernels (poa_kernels.hip):
 // traceback (align_lpo_po2.c:108-168), fusion (lpo.c:413-463,602-656) and MSA
 // column emission (lpo_format.c:337-393).  One lane = one window; the caller
 // supplies a reader for the move nibble of DP cell (row ii, column jj), both 1-based.
