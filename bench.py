@@ -120,6 +120,17 @@ def pmc_traffic(kernel, reads):
         return None
 
 
+def pmc_valu(reads):
+    """Wavefront-VALU instructions per step of the two fused kernel families (SQ_INSTS_VALU, same
+    committed PMC passes); None when the workload differs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        return int(t["valu_wave_insts_per_step"]) if int(t["reads_per_gpu"]) == int(reads) else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -258,6 +269,12 @@ def main():
                          "traffic": traffic,
                          "launches": int(launches), "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+            # what actually binds: VALU issue.  peak = 256 CUs x 4 SIMDs x one wavefront
+            # instruction per 4 cycles at 2.4 GHz; insts from the committed PMC passes, time measured live
+            "roofline_valu": (lambda v: None if v is None else {
+                "bound": "valu-issue", "wave_insts_per_step": v, "peak": 614.4, "unit": "G wave-insts/s",
+                "achieved": round(v * world / (dt_max / args.steps) / 1e9, 1),
+                "frac": round(v / (dt_max / args.steps) / 614.4e9, 4)})(pmc_valu(args.reads)),
             "reads_gathered": int(counters.shape[0]),
             "counters_checksum": int(counters[:, :ES_NCOUNTERS - 1].sum()),
         }
