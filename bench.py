@@ -35,6 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+WORKLOADS = {   # BASELINE.json configs restated as synthetic profiles (elector_amd/synthetic.py)
+    "ecoli30x_simlord_lordec": "E. coli 30X SimLord-like PacBio (15% err), LoRDEC-like corrected (1% err), ~8 kb reads",
+    "yeast50x_nanosim_consent": "S. cerevisiae 50X NanoSim-like ONT (12% err), CONSENT-like corrected (2% err), ~8 kb reads",
+    "chr1_20x_ont_50kb": "Human chr1 20X NanoSim-like ONT (12% err), corrected (2% err), ~50 kb reads",
+}
 
 
 def parse():
@@ -253,9 +258,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "E. coli 30X SimLord-like PacBio (15%% err), LoRDEC-like corrected (1%% err): "
-                                   "%d reads x ~8 kb per GPU per step, cut into windows by the ELECTOR splitter rules"
-                                   % args.reads,
+            "config": {"workload": "%s: %d reads per GPU per step, cut into windows by the ELECTOR splitter rules"
+                                   % (WORKLOADS.get(args.profile, args.profile), args.reads),
                        "profile": args.profile, "reads_per_gpu": args.reads, "windows_per_gpu": n,
                        "ref_bases_per_gpu": read_bases, "parallelism": "shard-by-read x%d" % world},
             "gcups": round(cells_all * args.steps / dt_max / 1e9, 3),
