@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("ELECTOR_BENCH_READS", "4000")),
-                    help="synthetic long reads per rank and step")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("ELECTOR_BENCH_READS", "10001")),
+                    help="synthetic long reads per rank and step (10,001 = one batch of ELECTOR's own protocol, "
+                         "elector/alignment.py:82, Master_Splitter.cpp:397-399)")
     ap.add_argument("--profile", default="ecoli30x_simlord_lordec")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
