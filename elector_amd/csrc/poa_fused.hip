@@ -41,6 +41,7 @@ struct FusedArgs {
   uint8_t *mv_pool;         // moves scratch of this launch: [block][mv_ns strips][mv_tw steps][64 lanes] words
   int mv_tw, mv_ns;
   const int32_t *nlist_dev; // k_fused_a: when set, only the first *nlist_dev windows of the list still need it
+  const uint8_t *triv;      // k_fused_b: when set, triv[w] = the graph of window w is a plain chain (k_trivial)
 };
 
 __device__ __forceinline__ int row_shr1(int old, int v)
@@ -665,8 +666,59 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   nsmax = __builtin_amdgcn_readfirstlane(nsmax);
 
   int best = kNeg, bestx = -1;
+  int dbg_one = 0, dbg_two = 0;                 // diagnostics (debug bit 5): steps on the one- / two-predecessor path
   const int gstar = ((Lu - 1) % RS) / R, kstar = ((Lu - 1) % RS) % R;
   if (a.debug & 1) nsmax = 0;
+  // A wavefront whose windows all have a plain chain as their graph (k_trivial: corrected = reference;
+  // the partition puts such windows side by side) needs no predecessor ring: every node's only
+  // predecessor is the previous column, so the cells left of and above-left of a lane's block are its
+  // own registers and the DPP value of the step before -- the recurrence of k_fused_a, at a third of
+  // the per-step overhead.  Same moves, same borders, same end cell (the chain's last node is its only
+  // FINAL one), so everything after the loop is shared.
+  const bool chain_wave = a.triv != nullptr && nsmax == 1 && !(a.debug & 128) &&
+                          __builtin_amdgcn_ballot_w64(valid && a.triv[w] == 0) == 0;
+  if (chain_wave) {
+    int yl[R], S[R], Ex[R], Ey[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int ii = R * g + 1 + k;
+      yl[k] = (valid && ii <= Lu) ? ys[ii - 1] : 255;
+      S[k] = -(kp.open_y + (ii - 1) * kp.ext_y);           // column -1: ii gap steps from the origin
+      Ex[k] = S[k] - kp.ext_x;
+      Ey[k] = S[k] - kp.ext_y;
+    }
+    int dg0 = (g == 0) ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y);   // cell (row above, column -1)
+    int xl_next = (valid && g == 0 && n1 >= 1) ? (int)((xinfo[1] >> 8) & 0xFF) : 0;
+    for (int t = 1; t <= tmax; ++t) {
+      const int bS = -(kp.open_x + (t - 1) * kp.ext_x), bEy = bS - kp.ext_y;   // the virtual row over a chain
+      const int upS = shift_in<G>(bS, S[R - 1], g);
+      const int upEy = shift_in<G>(bEy, Ey[R - 1], g);
+      const int jj = t - g;
+      const int xl = xl_next;
+      xl_next = (valid && jj >= 0 && jj < n1) ? (int)((xinfo[jj + 1] >> 8) & 0xFF) : 0;
+      if (valid && jj >= 1 && jj <= n1) {
+        int diag = dg0, insY = upEy;
+        uint32_t mv8 = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const int oldS = S[k];
+          const CellOut c = cell_1pred(diag, Ex[k], insY, xl == yl[k] ? kp.match : kp.mismatch);
+          S[k] = c.S;
+          Ex[k] = c.S - (c.m ? kp.open_x : kp.ext_x);
+          Ey[k] = c.S - (c.m ? kp.open_y : kp.ext_y);
+          mv8 |= ((c.nib & 1) | (c.nib >> 1)) << (2 * k);    // 2 bits: bit0 = x step, bit1 = y step
+          diag = oldS; insY = Ey[k];
+        }
+        dg0 = upS;
+        mv[t * 64 + lane] = (mv_t)mv8;
+      }
+    }
+    if (valid && g == gstar) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) if (k == kstar) best = S[k];
+      bestx = n1 - 1;
+    }
+  } else
   for (int s = 0; s < nsmax; ++s) {
     const bool sv = valid && s < ns;
     const int16_t *bcur = (s & 1) ? bnd1 : bnd0;
@@ -783,8 +835,8 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
           }
         }
       };
-      if (__builtin_amdgcn_ballot_w64(has2) != 0) cells(std::true_type{});
-      else cells(std::false_type{});
+      if (__builtin_amdgcn_ballot_w64(has2) != 0) { cells(std::true_type{}); if ((a.debug & 32) && lane == 0) ++dbg_two; }
+      else { cells(std::false_type{}); if ((a.debug & 32) && lane == 0) ++dbg_one; }
       if (act) {
 #pragma unroll
         for (int k = 0; k < R; ++k) { S[k] = nS[k]; M[k] = nM[k]; }
@@ -810,6 +862,10 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
     __builtin_amdgcn_wave_barrier();
   }
 
+  if ((a.debug & 32) && lane == 0) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 14, (unsigned long long)dbg_one);
+    atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 15, (unsigned long long)dbg_two);
+  }
   if (valid && g == gstar) { hdr[2] = best; hdr[3] = bestx; }
   if (valid) {
     uint16_t *x2y = reinterpret_cast<uint16_t *>(slot + W.off_x2y);

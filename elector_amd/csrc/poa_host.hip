@@ -46,6 +46,7 @@ struct FusedArgs {
   uint8_t *mv_pool;
   int mv_tw, mv_ns;
   const int32_t *nlist_dev;
+  const uint8_t *triv;
 };
 int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
 int launch_fused_b(const FusedArgs &a, int G, int R, int D, hipStream_t st);
@@ -851,6 +852,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       fa.rowinit = reinterpret_cast<int32_t *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b);   // phase stamps (debug)
       fa.debug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
       fa.keep_map = c->keep_graph ? 1 : 0;
+      fa.triv = use_trivial ? d_triv : nullptr;
       fa.slot_bytes = (int)((bin_need_a[(size_t)b] + 127) & ~(int64_t)127);   // alignment #1: the bin's own maximum
       fa.mv_pool = c->d_fmv.as<uint8_t>();
       for (int k = 0; k < sk; ++k) fa.mv_pool += fmv_stream[k];
@@ -948,6 +950,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     {
       unsigned long long hist[16] = {0};
       for (int b = 0; b < kBins; ++b) for (int k = 0; k < 16; ++k) hist[k] += hs[32 * (size_t)b + 16 + k];
+      unsigned long long one = 0, two = 0;
+      for (int b = 0; b < kBins; ++b) { one += hs[32 * (size_t)b + 14]; two += hs[32 * (size_t)b + 15]; }
+      std::fprintf(stderr, "[elector] k_fused_b steps on the one-predecessor path %llu, on the two-predecessor path %llu\n", one, two);
       std::fprintf(stderr, "[elector] ring depth needed (max predecessor distance + 2), windows:");
       for (int k = 0; k < 16; ++k) std::fprintf(stderr, " %d:%llu", k, hist[k]);
       std::fprintf(stderr, "\n");
