@@ -30,9 +30,10 @@ void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uin
                    unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, hipStream_t st);
 void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
                  uint8_t *rows, int64_t n, hipStream_t st);
-void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, hipStream_t st);
+void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, hipStream_t st);
+int partition_buckets();
 void launch_partition(const uint32_t *in, uint32_t *out, const int64_t *bins, int nbins, const void *chunks, int nchunks,
-                      const int32_t *bin_chunks, const uint8_t *triv, int32_t *chunk_need, int32_t *count, hipStream_t st);
+                      const int32_t *bin_chunks, const uint8_t *pkey, int32_t *chunk_cnt, int32_t *count, hipStream_t st);
 struct FusedArgs {
   BatchArgs b;
   const uint32_t *list;
@@ -726,8 +727,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
        c->d_moves.ensure((size_t)(max_dwords + bump_dwords) * 4 + 1024) | c->d_n1.ensure((size_t)n * 4) |
        c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
        c->d_bx2.ensure((size_t)n * 4) |
-       c->d_list.ensure((size_t)3 * n * 4 + (size_t)kBins * 32 + part_chunks_max * 20 + 64) |
-       c->d_done.ensure((size_t)3 * n + 64) |
+       c->d_list.ensure((size_t)3 * n * 4 + (size_t)kBins * 32 + part_chunks_max * (16 + 4 * (size_t)partition_buckets()) + 64) |
+       c->d_done.ensure((size_t)4 * n + 64) |
        c->d_rowinit.ensure(1024 + 256 * (size_t)kBins) |
        c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256);
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
@@ -743,7 +744,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   int64_t *d_chunks = d_bins + 2 * kBins;
   int32_t *d_bin_need = reinterpret_cast<int32_t *>(d_chunks + 2 * part_chunks_max);
   int32_t *d_bin_chunks = d_bin_need + kBins, *d_chunk_need = d_bin_chunks + 2 * kBins;
-  uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n, *d_triv = d_done_b + n;
+  uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n, *d_triv = d_done_b + n, *d_pkey = d_triv + n;
   // alignment #1 without a dynamic program for windows whose corrected sequence equals the reference:
   // valid when the diagonal is strictly best (see k_trivial)
   const bool use_trivial = use_fused && !std::getenv("ELECTOR_NO_TRIVIAL") && c->kp.match >= 0 &&
@@ -780,7 +781,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipEventRecord(h_done, st));
-  HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)3 * n, st));
+  HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)4 * n, st));
   HIPCHK(c, hipMemsetAsync(d_counters, 0, 16, st));
   if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 256 * (size_t)kBins, st));
 
@@ -822,8 +823,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   if (use_trivial) {
     a.n = n;
     timed_begin(c, 2, st);
-    launch_trivial(a, d_done_a, d_triv, st);
-    launch_partition(d_lists, d_lists2, d_bins, nbins_used, d_chunks, nchunks, d_bin_chunks, d_triv, d_chunk_need, d_bin_need, st);
+    launch_trivial(a, d_done_a, d_triv, d_pkey, st);
+    launch_partition(d_lists, d_lists2, d_bins, nbins_used, d_chunks, nchunks, d_bin_chunks, d_pkey, d_chunk_need, d_bin_need, st);
     timed_end(c, st);
   }
   const uint32_t *d_fused_lists = use_trivial ? d_lists2 : d_lists;

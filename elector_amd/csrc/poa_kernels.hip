@@ -361,19 +361,26 @@ __global__ void __launch_bounds__(256) k_left_b(BatchArgs a, uint32_t *list, int
 // traceback (align_lpo_po2.c:108-168) pairs letter i with letter i and the fusion (lpo.c:602-656)
 // gives the plain chain with every node holding both letters.  8 lanes per window compare the two
 // symbol strings and, when equal, write that chain; the window is then marked done for alignment #1.
-__global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv)
+// The windows that do need alignment #1 get a sort key: the 8-column bucket of the first letter at which
+// corrected and reference differ, i.e. where their graph will have its first two-predecessor node.
+// Wavefronts of k_fused_b whose windows reach such nodes at the same steps take its two-predecessor
+// path together instead of one after the other.
+constexpr int kPartBuckets = 16;        // 0..14: first difference in columns 8k..8k+7 (14: beyond), 15: trivial
+
+__global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey)
 {
   const int64_t w = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
   const int g = threadIdx.x & 7;
   if (w >= a.n) return;
   const int64_t o0 = a.off[3 * w], o1 = a.off[3 * w + 1], o2 = a.off[3 * w + 2];
   const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1);
-  bool eq = a.status[w] == 0 && Lr == Lc;
   const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
-  if (eq)
-    for (int i = g; i < Lr; i += 8) eq = eq && xs[i] == ys[i];
-  for (int d = 1; d < 8; d <<= 1) eq = __shfl_xor(eq ? 1 : 0, d, 8) != 0 && eq;
-  if (g == 0) triv[w] = eq ? 1 : 0;
+  const int nmin = min(Lr, Lc);
+  int fd = nmin;                                            // first index at which the two strings differ
+  for (int i = g; i < nmin && i < fd; i += 8) if (xs[i] != ys[i]) fd = i;
+  for (int d = 1; d < 8; d <<= 1) fd = min(fd, __shfl_xor(fd, d, 8));
+  const bool eq = a.status[w] == 0 && Lr == Lc && fd == nmin;
+  if (g == 0) { triv[w] = eq ? 1 : 0; pkey[w] = (uint8_t)(eq ? kPartBuckets - 1 : min(fd >> 3, kPartBuckets - 2)); }
   if (!eq) return;
   const int64_t nb = o0 + w;
   for (int n = g; n < Lr; n += 8) {
@@ -389,73 +396,75 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
   }
 }
 
-// Stable partition of every launch bin's window list: windows that still need alignment #1 first,
-// the trivial ones after them; count[bin] = how many need it.  Three small launches over chunks of
-// kPartChunk list entries: per-chunk counts, a scan over each bin's chunks, the scatter.
-// chunk table (host-built): first list index, length, bin slot, index of the bin's first chunk
+// Stable bucket sort of every launch bin's window list by pkey (so: windows that still need alignment
+// #1 first, ordered by where their first bubble will be; the trivial ones after them); count[bin] =
+// how many need alignment #1.  Three small launches over chunks of kPartChunk list entries: per-chunk
+// bucket counts, a scan over each bin's (bucket, chunk) pairs, the scatter.
+// chunk table (host-built): first list index, length, bin slot
 struct PartChunk { int64_t first; int32_t len, bin; };
 
 __global__ void __launch_bounds__(256) k_part_count(const uint32_t *__restrict__ in, const PartChunk *__restrict__ chunks,
-                                                    const uint8_t *__restrict__ triv, int32_t *__restrict__ chunk_need)
+                                                    const uint8_t *__restrict__ pkey, int32_t *__restrict__ chunk_cnt)
 {
-  __shared__ int s_wave[4];
+  __shared__ int s_cnt[kPartBuckets];
   const PartChunk ch = chunks[blockIdx.x];
-  int mine = 0;
-  for (int i = threadIdx.x; i < ch.len; i += 256) mine += triv[in[ch.first + i]] ? 0 : 1;
-  for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
-  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = mine;
+  if (threadIdx.x < kPartBuckets) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  if (threadIdx.x == 0) chunk_need[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  for (int i = threadIdx.x; i < ch.len; i += 256) atomicAdd(&s_cnt[pkey[in[ch.first + i]]], 1);
+  __syncthreads();
+  if (threadIdx.x < kPartBuckets) chunk_cnt[blockIdx.x * kPartBuckets + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
-// one wave per bin: exclusive scan of its chunks' counts (in place), total to count[bin]
+// one wave per bin: exclusive scan over its (bucket-major, chunk-minor) counts, in place;
+// the windows in front of the last bucket are the ones that need alignment #1
 __global__ void __launch_bounds__(64) k_part_scan(const int32_t *__restrict__ bin_chunks /* first chunk, #chunks per bin */,
-                                                  int32_t *__restrict__ chunk_need, int32_t *__restrict__ count)
+                                                  int32_t *__restrict__ chunk_cnt, int32_t *__restrict__ count)
 {
   const int c0 = bin_chunks[2 * blockIdx.x], nc = bin_chunks[2 * blockIdx.x + 1], lane = threadIdx.x;
   int run = 0;
-  for (int base = 0; base < nc; base += 64) {
-    const int i = base + lane;
-    const int v = i < nc ? chunk_need[c0 + i] : 0;
-    int inc = v;
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    if (i < nc) chunk_need[c0 + i] = run + inc - v;
-    run += __shfl(inc, 63);
+  for (int k = 0; k < kPartBuckets; ++k) {
+    if (k == kPartBuckets - 1 && lane == 0) count[blockIdx.x] = run;
+    for (int base = 0; base < nc; base += 64) {
+      const int i = base + lane;
+      const int v = i < nc ? chunk_cnt[(c0 + i) * kPartBuckets + k] : 0;
+      int inc = v;
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+      if (i < nc) chunk_cnt[(c0 + i) * kPartBuckets + k] = run + inc - v;
+      run += __shfl(inc, 63);
+    }
   }
-  if (lane == 0) count[blockIdx.x] = run;
 }
 
 __global__ void __launch_bounds__(256) k_part_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                       const PartChunk *__restrict__ chunks, const int64_t *__restrict__ bins,
-                                                      const uint8_t *__restrict__ triv, const int32_t *__restrict__ chunk_need,
-                                                      const int32_t *__restrict__ count)
+                                                      const uint8_t *__restrict__ pkey, const int32_t *__restrict__ chunk_base)
 {
-  __shared__ int s_wave[4], s_base;
+  __shared__ int s_wave[4][kPartBuckets], s_run[kPartBuckets];
   const PartChunk ch = chunks[blockIdx.x];
   const int64_t bin_first = bins[2 * ch.bin];
-  const int n_need = count[ch.bin], need_before = chunk_need[blockIdx.x];
-  const int idx0 = (int)(ch.first - bin_first);                 // entries of the bin before this chunk
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if (tid == 0) s_base = 0;
+  if (tid < kPartBuckets) s_run[tid] = chunk_base[blockIdx.x * kPartBuckets + tid];
   __syncthreads();
   for (int i0 = 0; i0 < ch.len; i0 += 256) {
     const int i = i0 + tid;
     const bool in_range = i < ch.len;
     const uint32_t w = in_range ? in[ch.first + i] : 0u;
-    const bool need = in_range && !triv[w];
-    const unsigned long long bm = __builtin_amdgcn_ballot_w64(need);
+    const int key = in_range ? (int)pkey[w] : -1;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    if (lane == 0) s_wave[wave] = __builtin_popcountll(bm);
+    int rank = 0;
+    for (int k = 0; k < kPartBuckets; ++k) {
+      const unsigned long long bm = __builtin_amdgcn_ballot_w64(key == k);
+      if (lane == 0) s_wave[wave][k] = __builtin_popcountll(bm);
+      if (key == k) rank = __builtin_popcountll(bm & below);
+    }
     __syncthreads();
-    int rank = s_base + __builtin_popcountll(bm & below), round = 0;
-    for (int k = 0; k < 4; ++k) { if (k < wave) rank += s_wave[k]; round += s_wave[k]; }
     if (in_range) {
-      const int64_t pos = need ? (int64_t)need_before + rank
-                               : (int64_t)n_need + (idx0 + i - (need_before + rank));   // trivial entries before this one
+      int pos = s_run[key] + rank;
+      for (int q = 0; q < wave; ++q) pos += s_wave[q][key];
       out[bin_first + pos] = w;
     }
     __syncthreads();
-    if (tid == 0) s_base += round;
+    if (tid < kPartBuckets) s_run[tid] += s_wave[0][tid] + s_wave[1][tid] + s_wave[2][tid] + s_wave[3][tid];
     __syncthreads();
   }
 }
@@ -537,20 +546,22 @@ void launch_fuse2(const BatchArgs &a, hipStream_t st)
   hipLaunchKernelGGL(k_fuse2, dim3(list_grid(a, 64, 256)), dim3(64), 0, st, a);
 }
 
-void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, hipStream_t st)
+void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, hipStream_t st)
 {
   if (a.n <= 0) return;
-  hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv);
+  hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv, pkey);
 }
 
+int partition_buckets() { return kPartBuckets; }
+
 void launch_partition(const uint32_t *in, uint32_t *out, const int64_t *bins, int nbins, const void *chunks, int nchunks,
-                      const int32_t *bin_chunks, const uint8_t *triv, int32_t *chunk_need, int32_t *count, hipStream_t st)
+                      const int32_t *bin_chunks, const uint8_t *pkey, int32_t *chunk_cnt, int32_t *count, hipStream_t st)
 {
   if (nbins <= 0 || nchunks <= 0) return;
   const PartChunk *ch = reinterpret_cast<const PartChunk *>(chunks);
-  hipLaunchKernelGGL(k_part_count, dim3((unsigned)nchunks), dim3(256), 0, st, in, ch, triv, chunk_need);
-  hipLaunchKernelGGL(k_part_scan, dim3((unsigned)nbins), dim3(64), 0, st, bin_chunks, chunk_need, count);
-  hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)nchunks), dim3(256), 0, st, in, out, ch, bins, triv, chunk_need, count);
+  hipLaunchKernelGGL(k_part_count, dim3((unsigned)nchunks), dim3(256), 0, st, in, ch, pkey, chunk_cnt);
+  hipLaunchKernelGGL(k_part_scan, dim3((unsigned)nbins), dim3(64), 0, st, bin_chunks, chunk_cnt, count);
+  hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)nchunks), dim3(256), 0, st, in, out, ch, bins, pkey, chunk_cnt);
 }
 
 void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
