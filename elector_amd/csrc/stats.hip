@@ -58,17 +58,23 @@ __global__ void __launch_bounds__(kStatsThreads) k_merge(MergeArgs a)
   const int64_t p = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t w0 = a.piece_first[p], w1 = a.piece_first[p + 1];
-  // surviving columns per window (Donatello.cpp:13-31)
-  for (int64_t w = w0 + wave; w < w1; w += kStatsThreads / 64) {
+  // surviving columns per window (Donatello.cpp:13-31).  The kernel is bound by the latency of its
+  // dependent loads (window descriptor -> columns), so every wave works on FOUR windows at a time, 16
+  // lanes each, and fetches 64 columns of a window (nearly always all of it) before it looks at them.
+  constexpr int kGroups = 4 * (kStatsThreads / 64);            // windows in flight per block
+  const int grp = tid >> 4, gl = tid & 15, gshift = (lane >> 4) * 16;
+  for (int64_t w = w0 + grp; w < w1; w += kGroups) {
     const int nc = a.status[w] == 0 ? a.ncol[w] : 0;
     const uint8_t *src = a.cols_in + 3 * a.off[3 * w];
     int cnt = 0;
     for (int c0 = 0; c0 < nc; c0 += 64) {
-      const int c = c0 + lane;
-      const bool keep = c < nc && src[3 * c + 1] != 'n';
-      cnt += __popcll(__ballot(keep));
+      uint8_t y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int c = c0 + 16 * u + gl; y[u] = c < nc ? src[3 * c + 1] : (uint8_t)'n'; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cnt += __popcll((__ballot(y[u] != 'n') >> gshift) & 0xFFFFull);
     }
-    if (lane == 0) a.woff[w] = cnt;
+    if (gl == 0) a.woff[w] = cnt;
   }
   if (tid == 0) s_carry = 0;
   __syncthreads();
@@ -98,21 +104,28 @@ __global__ void __launch_bounds__(kStatsThreads) k_merge(MergeArgs a)
   const int64_t rb = 3 * a.off[3 * w0];
   if (tid == 0) { a.row_off[p] = rb; a.cols[p] = n; }
   uint8_t *d0 = a.rows + rb, *d1 = d0 + n, *d2 = d1 + n;
-  for (int64_t w = w0 + wave; w < w1; w += kStatsThreads / 64) {
+  for (int64_t w = w0 + grp; w < w1; w += kGroups) {
     const int nc = a.status[w] == 0 ? a.ncol[w] : 0;
     const uint8_t *src = a.cols_in + 3 * a.off[3 * w];
     int64_t k = a.woff[w];
     for (int c0 = 0; c0 < nc; c0 += 64) {
-      const int c = c0 + lane;
-      uint8_t x = 0, y = 'n', z = 0;
-      if (c < nc) { x = src[3 * c]; y = src[3 * c + 1]; z = src[3 * c + 2]; }
-      const bool keep = c < nc && y != 'n';
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        const int64_t at = k + __popcll(m & ((1ull << lane) - 1ull));
-        d0[at] = x; d1[at] = y; d2[at] = z;
+      uint8_t x[4], y[4], z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u + gl;
+        x[u] = 0; y[u] = 'n'; z[u] = 0;
+        if (c < nc) { x[u] = src[3 * c]; y[u] = src[3 * c + 1]; z[u] = src[3 * c + 2]; }
       }
-      k += __popcll(m);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool keep = y[u] != 'n';
+        const unsigned long long m = (__ballot(keep) >> gshift) & 0xFFFFull;
+        if (keep) {
+          const int64_t at = k + __popcll(m & ((1ull << gl) - 1ull));
+          d0[at] = x[u]; d1[at] = y[u]; d2[at] = z[u];
+        }
+        k += __popcll(m);
+      }
     }
   }
 }
