@@ -91,6 +91,23 @@ struct BatchArgs {
   const uint8_t *skip_a;        // 1 = alignment #1 / fusion #1 already done by the fused kernel
   const uint8_t *skip_b;        // 1 = alignment #2 / fusion #2 already done by the fused kernel
   uint8_t *mark_b;              // when set, k_fuse2 marks the windows it finishes
+  const uint8_t *tiled;         // per window: bit 0 = alignment #1, bit 1 = alignment #2 computed by the tiled kernels
+};
+
+// Long windows (the reference's whole-read fallback) are cut into tiles of one strip of 63 rows by
+// kTileCols columns; the tiles of one anti-diagonal (strip + column block) are independent and run
+// in one launch (k_dp1_tile / k_dp2_tile), so a window of many strips uses many wavefronts.
+constexpr int kTileCols = 2048;          // multiple of 64
+constexpr int kTileRing = 32;            // ring depth of the tiled alignment #2 (ring class 0 graphs)
+// per strip and column-block parity: 64 boundary cells (+ for alignment #2: the ring, best score / column)
+constexpr int kTileState1 = 64, kTileState2 = 64 + kTileRing * 64 + 64;
+
+struct TileArgs {
+  const uint32_t *wlist;        // the long windows of this pass
+  const int64_t *st_off;        // per long window: its state area in tstate (ints)
+  int32_t *tstate;
+  uint8_t *tiled;
+  int d;                        // anti-diagonal of this launch
 };
 
 // LDS bytes the fused kernels need for a window worked on by a group of G lanes with R rows

@@ -24,6 +24,8 @@ namespace elector {
 void launch_symbolize(const uint8_t *in, uint8_t *out, int64_t nbytes, const DevTables *tab, hipStream_t st);
 void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st);
 void launch_fuse1(const BatchArgs &a, hipStream_t st);
+void launch_dp1_tile(const BatchArgs &a, const TileArgs &ta, bool gen, int ntiles, int nw, hipStream_t st);
+void launch_dp2_tile(const BatchArgs &a, const TileArgs &ta, bool gen, int ntiles, int nw, hipStream_t st);
 void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st);
 void launch_fuse2(const BatchArgs &a, hipStream_t st);
 void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uint8_t *done_b, int64_t *mv2,
@@ -298,7 +300,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit,
-                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv};
+                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist};
   for (DevBuf *b : bufs) b->release();
   for (auto &s : c->st_slot) s.release();
   for (int k = 0; k < 2; ++k) {
@@ -728,7 +730,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
        c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
        c->d_bx2.ensure((size_t)n * 4) |
        c->d_list.ensure((size_t)3 * n * 4 + (size_t)kBins * 32 + part_chunks_max * (16 + 4 * (size_t)partition_buckets()) + 64) |
-       c->d_done.ensure((size_t)4 * n + 64) |
+       c->d_done.ensure((size_t)5 * n + 64) |
        c->d_rowinit.ensure(1024 + 256 * (size_t)kBins) |
        c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256);
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
@@ -744,7 +746,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   int64_t *d_chunks = d_bins + 2 * kBins;
   int32_t *d_bin_need = reinterpret_cast<int32_t *>(d_chunks + 2 * part_chunks_max);
   int32_t *d_bin_chunks = d_bin_need + kBins, *d_chunk_need = d_bin_chunks + 2 * kBins;
-  uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n, *d_triv = d_done_b + n, *d_pkey = d_triv + n;
+  uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n, *d_triv = d_done_b + n, *d_pkey = d_triv + n,
+          *d_tiled = d_pkey + n;
   // alignment #1 without a dynamic program for windows whose corrected sequence equals the reference:
   // valid when the diagonal is strictly best (see k_trivial)
   const bool use_trivial = use_fused && !std::getenv("ELECTOR_NO_TRIVIAL") && c->kp.match >= 0 &&
@@ -781,7 +784,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipEventRecord(h_done, st));
-  HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)4 * n, st));
+  HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)5 * n, st));
   HIPCHK(c, hipMemsetAsync(d_counters, 0, 16, st));
   if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 256 * (size_t)kBins, st));
 
@@ -819,6 +822,62 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   a.kp = c->kp;
   a.skip_a = d_done_a;
   a.skip_b = d_done_b;
+  a.tiled = d_tiled;
+
+  // Long windows of the generic path (the reference's whole-read fallback): both dynamic programs as
+  // tiles of 63 rows x kTileCols columns, one launch per tile anti-diagonal (k_dp1_tile / k_dp2_tile),
+  // so that one window keeps up to min(strips, column blocks) wavefronts busy instead of one.
+  const int64_t tile_cells = std::getenv("ELECTOR_TILE_CELLS") ? std::atoll(std::getenv("ELECTOR_TILE_CELLS")) : ((int64_t)1 << 24);
+  struct LongWin { uint32_t w; int lr, lc, lu; };
+  auto long_windows = [&](int64_t k0, int64_t k1) {
+    std::vector<LongWin> v;
+    for (int64_t k = k0; k < k1; ++k) {
+      const int64_t w = h_generic[k];
+      if (h_status[w]) continue;
+      const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1], lu = off[3 * w + 3] - off[3 * w + 2];
+      if (std::max(lr * lc, (lr + lc) * lu) >= tile_cells) v.push_back({(uint32_t)w, (int)lr, (int)lc, (int)lu});
+    }
+    return v;
+  };
+  // phase 1: zero the windows' moves, mark them, alignment #1 by tiles; phase 2 (after fusion #1): alignment #2
+  auto run_tiles = [&](const std::vector<LongWin> &lw, int phase) -> int {
+    if (lw.empty()) return 0;
+    const int nw = (int)lw.size();
+    std::vector<int64_t> st_off((size_t)nw);
+    std::vector<uint32_t> wl((size_t)nw);
+    int64_t ints = 0;
+    int max_d = 0, max_tiles = 1;
+    for (int k = 0; k < nw; ++k) {
+      const LongWin &x = lw[(size_t)k];
+      const int ns = n_strips(phase == 1 ? x.lc : x.lu);
+      const int ncb = ((phase == 1 ? x.lr : x.lr + x.lc) + kTileCols - 1) / kTileCols;
+      wl[(size_t)k] = x.w;
+      st_off[(size_t)k] = ints;
+      ints += (int64_t)ns * 2 * (phase == 1 ? kTileState1 : kTileState2);
+      max_d = std::max(max_d, ns + ncb - 2);
+      max_tiles = std::max(max_tiles, std::min(ns, ncb));
+    }
+    if (c->d_tstate.ensure((size_t)ints * 4 + 64) || c->d_tlist.ensure((size_t)nw * 12 + 64)) return ELECTOR_E_NOMEM;
+    HIPCHK(c, hipStreamSynchronize(st));                 // the small tables below are reused from batch to batch
+    uint32_t *d_wl = c->d_tlist.as<uint32_t>();
+    int64_t *d_so = reinterpret_cast<int64_t *>(c->d_tlist.as<uint8_t>() + (((size_t)nw * 4 + 7) & ~(size_t)7));
+    HIPCHK(c, hipMemcpy(d_wl, wl.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_so, st_off.data(), (size_t)nw * 8, hipMemcpyHostToDevice));
+    if (phase == 1)
+      for (const LongWin &x : lw) {
+        const int64_t d1 = (int64_t)n_strips(x.lc) * mv_tw(x.lr) * 64, d2 = (int64_t)n_strips(x.lu) * mv_tw(x.lr + x.lc) * 64;
+        HIPCHK(c, hipMemsetAsync(c->d_moves.as<uint32_t>() + h_mv1[x.w], 0, (size_t)(d1 + d2) * 4, st));
+        HIPCHK(c, hipMemsetAsync(d_tiled + x.w, 1, 1, st));
+      }
+    TileArgs ta;
+    ta.wlist = d_wl; ta.st_off = d_so; ta.tstate = c->d_tstate.as<int32_t>(); ta.tiled = d_tiled;
+    for (int d = 0; d <= max_d; ++d) {
+      ta.d = d;
+      if (phase == 1) launch_dp1_tile(a, ta, c->gen, max_tiles, nw, st);
+      else launch_dp2_tile(a, ta, c->gen, max_tiles, nw, st);
+    }
+    return 0;
+  };
 
   if (use_trivial) {
     a.n = n;
@@ -884,8 +943,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       a.perm = d_generic + ch.k0;
       a.count_ptr = nullptr;
       timed_begin(c, 2, st);
+      const std::vector<LongWin> lw = long_windows(ch.k0, ch.k1);
+      if ((rc = run_tiles(lw, 1))) return fail(c, rc, "tiled alignment #1");
       launch_dp1(a, c->gen, st);
       launch_fuse1(a, st);
+      if ((rc = run_tiles(lw, 2))) return fail(c, rc, "tiled alignment #2");
       timed_end(c, st);
       if (chunks.size() > 1) {      // several chunks share the scratch: finish each one completely
         a.mark_b = d_done_b;
@@ -916,11 +978,14 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       a.perm = d_generic + ch.k0;
       a.count_ptr = nullptr;
       timed_begin(c, 0, st);
+      const std::vector<LongWin> lw = long_windows(ch.k0, ch.k1);
+      if ((rc = run_tiles(lw, 1))) return fail(c, rc, "tiled alignment #1");
       launch_dp1(a, c->gen, st);
       timed_end(c, st);
       timed_begin(c, 2, st);
       launch_fuse1(a, st);
       timed_end(c, st);
+      if ((rc = run_tiles(lw, 2))) return fail(c, rc, "tiled alignment #2");
       timed_begin(c, 1, st);
       for (int cls = 0; cls < 3; ++cls) launch_dp2(a, c->gen, cls, st);
       timed_end(c, st);

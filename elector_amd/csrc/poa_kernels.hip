@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) k_symbolize(const uint8_t *__restrict__ i
 template <bool GEN>
 __device__ void dp1_window(const BatchArgs &a, const Scoring<GEN> &sc, const uint32_t w, const int lane)
 {
-  if (a.status[w] || (a.skip_a && a.skip_a[w])) return;
+  if (a.status[w] || (a.skip_a && a.skip_a[w]) || (a.tiled && (a.tiled[w] & 1))) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2];
   const int Lx = (int)(o1 - o0), Ly = (int)(o2 - o1);
   const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
@@ -188,7 +188,7 @@ template <bool GEN, int D>
 __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring, const int cls, const uint32_t w,
                            const int lane)
 {
-  if (a.status[w] || (a.cls[w] & 3) != cls || (a.skip_b && a.skip_b[w])) return;
+  if (a.status[w] || (a.cls[w] & 3) != cls || (a.skip_b && a.skip_b[w]) || (a.tiled && (a.tiled[w] & 2))) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
   const int Lx = a.n1[w], Ly = (int)(o3 - o2);
   const uint8_t *ys = a.sym + o2;
@@ -301,6 +301,206 @@ __global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls)
     dp2_window<GEN, D>(a, sc, ring, cls, a.perm[i], lane);
     __syncthreads();
   }
+}
+
+// --------------------------------------------------------------- tiled DP ---
+// The same two recurrences for LONG windows, one tile (strip s, column block c) per wavefront and one
+// launch per anti-diagonal d = s + c (the grid's y index picks the window).  A tile needs from its left
+// neighbour (s, c-1) the cell of every row at the block's last column -- and, for alignment #2, that
+// wavefront's predecessor ring -- and from the tile above (s-1, c) the carry row over its own columns;
+// both ran on the anti-diagonal before.  The state lives per strip and block parity in `tstate`.
+// Moves are OR-ed into the (zeroed) scratch: a lane's dword of eight steps may straddle two tiles.
+
+template <bool GEN>
+__global__ void __launch_bounds__(64) k_dp1_tile(BatchArgs a, TileArgs ta)
+{
+  __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
+  const int lane = threadIdx.x;
+  load_tables<GEN>(lds_tab, a.tab, lane);
+  Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
+  const uint32_t w = ta.wlist[blockIdx.y];
+  if (a.status[w]) return;
+  const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2];
+  const int Lx = (int)(o1 - o0), Ly = (int)(o2 - o1);
+  const int tw = mv_tw(Lx), ns = n_strips(Ly), ncb = (Lx + kTileCols - 1) / kTileCols;
+  const int s = (int)blockIdx.x + max(0, ta.d - (ncb - 1)), c = ta.d - s;
+  if (s >= ns || c < 0) return;
+  const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
+  uint32_t *mv = a.moves + a.mv1[w];
+  int32_t *carry = a.carry + (o0 + w);
+  int32_t *stw = ta.tstate + ta.st_off[blockIdx.y];                     // [ns][2][kTileState1]
+  const int c_lo = c * kTileCols, c_hi = min(c_lo + kTileCols, Lx);       // this tile: columns (c_lo, c_hi]
+
+  const int ii = s * kStripRows + lane;
+  const bool rowok = lane >= 1 && ii <= Ly;
+  const int yl = rowok ? ys[ii - 1] : 0;
+  const int colp = a.liny[min(ii, Ly)];
+  const int32_t *src0 = (s == 0) ? a.linx : carry;
+  const bool wr_carry = (s + 1 < ns);
+  int S1 = 0, g1 = 0, sdiag = 0, xl = 0, xblk = 0, c0blk = 0;
+  if (c > 0) { const int p = stw[(s * 2 + ((c - 1) & 1)) * kTileState1 + lane]; S1 = cell_score(p); g1 = cell_tag(p); }
+  uint32_t mvacc = 0;
+  const int t_end = c_hi + 63;
+  for (int t = c_lo; t <= t_end; ++t) {
+    if ((t & 63) == 0) {
+      const int j = t + lane;
+      xblk = (j >= 1 && j <= Lx) ? xs[j - 1] : 0;
+      c0blk = (j <= c_hi) ? ld_carry(src0 + j) : 0;                        // the row above, this block's columns only
+    }
+    const int x0 = __builtin_amdgcn_readlane(xblk, t & 63);
+    const int c0 = __builtin_amdgcn_readlane(c0blk, t & 63);
+    const int s_up = wave_shr1(S1), g_up = wave_shr1(g1);
+    xl = wave_shr1(xl);
+    if (lane == 0) xl = x0;
+    const int jj = t - lane;
+    const bool incol = jj > c_lo && jj <= c_hi;
+    const bool first = c == 0 && jj == 0;                                  // column -1 of the window
+    const bool cell = rowok && incol;
+
+    const int insY = s_up - sc.pen_y(g_up);
+    const int mat = sdiag + sc.subst(xl, yl);
+    const int insX = S1 - sc.pen_x(g1);
+    const bool m = (mat > insY) && (mat > insX);
+    const bool xw = !m && (insX > insY);
+    int S = m ? mat : (xw ? insX : insY);
+    int g = m ? 0 : sc.next_tag(xw ? g1 : g_up);
+    uint32_t nib = m ? (kMoveX1 | kMoveY) : (xw ? kMoveX1 : kMoveY);
+    if (!cell) { S = S1; g = g1; nib = 0; }
+    if (first) { S = cell_score(colp); g = cell_tag(colp); }
+    if (lane == 0 && (incol || first)) { S = cell_score(c0); g = cell_tag(c0); }
+    sdiag = s_up;
+    S1 = S; g1 = g;
+
+    mvacc |= nib << (4 * (t & 7));
+    if ((t & 7) == 7 || t == t_end) {
+      if (mvacc) mv[((int64_t)s * tw + (t >> 3)) * 64 + lane] |= mvacc;
+      mvacc = 0;
+    }
+    if (wr_carry && lane == 63 && (incol || first)) st_carry(carry + jj, pack_cell(S, g));
+    if (cell && ii == Ly && jj == Lx) a.score1[w] = S;
+  }
+  stw[(s * 2 + (c & 1)) * kTileState1 + lane] = pack_cell(S1, g1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+
+template <bool GEN>
+__global__ void __launch_bounds__(64) k_dp2_tile(BatchArgs a, TileArgs ta)
+{
+  constexpr int D = kTileRing, MASK = D - 1;
+  __shared__ int ring[D * 64];
+  __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
+  const int lane = threadIdx.x;
+  load_tables<GEN>(lds_tab, a.tab, lane);
+  Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
+  const uint32_t w = ta.wlist[blockIdx.y];
+  if (a.status[w] || (a.cls[w] & 3) != 0) return;                         // deeper graphs: the one-wavefront kernel
+  const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
+  const int Lx = a.n1[w], Ly = (int)(o3 - o2);
+  const int tw = mv_tw(Lx), ns = n_strips(Ly), ncb = (Lx + kTileCols - 1) / kTileCols;
+  const int s = (int)blockIdx.x + max(0, ta.d - (ncb - 1)), c = ta.d - s;
+  if (s >= ns || c < 0 || c >= ncb) return;
+  const uint8_t *ys = a.sym + o2;
+  const int2 *xinfo = a.xinfo + (o0 + w);
+  uint32_t *mv = a.moves + a.mv2[w];
+  int32_t *carry = a.carry + (o0 + w);
+  int32_t *stw = ta.tstate + ta.st_off[blockIdx.y];                     // [ns][2][kTileState2]
+  const int32_t *st_in = stw + (int64_t)(s * 2 + ((c - 1) & 1)) * kTileState2;
+  int32_t *st_out = stw + (int64_t)(s * 2 + (c & 1)) * kTileState2;
+  const int c_lo = c * kTileCols, c_hi = min(c_lo + kTileCols, Lx);
+  constexpr int kNoPred = 0;
+
+  const int ii = s * kStripRows + lane;
+  const bool rowok = lane >= 1 && ii <= Ly;
+  const bool rowvirt = (s == 0 && lane == 0);
+  const int yl = rowok ? ys[ii - 1] : 0;
+  const int col_own = a.liny[min(ii, Ly)];
+  const int col_dg = a.liny[min(max(ii - 1, 0), Ly)];
+  const bool wr_carry = (s + 1 < ns);
+  int S1 = 0, g1 = 0, xlo = kNoPred, xhi = 0, xb_lo = kNoPred, xb_hi = 0, c0blk = 0;
+  int best = kNeg, bestx = -1;
+  if (c > 0) {
+    const int p = st_in[lane];
+    S1 = cell_score(p); g1 = cell_tag(p);
+    for (int k = 0; k < D; ++k) ring[k * 64 + lane] = st_in[64 + k * 64 + lane];
+    best = st_in[64 + D * 64]; bestx = st_in[64 + D * 64 + 1];
+  }
+  __syncthreads();
+  uint32_t mvacc = 0;
+  const int t_end = c_hi + 63;
+  for (int t = c_lo; t <= t_end; ++t) {
+    if ((t & 63) == 0) {
+      const int j = t + lane;
+      int2 xi = (j >= 1 && j <= Lx) ? xinfo[j] : make_int2(kNoPred, 0);
+      xb_lo = xi.x; xb_hi = xi.y;
+      c0blk = (s > 0 && j <= c_hi) ? ld_carry(carry + j) : 0;
+    }
+    const int x0lo = __builtin_amdgcn_readlane(xb_lo, t & 63);
+    const int x0hi = __builtin_amdgcn_readlane(xb_hi, t & 63);
+    const int c0 = __builtin_amdgcn_readlane(c0blk, t & 63);
+    const int s_up = wave_shr1(S1), g_up = wave_shr1(g1);
+    xlo = wave_shr1(xlo); xhi = wave_shr1(xhi);
+    if (lane == 0) { xlo = x0lo; xhi = x0hi; }
+    const int jj = t - lane;
+    const bool incol = jj > c_lo && jj <= c_hi;
+    const bool first = c == 0 && jj == 0;
+    const int d1 = xlo & 0xFFFF, d2 = (int)((uint32_t)xlo >> 16);
+    const int xl = xhi & 0xFF;
+    const bool has2 = incol && d2 != 0;
+    const bool virt1 = !incol || d1 == 0;
+    const int lm1 = max(lane - 1, 0);
+
+    int own1 = col_own, dg1 = col_dg, own2 = 0, dg2 = 0;
+    if (!virt1) {
+      own1 = ring[((t - d1) & MASK) * 64 + lane];
+      dg1 = ring[((t - d1 - 1) & MASK) * 64 + lm1];
+    }
+    if (has2) {
+      own2 = ring[((t - d2) & MASK) * 64 + lane];
+      dg2 = ring[((t - d2 - 1) & MASK) * 64 + lm1];
+    }
+    const int gx1 = cell_tag(own1), gx2 = cell_tag(own2);
+    const int cx1 = cell_score(own1) - sc.pen_x(gx1);
+    const int cx2 = has2 ? cell_score(own2) - sc.pen_x(gx2) : kNeg;
+    const bool px2 = cx2 > cx1;
+    const int insX = px2 ? cx2 : cx1, gX = px2 ? gx2 : gx1;
+    const int m1 = cell_score(dg1), m2 = has2 ? cell_score(dg2) : kNeg;
+    const bool pm2 = m2 > m1;
+    int mat = (pm2 ? m2 : m1) + sc.subst(xl, yl);
+    int insY = s_up - sc.pen_y(g_up);
+    if (rowvirt) { mat = kNeg; insY = kNeg; }
+
+    const bool m = (mat > insY) && (mat > insX);
+    const bool xw = !m && (insX > insY);
+    int S = m ? mat : (xw ? insX : insY);
+    int g = m ? 0 : sc.next_tag(xw ? gX : g_up);
+    uint32_t nib = m ? ((pm2 ? kMoveX2 : kMoveX1) | kMoveY) : (xw ? (px2 ? kMoveX2 : kMoveX1) : kMoveY);
+    const bool cell = rowok && incol;
+    if (!(cell || (rowvirt && incol))) { S = S1; g = g1; }
+    if (!cell) nib = 0;
+    if (first) { S = cell_score(col_own); g = cell_tag(col_own); }
+    if (lane == 0 && s > 0 && (incol || first)) { S = cell_score(c0); g = cell_tag(c0); }
+    S1 = S; g1 = g;
+
+    // only live cells enter the ring: a lane's last kTileRing columns must survive the idle steps at the tile's end
+    if (incol || first) ring[(t & MASK) * 64 + lane] = pack_cell(S, g);
+    __builtin_amdgcn_wave_barrier();
+
+    mvacc |= nib << (4 * (t & 7));
+    if ((t & 7) == 7 || t == t_end) {
+      if (mvacc) mv[((int64_t)s * tw + (t >> 3)) * 64 + lane] |= mvacc;
+      mvacc = 0;
+    }
+    if (wr_carry && lane == 63 && (incol || first)) st_carry(carry + jj, pack_cell(S, g));
+    if (cell && ii == Ly && ((xhi >> 8) & kFlagFinal) && S > best) { best = S; bestx = jj - 1; }
+  }
+  __syncthreads();
+  st_out[lane] = pack_cell(S1, g1);
+  for (int k = 0; k < D; ++k) st_out[64 + k * 64 + lane] = ring[k * 64 + lane];
+  if (lane == (Ly - 1) % kStripRows + 1) {
+    st_out[64 + D * 64] = best; st_out[64 + D * 64 + 1] = bestx;
+    if (s == ns - 1 && c == ncb - 1) { a.score2[w] = best; a.bx2[w] = bestx; ta.tiled[w] |= 2; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 // ---------------------------------------------------------------- k_fuse1 ---
@@ -512,6 +712,19 @@ void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st)
   const unsigned g = list_grid(a, 1, 4096);
   if (gen) hipLaunchKernelGGL(k_dp1<true>, dim3(g), dim3(64), 0, st, a);
   else hipLaunchKernelGGL(k_dp1<false>, dim3(g), dim3(64), 0, st, a);
+}
+
+// one launch per anti-diagonal of tiles; ntiles = upper bound of the tiles on it, nw = long windows
+void launch_dp1_tile(const BatchArgs &a, const TileArgs &ta, bool gen, int ntiles, int nw, hipStream_t st)
+{
+  if (gen) hipLaunchKernelGGL(k_dp1_tile<true>, dim3((unsigned)ntiles, (unsigned)nw), dim3(64), 0, st, a, ta);
+  else hipLaunchKernelGGL(k_dp1_tile<false>, dim3((unsigned)ntiles, (unsigned)nw), dim3(64), 0, st, a, ta);
+}
+
+void launch_dp2_tile(const BatchArgs &a, const TileArgs &ta, bool gen, int ntiles, int nw, hipStream_t st)
+{
+  if (gen) hipLaunchKernelGGL(k_dp2_tile<true>, dim3((unsigned)ntiles, (unsigned)nw), dim3(64), 0, st, a, ta);
+  else hipLaunchKernelGGL(k_dp2_tile<false>, dim3((unsigned)ntiles, (unsigned)nw), dim3(64), 0, st, a, ta);
 }
 
 void launch_fuse1(const BatchArgs &a, hipStream_t st)

@@ -140,3 +140,32 @@ def test_too_long_is_reported(engine):
     assert got[0] is None and got[1] == (b"acgt", b"acgt", b"acgt")
     with pytest.raises(Exception):
         engine.align([(big, b"ACGT", b"ACGT")])
+
+
+def test_tiled_long_windows(engine, monkeypatch):
+    """The tiled kernels of the long-window path (one tile = 63 rows x 2048 columns, one launch per tile
+    anti-diagonal) on windows of 2,100-6,500 bases -- several column blocks and up to a hundred strips --
+    with the size threshold lowered so that they take it; and mixed with ordinary windows."""
+    monkeypatch.setenv("ELECTOR_TILE_CELLS", "1000000")
+    long_ones = synth.window_triples(41, 5, 2100, 6500, err_unc=0.12, err_cor=0.02)
+    check(engine, long_ones)
+    check(engine, synth.window_triples(42, 200, 20, 120) + long_ones[:2] + synth.window_triples(43, 3, 1500, 2500))
+
+
+def test_tiled_general_matrix(monkeypatch):
+    from elector_amd.poa import PoaEngine
+    import tempfile, os
+    monkeypatch.setenv("ELECTOR_TILE_CELLS", "1000000")
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "m.mat")
+        open(path, "w").write(GENERAL_MATRIX)
+        from elector_amd.poa import read_params
+        eng = PoaEngine(0, read_params(path))
+        try:
+            triples = synth.window_triples(44, 3, 2100, 3000, err_unc=0.12, err_cor=0.02)
+            bases, off = synth.pack_windows(triples)
+            exp_rows, _, exp_scores, _ = oracle_lib.batch(np.frombuffer(bases, dtype=np.uint8), off, oracle_lib.read_params(path))
+            got, scores = eng.align(triples, want_scores=True)
+            assert got == exp_rows and np.array_equal(scores, exp_scores)
+        finally:
+            eng.close()
