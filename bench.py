@@ -268,7 +268,7 @@ def main():
                                    "alignment2_stage": round(t_dp2 / args.steps, 3),
                                    "other": round(t_oth / args.steps, 3),
                                    "merge_and_counters": round(t_st / args.steps, 3),
-                                   "note": "sum of per-launch HIP-event times; size classes overlap on 4 streams"},
+                                   "note": "sum of per-launch HIP-event times; the two launch chains overlap"},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic,

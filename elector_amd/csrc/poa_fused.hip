@@ -10,11 +10,13 @@
 // arrives by DPP row_shr:1 (wave_shr:1 for G > 16); the group's first lane
 // receives the strip's top border.
 //
-//   k_fused_a  alignment #1 (linear x linear) -> moves in LDS -> traceback ->
-//              fusion #1 -> PO graph (xinfo, ring1, virtual-row scores) to HBM.
-//              Replaces k_dp1 + k_fuse1; alignment #1 moves never reach HBM.
-//   k_fused_b  alignment #2 (PO x linear, time ring in LDS) -> traceback ->
-//              fusion #2 -> MSA columns.  Replaces k_dp2 + k_fuse2.
+//   k_fused_a  alignment #1 (linear x linear, registers only) -> traceback ->
+//              fusion #1 -> PO graph (xinfo, ring1) to HBM.  Replaces k_dp1 + k_fuse1.
+//   k_fused_b  alignment #2 (PO x linear, time ring in LDS; ring-free for wavefronts
+//              of chain graphs) -> traceback -> fusion #2 -> MSA columns.
+//              Replaces k_dp2 + k_fuse2.
+// The moves (2 bits per cell) stream to an HBM scratch, coalesced, one word per lane
+// and step, and are read back by the same wavefront's traceback, G cells per round.
 //
 // Uniform-scoring parameters only (the shipped matrix); other parameter sets and
 // windows that do not fit their LDS slot stay on the generic kernels of

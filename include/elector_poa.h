@@ -112,10 +112,11 @@ int elector_ctx_sync(elector_ctx *ctx);
 /* measurement hooks for bench.py: HIP-event time (ms) and span count of a
  * kernel class accumulated since the last reset, measured with events on the
  * stream each kernel is launched on.  kernel: 0 = alignment #1 stage
- * (k_fused_a<G> launches; k_dp1 on the generic path), 1 = alignment #2 stage
- * (k_fused_b<G>; k_dp2), 2 = everything else of the POA stage (symbolize, generic
- * leftovers), 3 = merge + statistics kernels (include/elector_stats.h).
- * Size classes run concurrently on separate streams: the sums overlap in wall time. */
+ * (k_fused_a<G,R> launches; k_dp1 on the generic path), 1 = alignment #2 stage
+ * (k_fused_b<G,R,D>; k_dp2), 2 = everything else of the POA stage (symbolize, the
+ * trivial-window pass and list sort, generic leftovers, tiled long windows),
+ * 3 = merge + statistics kernels (include/elector_stats.h).
+ * The geometry classes run on two concurrent launch chains: the sums overlap in wall time. */
 int elector_ctx_timing_enable(elector_ctx *ctx, int on);
 int elector_ctx_timing_read(elector_ctx *ctx, int kernel, double *ms, int64_t *launches);
 int elector_ctx_timing_reset(elector_ctx *ctx);
