@@ -4,6 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
+Two engine contexts per GPU take the steps in turn, so two batches are in flight
+(the serial head and tail of one batch overlap the alignment kernels of the other).
+
 A *step* is one pass of the hot path (symbolize -> alignment #1 -> fusion ->
 alignment #2 -> fusion + MSA columns -> merge of each read's windows -> per-read
 integer counters back on the host) over one batch of window triples that is
@@ -146,9 +149,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # ELECTOR_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (the ranks
+    # then share devices; the driver's runs use RCCL = "nccl", one GPU per rank)
+    backend = os.environ.get("ELECTOR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from elector_amd import split, synthetic
     from elector_amd.poa import PoaEngine
@@ -166,10 +177,17 @@ def main():
     lu = off[3::3] - off[2:-1:3]
     dev = torch.device("cuda", local)
     d_bases = torch.from_numpy(win.bases).to(dev)
-    d_cols = torch.empty(3 * int(off[-1]) + 64, dtype=torch.uint8, device=dev)
-    d_ncol = torch.empty(n, dtype=torch.int32, device=dev)
-    d_status = torch.empty(n, dtype=torch.int32, device=dev)
-    eng = PoaEngine(local)
+    # E engine contexts take the steps in turn (E = 2: two batches in flight, the serial head and tail
+    # of one batch -- symbolize / trivial pass / list sort, merge / statistics -- run beside the
+    # alignment kernels of the other).  Every context has its own output buffers.
+    # Measured on the 10,001-read step: 16.0 ms with one context, 14.4 with two, 14.0 with three, 14.8 with four.
+    n_eng = max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "2")))
+    engines = [PoaEngine(local) for _ in range(n_eng)]
+    outs = [(torch.empty(3 * int(off[-1]) + 64, dtype=torch.uint8, device=dev),
+             torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+            for _ in range(n_eng)]
+    eng = engines[0]
+    d_cols, d_ncol, d_status = outs[0]
     # one msa.fa record (piece) per read, one piece per read: the synthetic corrected reads are not split
     piece_first = win.read_first
     read_first = np.arange(win.n_reads + 1, dtype=np.int64)
@@ -177,24 +195,29 @@ def main():
     from elector_amd._capi import ES_NCOUNTERS
 
     pending = []
+    turn = [0]
 
     def collect():
         """per-read counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
-        counters, _ = eng.msa_stats_collect(pending.pop(0))
+        e, npieces = pending.pop(0)
+        counters, _ = engines[e].msa_stats_collect(npieces)
         return edist.gather_rows(counters) if world > 1 else counters
 
     def step():
         """Queue one step (windows in HBM -> POA kernels -> merge -> counters -> pinned host memory),
-        then hand out the counters of the step before it: the host prepares step i+1 while the GPU
-        still works on step i, as a run over many 10,001-read batches would."""
-        eng.align_device(d_bases, off, d_cols, d_ncol, d_status)
-        pending.append(eng.msa_stats_enqueue(n, d_cols, d_ncol, d_status, piece_first, read_first))
-        return collect() if len(pending) > 1 else None
+        then hand out the counters of the oldest step in flight: the host prepares step i+1 while the
+        GPU still works on step i, as a run over many 10,001-read batches would."""
+        e = turn[0] % n_eng
+        turn[0] += 1
+        dc, dn, ds = outs[e]
+        engines[e].align_device(d_bases, off, dc, dn, ds)
+        pending.append((e, engines[e].msa_stats_enqueue(n, dc, dn, ds, piece_first, read_first)))
+        return collect() if len(pending) > n_eng else None
 
     # untimed setup, continued: grow every workspace (both halves of the double-buffered upload staging
     # and of the statistics slots) and let the HIP runtime size its queues for overlapped batches -- the
     # first batch that is enqueued while another still runs pays a one-time ~14 ms inside the runtime
-    for _ in range(3):
+    for _ in range(3 * n_eng):
         step()
     while pending:
         collect()
@@ -202,21 +225,24 @@ def main():
         step()
     while pending:
         collect()
-    eng.sync()
-    eng.timing_enable(True)
-    eng.timing_reset()
+    for g in engines:
+        g.sync()
+        g.timing_enable(True)
+        g.timing_reset()
 
     # ---- timed region ----------------------------------------------------
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.sync()
+    for g in engines:
+        g.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     while pending:
         counters = collect()                     # every step's counters are on the host before the clock stops
-    eng.sync()
+    for g in engines:
+        g.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -229,12 +255,15 @@ def main():
         raise SystemExit("bench: %d windows failed on device" % int((status != 0).sum()))
     po = eng.last_po_sizes(n).astype(np.int64)
     cells1, cells2 = int((lr * lc).sum()), int((po * lu).sum())
-    t_dp1, k_dp1 = eng.timing_read(0)
-    t_dp2, k_dp2 = eng.timing_read(1)
-    t_oth, _ = eng.timing_read(2)
-    t_st, _ = eng.timing_read(3)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tot = torch.tensor([read_bases, n, cells1 + cells2], dtype=torch.int64, device=dev)
+    t_dp1, k_dp1, t_dp2, k_dp2, t_oth, t_st = 0.0, 0, 0.0, 0, 0.0, 0.0
+    for g in engines:
+        x, y = g.timing_read(0); t_dp1 += x; k_dp1 += y
+        x, y = g.timing_read(1); t_dp2 += x; k_dp2 += y
+        t_oth += g.timing_read(2)[0]
+        t_st += g.timing_read(3)[0]
+    rdev = dev if backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    tot = torch.tensor([read_bases, n, cells1 + cells2], dtype=torch.int64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -262,7 +291,8 @@ def main():
             "config": {"workload": "%s: %d reads per GPU per step, cut into windows by the ELECTOR splitter rules"
                                    % (WORKLOADS.get(args.profile, args.profile), args.reads),
                        "profile": args.profile, "reads_per_gpu": args.reads, "windows_per_gpu": n,
-                       "ref_bases_per_gpu": read_bases, "parallelism": "shard-by-read x%d" % world},
+                       "ref_bases_per_gpu": read_bases, "parallelism": "shard-by-read x%d" % world,
+                       "batches_in_flight_per_gpu": n_eng},
             "gcups": round(cells_all * args.steps / dt_max / 1e9, 3),
             "kernel_ms_per_step": {"alignment1_stage": round(t_dp1 / args.steps, 3),
                                    "alignment2_stage": round(t_dp2 / args.steps, 3),
@@ -286,7 +316,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(win, lr, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    eng.close()
+    for g in engines:
+        g.close()
     if world > 1:
         dist.destroy_process_group()
 
