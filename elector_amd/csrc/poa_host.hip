@@ -617,16 +617,42 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   bin_first[0] = 0;
   for (int b = 0; b < kBins; ++b) bin_first[(size_t)b + 1] = bin_first[(size_t)b] + bin_cnt[(size_t)b];
   {
-    std::vector<uint32_t> order((size_t)n);
-    for (int64_t w = 0; w < n; ++w) order[(size_t)key_cnt[wkey[(size_t)w]]++] = (uint32_t)w;
-    std::vector<int64_t> pos(bin_first.begin(), bin_first.end() - 1);
-    int64_t gpos = 0;
-    for (int64_t k = 0; k < n; ++k) {
-      const uint32_t w = order[(size_t)k];
-      const int b = bin[w];
-      if (b >= 0) h_list[pos[(size_t)bin_final[(size_t)b]]++] = w;
-      else h_generic[gpos++] = w;
+    // parallel stable counting sort of the windows by (destination list, size key): every thread counts
+    // its contiguous range, the counts are scanned destination-major / key / thread, every thread places
+    // its range.  Destination = a launch bin's list, or the generic-path list.
+    std::vector<int> dest_of_bin((size_t)kBins, -1);
+    std::vector<int64_t> dest_first;
+    for (int b = 0; b < kBins; ++b)
+      if (bin_cnt[(size_t)b]) { dest_of_bin[(size_t)b] = (int)dest_first.size(); dest_first.push_back(bin_first[(size_t)b]); }
+    const int gen_dest = (int)dest_first.size(), nbuckets = (gen_dest + 1) * NB;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
+    std::vector<std::vector<int64_t>> cnt((size_t)T, std::vector<int64_t>((size_t)nbuckets, 0));
+    auto dest = [&](int64_t w) { const int b = bin[(size_t)w]; return b >= 0 ? dest_of_bin[(size_t)bin_final[(size_t)b]] : gen_dest; };
+    auto pass = [&](int t, bool place) {
+      const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
+      int64_t *my = cnt[(size_t)t].data();
+      for (int64_t w = w0; w < w1; ++w) {
+        const int dd = dest(w);
+        int64_t &slot = my[dd * NB + wkey[(size_t)w]];
+        if (!place) { ++slot; continue; }
+        const int64_t pos = slot++;
+        if (dd == gen_dest) h_generic[pos] = (uint32_t)w;
+        else h_list[dest_first[(size_t)dd] + pos] = (uint32_t)w;
+      }
+    };
+    auto run = [&](bool place) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; ++t) th.emplace_back(pass, t, place);
+      pass(0, place);
+      for (auto &x : th) x.join();
+    };
+    run(false);
+    for (int dd = 0; dd <= gen_dest; ++dd) {
+      int64_t at = 0;
+      for (int k = 0; k < NB; ++k)
+        for (int t = 0; t < T; ++t) { int64_t &v = cnt[(size_t)t][(size_t)(dd * NB + k)]; const int64_t c0 = v; v = at; at += c0; }
     }
+    run(true);
   }
   if (std::getenv("ELECTOR_DEBUG_BINS")) {
     std::fprintf(stderr, "[elector] n=%lld generic=%lld classes:", (long long)n, (long long)n_generic);
