@@ -11,6 +11,7 @@
 //
 // No MFMA: the recurrence is an integer max-plus chain, not a contraction.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "poa_device.h"
 #include "poa_serial.h"
 
@@ -567,7 +568,7 @@ __global__ void __launch_bounds__(256) k_left_b(BatchArgs a, uint32_t *list, int
 // path together instead of one after the other.
 constexpr int kPartBuckets = 16;        // 0..14: first difference in columns 8k..8k+7 (14: beyond), 15: trivial
 
-__global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey)
+__global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, int one_sub_ok)
 {
   const int64_t w = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
   const int g = threadIdx.x & 7;
@@ -581,7 +582,41 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
   for (int d = 1; d < 8; d <<= 1) fd = min(fd, __shfl_xor(fd, d, 8));
   const bool eq = a.status[w] == 0 && Lr == Lc && fd == nmin;
   if (g == 0) { triv[w] = eq ? 1 : 0; pkey[w] = (uint8_t)(eq ? kPartBuckets - 1 : min(fd >> 3, kPartBuckets - 2)); }
-  if (!eq) return;
+  if (!eq) {
+    // One substitution and nothing else (same length, the strings agree after position fd): the diagonal
+    // with its one mismatch beats every alignment with gaps (two gap openings at least) and is the
+    // strictly best predecessor of every diagonal cell as long as |mismatch| < open + extension, so the
+    // pairs are again letter i with letter i; the fusion puts the corrected letter in a node of its own
+    // right before the reference letter's, both in one ring (lpo.c:449-450,647-649).  No dynamic program.
+    if (!one_sub_ok || a.status[w] != 0 || Lr != Lc) return;
+    bool rest = true;
+    for (int i = fd + 1 + g; i < Lr; i += 8) rest = rest && xs[i] == ys[i];
+    for (int d = 1; d < 8; d <<= 1) rest = __shfl_xor(rest ? 1 : 0, d, 8) != 0 && rest;
+    if (!rest) return;
+    const int e = fd, L = Lr;
+    const int64_t nb = o0 + w;
+    for (int i = g; i < L; i += 8) {
+      const int fl_pos = (i == 0 ? kFlagInitial : 0) | (i == L - 1 ? kFlagFinal : 0);
+      if (i != e) {
+        const int n = i < e ? i : i + 1;
+        const int d1 = i == 0 ? 0 : 1, d2 = i == e + 1 ? 2 : 0;          // after the bubble: the reference letter's node, then the corrected letter's
+        a.xinfo[nb + n + 1] = make_int2(d1 | (d2 << 16), xs[i] | ((kFlagHasRef | kFlagHasCor | fl_pos) << 8));
+        a.ring1[nb + n] = (uint16_t)n;
+      } else {
+        a.xinfo[nb + e + 1] = make_int2(e == 0 ? 0 : 1, ys[e] | ((kFlagHasCor | fl_pos) << 8));
+        a.ring1[nb + e] = (uint16_t)e;
+        a.xinfo[nb + e + 2] = make_int2(e == 0 ? 0 : 2, xs[e] | ((kFlagHasRef | fl_pos) << 8));
+        a.ring1[nb + e + 1] = (uint16_t)e;
+      }
+    }
+    if (g == 0) {
+      a.n1[w] = L + 1;
+      a.cls[w] = 0;                     // max predecessor distance 2: ring need 4
+      a.score1[w] = (L - 1) * a.kp.match + a.kp.mismatch;
+      done_a[w] = 1;
+    }
+    return;
+  }
   const int64_t nb = o0 + w;
   for (int n = g; n < Lr; n += 8) {
     const int fl = kFlagHasRef | kFlagHasCor | (n == 0 ? kFlagInitial : 0) | (n == Lr - 1 ? kFlagFinal : 0);
@@ -762,7 +797,11 @@ void launch_fuse2(const BatchArgs &a, hipStream_t st)
 void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, hipStream_t st)
 {
   if (a.n <= 0) return;
-  hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv, pkey);
+  // the one-substitution shortcut needs |mismatch - match| < gap opening + extension in both directions
+  const int one_sub_ok = !std::getenv("ELECTOR_NO_ONESUB") &&
+                         (a.kp.match - a.kp.mismatch) < (a.kp.open_x < a.kp.open_y ? a.kp.open_x : a.kp.open_y) +
+                                                         (a.kp.ext_x < a.kp.ext_y ? a.kp.ext_x : a.kp.ext_y);
+  hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv, pkey, one_sub_ok);
 }
 
 int partition_buckets() { return kPartBuckets; }
