@@ -63,3 +63,15 @@ def test_batch_shapes(engine):
     t = synth.window_triples(80, 3000, 20, 90, err_cor=0.0)                  # all trivial, mixed sizes
     check(engine, t)
     check(engine, [(r, synth.mutate(rng, r, 0.2) + b"A", u) for r, _, u in t])   # none trivial
+
+
+def test_degenerate_batches(engine):
+    from elector_amd._capi import W_EMPTY
+    assert engine.align([]) == []
+    got = engine.align([(b"", b"ACGT", b"ACGT"), (b"ACGT", b"", b"ACGT"), (b"ACGT", b"ACGT", b""), (b"A", b"A", b"A")], strict=False)
+    assert got[:3] == [None, None, None] and got[3] == (b"a", b"a", b"a")
+    rows, row_off, ncol, status, _ = engine.align_packed(*[np.asarray(x) for x in (np.frombuffer(b"ACGTACGT", dtype=np.uint8),
+                                                                                   np.array([0, 0, 4, 8], dtype=np.int64))], strict=False)
+    assert status[0] == W_EMPTY and ncol[0] == 0
+    with pytest.raises(Exception):
+        engine.align([(b"", b"ACGT", b"ACGT")])          # strict: a failed window raises
