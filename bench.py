@@ -1,67 +1,96 @@
 #!/usr/bin/env python3
 """bench.py -- triplet-MSA throughput of the HIP hot path on N MI355X GPUs.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    python bench.py --gpus N --steps K --warmup W [--profile P] [--reads R] [--serial]
 
-Three engine contexts per GPU take the steps in turn, so three batches are in flight
-(the serial head and tail of one batch overlap the alignment kernels of the others).
+N > 1: one rank per GPU over RCCL.  The driver launches the ranks with torch.distributed.run; when
+WORLD_SIZE is not set and N > 1 this script starts them itself (fresh child processes, before
+anything in this process touches a GPU) and relays rank 0's JSON line.  A WORLD_SIZE that differs
+from --gpus is an error (exit 2).
 
-A *step* is one pass of the hot path (symbolize -> alignment #1 -> fusion ->
-alignment #2 -> fusion + MSA columns -> merge of each read's windows -> per-read
-integer counters back on the host) over one batch of window triples that is
-already resident in HBM.  The batch is what ELECTOR's own batch protocol hands
-to its POA engine: the windows of `--reads` synthetic long reads
-(BASELINE.json configs[1] profile: E. coli 30X SimLord-like PacBio reads, 15 %
-error, LoRDEC-like 1 % corrected), cut by this repository's reference-compatible
-splitter on the host before the timed region.  Weak scaling: every rank
-processes its own shard of reads (independent triples, no data-path
-collective); rank 0 gathers the per-read integer counters over RCCL once per step.
+A *step* is one pass of the hot path (symbolize -> alignment #1 -> fusion -> alignment #2 ->
+fusion + MSA columns -> merge of each piece's windows -> per-piece integer counters back on the
+host) over one batch of window triples that is already resident in HBM.  The batch is what
+ELECTOR's own batch protocol hands to its POA engine: the windows of `--reads` synthetic long
+reads (default 10,001, profile = BASELINE.json configs[1]: E. coli 30X SimLord-like PacBio reads,
+15 % error, LoRDEC-like 1 % corrected), cut by this repository's reference-compatible splitter
+on the host before the timed region.  Weak scaling: every rank processes its own shard of reads
+(independent triples, no data-path collective); rank 0 gathers the per-piece integer counters
+over RCCL once per step.  Several engine contexts per GPU take the steps in turn, so several
+batches are in flight (the serial head and tail of one batch overlap the alignment kernels of
+the others).
 
-Prints ONE JSON line (rank 0).  `value` = reference-read bases of all ranks per
-second of the slowest rank.  `roofline` prices the dominant kernel against HBM
-peak using the algorithmic bytes of DESIGN.md; `cpu_baseline` times the
-reference poaV2 binary (oracle/_ref/poa, when it travelled with the snapshot)
-or the C oracle port on this host's cores over a bounded sample.
+Prints ONE JSON line (rank 0).  `value` = reference-read bases of all ranks' triples per second
+of the slowest rank.  `roofline` prices the dominant kernel against HBM peak using the
+algorithmic bytes of DESIGN.md and that kernel's UN-OVERLAPPED launch durations: HIP events on
+the launch stream during a serial pass (one context, one launch chain, every kernel alone on
+the chip) that follows the timed region -- with `--serial` the timed region itself runs that
+way, which is the command profiles/*_serial_kernel_stats.csv was taken from.  `roofline_valu`
+is the ceiling that actually binds (VALU issue); `cpu_baseline` times the reference poaV2 binary
+(oracle/_ref/poa, when it travelled with the snapshot) or the C oracle port on this host's cores
+over a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue peak: 256 CUs x 4 SIMD-32 per CU, one wave64 VALU instruction per 2 cycles per SIMD when
+# more than one wave shares it (MI355X_MICROARCH.md "Each CU has 4 SIMD-32 units"), 2.4 GHz
+VALU_PEAK_GINSTS = 256 * 4 * 2.4 / 2
 WORKLOADS = {   # BASELINE.json configs restated as synthetic profiles (elector_amd/synthetic.py)
     "ecoli30x_simlord_lordec": "E. coli 30X SimLord-like PacBio (15% err), LoRDEC-like corrected (1% err), ~8 kb reads",
-    "yeast50x_nanosim_consent": "S. cerevisiae 50X NanoSim-like ONT (12% err), CONSENT-like corrected (2% err), ~8 kb reads",
-    "chr1_20x_ont_50kb": "Human chr1 20X NanoSim-like ONT (12% err), corrected (2% err), ~50 kb reads",
+    "yeast50x_nanosim_consent": "S. cerevisiae 50X NanoSim-like ONT (12% err), CONSENT-like corrected (2% err), ~8 kb reads, whole corrected reads",
+    "yeast50x_nanosim_consent_split": "S. cerevisiae 50X NanoSim-like ONT (12% err), CONSENT-like corrected (2% err) with -split: 33% of the reads in 2-3 pieces, 10% trimmed, ~8 kb reads",
+    "celegans30x_simlord_mixed": "C. elegans 30X SimLord-like PacBio (15% err), corrected 1.5% err, mixed: 30% trimmed, 25% split, 5% extended, ~8 kb reads",
+    "chr1_20x_ont_50kb": "Human chr1 20X NanoSim-like ONT (12% err), corrected (2% err), log-normal read lengths, mean 50 kb",
 }
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("ELECTOR_BENCH_READS", "10001")),
                     help="synthetic long reads per rank and step (10,001 = one batch of ELECTOR's own protocol, "
                          "elector/alignment.py:82, Master_Splitter.cpp:397-399)")
-    ap.add_argument("--profile", default="ecoli30x_simlord_lordec")
+    ap.add_argument("--profile", default="ecoli30x_simlord_lordec", choices=sorted(WORKLOADS))
+    ap.add_argument("--serial", action="store_true",
+                    help="one engine context, one launch chain: every kernel runs alone on the chip (per-kernel times add up to the step)")
+    ap.add_argument("--serial-steps", type=int, default=5, help="steps of the serial pass behind the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="three FASTA files -> getPOA -> outputRecallPrecision with a stage table (see bench_e2e.py)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks as fresh processes (this process has not
+    touched a GPU and never will) and pass rank 0's line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(windows, ref_bases_per_window, seconds):
     """Reference poaV2 (or the oracle port) on this host's cores over a bounded
     sample of the same window stream.  Test infrastructure: uses oracle/."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     ncores = os.cpu_count() or 1
@@ -115,36 +144,57 @@ def cpu_baseline(windows, ref_bases_per_window, seconds):
             "sample": "%d windows (%d reference bases), oracle/poa_oracle.c single thread, wall %.2f s" % (ns, int(nb), dt)}
 
 
-def pmc_traffic(kernel, reads):
-    """HBM bytes per launch of `kernel` from the committed PMC passes over this very command
-    (profiles/pmc_traffic.json, written from tests/_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in
-    separate rocprofv3 passes, gfx950 correction applied); None when the workload differs."""
+def pmc_file(profile, reads):
+    """The committed PMC passes over this very command (profiles/pmc_traffic.json, written by
+    tests/_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, gfx950 correction
+    applied, SQ_INSTS_VALU); None when they were taken on another workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
-        if int(t["reads_per_gpu"]) != int(reads):
+        if int(t["reads_per_gpu"]) != int(reads) or t.get("profile", "ecoli30x_simlord_lordec") != profile:
             return None
-        return int(t["kernels"][kernel]["traffic_bytes_per_launch"])
+        return t
     except (OSError, KeyError, ValueError):
         return None
 
 
-def pmc_valu(reads):
-    """Wavefront-VALU instructions per step of the two fused kernel families (SQ_INSTS_VALU, same
-    committed PMC passes); None when the workload differs."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        return int(t["valu_wave_insts_per_step"]) if int(t["reads_per_gpu"]) == int(reads) else None
-    except (OSError, KeyError, ValueError):
-        return None
+def skipped_alignment1(win, lr, lc):
+    """Windows whose alignment #1 the device skips (k_trivial, poa_kernels.hip): corrected equals the
+    reference, or differs from it by exactly one substitution.  Host-side count for the `gcups` split."""
+    import numpy as np
+    same = np.nonzero(lr == lc)[0]
+    if len(same) == 0:
+        return np.zeros(len(lr), dtype=bool)
+    off = win.off
+    L = lr[same]
+    ends = np.cumsum(L)
+    idx = np.repeat(off[3 * same] - (ends - L), L) + np.arange(int(ends[-1]), dtype=np.int64)
+    mism = win.bases[idx] != win.bases[idx + np.repeat(L, L)]
+    starts = ends - L
+    nmis = np.add.reduceat(mism.astype(np.int64), starts)
+    out = np.zeros(len(lr), dtype=bool)
+    out[same[nmis <= 1]] = True
+    return out
 
 
 def main():
     args = parse()
+    if args.end_to_end:
+        import bench_e2e
+        return bench_e2e.main(args)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU "
+                             "(python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)\n"
+                             % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
+    import numpy as np
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -165,11 +215,12 @@ def main():
     from elector_amd.poa import PoaEngine
 
     # ---- untimed setup: synthetic reads -> windows (host), upload --------
-    reads = synthetic.read_triples(args.profile, args.reads, seed=1000 + rank)
-    read_bases = int(sum(len(r[0]) for r in reads))
+    triples, headers, read_of = synthetic.read_pieces(args.profile, args.reads, seed=1000 + rank)
+    piece_bases = int(sum(len(r[0]) for r in triples))
     nthreads = max(1, (os.cpu_count() or 1) // max(1, world))
-    win = split.split_reads(reads, 0.1, None, nthreads=nthreads)
-    del reads
+    win = split.split_reads(triples, 0.1, headers, nthreads=nthreads)
+    n_pieces_in = len(triples)
+    del triples
     off = win.off
     n = win.n_windows
     lr = off[1::3] - off[0:-1:3]
@@ -180,17 +231,19 @@ def main():
     # E engine contexts take the steps in turn (several batches in flight: the serial head and tail
     # of one batch -- symbolize / trivial pass / list sort, merge / statistics -- run beside the
     # alignment kernels of the other).  Every context has its own output buffers.
-    # Measured on the 10,001-read step: 16.0 ms with one context, 14.3 with two, 13.6 with three, 14.8 with four.
-    n_eng = max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "3")))
+    n_eng = 1 if args.serial else max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "3")))
     engines = [PoaEngine(local) for _ in range(n_eng)]
+    if args.serial:
+        engines[0].option("chains", 1)
     outs = [(torch.empty(3 * int(off[-1]) + 64, dtype=torch.uint8, device=dev),
              torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
             for _ in range(n_eng)]
     eng = engines[0]
     d_cols, d_ncol, d_status = outs[0]
-    # one msa.fa record (piece) per read, one piece per read: the synthetic corrected reads are not split
+    # one msa.fa record per corrected piece (= per emitted read of the splitter); the pieces of one
+    # read are one read again for the statistics (computeStats.py:45-56)
     piece_first = win.read_first
-    read_first = np.arange(win.n_reads + 1, dtype=np.int64)
+    read_first = synthetic.piece_groups(read_of, win.read_index)
     from elector_amd import distributed as edist
     from elector_amd._capi import ES_NCOUNTERS
 
@@ -198,7 +251,7 @@ def main():
     turn = [0]
 
     def collect():
-        """per-read counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
+        """per-piece counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
         e, npieces = pending.pop(0)
         counters, _ = engines[e].msa_stats_collect(npieces)
         return edist.gather_rows(counters) if world > 1 else counters
@@ -227,7 +280,7 @@ def main():
         collect()
     for g in engines:
         g.sync()
-        g.timing_enable(True)
+        g.timing_enable(args.serial)
         g.timing_reset()
 
     # ---- timed region ----------------------------------------------------
@@ -248,69 +301,106 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
 
-    # ---- after the clock: checks, counters, gather -------------------------
+    # ---- after the clock: serial pass for the per-kernel roofline, checks, counters, gather -----------
+    serial_steps = args.steps if args.serial else max(1, args.serial_steps)
+    serial_wall = dt / args.steps
+    if not args.serial:
+        eng.option("chains", 1)
+        eng.timing_enable(True)
+        eng.timing_reset()
+        def serial_step():
+            eng.align_device(d_bases, off, d_cols, d_ncol, d_status)
+            eng.msa_stats_collect(eng.msa_stats_enqueue(n, d_cols, d_ncol, d_status, piece_first, read_first))
+        for _ in range(2):                       # the single-chain scratch layout differs: grow it first
+            serial_step()
+        eng.sync()
+        eng.timing_reset()
+        ts = time.perf_counter()
+        for _ in range(serial_steps):
+            serial_step()
+        eng.sync()
+        serial_wall = (time.perf_counter() - ts) / serial_steps
     status = d_status.cpu().numpy()
     ncol = d_ncol.cpu().numpy().astype(np.int64)
     if status.any():
         raise SystemExit("bench: %d windows failed on device" % int((status != 0).sum()))
     po = eng.last_po_sizes(n).astype(np.int64)
+    skipped = skipped_alignment1(win, lr, lc)
     cells1, cells2 = int((lr * lc).sum()), int((po * lu).sum())
-    t_dp1, k_dp1, t_dp2, k_dp2, t_oth, t_st = 0.0, 0, 0.0, 0, 0.0, 0.0
-    for g in engines:
-        x, y = g.timing_read(0); t_dp1 += x; k_dp1 += y
-        x, y = g.timing_read(1); t_dp2 += x; k_dp2 += y
-        t_oth += g.timing_read(2)[0]
-        t_st += g.timing_read(3)[0]
+    cells1_computed = int((lr * lc)[~skipped].sum())
+    t_dp1, k_dp1 = eng.timing_read(0)
+    t_dp2, k_dp2 = eng.timing_read(1)
+    t_oth = eng.timing_read(2)[0]
+    t_st = eng.timing_read(3)[0]
     rdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
-    tot = torch.tensor([read_bases, n, cells1 + cells2], dtype=torch.int64, device=rdev)
+    tot = torch.tensor([piece_bases, n, cells1 + cells2, cells1_computed + cells2], dtype=torch.int64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt_max = float(tmax.item())
-    bases_all, windows_all, cells_all = (int(x) for x in tot.tolist())
+    bases_all, windows_all, cells_all, cells_comp_all = (int(x) for x in tot.tolist())
 
     if rank == 0:
         value = bases_all * args.steps / dt_max / 1e6
         # roofline of the dominant kernel: algorithmic bytes = 8-bit inputs + 8-bit MSA out + descriptors
         alg_bytes = int((lr + lc + lu).sum() + 3 * ncol.sum() + 28 * n)
         # kernel classes: 0 = alignment #1 stage (k_fused_a<G>, or k_dp1 on the generic path),
-        # 1 = alignment #2 stage (k_fused_b<G> / k_dp2); launches of the geometry classes run
-        # concurrently on separate streams, so their event times overlap in wall time
+        # 1 = alignment #2 stage (k_fused_b<G> / k_dp2); measured un-overlapped (serial pass)
         dom = ("k_fused_b", t_dp2, k_dp2) if t_dp2 >= t_dp1 else ("k_fused_a", t_dp1, k_dp1)
         launches = max(1, dom[2])
         avg_ms = dom[1] / launches
-        bytes_per_launch = alg_bytes * args.steps / launches
+        bytes_per_launch = alg_bytes * serial_steps / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = pmc_traffic(dom[0], args.reads)
+        pmc = pmc_file(args.profile, args.reads)
+        traffic = valu = None
+        if pmc:
+            try:
+                traffic = int(pmc["kernels"][dom[0]]["traffic_bytes_per_launch"])
+                valu = int(pmc["valu_wave_insts_per_step"])
+            except (KeyError, ValueError):
+                pass
+        step_s = dt_max / args.steps
         out = {
             "metric": "triplet-MSA Mbases/s", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s: %d reads per GPU per step, cut into windows by the ELECTOR splitter rules"
-                                   % (WORKLOADS.get(args.profile, args.profile), args.reads),
-                       "profile": args.profile, "reads_per_gpu": args.reads, "windows_per_gpu": n,
-                       "ref_bases_per_gpu": read_bases, "parallelism": "shard-by-read x%d" % world,
-                       "batches_in_flight_per_gpu": n_eng},
-            "gcups": round(cells_all * args.steps / dt_max / 1e9, 3),
-            "kernel_ms_per_step": {"alignment1_stage": round(t_dp1 / args.steps, 3),
-                                   "alignment2_stage": round(t_dp2 / args.steps, 3),
-                                   "other": round(t_oth / args.steps, 3),
-                                   "merge_and_counters": round(t_st / args.steps, 3),
-                                   "note": "sum of per-launch HIP-event times; the two launch chains overlap"},
+                                   % (WORKLOADS[args.profile], args.reads),
+                       "profile": args.profile, "reads_per_gpu": args.reads, "triples_per_gpu": n_pieces_in,
+                       "windows_per_gpu": n, "ref_bases_per_gpu": piece_bases,
+                       "filler_windows_per_gpu": int((lc == 1).sum()),
+                       "parallelism": "shard-by-read x%d" % world,
+                       "batches_in_flight_per_gpu": n_eng, "serial": bool(args.serial)},
+            # DP cells per second.  effective: every cell the reference computes (Lr*Lc + |PO|*Lu per window);
+            # computed: without alignment #1 of the windows whose corrected sequence equals the reference or
+            # differs by one substitution, which the device settles without a dynamic program (k_trivial)
+            "gcups_effective": round(cells_all * args.steps / dt_max / 1e9, 3),
+            "gcups_computed": round(cells_comp_all * args.steps / dt_max / 1e9, 3),
+            "alignment1_skipped_windows_frac": round(float(skipped.mean()), 4),
+            "kernel_ms_per_step": {"alignment1_stage": round(t_dp1 / serial_steps, 3),
+                                   "alignment2_stage": round(t_dp2 / serial_steps, 3),
+                                   "other": round(t_oth / serial_steps, 3),
+                                   "merge_and_counters": round(t_st / serial_steps, 3),
+                                   "serial_step_wall": round(serial_wall * 1e3, 3),
+                                   "note": "HIP-event time per launch, summed per step, from %d un-overlapped steps "
+                                           "(one context, one launch chain)%s"
+                                           % (serial_steps, "" if args.serial else " run after the timed region")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic,
                          "launches": int(launches), "avg_launch_ms": round(avg_ms, 4),
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch)},
-            # what actually binds: VALU issue.  peak = 256 CUs x 4 SIMDs x one wavefront
-            # instruction per 4 cycles at 2.4 GHz; insts from the committed PMC passes, time measured live
-            "roofline_valu": (lambda v: None if v is None else {
-                "bound": "valu-issue", "wave_insts_per_step": v, "peak": 614.4, "unit": "G wave-insts/s",
-                "achieved": round(v * world / (dt_max / args.steps) / 1e9, 1),
-                "frac": round(v / (dt_max / args.steps) / 614.4e9, 4)})(pmc_valu(args.reads)),
-            "reads_gathered": int(counters.shape[0]),
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "whole_step_frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 6)},
+            # what actually binds: VALU issue + latency.  Per GPU: wave-instructions per
+            # step from the committed PMC passes of this command, time measured live
+            "roofline_valu": None if valu is None else {
+                "bound": "valu-issue", "wave_insts_per_step": valu, "peak": round(VALU_PEAK_GINSTS, 1),
+                "unit": "G wave-insts/s per GPU",
+                "achieved": round(valu / step_s / 1e9, 1),
+                "frac": round(valu / step_s / 1e9 / VALU_PEAK_GINSTS, 4)},
+            "pieces_gathered": int(counters.shape[0]),
             "counters_checksum": int(counters[:, :ES_NCOUNTERS - 1].sum()),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -36,7 +36,7 @@ EXPORTS = [
     "elector_ctx_create", "elector_ctx_destroy", "elector_ctx_last_error",
     "elector_poa_batch", "elector_poa_batch_device", "elector_ctx_sync",
     "elector_ctx_timing_enable", "elector_ctx_timing_read", "elector_ctx_timing_reset",
-    "elector_ctx_last_po_sizes", "elector_ctx_keep_graph", "elector_poa_bundles",
+    "elector_ctx_last_po_sizes", "elector_ctx_option", "elector_ctx_keep_graph", "elector_poa_bundles",
     "elector_stats_batch", "elector_msa_stats_device", "elector_msa_stats_enqueue", "elector_msa_stats_collect",
     "elector_msa_rows_fetch", "elector_homopolymer_pairs",
     "elector_split_reads", "elector_windows_free", "elector_merge_windows", "elector_msa_free",
@@ -88,6 +88,7 @@ def lib():
     L.elector_ctx_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]
     L.elector_ctx_timing_reset.argtypes = [vp]
     L.elector_ctx_last_po_sizes.argtypes = [vp, i64, vp]
+    L.elector_ctx_option.argtypes = [vp, C.c_char_p, i64]
     L.elector_ctx_keep_graph.argtypes = [vp, C.c_int]
     L.elector_poa_bundles.argtypes = [vp, i64, C.c_float, vp, i64, vp, vp]
     L.elector_msa_stats_device.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64]

@@ -64,6 +64,12 @@ def _poa_header(href):
     return b">" + name + b" " + (rest if rest else b"untitled")
 
 
+def _donatello_header(h):
+    """Donatello prints header.substr(0, header.size() - 11) + " " (Donatello.cpp:71-73); the
+    subtraction is unsigned, so a header line shorter than 11 bytes wraps around and is kept whole."""
+    return (h if len(h) < 11 else h[: len(h) - 11]) + b" "
+
+
 def align_batch(engine, reads, headers, size_threshold, threads):
     """One batch: [(reference, corrected, uncorrected)] + header lines ->
     (list of (header_out, ref_row, cor_row, unc_row) per output record, small, wrong)."""
@@ -88,7 +94,7 @@ def align_batch(engine, reads, headers, size_threshold, threads):
     for k in range(len(groups) - 1):
         h = hdr[groups[k]]
         a, nc = int(moff[k]), int(mcols[k])
-        out.append((h[: len(h) - 11] + b" ", buf[a:a + nc], buf[a + nc:a + 2 * nc], buf[a + 2 * nc:a + 3 * nc]))
+        out.append((_donatello_header(h), buf[a:a + nc], buf[a + nc:a + 2 * nc], buf[a + 2 * nc:a + 3 * nc]))
     return out, win.small_reads, win.wrong_reads
 
 

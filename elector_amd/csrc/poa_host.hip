@@ -366,6 +366,18 @@ extern "C" int elector_ctx_timing_reset(elector_ctx *c)
   return ELECTOR_OK;
 }
 
+extern "C" int elector_ctx_option(elector_ctx *c, const char *name, int64_t value)
+{
+  if (!c || !name) return ELECTOR_E_INVAL;
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!std::strcmp(name, "chains")) {                 // concurrent launch chains of the fused classes; 0 = default
+    if (value < 0 || value > elector_ctx::kAux) return fail(c, ELECTOR_E_INVAL, "chains must be 0..4");
+    c->chains = (int)value;
+    return ELECTOR_OK;
+  }
+  return fail(c, ELECTOR_E_INVAL, "unknown option");
+}
+
 extern "C" int elector_ctx_last_po_sizes(elector_ctx *c, int64_t n, int32_t *po_nodes)
 {
   if (!c || !po_nodes || n < 0 || n > c->last_n) return ELECTOR_E_INVAL;
@@ -702,7 +714,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // geometry compete for LDS and L2 -- and a single chain pays every kernel's tail), so the four
   // launches go to TWO streams; within a chain big classes first, alignment #1 then #2 of each bin.
   // ELECTOR_CHAINS=1|4 are the alternatives for experiments (4 = one stream per group size).
-  static const int n_chains = std::getenv("ELECTOR_CHAINS") ? std::max(1, std::min(4, std::atoi(std::getenv("ELECTOR_CHAINS")))) : 2;
+  const int n_chains = c->chains > 0 ? c->chains
+                       : std::getenv("ELECTOR_CHAINS") ? std::max(1, std::min(4, std::atoi(std::getenv("ELECTOR_CHAINS")))) : 2;
   std::vector<int> bin_stream((size_t)kBins, 0), bin_order;
   {
     auto group_of = [&](int b) { const int G = kClsG[b / kNT]; return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };

@@ -1,5 +1,5 @@
 """Multi-GPU layer: one process per GPU (torchrun), reads sharded by contiguous
-ranges balanced by bases, NO data-path collective; a single gather of the
+ranges balanced by DP cells (read_cell_estimate), NO data-path collective; a single gather of the
 per-piece integer counters to rank 0 at the end.
 
 `backend="nccl"` is RCCL over xGMI on the GPU node; the same code runs on the
@@ -20,9 +20,25 @@ def shard_bounds(weights, world):
     cum = np.cumsum(np.asarray(weights, dtype=np.float64))
     total = cum[-1]
     for r in range(1, world):
-        b[r] = int(np.searchsorted(cum, total * r / world, side="left"))
+        t = total * r / world
+        k = int(np.searchsorted(cum, t, side="left"))          # first prefix whose sum reaches the target
+        # cut after item k when that lands closer to the target than cutting in front of it
+        before = cum[k - 1] if k > 0 else 0.0
+        b[r] = k + 1 if k < n and (cum[k] - t) <= (t - before) else k
     b[world] = n
     return np.maximum.accumulate(b)
+
+
+def read_cell_estimate(lr, lc, lu, window=60):
+    """DP cells a read triple will cost, known before it is split (shards are balanced
+    by sum of cells, Lr*Lc + |PO|*Lu per window).  Windows are about `window` bases long whatever the read
+    length, so alignment #1 costs ~window cells per corrected base and alignment #2 ~window cells per
+    uncorrected base where the corrected read covers the reference, 1 + 1 cells per base where it does
+    not (`N` filler windows: Lr x 1 and (Lr + 1) x Lu / windows)."""
+    lr = np.asarray(lr, dtype=np.float64)
+    lc = np.minimum(np.asarray(lc, dtype=np.float64), lr)
+    lu = np.asarray(lu, dtype=np.float64)
+    return window * (lc + lu * 1.05) + (lr - lc)
 
 
 def gather_rows(local, group=None, dst=0):
@@ -54,7 +70,7 @@ def sharded_counters(pieces, counter_fn, group=None):
     counter_fn(sub_pieces) -> int64[n_pieces_local, C]; rank 0 receives all rows in
     piece order.  `pieces` is the full elector_amd.computeStats.Pieces on every rank."""
     import torch.distributed as dist
-    from .computeStats import Pieces
+    from .computeStats import Pieces, ES_NCOUNTERS
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_reads = len(pieces.read_first) - 1
@@ -68,5 +84,5 @@ def sharded_counters(pieces, counter_fn, group=None):
     sub.row_off = np.ascontiguousarray(pieces.row_off[p0:p1 + 1] - pieces.row_off[p0])
     sub.rows = np.ascontiguousarray(pieces.rows[pieces.row_off[p0]:pieces.row_off[p1]])
     sub.read_first = np.ascontiguousarray(pieces.read_first[r0:r1 + 1] - p0)
-    local = counter_fn(sub) if p1 > p0 else np.zeros((0, 1), dtype=np.int64)
+    local = counter_fn(sub) if p1 > p0 else np.zeros((0, ES_NCOUNTERS), dtype=np.int64)
     return gather_rows(local, group)

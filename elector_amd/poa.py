@@ -213,6 +213,10 @@ class PoaEngine:
         self._check(self._lib.elector_ctx_timing_read(self._h, kernel, C.byref(ms), C.byref(k)))
         return ms.value, k.value
 
+    def option(self, name, value):
+        """elector_ctx_option: "chains" = concurrent launch chains of the fused classes (0 = default)."""
+        self._check(self._lib.elector_ctx_option(self._h, name.encode(), int(value)))
+
     def last_po_sizes(self, n):
         out = np.zeros(n, dtype=np.int32)
         self._check(self._lib.elector_ctx_last_po_sizes(self._h, n, out.ctypes.data))

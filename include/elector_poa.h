@@ -120,6 +120,11 @@ int elector_ctx_sync(elector_ctx *ctx);
 int elector_ctx_timing_enable(elector_ctx *ctx, int on);
 int elector_ctx_timing_read(elector_ctx *ctx, int kernel, double *ms, int64_t *launches);
 int elector_ctx_timing_reset(elector_ctx *ctx);
+/* tuning / measurement knobs.  "chains" = number of concurrent launch chains the
+ * geometry classes of the fused kernels are dealt to (1..4; 0 = the default, 2):
+ * with 1 every kernel of a batch runs alone on the chip, which is what an
+ * un-overlapped per-kernel measurement needs (bench.py's serial pass). */
+int elector_ctx_option(elector_ctx *ctx, const char *name, int64_t value);
 /* diagnostics: |PO| (nodes after fusion #1) of the first n windows of the last
  * batch, so callers can count the DP cells of alignment #2 (|PO| x Lu). */
 int elector_ctx_last_po_sizes(elector_ctx *ctx, int64_t n, int32_t *po_nodes);

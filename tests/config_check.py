@@ -1,0 +1,141 @@
+"""One BASELINE.json workload pushed through the product on the GPU at the size bench.py runs it,
+checked with size-independent properties plus stratified samples against the CPU oracles
+(TEST INFRASTRUCTURE: imports oracle/).
+
+    pieces -> elector_split_reads -> elector_poa_batch_device -> elector_msa_stats_device
+
+  * every window finishes with status 0;
+  * every MSA row, gaps removed, spells its input sequence (a misplaced, lost or duplicated letter
+    breaks it) and max(L) <= ncol <= sum(L);
+  * a sample of windows stratified by size class -- including `N` filler windows, the longest
+    windows and any window ids the caller names -- is bit-exact against oracle/poa_oracle.c;
+  * the per-piece integer counters of the first reads (all their pieces) equal the statistics
+    oracle run on the msa.fa text the oracle chain writes for those reads;
+  * whole-batch conservation: the counters' non-gap lengths sum to the input lengths of the
+    emitted pieces (minus the dropped `n` columns), whatever the batch size.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import oracle_lib  # noqa: E402
+
+
+def ranges_gather(starts, lengths):
+    """indices of the concatenation of [starts[i], starts[i] + lengths[i])"""
+    total = int(lengths.sum())
+    ends = np.cumsum(lengths)
+    base = np.repeat(starts - (ends - lengths), lengths)
+    return base + np.arange(total, dtype=np.int64)
+
+
+def oracle_window_sample(win, cols, ncol, pick):
+    lens = np.diff(win.off)
+    off = win.off
+    sb = b"".join(bytes(win.bases[off[3 * w]:off[3 * w + 3]]) for w in pick)
+    soff = np.zeros(3 * len(pick) + 1, dtype=np.int64)
+    np.cumsum(np.concatenate([lens[3 * w:3 * w + 3] for w in pick]), out=soff[1:])
+    exp_rows, exp_ncol, _, _ = oracle_lib.batch(np.frombuffer(sb, dtype=np.uint8), soff)
+    for k, w in enumerate(pick):
+        nc = int(ncol[w])
+        assert nc == exp_ncol[k], (int(w), nc, int(exp_ncol[k]))
+        block = cols[3 * off[3 * w]:3 * off[3 * w] + 3 * nc].reshape(nc, 3)
+        assert tuple(bytes(block[:, r]) for r in range(3)) == exp_rows[k], int(w)
+
+
+def run_workload(engine, triples, headers, read_of, tmp_path, oracle_windows=500, oracle_reads=8,
+                 must_check=(), max_oracle_cells=3.0e9, nthreads=16):
+    """-> dict of what was seen (counts for the caller's own assertions)"""
+    import torch
+    import msa_gen
+    import stats_oracle
+    from test_stats_cpu import oracle_counter_array
+    from elector_amd import computeStats as cs
+    from elector_amd import split, synthetic
+
+    win = split.split_reads(triples, 0.1, headers, nthreads=nthreads)
+    off, n = win.off, win.n_windows
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(win.bases).to(dev)
+    d_cols = torch.zeros(3 * int(off[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_ncol = torch.empty(n, dtype=torch.int32, device=dev)
+    d_status = torch.empty(n, dtype=torch.int32, device=dev)
+    engine.align_device(d_bases, off, d_cols, d_ncol, d_status)
+    engine.sync()
+    status = d_status.cpu().numpy()
+    assert not status.any(), "windows failed: %s" % np.unique(status, return_counts=True)
+    cols = d_cols.cpu().numpy()
+    ncol = d_ncol.cpu().numpy().astype(np.int64)
+
+    lens = np.diff(off)
+    lr, lc, lu = lens[0::3], lens[1::3], lens[2::3]
+    assert (ncol >= np.maximum(np.maximum(lr, lc), lu)).all() and (ncol <= lr + lc + lu).all()
+    msa = cols[ranges_gather(3 * off[0:-1:3], 3 * ncol)].reshape(-1, 3)
+    lower = np.frombuffer(bytes(win.bases).lower(), dtype=np.uint8)
+    for r in range(3):
+        got = msa[:, r][msa[:, r] != ord(".")]
+        exp = lower[ranges_gather(off[r:-1:3], lens[r::3])]
+        assert got.shape == exp.shape and np.array_equal(got, exp), "row %d does not spell its input" % r
+    del msa
+
+    # ---- windows against the POA oracle, stratified by size; filler and long windows included ----
+    rng = np.random.default_rng(7)
+    order = np.argsort(lu, kind="stable")
+    filler = np.nonzero(lc == 1)[0]
+    cells = lr * lc + (lr + lc) * lu
+    pick = np.unique(np.concatenate([order[:: max(1, n // max(1, oracle_windows // 2))], order[-12:],
+                                     rng.integers(0, n, oracle_windows // 4),
+                                     filler[:: max(1, len(filler) // max(1, oracle_windows // 4))][: oracle_windows // 4],
+                                     np.asarray(list(must_check), dtype=np.int64)]))
+    # keep the oracle's share of the run bounded (it does ~50 M cells per second)
+    keep, acc = [], 0.0
+    forced = set(int(x) for x in must_check)
+    for w in pick[np.argsort(cells[pick], kind="stable")]:
+        if acc + cells[w] <= max_oracle_cells or int(w) in forced:
+            keep.append(int(w))
+            acc += float(cells[w])
+    oracle_window_sample(win, cols, ncol, np.asarray(sorted(keep), dtype=np.int64))
+
+    # ---- merge + statistics on the device; the first reads against the statistics oracle ----
+    read_first = synthetic.piece_groups(read_of, win.read_index)
+    counters, piece_cols, _, _ = engine.msa_stats_device(n, d_cols, d_ncol, d_status, win.read_first, read_first)
+    n_reads = len(read_first) - 1
+    kr = min(oracle_reads, n_reads)
+    if kr:
+        p1 = int(read_first[kr])
+        sub = [(headers[int(i)],) + tuple(triples[int(i)]) for i in win.read_index[:p1]]
+        txt, _, _ = msa_gen.msa_text(sub)
+        path = os.path.join(str(tmp_path), "sample_msa.fa")
+        with open(path, "w") as f:
+            f.write(txt)
+        pieces = cs.parse_msa(path, cs.getSplit(path))
+        assert np.array_equal(pieces.read_first, read_first[:kr + 1])
+        assert np.array_equal(piece_cols[:p1], pieces.cols)
+        _, oracle_pieces = stats_oracle.compute_metrics(txt, 5)
+        exp = oracle_counter_array(pieces, oracle_pieces)
+        got = counters[:p1]
+        assert np.array_equal(got[:, cs.ES_PROCESSED], exp[:, cs.ES_PROCESSED])
+        proc = exp[:, cs.ES_PROCESSED] == 1
+        assert np.array_equal(got[proc], exp[proc]), np.argwhere(got[proc] != exp[proc])[:5]
+
+    # ---- conservation over the whole batch ----
+    proc = counters[:, cs.ES_PROCESSED] == 1
+    wf = win.read_first
+    piece_lr = np.add.reduceat(lr, wf[:-1])
+    piece_lu = np.add.reduceat(lu, wf[:-1])
+    nfill = np.add.reduceat((lc == 1) & (win.bases[off[1:-1:3]] == ord("N")), wf[:-1])
+    piece_lc = np.add.reduceat(lc, wf[:-1]) - nfill
+    # the column of an `N` filler is dropped (Donatello.cpp:13-31) together with the reference /
+    # uncorrected letter that may share it: at most one letter per filler window
+    for idx, tot in ((cs.ES_LEN_REF, piece_lr), (cs.ES_LEN_UNC, piece_lu)):
+        assert (counters[proc, idx] <= tot[proc]).all() and (counters[proc, idx] >= (tot - nfill)[proc]).all()
+    assert np.array_equal(counters[proc, cs.ES_LEN_COR], piece_lc[proc])
+    return dict(windows=n, pieces=int(win.n_reads), reads=n_reads, filler=int(len(filler)), small=int(win.small_reads),
+                wrong=int(win.wrong_reads), max_window=int(max(lr.max(), lu.max())), checked=len(keep),
+                split_reads=int((np.diff(read_first) > 1).sum()), win=win, cols=cols, ncol=ncol)

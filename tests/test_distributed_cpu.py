@@ -85,3 +85,60 @@ def test_shard_bounds():
     assert shard_bounds([], 4).tolist() == [0, 0, 0, 0, 0]
     b = shard_bounds(np.ones(101), 8)
     assert b[0] == 0 and b[-1] == 101 and np.all(np.diff(b) >= 12) and np.all(np.diff(b) <= 14)
+
+
+def test_empty_shard_gathers(tmp_path):
+    """Fewer reads than ranks: the rank whose shard is empty must send a [0, ES_NCOUNTERS] block."""
+    import msa_gen
+    from elector_amd import computeStats as cs
+    reads = msa_gen.make_reads(78, 1, 700)[:1]
+    txt, _, _ = msa_gen.msa_text(reads)
+    msa = str(tmp_path / "msa.fa")
+    open(msa, "w").write(txt)
+    res = str(tmp_path / "counters.npy")
+    mp.spawn(_worker, args=(2, 29519, msa, res), nprocs=2, join=True)
+    got = np.load(res)
+    pieces = cs.parse_msa(msa, cs.getSplit(msa))
+    assert np.array_equal(got, _oracle_counter_fn(pieces))
+
+
+def test_read_cell_estimate_balances_by_cells():
+    """ranks get contiguous read ranges of near-equal DP cells, not near-equal counts."""
+    from elector_amd.distributed import read_cell_estimate, shard_bounds
+    lr = np.array([8000] * 50 + [50000] * 10)
+    w = read_cell_estimate(lr, lr, lr)
+    b = shard_bounds(w, 2)
+    assert b[1] > 50                       # the ten long reads weigh more than the fifty short ones
+    assert abs(w[: b[1]].sum() - w[b[1]:].sum()) <= w.max()
+    # a trimmed corrected read costs less than a whole one (its missing part becomes 1-letter `N` windows)
+    assert read_cell_estimate(np.array([8000]), np.array([2000]), np.array([8000]))[0] < w[0]
+
+
+def test_bench_refuses_world_size_mismatch():
+    """`bench.py --gpus N` with another WORLD_SIZE must fail loudly, before any GPU call (no GPU here)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """--gpus N without WORLD_SIZE starts N fresh rank processes through torch.distributed.run."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.self_launch(bench.parse()) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
