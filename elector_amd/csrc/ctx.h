@@ -83,7 +83,7 @@ struct elector_ctx {
   elector::DevBuf d_tab, d_linx, d_liny;
   // per-batch workspace
   elector::DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
-      d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_fmv, d_tstate, d_tlist;
+      d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_fmv, d_tstate, d_tlist, d_gring;
   // host API staging
   elector::DevBuf d_bases, d_cols, d_ncol, d_status, d_scores, d_rowoff, d_rows;
   // pinned upload staging of the per-batch metadata, double-buffered: a batch's host-to-device copies

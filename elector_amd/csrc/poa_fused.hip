@@ -435,9 +435,9 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
     a.b.n1[W.w] = n1;
     const int need = maxd + 2;
     if (a.debug & 32) atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 16 + min(need, 15), 1ull);   // histogram (diagnostics)
-    // bits 0-1: ring class of the generic k_dp2; bit 6 / bit 7: too deep for k_fused_b's 4- / 8-deep ring
-    a.b.cls[W.w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 4 ? 0x40 : 0) | (need > 8 ? 0x80 : 0));
-    if (need > 512) a.b.status[W.w] = 2;
+    // bits 0-1: ring class of the generic k_dp2 (0: LDS ring, 1: with the HBM shadow); bit 6 / bit 7: too deep
+    // for k_fused_b's 4- / 8-deep ring
+    a.b.cls[W.w] = (uint8_t)((need <= 32 ? 0 : 1) | (need > 4 ? 0x40 : 0) | (need > 8 ? 0x80 : 0));
     if (bad) a.b.status[W.w] = 3;
     a.done_a[W.w] = 1;
   }

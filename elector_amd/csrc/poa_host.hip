@@ -26,10 +26,11 @@ void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st);
 void launch_fuse1(const BatchArgs &a, hipStream_t st);
 void launch_dp1_tile(const BatchArgs &a, const TileArgs &ta, bool gen, int ntiles, int nw, hipStream_t st);
 void launch_dp2_tile(const BatchArgs &a, const TileArgs &ta, bool gen, int ntiles, int nw, hipStream_t st);
-void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st);
+void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st, int32_t *gring, int64_t gring_block, int blocks);
 void launch_fuse2(const BatchArgs &a, hipStream_t st);
 void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uint8_t *done_b, int64_t *mv2,
-                   unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, hipStream_t st);
+                   unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, int round,
+                   int last_round, hipStream_t st);
 void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
                  uint8_t *rows, int64_t n, hipStream_t st);
 void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, hipStream_t st);
@@ -300,7 +301,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit,
-                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist};
+                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring};
   for (DevBuf *b : bufs) b->release();
   for (auto &s : c->st_slot) s.release();
   for (int k = 0; k < 2; ++k) {
@@ -395,7 +396,9 @@ extern "C" int elector_ctx_last_po_sizes(elector_ctx *c, int64_t n, int32_t *po_
 // scratch stays below this, and the device-side bump allocator (windows the fused
 // kernels hand back) gets a fixed budget on top.
 static const int64_t kMovesBudgetDwords = (int64_t)3 << 28;   // 3 GiB
-static const int64_t kBumpBudgetDwords = (int64_t)1 << 28;    // 1 GiB
+static const int64_t kBumpBudgetDwords = (int64_t)1 << 30;    // 4 GiB
+static const int kLeftRoundsMax = 6;                          // passes over the handed-back windows (see run_device_batch)
+static const int64_t kDeepRingBytes = (int64_t)1 << 30;       // HBM shadow rings of the deep-graph alignment #2 (k_dp2 DEEP)
 
 // fused-kernel geometry classes: G lanes per window x R rows per lane, ordered by the rows one
 // strip holds (must match ELECTOR_FUSED_CLASSES in poa_fused.hip).  A window goes to the first
@@ -481,6 +484,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   build_tiers();
   std::vector<int16_t> bin((size_t)n, -1);
   int64_t key_cnt[NB + 1] = {0}, n_generic = 0;
+  int64_t left_worst = 0;        // moves (dwords) of alignment #2 if every fused-routed window were handed back
+  int64_t max_po_bound = 0;      // largest Lr + Lc of the batch (bounds |PO| and with it a strip's steps)
   std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)5 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc
   int64_t *bin_max_lr = bin_need_a.data() + kBins, *bin_max_lc = bin_max_lr + kBins, *bin_max_lu = bin_max_lc + kBins,
           *bin_max_po = bin_max_lu + kBins;
@@ -507,7 +512,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
     // per thread: size keys, bin counts, generic count, then per bin the maxima of
     // alignment #1's slot need, Lr, Lc, Lu and Lr + Lc (the bound on |PO|)
-    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + 1 + 5 * kBins, 0));
+    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + 1 + 5 * kBins + 2, 0));
     auto work = [&](int t) {
       const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
       int64_t *cnt = tcnt[(size_t)t].data();
@@ -556,8 +561,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
             mx[4 * kBins] = std::max<int64_t>(mx[4 * kBins], lr + lc);
           }
         }
-        if (bin[(size_t)w] >= 0) cnt[NB + bin[(size_t)w]]++;
-        else cnt[NB + kBins]++;                           // generic (incl. failed windows)
+        if (bin[(size_t)w] >= 0) {
+          cnt[NB + bin[(size_t)w]]++;
+          // moves the generic alignment #2 needs if the fused kernels hand this window back
+          cnt[NB + kBins + 1 + 5 * kBins] += (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64;
+        } else cnt[NB + kBins]++;                         // generic (incl. failed windows)
+        if (!st) cnt[NB + kBins + 2 + 5 * kBins] = std::max(cnt[NB + kBins + 2 + 5 * kBins], lr + lc);
         const int64_t mlen = std::max(lr, lu);
         int k = (int)(mlen >> 3);
         if (k >= NB) k = NB - 1;
@@ -574,6 +583,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       for (int b = 0; b < kBins; ++b) bin_cnt[b] += tcnt[(size_t)t][(size_t)(NB + b)];
       n_generic += tcnt[(size_t)t][(size_t)(NB + kBins)];
       for (int b = 0; b < 5 * kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + 1 + b)]);
+      left_worst += tcnt[(size_t)t][(size_t)(NB + kBins + 1 + 5 * kBins)];
+      max_po_bound = std::max(max_po_bound, tcnt[(size_t)t][(size_t)(NB + kBins + 2 + 5 * kBins)]);
     }
   }
   if (bad_offsets.load()) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
@@ -696,7 +707,16 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   }
   int64_t max_dwords = 0;
   for (auto &ch : chunks) max_dwords = std::max(max_dwords, ch.dwords);
-  const int64_t bump_dwords = use_fused ? std::min<int64_t>(kBumpBudgetDwords, ((int64_t)1 << 24) + 16 * (total + 64 * n)) : 0;
+  // Windows the fused kernels hand back get their moves from a device-side bump allocator.  Its budget covers
+  // the worst case (every window handed back) up to 4 GiB; beyond that the leftovers are worked off in several
+  // rounds (collect what fits -> alignment #2 -> fusion #2), so no window within the documented limits is ever
+  // refused for lack of scratch.  Rounds that find nothing left cost four empty launches.
+  const int64_t bump_dwords = use_fused ? std::min<int64_t>(kBumpBudgetDwords, std::max<int64_t>((int64_t)1 << 22, left_worst)) : 0;
+  const int left_rounds = use_fused ? (int)std::min<int64_t>(kLeftRoundsMax, (left_worst + bump_dwords - 1) / std::max<int64_t>(1, bump_dwords) +
+                                                                            (left_worst > bump_dwords ? 1 : 0)) : 0;
+  // HBM shadow rings of the deep-graph alignment #2: one region of (|PO| + 66) x 64 cells per block
+  const int64_t gring_block = (max_po_bound + 66) * 64;
+  const int deep_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, kDeepRingBytes / (gring_block * 4)));
 
   // moves scratch of the fused kernels: launches on one stream run one after the other and the moves
   // of a launch die with it, so every stream owns one region as large as its largest launch needs
@@ -771,7 +791,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
        c->d_list.ensure((size_t)3 * n * 4 + (size_t)kBins * 32 + part_chunks_max * (16 + 4 * (size_t)partition_buckets()) + 64) |
        c->d_done.ensure((size_t)5 * n + 64) |
        c->d_rowinit.ensure(1024 + 256 * (size_t)kBins) |
-       c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256);
+       c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256) |
+       c->d_gring.ensure((size_t)deep_blocks * (size_t)gring_block * 4 + 256);
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
   if (use_fused && (rc = ensure_streams(c))) return fail(c, rc, "auxiliary streams");
 
@@ -824,7 +845,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipEventRecord(h_done, st));
   HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)5 * n, st));
-  HIPCHK(c, hipMemsetAsync(d_counters, 0, 16, st));
+  HIPCHK(c, hipMemsetAsync(d_counters, 0, 64, st));
   if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 256 * (size_t)kBins, st));
 
   const double tp4 = now_ms();
@@ -990,7 +1011,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       timed_end(c, st);
       if (chunks.size() > 1) {      // several chunks share the scratch: finish each one completely
         a.mark_b = d_done_b;
-        for (int cls = 0; cls < 3; ++cls) launch_dp2(a, c->gen, cls, st);
+        for (int cls = 0; cls < 2; ++cls) launch_dp2(a, c->gen, cls, st, c->d_gring.as<int32_t>(), gring_block, deep_blocks);
         launch_fuse2(a, st);
         a.mark_b = nullptr;
       }
@@ -1001,13 +1022,21 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     a.perm = nullptr;
     a.count_ptr = nullptr;
     timed_begin(c, 2, st);
-    launch_left_b(a, d_leftb, d_counters, d_done_b, c->d_mv2.as<int64_t>(),
-                  reinterpret_cast<unsigned long long *>(d_counters + 2), (unsigned long long)max_dwords,
-                  (unsigned long long)bump_dwords, st);
-    a.perm = d_leftb;
-    a.count_ptr = d_counters;
-    for (int cls = 0; cls < 3; ++cls) launch_dp2(a, c->gen, cls, st);
-    launch_fuse2(a, st);
+    for (int round = 0; round < std::max(1, left_rounds); ++round) {
+      if (round > 0) HIPCHK(c, hipMemsetAsync(d_counters, 0, 16, st));            // list length, bump pointer
+      a.n = n;
+      a.perm = nullptr;
+      a.count_ptr = nullptr;
+      launch_left_b(a, d_leftb, d_counters, d_done_b, c->d_mv2.as<int64_t>(),
+                    reinterpret_cast<unsigned long long *>(d_counters + 2), (unsigned long long)max_dwords,
+                    (unsigned long long)bump_dwords, round, round + 1 >= std::max(1, left_rounds) ? 1 : 0, st);
+      a.perm = d_leftb;
+      a.count_ptr = d_counters;
+      a.mark_b = d_done_b;
+      for (int cls = 0; cls < 2; ++cls) launch_dp2(a, c->gen, cls, st, c->d_gring.as<int32_t>(), gring_block, deep_blocks);
+      launch_fuse2(a, st);
+      a.mark_b = nullptr;
+    }
     timed_end(c, st);
   } else {
     // ---- generic path only (general scoring parameters, or fused kernels disabled) ----
@@ -1026,7 +1055,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       timed_end(c, st);
       if ((rc = run_tiles(lw, 2))) return fail(c, rc, "tiled alignment #2");
       timed_begin(c, 1, st);
-      for (int cls = 0; cls < 3; ++cls) launch_dp2(a, c->gen, cls, st);
+      for (int cls = 0; cls < 2; ++cls) launch_dp2(a, c->gen, cls, st, c->d_gring.as<int32_t>(), gring_block, deep_blocks);
       timed_end(c, st);
       timed_begin(c, 2, st);
       launch_fuse2(a, st);

@@ -185,9 +185,13 @@ __global__ void __launch_bounds__(64) k_dp1(BatchArgs a)
 // by this lane d = jj - pp steps ago, and (ii-1, pp) by lane-1 one step before
 // that.  Bank = lane, so ring accesses never conflict.
 
-template <bool GEN, int D>
+// DEEP: predecessors farther back than the LDS ring reaches (a corrected piece whose long unaligned
+// tail sits between two reference letters, Master_Splitter.cpp:295-301, puts hundreds of nodes between
+// a node and its predecessor) come from a shadow of the ring in HBM that holds every step of the strip:
+// gring[t][lane], written once per step (fire and forget), read only by the rare far accesses.
+template <bool GEN, int D, bool DEEP>
 __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring, const int cls, const uint32_t w,
-                           const int lane)
+                           const int lane, int32_t *gring)
 {
   if (a.status[w] || (a.cls[w] & 3) != cls || (a.skip_b && a.skip_b[w]) || (a.tiled && (a.tiled[w] & 2))) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
@@ -236,15 +240,28 @@ __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring
 
       // predecessor cells: own row from this lane's ring, row above from lane-1's
       int own1 = col_own, dg1 = col_dg, own2 = 0, dg2 = 0;
+      const bool far1 = DEEP && !virt1 && d1 > D - 2, far2 = DEEP && has2 && d2 > D - 2;
+      if (DEEP && __builtin_amdgcn_ballot_w64(far1 || far2) != 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the shadow stores of the steps read below have landed
       if (!virt1) {
         const int d = d1;
-        own1 = ring[((t - d) & MASK) * 64 + lane];
-        dg1 = ring[((t - d - 1) & MASK) * 64 + lm1];
+        if (far1) {
+          own1 = ld_carry(gring + (int64_t)(t - d) * 64 + lane);
+          dg1 = ld_carry(gring + (int64_t)(t - d - 1) * 64 + lm1);
+        } else {
+          own1 = ring[((t - d) & MASK) * 64 + lane];
+          dg1 = ring[((t - d - 1) & MASK) * 64 + lm1];
+        }
       }
       if (has2) {
         const int d = d2;
-        own2 = ring[((t - d) & MASK) * 64 + lane];
-        dg2 = ring[((t - d - 1) & MASK) * 64 + lm1];
+        if (far2) {
+          own2 = ld_carry(gring + (int64_t)(t - d) * 64 + lane);
+          dg2 = ld_carry(gring + (int64_t)(t - d - 1) * 64 + lm1);
+        } else {
+          own2 = ring[((t - d) & MASK) * 64 + lane];
+          dg2 = ring[((t - d - 1) & MASK) * 64 + lm1];
+        }
       }
       // X-insertion: first maximum over the predecessor list wins (:361-371)
       const int gx1 = cell_tag(own1), gx2 = cell_tag(own2);
@@ -273,6 +290,7 @@ __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring
       S1 = S; g1 = g;
 
       ring[(t & MASK) * 64 + lane] = pack_cell(S, g);
+      if (DEEP) st_carry(gring + (int64_t)t * 64 + lane, pack_cell(S, g));
       __builtin_amdgcn_wave_barrier();
 
       mvacc |= nib << (4 * (t & 7));
@@ -289,8 +307,8 @@ __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring
   if (lane == (Ly - 1) % kStripRows + 1) { a.score2[w] = best; a.bx2[w] = bestx; }
 }
 
-template <bool GEN, int D>
-__global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls)
+template <bool GEN, int D, bool DEEP>
+__global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls, int32_t *gring, int64_t gring_block)
 {
   __shared__ int ring[D * 64];
   __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
@@ -299,7 +317,7 @@ __global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls)
   Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
   const int64_t cnt = list_count(a);
   for (int64_t i = blockIdx.x; i < cnt; i += gridDim.x) {
-    dp2_window<GEN, D>(a, sc, ring, cls, a.perm[i], lane);
+    dp2_window<GEN, D, DEEP>(a, sc, ring, cls, a.perm[i], lane, DEEP ? gring + blockIdx.x * gring_block : nullptr);
     __syncthreads();
   }
 }
@@ -537,18 +555,23 @@ __global__ void __launch_bounds__(64) k_fuse2(BatchArgs a)
 // allocator over a fixed scratch budget.
 __global__ void __launch_bounds__(256) k_left_b(BatchArgs a, uint32_t *list, int32_t *count, const uint8_t *done_b,
                                                int64_t *mv2, unsigned long long *bump, unsigned long long bump_base,
-                                               unsigned long long bump_cap)
+                                               unsigned long long bump_cap, int32_t *overflow, int round, int last_round)
 {
+  // overflow[r] = windows that found no room in round r; a round that follows one without overflow has nothing to do
+  if (round > 0 && overflow[round - 1] == 0) return;
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= a.n) return;
   if (a.status[w]) { if (!done_b[w]) a.ncol[w] = 0; return; }
   if (done_b[w]) return;
   if (mv2[w] < 0) {
-    const int64_t o0 = a.off[3 * w], o2 = a.off[3 * w + 2], o3 = a.off[3 * w + 3];
-    (void)o0;
+    const int64_t o2 = a.off[3 * w + 2], o3 = a.off[3 * w + 3];
     const unsigned long long need = (unsigned long long)n_strips((int)(o3 - o2)) * mv_tw(a.n1[w]) * 64;
     const unsigned long long at = atomicAdd(bump, need);
-    if (at + need > bump_cap) { a.status[w] = 2; a.ncol[w] = 0; return; }
+    if (at + need > bump_cap) {
+      atomicAdd(overflow + round, 1);
+      if (last_round) { a.status[w] = 2; a.ncol[w] = 0; }     // more scratch than kLeftRoundsMax passes provide
+      return;                                                  // otherwise: the next round takes it
+    }
     mv2[w] = (int64_t)(bump_base + at);
   }
   list[atomicAdd(count, 1)] = (uint32_t)w;
@@ -768,25 +791,28 @@ void launch_fuse1(const BatchArgs &a, hipStream_t st)
 }
 
 void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uint8_t *done_b, int64_t *mv2,
-                   unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, hipStream_t st)
+                   unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, int round,
+                   int last_round, hipStream_t st)
 {
   if (a.n <= 0) return;
   hipLaunchKernelGGL(k_left_b, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a, list, count, done_b, mv2, bump,
-                     bump_base, bump_cap);
+                     bump_base, bump_cap, count + 8, round, last_round);
 }
 
-void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st)
+// cls 0: every predecessor within 30 nodes (LDS ring of 32 steps); cls 1: deeper graphs, the DEEP variant
+// with its HBM shadow ring -- gring holds `blocks` regions of gring_block ints, one per block of the launch
+void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st, int32_t *gring, int64_t gring_block, int blocks)
 {
-  const dim3 g(list_grid(a, 1, cls == 0 ? 4096 : 512)), b(64);
-  if (gen) {
-    if (cls == 0) hipLaunchKernelGGL((k_dp2<true, 32>), g, b, 0, st, a, cls);
-    else if (cls == 1) hipLaunchKernelGGL((k_dp2<true, 256>), g, b, 0, st, a, cls);
-    else hipLaunchKernelGGL((k_dp2<true, 512>), g, b, 0, st, a, cls);
-  } else {
-    if (cls == 0) hipLaunchKernelGGL((k_dp2<false, 32>), g, b, 0, st, a, cls);
-    else if (cls == 1) hipLaunchKernelGGL((k_dp2<false, 256>), g, b, 0, st, a, cls);
-    else hipLaunchKernelGGL((k_dp2<false, 512>), g, b, 0, st, a, cls);
+  if (cls == 0) {
+    const dim3 g(list_grid(a, 1, 4096)), b(64);
+    if (gen) hipLaunchKernelGGL((k_dp2<true, 32, false>), g, b, 0, st, a, cls, nullptr, (int64_t)0);
+    else hipLaunchKernelGGL((k_dp2<false, 32, false>), g, b, 0, st, a, cls, nullptr, (int64_t)0);
+    return;
   }
+  if (!gring || blocks <= 0) return;                  // no window of the batch can be that deep
+  const dim3 g((unsigned)blocks), b(64);
+  if (gen) hipLaunchKernelGGL((k_dp2<true, 32, true>), g, b, 0, st, a, cls, gring, gring_block);
+  else hipLaunchKernelGGL((k_dp2<false, 32, true>), g, b, 0, st, a, cls, gring, gring_block);
 }
 
 void launch_fuse2(const BatchArgs &a, hipStream_t st)

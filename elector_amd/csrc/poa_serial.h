@@ -100,8 +100,7 @@ __device__ void fuse1_window(const BatchArgs &a, const uint32_t w, const MV getm
   a.n1[w] = n;
   // ring depth class for k_dp2: D must cover max predecessor distance + 2
   const int need = nw.maxd + 2;
-  a.cls[w] = (uint8_t)((need <= 32 ? 0 : need <= 256 ? 1 : 2) | (need > 4 ? 0x40 : 0) | (need > 8 ? 0x80 : 0));
-  if (need > 512) a.status[w] = 2;      // ELECTOR_W_TOOLONG: predecessor farther back than the deepest ring
+  a.cls[w] = (uint8_t)((need <= 32 ? 0 : 1) | (need > 4 ? 0x40 : 0) | (need > 8 ? 0x80 : 0));
   if (nw.bad) a.status[w] = 3;
 }
 

@@ -45,6 +45,31 @@ def test_long_windows(engine):
     check(engine, synth.window_triples(16, 12, 1500, 3000))
 
 
+def deep_graph_triples(seed):
+    """Windows whose graph has predecessors hundreds or thousands of nodes back: what the splitter
+    emits for a trimmed / split corrected piece -- the piece's whole tail beyond the last anchor lands
+    in ONE window next to a reference window of ordinary size (Master_Splitter.cpp:295-301), and the
+    tail's letters, unaligned, sit between two consecutive reference letters in the graph."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for lr, tail in ((60, 300), (80, 900), (57, 2000), (120, 5000), (300, 700), (45, 33), (64, 511), (64, 512)):
+        ref = synth.random_seq(rng, lr)
+        unc = synth.mutate(rng, ref, 0.15)
+        cor = synth.mutate(rng, ref, 0.02)
+        junk = synth.random_seq(rng, tail)
+        k = lr // 2
+        out.append((ref, cor[:k] + junk + cor[k:], unc))      # a long insertion inside the window
+        out.append((ref, cor + junk, unc))                    # the piece runs on beyond the window
+        out.append((ref, junk + cor, unc))
+        out.append((ref + junk, cor, unc))                    # and the mirror image: reference-only stretch
+    return out
+
+
+def test_deep_graphs(engine):
+    """predecessor distances beyond every on-chip ring: the HBM shadow ring of k_dp2"""
+    check(engine, deep_graph_triples(61))
+
+
 @pytest.mark.parametrize("name", ["windows_example.tsv", "windows_synth.tsv", "windows_adversarial.tsv"])
 def test_golden_vectors(engine, name):
     """HIP path against rows printed by the real reference binary (tests/golden)."""
@@ -82,7 +107,7 @@ def test_general_scoring_matrix(tmp_path):
 
 def test_window_status_codes(engine):
     from elector_amd import _capi
-    triples = [(b"ACGT", b"ACGT", b"ACGT"), (b"ACGT", b"", b"ACGT"), (b"A" * 20000, b"ACGT", b"ACGT"),
+    triples = [(b"ACGT", b"ACGT", b"ACGT"), (b"ACGT", b"", b"ACGT"), (b"A" * (_capi.ELECTOR_MAX_SEQ + 1), b"ACGT", b"ACGT"),
                (b"GATTACA", b"GATACA", b"GATTTACA")]
     with pytest.raises(_capi.ElectorError):
         engine.align(triples)
