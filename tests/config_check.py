@@ -69,7 +69,7 @@ def run_workload(engine, triples, headers, read_of, tmp_path, oracle_windows=500
     engine.align_device(d_bases, off, d_cols, d_ncol, d_status)
     engine.sync()
     status = d_status.cpu().numpy()
-    assert not status.any(), "windows failed: %s" % np.unique(status, return_counts=True)
+    assert not status.any(), "windows failed (status, count): %s" % (np.unique(status, return_counts=True),)
     cols = d_cols.cpu().numpy()
     ncol = d_ncol.cpu().numpy().astype(np.int64)
 
