@@ -398,7 +398,7 @@ extern "C" int elector_ctx_last_po_sizes(elector_ctx *c, int64_t n, int32_t *po_
 static const int64_t kMovesBudgetDwords = (int64_t)3 << 28;   // 3 GiB
 static const int64_t kBumpBudgetDwords = (int64_t)1 << 30;    // 4 GiB
 static const int kLeftRoundsMax = 6;                          // passes over the handed-back windows (see run_device_batch)
-static const int64_t kDeepRingBytes = (int64_t)1 << 30;       // HBM shadow rings of the deep-graph alignment #2 (k_dp2 DEEP)
+static const int64_t kDeepRingBytes = (int64_t)4 << 30;       // HBM shadow rings of the deep-graph alignment #2 (k_dp2 DEEP)
 
 // fused-kernel geometry classes: G lanes per window x R rows per lane, ordered by the rows one
 // strip holds (must match ELECTOR_FUSED_CLASSES in poa_fused.hip).  A window goes to the first
@@ -716,7 +716,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
                                                                             (left_worst > bump_dwords ? 1 : 0)) : 0;
   // HBM shadow rings of the deep-graph alignment #2: one region of (|PO| + 66) x 64 cells per block
   const int64_t gring_block = (max_po_bound + 66) * 64;
-  const int deep_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(256, kDeepRingBytes / (gring_block * 4)));
+  const int deep_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, kDeepRingBytes / (gring_block * 4)));
 
   // moves scratch of the fused kernels: launches on one stream run one after the other and the moves
   // of a launch die with it, so every stream owns one region as large as its largest launch needs

@@ -195,6 +195,12 @@ __device__ int right_gaps(const uint8_t *row, int n)
 //                         cleared by a reference letter
 // A column is a "hit" when cg >= THRESH and cgr < THRESH2 (:133); hits exist only inside runs of at least
 // THRESH corrected gaps.  One lane walks one such run and reports its first and last hit.
+// Runs longer than kWalkCap columns (the part of the reference a trimmed or split piece does not cover:
+// thousands of columns) are not walked by one lane: it returns first_hit = kRunLong with the run's entry
+// count in *last_hit, and the whole block finishes the run (block_gap_run).
+constexpr int kWalkCap = 192;
+constexpr int kRunLong = -2;
+
 __device__ void walk_gap_run(const uint8_t *cor, const uint8_t *ref, int n, int s, int *first_hit, int *last_hit)
 {
   // reference-gap count on entry: replay the reference gap run that reaches column s - 1
@@ -208,13 +214,64 @@ __device__ void walk_gap_run(const uint8_t *cor, const uint8_t *ref, int n, int 
     if (!rgap) cgr = 0;
   };
   for (int x = rb; x < s; ++x) step(x);
+  const int entry = cgr;
   int fh = -1, lh = -1;
   for (int x = s; x < n && cor[x] == '.'; ++x) {
+    if (x - s >= kWalkCap) { *first_hit = kRunLong; *last_hit = entry; return; }
     step(x);
     if (x - s + 1 >= kThresh && cgr < kThresh2) { if (fh < 0) fh = x; lh = x; }
   }
   *first_hit = fh;
   *last_hit = lh;
+}
+
+// The same for one long run, by the whole block.  Inside a run every corrected column is a gap, so the
+// count at column x depends only on the reference gaps that reach x without interruption:
+//   reference letter at x                        -> 0
+//   streak of reference gaps starting at a > s    -> 2 + (x - a)
+//   streak starting at the run's first column s   -> c0 + (x - s) when c0 > 0, else x - s + 1 (0 at x = s)
+// with c0 = the count on entry (1 for a run that starts the record).  A column is a hit when it is at least
+// the THRESH-th of the run and the count is below THRESH2, so looking back THRESH2 columns decides it.
+__device__ void block_gap_run(const uint8_t *cor, const uint8_t *ref, int n, int s, int entry, int *sh /* 3 ints, shared */,
+                              int *first_hit, int *last_hit)
+{
+  const int tid = threadIdx.x;
+  // the run's end
+  int end = -1;
+  for (int base = s; end < 0; base += kStatsThreads) {
+    __syncthreads();
+    if (tid == 0) sh[0] = 0x7fffffff;
+    __syncthreads();
+    const int x = base + tid;
+    if (x >= n || cor[x] != '.') atomicMin(&sh[0], x);
+    __syncthreads();
+    if (sh[0] != 0x7fffffff) end = sh[0] - 1;
+  }
+  __syncthreads();
+  if (tid == 0) { sh[1] = 0x7fffffff; sh[2] = -1; }
+  __syncthreads();
+  const int c0 = s == 0 ? 1 : entry;
+  int fh = 0x7fffffff, lh = -1;
+  for (int x = s + kThresh - 1 + tid; x <= end; x += kStatsThreads) {
+    int cgr;
+    if (ref[x] != '.') cgr = 0;
+    else {
+      int a = -1;                                        // start of the streak of reference gaps that reaches x
+      for (int j = 1; j <= kThresh2 && a < 0; ++j) {
+        if (x - j < s) a = s;
+        else if (ref[x - j] != '.') a = x - j + 1;
+      }
+      if (a < 0) cgr = kThresh2;                          // a longer streak: the count is past THRESH2 whatever c0 is
+      else if (a > s) cgr = 2 + (x - a);
+      else cgr = c0 > 0 ? c0 + (x - s) : x - s + 1;
+    }
+    if (cgr < kThresh2) { fh = min(fh, x); lh = max(lh, x); }
+  }
+  if (lh >= 0) { atomicMin(&sh[1], fh); atomicMax(&sh[2], lh); }
+  __syncthreads();
+  *first_hit = sh[2] >= 0 ? sh[1] : -1;
+  *last_hit = sh[2];
+  __syncthreads();
 }
 
 // the interval-list part of findGapStretches (:146-188) on the runs that had hits: pairs in `runs`
@@ -287,6 +344,7 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
   __shared__ int s_red[kStatsThreads / 64];
   __shared__ int s_end[4];                 // end-gap scans: left ref, left unc, right ref, right unc
   __shared__ int s_acc[kAccN];
+  __shared__ int s_long[3];               // block_gap_run: end of the run, first and last hit
   __shared__ int s_n[8];                   // 0: long-run fill  1: stretches kept  2: clip left  3: clip right  4: earliest qualifying run end
   __shared__ int32_t *s_lists;
   __shared__ uint8_t *s_uni;
@@ -391,6 +449,13 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
       __syncthreads();
       for (int e = tid; e < m; e += kStatsThreads) walk_gap_run(cor, ref, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1]);
       __syncthreads();
+      for (int e = 0; e < m; ++e) {                                   // long runs: all threads together
+        if (mrg[2 * e] != kRunLong) continue;
+        int fh, lh;
+        block_gap_run(cor, ref, n, runs[e], mrg[2 * e + 1], s_long, &fh, &lh);
+        if (tid == 0) { mrg[2 * e] = fh; mrg[2 * e + 1] = lh; }
+        __syncthreads();
+      }
       if (tid == 0) {
         int n_ne = 0, first_hit = 0x7fffffff;
         for (int e = 0; e < m; ++e) {

@@ -165,3 +165,47 @@ def test_stats_pool_growth(tmp_path, engine):
     # all letters of cor agree with ref, the gap columns are deletions outside the masked left end
     assert got[0, cs.ES_PROCESSED] == 1 and got[0, cs.ES_SUB_C] == 0 and got[0, cs.ES_INS_C] == 0
     assert got[0, cs.ES_LEN_REF] == n and got[0, cs.ES_LEN_COR] == int((cor != ord(".")).sum())
+
+
+def test_long_gap_runs_block_walk(tmp_path, engine):
+    """Runs of corrected gaps longer than one lane walks (trimmed / split pieces): reference-gap streaks of
+    18-22 columns inside the run (the THRESH2 edge), a run that starts the record, a run entered with a
+    running reference-gap count, runs that reach the record's end."""
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"acgt", dtype=np.uint8)
+
+    def letters(k):
+        return acgt[rng.integers(0, 4, k)].tobytes().decode()
+
+    recs = []
+    # 1: long run in the middle, reference-gap streaks of every length around THRESH2 inside it
+    ref = letters(60)
+    cor = ref
+    for k in (3, 17, 18, 19, 20, 21, 22, 40):
+        ref += letters(37) + "." * k
+        cor += "." * (37 + k)
+    ref += letters(300) + letters(80)
+    cor += "." * 300 + ref[-80:]
+    recs.append(("r1", ref, cor, ref.replace(".", "a")))
+    # 2: the run starts the record, with reference gaps at its very first columns
+    ref = "." * 7 + letters(400) + "." * 25 + letters(200)
+    cor = "." * 500 + ref[500:]
+    recs.append(("r2", ref, cor, ref.replace(".", "c")))
+    # 3: the run is entered with a running count: reference gaps (under corrected letters, then gaps) just before it
+    ref = letters(50) + "." * 12 + "." * 9 + letters(600)
+    cor = ref[:50] + letters(4) + "." * 3 + letters(5) + "." * 9 + "." * 500 + ref[-100:]
+    recs.append(("r3", ref, cor, ref.replace(".", "g")))
+    # 4: run to the end of the record
+    ref = letters(100) + letters(900)
+    cor = ref[:100] + "." * 900
+    recs.append(("r4", ref, cor, ref))
+    for h, a, b, c in recs:
+        assert len(a) == len(b) == len(c), h
+    txt = "".join(">%s \n%s\n>%s \n%s\n>%s \n%s\n" % (h, a, h, b, h, c) for h, a, b, c in recs)
+    path = tmp_path / "msa.fa"
+    path.write_text(txt)
+    pieces = cs.parse_msa(str(path), cs.getSplit(str(path)))
+    _, oracle_pieces = stats_oracle.compute_metrics(txt, 5)
+    exp = oracle_counter_array(pieces, oracle_pieces)
+    got, _ = cs.stats_counters(pieces, None, engine)
+    assert np.array_equal(got, exp), np.argwhere(got != exp)
