@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -83,7 +85,8 @@ struct elector_ctx {
   elector::DevBuf d_tab, d_linx, d_liny;
   // per-batch workspace
   elector::DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
-      d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_fmv, d_tstate, d_tlist, d_gring;
+      d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_fmv, d_tstate, d_tlist, d_gring,
+      d_hand, d_mvpool, d_mvbusy;
   // host API staging
   elector::DevBuf d_bases, d_cols, d_ncol, d_status, d_scores, d_rowoff, d_rows;
   // pinned upload staging of the per-batch metadata, double-buffered: a batch's host-to-device copies
@@ -135,6 +138,16 @@ inline void timed_begin(elector_ctx *c, int kind, hipStream_t st)
 }
 inline void timed_end(elector_ctx *c, hipStream_t st)
 {
+  // ELECTOR_DEBUG_PROGRESS=<file>: wait for every bracketed launch group and log it (finds a hanging kernel)
+  static const char *progress = std::getenv("ELECTOR_DEBUG_PROGRESS");
+  if (progress) {
+    static int seq = 0;
+    FILE *f = std::fopen(progress, "a");
+    if (f) { std::fprintf(f, "group %d launched, waiting\n", seq); std::fclose(f); }
+    const hipError_t e = hipStreamSynchronize(st);
+    f = std::fopen(progress, "a");
+    if (f) { std::fprintf(f, "group %d done: %s\n", seq++, hipGetErrorString(e)); std::fclose(f); }
+  }
   if (!c->timing || c->spans.empty()) return;
   (void)hipEventRecord(c->spans.back().b, st);
 }

@@ -161,4 +161,36 @@ __host__ __device__ inline int fused_b_slot_need(int n1, int Lu, int G, int R)
 // bytes of one wave's score ring in k_fused_b: D time slots x 64 lanes x R 16-bit cells
 __host__ __device__ inline int fused_ring_bytes(int R, int D) { return D * 64 * 4 * ((R + 1) / 2); }
 
+// free-slot queue of k_poa's moves scratch, per XCD: [head, pad to 16 ints][tail, pad][slot ids]
+constexpr int kPoolSlotsMax = 32 * 32 + 8;
+constexpr int kPoolStride = 32 + ((kPoolSlotsMax + 31) & ~31);
+
+// LDS slot of one window in k_poa (poa_pack.hip), see the layout there
+__host__ __device__ inline int poa_xi_cap(int Lr, int Lc)
+{
+  // nodes after fusion #1: Lr + Lc minus the fused pairs; a well-corrected read fuses nearly all of min(Lr, Lc)
+  const int lo = Lr < Lc ? Lr : Lc, hi = Lr < Lc ? Lc : Lr;
+  return hi + lo / 8 + 8;
+}
+
+__host__ __device__ inline int poa_union_a(int Lr, int Lc)
+{
+  return ((Lr + Lc + 3) & ~3) + 2 * ((Lr + 1) & ~1) * 2 + 2 * ((Lc + 1) & ~1) * 2;
+}
+
+__host__ __device__ inline int poa_union_b(int n1, int Lu, int G)
+{
+  const int x2y = (2 * n1 + 3) & ~3;
+  const int cols = ((3 * (n1 + Lu) + 8 + 3) & ~3) + 2 * Lu + 4;
+  const int ord = (8 + n1 / 4) * G;
+  return x2y + (cols > ord ? cols : ord);
+}
+
+__host__ __device__ inline int poa_slot_need(int Lr, int Lc, int Lu, int G)
+{
+  const int cap = poa_xi_cap(Lr, Lc);
+  const int ua = poa_union_a(Lr, Lc), ub = poa_union_b(cap, Lu, G);
+  return 16 + ((Lu + 3) & ~3) + 4 * (cap + 1) + (ua > ub ? ua : ub);
+}
+
 }  // namespace elector

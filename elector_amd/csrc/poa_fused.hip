@@ -44,6 +44,7 @@ struct FusedArgs {
   int mv_tw, mv_ns;
   const int32_t *nlist_dev; // k_fused_a: when set, only the first *nlist_dev windows of the list still need it
   const uint8_t *triv;      // k_fused_b: when set, triv[w] = the graph of window w is a plain chain (k_trivial)
+  int64_t grid_blocks;      // > 0: launch at most this many blocks (they loop over the list)
 };
 
 __device__ __forceinline__ int row_shr1(int old, int v)
@@ -152,16 +153,15 @@ __device__ __forceinline__ WinA load_win_a(const FusedArgs &a, int64_t li)
 
 // WV wavefronts per block, each owning 64/G windows from staging to the fused graph.
 template <int G, int R, int WV>
-__global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
+__device__ __forceinline__ void fused_a_body(const FusedArgs &a, uint8_t *lds, const int64_t vblk)
 {
-  extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NW = 64 / G, RS = R * G;     // windows per wave, rows per strip
   using mv_t = typename MvWord<R>::type;     // a lane's R move pairs of one column
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
   const int sidx = wv * NW + q;               // this lane's window slot in the block
-  if (a.nlist_dev && (int64_t)(NW * WV) * blockIdx.x >= (int64_t)*a.nlist_dev) return;   // the rest of the list is done already
-  const WinA W = load_win_a<G, R>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
+  if (a.nlist_dev && (int64_t)(NW * WV) * vblk >= (int64_t)*a.nlist_dev) return;   // the rest of the list is done already
+  const WinA W = load_win_a<G, R>(a, (int64_t)(NW * WV) * vblk + sidx);
   const bool valid = W.valid;
   const int Lr = W.Lr, Lc = W.Lc, ns = W.ns;
   uint8_t *slot = lds + sidx * a.slot_bytes;
@@ -445,6 +445,20 @@ __global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
   if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 4, 1ull);
 }
 
+// The kernel: a block takes the list's chunks of NW * WV windows in a grid-stride loop (the launches behind
+// k_poa work on short device-built lists with a grid much smaller than the list's capacity).
+template <int G, int R, int WV>
+__global__ void __launch_bounds__(64 * WV) k_fused_a(FusedArgs a)
+{
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int NW = 64 / G;
+  const int64_t cnt = a.nlist_dev ? (int64_t)*a.nlist_dev : a.nlist;
+  for (int64_t vblk = blockIdx.x; vblk * (NW * WV) < cnt; vblk += gridDim.x) {
+    fused_a_body<G, R, WV>(a, lds, vblk);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- k_fused_b ---
 // Alignment #2 on the PO graph of (ref + cor).  A node has <= 2 DP predecessors at
 // any distance; the common case (one predecessor, the previous node) is served from
@@ -526,7 +540,7 @@ __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
   constexpr int RS = R * G;
   const KParams kp = a.b.kp;
   WinB v;
-  v.valid = li < a.nlist;
+  v.valid = li < (a.nlist_dev ? (int64_t)*a.nlist_dev : a.nlist);
   v.w = v.valid ? a.list[li] : 0;
   v.valid = v.valid && a.b.status[v.w] == 0 && a.done_a[v.w] != 0 && a.done_b[v.w] == 0 &&
             (a.b.cls[v.w] & (D >= 8 ? 0x83 : 0xC3)) == 0;
@@ -552,9 +566,8 @@ __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
 }
 
 template <int G, int R, int D, int WV>
-__global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
+__device__ __forceinline__ void fused_b_body(const FusedArgs &a, uint8_t *lds, const int64_t vblk)
 {
-  extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NW = 64 / G, RS = R * G;     // windows per wave, rows per strip
   constexpr int RW = (R + 1) / 2;                         // ring dwords per lane and slot
   constexpr int kRingDepth = D;
@@ -563,7 +576,7 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
   const int sidx = wv * NW + q;
-  const WinB W = load_win_b<G, R, D>(a, (int64_t)(NW * WV) * blockIdx.x + sidx);
+  const WinB W = load_win_b<G, R, D>(a, (int64_t)(NW * WV) * vblk + sidx);
   bool valid = W.valid;
   if (WV == 1 && __builtin_amdgcn_ballot_w64(valid) == 0) return;       // nothing left for this wave
   const uint32_t w = W.w;
@@ -1045,7 +1058,27 @@ __global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
   if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.rowinit) + 12, 1ull);
 }
 
+template <int G, int R, int D, int WV>
+__global__ void __launch_bounds__(64 * WV) k_fused_b(FusedArgs a)
+{
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int NW = 64 / G;
+  const int64_t cnt = a.nlist_dev ? (int64_t)*a.nlist_dev : a.nlist;
+  for (int64_t vblk = blockIdx.x; vblk * (NW * WV) < cnt; vblk += gridDim.x) {
+    fused_b_body<G, R, D, WV>(a, lds, vblk);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- launcher ---
+
+// blocks of a launch: one per NB windows of the list, or a.grid_blocks when the caller caps the grid (the
+// kernels loop over the list)
+static int64_t fused_grid(const FusedArgs &a, int NB)
+{
+  const int64_t full = (a.nlist + NB - 1) / NB;
+  return a.grid_blocks > 0 && a.grid_blocks < full ? a.grid_blocks : full;
+}
 
 template <int G, int R>
 static int launch_a_t(const FusedArgs &a, hipStream_t st)
@@ -1058,7 +1091,7 @@ static int launch_a_t(const FusedArgs &a, hipStream_t st)
       return -1;
     attr = true;
   }
-  hipLaunchKernelGGL((k_fused_a<G, R, 1>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64), NB * a.slot_bytes, st, a);
+  hipLaunchKernelGGL((k_fused_a<G, R, 1>), dim3((unsigned)fused_grid(a, NB)), dim3(64), NB * a.slot_bytes, st, a);
   return 0;
 }
 
@@ -1073,7 +1106,7 @@ static int launch_b_t(const FusedArgs &a, hipStream_t st)
       return -1;
     attr = true;
   }
-  hipLaunchKernelGGL((k_fused_b<G, R, D, 1>), dim3((unsigned)((a.nlist + NB - 1) / NB)), dim3(64),
+  hipLaunchKernelGGL((k_fused_b<G, R, D, 1>), dim3((unsigned)fused_grid(a, NB)), dim3(64),
                      64 + NB * a.slot_bytes + fused_ring_bytes(R, D), st, a);
   return 0;
 }

@@ -33,7 +33,7 @@ void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uin
                    int last_round, hipStream_t st);
 void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, const int64_t *row_off,
                  uint8_t *rows, int64_t n, hipStream_t st);
-void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, hipStream_t st);
+void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, bool flags_only, hipStream_t st);
 int partition_buckets();
 void launch_partition(const uint32_t *in, uint32_t *out, const int64_t *bins, int nbins, const void *chunks, int nchunks,
                       const int32_t *bin_chunks, const uint8_t *pkey, int32_t *chunk_cnt, int32_t *count, hipStream_t st);
@@ -51,7 +51,27 @@ struct FusedArgs {
   int mv_tw, mv_ns;
   const int32_t *nlist_dev;
   const uint8_t *triv;
+  int64_t grid_blocks;
 };
+struct PackArgs {
+  BatchArgs b;
+  const uint32_t *list;
+  int64_t nlist;
+  int slot_bytes;
+  uint8_t *done_a;
+  uint8_t *done_b;
+  const uint8_t *triv;
+  uint32_t *mv_pool;
+  int mv_tw;
+  int32_t *mv_q;
+  int mv_slots;
+  uint32_t *hand;
+  int32_t *hand_count;
+  int debug;
+  unsigned long long *stamps;
+};
+int launch_poa(const PackArgs &a, int G, int R, hipStream_t st);
+void launch_poa_pool_init(int32_t *q, int nq, int slots, hipStream_t st);
 int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
 int launch_fused_b(const FusedArgs &a, int G, int R, int D, hipStream_t st);
 }  // namespace elector
@@ -301,7 +321,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit,
-                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring};
+                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy};
   for (DevBuf *b : bufs) b->release();
   for (auto &s : c->st_slot) s.release();
   for (int k = 0; k < 2; ++k) {
@@ -448,6 +468,15 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const int64_t total = off[3 * n];
   if (off[0] != 0 || total < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
   const bool use_fused = !c->gen && !std::getenv("ELECTOR_NO_FUSED");
+  // alignment #1 without a dynamic program for windows whose corrected sequence equals the reference:
+  // valid when the diagonal is strictly best (see k_trivial)
+  const bool use_trivial = use_fused && !std::getenv("ELECTOR_NO_TRIVIAL") && c->kp.match >= 0 &&
+                           c->kp.mismatch <= c->kp.match && c->kp.open_x > 0 && c->kp.ext_x > 0 && c->kp.open_y > 0 &&
+                           c->kp.ext_y > 0;
+  // the one-kernel, two-windows-per-lane-group path (poa_pack.hip): symmetric gap penalties, and not when the
+  // graph has to stay in HBM for the bundle search
+  const bool use_pack = use_trivial && !std::getenv("ELECTOR_NO_PACK") && !c->keep_graph && c->kp.open_x == c->kp.open_y &&
+                        c->kp.ext_x == c->kp.ext_y;
 
   // ---- host metadata ----
   const bool host_prof = std::getenv("ELECTOR_DEBUG_HOST") != nullptr;
@@ -486,9 +515,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   int64_t key_cnt[NB + 1] = {0}, n_generic = 0;
   int64_t left_worst = 0;        // moves (dwords) of alignment #2 if every fused-routed window were handed back
   int64_t max_po_bound = 0;      // largest Lr + Lc of the batch (bounds |PO| and with it a strip's steps)
-  std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)5 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc
+  std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)6 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc, k_poa's slot need
   int64_t *bin_max_lr = bin_need_a.data() + kBins, *bin_max_lc = bin_max_lr + kBins, *bin_max_lu = bin_max_lc + kBins,
-          *bin_max_po = bin_max_lu + kBins;
+          *bin_max_po = bin_max_lu + kBins, *bin_need_pack = bin_max_po + kBins;
   const int maxpen = std::max(std::max(std::abs(c->kp.mismatch), std::abs(c->kp.match)),
                               std::max(std::max(c->kp.open_x, c->kp.open_y), std::max(c->kp.ext_x, c->kp.ext_y)));
   int pen_abs_max = 1;                       // largest |score| or gap penalty of the parameter set
@@ -512,7 +541,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
     // per thread: size keys, bin counts, generic count, then per bin the maxima of
     // alignment #1's slot need, Lr, Lc, Lu and Lr + Lc (the bound on |PO|)
-    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + 1 + 5 * kBins + 2, 0));
+    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + 1 + 6 * kBins + 2, 0));
     auto work = [&](int t) {
       const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
       int64_t *cnt = tcnt[(size_t)t].data();
@@ -559,14 +588,15 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
             mx[2 * kBins] = std::max<int64_t>(mx[2 * kBins], lc);
             mx[3 * kBins] = std::max<int64_t>(mx[3 * kBins], lu);
             mx[4 * kBins] = std::max<int64_t>(mx[4 * kBins], lr + lc);
+            mx[5 * kBins] = std::max<int64_t>(mx[5 * kBins], poa_slot_need((int)lr, (int)lc, (int)lu, G));
           }
         }
         if (bin[(size_t)w] >= 0) {
           cnt[NB + bin[(size_t)w]]++;
           // moves the generic alignment #2 needs if the fused kernels hand this window back
-          cnt[NB + kBins + 1 + 5 * kBins] += (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64;
+          cnt[NB + kBins + 1 + 6 * kBins] += (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64;
         } else cnt[NB + kBins]++;                         // generic (incl. failed windows)
-        if (!st) cnt[NB + kBins + 2 + 5 * kBins] = std::max(cnt[NB + kBins + 2 + 5 * kBins], lr + lc);
+        if (!st) cnt[NB + kBins + 2 + 6 * kBins] = std::max(cnt[NB + kBins + 2 + 6 * kBins], lr + lc);
         const int64_t mlen = std::max(lr, lu);
         int k = (int)(mlen >> 3);
         if (k >= NB) k = NB - 1;
@@ -582,9 +612,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       for (int k = 0; k < NB; ++k) key_cnt[k + 1] += tcnt[(size_t)t][(size_t)k];
       for (int b = 0; b < kBins; ++b) bin_cnt[b] += tcnt[(size_t)t][(size_t)(NB + b)];
       n_generic += tcnt[(size_t)t][(size_t)(NB + kBins)];
-      for (int b = 0; b < 5 * kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + 1 + b)]);
-      left_worst += tcnt[(size_t)t][(size_t)(NB + kBins + 1 + 5 * kBins)];
-      max_po_bound = std::max(max_po_bound, tcnt[(size_t)t][(size_t)(NB + kBins + 2 + 5 * kBins)]);
+      for (int b = 0; b < 6 * kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + 1 + b)]);
+      left_worst += tcnt[(size_t)t][(size_t)(NB + kBins + 1 + 6 * kBins)];
+      max_po_bound = std::max(max_po_bound, tcnt[(size_t)t][(size_t)(NB + kBins + 2 + 6 * kBins)]);
     }
   }
   if (bad_offsets.load()) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
@@ -602,7 +632,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   for (int b = 0; b < kBins; ++b) bin_final[(size_t)b] = (int16_t)b;
   auto merge_into = [&](int b, int into) {
     bin_cnt[(size_t)into] += bin_cnt[(size_t)b];
-    for (int q = 0; q < 5; ++q)
+    for (int q = 0; q < 6; ++q)
       bin_need_a[(size_t)(q * kBins + into)] = std::max(bin_need_a[(size_t)(q * kBins + into)], bin_need_a[(size_t)(q * kBins + b)]);
     bin_cnt[(size_t)b] = 0;
     for (int x = 0; x < kBins; ++x) if (bin_final[(size_t)x] == b) bin_final[(size_t)x] = (int16_t)into;
@@ -722,13 +752,40 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // of a launch die with it, so every stream owns one region as large as its largest launch needs
   // ([block][strips][steps][64 lanes] words; strips and steps from the bin's maxima)
   int64_t fmv_stream[4] = {0, 0, 0, 0};
+  // blocks of the k_fused_a / k_fused_b launches of a bin: one per 64 / G windows -- behind k_poa they only see
+  // the windows it handed back (a device-built list), with a grid of a sixteenth and a loop inside
+  auto old_grid = [&](int b) {
+    const int G = kClsG[b / kNT];
+    const int64_t full = (bin_cnt[(size_t)b] + 64 / G - 1) / (64 / G);
+    return use_pack ? std::min<int64_t>(full, std::max<int64_t>(256, full / 16)) : full;
+  };
   auto fmv_geom = [&](int b, bool second, int *tw, int *ns) {
     const int G = kClsG[b / kNT], R = kClsR[b / kNT];
     *tw = (int)(second ? bin_max_po[b] : bin_max_lr[b]) + G;
     *ns = (int)(((second ? bin_max_lu[b] : bin_max_lc[b]) + G * R - 1) / (G * R));
-    const int64_t blocks = (bin_cnt[(size_t)b] + 64 / G - 1) / (64 / G);
+    const int64_t blocks = old_grid(b);
     return blocks * *ns * *tw * 64 * fused_mv_bytes(R);
   };
+  // k_poa: LDS slot, moves geometry and scratch-slot pool of a bin
+  struct PackGeom { int slot, tw, slots; int64_t pool_words; };
+  auto pack_geom = [&](int b) {
+    const int G = kClsG[b / kNT], nw = 2 * (64 / G);
+    PackGeom pg;
+    const int max_slot = ((160 * 1024 - 256 - 64) / nw) & ~15;
+    pg.slot = (int)std::min<int64_t>(max_slot, (bin_need_pack[b] + 15) & ~(int64_t)15);
+    pg.tw = (int)bin_max_po[b] + 8 + G + 4;
+    const int lds_block = 64 + nw * pg.slot;
+    const int waves_cu = std::max(1, std::min(32, (160 * 1024) / lds_block));
+    pg.slots = 32 * waves_cu + 8;                                  // per XCD: 32 CUs, every wave they can hold, and a margin
+    pg.pool_words = (int64_t)8 * pg.slots * pg.tw * 64;
+    if (std::getenv("ELECTOR_POA_BLOCKSCRATCH")) {                 // experiment: one region per block
+      pg.slots = 0;
+      pg.pool_words = ((bin_cnt[(size_t)b] + nw - 1) / nw) * (int64_t)pg.tw * 64;
+    }
+    return pg;
+  };
+  int64_t pool_stream[4] = {0, 0, 0, 0};
+  int pool_slots[4] = {0, 0, 0, 0}, pool_tw[4] = {0, 0, 0, 0};     // per launch chain: slots per XCD, longest moves region
   // Launch chains.  Two kernels side by side use the chip best (measured on the bench batch: 8.1 ms
   // per step with two concurrent launch chains, 9.9 ms with four or more -- kernels of unlike
   // geometry compete for LDS and L2 -- and a single chain pays every kernel's tail), so the four
@@ -777,7 +834,16 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       int tw, ns;
       int64_t &r = fmv_stream[stream_of(b)];
       r = std::max(r, std::max(fmv_geom(b, false, &tw, &ns), fmv_geom(b, true, &tw, &ns)));
+      if (use_pack) {
+        const PackGeom pg = pack_geom(b);
+        const int sk = stream_of(b);
+        pool_slots[sk] = std::max(pool_slots[sk], pg.slots);
+        pool_tw[sk] = std::max(pool_tw[sk], pg.tw);
+        pool_stream[sk] = std::max(pool_stream[sk], pg.pool_words);      // (block-scratch experiment)
+      }
     }
+  if (use_pack && !std::getenv("ELECTOR_POA_BLOCKSCRATCH"))
+    for (int k = 0; k < 4; ++k) pool_stream[k] = (int64_t)8 * pool_slots[k] * pool_tw[k] * 64;
   for (int k = 0; k < 4; ++k) fmv_stream[k] = (fmv_stream[k] + 255) & ~(int64_t)255;
 
   // ---- workspace ----
@@ -793,6 +859,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
        c->d_rowinit.ensure(1024 + 256 * (size_t)kBins) |
        c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256) |
        c->d_gring.ensure((size_t)deep_blocks * (size_t)gring_block * 4 + 256);
+  if (!rc && use_pack)
+    rc = c->d_hand.ensure((size_t)n * 4 + (size_t)kBins * 4 + 64) |
+         c->d_mvpool.ensure((size_t)(pool_stream[0] + pool_stream[1] + pool_stream[2] + pool_stream[3]) * 4 + 256) |
+         c->d_mvbusy.ensure((size_t)4 * 8 * kPoolStride * 4);
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
   if (use_fused && (rc = ensure_streams(c))) return fail(c, rc, "auxiliary streams");
 
@@ -808,11 +878,6 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   int32_t *d_bin_chunks = d_bin_need + kBins, *d_chunk_need = d_bin_chunks + 2 * kBins;
   uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n, *d_triv = d_done_b + n, *d_pkey = d_triv + n,
           *d_tiled = d_pkey + n;
-  // alignment #1 without a dynamic program for windows whose corrected sequence equals the reference:
-  // valid when the diagonal is strictly best (see k_trivial)
-  const bool use_trivial = use_fused && !std::getenv("ELECTOR_NO_TRIVIAL") && c->kp.match >= 0 &&
-                           c->kp.mismatch <= c->kp.match && c->kp.open_x > 0 && c->kp.ext_x > 0 && c->kp.open_y > 0 &&
-                           c->kp.ext_y > 0;
   int nbins_used = 0, nchunks = 0;
   std::vector<int> bin_slot((size_t)kBins, -1);
   if (use_trivial)
@@ -846,6 +911,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipEventRecord(h_done, st));
   HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)5 * n, st));
   HIPCHK(c, hipMemsetAsync(d_counters, 0, 64, st));
+  if (use_pack) {
+    HIPCHK(c, hipMemsetAsync(c->d_hand.as<uint32_t>() + n, 0, (size_t)kBins * 4, st));
+    for (int k = 0; k < 4; ++k)
+      if (pool_slots[k] > 0) launch_poa_pool_init(c->d_mvbusy.as<int32_t>() + (size_t)k * 8 * kPoolStride, 8, pool_slots[k], st);
+  }
   if (std::getenv("ELECTOR_DEBUG_FUSED")) HIPCHK(c, hipMemsetAsync(c->d_rowinit.as<uint8_t>() + 1024, 0, 256 * (size_t)kBins, st));
 
   const double tp4 = now_ms();
@@ -942,7 +1012,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   if (use_trivial) {
     a.n = n;
     timed_begin(c, 2, st);
-    launch_trivial(a, d_done_a, d_triv, d_pkey, st);
+    launch_trivial(a, d_done_a, d_triv, d_pkey, use_pack, st);
     launch_partition(d_lists, d_lists2, d_bins, nbins_used, d_chunks, nchunks, d_bin_chunks, d_pkey, d_chunk_need, d_bin_need, st);
     timed_end(c, st);
   }
@@ -961,18 +1031,46 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       const int bG = kClsG[b / kNT], bR = kClsR[b / kNT], bslot = g_tier_bytes[b % kNT];
       const int sk = stream_of(b);
       hipStream_t sx = c->aux[sk];
+      const int fdebug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
+      uint32_t *d_hand_list = use_pack ? c->d_hand.as<uint32_t>() + bin_first[(size_t)b] : nullptr;
+      int32_t *d_hand_cnt = use_pack ? reinterpret_cast<int32_t *>(c->d_hand.as<uint32_t>() + n) + bin_slot[(size_t)b] : nullptr;
+      if (use_pack && (!split_ab || pass == 0)) {
+        // the whole window in one kernel; what it cannot take lands on the bin's hand-back list
+        const PackGeom pg = pack_geom(b);
+        PackArgs pa;
+        pa.b = a;
+        pa.list = d_fused_lists + bin_first[(size_t)b];
+        pa.nlist = bin_cnt[(size_t)b];
+        pa.slot_bytes = pg.slot;
+        pa.done_a = d_done_a;
+        pa.done_b = d_done_b;
+        pa.triv = d_triv;
+        pa.mv_pool = c->d_mvpool.as<uint32_t>();
+        for (int k = 0; k < sk; ++k) pa.mv_pool += pool_stream[k];
+        pa.mv_tw = pg.tw;
+        pa.mv_q = c->d_mvbusy.as<int32_t>() + (size_t)sk * 8 * kPoolStride;
+        pa.mv_slots = pg.slots > 0 ? pool_slots[sk] : 0;
+        pa.hand = d_hand_list;
+        pa.hand_count = d_hand_cnt;
+        pa.debug = fdebug;
+        pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b) + 16;
+        timed_begin(c, 1, sx);
+        if (launch_poa(pa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
+        timed_end(c, sx);
+      }
       FusedArgs fa;
       fa.b = a;
-      fa.list = d_fused_lists + bin_first[(size_t)b];
-      fa.nlist_dev = use_trivial ? d_bin_need + bin_slot[(size_t)b] : nullptr;
+      fa.grid_blocks = use_pack ? old_grid(b) : 0;
+      fa.list = use_pack ? d_hand_list : d_fused_lists + bin_first[(size_t)b];
+      fa.nlist_dev = use_pack ? d_hand_cnt : use_trivial ? d_bin_need + bin_slot[(size_t)b] : nullptr;
       fa.nlist = bin_cnt[(size_t)b];
       fa.slot_bytes = bslot;
       fa.done_a = d_done_a;
       fa.done_b = d_done_b;
       fa.rowinit = reinterpret_cast<int32_t *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b);   // phase stamps (debug)
-      fa.debug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
+      fa.debug = fdebug;
       fa.keep_map = c->keep_graph ? 1 : 0;
-      fa.triv = use_trivial ? d_triv : nullptr;
+      fa.triv = use_trivial && !use_pack ? d_triv : nullptr;
       fa.slot_bytes = (int)((bin_need_a[(size_t)b] + 127) & ~(int64_t)127);   // alignment #1: the bin's own maximum
       fa.mv_pool = c->d_fmv.as<uint8_t>();
       for (int k = 0; k < sk; ++k) fa.mv_pool += fmv_stream[k];
@@ -984,7 +1082,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       }
       if (split_ab && pass == 0) continue;
       fa.slot_bytes = bslot;
-      fa.nlist_dev = nullptr;
+      fa.nlist_dev = use_pack ? d_hand_cnt : nullptr;
       (void)fmv_geom(b, true, &fa.mv_tw, &fa.mv_ns);
       timed_begin(c, 1, sx);
       // Ring depth 8.  (Measured: a 4-deep ring for the 99.8 % of windows that need no more, followed by
@@ -1008,16 +1106,17 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       launch_dp1(a, c->gen, st);
       launch_fuse1(a, st);
       if ((rc = run_tiles(lw, 2))) return fail(c, rc, "tiled alignment #2");
-      timed_end(c, st);
-      if (chunks.size() > 1) {      // several chunks share the scratch: finish each one completely
+      {   // finish the host-routed windows here, beside the fused launch chains: a few long windows on one
+          // wavefront each are a long critical path that must not wait for the chains to end
         a.mark_b = d_done_b;
         for (int cls = 0; cls < 2; ++cls) launch_dp2(a, c->gen, cls, st, c->d_gring.as<int32_t>(), gring_block, deep_blocks);
         launch_fuse2(a, st);
         a.mark_b = nullptr;
       }
+      timed_end(c, st);
     }
     for (int k = 0; k < std::min(used, (int)elector_ctx::kAux); ++k) HIPCHK(c, hipStreamWaitEvent(st, c->aux_done[k], 0));
-    // everything alignment #2 still owes: host-routed windows (single chunk) + windows handed back
+    // everything alignment #2 still owes: the windows the fused kernels handed back
     a.n = n;
     a.perm = nullptr;
     a.count_ptr = nullptr;

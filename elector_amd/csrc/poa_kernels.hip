@@ -605,6 +605,9 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
   for (int d = 1; d < 8; d <<= 1) fd = min(fd, __shfl_xor(fd, d, 8));
   const bool eq = a.status[w] == 0 && Lr == Lc && fd == nmin;
   if (g == 0) { triv[w] = eq ? 1 : 0; pkey[w] = (uint8_t)(eq ? kPartBuckets - 1 : min(fd >> 3, kPartBuckets - 2)); }
+  const bool flags_only = (one_sub_ok & 2) != 0;      // k_poa builds these graphs itself, in LDS
+  one_sub_ok &= 1;
+  if (flags_only && eq) return;
   if (!eq) {
     // One substitution and nothing else (same length, the strings agree after position fd): the diagonal
     // with its one mismatch beats every alignment with gaps (two gap openings at least) and is the
@@ -616,6 +619,7 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
     for (int i = fd + 1 + g; i < Lr; i += 8) rest = rest && xs[i] == ys[i];
     for (int d = 1; d < 8; d <<= 1) rest = __shfl_xor(rest ? 1 : 0, d, 8) != 0 && rest;
     if (!rest) return;
+    if (flags_only) { if (g == 0) triv[w] = 2; return; }
     const int e = fd, L = Lr;
     const int64_t nb = o0 + w;
     for (int i = g; i < L; i += 8) {
@@ -820,14 +824,15 @@ void launch_fuse2(const BatchArgs &a, hipStream_t st)
   hipLaunchKernelGGL(k_fuse2, dim3(list_grid(a, 64, 256)), dim3(64), 0, st, a);
 }
 
-void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, hipStream_t st)
+void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, bool flags_only, hipStream_t st)
 {
   if (a.n <= 0) return;
   // the one-substitution shortcut needs |mismatch - match| < gap opening + extension in both directions
   const int one_sub_ok = !std::getenv("ELECTOR_NO_ONESUB") &&
                          (a.kp.match - a.kp.mismatch) < (a.kp.open_x < a.kp.open_y ? a.kp.open_x : a.kp.open_y) +
                                                          (a.kp.ext_x < a.kp.ext_y ? a.kp.ext_x : a.kp.ext_y);
-  hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv, pkey, one_sub_ok);
+  hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv, pkey,
+                     one_sub_ok | (flags_only ? 2 : 0));
 }
 
 int partition_buckets() { return kPartBuckets; }

@@ -1,0 +1,1013 @@
+// elector_amd/csrc/poa_pack.hip -- the whole window in ONE kernel, two windows per lane group, packed
+// 16-bit arithmetic: k_poa<G,R>.
+//
+//   symbols -> [alignment #1 -> traceback -> fusion #1] -> alignment #2 -> traceback -> fusion #2 -> MSA columns
+//
+// What it changes against the k_fused_a / k_fused_b pair of poa_fused.hip (which stays as the path for the
+// windows this kernel hands back):
+//   * the graph after fusion #1 never leaves LDS (no 10 B/node round trip through HBM, one launch per
+//     geometry class instead of two);
+//   * a group of G lanes works on TWO windows at once: every score register holds window A's value in its low
+//     half and window B's in its high half, and the recurrence runs on v_pk_max_i16 / v_pk_add_i16 /
+//     v_pk_sub_i16 / v_pk_mad_i16 / v_pk_min_u16 -- one instruction, two cells.  Scores fit 16 bits for the
+//     windows taken here (|score| <= 10 (Lx + Ly) < 16000);
+//   * alignment #2 needs no score ring in LDS: a window is taken when every predecessor of its graph lies at
+//     most two nodes back (99.8 % of the windows of well-corrected reads), so the predecessor columns are the
+//     two columns the lane computed last, held in registers; which of the two, per window, is a bit-field
+//     select (v_bfi_b32) under a mask built from the node's record;
+//   * the windows whose corrected sequence equals the reference, or differs by one substitution, get their
+//     graph written straight into LDS (k_trivial only classifies and sorts now).
+// Windows that do not qualify (deeper graphs, more rows than one strip holds, scores beyond 16 bits, general
+// or asymmetric scoring parameters, LDS slot too small) are appended to a device list and go through
+// k_fused_a / k_fused_b / the generic kernels afterwards.
+//
+// Geometry as in poa_fused.hip: lane g of a group holds R consecutive rows of the linear read y and computes
+// column jj = t - g at anti-diagonal step t; the row above a lane's block arrives by DPP.  One strip only.
+// Reference behaviour restated: align_lpo_po2.c:178-433 (DP, tie-breaks), :108-168 (traceback),
+// lpo.c:413-463,602-656 (fusion), lpo_format.c:337-393 (rows).
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <type_traits>
+#include "poa_device.h"
+
+namespace elector {
+
+struct PackArgs {
+  BatchArgs b;
+  const uint32_t *list;     // window ids of this bin, in processing order; entries 2p, 2p+1 form pair p
+  int64_t nlist;
+  int slot_bytes;           // LDS bytes per window slot
+  uint8_t *done_a;
+  uint8_t *done_b;
+  const uint8_t *triv;      // per window: 0 = needs alignment #1, 1 = corrected == reference, 2 = one substitution
+  uint32_t *mv_pool;        // moves scratch: [XCD][slot][mv_tw steps][64 lanes] words; a wave borrows a slot of its XCD
+  int mv_tw;
+  int32_t *mv_q;            // per XCD a queue of free slot ids: [head][tail][ids ...], kPoolStride ints apart
+  int mv_slots;             // slots per XCD: at least the wavefronts an XCD can hold of any launch of the chain
+  uint32_t *hand;           // windows handed back to the two-kernel path, appended at hand[atomicAdd(hand_count, 1)]
+  int32_t *hand_count;
+  int debug;
+  unsigned long long *stamps;
+};
+
+// ------------------------------------------------------------ packed helpers ---
+// two 16-bit lanes per register: window A low, window B high.  Inline asm where hipcc would otherwise
+// unpack the halves (it turns min(x, 1) and multiply-add on short2 into per-half compares and selects).
+__device__ __forceinline__ uint32_t pk2(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ uint32_t pk1(int v) { return pk2(v, v); }
+__device__ __forceinline__ int pk_half(uint32_t v, int h) { return h ? (int)((int32_t)v >> 16) : (int)(int16_t)(v & 0xFFFFu); }
+
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
+{
+  uint32_t d;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+  uint32_t d;
+  asm("v_pk_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+  uint32_t d;
+  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// a * b + c per half
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t d;
+  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// min(x, 1) per half, x >= 0: the "differs" / "is greater" bit
+__device__ __forceinline__ uint32_t pk_bit(uint32_t x, uint32_t ones)
+{
+  uint32_t d;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(ones));
+  return d;
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+
+__device__ __forceinline__ int dpp_row_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_wave_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xF, 0xF, false); }
+
+// value of the lane above inside a group of G lanes; the group's first lane gets `border`
+template <int G>
+__device__ __forceinline__ uint32_t pk_shift_in(uint32_t border, uint32_t v, int g)
+{
+  if (G == 16) return (uint32_t)dpp_row_shr1((int)border, (int)v);
+  if (G == 8) { const uint32_t r = (uint32_t)dpp_row_shr1((int)border, (int)v); return g == 0 ? border : r; }
+  const uint32_t r = (uint32_t)dpp_wave_shr1((int)border, (int)v);
+  return (G < 64 && g == 0) ? border : r;
+}
+
+// the traceback reads the moves its wave stored a moment ago: served by L2 (sc1), never by a line another
+// wave's earlier use of the same scratch slot left in this CU's L1
+__device__ __forceinline__ uint32_t ld_moves(const uint32_t *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int pk_align_up(int x, int a) { return (x + a - 1) & ~(a - 1); }
+
+template <int G>
+__device__ __forceinline__ int pk_diag_run(bool flag, int q)
+{
+  const unsigned long long bm = __builtin_amdgcn_ballot_w64(flag);
+  if (G == 64) return ~bm == 0ull ? 64 : __builtin_ctzll(~bm);
+  const unsigned long long gm = (bm >> (q * G)) & ((1ull << (G & 63)) - 1);
+  return __builtin_ctzll(~gm | (1ull << (G & 63)));
+}
+
+// ------------------------------------------------------------------- node record ---
+// one dword per node of the graph after fusion #1, as alignment #2 reads it (LDS only):
+//   bit 0   first predecessor two nodes back (else one node back)
+//   bit 1   second predecessor two nodes back (a node without one repeats bit 0: both candidates are then the
+//           same cell and the first wins every comparison)
+//   bit 2   has a second predecessor       bit 3   first predecessor is the virtual start
+//   bit 4   second predecessor is the virtual start          bit 5   node opens a new MSA column (ring)
+//   bits 8-12 letter    bits 16-19 flags (kFlag*)    bits 24-31 ordinal among the two-predecessor nodes
+constexpr uint32_t kN_Far1 = 1u, kN_Far2 = 2u, kN_Has2 = 4u, kN_Virt1 = 8u, kN_Virt2 = 16u, kN_NewCol = 32u;
+
+// LDS slot of one window (bytes); must mirror poa_slot_need() below.
+//   [hdr 16][unc symbols][node records u32 (xi_cap + 1)][union]
+//   union, alignment #1 .. fusion #1: [ref + cor symbols][x2y u16 Lr][node_ref u16 Lr][node_cor u16 Lc][y2x u16 Lc]
+//   union, alignment #2 .. output:    [x2y u16 n1][ordinal bytes k2 * G | staged columns 3 (n1 + Lu) + 8, col_y u16 Lu]
+struct WinP {
+  bool valid;
+  uint32_t w;
+  int64_t o0;
+  int Lr, Lc, Lu, n1, triv, xi_cap;
+  uint8_t *slot;
+  int off_xi, off_u;
+  int score1, k2n;
+};
+
+// phase stamps (debug bit 2): cycles per phase summed over waves
+#define PK_STAMP(idx)                                                                             \
+  do {                                                                                            \
+    if ((a.debug & 4) && threadIdx.x == 0) {                                                      \
+      const unsigned long long now_ = __builtin_readcyclecounter();                               \
+      atomicAdd(a.stamps + (idx), now_ - stamp_);                                                 \
+      stamp_ = now_;                                                                              \
+    }                                                                                             \
+  } while (0)
+
+// ------------------------------------------------------------------ per-window phases ---
+
+// traceback of alignment #1 (align_lpo_po2.c:108-168), G cells per round (see poa_fused.hip).  Moves: bit 1 =
+// match (diagonal), bit 0 = x-insertion beats y-insertion; window half h of the word at [step][lane].
+template <int G, int R>
+__device__ __forceinline__ bool traceback_a(const WinP &W, const uint32_t *mv, int h, int q, int g, uint16_t *x2y)
+{
+  bool bad = false;
+  int x = W.Lr - 1, y = W.Lc - 1, guard = W.Lr + W.Lc + 2;
+  bool alive = W.valid && W.triv == 0;
+  while (__builtin_amdgcn_ballot_w64(alive) != 0) {
+    const int cx = x - g, cy = y - g;
+    const bool inb = alive && cx >= 0 && cy >= 0;
+    int xo = 0, yo = 0;
+    if (inb) {
+      const int rl = cy / R, rk = cy - rl * R;
+      const uint32_t two = (ld_moves(mv + (cx + 1 + rl) * 64 + q * G + rl) >> (16 * h + 2 * rk)) & 3u;
+      const int m = two >> 1, xw = two & 1;
+      xo = m | xw; yo = m | (xw ^ 1);
+    }
+    const int run = pk_diag_run<G>(inb && xo && yo, q);
+    if (g < run) x2y[cx] = (uint16_t)cy;
+    const bool stop = !inb;
+    int nx = cx - xo, ny = cy - yo, fl = stop ? 1 : 0;
+    const int src = min(run, G - 1);
+    nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
+    if (run >= G) { nx = x - G; ny = y - G; fl = 0; }
+    if (alive) {
+      x = nx; y = ny;
+      if ((fl & 1) || --guard <= 0) alive = false;
+    }
+  }
+  return bad;
+}
+
+// fusion #1 (lpo.c:602-668 on two linear sequences) spread over the window's G lanes, as in k_fused_a; the
+// node records go to LDS.  Returns false when the graph does not qualify for this kernel (a predecessor more
+// than two nodes back, more nodes than the slot holds) -- the window is then handed back.
+template <int G>
+__device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, const uint8_t *ys, uint16_t *x2y,
+                                         uint32_t *xinfo, bool *bad_out)
+{
+  const int Lr = W.Lr, Lc = W.Lc;
+  const bool on = W.valid && W.triv == 0;
+  bool bad = false;
+  uint16_t *node_ref = x2y + ((Lr + 1) & ~1);
+  uint16_t *node_cor = node_ref + ((Lr + 1) & ~1);
+  uint16_t *y2x = node_cor + ((Lc + 1) & ~1);
+  const int cx = (Lr + G - 1) / G, cy = (Lc + G - 1) / G;               // letters per lane
+  int cxmax = on ? cx : 0, cymax = on ? cy : 0;
+  for (int d = G; d < 64; d <<= 1) {
+    cxmax = max(cxmax, __shfl_xor(cxmax, d));
+    cymax = max(cymax, __shfl_xor(cymax, d));
+  }
+  cxmax = __builtin_amdgcn_readfirstlane(cxmax);
+  cymax = __builtin_amdgcn_readfirstlane(cymax);
+  if (on) for (int i = g; i < Lc; i += G) y2x[i] = (uint16_t)kNone16;
+  __builtin_amdgcn_wave_barrier();
+  const int x0 = g * cx, x1 = on ? min(Lr, x0 + cx) : 0;
+  const int y0 = g * cy, y1 = on ? min(Lc, y0 + cy) : 0;
+  int pmax = 0, fcnt = 0;
+  for (int it = 0; it < cxmax; ++it) {
+    const int ix = x0 + it;
+    if (ix < x1) {
+      const int ay = x2y[ix];
+      if (ay != (int)kNone16) {
+        if (ay < Lc) y2x[ay] = (uint16_t)ix; else bad = true;
+        if (ay + 1 <= pmax) bad = true;                                // a path is monotone
+        pmax = ay + 1;
+        fcnt += (ay < Lc && xs[ix] == ys[ay]);
+      }
+    }
+  }
+  int sp = pmax, sf = fcnt;
+  for (int d = 1; d < G; d <<= 1) {
+    const int tp = __shfl_up(sp, d, G), tf = __shfl_up(sf, d, G);
+    if (g >= d) { sp = max(sp, tp); sf += tf; }
+  }
+  const int fused_all = __shfl(sf, G - 1, G);
+  int P = __shfl_up(sp, 1, G), F = sf - fcnt;
+  if (g == 0) P = 0;
+  if (pmax > 0 && x1 > x0) {
+    int first = 0;
+    for (int ix = x0; ix < x1; ++ix) { const int ay = x2y[ix]; if (ay != (int)kNone16) { first = ay + 1; break; } }
+    if (first <= P) bad = true;
+  }
+  for (int it = 0; it < cxmax; ++it) {
+    const int ix = x0 + it;
+    if (ix < x1) {
+      const int ay = x2y[ix];
+      if (ay != (int)kNone16) { P = ay + 1; F += (ay < Lc && xs[ix] == ys[ay]); }
+      node_ref[ix] = (uint16_t)(ix + P - F);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  constexpr int kUndef = -1;
+  int fy = 0, klow = kUndef;
+  for (int it = 0; it < cymax; ++it) {
+    const int y = y1 - 1 - it;
+    if (y >= y0) {
+      const int x = y2x[y];
+      if (x != (int)kNone16) { klow = x; fy += xs[x] == ys[y]; }
+    }
+  }
+  int sfy = fy, sfx = klow;
+  for (int d = 1; d < G; d <<= 1) {
+    const int tf = __shfl_up(sfy, d, G), tk = __shfl_down(sfx, d, G);
+    if (g >= d) sfy += tf;
+    if (g + d < G && sfx == kUndef) sfx = tk;
+  }
+  int K = __shfl_down(sfx, 1, G), fy_run = sfy;
+  if (g == G - 1 || K == kUndef) K = Lr;
+  for (int it = 0; it < cymax; ++it) {
+    const int y = y1 - 1 - it;
+    if (y >= y0) {
+      const int x = y2x[y];
+      const bool al = x != (int)kNone16, fu = al && xs[x] == ys[y];
+      if (fu) --fy_run;
+      if (al) K = x;
+      node_cor[y] = fu ? node_ref[x] : (uint16_t)(y - fy_run + K);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int n1 = Lr + Lc - fused_all;
+  bool fits = n1 <= W.xi_cap && n1 >= 1;
+  // every lane of the group must agree before any node is written
+  int maxd = 1, k2 = 0;
+  if (on && fits) {
+    auto emit = [&](int n, int letter, int flags, int ring, int sa, int sb) {
+      // sa / sb: predecessor nodes (-1 none); an INITIAL node has the virtual start first (align_lpo_po2.c:69-79)
+      uint32_t rec = ((uint32_t)letter << 8) | ((uint32_t)flags << 16) | (ring == n ? kN_NewCol : 0u);
+      int d1, d2 = 0;
+      bool v1 = false, v2 = false, has2 = false;
+      // the virtual start is column 0: from node n (column n + 1) it lies n + 1 columns back
+      if (sa < 0) { v1 = true; d1 = n + 1; }
+      else if (flags & kFlagInitial) { v1 = true; d1 = n + 1; has2 = true; d2 = n - sa; if (sb >= 0) bad = true; }
+      else { d1 = n - sa; if (sb >= 0) { has2 = true; d2 = n - sb; } }
+      maxd = max(maxd, max(d1, d2));
+      if (v1) rec |= kN_Virt1;
+      if (d1 == 2) rec |= kN_Far1;
+      if (has2) { rec |= kN_Has2; if (d2 == 2) rec |= kN_Far2; ++k2; }
+      else if (d1 == 2) rec |= kN_Far2;
+      (void)v2;
+      if (n >= 0 && n < n1) xinfo[n + 1] = rec; else bad = true;
+    };
+    for (int it = 0; it < cxmax; ++it) {
+      const int ix = x0 + it;
+      if (ix < x1) {
+        const int ay = x2y[ix], n = node_ref[ix];
+        const bool al = ay != (int)kNone16 && ay < Lc, fu = al && xs[ix] == ys[ay];
+        int fl = kFlagHasRef | (ix == 0 ? kFlagInitial : 0) | (ix == Lr - 1 ? kFlagFinal : 0);
+        int sa = ix > 0 ? (int)node_ref[ix - 1] : -1, sb = -1, ring = n;
+        if (fu) {
+          fl |= kFlagHasCor | (ay == 0 ? kFlagInitial : 0) | (ay == Lc - 1 ? kFlagFinal : 0);
+          const int lasty = ay > 0 ? (int)node_cor[ay - 1] : -1;
+          if (lasty >= 0 && lasty != sa) { if (sa < 0) sa = lasty; else sb = lasty; }
+        } else if (al) ring = n - 1;                                       // joins the ring of its corrected partner
+        emit(n, xs[ix], fl, ring, sa, sb);
+      }
+    }
+    for (int it = 0; it < cymax; ++it) {
+      const int y = y0 + it;
+      if (y < y1) {
+        const int x = y2x[y];
+        if (!(x != (int)kNone16 && xs[x] == ys[y])) {
+          const int n = node_cor[y];
+          emit(n, ys[y], kFlagHasCor | (y == 0 ? kFlagInitial : 0) | (y == Lc - 1 ? kFlagFinal : 0), n,
+               y > 0 ? (int)node_cor[y - 1] : -1, -1);
+        }
+      }
+    }
+  }
+  for (int d = 1; d < G; d <<= 1) {
+    maxd = max(maxd, __shfl_xor(maxd, d, G));
+    bad = bad || __shfl_xor(bad ? 1 : 0, d, G) != 0;
+  }
+  if (on) W.n1 = n1;
+  *bad_out = bad;
+  return !on || (fits && maxd <= 2 && !bad);
+}
+
+// the graph of a window whose corrected sequence equals its reference (chain, every node holds both letters)
+// or differs from it by one substitution at position e (the corrected letter gets a node of its own right
+// before the reference letter's, both in one ring: lpo.c:449-450,647-649) -- see k_trivial in poa_kernels.hip
+template <int G>
+__device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs, const uint8_t *ys, uint32_t *xinfo)
+{
+  if (!W.valid || W.triv == 0) return;
+  const int L = W.Lr;
+  if (W.triv == 1) {
+    for (int n = g; n < L; n += G) {
+      const int fl = kFlagHasRef | kFlagHasCor | (n == 0 ? kFlagInitial : 0) | (n == L - 1 ? kFlagFinal : 0);
+      xinfo[n + 1] = ((uint32_t)xs[n] << 8) | ((uint32_t)fl << 16) | kN_NewCol | (n == 0 ? kN_Virt1 : 0u);
+    }
+    W.n1 = L;
+    return;
+  }
+  int e = L;
+  for (int i = g; i < L && i < e; i += G) if (xs[i] != ys[i]) e = i;
+  for (int d = 1; d < G; d <<= 1) e = min(e, __shfl_xor(e, d, G));
+  for (int i = g; i < L; i += G) {
+    const int fl_pos = (i == 0 ? kFlagInitial : 0) | (i == L - 1 ? kFlagFinal : 0);
+    if (i != e) {
+      const int n = i < e ? i : i + 1;
+      // after the bubble: first predecessor the reference letter's node (1 back), second the corrected letter's (2 back)
+      uint32_t rec = ((uint32_t)xs[i] << 8) | ((uint32_t)(kFlagHasRef | kFlagHasCor | fl_pos) << 16) | kN_NewCol;
+      if (i == 0) rec |= kN_Virt1;
+      if (i == e + 1) rec |= kN_Has2 | kN_Far2;
+      xinfo[n + 1] = rec;
+    } else {
+      // corrected letter: predecessor one back (virtual at the window's start); opens the column
+      uint32_t rc = ((uint32_t)ys[e] << 8) | ((uint32_t)(kFlagHasCor | fl_pos) << 16) | kN_NewCol | (e == 0 ? kN_Virt1 : 0u);
+      // reference letter: predecessor two back (the node before the bubble), same column
+      uint32_t rr = ((uint32_t)xs[e] << 8) | ((uint32_t)(kFlagHasRef | fl_pos) << 16) | kN_Far1 | kN_Far2 | (e == 0 ? kN_Virt1 : 0u);
+      xinfo[e + 1] = rc;
+      xinfo[e + 2] = rr;
+    }
+  }
+  W.n1 = L + 1;
+}
+
+// the column layout rule in its plain serial form (one lane): the fallback of the parallel version in k_poa
+// (fuse2_columns_serial of poa_fused.hip with the ring ids read off the column-start bits)
+__device__ __noinline__ int pk_columns_serial(int n1, int Lu, const uint32_t *xinfo, const uint16_t *x2y, const uint8_t *ys,
+                                              const uint8_t *chr, uint8_t *cols_st)
+{
+  int col = 0, prev_ring = 0;
+  uint8_t c0 = '.', c1 = '.', c2 = '.';
+  auto flush = [&]() { cols_st[3 * col] = c0; cols_st[3 * col + 1] = c1; cols_st[3 * col + 2] = c2; };
+  auto place = [&](int ring_id, int letter, bool r, bool c, bool u) {
+    if (ring_id != prev_ring) { flush(); ++col; c0 = c1 = c2 = '.'; prev_ring = ring_id; }
+    const uint8_t ch = chr[letter & 31];
+    if (r) c0 = ch;
+    if (c) c1 = ch;
+    if (u) c2 = ch;
+  };
+  int n = 0, iy = 0, blk_new = -1;
+  for (int ix = 0; ix < n1; ++ix) {
+    if (xinfo[ix + 1] & kN_NewCol) blk_new = -1;
+    for (int k = ix; k < n1 && (k == ix || !(xinfo[k + 1] & kN_NewCol)); ++k) {
+      const int ay = x2y[k];
+      if (ay != (int)kNone16) {
+        while (iy < ay) { place(n, ys[iy], false, false, true); ++n; ++iy; }
+        break;
+      }
+    }
+    const uint32_t xv = xinfo[ix + 1];
+    const int letter = (xv >> 8) & 0xFF, fl = (int)((xv >> 16) & 0xFF);
+    bool fused = false;
+    if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
+      if (letter == ys[iy]) fused = true;
+      else {
+        if (blk_new < 0) blk_new = n;
+        place(blk_new, ys[iy], false, false, true);
+        ++n;
+      }
+      ++iy;
+    }
+    if (blk_new < 0) blk_new = n;
+    place(blk_new, letter, (fl & kFlagHasRef) != 0, (fl & kFlagHasCor) != 0, fused);
+    ++n;
+  }
+  while (iy < Lu) { place(n, ys[iy], false, false, true); ++n; ++iy; }
+  flush();
+  return col + 1;
+}
+
+
+// traceback of alignment #2 (align_lpo_po2.c:108-168), G cells per round: a cell keeps the walk on its
+// diagonal when it is a match whose chosen predecessor is the node right before it
+template <int G, int R>
+__device__ __forceinline__ bool traceback_b(const WinP &W, const uint32_t *mv, int h, int q, int g, const uint32_t *xinfo,
+                                            const uint8_t *ordb, uint16_t *x2y, int bestx)
+{
+  bool bad = false;
+  int x = W.valid ? bestx : -1, y = W.Lu - 1, guard = W.n1 + W.Lu + 2;
+  bool alive = W.valid;
+  while (__builtin_amdgcn_ballot_w64(alive) != 0) {
+    const int cx = x - g, cy = y - g;
+    const bool inb = alive && cx >= 0 && cy >= 0;
+    int xo = 0, yo = 0, px = cx;
+    if (inb) {
+      const int rl = cy / R, rk = cy - rl * R;
+      const uint32_t rec = xinfo[cx + 1];
+      const uint32_t two = (ld_moves(mv + (cx + 1 + rl) * 64 + q * G + rl) >> (16 * h + 2 * rk)) & 3u;
+      const int m = two >> 1, xw = two & 1;
+      xo = m | xw; yo = m | (xw ^ 1);
+      if (xo) {
+        const int sec = (rec & kN_Has2) ? (ordb[(rec >> 24) * G + rl] >> rk) & 1 : 0;
+        const int far = sec ? (int)((rec >> 1) & 1u) : (int)(rec & 1u);
+        px = cx - 1 - far;                                           // < 0: the virtual start
+        if (px < -1) px = -1;
+      }
+    }
+    const int run = pk_diag_run<G>(inb && xo && yo && px == cx - 1, q);
+    if (inb && xo && yo && g <= run) x2y[cx] = (uint16_t)cy;        // the run's pairs, and the breaker's if it is a match
+    const bool stop = !inb;
+    int nx = px, ny = cy - yo, fl = stop ? 1 : 0;
+    const int src = min(run, G - 1);
+    nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
+    if (run >= G) { nx = x - G; ny = y - G; fl = 0; }
+    if (alive) {
+      x = nx; y = ny;
+      if ((fl & 1) || --guard <= 0) { if (guard <= 0) bad = true; alive = false; }
+    }
+  }
+  return bad;
+}
+
+// fusion #2 and the MSA columns (lpo.c:602-668 column layout rule, lpo_format.c:337-393) over the window's G
+// lanes, as in k_fused_b: every ring of the (ref + cor) graph is one column, an uncorrected letter aligned to
+// one of the ring's nodes joins it, every other uncorrected letter gets a column of its own just before the
+// next ring that holds an aligned letter.  Returns the number of columns staged in cols_st.
+template <int G>
+__device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *xinfo, const uint16_t *x2y, const uint8_t *ys,
+                                         const uint8_t *chr, uint8_t *cols_st, uint16_t *col_y, bool bad)
+{
+  const bool valid = W.valid;
+  const int n1 = W.n1, Lu = W.Lu;
+  const int cn = (n1 + G - 1) / G, cy = (Lu + G - 1) / G;
+  int cnmax = valid ? cn : 0, cymax = valid ? cy : 0;
+  for (int d = G; d < 64; d <<= 1) {
+    cnmax = max(cnmax, __shfl_xor(cnmax, d));
+    cymax = max(cymax, __shfl_xor(cymax, d));
+  }
+  cnmax = __builtin_amdgcn_readfirstlane(cnmax);
+  cymax = __builtin_amdgcn_readfirstlane(cymax);
+  if (valid) for (int i = g; i < Lu; i += G) col_y[i] = (uint16_t)kNone16;
+  const int i0 = g * cn, i1 = valid ? min(n1, i0 + cn) : 0;
+  auto starts = [&](int ix) { return (xinfo[ix + 1] & kN_NewCol) != 0; };
+  // the aligned letter of the ring that starts at node ix (-1: none); cnt > 1 cannot come from a path
+  auto ring_aligned = [&](int ix, bool *odd) {
+    int ay = -1, cnt = 0;
+    for (int k = ix; k < n1 && (k == ix || !starts(k)); ++k) {
+      const int v = x2y[k];
+      if (v != (int)kNone16) { if (!cnt) ay = v; ++cnt; }
+    }
+    if (cnt > 1) *odd = true;
+    return ay;
+  };
+  bool odd = false;
+  int ngs = 0, nal = 0, last_ay = -1;
+  for (int it = 0; it < cnmax; ++it) {
+    const int ix = i0 + it;
+    if (ix < i1 && starts(ix)) {
+      ++ngs;
+      const int ay = ring_aligned(ix, &odd);
+      if (ay >= 0) { ++nal; if (ay <= last_ay) odd = true; last_ay = ay; }
+    }
+  }
+  int sg = ngs, sa = nal, sy = last_ay;                                  // inclusive scans over the group's lanes
+  for (int d = 1; d < G; d <<= 1) {
+    const int tg = __shfl_up(sg, d, G), ta = __shfl_up(sa, d, G), ty = __shfl_up(sy, d, G);
+    if (g >= d) { sg += tg; sa += ta; sy = max(sy, ty); }
+  }
+  const int prev_ay = __shfl_up(sy, 1, G);
+  int gcount = sg - ngs, alc = sa - nal, A = g > 0 ? prev_ay : -1;
+  const int ngroups = __shfl(sg, G - 1, G), nal_all = __shfl(sa, G - 1, G);
+  int ncol = ngroups + Lu - nal_all;
+  __builtin_amdgcn_wave_barrier();
+  for (int it = 0; it < cnmax; ++it) {
+    const int ix = i0 + it;
+    if (ix < i1 && starts(ix)) {
+      int ay = -1;
+      uint8_t c0 = '.', c1 = '.';
+      for (int k = ix; k < n1 && (k == ix || !starts(k)); ++k) {
+        const uint32_t xv = xinfo[k + 1];
+        const uint8_t ch = chr[(xv >> 8) & 31];
+        if ((xv >> 16) & kFlagHasRef) c0 = ch;
+        if ((xv >> 16) & kFlagHasCor) c1 = ch;
+        const int v = x2y[k];
+        if (v != (int)kNone16 && ay < 0) ay = v;
+      }
+      if (ay >= 0) { if (ay <= A) odd = true; ++alc; A = ay; }
+      const int col = gcount + (alc >= 1 ? A - (alc - 1) : 0);
+      if (col >= 0 && col < n1 + Lu) {
+        cols_st[3 * col] = c0;
+        cols_st[3 * col + 1] = c1;
+        cols_st[3 * col + 2] = ay >= 0 ? chr[ys[ay] & 31] : (uint8_t)'.';
+      } else odd = true;
+      if (ay >= 0) col_y[ay] = (uint16_t)col;
+      ++gcount;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // letters without a partner: column = K + y with K = (column - letter) of the next aligned letter
+  constexpr int kUndef = -0x40000000;
+  const int y0 = g * cy, y1 = valid ? min(Lu, y0 + cy) : 0;
+  int klow = kUndef;
+  for (int it = 0; it < cymax; ++it) {
+    const int y = y1 - 1 - it;
+    if (y >= y0) { const int c = col_y[y]; if (c != (int)kNone16) klow = c - y; }
+  }
+  int sfx = klow;                                                        // nearest defined value at or after this lane
+  for (int d = 1; d < G; d <<= 1) {
+    const int t = __shfl_down(sfx, d, G);
+    if (g + d < G && sfx == kUndef) sfx = t;
+  }
+  int K = __shfl_down(sfx, 1, G);
+  if (g == G - 1 || K == kUndef) K = ncol - Lu;
+  for (int it = 0; it < cymax; ++it) {
+    const int y = y1 - 1 - it;
+    if (y >= y0) {
+      const int c = col_y[y];
+      if (c != (int)kNone16) K = c - y;
+      else {
+        const int col = K + y;
+        if (col >= 0 && col < n1 + Lu) {
+          cols_st[3 * col] = '.'; cols_st[3 * col + 1] = '.'; cols_st[3 * col + 2] = chr[ys[y] & 31];
+        } else odd = true;
+      }
+    }
+  }
+  for (int d = 1; d < G; d <<= 1) odd = odd || __shfl_xor(odd ? 1 : 0, d, G) != 0;
+  __builtin_amdgcn_wave_barrier();
+  // an alignment that is not a monotone path through the rings cannot happen; if it ever does, the plain
+  // serial form of the rule decides
+  if (valid && odd && g == 0 && !bad) ncol = pk_columns_serial(n1, Lu, xinfo, x2y, ys, chr, cols_st);
+  ncol = __shfl(ncol, 0, G);
+  return ncol;
+}
+
+// ------------------------------------------------------------------------ k_poa ---
+
+template <int G, int R>
+__device__ __forceinline__ void load_win(WinP &W, const PackArgs &a, int64_t li, uint8_t *slot)
+{
+  constexpr int RS = R * G;
+  const KParams kp = a.b.kp;
+  W.valid = li < a.nlist;
+  W.w = W.valid ? a.list[li] : 0;
+  W.valid = W.valid && a.b.status[W.w] == 0 && a.done_a[W.w] == 0 && a.done_b[W.w] == 0;
+  W.o0 = 0; W.Lr = 0; W.Lc = 0; W.Lu = 0; W.n1 = 0; W.triv = 0; W.score1 = kNeg; W.k2n = 0;
+  if (W.valid) {
+    W.o0 = a.b.off[3 * (int64_t)W.w];
+    const int64_t o1 = a.b.off[3 * (int64_t)W.w + 1], o2 = a.b.off[3 * (int64_t)W.w + 2], o3 = a.b.off[3 * (int64_t)W.w + 3];
+    W.Lr = (int)(o1 - W.o0); W.Lc = (int)(o2 - o1); W.Lu = (int)(o3 - o2);
+    W.triv = a.triv ? a.triv[W.w] : 0;
+  }
+  W.slot = slot;
+  W.xi_cap = poa_xi_cap(W.Lr, W.Lc);
+  W.off_xi = 16 + pk_align_up(W.Lu, 4);
+  W.off_u = W.off_xi + 4 * (W.xi_cap + 1);
+  const int ua = poa_union_a(W.Lr, W.Lc), ub = poa_union_b(W.xi_cap, W.Lu, G);
+  const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(kp.open_x, kp.ext_x));
+  W.valid = W.valid && W.off_u + max(ua, ub) <= a.slot_bytes && W.Lc <= RS && W.Lu <= RS &&
+            max(W.Lr, W.xi_cap) + G + 2 <= a.mv_tw && maxpen * (W.Lr + W.Lc + W.Lu + 8) < 16000;
+}
+
+template <int G, int R>
+__global__ void __launch_bounds__(64) k_poa(PackArgs a)
+{
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int NP = 64 / G;                       // pairs of windows per wave
+  const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
+  const KParams kp = a.b.kp;
+  uint8_t *chr = lds;
+  unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
+  if (lane < 32) chr[lane] = a.b.tab->chr[lane];
+
+  WinP W[2];
+  const int64_t pi = (int64_t)blockIdx.x * NP + q;
+  bool listed[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    load_win<G, R>(W[h], a, 2 * pi + h, lds + 64 + (size_t)(2 * q + h) * a.slot_bytes);
+    listed[h] = 2 * pi + h < a.nlist && a.b.status[W[h].w] == 0 && a.done_b[W[h].w] == 0 && a.done_a[W[h].w] == 0;
+  }
+  // a listed window this kernel cannot take (slot, rows, score range) goes to the two-kernel path at once
+#pragma unroll
+  for (int h = 0; h < 2; ++h) if (listed[h] && !W[h].valid && g == 0) a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
+  if (__builtin_amdgcn_ballot_w64(W[0].valid || W[1].valid) == 0) return;
+  // Moves scratch.  The moves of a wave are dead when it ends, so the scratch is a pool of slots as large as the
+  // number of waves that can be resident, not one region per block: the same few dozen megabytes are written and
+  // read back over and over and stay in L2 / Infinity Cache instead of streaming through HBM.  The per-XCD L2s
+  // are not coherent with each other, so a slot is only ever used from one XCD: the pool is split by XCC id, and
+  // every XCD has a queue of its free slot ids -- a wave takes the id at its ticket (head), gives it back at the
+  // end (tail).  There are more slots than an XCD can hold waves, so a ticket's entry is filled by the time it
+  // is drawn or shortly after.
+  uint32_t xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  int mslot = 0;
+  int32_t *mvq = a.mv_q + (size_t)xcc * kPoolStride;
+  if (a.mv_slots <= 0) { xcc = 0; mslot = (int)blockIdx.x; }          // experiment: one scratch region per block
+  else if (lane == 0) {
+    const uint32_t t = (uint32_t)atomicAdd(mvq, 1);
+    int32_t *e = mvq + 32 + t % (uint32_t)a.mv_slots;
+    while ((mslot = atomicExch(e, -1)) < 0) __builtin_amdgcn_s_sleep(2);
+  }
+  mslot = __builtin_amdgcn_readfirstlane(mslot);
+  uint32_t *mv = a.mv_pool + ((size_t)xcc * (a.mv_slots > 0 ? a.mv_slots : 0) + mslot) * (size_t)a.mv_tw * 64;
+
+  uint8_t *us[2], *U[2];
+  uint32_t *xinfo[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    us[h] = W[h].slot + 16;
+    xinfo[h] = reinterpret_cast<uint32_t *>(W[h].slot + W[h].off_xi);
+    U[h] = W[h].slot + W[h].off_u;
+  }
+  // ---- staging: the three symbol strings of both windows ----
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (W[h].valid) {
+      const uint8_t *src = a.b.sym + W[h].o0;
+      const int nrc = W[h].Lr + W[h].Lc;
+      for (int i = g; i < nrc; i += G) U[h][i] = src[i];
+      for (int i = g; i < W[h].Lu; i += G) us[h][i] = src[nrc + i];
+    }
+  }
+  __syncthreads();
+  PK_STAMP(0);
+
+  // packed constants (both halves alike)
+  const uint32_t ONES = 0x00010001u;
+  const uint32_t KSUB = pk1(kp.mismatch - kp.match), KMATCH = pk1(kp.match), KEXT = pk1(kp.ext_x),
+                 KDELTA = pk1(-(kp.open_x - kp.ext_x));
+  const bool match0 = kp.match == 0;
+
+  // ================= alignment #1 (linear x linear), the windows that need it =================
+  bool needA[2] = {W[0].valid && W[0].triv == 0, W[1].valid && W[1].triv == 0};
+  if (__builtin_amdgcn_ballot_w64(needA[0] || needA[1]) != 0) {
+    const uint8_t *xsA = U[0], *xsB = U[1];
+    uint32_t ylp[R], S[R], E[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int ii = R * g + 1 + k;
+      const int ya = (needA[0] && ii <= W[0].Lc) ? U[0][W[0].Lr + ii - 1] : 255;
+      const int yb = (needA[1] && ii <= W[1].Lc) ? U[1][W[1].Lr + ii - 1] : 255;
+      ylp[k] = pk2(ya, yb);
+      const int v = -(kp.open_y + (ii - 1) * kp.ext_y);       // column -1: ii gap steps from the origin
+      S[k] = pk1(v);
+      E[k] = pk1(v - kp.ext_x);
+    }
+    uint32_t dg0 = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // cell (row above, column -1)
+    int tmax = max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0) + G - 1;
+    for (int d = G; d < 64; d <<= 1) tmax = max(tmax, __shfl_xor(tmax, d));
+    tmax = __builtin_amdgcn_readfirstlane(tmax);
+    const int lrmax = max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0);
+    int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? xsA[0] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? xsB[0] : 0;
+    const int gstar0 = (W[0].Lc - 1) / R, kstar0 = (W[0].Lc - 1) % R, gstar1 = (W[1].Lc - 1) / R, kstar1 = (W[1].Lc - 1) % R;
+    uint32_t bS = pk1(-kp.open_x);                             // row -1 at column t: -(open_x + (t - 1) ext_x)
+    for (int t = 1; t <= tmax; ++t) {
+      const uint32_t upS = pk_shift_in<G>(bS, S[R - 1], g);
+      const uint32_t upE = pk_shift_in<G>(pk_sub(bS, KEXT), E[R - 1], g);
+      bS = pk_sub(bS, KEXT);
+      const int jj = t - g;
+      const uint32_t xlp = pk2(xa_next, xb_next);
+      xa_next = (needA[0] && jj >= 0 && jj < W[0].Lr) ? xsA[jj] : 0;
+      xb_next = (needA[1] && jj >= 0 && jj < W[1].Lr) ? xsB[jj] : 0;
+      if (jj >= 1 && jj <= lrmax) {
+        uint32_t diag = dg0, insY = upE, mvw = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const uint32_t oldS = S[k];
+          const uint32_t ne = pk_bit(xlp ^ ylp[k], ONES);
+          uint32_t mat = pk_mad(ne, KSUB, diag);
+          if (!match0) mat = pk_add(mat, KMATCH);
+          const uint32_t mx = pk_max(E[k], insY);
+          const uint32_t Sn = pk_max(mat, mx);
+          const uint32_t mbit = pk_bit(pk_sub(Sn, mx), ONES);          // match strictly best (align_lpo_po2.c:384)
+          const uint32_t xbit = pk_bit(pk_sub(mx, insY), ONES);        // x-insertion strictly above y-insertion (:392)
+          mvw |= ((mbit << 1) | xbit) << (2 * k);
+          S[k] = Sn;
+          E[k] = pk_mad(mbit, KDELTA, pk_sub(Sn, KEXT));               // Sn - (match ? open : ext)
+          diag = oldS; insY = E[k];
+        }
+        dg0 = upS;
+        const bool actA = needA[0] && jj <= W[0].Lr, actB = needA[1] && jj <= W[1].Lr;
+        if (actA || actB) mv[t * 64 + lane] = mvw;
+        if ((actA && jj == W[0].Lr && g == gstar0) || (actB && jj == W[1].Lr && g == gstar1)) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            if (actA && jj == W[0].Lr && g == gstar0 && k == kstar0) W[0].score1 = pk_half(S[k], 0);
+            if (actB && jj == W[1].Lr && g == gstar1 && k == kstar1) W[1].score1 = pk_half(S[k], 1);
+          }
+        }
+      }
+    }
+  }
+  // the score sits with the lane that holds the corrected read's last row
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int sc = __shfl(W[h].score1, needA[h] ? (W[h].Lc - 1) / R : 0, G);
+    if (needA[h]) W[h].score1 = sc;
+  }
+  PK_STAMP(1);
+  // ---- traceback #1, fusion #1 (per window), trivial graphs ----
+  bool bad[2] = {false, false}, keep[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint16_t *x2y = reinterpret_cast<uint16_t *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
+    if (needA[h]) for (int i = g; i < W[h].Lr; i += G) x2y[i] = (uint16_t)kNone16;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint16_t *x2y = reinterpret_cast<uint16_t *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
+    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0) traceback_a<G, R>(W[h], mv, h, q, g, x2y);
+  }
+  __builtin_amdgcn_wave_barrier();
+  PK_STAMP(2);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint16_t *x2y = reinterpret_cast<uint16_t *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
+    keep[h] = true;
+    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0) keep[h] = fusion_1<G>(W[h], g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h]);
+    trivial_graph<G>(W[h], g, U[h], U[h] + W[h].Lr, xinfo[h]);
+    if (W[h].valid && W[h].triv == 1) W[h].score1 = W[h].Lr * kp.match;
+    if (W[h].valid && W[h].triv == 2) W[h].score1 = (W[h].Lr - 1) * kp.match + kp.mismatch;
+  }
+  __syncthreads();
+  PK_STAMP(3);
+
+  // ---- ordinals of the two-predecessor nodes (they own a row of ordinal bytes); final fit check ----
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const bool on = W[h].valid && keep[h];
+    const int n1 = W[h].n1;
+    const int cn = (n1 + G - 1) / G;
+    int cnmax = on ? cn : 0;
+    for (int d = G; d < 64; d <<= 1) cnmax = max(cnmax, __shfl_xor(cnmax, d));
+    cnmax = __builtin_amdgcn_readfirstlane(cnmax);
+    const int j0 = 1 + g * cn, j1 = on ? min(n1 + 1, j0 + cn) : 0;
+    int cnt = 0;
+    for (int it = 0; it < cnmax; ++it) { const int jj = j0 + it; if (jj < j1) cnt += (xinfo[h][jj] & kN_Has2) != 0; }
+    int sc = cnt;
+    for (int d = 1; d < G; d <<= 1) { const int t = __shfl_up(sc, d, G); if (g >= d) sc += t; }
+    const int k2n = __shfl(sc, G - 1, G);
+    int k = sc - cnt;
+    for (int it = 0; it < cnmax; ++it) {
+      const int jj = j0 + it;
+      if (jj < j1) {
+        const uint32_t inf = xinfo[h][jj];
+        if (inf & kN_Has2) { xinfo[h][jj] = inf | ((uint32_t)min(k, 255) << 24); ++k; }
+      }
+    }
+    W[h].k2n = k2n;
+    const int region = pk_align_up(2 * n1, 4);
+    const int cols_need = pk_align_up(3 * (n1 + W[h].Lu) + 8, 4) + 2 * W[h].Lu + 4;
+    if (on && !(k2n <= 255 && W[h].off_u + region + max(k2n * G, cols_need) <= a.slot_bytes && n1 + G + 2 <= a.mv_tw)) keep[h] = false;
+    if (W[h].valid && (!keep[h] || bad[h])) {
+      // not for this kernel: the two-kernel path takes the window from scratch
+      if (g == 0) a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
+      W[h].valid = false;
+    }
+  }
+  __syncthreads();
+  PK_STAMP(4);
+
+
+  // ================= alignment #2 (graph x linear): the two predecessor columns in registers =================
+  uint16_t *x2yb[2];
+  uint8_t *ordb[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    x2yb[h] = reinterpret_cast<uint16_t *>(U[h]);
+    ordb[h] = U[h] + pk_align_up(2 * W[h].n1, 4);
+  }
+  int best[2] = {kNeg, kNeg}, bestx[2] = {-1, -1};
+  {
+    int tmax = max(W[0].valid ? W[0].n1 : 0, W[1].valid ? W[1].n1 : 0) + G - 1;
+    for (int d = G; d < 64; d <<= 1) tmax = max(tmax, __shfl_xor(tmax, d));
+    tmax = (__builtin_amdgcn_readfirstlane(tmax) + 1) & ~1;
+    uint32_t ylp[R], S1[R], E1[R], S2[R], E2[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int ii = R * g + 1 + k;
+      const int ya = (W[0].valid && ii <= W[0].Lu) ? us[0][ii - 1] : 255;
+      const int yb = (W[1].valid && ii <= W[1].Lu) ? us[1][ii - 1] : 255;
+      ylp[k] = pk2(ya, yb);
+      const int v = -(kp.open_y + (ii - 1) * kp.ext_y);        // column 0 (the virtual start): ii gap steps, not a match
+      S1[k] = S2[k] = pk1(v);
+      E1[k] = E2[k] = pk1(v - kp.ext_x);
+    }
+    uint32_t last3 = S1[R - 1];
+    // row -1 over the graph (align_lpo_po2.c:275-286) at the two columns before this one: score, and score less
+    // the gap it offers; the origin counts as "open"
+    uint32_t BR1 = 0, BR2 = 0, BE1 = pk1(-kp.open_x), BE2 = pk1(-kp.open_x);
+    const int gstar0 = (W[0].Lu - 1) / R, kstar0 = (W[0].Lu - 1) % R, gstar1 = (W[1].Lu - 1) / R, kstar1 = (W[1].Lu - 1) % R;
+    uint32_t xiA_next = (W[0].valid && g == 0 && W[0].n1 >= 1) ? xinfo[0][1] : 0u;
+    uint32_t xiB_next = (W[1].valid && g == 0 && W[1].n1 >= 1) ? xinfo[1][1] : 0u;
+
+    auto step = [&](int t, uint32_t (&Sa)[R], uint32_t (&Ea)[R], uint32_t (&Sb)[R], uint32_t (&Eb)[R]) {
+      const int jj = t - g;
+      const uint32_t xiA = xiA_next, xiB = xiB_next;
+      xiA_next = (W[0].valid && jj >= 0 && jj < W[0].n1) ? xinfo[0][jj + 1] : 0u;
+      xiB_next = (W[1].valid && jj >= 0 && jj < W[1].n1) ? xinfo[1][jj + 1] : 0u;
+      // per-half select masks: predecessor two columns back (else one)
+      const uint32_t M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
+      const uint32_t M2 = bfi(0xFFFFu, 0u - ((xiA >> 1) & 1u), 0u - ((xiB >> 1) & 1u));
+      const uint32_t xlp = ((xiA >> 8) & 0xFFu) | ((xiB << 8) & 0xFF0000u);
+      const bool two = __builtin_amdgcn_ballot_w64(((xiA | xiB) & kN_Has2) != 0u) != 0;
+      const uint32_t BRj = pk_max(bfi(M1, BE2, BE1), bfi(M2, BE2, BE1));
+      const uint32_t BEj = pk_sub(BRj, KEXT);
+      const uint32_t up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);        // row above at column jj - 1
+      const uint32_t up2 = pk_shift_in<G>(BR2, last3, g);            // ... at column jj - 2
+      const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
+      if (jj >= 1) {                                                 // before its first column a lane keeps column 0
+        const uint32_t sv3 = Sb[R - 1];
+        uint32_t dt1 = bfi(M1, up2, up1), dt2 = bfi(M2, up2, up1), insY = upE, mvw = 0, secw = 0;
+        auto cells = [&](auto two_tag) {
+          constexpr bool TWO = decltype(two_tag)::value;
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            const uint32_t c1S = bfi(M1, Sb[k], Sa[k]), c1E = bfi(M1, Eb[k], Ea[k]);
+            uint32_t insX = c1E, dmax = dt1, c2S = c1S;
+            if (TWO) {
+              c2S = bfi(M2, Sb[k], Sa[k]);
+              const uint32_t c2E = bfi(M2, Eb[k], Ea[k]);
+              insX = pk_max(c1E, c2E);                                // first maximum wins (:361-371)
+              dmax = pk_max(dt1, dt2);                                // (:348-357)
+            }
+            const uint32_t ne = pk_bit(xlp ^ ylp[k], ONES);
+            uint32_t mat = pk_mad(ne, KSUB, dmax);
+            if (!match0) mat = pk_add(mat, KMATCH);
+            const uint32_t mx = pk_max(insX, insY);
+            const uint32_t Sn = pk_max(mat, mx);
+            const uint32_t mbit = pk_bit(pk_sub(Sn, mx), ONES);
+            const uint32_t xbit = pk_bit(pk_sub(mx, insY), ONES);
+            mvw |= ((mbit << 1) | xbit) << (2 * k);
+            if (TWO) {
+              const uint32_t pm = pk_bit(pk_sub(dmax, dt1), ONES);   // second predecessor strictly better on the diagonal
+              const uint32_t px = pk_bit(pk_sub(insX, c1E), ONES);   // ... for the x-insertion
+              secw |= bfi(pk_sub(0u, mbit), pm, px) << k;
+            }
+            const uint32_t En = pk_mad(mbit, KDELTA, pk_sub(Sn, KEXT));
+            dt1 = c1S; dt2 = c2S;
+            Sb[k] = Sn; Eb[k] = En; insY = En;
+          }
+        };
+        if (two) cells(std::true_type{}); else cells(std::false_type{});
+        last3 = sv3;
+        BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
+        const bool actA = xiA != 0u, actB = xiB != 0u;
+        if (actA || actB) mv[t * 64 + lane] = mvw;
+        if (two) {
+          if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
+          if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
+        }
+        const bool finA = actA && g == gstar0 && ((xiA >> 16) & kFlagFinal) != 0u;
+        const bool finB = actB && g == gstar1 && ((xiB >> 16) & kFlagFinal) != 0u;
+        if (finA || finB) {
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            if (finA && k == kstar0) { const int v = pk_half(Sb[k], 0); if (v > best[0]) { best[0] = v; bestx[0] = jj - 1; } }
+            if (finB && k == kstar1) { const int v = pk_half(Sb[k], 1); if (v > best[1]) { best[1] = v; bestx[1] = jj - 1; } }
+          }
+        }
+      }
+    };
+    for (int t = 1; t <= tmax; t += 2) {
+      step(t, S1, E1, S2, E2);
+      step(t + 1, S2, E2, S1, E1);
+    }
+  }
+  PK_STAMP(5);
+  // best end cell to every lane of the group
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int gs = (W[h].Lu - 1) / R;
+    best[h] = __shfl(best[h], W[h].valid ? gs : 0, G);
+    bestx[h] = __shfl(bestx[h], W[h].valid ? gs : 0, G);
+    if (W[h].valid) for (int i = g; i < W[h].n1; i += G) x2yb[h][i] = (uint16_t)kNone16;
+  }
+  __syncthreads();
+  bool badb[2] = {false, false};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (__builtin_amdgcn_ballot_w64(W[h].valid) != 0)
+      badb[h] = traceback_b<G, R>(W[h], mv, h, q, g, xinfo[h], ordb[h], x2yb[h], bestx[h]);
+  __builtin_amdgcn_wave_barrier();
+  PK_STAMP(6);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (__builtin_amdgcn_ballot_w64(W[h].valid) == 0) continue;
+    uint8_t *cols_st = ordb[h];                                       // the ordinal bytes are dead after the traceback
+    uint16_t *col_y = reinterpret_cast<uint16_t *>(cols_st + pk_align_up(3 * (W[h].n1 + W[h].Lu) + 8, 4));
+    for (int d = 1; d < G; d <<= 1) badb[h] = badb[h] || __shfl_xor(badb[h] ? 1 : 0, d, G) != 0;
+    const int ncol = columns_2<G>(W[h], g, xinfo[h], x2yb[h], us[h], chr, cols_st, col_y, badb[h]);
+    __builtin_amdgcn_wave_barrier();
+    if (W[h].valid) {
+      uint8_t *gc = a.b.cols + 3 * W[h].o0;
+      for (int i = g; i < 3 * ncol; i += G) gc[i] = cols_st[i];
+      if (g == 0) {
+        const uint32_t w = W[h].w;
+        a.b.ncol[w] = ncol;
+        a.b.n1[w] = W[h].n1;
+        a.b.score1[w] = W[h].score1;
+        a.b.score2[w] = best[h];
+        a.b.bx2[w] = bestx[h];
+        if (badb[h]) a.b.status[w] = 3;
+        a.done_a[w] = 1;
+        a.done_b[w] = 1;
+      }
+    }
+  }
+  PK_STAMP(7);
+  if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
+  // give the moves slot back: every access of this wave to it has completed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && a.mv_slots > 0) {
+    const uint32_t t = (uint32_t)atomicAdd(mvq + 16, 1);
+    int32_t *e = mvq + 32 + t % (uint32_t)a.mv_slots;
+    while (atomicCAS(e, -1, mslot) != -1) __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// ---------------------------------------------------------------- launcher ---
+
+// free-slot queues of the moves scratch: every XCD's queue holds the ids 0 .. slots - 1, head 0, tail = slots
+__global__ void __launch_bounds__(256) k_poa_pool_init(int32_t *q, int nq, int slots)
+{
+  for (int x = blockIdx.x; x < nq; x += gridDim.x) {
+    int32_t *mvq = q + (size_t)x * kPoolStride;
+    if (threadIdx.x == 0) { mvq[0] = 0; mvq[16] = slots; }
+    for (int i = threadIdx.x; i < kPoolStride - 32; i += 256) mvq[32 + i] = i < slots ? i : -1;
+  }
+}
+
+void launch_poa_pool_init(int32_t *q, int nq, int slots, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_poa_pool_init, dim3((unsigned)nq), dim3(256), 0, st, q, nq, slots);
+}
+
+template <int G, int R>
+static int launch_poa_t(const PackArgs &a, hipStream_t st)
+{
+  constexpr int NW = 2 * (64 / G);     // windows per block (one wave)
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_poa<G, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 256) != hipSuccess)
+      return -1;
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_poa<G, R>), dim3((unsigned)((a.nlist + NW - 1) / NW)), dim3(64), 64 + NW * a.slot_bytes, st, a);
+  return 0;
+}
+
+#define ELECTOR_PACK_CLASSES(X) \
+  X(8, 4) X(8, 5) X(8, 6) X(8, 7) X(8, 8) X(16, 5) X(16, 6) X(16, 7) X(16, 8) \
+  X(32, 5) X(32, 6) X(32, 7) X(32, 8) X(64, 5) X(64, 6) X(64, 7) X(64, 8)
+
+int launch_poa(const PackArgs &a, int G, int R, hipStream_t st)
+{
+  if (a.nlist <= 0) return 0;
+#define X(g, r) if (G == g && R == r) return launch_poa_t<g, r>(a, st);
+  ELECTOR_PACK_CLASSES(X)
+#undef X
+  return -2;
+}
+
+}  // namespace elector

@@ -17,7 +17,9 @@ def check(engine, triples):
     bad = [w for w in range(len(triples)) if got[w] != exp_rows[w]]
     assert not bad, "first differing window %d of %d: %r\n got %r\n exp %r" % (
         bad[0], len(bad), triples[bad[0]], got[bad[0]], exp_rows[bad[0]])
-    assert np.array_equal(scores, exp_scores)
+    d = np.argwhere(scores != exp_scores)
+    assert len(d) == 0, "scores differ at %s: got %s exp %s, window %r" % (
+        d[:5].tolist(), scores[d[0][0]].tolist(), exp_scores[d[0][0]].tolist(), triples[d[0][0]])
 
 
 def test_small_windows(engine):
