@@ -75,6 +75,7 @@ struct elector_ctx {
   hipEvent_t aux_done[kAux] = {};
   hipEvent_t fork = nullptr;
   bool aux_ready = false;
+  std::vector<hipEvent_t> hb_events;   // k_poa -> hand-back launches (one per bin of a batch)
   int chains = 0;               // launch chains for the fused classes (elector_ctx_option "chains"; 0 = default)
   elector_params params;
   elector::KParams kp;

@@ -181,8 +181,8 @@ __host__ __device__ inline int poa_union_a(int Lr, int Lc)
 __host__ __device__ inline int poa_union_b(int n1, int Lu, int G)
 {
   const int x2y = (2 * n1 + 3) & ~3;
-  const int cols = ((3 * (n1 + Lu) + 8 + 3) & ~3) + 2 * Lu + 4;
-  const int ord = (8 + n1 / 4) * G;
+  const int cols = 2 * Lu + 4;
+  const int ord = (8 + n1 / 8) * G;
   return x2y + (cols > ord ? cols : ord);
 }
 

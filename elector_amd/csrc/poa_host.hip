@@ -315,6 +315,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  for (auto &e : c->hb_events) (void)hipEventDestroy(e);
   DevBuf *bufs[] = {&c->d_tab, &c->d_linx, &c->d_liny, &c->d_off, &c->d_perm, &c->d_mv1, &c->d_mv2, &c->d_sym,
                     &c->d_xinfo, &c->d_ring1, &c->d_map16, &c->d_carry, &c->d_moves, &c->d_n1, &c->d_cls,
                     &c->d_score1, &c->d_score2, &c->d_bx2, &c->d_bases, &c->d_cols, &c->d_ncol, &c->d_status,
@@ -473,10 +474,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const bool use_trivial = use_fused && !std::getenv("ELECTOR_NO_TRIVIAL") && c->kp.match >= 0 &&
                            c->kp.mismatch <= c->kp.match && c->kp.open_x > 0 && c->kp.ext_x > 0 && c->kp.open_y > 0 &&
                            c->kp.ext_y > 0;
-  // the one-kernel, two-windows-per-lane-group path (poa_pack.hip): symmetric gap penalties, and not when the
-  // graph has to stay in HBM for the bundle search
+  // the one-kernel, two-windows-per-lane-group path (poa_pack.hip): symmetric gap penalties and a match score of 0
+  // (the shipped parameters), and not when the graph has to stay in HBM for the bundle search
   const bool use_pack = use_trivial && !std::getenv("ELECTOR_NO_PACK") && !c->keep_graph && c->kp.open_x == c->kp.open_y &&
-                        c->kp.ext_x == c->kp.ext_y;
+                        c->kp.ext_x == c->kp.ext_y && c->kp.match == 0;
 
   // ---- host metadata ----
   const bool host_prof = std::getenv("ELECTOR_DEBUG_HOST") != nullptr;
@@ -832,7 +833,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     for (int b = 0; b < kBins; ++b) {
       if (!bin_cnt[(size_t)b]) continue;
       int tw, ns;
-      int64_t &r = fmv_stream[stream_of(b)];
+      int64_t &r = fmv_stream[use_pack ? 3 : stream_of(b)];      // behind k_poa the two-kernel path runs on the last stream
       r = std::max(r, std::max(fmv_geom(b, false, &tw, &ns), fmv_geom(b, true, &tw, &ns)));
       if (use_pack) {
         const PackGeom pg = pack_geom(b);
@@ -1023,8 +1024,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     HIPCHK(c, hipEventRecord(c->fork, st));
     const int used = n_chains;                         // launch chains = auxiliary streams in use
     for (int k = 0; k < used; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
+    if (use_pack && used <= 3) HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->fork, 0));
     // ELECTOR_LAUNCH_ORDER=ab (experiment): per stream all alignment #1 launches first, then all #2
     static const bool split_ab = std::getenv("ELECTOR_LAUNCH_ORDER") && std::string(std::getenv("ELECTOR_LAUNCH_ORDER")) == "ab";
+    int hb_used = 0;
     for (int pass = 0; pass < (split_ab ? 2 : 1); ++pass)
     for (int b : bin_order) {                       // within a chain: most work first
       if (!bin_cnt[(size_t)b]) continue;
@@ -1058,6 +1061,20 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         if (launch_poa(pa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
         timed_end(c, sx);
       }
+      // behind k_poa the two-kernel path only sees the windows handed back: its small launches go to a stream
+      // of their own (after this bin's k_poa), so that the chain can start its next k_poa at once
+      const int so = use_pack ? 3 : sk;
+      if (use_pack) {
+        if (c->hb_events.size() <= (size_t)hb_used) {
+          hipEvent_t e;
+          HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          c->hb_events.push_back(e);
+        }
+        HIPCHK(c, hipEventRecord(c->hb_events[(size_t)hb_used], sx));
+        HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->hb_events[(size_t)hb_used], 0));
+        ++hb_used;
+        sx = c->aux[3];
+      }
       FusedArgs fa;
       fa.b = a;
       fa.grid_blocks = use_pack ? old_grid(b) : 0;
@@ -1073,7 +1090,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       fa.triv = use_trivial && !use_pack ? d_triv : nullptr;
       fa.slot_bytes = (int)((bin_need_a[(size_t)b] + 127) & ~(int64_t)127);   // alignment #1: the bin's own maximum
       fa.mv_pool = c->d_fmv.as<uint8_t>();
-      for (int k = 0; k < sk; ++k) fa.mv_pool += fmv_stream[k];
+      for (int k = 0; k < so; ++k) fa.mv_pool += fmv_stream[k];
       (void)fmv_geom(b, false, &fa.mv_tw, &fa.mv_ns);
       if (!split_ab || pass == 0) {
         timed_begin(c, 0, sx);
@@ -1091,7 +1108,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       if (launch_fused_b(fa, bG, bR, 8, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
       timed_end(c, sx);
     }
-    for (int k = 0; k < std::min(used, (int)elector_ctx::kAux); ++k) {
+    const int join_n = use_pack ? (int)elector_ctx::kAux : std::min(used, (int)elector_ctx::kAux);
+    for (int k = 0; k < join_n; ++k) {
+      if (k >= used && k != 3) continue;
       HIPCHK(c, hipEventRecord(c->aux_done[k], c->aux[k]));
     }
     // generic alignment #1 for the host-routed windows runs on the main stream meanwhile
@@ -1115,7 +1134,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       }
       timed_end(c, st);
     }
-    for (int k = 0; k < std::min(used, (int)elector_ctx::kAux); ++k) HIPCHK(c, hipStreamWaitEvent(st, c->aux_done[k], 0));
+    for (int k = 0; k < join_n; ++k) {
+      if (k >= used && k != 3) continue;
+      HIPCHK(c, hipStreamWaitEvent(st, c->aux_done[k], 0));
+    }
     // everything alignment #2 still owes: the windows the fused kernels handed back
     a.n = n;
     a.perm = nullptr;
@@ -1173,6 +1195,15 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   c->graph_valid = c->keep_graph;
   c->last_ncol = d_ncol;
   c->last_status = d_status;
+  if (use_pack && std::getenv("ELECTOR_DEBUG_BINS")) {
+    (void)hipStreamSynchronize(st);
+    std::vector<int32_t> hc((size_t)kBins, 0);
+    (void)hipMemcpy(hc.data(), c->d_hand.as<uint32_t>() + n, (size_t)nbins_used * 4, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[elector] k_poa handed back:");
+    for (int b = 0; b < kBins; ++b)
+      if (bin_cnt[(size_t)b]) std::fprintf(stderr, " G%dxR%d:%d/%lld", kClsG[b / kNT], kClsR[b / kNT], hc[(size_t)bin_slot[(size_t)b]], (long long)bin_cnt[(size_t)b]);
+    std::fprintf(stderr, "\n");
+  }
   if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 4)) {
     (void)hipStreamSynchronize(st);
     int32_t hc[4];
@@ -1192,6 +1223,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     }
     for (int b = 0; b < kBins; ++b) {
       const unsigned long long *p = hs.data() + 32 * (size_t)b;
+      if (p[16 + 15])
+        std::fprintf(stderr, "[elector] bin G%dxR%d  k_poa waves %llu: stage %.0f dpA %.0f tbA %.0f fus1 %.0f ord %.0f dpB %.0f tbB %.0f cols+out %.0f  (cycles per wave)\n",
+                     kClsG[b / kNT], kClsR[b / kNT], p[31], (double)p[16] / p[31], (double)p[17] / p[31], (double)p[18] / p[31],
+                     (double)p[19] / p[31], (double)p[20] / p[31], (double)p[21] / p[31], (double)p[22] / p[31], (double)p[23] / p[31]);
       if (!p[4]) continue;
       std::fprintf(stderr, "[elector] bin G%dxR%d/%d  A waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f | B waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f  (cycles per wave)\n",
                    kClsG[b / kNT], kClsR[b / kNT], g_tier_bytes[b % kNT], p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[5] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],

@@ -75,21 +75,37 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
   asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
-// a * b + c per half
-__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
+// a * K + c per half, K wave-uniform (an SGPR operand: no copy into a VGPR)
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t K, uint32_t c)
 {
   uint32_t d;
-  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(K), "v"(c));
+  return d;
+}
+// a - K per half, K wave-uniform
+__device__ __forceinline__ uint32_t pk_subk(uint32_t a, uint32_t K)
+{
+  uint32_t d;
+  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(K));
   return d;
 }
 // min(x, 1) per half, x >= 0: the "differs" / "is greater" bit
 __device__ __forceinline__ uint32_t pk_bit(uint32_t x, uint32_t ones)
 {
   uint32_t d;
-  asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(ones));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(x), "s"(ones));
   return d;
 }
-__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+// (m & a) | (~m & b)
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b)
+{
+  uint32_t d;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+  return d;
+}
+// keep an accumulator materialised here (the compiler otherwise postpones the OR chain and holds every
+// pair's bits in a register of its own)
+__device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
 
 __device__ __forceinline__ int dpp_row_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xF, 0xF, false); }
 __device__ __forceinline__ int dpp_wave_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xF, 0xF, false); }
@@ -127,15 +143,16 @@ __device__ __forceinline__ int pk_diag_run(bool flag, int q)
 //   bit 0   first predecessor two nodes back (else one node back)
 //   bit 1   second predecessor two nodes back (a node without one repeats bit 0: both candidates are then the
 //           same cell and the first wins every comparison)
-//   bit 2   has a second predecessor       bit 3   first predecessor is the virtual start
-//   bit 4   second predecessor is the virtual start          bit 5   node opens a new MSA column (ring)
+//   bit 2   has a second predecessor       bit 3   first predecessor is the virtual start, more than two columns
+//   back (a virtual start one or two columns back is column 0 in the registers: bits 0 / 1 as for any node)
+//   bit 4   unused                         bit 5   node opens a new MSA column (ring)
 //   bits 8-12 letter    bits 16-19 flags (kFlag*)    bits 24-31 ordinal among the two-predecessor nodes
 constexpr uint32_t kN_Far1 = 1u, kN_Far2 = 2u, kN_Has2 = 4u, kN_Virt1 = 8u, kN_Virt2 = 16u, kN_NewCol = 32u;
 
 // LDS slot of one window (bytes); must mirror poa_slot_need() below.
 //   [hdr 16][unc symbols][node records u32 (xi_cap + 1)][union]
 //   union, alignment #1 .. fusion #1: [ref + cor symbols][x2y u16 Lr][node_ref u16 Lr][node_cor u16 Lc][y2x u16 Lc]
-//   union, alignment #2 .. output:    [x2y u16 n1][ordinal bytes k2 * G | staged columns 3 (n1 + Lu) + 8, col_y u16 Lu]
+//   union, alignment #2 .. output:    [x2y u16 n1][ordinal bytes k2 * G | col_y u16 Lu]
 struct WinP {
   bool valid;
   uint32_t w;
@@ -293,8 +310,10 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
       if (sa < 0) { v1 = true; d1 = n + 1; }
       else if (flags & kFlagInitial) { v1 = true; d1 = n + 1; has2 = true; d2 = n - sa; if (sb >= 0) bad = true; }
       else { d1 = n - sa; if (sb >= 0) { has2 = true; d2 = n - sb; } }
+      // a virtual start more than two columns back cannot come from the two register columns: the DP patches
+      // in the cells of column 0, which depend on the row only
+      if (v1 && d1 > 2) { rec |= kN_Virt1; d1 = 1; }
       maxd = max(maxd, max(d1, d2));
-      if (v1) rec |= kN_Virt1;
       if (d1 == 2) rec |= kN_Far1;
       if (has2) { rec |= kN_Has2; if (d2 == 2) rec |= kN_Far2; ++k2; }
       else if (d1 == 2) rec |= kN_Far2;
@@ -447,7 +466,7 @@ __device__ __forceinline__ bool traceback_b(const WinP &W, const uint32_t *mv, i
         const int sec = (rec & kN_Has2) ? (ordb[(rec >> 24) * G + rl] >> rk) & 1 : 0;
         const int far = sec ? (int)((rec >> 1) & 1u) : (int)(rec & 1u);
         px = cx - 1 - far;                                           // < 0: the virtual start
-        if (px < -1) px = -1;
+        if (px < -1 || (!sec && (rec & kN_Virt1))) px = -1;
       }
     }
     const int run = pk_diag_run<G>(inb && xo && yo && px == cx - 1, q);
@@ -606,7 +625,7 @@ __device__ __forceinline__ void load_win(WinP &W, const PackArgs &a, int64_t li,
 }
 
 template <int G, int R>
-__global__ void __launch_bounds__(64) k_poa(PackArgs a)
+__global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NP = 64 / G;                       // pairs of windows per wave
@@ -657,14 +676,25 @@ __global__ void __launch_bounds__(64) k_poa(PackArgs a)
     xinfo[h] = reinterpret_cast<uint32_t *>(W[h].slot + W[h].off_xi);
     U[h] = W[h].slot + W[h].off_u;
   }
-  // ---- staging: the three symbol strings of both windows ----
+  // ---- staging: the three symbol strings of both windows (contiguous in HBM; reference + corrected go to the
+  // union region, the uncorrected string to its own place); eight loads in flight per lane ----
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    if (W[h].valid) {
-      const uint8_t *src = a.b.sym + W[h].o0;
-      const int nrc = W[h].Lr + W[h].Lc;
-      for (int i = g; i < nrc; i += G) U[h][i] = src[i];
-      for (int i = g; i < W[h].Lu; i += G) us[h][i] = src[nrc + i];
+    const uint8_t *src = a.b.sym + W[h].o0;
+    const int nrc = W[h].Lr + W[h].Lc, ntot = W[h].valid ? nrc + W[h].Lu : 0;
+    int nmax = ntot;
+    for (int d = G; d < 64; d <<= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    for (int ib = g; ib < nmax; ib += 8 * G) {
+      uint8_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = ib + u * G; v[u] = i < ntot ? src[i] : (uint8_t)0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = ib + u * G;
+        if (i < nrc) U[h][i] = v[u];
+        else if (i < ntot) us[h][i - nrc] = v[u];
+      }
     }
   }
   __syncthreads();
@@ -672,9 +702,7 @@ __global__ void __launch_bounds__(64) k_poa(PackArgs a)
 
   // packed constants (both halves alike)
   const uint32_t ONES = 0x00010001u;
-  const uint32_t KSUB = pk1(kp.mismatch - kp.match), KMATCH = pk1(kp.match), KEXT = pk1(kp.ext_x),
-                 KDELTA = pk1(-(kp.open_x - kp.ext_x));
-  const bool match0 = kp.match == 0;
+  const uint32_t KSUB = pk1(kp.mismatch), KEXT = pk1(kp.ext_x), KDELTA = pk1(-(kp.open_x - kp.ext_x));   // match == 0 (host)
 
   // ================= alignment #1 (linear x linear), the windows that need it =================
   bool needA[2] = {W[0].valid && W[0].triv == 0, W[1].valid && W[1].triv == 0};
@@ -701,8 +729,8 @@ __global__ void __launch_bounds__(64) k_poa(PackArgs a)
     uint32_t bS = pk1(-kp.open_x);                             // row -1 at column t: -(open_x + (t - 1) ext_x)
     for (int t = 1; t <= tmax; ++t) {
       const uint32_t upS = pk_shift_in<G>(bS, S[R - 1], g);
-      const uint32_t upE = pk_shift_in<G>(pk_sub(bS, KEXT), E[R - 1], g);
-      bS = pk_sub(bS, KEXT);
+      const uint32_t upE = pk_shift_in<G>(pk_subk(bS, KEXT), E[R - 1], g);
+      bS = pk_subk(bS, KEXT);
       const int jj = t - g;
       const uint32_t xlp = pk2(xa_next, xb_next);
       xa_next = (needA[0] && jj >= 0 && jj < W[0].Lr) ? xsA[jj] : 0;
@@ -713,15 +741,15 @@ __global__ void __launch_bounds__(64) k_poa(PackArgs a)
         for (int k = 0; k < R; ++k) {
           const uint32_t oldS = S[k];
           const uint32_t ne = pk_bit(xlp ^ ylp[k], ONES);
-          uint32_t mat = pk_mad(ne, KSUB, diag);
-          if (!match0) mat = pk_add(mat, KMATCH);
+          const uint32_t mat = pk_mad(ne, KSUB, diag);
           const uint32_t mx = pk_max(E[k], insY);
           const uint32_t Sn = pk_max(mat, mx);
           const uint32_t mbit = pk_bit(pk_sub(Sn, mx), ONES);          // match strictly best (align_lpo_po2.c:384)
           const uint32_t xbit = pk_bit(pk_sub(mx, insY), ONES);        // x-insertion strictly above y-insertion (:392)
           mvw |= ((mbit << 1) | xbit) << (2 * k);
+          pin(mvw);
           S[k] = Sn;
-          E[k] = pk_mad(mbit, KDELTA, pk_sub(Sn, KEXT));               // Sn - (match ? open : ext)
+          E[k] = pk_mad(mbit, KDELTA, pk_subk(Sn, KEXT));              // Sn - (match ? open : ext)
           diag = oldS; insY = E[k];
         }
         dg0 = upS;
@@ -796,7 +824,7 @@ __global__ void __launch_bounds__(64) k_poa(PackArgs a)
     }
     W[h].k2n = k2n;
     const int region = pk_align_up(2 * n1, 4);
-    const int cols_need = pk_align_up(3 * (n1 + W[h].Lu) + 8, 4) + 2 * W[h].Lu + 4;
+    const int cols_need = 2 * W[h].Lu + 4;
     if (on && !(k2n <= 255 && W[h].off_u + region + max(k2n * G, cols_need) <= a.slot_bytes && n1 + G + 2 <= a.mv_tw)) keep[h] = false;
     if (W[h].valid && (!keep[h] || bad[h])) {
       // not for this kernel: the two-kernel path takes the window from scratch
@@ -833,6 +861,9 @@ __global__ void __launch_bounds__(64) k_poa(PackArgs a)
       E1[k] = E2[k] = pk1(v - kp.ext_x);
     }
     uint32_t last3 = S1[R - 1];
+    const uint32_t colS0 = pk1(-(kp.open_y + (R * g) * kp.ext_y));               // column 0 at this lane's first row
+    const uint32_t colAbove = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // ... at the row above it (the origin for lane 0)
+    const uint32_t KOPENNEG = pk1(-kp.open_x);
     // row -1 over the graph (align_lpo_po2.c:275-286) at the two columns before this one: score, and score less
     // the gap it offers; the origin counts as "open"
     uint32_t BR1 = 0, BR2 = 0, BE1 = pk1(-kp.open_x), BE2 = pk1(-kp.open_x);
@@ -849,46 +880,67 @@ __global__ void __launch_bounds__(64) k_poa(PackArgs a)
       const uint32_t M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
       const uint32_t M2 = bfi(0xFFFFu, 0u - ((xiA >> 1) & 1u), 0u - ((xiB >> 1) & 1u));
       const uint32_t xlp = ((xiA >> 8) & 0xFFu) | ((xiB << 8) & 0xFF0000u);
-      const bool two = __builtin_amdgcn_ballot_w64(((xiA | xiB) & kN_Has2) != 0u) != 0;
-      const uint32_t BRj = pk_max(bfi(M1, BE2, BE1), bfi(M2, BE2, BE1));
-      const uint32_t BEj = pk_sub(BRj, KEXT);
+      const bool virt = __builtin_amdgcn_ballot_w64(((xiA | xiB) & kN_Virt1) != 0u) != 0;
+      const bool two = virt || __builtin_amdgcn_ballot_w64(((xiA | xiB) & kN_Has2) != 0u) != 0;
+      uint32_t V1 = 0, V2 = 0, bb1 = bfi(M1, BE2, BE1), bb2 = bfi(M2, BE2, BE1);
+      if (virt) {
+        V1 = bfi(0xFFFFu, 0u - ((xiA >> 3) & 1u), 0u - ((xiB >> 3) & 1u));
+        // a node without a second predecessor repeats the first: the repeat is virtual too
+        V2 = V1 & ~bfi(0xFFFFu, 0u - ((xiA >> 2) & 1u), 0u - ((xiB >> 2) & 1u));
+        bb1 = bfi(V1, KOPENNEG, bb1);
+        bb2 = bfi(V2, KOPENNEG, bb2);
+      }
+      const uint32_t BRj = pk_max(bb1, bb2);
+      const uint32_t BEj = pk_subk(BRj, KEXT);
       const uint32_t up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);        // row above at column jj - 1
       const uint32_t up2 = pk_shift_in<G>(BR2, last3, g);            // ... at column jj - 2
       const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
       if (jj >= 1) {                                                 // before its first column a lane keeps column 0
         const uint32_t sv3 = Sb[R - 1];
         uint32_t dt1 = bfi(M1, up2, up1), dt2 = bfi(M2, up2, up1), insY = upE, mvw = 0, secw = 0;
-        auto cells = [&](auto two_tag) {
-          constexpr bool TWO = decltype(two_tag)::value;
+        if (virt) { dt1 = bfi(V1, colAbove, dt1); dt2 = bfi(V2, colAbove, dt2); }
+        auto cells = [&](auto two_tag, auto virt_tag) {
+          constexpr bool TWO = decltype(two_tag)::value, VIRT = decltype(virt_tag)::value;
+          uint32_t vcS = colS0;                                        // column 0 at this lane's rows, top down
 #pragma unroll
           for (int k = 0; k < R; ++k) {
-            const uint32_t c1S = bfi(M1, Sb[k], Sa[k]), c1E = bfi(M1, Eb[k], Ea[k]);
+            uint32_t c1S = bfi(M1, Sb[k], Sa[k]), c1E = bfi(M1, Eb[k], Ea[k]);
             uint32_t insX = c1E, dmax = dt1, c2S = c1S;
+            if (VIRT) {
+              if (k > 0) vcS = pk_subk(vcS, KEXT);
+              c1S = bfi(V1, vcS, c1S);
+              c1E = bfi(V1, pk_subk(vcS, KEXT), c1E);
+              insX = c1E;
+            }
             if (TWO) {
               c2S = bfi(M2, Sb[k], Sa[k]);
-              const uint32_t c2E = bfi(M2, Eb[k], Ea[k]);
+              uint32_t c2E = bfi(M2, Eb[k], Ea[k]);
+              if (VIRT) { c2S = bfi(V2, vcS, c2S); c2E = bfi(V2, pk_subk(vcS, KEXT), c2E); }
               insX = pk_max(c1E, c2E);                                // first maximum wins (:361-371)
               dmax = pk_max(dt1, dt2);                                // (:348-357)
             }
             const uint32_t ne = pk_bit(xlp ^ ylp[k], ONES);
-            uint32_t mat = pk_mad(ne, KSUB, dmax);
-            if (!match0) mat = pk_add(mat, KMATCH);
+            const uint32_t mat = pk_mad(ne, KSUB, dmax);
             const uint32_t mx = pk_max(insX, insY);
             const uint32_t Sn = pk_max(mat, mx);
             const uint32_t mbit = pk_bit(pk_sub(Sn, mx), ONES);
             const uint32_t xbit = pk_bit(pk_sub(mx, insY), ONES);
             mvw |= ((mbit << 1) | xbit) << (2 * k);
+            pin(mvw);
             if (TWO) {
               const uint32_t pm = pk_bit(pk_sub(dmax, dt1), ONES);   // second predecessor strictly better on the diagonal
               const uint32_t px = pk_bit(pk_sub(insX, c1E), ONES);   // ... for the x-insertion
               secw |= bfi(pk_sub(0u, mbit), pm, px) << k;
+              pin(secw);
             }
-            const uint32_t En = pk_mad(mbit, KDELTA, pk_sub(Sn, KEXT));
+            const uint32_t En = pk_mad(mbit, KDELTA, pk_subk(Sn, KEXT));
             dt1 = c1S; dt2 = c2S;
             Sb[k] = Sn; Eb[k] = En; insY = En;
           }
         };
-        if (two) cells(std::true_type{}); else cells(std::false_type{});
+        if (virt) cells(std::true_type{}, std::true_type{});
+        else if (two) cells(std::true_type{}, std::false_type{});
+        else cells(std::false_type{}, std::false_type{});
         last3 = sv3;
         BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
         const bool actA = xiA != 0u, actB = xiB != 0u;
@@ -933,14 +985,14 @@ __global__ void __launch_bounds__(64) k_poa(PackArgs a)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (__builtin_amdgcn_ballot_w64(W[h].valid) == 0) continue;
-    uint8_t *cols_st = ordb[h];                                       // the ordinal bytes are dead after the traceback
-    uint16_t *col_y = reinterpret_cast<uint16_t *>(cols_st + pk_align_up(3 * (W[h].n1 + W[h].Lu) + 8, 4));
+    // the columns go straight to the window's place in the output (3 (Lr + Lc + Lu) bytes of room, at most
+    // n1 + Lu columns); the column of every uncorrected letter lives where the ordinal bytes were
+    uint8_t *cols_st = a.b.cols + 3 * W[h].o0;
+    uint16_t *col_y = reinterpret_cast<uint16_t *>(ordb[h]);
     for (int d = 1; d < G; d <<= 1) badb[h] = badb[h] || __shfl_xor(badb[h] ? 1 : 0, d, G) != 0;
     const int ncol = columns_2<G>(W[h], g, xinfo[h], x2yb[h], us[h], chr, cols_st, col_y, badb[h]);
     __builtin_amdgcn_wave_barrier();
     if (W[h].valid) {
-      uint8_t *gc = a.b.cols + 3 * W[h].o0;
-      for (int i = g; i < 3 * ncol; i += G) gc[i] = cols_st[i];
       if (g == 0) {
         const uint32_t w = W[h].w;
         a.b.ncol[w] = ncol;
