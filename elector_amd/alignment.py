@@ -7,36 +7,61 @@ hot path (elector/__main__.py:140):
 Same signature, same return value, same `outDir/msa.fa` (or `msa_<soft>.fa`)
 bytes.  Where the reference spawns `masterSplitter`, 200 `poa` processes and 200
 `Donatello` processes per batch and moves every window through files
-(alignment.py:98-129), this keeps a batch in memory: the splitter and the merger
-are host functions of the library (include/elector_split.h), the triplet MSAs
-are computed on the GPU (include/elector_poa.h).  There is no CPU fallback.
+(alignment.py:98-129), a batch here never leaves memory, and the bulk of it never
+leaves the GPU:
 
-Batch protocol kept from the reference: 10,001 reads per batch
-(Master_Splitter.cpp:362,397-399: `i > max_nuc_amount`), reads with a reference
-shorter than 3 bases are skipped without counting (:414), windows of a read are
-merged in input order, the output file is opened in append mode like
-Donatello's (Donatello.cpp:48).
+    reader thread   three FASTA files -> batches of reads -> windows   (elector_split_reads, host threads)
+    main thread     windows -> HBM -> triplet MSAs (elector_poa_batch_device) -> one record per piece
+                    (k_merge) -> per-piece integer counters (k_stats) -> merged rows back for msa.fa
+
+Two engine contexts take the batches in turn, so the host work of one batch
+(parsing, splitting, writing msa.fa) overlaps the kernels of the other.  The
+per-piece counters the device computed on the way are kept for call site #2
+(elector_amd.computeStats.outputRecallPrecision), which then does not have to
+parse msa.fa again.  There is no CPU fallback.
+
+Batch protocol kept from the reference, because it decides bytes of msa.fa:
+10,001 reads per masterSplitter batch (Master_Splitter.cpp:362,397-399:
+`i > max_nuc_amount`), reads with a reference shorter than 3 bases are skipped
+without counting (:414), a read lands in slot file `k // 51` of its batch
+(:366-369,435) and Donatello concatenates neighbouring windows with the same
+header line inside one slot file (Donatello.cpp:61-84), the output file is opened
+in append mode like Donatello's (Donatello.cpp:48).  A processing batch here is a
+reference batch extended to the end of its last read (all pieces of a read are
+counted together), which changes nothing in the file: the slot of a record is
+computed from its position in the reference's own batches.
+
+Multi-GPU (one process per GPU, torch.distributed initialised by the caller or
+by torchrun): every rank takes a contiguous range of reads balanced by DP cells,
+writes its part of msa.fa, rank 0 concatenates the parts in rank order and
+receives every rank's counters in one gather (RCCL over xGMI when the backend is
+nccl); no collective touches the alignment data.
 """
 import os
+import queue
 import sys
+import threading
 
 import numpy as np
 
 from . import split
-from .poa import PoaEngine, read_params, default_params
+from ._capi import ElectorError, ES_NCOUNTERS
+from .poa import EnginePool, PoaEngine, read_params, default_params
 
 READS_PER_BATCH = 10001          # alignment.py:82 amount_read = 10000, splitter stops after i > amount
 READS_PER_SLOT = 10000 // 200 + 1   # Master_Splitter.cpp:366-369: slot = i / (max/nb_file + 1)
 
-_engine = None
+_pool = None
+# msa path -> what outputRecallPrecision needs instead of the text file (see computeStats.cached_pieces)
+MSA_CACHE = {}
 
 
-def _get_engine(matrix_path=None):
-    global _engine
-    if _engine is None:
+def _get_pool(matrix_path=None, n=2):
+    global _pool
+    if _pool is None:
         params = read_params(matrix_path) if matrix_path else default_params()
-        _engine = PoaEngine(int(os.environ.get("LOCAL_RANK", "0")), params)
-    return _engine
+        _pool = EnginePool(int(os.environ.get("LOCAL_RANK", "0")), n, params)
+    return _pool
 
 
 def _records(path):
@@ -70,71 +95,300 @@ def _donatello_header(h):
     return (h if len(h) < 11 else h[: len(h) - 11]) + b" "
 
 
-def align_batch(engine, reads, headers, size_threshold, threads):
-    """One batch: [(reference, corrected, uncorrected)] + header lines ->
-    (list of (header_out, ref_row, cor_row, unc_row) per output record, small, wrong)."""
+class _Batch:
+    """One processing batch: reads, their msa.fa header lines, and where its first read stands in the
+    reference's own batch protocol."""
+    __slots__ = ("reads", "headers", "out_hdr", "first_index", "win", "piece_first", "read_first", "rec_hdr",
+                 "small", "wrong", "last")
+
+
+def _triples(reference, uncorrected, corrected, start=0, stop=None):
+    """(header line of the reference record, reference, corrected, uncorrected) of the records
+    [start, stop) that masterSplitter does not skip, with their index among the kept records."""
+    it_ref, it_unc, it_cor = _records(reference), _records(uncorrected), _records(corrected)
+    k = 0
+    while True:
+        try:
+            href, ref = next(it_ref)
+            _, unc = next(it_unc)
+            _, cor = next(it_cor)
+        except StopIteration:
+            return
+        if len(ref) > 2:                              # Master_Splitter.cpp:414
+            if stop is not None and k >= stop:
+                return
+            if k >= start:
+                yield k, href, ref, cor, unc
+            k += 1
+
+
+def _batches(reference, uncorrected, corrected, start=0, stop=None):
+    """Processing batches: at least READS_PER_BATCH records, extended to the end of the last read
+    (= run of records with one msa.fa header line, computeStats.py:45-56)."""
+    cur, cur_hdr, first = [], [], None
+    last_key = None
+    for k, href, ref, cor, unc in _triples(reference, uncorrected, corrected, start, stop):
+        key = _donatello_header(_poa_header(href))
+        if len(cur) >= READS_PER_BATCH and key != last_key:
+            yield first, cur, cur_hdr
+            cur, cur_hdr, first = [], [], None
+        if first is None:
+            first = k
+        cur.append((ref, cor, unc))
+        cur_hdr.append(href)
+        last_key = key
+    if cur:
+        yield first, cur, cur_hdr
+
+
+def _prepare(first_index, reads, headers, size_threshold, threads):
+    """Host half of a batch: windows, record boundaries (Donatello's same-header rule), read boundaries."""
+    b = _Batch()
+    b.reads, b.headers, b.first_index = reads, headers, first_index
     win = split.split_reads(reads, size_threshold, headers, nthreads=max(1, int(threads)))
-    if win.n_windows == 0:
-        return [], win.small_reads, win.wrong_reads
-    rows, row_off, ncol, status, _ = engine.align_packed(win.bases, win.off)
-    # Donatello concatenates consecutive windows with the same header inside one
-    # slot file (Donatello.cpp:61-84); reads keep distinct headers in ELECTOR, so
-    # this is one record per read unless two neighbours share a header line.
+    b.win, b.small, b.wrong = win, win.small_reads, win.wrong_reads
     hdr = [_poa_header(headers[int(i)]) for i in win.read_index]
+    # Donatello concatenates consecutive windows with the same header inside one slot file
+    # (Donatello.cpp:61-84); the slot is the read's position in its reference batch // 51
+    # (Master_Splitter.cpp:366-369,435).  win.read_index = position in this processing batch.
     groups = [0]
     for r in range(1, win.n_reads):
-        same_slot = (r // READS_PER_SLOT) == ((r - 1) // READS_PER_SLOT)
+        ka, kb = first_index + int(win.read_index[r - 1]), first_index + int(win.read_index[r])
+        same_slot = (ka // READS_PER_BATCH == kb // READS_PER_BATCH and
+                     (ka % READS_PER_BATCH) // READS_PER_SLOT == (kb % READS_PER_BATCH) // READS_PER_SLOT)
         if not (same_slot and hdr[r] == hdr[r - 1]):
             groups.append(r)
     groups.append(win.n_reads)
-    first = np.array([win.read_first[g] for g in groups], dtype=np.int64)
-    mrows, moff, mcols = split.merge_windows(first, rows, row_off, ncol)
-    buf = mrows.tobytes()
-    out = []
-    for k in range(len(groups) - 1):
-        h = hdr[groups[k]]
-        a, nc = int(moff[k]), int(mcols[k])
-        out.append((_donatello_header(h), buf[a:a + nc], buf[a + nc:a + 2 * nc], buf[a + 2 * nc:a + 3 * nc]))
-    return out, win.small_reads, win.wrong_reads
+    b.piece_first = np.asarray([win.read_first[g] for g in groups], dtype=np.int64)
+    b.rec_hdr = [_donatello_header(hdr[g]) for g in groups[:-1]]
+    # reads for the statistics: runs of records with one header line (computeStats.py:45-56)
+    rf = [0]
+    for p in range(1, len(b.rec_hdr)):
+        if b.rec_hdr[p] != b.rec_hdr[p - 1]:
+            rf.append(p)
+    rf.append(len(b.rec_hdr))
+    b.read_first = np.asarray(rf, dtype=np.int64)
+    b.last = False
+    return b
+
+
+class _Buffers:
+    """Device buffers of one engine context, grown on demand."""
+
+    def __init__(self, dev):
+        self.dev, self.cap_bases, self.cap_win = dev, 0, 0
+        self.bases = self.cols = self.ncol = self.status = None
+
+    def fit(self, total, n):
+        import torch
+        if total > self.cap_bases:
+            self.cap_bases = int(total * 1.25) + 4096
+            self.bases = torch.empty(self.cap_bases, dtype=torch.uint8, device=self.dev)
+            self.cols = torch.empty(3 * self.cap_bases + 64, dtype=torch.uint8, device=self.dev)
+        if n > self.cap_win:
+            self.cap_win = int(n * 1.25) + 1024
+            self.ncol = torch.empty(self.cap_win, dtype=torch.int32, device=self.dev)
+            self.status = torch.empty(self.cap_win, dtype=torch.int32, device=self.dev)
+
+
+def _shard(reference, uncorrected, corrected, world):
+    """Contiguous ranges of kept records per rank, cut at read boundaries and balanced by the DP cells the
+    reads will cost (elector_amd.distributed.read_cell_estimate).  One pass over the three files."""
+    from .distributed import read_cell_estimate, shard_bounds
+    keys, lr, lc, lu = [], [], [], []
+    for k, href, ref, cor, unc in _triples(reference, uncorrected, corrected):
+        keys.append(_donatello_header(_poa_header(href)))
+        lr.append(len(ref)); lc.append(len(cor)); lu.append(len(unc))
+    n = len(keys)
+    starts = [0] + [i for i in range(1, n) if keys[i] != keys[i - 1]] + [n]
+    w = read_cell_estimate(np.asarray(lr), np.asarray(lc), np.asarray(lu)) if n else np.zeros(0)
+    wr = np.add.reduceat(w, starts[:-1]) if n else np.zeros(0)
+    b = shard_bounds(wr, world)
+    return [int(starts[int(x)]) for x in b]
 
 
 def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_READ_THRESHOLD, soft=None,
-           engine=None, matrix=None):
-    """elector/alignment.py:67-131"""
+           engine=None, matrix=None, parity="raise"):
+    """elector/alignment.py:67-131.
+
+    parity="raise" (default): a window the device cannot align (ELECTOR_W_*: an empty sequence, a
+    sequence beyond ELECTOR_MAX_SEQ) raises.  parity="skip": its record is left out of msa.fa, as a
+    `poa` process that dies on such a window leaves its slot's reads out in the reference
+    (alignment.py:62); the number of records left out is printed."""
+    import torch
     amount_read = 1000 * 10
     print("- Means that a large amount of reads has been handled: " + str(amount_read))
-    engine = engine or _get_engine(matrix)
+    if engine is not None:
+        pool = engine if isinstance(engine, EnginePool) else None
+        engines = pool.engines if pool else [engine]
+    else:
+        engines = _get_pool(matrix).engines
     if soft is not None:
         mergeOut = outDir + "/msa_" + soft + ".fa"
     else:
         mergeOut = outDir + "/msa.fa"
-    small_reads = 0
-    wrongly_cor_reads = 0
-    it_ref, it_unc, it_cor = _records(reference), _records(uncorrected), _records(corrected)
-    done = False
-    with open(mergeOut, "ab") as out:
-        while not done:
-            reads, headers = [], []
-            while len(reads) < READS_PER_BATCH:
-                try:
-                    href, ref = next(it_ref)
-                    _, unc = next(it_unc)
-                    _, cor = next(it_cor)
-                except StopIteration:
-                    done = True
-                    break
-                if len(ref) > 2:                      # Master_Splitter.cpp:414
-                    reads.append((ref, cor, unc))
-                    headers.append(href)
-            records, small, wrong = align_batch(engine, reads, headers, SIZE_CORRECTED_READ_THRESHOLD, threads)
-            small_reads += small
-            wrongly_cor_reads += wrong
-            for h, r0, r1, r2 in records:
-                out.write(h + b"\n" + r0 + b"\n" + h + b"\n" + r1 + b"\n" + h + b"\n" + r2 + b"\n")
-            with open(outDir + "/small_reads.txt", "w") as f:
-                f.write(str(small) + "\n")
-            with open(outDir + "/wrongly_cor_reads.txt", "w") as f:
-                f.write(str(wrong) + "\n")
-            sys.stdout.write('-' * 200)
-            sys.stdout.flush()
+    rank, world = 0, 1
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        dist = None
+    start, stop = 0, None
+    if world > 1:
+        bounds = _shard(reference, uncorrected, corrected, world)
+        start, stop = bounds[rank], bounds[rank + 1]
+    part_path = mergeOut if world == 1 else mergeOut + ".part%d" % rank
+
+    dev = torch.device("cuda", engines[0].device)
+    bufs = [_Buffers(dev) for _ in engines]
+    work = queue.Queue(maxsize=2)
+    failure = []
+
+    def reader():
+        try:
+            for first, reads, headers in _batches(reference, uncorrected, corrected, start, stop):
+                work.put(_prepare(first, reads, headers, SIZE_CORRECTED_READ_THRESHOLD, threads))
+        except BaseException as e:           # noqa: BLE001 -- handed to the main thread
+            failure.append(e)
+        work.put(None)
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+
+    small_reads = wrongly_cor_reads = 0
+    skipped = 0
+    existed = os.path.exists(part_path) and os.path.getsize(part_path) > 0
+    all_hdr, all_cols, all_counters, all_read_first = [], [], [], [0]
+    last_rows = last_mask = None
+    cache_ok = not existed
+    pending = []                                   # (engine index, batch, n_pieces, last_cap)
+
+    def finish(out):
+        nonlocal skipped, last_rows, last_mask, cache_ok
+        e, b, npieces, last_cap = pending.pop(0)
+        eng = engines[e]
+        counters, piece_cols, lrows, lmask = eng.msa_stats_collect(npieces, last_cap)
+        status = bufs[e].status[: b.win.n_windows].cpu().numpy()
+        drop = np.zeros(npieces, dtype=bool)
+        if status.any():
+            bad = np.nonzero(status)[0]
+            if parity != "skip":
+                raise ElectorError(-7, "window %d of the batch starting at read %d: status %d"
+                                   % (int(bad[0]), b.first_index, int(status[bad[0]])))
+            drop[np.unique(np.searchsorted(b.piece_first, bad, side="right") - 1)] = True
+            skipped += int(drop.sum())
+            cache_ok = False                       # the counters of a read's other pieces saw the dropped one
+        rows = eng.msa_rows_fetch(piece_cols).tobytes()
+        at = 0
+        for p in range(npieces):
+            nc = int(piece_cols[p])
+            if not drop[p]:
+                h = b.rec_hdr[p]
+                out.write(h + b"\n" + rows[at:at + nc] + b"\n" + h + b"\n" + rows[at + nc:at + 2 * nc] + b"\n" +
+                          h + b"\n" + rows[at + 2 * nc:at + 3 * nc] + b"\n")
+            at += 3 * nc
+        all_hdr.extend(b.rec_hdr)
+        all_cols.append(piece_cols)
+        all_counters.append(counters)
+        base = all_read_first[-1]
+        all_read_first.extend((base + b.read_first[1:]).tolist())
+        if lrows is not None and npieces:
+            nl = int(piece_cols[int(b.read_first[-2]):].sum())          # columns of the batch's last read
+            last_rows, last_mask = lrows[:3 * nl].copy(), lmask[:nl].copy()
+        with open(outDir + "/small_reads.txt", "w") as f:
+            f.write(str(b.small) + "\n")
+        with open(outDir + "/wrongly_cor_reads.txt", "w") as f:
+            f.write(str(b.wrong) + "\n")
+        sys.stdout.write('-' * 200)
+        sys.stdout.flush()
+
+    turn = 0
+    with open(part_path, "ab") as out:
+        while True:
+            b = work.get()
+            if failure:
+                raise failure[0]
+            if b is None:
+                break
+            small_reads += b.small
+            wrongly_cor_reads += b.wrong
+            win = b.win
+            if win.n_windows == 0:
+                continue
+            e = turn % len(engines)
+            turn += 1
+            # one job per context at a time: its buffers and its statistics slot are busy until collected
+            while any(p[0] == e for p in pending):
+                finish(out)
+            buf = bufs[e]
+            total = int(win.off[-1])
+            buf.fit(total, win.n_windows)
+            buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
+            engines[e].align_device(buf.bases, win.off, buf.cols, buf.ncol, buf.status)
+            npieces = engines[e].msa_stats_enqueue(win.n_windows, buf.cols, buf.ncol, buf.status, b.piece_first,
+                                                   b.read_first)
+            # rows + mask of the batch's last read, for the homopolymer ratio of the run's last read
+            p0 = int(b.read_first[-2])
+            w0 = int(b.piece_first[p0])
+            last_cap = int(win.off[-1] - win.off[3 * w0]) + 16
+            pending.append((e, b, npieces, last_cap))
+        while pending:
+            finish(out)
+    th.join()
+    if failure:
+        raise failure[0]
+    if skipped:
+        print("\n- " + str(skipped) + " records left out of " + mergeOut + " (windows the device refused, parity=\"skip\")")
+
+    counters = np.concatenate(all_counters) if all_counters else np.zeros((0, ES_NCOUNTERS), dtype=np.int64)
+    piece_cols = np.concatenate(all_cols) if all_cols else np.zeros(0, dtype=np.int64)
+    if world > 1:
+        # one gather of integer counters to rank 0; msa.fa = the ranks' parts in rank order
+        from .distributed import gather_rows
+        meta = np.concatenate([counters, piece_cols[:, None]], axis=1) if len(piece_cols) else \
+            np.zeros((0, ES_NCOUNTERS + 1), dtype=np.int64)
+        meta = gather_rows(meta)
+        tot = torch.tensor([small_reads, wrongly_cor_reads], dtype=torch.int64,
+                           device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tot)
+        small_reads, wrongly_cor_reads = int(tot[0]), int(tot[1])
+        hdr_all = [None] * world
+        dist.all_gather_object(hdr_all, (all_hdr, all_read_first, cache_ok,
+                                         None if last_rows is None else (last_rows.tobytes(), last_mask.tobytes())))
+        dist.barrier()
+        if rank == 0:
+            with open(mergeOut, "ab") as out:
+                for r in range(world):
+                    part = mergeOut + ".part%d" % r
+                    with open(part, "rb") as f:
+                        while True:
+                            chunk = f.read(1 << 24)
+                            if not chunk:
+                                break
+                            out.write(chunk)
+                    os.remove(part)
+            counters, piece_cols = meta[:, :ES_NCOUNTERS], meta[:, ES_NCOUNTERS]
+            all_hdr, all_read_first, cache_ok = [], [0], not existed
+            for hs, rf, ok, lr in hdr_all:
+                base = all_read_first[-1]
+                all_hdr.extend(hs)
+                all_read_first.extend(base + x for x in rf[1:])
+                cache_ok = cache_ok and ok
+                if lr is not None:
+                    last_rows = np.frombuffer(lr[0], dtype=np.uint8)
+                    last_mask = np.frombuffer(lr[1], dtype=np.uint8)
+        dist.barrier()
+        if rank != 0:
+            return small_reads, wrongly_cor_reads
+
+    MSA_CACHE.pop(os.path.abspath(mergeOut), None)
+    if cache_ok and len(piece_cols):
+        st = os.stat(mergeOut)
+        p0 = all_read_first[-2]
+        plain = all(b" " not in h[1:-1] and b"\t" not in h for h in all_hdr)
+        MSA_CACHE[os.path.abspath(mergeOut)] = dict(
+            sig=(st.st_size, st.st_mtime_ns), headers=all_hdr, plain_headers=plain, cols=piece_cols,
+            read_first=np.asarray(all_read_first, dtype=np.int64), counters=counters,
+            last_first_piece=p0, last_rows=last_rows, last_mask=last_mask)
     return small_reads, wrongly_cor_reads

@@ -262,9 +262,55 @@ def aggregate(pieces, counters, ratios, outPerReadMetrics):
             extendedBasesCount)
 
 
-def computeMetrics(fileName, outPerReadMetrics, correctedFileName, reportedThreshold, clipsNb, readsToSplit,
+def cached_pieces(fileName, clipsNb):
+    """What elector_amd.alignment.getPOA left behind for this msa file, if the file is still exactly what it
+    wrote: (Pieces with read_first / cols only, counters, Pieces of the last read with its rows, its mask).
+    The counters were computed on the device while the MSAs were there (elector_msa_stats_enqueue), so the
+    text file does not have to be parsed or uploaded again.  None when there is nothing usable: another
+    file, a file appended to, soft clips to apply (computeStats.py:718-741 needs them per header)."""
+    if clipsNb:
+        return None
+    from . import alignment
+    ent = alignment.MSA_CACHE.get(os.path.abspath(fileName))
+    if ent is None:
+        return None
+    try:
+        st = os.stat(fileName)
+    except OSError:
+        return None
+    if (st.st_size, st.st_mtime_ns) != ent["sig"]:
+        return None
+    # The reference finds a read's pieces through two different views of its header line (getSplit's key: the
+    # line without blanks, computeStats.py:52; the walk's key: its first blank-delimited token, :548,612).  They
+    # agree unless the header has a title; then the reference's own bookkeeping derails (KeyError, or pieces
+    # counted under another read) and only the parsing path reproduces that.
+    if not ent.get("plain_headers", False):
+        return None
+    p = Pieces()
+    p.headers = p.header_nos = None
+    p.cols = ent["cols"]
+    p.read_first = ent["read_first"]
+    p.rows = p.row_off = None
+    last = Pieces()
+    p0 = int(ent["last_first_piece"])
+    last.cols = np.ascontiguousarray(ent["cols"][p0:])
+    last.row_off = np.zeros(len(last.cols) + 1, dtype=np.int64)
+    np.cumsum(3 * last.cols, out=last.row_off[1:])
+    last.rows = np.ascontiguousarray(ent["last_rows"])
+    last.read_first = np.asarray([0, len(last.cols)], dtype=np.int64)
+    return p, ent["counters"], last, np.ascontiguousarray(ent["last_mask"])
+
+
+def computeMetrics(fileName, outPerReadMetrics, correctedFileName, reportedThreshold, clipsNb, readsToSplit=None,
                    engine=None):
     """Same return tuple as the reference's computeMetrics (computeStats.py:519-675)."""
+    hit = cached_pieces(fileName, clipsNb)
+    if hit is not None:
+        pieces, counters, last, last_mask = hit
+        ratios = homopolymer_ratios(last, last_mask, reportedThreshold)
+        return aggregate(pieces, counters, ratios, outPerReadMetrics)
+    if readsToSplit is None:
+        readsToSplit = getSplit(fileName)
     pieces = parse_msa(fileName, readsToSplit)
     counters, last_mask = stats_counters(pieces, clipsNb, engine)
     ratios = homopolymer_ratios(pieces, last_mask, reportedThreshold)
@@ -300,11 +346,10 @@ def outputRecallPrecision(correctedFileName, outDir, logFile, smallReadNumber, w
         outMetrics = open(outDir + "/per_read_metrics.txt", 'w')
         msa = outDir + "/msa.fa"
     outMetrics.write("score metric\n")
-    readsToSplit = getSplit(msa)
     (nbReads, throughput, uncorThroughput, precision, recall, corBasesRate, errorRate, uncorCorBasesRate,
      uncorErrorRate, missingSize, GCRateRef, GCRateCorr, indelsubsUncorr, indelsubsCorr, ratioHomopolymers,
      lenAllCorrectedReads, countReadSplit, countReadTrimmed, countReadExtended, extendedBasesCount) = \
-        computeMetrics(msa, outMetrics, correctedFileName, reportedHomopolThreshold, clipsNb, readsToSplit)
+        computeMetrics(msa, outMetrics, correctedFileName, reportedHomopolThreshold, clipsNb)
 
     outputReadSizeDistribution(correctedFileName, fileSizeName, outDir, countReadSplit + countReadTrimmed,
                                lenAllCorrectedReads)

@@ -150,12 +150,21 @@ class PoaEngine:
             clips.ctypes.data if clips is not None else None))
         return len(piece_first) - 1
 
-    def msa_stats_collect(self, n_pieces):
-        """Wait for the oldest queued job -> (counters int64[n_pieces, ES_NCOUNTERS], piece_cols)."""
+    def msa_stats_collect(self, n_pieces, last_cap=0):
+        """Wait for the oldest queued job -> (counters int64[n_pieces, ES_NCOUNTERS], piece_cols); with
+        last_cap > 0 (room in columns) also the rows and the statistics mask of the job's LAST read:
+        -> (counters, piece_cols, last_rows uint8[3 * last_cap], last_mask uint8[last_cap]), per piece
+        3 * cols row bytes resp. cols mask bytes back to back (the caller knows the read's pieces)."""
         counters = np.zeros((n_pieces, ES_NCOUNTERS), dtype=np.int64)
         piece_cols = np.zeros(n_pieces, dtype=np.int64)
-        self._check(self._lib.elector_msa_stats_collect(self._h, n_pieces, counters.ctypes.data,
-                                                        piece_cols.ctypes.data, None, None, 0))
+        last_rows = np.zeros(3 * last_cap + 1, dtype=np.uint8) if last_cap > 0 else None
+        last_mask = np.zeros(last_cap + 1, dtype=np.uint8) if last_cap > 0 else None
+        self._check(self._lib.elector_msa_stats_collect(
+            self._h, n_pieces, counters.ctypes.data, piece_cols.ctypes.data,
+            last_rows.ctypes.data if last_rows is not None else None,
+            last_mask.ctypes.data if last_mask is not None else None, last_cap))
+        if last_cap > 0:
+            return counters, piece_cols, last_rows, last_mask
         return counters, piece_cols
 
     def msa_rows_fetch(self, piece_cols):

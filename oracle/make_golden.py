@@ -263,6 +263,55 @@ def make_pipeline_golden():
                           "unc": open(d + "/unc.fa").read(), "msa": open(msa).read(), "small": small, "wrong": wrong})
             print("pipeline", name, len(reads), "reads ->", len(cases[-1]["msa"]), "bytes of msa.fa, small", small, "wrong", wrong)
     json.dump(cases, open(os.path.join(GOLD, "pipeline_golden.json"), "w"))
+    # a13 protocol edges (slot files of 51 reads, batches of 10,001): the inputs are regenerated from their
+    # seed by tests/msa_gen.py, the fixture keeps the digest of the msa.fa the real chain wrote, its size and
+    # the records around the edges
+    import hashlib
+    edges = []
+    for name, reads in (("slots", msa_gen.edge_reads_slots()), ("batchcut", msa_gen.edge_reads_batchcut())):
+        with tempfile.TemporaryDirectory() as d:
+            msa_txt, small, wrong = run_reference_chain(reads, d)
+        lines = msa_txt.split("\n")
+        keep = [i for i, ln in enumerate(lines) if ln.startswith((">same_", ">cut"))]
+        edges.append({"name": name, "n_reads": len(reads), "msa_sha256": hashlib.sha256(msa_txt.encode()).hexdigest(),
+                      "msa_bytes": len(msa_txt), "msa_records": sum(1 for ln in lines if ln.startswith(">")) // 3,
+                      "edge_lines": {str(i): lines[i] for i in keep}, "edge_rows_sha256":
+                      {str(i): hashlib.sha256(lines[i + 1].encode()).hexdigest() for i in keep},
+                      "small": small, "wrong": wrong})
+        print("pipeline edge", name, len(reads), "reads ->", len(msa_txt), "bytes,", edges[-1]["msa_records"], "records, small",
+              small, "wrong", wrong)
+    json.dump(edges, open(os.path.join(GOLD, "pipeline_edges.json"), "w"), indent=0)
+
+
+def run_reference_chain(reads, d):
+    """[(header, ref, cor, unc)] -> (msa.fa text, small, wrong) through the real masterSplitter / poa / Donatello
+    exactly as elector/alignment.py:98-122 drives them."""
+    for fn, k in (("ref.fa", 1), ("cor.fa", 2), ("unc.fa", 3)):
+        with open(os.path.join(d, fn), "wb") as f:
+            for r in reads:
+                f.write(r[0] + b"\n" + r[k] + b"\n")
+    rc = 1
+    small = wrong = 0
+    msa = os.path.join(d, "msa.fa")
+    while rc != 0:
+        rc = subprocess.run([os.path.join(REF, "masterSplitter"), d + "/ref.fa", d + "/unc.fa", d + "/cor.fa",
+                             d + "/out1", d + "/out2", d + "/out3", "7", "200", "10000", "0.1", d],
+                            stdout=subprocess.DEVNULL).returncode
+        small += int(open(d + "/small_reads.txt").readline())
+        wrong += int(open(d + "/wrongly_cor_reads.txt").readline())
+        for i in range(200):
+            if os.stat(d + "/out3%d" % i).st_size != 0:
+                subprocess.run([os.path.join(REF, "poa"), "-pir", d + "/smsa%d" % i, "-preserve_seqorder",
+                                "-corrected_reads_fasta", d + "/out3%d" % i, "-reference_reads_fasta",
+                                d + "/out1%d" % i, "-uncorrected_reads_fasta", d + "/out2%d" % i,
+                                "-preserve_seqorder", "-threads", "1", "-pathMatrix", MATRIX],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for i in range(200):
+            subprocess.run([os.path.join(REF, "Donatello"), d + "/smsa%d" % i, msa])
+        for f in os.listdir(d):
+            if f.startswith(("out1", "out2", "out3", "smsa")):
+                os.remove(os.path.join(d, f))
+    return open(msa).read(), small, wrong
 
 
 if __name__ == "__main__" and ("--pipeline-only" in sys.argv or len(sys.argv) == 1):

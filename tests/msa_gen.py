@@ -61,3 +61,50 @@ def msa_text(reads, size_threshold=0.1):
             out.append(hd)
             out.append(buf[a + r * nc: a + (r + 1) * nc])
     return (b"\n".join(out) + b"\n").decode(), win.small_reads, win.wrong_reads
+
+
+def edge_reads_slots(seed=51):
+    """a13 edge: more reads than one slot file holds (51), with runs of IDENTICAL header lines placed inside a
+    slot (Donatello concatenates their windows into one record, Donatello.cpp:61-84) and across the slot
+    boundaries 50|51 and 101|102 (different slot files: separate records)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(130):
+        ref = synth.random_seq(rng, int(rng.integers(260, 420)))
+        cor = synth.mutate(rng, ref, 0.02)
+        unc = synth.mutate(rng, ref, 0.12)
+        name = b">r%03d_0" % i
+        if i in (10, 11, 12):            # three in a row inside slot 0
+            name = b">same_a_0"
+        if i in (49, 50, 51, 52):        # 49, 50 in slot 0; 51, 52 in slot 1
+            name = b">same_b_0"
+        if i in (101, 102):              # 101 in slot 1; 102 in slot 2
+            name = b">same_c_0"
+        if i == 77:                      # a titled header: poa prints the title instead of "untitled"
+            name = b">r077_0 some title"
+        out.append((name, ref, cor, unc))
+    return out
+
+
+def edge_reads_batchcut(seed=52, n=10060):
+    """a13 edge: more reads than one masterSplitter batch (10,001: Master_Splitter.cpp:397-399).  Nearly all
+    reads are too short to anchor (they become `AAA` dummies, :417-423), which keeps the case cheap; the
+    reads around the cut are real, and identical header lines sit on both sides of it (records 9999|10000
+    share a slot, 10000|10001 are in different batches, 10001|10002 share slot 0 of the second batch)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        real = 9990 <= i <= 10012 or i % 997 == 0
+        if real:
+            ref = synth.random_seq(rng, int(rng.integers(180, 260)))
+            cor, unc = synth.mutate(rng, ref, 0.02), synth.mutate(rng, ref, 0.12)
+        else:
+            ref = synth.random_seq(rng, int(rng.integers(12, 20)))
+            cor, unc = ref, ref
+        name = b">q%05d_0" % i
+        if i in (9999, 10000, 10001, 10002):
+            name = b">cut_0"
+        if i == 5000:                     # a record masterSplitter skips without counting (:414)
+            ref, cor, unc = b"AC", b"AC", b"AC"
+        out.append((name, ref, cor, unc))
+    return out

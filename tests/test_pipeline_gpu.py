@@ -53,3 +53,101 @@ def test_getpoa_writes_reference_msa(tmp_path, engine, capsys, idx):
                                              "sizes.txt", {})
     out = capsys.readouterr().out
     assert tup == exp_tuple and out == "None\n" + exp_out and log.getvalue() == exp_log
+
+
+def _write_reads(tmp_path, reads):
+    for fn, k in (("ref.fa", 1), ("cor.fa", 2), ("unc.fa", 3)):
+        with open(tmp_path / fn, "wb") as f:
+            for r in reads:
+                f.write(r[0] + b"\n" + r[k] + b"\n")
+
+
+@pytest.mark.parametrize("name", ["slots", "batchcut"])
+def test_getpoa_protocol_edges(tmp_path, engine, capsys, name):
+    """a13 edges against the real chain (tests/golden/pipeline_edges.json, oracle/make_golden.py): more reads
+    than a slot file holds with identical header lines inside a slot and across slot boundaries
+    (Master_Splitter.cpp:366-369,435, Donatello.cpp:61-84), and more reads than one masterSplitter batch with
+    identical header lines across the cut (:397-399)."""
+    import hashlib
+    import msa_gen
+    gold = [g for g in json.load(open(os.path.join(ROOT, "tests", "golden", "pipeline_edges.json"))) if g["name"] == name][0]
+    reads = msa_gen.edge_reads_slots() if name == "slots" else msa_gen.edge_reads_batchcut()
+    assert len(reads) == gold["n_reads"]
+    _write_reads(tmp_path, reads)
+    small, wrong = alignment.getPOA(str(tmp_path / "cor.fa"), str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"),
+                                    8, str(tmp_path), 0.1, engine=engine)
+    capsys.readouterr()
+    assert (small, wrong) == (gold["small"], gold["wrong"])
+    txt = (tmp_path / "msa.fa").read_text()
+    lines = txt.split("\n")
+    assert sum(1 for ln in lines if ln.startswith(">")) // 3 == gold["msa_records"]
+    for i, ln in gold["edge_lines"].items():
+        assert lines[int(i)] == ln, (i, lines[int(i)], ln)
+        assert hashlib.sha256(lines[int(i) + 1].encode()).hexdigest() == gold["edge_rows_sha256"][i], i
+    assert len(txt) == gold["msa_bytes"]
+    assert hashlib.sha256(txt.encode()).hexdigest() == gold["msa_sha256"]
+
+
+def test_device_counters_reach_call_site_2(tmp_path, engine, capsys):
+    """getPOA leaves the per-piece counters the device computed on the way (merged MSAs never left HBM) for
+    outputRecallPrecision: the report from them must be the report from parsing msa.fa again, and the
+    statistics oracle's."""
+    import msa_gen
+    from elector_amd import synthetic
+    reads = msa_gen.make_reads(91, 40, 1200)              # plain, trimmed, split, extended, homopolymer-rich
+    _write_reads(tmp_path, reads)
+    small, wrong = alignment.getPOA(str(tmp_path / "cor.fa"), str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"),
+                                    8, str(tmp_path), 0.1, engine=engine)
+    capsys.readouterr()
+    msa = str(tmp_path / "msa.fa")
+    assert computeStats.cached_pieces(msa, {}) is not None
+    computeStats._engine = engine
+    log1 = io.StringIO()
+    tup1 = computeStats.outputRecallPrecision(str(tmp_path / "cor.fa"), str(tmp_path), log1, small, wrong, 5, 0.1, "sizes.txt", {})
+    out1 = capsys.readouterr().out
+    per1 = (tmp_path / "per_read_metrics.txt").read_text()
+    alignment.MSA_CACHE.clear()                            # second time: the text file is parsed
+    assert computeStats.cached_pieces(msa, {}) is None
+    log2 = io.StringIO()
+    tup2 = computeStats.outputRecallPrecision(str(tmp_path / "cor.fa"), str(tmp_path), log2, small, wrong, 5, 0.1, "sizes.txt", {})
+    out2 = capsys.readouterr().out
+    assert tup1 == tup2 and out1 == out2 and log1.getvalue() == log2.getvalue()
+    assert per1 == (tmp_path / "per_read_metrics.txt").read_text()
+    exp_tuple, exp_out, exp_log, _, _ = stats_oracle.output_recall_precision((tmp_path / "msa.fa").read_text(), small, wrong, 5, 0.1)
+    assert tup1 == exp_tuple and out1 == "None\n" + exp_out and log1.getvalue() == exp_log
+    # a file that changed since getPOA wrote it is never served from the cache
+    alignment.getPOA(str(tmp_path / "cor.fa"), str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"), 8, str(tmp_path), 0.1,
+                     engine=engine)                        # appends: msa.fa now holds every record twice
+    capsys.readouterr()
+    assert computeStats.cached_pieces(msa, {}) is None
+
+
+def test_getpoa_skip_mode(tmp_path, engine, capsys):
+    """A window the device refuses (here: an empty corrected end piece is impossible to build from files, so a
+    sequence beyond ELECTOR_MAX_SEQ in an un-anchored window): parity="raise" raises, parity="skip" leaves the
+    record out and keeps the rest."""
+    from elector_amd import _capi
+    import numpy as np
+    rng = np.random.default_rng(3)
+    import synth
+    good = synth.random_seq(rng, 600)
+    # no k-mer is unique in a long homopolymer run: the splitter finds no anchor and hands the whole read over
+    # as one window (Master_Splitter.cpp:256-261) -- which also makes it a "wrong" read (one window) replaced by
+    # a dummy; so build a read with exactly two anchors around a run longer than the device limit
+    run = b"A" * (_capi.ELECTOR_MAX_SEQ + 200)
+    left, right = synth.random_seq(rng, 300), synth.random_seq(rng, 300)
+    big = left + run + right
+    reads = [(b">ok1_0", good, synth.mutate(rng, good, 0.02), synth.mutate(rng, good, 0.1)),
+             (b">big_0", big, big, big),
+             (b">ok2_0", good, synth.mutate(rng, good, 0.02), synth.mutate(rng, good, 0.1))]
+    _write_reads(tmp_path, reads)
+    with pytest.raises(_capi.ElectorError):
+        alignment.getPOA(str(tmp_path / "cor.fa"), str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"), 4, str(tmp_path), 0.1,
+                         engine=engine)
+    capsys.readouterr()
+    os.remove(tmp_path / "msa.fa")
+    alignment.getPOA(str(tmp_path / "cor.fa"), str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"), 4, str(tmp_path), 0.1,
+                     engine=engine, parity="skip")
+    assert "1 records left out" in capsys.readouterr().out
+    hdrs = [ln for ln in (tmp_path / "msa.fa").read_text().split("\n") if ln.startswith(">")]
+    assert hdrs == [">ok1 "] * 3 + [">ok2 "] * 3
