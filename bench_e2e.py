@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench_e2e.py -- the two call sites end to end: three FASTA files -> getPOA -> outputRecallPrecision.
+
+    python bench.py --end-to-end [--profile P] [--reads R]        (or python bench_e2e.py ...)
+
+What elector/__main__.py:140-141 does for one corrector: the sorted reference / uncorrected / corrected
+FASTA files go through elector_amd.alignment.getPOA (reader thread: parse + split on the host cores;
+main thread: windows to HBM, triplet MSAs, merge and per-piece counters on the GPU, msa.fa written from
+the merged records) and elector_amd.computeStats.outputRecallPrecision (the 19-tuple, report, side
+files -- from the counters the device left behind, no second pass over msa.fa).
+
+Prints ONE JSON line: end-to-end Mbases/s (reference-read bases of all triples / wall), a stage table
+(seconds of host or wait time per stage, summed over batches; the reader thread's stages overlap the main
+thread's) and, timed on this host's cores over a bounded sample of the same files, the reference chain
+(oracle/_ref: masterSplitter -> poa per slot file under a Pool of all cores -> Donatello, exactly
+elector/alignment.py:98-122) followed by the statistics port (oracle/stats_oracle.py; the reference module
+itself is not on the GPU box).  This is a reported baseline, not the metric of BASELINE.json (bench.py's
+default mode measures that).  Test infrastructure: uses oracle/.
+"""
+import argparse
+import io
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def write_fasta(d, triples, headers):
+    paths = [os.path.join(d, n) for n in ("ref.fa", "cor.fa", "unc.fa")]
+    with open(paths[0], "wb") as fr, open(paths[1], "wb") as fc, open(paths[2], "wb") as fu:
+        for (r, c, u), h in zip(triples, headers):
+            fr.write(h + b"\n" + r + b"\n")
+            fc.write(h + b"\n" + c + b"\n")
+            fu.write(h + b"\n" + u + b"\n")
+    return paths
+
+
+def _poa_slot(args):
+    ref_dir, d, i, mat = args
+    if os.stat(d + "/out3%d" % i).st_size != 0:
+        subprocess.run([os.path.join(ref_dir, "poa"), "-pir", d + "/smsa%d" % i, "-preserve_seqorder",
+                        "-corrected_reads_fasta", d + "/out3%d" % i, "-reference_reads_fasta", d + "/out1%d" % i,
+                        "-uncorrected_reads_fasta", d + "/out2%d" % i, "-preserve_seqorder", "-threads", "1",
+                        "-pathMatrix", mat], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return i
+
+
+def reference_chain(ref_dir, paths, n_sample, cores):
+    """masterSplitter -> 200 x poa under Pool(cores) -> 200 x Donatello on the first n_sample records of the
+    files (elector/alignment.py:98-122), then the statistics port on the msa.fa it wrote."""
+    from multiprocessing import Pool
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib
+    import stats_oracle
+    out = {"cores": cores, "records": n_sample}
+    with tempfile.TemporaryDirectory() as d:
+        sub = []
+        bases = 0
+        for p in paths:
+            q = os.path.join(d, os.path.basename(p))
+            with open(p, "rb") as f, open(q, "wb") as g:
+                for k in range(2 * n_sample):
+                    ln = f.readline()
+                    if not ln:
+                        break
+                    g.write(ln)
+                    if p is paths[0] and (k & 1):
+                        bases += len(ln) - 1
+            sub.append(q)
+        mat = oracle_lib.write_matrix(os.path.join(d, "params.mat"))
+        t_split = t_poa = t_merge = 0.0
+        rc = 1
+        small = wrong = 0
+        while rc != 0:
+            t0 = time.perf_counter()
+            rc = subprocess.run([os.path.join(ref_dir, "masterSplitter"), sub[0], sub[2], sub[1], d + "/out1", d + "/out2",
+                                 d + "/out3", "7", "200", "10000", "0.1", d], stdout=subprocess.DEVNULL).returncode
+            t_split += time.perf_counter() - t0
+            small += int(open(d + "/small_reads.txt").readline())
+            wrong += int(open(d + "/wrongly_cor_reads.txt").readline())
+            t0 = time.perf_counter()
+            with Pool(processes=cores) as pool:
+                for _ in pool.imap_unordered(_poa_slot, [(ref_dir, d, i, mat) for i in range(200)]):
+                    pass
+            t_poa += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for i in range(200):
+                subprocess.run([os.path.join(ref_dir, "Donatello"), d + "/smsa%d" % i, d + "/msa.fa"])
+            t_merge += time.perf_counter() - t0
+            for f in os.listdir(d):
+                if f.startswith(("out1", "out2", "out3", "smsa")):
+                    os.remove(os.path.join(d, f))
+        t0 = time.perf_counter()
+        txt = open(d + "/msa.fa").read()
+        with redirect_stdout(io.StringIO()):
+            stats_oracle.output_recall_precision(txt, small, wrong, 5, 0.1)
+        t_stats = time.perf_counter() - t0
+    out.update({"ref_bases": bases, "seconds": {"masterSplitter": round(t_split, 3), "poa x200 (Pool)": round(t_poa, 3),
+                                                  "Donatello x200": round(t_merge, 3),
+                                                  "statistics (oracle/stats_oracle.py, the port)": round(t_stats, 3)},
+                "Mbases_per_s": round(bases / (t_split + t_poa + t_merge + t_stats) / 1e6, 4)})
+    return out
+
+
+def main(args=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--profile", default="ecoli30x_simlord_lordec")
+    ap.add_argument("--reads", type=int, default=20002, help="reads in the three files (two batches of ELECTOR's protocol)")
+    ap.add_argument("--reference-sample", type=int, default=1500, help="records the reference chain is timed on")
+    ap.add_argument("--no-reference", action="store_true")
+    ap.add_argument("--end-to-end", action="store_true")
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    a, _ = ap.parse_known_args()
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_e2e.py needs a GPU: the HIP path has no CPU fallback")
+    from elector_amd import alignment, computeStats, synthetic
+    triples, headers, read_of = synthetic.read_pieces(a.profile, a.reads, seed=2000)
+    bases = int(sum(len(t[0]) for t in triples))
+    work = tempfile.mkdtemp(prefix="elector_e2e_")
+    try:
+        paths = write_fasta(work, triples, headers)
+        del triples
+        # warm-up on a small prefix: context creation, workspace growth, first-launch costs
+        wdir = os.path.join(work, "warm")
+        os.mkdir(wdir)
+        small_paths = []
+        for p in paths:
+            q = os.path.join(wdir, os.path.basename(p))
+            with open(p, "rb") as f, open(q, "wb") as g:
+                for _ in range(2 * 600):
+                    g.write(f.readline())
+            small_paths.append(q)
+        with redirect_stdout(io.StringIO()):
+            alignment.getPOA(small_paths[1], small_paths[0], small_paths[2], a.threads, wdir, 0.1)
+        alignment.STAGE_SECONDS.clear()
+
+        outdir = os.path.join(work, "out")
+        os.mkdir(outdir)
+        buf = io.StringIO()
+        t0 = time.perf_counter()
+        with redirect_stdout(buf):
+            small, wrong = alignment.getPOA(paths[1], paths[0], paths[2], a.threads, outdir, 0.1)
+        t1 = time.perf_counter()
+        hit = computeStats.cached_pieces(outdir + "/msa.fa", {}) is not None
+        log = io.StringIO()
+        with redirect_stdout(buf):
+            tup = computeStats.outputRecallPrecision(paths[1], outdir, log, small, wrong, 5, 0.1, "sizes.txt", {})
+        t2 = time.perf_counter()
+        stages = {k: round(v, 3) for k, v in alignment.STAGE_SECONDS.items()}
+        # the same report from the text file (what call site #2 cost before the counters were handed over)
+        alignment.MSA_CACHE.clear()
+        with redirect_stdout(buf):
+            tup2 = computeStats.outputRecallPrecision(paths[1], outdir, io.StringIO(), small, wrong, 5, 0.1, "sizes.txt", {})
+        t3 = time.perf_counter()
+        assert tup == tup2, "device counters and parsed msa.fa disagree"
+        out = {
+            "metric": "end-to-end Mbases/s: three FASTA files -> getPOA -> outputRecallPrecision (19-tuple)",
+            "value": round(bases / (t2 - t0) / 1e6, 3), "unit": "Mbases/s", "n_gpus": 1,
+            "config": {"workload": a.profile, "reads": a.reads, "triples": len(headers), "ref_bases": bases,
+                       "host_threads": a.threads, "msa_fa_bytes": os.path.getsize(outdir + "/msa.fa")},
+            "seconds": {"getPOA (wall)": round(t1 - t0, 3), "outputRecallPrecision (wall, device counters)": round(t2 - t1, 3),
+                        "outputRecallPrecision from the text file instead": round(t3 - t2, 3)},
+            "getPOA_stage_seconds": stages,
+            "device_counters_used": hit,
+            "recall": tup[3], "precision": tup[2], "assessed_reads": tup[0],
+        }
+        ref_dir = os.path.join(ROOT, "oracle", "_ref")
+        if not a.no_reference and os.path.exists(os.path.join(ref_dir, "masterSplitter")):
+            out["reference_chain"] = reference_chain(ref_dir, paths, a.reference_sample, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

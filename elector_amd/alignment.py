@@ -52,6 +52,16 @@ READS_PER_BATCH = 10001          # alignment.py:82 amount_read = 10000, splitter
 READS_PER_SLOT = 10000 // 200 + 1   # Master_Splitter.cpp:366-369: slot = i / (max/nb_file + 1)
 
 _pool = None
+# seconds spent per stage since the last reset, summed over batches (bench_e2e.py reads them; the reader
+# thread's stages overlap the main thread's)
+STAGE_SECONDS = {}
+
+
+def _tick(stage, t0):
+    import time
+    STAGE_SECONDS[stage] = STAGE_SECONDS.get(stage, 0.0) + (time.perf_counter() - t0)
+
+
 # msa path -> what outputRecallPrecision needs instead of the text file (see computeStats.cached_pieces)
 MSA_CACHE = {}
 
@@ -143,9 +153,13 @@ def _batches(reference, uncorrected, corrected, start=0, stop=None):
 
 def _prepare(first_index, reads, headers, size_threshold, threads):
     """Host half of a batch: windows, record boundaries (Donatello's same-header rule), read boundaries."""
+    import time
     b = _Batch()
     b.reads, b.headers, b.first_index = reads, headers, first_index
+    t0 = time.perf_counter()
     win = split.split_reads(reads, size_threshold, headers, nthreads=max(1, int(threads)))
+    _tick("split (host threads)", t0)
+    t0 = time.perf_counter()
     b.win, b.small, b.wrong = win, win.small_reads, win.wrong_reads
     hdr = [_poa_header(headers[int(i)]) for i in win.read_index]
     # Donatello concatenates consecutive windows with the same header inside one slot file
@@ -169,6 +183,7 @@ def _prepare(first_index, reads, headers, size_threshold, threads):
     rf.append(len(b.rec_hdr))
     b.read_first = np.asarray(rf, dtype=np.int64)
     b.last = False
+    _tick("record / read boundaries (host)", t0)
     return b
 
 
@@ -246,9 +261,13 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     failure = []
 
     def reader():
+        import time
         try:
+            t0 = time.perf_counter()
             for first, reads, headers in _batches(reference, uncorrected, corrected, start, stop):
+                _tick("parse FASTA (reader thread)", t0)
                 work.put(_prepare(first, reads, headers, SIZE_CORRECTED_READ_THRESHOLD, threads))
+                t0 = time.perf_counter()
         except BaseException as e:           # noqa: BLE001 -- handed to the main thread
             failure.append(e)
         work.put(None)
@@ -266,10 +285,14 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
 
     def finish(out):
         nonlocal skipped, last_rows, last_mask, cache_ok
+        import time
         e, b, npieces, last_cap = pending.pop(0)
         eng = engines[e]
+        t0 = time.perf_counter()
         counters, piece_cols, lrows, lmask = eng.msa_stats_collect(npieces, last_cap)
         status = bufs[e].status[: b.win.n_windows].cpu().numpy()
+        _tick("wait for the GPU (kernels not hidden behind host work)", t0)
+        t0 = time.perf_counter()
         drop = np.zeros(npieces, dtype=bool)
         if status.any():
             bad = np.nonzero(status)[0]
@@ -280,6 +303,8 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             skipped += int(drop.sum())
             cache_ok = False                       # the counters of a read's other pieces saw the dropped one
         rows = eng.msa_rows_fetch(piece_cols).tobytes()
+        _tick("merged rows D2H", t0)
+        t0 = time.perf_counter()
         at = 0
         for p in range(npieces):
             nc = int(piece_cols[p])
@@ -288,6 +313,7 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
                 out.write(h + b"\n" + rows[at:at + nc] + b"\n" + h + b"\n" + rows[at + nc:at + 2 * nc] + b"\n" +
                           h + b"\n" + rows[at + 2 * nc:at + 3 * nc] + b"\n")
             at += 3 * nc
+        _tick("write msa.fa", t0)
         all_hdr.extend(b.rec_hdr)
         all_cols.append(piece_cols)
         all_counters.append(counters)
@@ -321,13 +347,18 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             # one job per context at a time: its buffers and its statistics slot are busy until collected
             while any(p[0] == e for p in pending):
                 finish(out)
+            import time
             buf = bufs[e]
             total = int(win.off[-1])
+            t0 = time.perf_counter()
             buf.fit(total, win.n_windows)
             buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
+            _tick("windows H2D", t0)
+            t0 = time.perf_counter()
             engines[e].align_device(buf.bases, win.off, buf.cols, buf.ncol, buf.status)
             npieces = engines[e].msa_stats_enqueue(win.n_windows, buf.cols, buf.ncol, buf.status, b.piece_first,
                                                    b.read_first)
+            _tick("classify + enqueue kernels (host)", t0)
             # rows + mask of the batch's last read, for the homopolymer ratio of the run's last read
             p0 = int(b.read_first[-2])
             w0 = int(b.piece_first[p0])

@@ -151,3 +151,51 @@ def test_getpoa_skip_mode(tmp_path, engine, capsys):
     assert "1 records left out" in capsys.readouterr().out
     hdrs = [ln for ln in (tmp_path / "msa.fa").read_text().split("\n") if ln.startswith(">")]
     assert hdrs == [">ok1 "] * 3 + [">ok2 "] * 3
+
+
+def _rank_getpoa(rank, world, port, d, result):
+    """one rank of the two-rank getPOA: gloo rendezvous, both ranks on this box's GPU"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from elector_amd import alignment as al, computeStats as cs
+    from contextlib import redirect_stdout
+    with redirect_stdout(io.StringIO()):
+        small, wrong = al.getPOA(d + "/cor.fa", d + "/ref.fa", d + "/unc.fa", 4, d + "/out2", 0.1)
+    if rank == 0:
+        log = io.StringIO()
+        buf = io.StringIO()
+        hit = cs.cached_pieces(d + "/out2/msa.fa", {}) is not None
+        with redirect_stdout(buf):
+            tup = cs.outputRecallPrecision(d + "/cor.fa", d + "/out2", log, small, wrong, 5, 0.1, "sizes.txt", {})
+        json.dump({"small": small, "wrong": wrong, "hit": hit, "tuple": json.loads(json.dumps(tup)), "log": log.getvalue()},
+                  open(result, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_getpoa_two_ranks_equal_one(tmp_path, engine, capsys):
+    """WORLD_SIZE = 2 (gloo here, RCCL on the 8-GPU node): each rank aligns its own contiguous range of reads,
+    rank 0 ends up with the same msa.fa bytes, counters and report as a single process."""
+    import msa_gen
+    import torch.multiprocessing as mp
+    reads = msa_gen.make_reads(93, 60, 900) + msa_gen.edge_reads_slots(55)
+    _write_reads(tmp_path, reads)
+    (tmp_path / "out1").mkdir()
+    (tmp_path / "out2").mkdir()
+    small, wrong = alignment.getPOA(str(tmp_path / "cor.fa"), str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"), 8,
+                                    str(tmp_path / "out1"), 0.1, engine=engine)
+    computeStats._engine = engine
+    log = io.StringIO()
+    tup = computeStats.outputRecallPrecision(str(tmp_path / "cor.fa"), str(tmp_path / "out1"), log, small, wrong, 5, 0.1,
+                                             "sizes.txt", {})
+    capsys.readouterr()
+    res = str(tmp_path / "two.json")
+    mp.spawn(_rank_getpoa, args=(2, 29533, str(tmp_path), res), nprocs=2, join=True)
+    two = json.load(open(res))
+    assert (tmp_path / "out2" / "msa.fa").read_bytes() == (tmp_path / "out1" / "msa.fa").read_bytes()
+    assert not [f for f in os.listdir(tmp_path / "out2") if ".part" in f]
+    assert (two["small"], two["wrong"]) == (small, wrong) and two["hit"]
+    assert two["tuple"] == json.loads(json.dumps(tup)) and two["log"] == log.getvalue()
