@@ -173,9 +173,12 @@ __host__ __device__ inline int poa_xi_cap(int Lr, int Lc)
   return hi + lo / 8 + 8;
 }
 
-__host__ __device__ inline int poa_union_a(int Lr, int Lc)
+// bytes per entry of the alignment #1 / fusion #1 index maps of a geometry class
+__host__ __device__ constexpr int poa_idx_bytes(int G) { return G == 8 ? 1 : 2; }
+
+__host__ __device__ inline int poa_union_a(int Lr, int Lc, int G)
 {
-  return ((Lr + Lc + 3) & ~3) + 2 * ((Lr + 1) & ~1) * 2 + 2 * ((Lc + 1) & ~1) * 2;
+  return ((Lr + Lc + 3) & ~3) + ((poa_idx_bytes(G) * (2 * ((Lr + 1) & ~1) + 2 * ((Lc + 1) & ~1)) + 3) & ~3);
 }
 
 __host__ __device__ inline int poa_union_b(int n1, int Lu, int G)
@@ -189,7 +192,7 @@ __host__ __device__ inline int poa_union_b(int n1, int Lu, int G)
 __host__ __device__ inline int poa_slot_need(int Lr, int Lc, int Lu, int G)
 {
   const int cap = poa_xi_cap(Lr, Lc);
-  const int ua = poa_union_a(Lr, Lc), ub = poa_union_b(cap, Lu, G);
+  const int ua = poa_union_a(Lr, Lc, G), ub = poa_union_b(cap, Lu, G);
   return 16 + ((Lu + 3) & ~3) + 4 * (cap + 1) + (ua > ub ? ua : ub);
 }
 

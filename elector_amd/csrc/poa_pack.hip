@@ -151,7 +151,8 @@ constexpr uint32_t kN_Far1 = 1u, kN_Far2 = 2u, kN_Has2 = 4u, kN_Virt1 = 8u, kN_V
 
 // LDS slot of one window (bytes); must mirror poa_slot_need() below.
 //   [hdr 16][unc symbols][node records u32 (xi_cap + 1)][union]
-//   union, alignment #1 .. fusion #1: [ref + cor symbols][x2y u16 Lr][node_ref u16 Lr][node_cor u16 Lc][y2x u16 Lc]
+//   union, alignment #1 .. fusion #1: [ref + cor symbols][x2y Lr][node_ref Lr][node_cor Lc][y2x Lc]  (one byte per
+//          entry in the 8-lane classes, whose windows have fewer than 255 nodes; two otherwise)
 //   union, alignment #2 .. output:    [x2y u16 n1][ordinal bytes k2 * G | col_y u16 Lu]
 struct WinP {
   bool valid;
@@ -177,8 +178,8 @@ struct WinP {
 
 // traceback of alignment #1 (align_lpo_po2.c:108-168), G cells per round (see poa_fused.hip).  Moves: bit 1 =
 // match (diagonal), bit 0 = x-insertion beats y-insertion; window half h of the word at [step][lane].
-template <int G, int R>
-__device__ __forceinline__ bool traceback_a(const WinP &W, const uint32_t *mv, int h, int q, int g, uint16_t *x2y)
+template <int G, int R, typename IT>
+__device__ __forceinline__ bool traceback_a(const WinP &W, const uint32_t *mv, int h, int q, int g, IT *x2y)
 {
   bool bad = false;
   int x = W.Lr - 1, y = W.Lc - 1, guard = W.Lr + W.Lc + 2;
@@ -194,7 +195,7 @@ __device__ __forceinline__ bool traceback_a(const WinP &W, const uint32_t *mv, i
       xo = m | xw; yo = m | (xw ^ 1);
     }
     const int run = pk_diag_run<G>(inb && xo && yo, q);
-    if (g < run) x2y[cx] = (uint16_t)cy;
+    if (g < run) x2y[cx] = (IT)cy;
     const bool stop = !inb;
     int nx = cx - xo, ny = cy - yo, fl = stop ? 1 : 0;
     const int src = min(run, G - 1);
@@ -211,16 +212,17 @@ __device__ __forceinline__ bool traceback_a(const WinP &W, const uint32_t *mv, i
 // fusion #1 (lpo.c:602-668 on two linear sequences) spread over the window's G lanes, as in k_fused_a; the
 // node records go to LDS.  Returns false when the graph does not qualify for this kernel (a predecessor more
 // than two nodes back, more nodes than the slot holds) -- the window is then handed back.
-template <int G>
-__device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, const uint8_t *ys, uint16_t *x2y,
+template <int G, typename IT>
+__device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, const uint8_t *ys, IT *x2y,
                                          uint32_t *xinfo, bool *bad_out)
 {
+  constexpr int kNoneI = (int)(IT)~(IT)0;                               // "not aligned" in the index type of this class
   const int Lr = W.Lr, Lc = W.Lc;
   const bool on = W.valid && W.triv == 0;
   bool bad = false;
-  uint16_t *node_ref = x2y + ((Lr + 1) & ~1);
-  uint16_t *node_cor = node_ref + ((Lr + 1) & ~1);
-  uint16_t *y2x = node_cor + ((Lc + 1) & ~1);
+  IT *node_ref = x2y + ((Lr + 1) & ~1);
+  IT *node_cor = node_ref + ((Lr + 1) & ~1);
+  IT *y2x = node_cor + ((Lc + 1) & ~1);
   const int cx = (Lr + G - 1) / G, cy = (Lc + G - 1) / G;               // letters per lane
   int cxmax = on ? cx : 0, cymax = on ? cy : 0;
   for (int d = G; d < 64; d <<= 1) {
@@ -229,7 +231,7 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
   }
   cxmax = __builtin_amdgcn_readfirstlane(cxmax);
   cymax = __builtin_amdgcn_readfirstlane(cymax);
-  if (on) for (int i = g; i < Lc; i += G) y2x[i] = (uint16_t)kNone16;
+  if (on) for (int i = g; i < Lc; i += G) y2x[i] = (IT)kNoneI;
   __builtin_amdgcn_wave_barrier();
   const int x0 = g * cx, x1 = on ? min(Lr, x0 + cx) : 0;
   const int y0 = g * cy, y1 = on ? min(Lc, y0 + cy) : 0;
@@ -238,8 +240,8 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
     const int ix = x0 + it;
     if (ix < x1) {
       const int ay = x2y[ix];
-      if (ay != (int)kNone16) {
-        if (ay < Lc) y2x[ay] = (uint16_t)ix; else bad = true;
+      if (ay != kNoneI) {
+        if (ay < Lc) y2x[ay] = (IT)ix; else bad = true;
         if (ay + 1 <= pmax) bad = true;                                // a path is monotone
         pmax = ay + 1;
         fcnt += (ay < Lc && xs[ix] == ys[ay]);
@@ -256,15 +258,15 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
   if (g == 0) P = 0;
   if (pmax > 0 && x1 > x0) {
     int first = 0;
-    for (int ix = x0; ix < x1; ++ix) { const int ay = x2y[ix]; if (ay != (int)kNone16) { first = ay + 1; break; } }
+    for (int ix = x0; ix < x1; ++ix) { const int ay = x2y[ix]; if (ay != kNoneI) { first = ay + 1; break; } }
     if (first <= P) bad = true;
   }
   for (int it = 0; it < cxmax; ++it) {
     const int ix = x0 + it;
     if (ix < x1) {
       const int ay = x2y[ix];
-      if (ay != (int)kNone16) { P = ay + 1; F += (ay < Lc && xs[ix] == ys[ay]); }
-      node_ref[ix] = (uint16_t)(ix + P - F);
+      if (ay != kNoneI) { P = ay + 1; F += (ay < Lc && xs[ix] == ys[ay]); }
+      node_ref[ix] = (IT)(ix + P - F);
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -274,7 +276,7 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
     const int y = y1 - 1 - it;
     if (y >= y0) {
       const int x = y2x[y];
-      if (x != (int)kNone16) { klow = x; fy += xs[x] == ys[y]; }
+      if (x != kNoneI) { klow = x; fy += xs[x] == ys[y]; }
     }
   }
   int sfy = fy, sfx = klow;
@@ -289,10 +291,10 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
     const int y = y1 - 1 - it;
     if (y >= y0) {
       const int x = y2x[y];
-      const bool al = x != (int)kNone16, fu = al && xs[x] == ys[y];
+      const bool al = x != kNoneI, fu = al && xs[x] == ys[y];
       if (fu) --fy_run;
       if (al) K = x;
-      node_cor[y] = fu ? node_ref[x] : (uint16_t)(y - fy_run + K);
+      node_cor[y] = fu ? node_ref[x] : (IT)(y - fy_run + K);
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -324,7 +326,7 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
       const int ix = x0 + it;
       if (ix < x1) {
         const int ay = x2y[ix], n = node_ref[ix];
-        const bool al = ay != (int)kNone16 && ay < Lc, fu = al && xs[ix] == ys[ay];
+        const bool al = ay != kNoneI && ay < Lc, fu = al && xs[ix] == ys[ay];
         int fl = kFlagHasRef | (ix == 0 ? kFlagInitial : 0) | (ix == Lr - 1 ? kFlagFinal : 0);
         int sa = ix > 0 ? (int)node_ref[ix - 1] : -1, sb = -1, ring = n;
         if (fu) {
@@ -339,7 +341,7 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
       const int y = y0 + it;
       if (y < y1) {
         const int x = y2x[y];
-        if (!(x != (int)kNone16 && xs[x] == ys[y])) {
+        if (!(x != kNoneI && xs[x] == ys[y])) {
           const int n = node_cor[y];
           emit(n, ys[y], kFlagHasCor | (y == 0 ? kFlagInitial : 0) | (y == Lc - 1 ? kFlagFinal : 0), n,
                y > 0 ? (int)node_cor[y - 1] : -1, -1);
@@ -618,9 +620,10 @@ __device__ __forceinline__ void load_win(WinP &W, const PackArgs &a, int64_t li,
   W.xi_cap = poa_xi_cap(W.Lr, W.Lc);
   W.off_xi = 16 + pk_align_up(W.Lu, 4);
   W.off_u = W.off_xi + 4 * (W.xi_cap + 1);
-  const int ua = poa_union_a(W.Lr, W.Lc), ub = poa_union_b(W.xi_cap, W.Lu, G);
+  const int ua = poa_union_a(W.Lr, W.Lc, G), ub = poa_union_b(W.xi_cap, W.Lu, G);
   const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(kp.open_x, kp.ext_x));
   W.valid = W.valid && W.off_u + max(ua, ub) <= a.slot_bytes && W.Lc <= RS && W.Lu <= RS &&
+            (poa_idx_bytes(G) > 1 || W.Lr + W.Lc <= 254) &&
             max(W.Lr, W.xi_cap) + G + 2 <= a.mv_tw && maxpen * (W.Lr + W.Lc + W.Lu + 8) < 16000;
 }
 
@@ -629,6 +632,8 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NP = 64 / G;                       // pairs of windows per wave
+  // index type of the alignment #1 / fusion #1 maps: one byte in the classes whose windows are short
+  using IT = typename std::conditional<poa_idx_bytes(G) == 1, uint8_t, uint16_t>::type;
   const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
   const KParams kp = a.b.kp;
   uint8_t *chr = lds;
@@ -776,22 +781,22 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
   bool bad[2] = {false, false}, keep[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    uint16_t *x2y = reinterpret_cast<uint16_t *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
-    if (needA[h]) for (int i = g; i < W[h].Lr; i += G) x2y[i] = (uint16_t)kNone16;
+    IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
+    if (needA[h]) for (int i = g; i < W[h].Lr; i += G) x2y[i] = (IT)~(IT)0;
   }
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    uint16_t *x2y = reinterpret_cast<uint16_t *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
-    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0) traceback_a<G, R>(W[h], mv, h, q, g, x2y);
+    IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
+    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0) traceback_a<G, R, IT>(W[h], mv, h, q, g, x2y);
   }
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(2);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    uint16_t *x2y = reinterpret_cast<uint16_t *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
+    IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
     keep[h] = true;
-    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0) keep[h] = fusion_1<G>(W[h], g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h]);
+    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0) keep[h] = fusion_1<G, IT>(W[h], g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h]);
     trivial_graph<G>(W[h], g, U[h], U[h] + W[h].Lr, xinfo[h]);
     if (W[h].valid && W[h].triv == 1) W[h].score1 = W[h].Lr * kp.match;
     if (W[h].valid && W[h].triv == 2) W[h].score1 = (W[h].Lr - 1) * kp.match + kp.mismatch;

@@ -43,32 +43,47 @@ inline kmer_t roll(kmer_t v, uint8_t c, int k)
 {
   v <<= 2;
   switch (c) { case 'C': v += 1; break; case 'G': v += 2; break; case 'T': v += 3; break; default: break; }
-  return v % (kmer_t)(1u << (2 * k));
+  return v & (kmer_t)((1u << (2 * k)) - 1u);
 }
 
 // ---- k-mer -> position table (open addressing, per thread, reused) ---------
+// One 12-byte entry per slot, occupied when its stamp is the table's current epoch: clearing the table is
+// bumping the epoch, and a lookup touches one cache line.
 struct KmerTable {
-  std::vector<kmer_t> keys;
-  std::vector<int32_t> vals;     // position, or -1 = repeated
-  std::vector<uint8_t> used;
-  uint32_t mask = 0;
+  struct Entry { kmer_t key; int32_t val; uint32_t stamp; };   // val: position, or -1 = repeated
+  std::vector<Entry> e;
+  uint32_t mask = 0, epoch = 0;
   void reset(size_t n)
   {
     size_t cap = 64;
     while (cap < 2 * n + 2) cap <<= 1;
-    if (keys.size() != cap) { keys.assign(cap, 0); vals.assign(cap, 0); used.assign(cap, 0); }
-    else std::fill(used.begin(), used.end(), 0);
-    mask = (uint32_t)cap - 1;
+    if (e.size() < cap) { e.assign(cap, Entry{0, 0, 0}); epoch = 0; }
+    mask = (uint32_t)e.size() - 1;
+    if (++epoch == 0) { for (auto &x : e) x.stamp = 0; epoch = 1; }
   }
-  inline uint32_t slot(kmer_t k) const
+  // the entry of k, or the free slot where it would go
+  inline Entry *slot(kmer_t k)
   {
     uint32_t h = (k * 2654435761u) & mask;
-    while (used[h] && keys[h] != k) h = (h + 1) & mask;
-    return h;
+    while (e[h].stamp == epoch && e[h].key != k) h = (h + 1) & mask;
+    return &e[h];
   }
-  inline bool has(kmer_t k) const { return used[slot(k)] != 0; }
-  inline int32_t get(kmer_t k) const { return vals[slot(k)]; }
-  inline void put(kmer_t k, int32_t v) { uint32_t h = slot(k); used[h] = 1; keys[h] = k; vals[h] = v; }
+  inline const Entry *find(kmer_t k) const
+  {
+    uint32_t h = (k * 2654435761u) & mask;
+    while (e[h].stamp == epoch && e[h].key != k) h = (h + 1) & mask;
+    return e[h].stamp == epoch ? &e[h] : nullptr;
+  }
+  inline bool has(kmer_t k) const { return find(k) != nullptr; }
+  inline int32_t get(kmer_t k) const { const Entry *x = find(k); return x ? x->val : 0; }
+  // first occurrence keeps its position, any later one marks the k-mer as repeated
+  inline void add(kmer_t k, int32_t pos)
+  {
+    Entry *x = slot(k);
+    if (x->stamp == epoch) x->val = -1;
+    else { x->key = k; x->val = pos; x->stamp = epoch; }
+  }
+  inline void put(kmer_t k, int32_t v) { Entry *x = slot(k); x->key = k; x->val = v; x->stamp = epoch; }
 };
 
 struct Anchor { int32_t r, a, b; };
@@ -122,40 +137,34 @@ void split(Seq ref, Seq S1, Seq S2, std::vector<Window> &out, bool first_call, i
   KmerTable &kref = sc.t_ref, &kin1 = sc.t_s1, &ksh = sc.t_sh;
   kref.reset(ref.n); kin1.reset(S1.n); ksh.reset(S2.n);
 
+  auto unique_in = [](const KmerTable &t, kmer_t q) { const KmerTable::Entry *x = t.find(q); return x && x->val != -1; };
   kmer_t seq = first_kmer(ref, k);
   kref.put(seq, 0);
   for (uint32_t j = 0; (uint64_t)j + k < ref.n; ++j) {
     seq = roll(seq, ref.p[j + k], k);
-    if (!kref.has(seq)) kref.put(seq, (int32_t)(j + 1));
-    else kref.put(seq, -1);                                 // repeated in the reference read
+    kref.add(seq, (int32_t)(j + 1));                        // a second occurrence: repeated in the reference read
   }
   seq = first_kmer(S1, k);
-  if (kref.has(seq) && kref.get(seq) != -1) kin1.put(seq, 0);
+  if (unique_in(kref, seq)) kin1.put(seq, 0);
   for (uint32_t j = 0; (uint64_t)j + k < S1.n; ++j) {
     seq = roll(seq, S1.p[j + k], k);
-    if (kref.has(seq) && kref.get(seq) != -1) {
-      if (!kin1.has(seq)) kin1.put(seq, (int32_t)(j + 1));
-      else kin1.put(seq, -1);
-    }
+    if (unique_in(kref, seq)) kin1.add(seq, (int32_t)(j + 1));
   }
   seq = first_kmer(S2, k);
-  if (kin1.has(seq) && kin1.get(seq) != -1) ksh.put(seq, 0);
+  if (unique_in(kin1, seq)) ksh.put(seq, 0);
   for (uint32_t j = 0; (uint64_t)j + k < S2.n; ++j) {
     seq = roll(seq, S2.p[j + k], k);
-    if (kin1.has(seq) && kin1.get(seq) != -1) {
-      if (!ksh.has(seq)) ksh.put(seq, (int32_t)(j + 1));
-      else ksh.put(seq, -1);
-    }
+    if (unique_in(kin1, seq)) ksh.add(seq, (int32_t)(j + 1));
   }
 
   // anchors: k-mers unique in all three reads, at least minSize apart on the reference (:234-251)
   sc.anchors.clear();
   seq = first_kmer(ref, k);
-  if (ksh.has(seq) && ksh.get(seq) != -1) sc.anchors.push_back({kref.get(seq), kin1.get(seq), ksh.get(seq)});
+  if (unique_in(ksh, seq)) sc.anchors.push_back({kref.get(seq), kin1.get(seq), ksh.get(seq)});
   uint32_t last_indexed = 0;
   for (uint32_t j = 0; (uint64_t)j + k < ref.n; ++j) {
     seq = roll(seq, ref.p[j + k], k);
-    if (ksh.has(seq) && ksh.get(seq) != -1 && (uint32_t)(j - last_indexed) > minSize) {
+    if ((uint32_t)(j - last_indexed) > minSize && unique_in(ksh, seq)) {
       sc.anchors.push_back({kref.get(seq), kin1.get(seq), ksh.get(seq)});
       last_indexed = j;
     }
