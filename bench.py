@@ -332,6 +332,7 @@ def main():
     t_dp2, k_dp2 = eng.timing_read(1)
     t_oth = eng.timing_read(2)[0]
     t_st = eng.timing_read(3)[0]
+    t_poa, k_poa = eng.timing_read(4)
     rdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     tot = torch.tensor([piece_bases, n, cells1 + cells2, cells1_computed + cells2], dtype=torch.int64, device=rdev)
@@ -345,9 +346,10 @@ def main():
         value = bases_all * args.steps / dt_max / 1e6
         # roofline of the dominant kernel: algorithmic bytes = 8-bit inputs + 8-bit MSA out + descriptors
         alg_bytes = int((lr + lc + lu).sum() + 3 * ncol.sum() + 28 * n)
-        # kernel classes: 0 = alignment #1 stage (k_fused_a<G>, or k_dp1 on the generic path),
-        # 1 = alignment #2 stage (k_fused_b<G> / k_dp2); measured un-overlapped (serial pass)
-        dom = ("k_fused_b", t_dp2, k_dp2) if t_dp2 >= t_dp1 else ("k_fused_a", t_dp1, k_dp1)
+        # kernel classes: 4 = k_poa (the whole window in one kernel: both alignments, tracebacks, fusions); 0 / 1 =
+        # alignment #1 / #2 stage of the two-kernel path (k_fused_a / k_fused_b; behind k_poa only the windows it
+        # handed back); measured un-overlapped (serial pass)
+        dom = max((("k_poa", t_poa, k_poa), ("k_fused_b", t_dp2, k_dp2), ("k_fused_a", t_dp1, k_dp1)), key=lambda x: x[1])
         launches = max(1, dom[2])
         avg_ms = dom[1] / launches
         bytes_per_launch = alg_bytes * serial_steps / launches
@@ -379,7 +381,8 @@ def main():
             "gcups_effective": round(cells_all * args.steps / dt_max / 1e9, 3),
             "gcups_computed": round(cells_comp_all * args.steps / dt_max / 1e9, 3),
             "alignment1_skipped_windows_frac": round(float(skipped.mean()), 4),
-            "kernel_ms_per_step": {"alignment1_stage": round(t_dp1 / serial_steps, 3),
+            "kernel_ms_per_step": {"k_poa": round(t_poa / serial_steps, 3),
+                                   "alignment1_stage": round(t_dp1 / serial_steps, 3),
                                    "alignment2_stage": round(t_dp2 / serial_steps, 3),
                                    "other": round(t_oth / serial_steps, 3),
                                    "merge_and_counters": round(t_st / serial_steps, 3),

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libelector_poa.so")
 
 ELECTOR_MAX_SYMBOL = 32
 ELECTOR_MAX_GAPTAB = 64
-ELECTOR_MAX_SEQ = 65520
+ELECTOR_MAX_SEQ = 524000
 ES_NCOUNTERS = 25          # include/elector_stats.h
 
 E_WINDOW = -7

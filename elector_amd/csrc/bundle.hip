@@ -43,7 +43,7 @@ struct BundleArgs {
   const uint8_t *sym;
   const int2 *xinfo;
   const uint16_t *ring1;
-  const uint16_t *map16;      // x_to_y of alignment #2 per node of the graph after fusion #1
+  const uint32_t *map16;      // x_to_y of alignment #2 per node of the graph after fusion #1 (kNone32 = unaligned)
   const int32_t *n1;
   const int32_t *ncol;        // from the POA kernels (cross-check)
   int32_t *status;
@@ -94,7 +94,8 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
   const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1), Lu = (int)(o3 - o2), n1 = a.n1[w];
   const int64_t nb = o0 + w;
   const int2 *xinfo = a.xinfo + nb;
-  const uint16_t *ring1 = a.ring1 + nb, *x2y = a.map16 + nb;
+  const uint16_t *ring1 = a.ring1 + nb;
+  const uint32_t *x2y = a.map16 + nb;
   const uint8_t *ys = a.sym + o2;
   uint4 *node = a.node + nb;
   uint16_t *nodeh = reinterpret_cast<uint16_t *>(node);
@@ -124,8 +125,8 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
     const int r0 = ring1[ix];
     if (r0 != blk_old) { blk_old = r0; blk_new = -1; }
     for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
-      const int ay = x2y[k];
-      if (ay != (int)kNone16) {
+      const int ay = (int)x2y[k];
+      if (ay != (int)kNone32) {
         while (iy < ay && iy < Lu) { add(n, ys[iy], false, false, iy); ++iy; }
         break;
       }
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
     const int xi = xinfo[ix + 1].y;
     const int letter = xi & 0xFF, fl = xi >> 8;
     int fused_pos = -1;
-    if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
+    if (x2y[ix] != kNone32 && iy < Lu) {
       if (letter == ys[iy]) fused_pos = iy;
       else {
         if (blk_new < 0) blk_new = n;
@@ -267,7 +268,7 @@ extern "C" int elector_poa_bundles(elector_ctx *c, int64_t n, float minimum_frac
   a.sym = c->d_sym.as<uint8_t>();
   a.xinfo = c->d_xinfo.as<int2>();
   a.ring1 = c->d_ring1.as<uint16_t>();
-  a.map16 = c->d_map16.as<uint16_t>();
+  a.map16 = c->d_map16.as<uint32_t>();
   a.n1 = c->d_n1.as<int32_t>();
   a.ncol = c->last_ncol;
   a.status = c->last_status;

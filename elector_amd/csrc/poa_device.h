@@ -14,7 +14,7 @@
 //                             .y = letter | flags<<8
 //       ring1[nb+j]   u16   ring id (column id) of node j, low 16 bits (only ever compared
 //                           between neighbouring nodes)
-//       map16[nb+j]   u16   x_to_y of the alignment being traced (0xFFFF = unaligned)
+//       map16[nb+j]   u32   x_to_y of the alignment being traced (0xFFFFFFFF = unaligned)
 //       carry[nb+jj]  i32   packed (score, tag) of the last row of a DP strip
 //   moves         u32     per window and alignment: [strip][t>>3][lane] dwords,
 //                         8 steps x 4 bits per dword (see mv_index)
@@ -33,6 +33,7 @@ namespace elector {
 constexpr int kStripRows = 63;
 constexpr int kNeg = -999999;           // min_score, align_lpo_po2.c:198
 constexpr uint32_t kNone16 = 0xFFFFu;
+constexpr uint32_t kNone32 = 0xFFFFFFFFu;   // "not aligned" in the 32-bit maps of the generic path
 constexpr int kTagBits = 6;             // packed cell = score << 6 | tag
 
 // node flags (xinfo.y >> 8)
@@ -74,7 +75,7 @@ struct BatchArgs {
   uint8_t *sym;
   int2 *xinfo;
   uint16_t *ring1;
-  uint16_t *map16;
+  uint32_t *map16;           // x_to_y of the alignment being traced, 32 bits per node (kNone32 = unaligned)
   int32_t *carry;
   uint32_t *moves;
   const int64_t *mv1;        // dword offset of alignment #1 moves per window

@@ -930,8 +930,8 @@ __device__ __forceinline__ void fused_b_body(const FusedArgs &a, uint8_t *lds, c
   }
   __builtin_amdgcn_wave_barrier();
   if (a.keep_map && valid) {
-    uint16_t *gm = a.b.map16 + o0 + w;
-    for (int i = g; i < n1; i += G) gm[i] = x2y[i];
+    uint32_t *gm = a.b.map16 + o0 + w;
+    for (int i = g; i < n1; i += G) gm[i] = x2y[i] == (uint16_t)kNone16 ? kNone32 : (uint32_t)x2y[i];
   }
   PHASE_STAMP(13);
   // ---- fusion #2 and the MSA columns (lpo.c:602-668 column layout rule, lpo_format.c:337-393), spread

@@ -418,6 +418,7 @@ extern "C" int elector_ctx_last_po_sizes(elector_ctx *c, int64_t n, int32_t *po_
 // kernels hand back) gets a fixed budget on top.
 static const int64_t kMovesBudgetDwords = (int64_t)3 << 28;   // 3 GiB
 static const int64_t kBumpBudgetDwords = (int64_t)1 << 30;    // 4 GiB
+static const int64_t kWindowMovesMaxDwords = (int64_t)8 << 30;   // moves of ONE window (4 bits per DP cell): 32 GiB
 static const int kLeftRoundsMax = 6;                          // passes over the handed-back windows (see run_device_batch)
 static const int64_t kDeepRingBytes = (int64_t)4 << 30;       // HBM shadow rings of the deep-graph alignment #2 (k_dp2 DEEP)
 
@@ -554,7 +555,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         if (lr < 0 || lc < 0 || lu < 0) { bad_offsets.store(1); continue; }
         if (lr == 0 || lc == 0 || lu == 0) st = ELECTOR_W_EMPTY;
         else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ ||
-                 (int64_t)pen_abs_max * (lr + lc + lu + 4) >= ((int64_t)1 << 24))
+                 (int64_t)pen_abs_max * (lr + lc + lu + 4) >= ((int64_t)1 << 24) ||
+                 (int64_t)n_strips((int)lc) * mv_tw((int)lr) * 64 + (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64 >
+                     kWindowMovesMaxDwords)
           st = ELECTOR_W_TOOLONG;
         h_status[w] = st;
         h_mv1[w] = h_mv2[w] = -1;
@@ -709,6 +712,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     run(true);
   }
   if (std::getenv("ELECTOR_DEBUG_BINS")) {
+    int64_t nbad = 0;
+    for (int64_t w = 0; w < n; ++w) nbad += h_status[w] != 0;
+    std::fprintf(stderr, "[elector] windows refused by the host checks: %lld\n", (long long)nbad);
     std::fprintf(stderr, "[elector] n=%lld generic=%lld classes:", (long long)n, (long long)n_generic);
     for (int b = 0; b < kBins; ++b)
       if (bin_cnt[(size_t)b])
@@ -851,7 +857,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const size_t nodes = (size_t)total + (size_t)n + 8;
   rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_perm.ensure((size_t)n * 4 + 64) | c->d_mv1.ensure((size_t)n * 8) |
        c->d_mv2.ensure((size_t)n * 8) | c->d_sym.ensure((size_t)total + 64) | c->d_xinfo.ensure(nodes * 8) |
-       c->d_ring1.ensure(nodes * 2) | c->d_map16.ensure(nodes * 2) | c->d_carry.ensure(nodes * 4) |
+       c->d_ring1.ensure(nodes * 2) | c->d_map16.ensure(nodes * 4) | c->d_carry.ensure(nodes * 4) |
        c->d_moves.ensure((size_t)(max_dwords + bump_dwords) * 4 + 1024) | c->d_n1.ensure((size_t)n * 4) |
        c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
        c->d_bx2.ensure((size_t)n * 4) |
@@ -934,7 +940,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   a.sym = c->d_sym.as<uint8_t>();
   a.xinfo = c->d_xinfo.as<int2>();
   a.ring1 = c->d_ring1.as<uint16_t>();
-  a.map16 = c->d_map16.as<uint16_t>();
+  a.map16 = c->d_map16.as<uint32_t>();
   a.carry = c->d_carry.as<int32_t>();
   a.moves = c->d_moves.as<uint32_t>();
   a.mv1 = c->d_mv1.as<int64_t>();
@@ -1057,7 +1063,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         pa.hand_count = d_hand_cnt;
         pa.debug = fdebug;
         pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b) + 16;
-        timed_begin(c, 1, sx);
+        timed_begin(c, 4, sx);
         if (launch_poa(pa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
         timed_end(c, sx);
       }

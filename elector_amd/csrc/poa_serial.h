@@ -26,6 +26,7 @@ struct NodeWriter {
   uint16_t *ring1;
   int maxd;
   bool bad;
+  bool far = false;          // a predecessor more than 65,535 nodes back: ELECTOR_W_TOOLONG
   // sa, sb: stored predecessors (new indices) in stored order, -1 = none
   __device__ __forceinline__ void emit(int n, int letter, int flags, int ring, int sa, int sb)
   {
@@ -34,6 +35,7 @@ struct NodeWriter {
     else if (flags & kFlagInitial) { d1 = 0; d2 = n - sa; if (sb >= 0) bad = true; }   // virtual -1 first (:69-79)
     else { d1 = n - sa; if (sb >= 0) d2 = n - sb; }
     maxd = max(maxd, max(d1, d2));
+    if (d1 > 0xFFFF || d2 > 0xFFFF) { far = true; d1 &= 0xFFFF; d2 &= 0xFFFF; }   // the node record holds 16-bit distances
     const int jj = n + 1;
     xinfo[jj] = make_int2(d1 | (d2 << 16), letter | (flags << 8));
     ring1[n] = (uint16_t)ring;
@@ -48,16 +50,16 @@ __device__ void fuse1_window(const BatchArgs &a, const uint32_t w, const MV getm
   const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1);
   const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
   const int64_t nb = o0 + w;
-  uint16_t *x2y = a.map16 + nb;
+  uint32_t *x2y = a.map16 + nb;
   NodeWriter nw{a.xinfo + nb, a.ring1 + nb, 1, false};
 
-  for (int j = 0; j < Lr; ++j) x2y[j] = (uint16_t)kNone16;
+  for (int j = 0; j < Lr; ++j) x2y[j] = kNone32;
   {
     int x = Lr - 1, y = Lc - 1, guard = Lr + Lc + 2;
     while (x >= 0 && y >= 0 && guard-- > 0) {
       const uint32_t nib = getmv(y + 1, x + 1);
       const int xo = nib & 3, yo = nib >> 2;
-      if (xo && yo) x2y[x] = (uint16_t)y;
+      if (xo && yo) x2y[x] = (uint32_t)y;
       if (!xo && !yo) { nw.bad = true; break; }
       if (xo) --x;
       if (yo) --y;
@@ -66,8 +68,8 @@ __device__ void fuse1_window(const BatchArgs &a, const uint32_t w, const MV getm
 
   int n = 0, iy = 0, lastx = -1, lasty = -1;
   for (int ix = 0; ix < Lr; ++ix) {
-    const int ay = x2y[ix];
-    const bool al = ay != (int)kNone16;
+    const int ay = (int)x2y[ix];
+    const bool al = ay != (int)kNone32;
     if (al)
       while (iy < ay) {                                         // pending y-only letters go first (lpo.c:432-438)
         const int fl = kFlagHasCor | (iy == 0 ? kFlagInitial : 0) | (iy == Lc - 1 ? kFlagFinal : 0);
@@ -101,6 +103,7 @@ __device__ void fuse1_window(const BatchArgs &a, const uint32_t w, const MV getm
   // ring depth class for k_dp2: D must cover max predecessor distance + 2
   const int need = nw.maxd + 2;
   a.cls[w] = (uint8_t)((need <= 32 ? 0 : 1) | (need > 4 ? 0x40 : 0) | (need > 8 ? 0x80 : 0));
+  if (nw.far) a.status[w] = 2;
   if (nw.bad) a.status[w] = 3;
 }
 
@@ -122,18 +125,18 @@ __device__ void fuse2_window(const BatchArgs &a, const uint32_t w, const MV getm
   const int64_t nb = o0 + w;
   const int2 *xinfo = a.xinfo + nb;
   const uint16_t *ring1 = a.ring1 + nb;
-  uint16_t *x2y = a.map16 + nb;
+  uint32_t *x2y = a.map16 + nb;
   uint8_t *cols = a.cols + 3 * o0;
   const uint8_t *chr = a.tab->chr;
   bool bad = false;
 
-  for (int j = 0; j < n1; ++j) x2y[j] = (uint16_t)kNone16;
+  for (int j = 0; j < n1; ++j) x2y[j] = kNone32;
   {
     int x = a.bx2[w], y = Lu - 1, guard = n1 + Lu + 2;
     while (x >= 0 && y >= 0 && guard-- > 0) {
       const uint32_t nib = getmv(y + 1, x + 1);
       const int xo = nib & 3, yo = nib >> 2;
-      if (xo && yo) x2y[x] = (uint16_t)y;
+      if (xo && yo) x2y[x] = (uint32_t)y;
       if (!xo && !yo) { bad = true; break; }
       if (xo) {
         const uint32_t pl = (uint32_t)xinfo[x + 1].x;
@@ -162,8 +165,8 @@ __device__ void fuse2_window(const BatchArgs &a, const uint32_t w, const MV getm
     if (r0 != blk_old) { blk_old = r0; blk_new = -1; }
     // if any later member of this ring block is aligned, its pending y letters come first (lpo.c:432-438)
     for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
-      const int ay = x2y[k];
-      if (ay != (int)kNone16) {
+      const int ay = (int)x2y[k];
+      if (ay != (int)kNone32) {
         while (iy < ay) { place(n, ys[iy], false, false, true); ++n; ++iy; }
         break;
       }
@@ -171,7 +174,7 @@ __device__ void fuse2_window(const BatchArgs &a, const uint32_t w, const MV getm
     const int xi = xinfo[ix + 1].y;
     const int letter = xi & 0xFF, fl = xi >> 8;
     bool fused = false;
-    if (x2y[ix] != (uint16_t)kNone16 && iy < Lu) {
+    if (x2y[ix] != kNone32 && iy < Lu) {
       if (letter == ys[iy]) fused = true;
       else {
         if (blk_new < 0) blk_new = n;                           // y becomes the ring's smallest index

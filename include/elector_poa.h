@@ -31,7 +31,9 @@ extern "C" {
 
 #define ELECTOR_MAX_SYMBOL 32     /* device alphabet limit (shipped matrix: 31) */
 #define ELECTOR_MAX_GAPTAB 64     /* max_gap_length + 2 must fit               */
-#define ELECTOR_MAX_SEQ    65520  /* longest sequence of a window (bases): 16-bit row indices */
+#define ELECTOR_MAX_SEQ    524000 /* longest sequence of a window (bases): with the largest penalty (500) scores of
+                                     three such sequences still fit the packed DP cell; windows whose moves scratch
+                                     would not fit device memory are refused per batch (ELECTOR_W_TOOLONG) */
 
 /* error codes (negative) */
 #define ELECTOR_OK            0
@@ -45,7 +47,9 @@ extern "C" {
 /* per-window status values */
 #define ELECTOR_W_OK          0
 #define ELECTOR_W_EMPTY       1     /* a sequence of the window is empty           */
-#define ELECTOR_W_TOOLONG     2     /* a sequence exceeds ELECTOR_MAX_SEQ, or scores could leave the packed-cell range */
+#define ELECTOR_W_TOOLONG     2     /* a sequence exceeds ELECTOR_MAX_SEQ, scores could leave the packed-cell range,
+                                       the moves of the window (4 bits per DP cell) exceed the scratch budget, or a
+                                       graph node has a predecessor more than 65,535 nodes back */
 #define ELECTOR_W_INTERNAL    3     /* graph invariant violated on device          */
 
 /* Scoring parameters = what the reference's read_score_matrix() leaves behind
@@ -115,7 +119,8 @@ int elector_ctx_sync(elector_ctx *ctx);
  * (k_fused_a<G,R> launches; k_dp1 on the generic path), 1 = alignment #2 stage
  * (k_fused_b<G,R,D>; k_dp2), 2 = everything else of the POA stage (symbolize, the
  * trivial-window pass and list sort, generic leftovers, tiled long windows),
- * 3 = merge + statistics kernels (include/elector_stats.h).
+ * 3 = merge + statistics kernels (include/elector_stats.h), 4 = k_poa (the whole window in one kernel,
+ * poa_pack.hip: when it is in use, kinds 0 and 1 only see the windows it handed back).
  * The geometry classes run on two concurrent launch chains: the sums overlap in wall time. */
 int elector_ctx_timing_enable(elector_ctx *ctx, int on);
 int elector_ctx_timing_read(elector_ctx *ctx, int kernel, double *ms, int64_t *launches);

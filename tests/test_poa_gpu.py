@@ -160,6 +160,20 @@ def test_windows_beyond_16k(engine):
     check(engine, synth.window_triples(31, 2, 16500, 17500, err_unc=0.12, err_cor=0.01))
 
 
+def test_windows_beyond_65k(engine):
+    """Nothing the reference aligns is refused for its length alone (align_lpo_po2.c:254-257 takes any): a
+    window with a sequence of more than 65,535 bases in each of the three places -- columns of alignment #1,
+    rows of alignment #1, rows of alignment #2 (32-bit maps on the generic / tiled path).  The other two
+    sequences are short so that the oracle finishes in seconds."""
+    rng = np.random.default_rng(71)
+    long_ref = synth.random_seq(rng, 66100)
+    short = long_ref[30000:31500]
+    trip = [(long_ref, synth.mutate(rng, short, 0.02), synth.mutate(rng, short, 0.12)),
+            (short, synth.mutate(rng, long_ref, 0.02), synth.mutate(rng, short, 0.12)),
+            (short, synth.mutate(rng, short, 0.02), synth.mutate(rng, long_ref, 0.12))]
+    check(engine, trip)
+
+
 def test_too_long_is_reported(engine):
     from elector_amd._capi import ELECTOR_MAX_SEQ
     big = b"A" * (ELECTOR_MAX_SEQ + 1)
