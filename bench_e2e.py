@@ -4,9 +4,9 @@
     python bench.py --end-to-end [--profile P] [--reads R]        (or python bench_e2e.py ...)
 
 What elector/__main__.py:140-141 does for one corrector: the sorted reference / uncorrected / corrected
-FASTA files go through elector_amd.alignment.getPOA (reader thread: parse + split on the host cores;
-main thread: windows to HBM, triplet MSAs, merge and per-piece counters on the GPU, msa.fa written from
-the merged records) and elector_amd.computeStats.outputRecallPrecision (the 19-tuple, report, side
+FASTA files go through elector_amd.alignment.getPOA (reader thread: parse, reads to HBM, split on the GPU;
+main thread: triplet MSAs, merge and per-piece counters on the GPU, msa.fa written from the merged
+records; ELECTOR_HOST_SPLIT=1 splits on the host cores instead) and elector_amd.computeStats.outputRecallPrecision (the 19-tuple, report, side
 files -- from the counters the device left behind, no second pass over msa.fa).
 
 Prints ONE JSON line: end-to-end Mbases/s (reference-read bases of all triples / wall), a stage table
@@ -113,7 +113,7 @@ def reference_chain(ref_dir, paths, n_sample, cores):
 def main(args=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--profile", default="ecoli30x_simlord_lordec")
-    ap.add_argument("--reads", type=int, default=20002, help="reads in the three files (two batches of ELECTOR's protocol)")
+    ap.add_argument("--reads", type=int, default=40004, help="reads in the three files (four batches of ELECTOR's protocol)")
     ap.add_argument("--reference-sample", type=int, default=1500, help="records the reference chain is timed on")
     ap.add_argument("--no-reference", action="store_true")
     ap.add_argument("--end-to-end", action="store_true")
@@ -129,14 +129,14 @@ def main(args=None):
     try:
         paths = write_fasta(work, triples, headers)
         del triples
-        # warm-up on a small prefix: context creation, workspace growth, first-launch costs
+        # warm-up on the first batch: context creation, workspace growth to the batch size, first-launch costs
         wdir = os.path.join(work, "warm")
         os.mkdir(wdir)
         small_paths = []
         for p in paths:
             q = os.path.join(wdir, os.path.basename(p))
             with open(p, "rb") as f, open(q, "wb") as g:
-                for _ in range(2 * 600):
+                for _ in range(2 * 10001):
                     g.write(f.readline())
             small_paths.append(q)
         with redirect_stdout(io.StringIO()):

@@ -16,6 +16,7 @@ ELECTOR_MAX_SEQ = 524000
 ES_NCOUNTERS = 25          # include/elector_stats.h
 
 E_WINDOW = -7
+E_LIMIT = -8
 W_OK, W_EMPTY, W_TOOLONG, W_INTERNAL = 0, 1, 2, 3
 
 
@@ -40,6 +41,7 @@ EXPORTS = [
     "elector_stats_batch", "elector_msa_stats_device", "elector_msa_stats_enqueue", "elector_msa_stats_collect",
     "elector_msa_rows_fetch", "elector_homopolymer_pairs",
     "elector_split_reads", "elector_windows_free", "elector_merge_windows", "elector_msa_free",
+    "elector_split_reads_device", "elector_windows_dev_free", "elector_ctx_copy", "elector_ctx_copy_to_host",
 ]
 
 _lib = None

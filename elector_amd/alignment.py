@@ -10,8 +10,10 @@ bytes.  Where the reference spawns `masterSplitter`, 200 `poa` processes and 200
 (alignment.py:98-129), a batch here never leaves memory, and the bulk of it never
 leaves the GPU:
 
-    reader thread   three FASTA files -> batches of reads -> windows   (elector_split_reads, host threads)
-    main thread     windows -> HBM -> triplet MSAs (elector_poa_batch_device) -> one record per piece
+    reader thread   three FASTA files -> batches of reads -> HBM -> windows (elector_split_reads_device: one
+                    workgroup per read on a splitter context of its own; ELECTOR_HOST_SPLIT=1 keeps the host
+                    threads of elector_split_reads instead)
+    main thread     windows (already in HBM) -> triplet MSAs (elector_poa_batch_device) -> one record per piece
                     (k_merge) -> per-piece integer counters (k_stats) -> merged rows back for msa.fa
 
 Two engine contexts take the batches in turn, so the host work of one batch
@@ -52,6 +54,7 @@ READS_PER_BATCH = 10001          # alignment.py:82 amount_read = 10000, splitter
 READS_PER_SLOT = 10000 // 200 + 1   # Master_Splitter.cpp:366-369: slot = i / (max/nb_file + 1)
 
 _pool = None
+_splitters = {}
 # seconds spent per stage since the last reset, summed over batches (bench_e2e.py reads them; the reader
 # thread's stages overlap the main thread's)
 STAGE_SECONDS = {}
@@ -72,6 +75,15 @@ def _get_pool(matrix_path=None, n=2):
         params = read_params(matrix_path) if matrix_path else default_params()
         _pool = EnginePool(int(os.environ.get("LOCAL_RANK", "0")), n, params)
     return _pool
+
+
+def _get_splitter(device):
+    """the reader thread's engine context: the device splitter works on its own streams and workspace"""
+    if os.environ.get("ELECTOR_HOST_SPLIT", "0") not in ("", "0"):
+        return None
+    if device not in _splitters:
+        _splitters[device] = PoaEngine(device)
+    return _splitters[device]
 
 
 def _records(path):
@@ -109,7 +121,7 @@ class _Batch:
     """One processing batch: reads, their msa.fa header lines, and where its first read stands in the
     reference's own batch protocol."""
     __slots__ = ("reads", "headers", "out_hdr", "first_index", "win", "piece_first", "read_first", "rec_hdr",
-                 "small", "wrong", "last")
+                 "small", "wrong", "last", "d_bases")
 
 
 def _triples(reference, uncorrected, corrected, start=0, stop=None):
@@ -151,14 +163,22 @@ def _batches(reference, uncorrected, corrected, start=0, stop=None):
         yield first, cur, cur_hdr
 
 
-def _prepare(first_index, reads, headers, size_threshold, threads):
-    """Host half of a batch: windows, record boundaries (Donatello's same-header rule), read boundaries."""
+def _prepare(first_index, reads, headers, size_threshold, threads, splitter=None):
+    """Reader half of a batch: windows, record boundaries (Donatello's same-header rule), read boundaries."""
     import time
     b = _Batch()
     b.reads, b.headers, b.first_index = reads, headers, first_index
     t0 = time.perf_counter()
-    win = split.split_reads(reads, size_threshold, headers, nthreads=max(1, int(threads)))
-    _tick("split (host threads)", t0)
+    b.d_bases = None
+    if splitter is not None:
+        win = split.split_reads_device(splitter, reads, size_threshold, headers, nthreads=max(1, int(threads)))
+        # out of the splitter's workspace, which its next call reuses
+        b.d_bases = win.d_bases.to_tensor() if isinstance(win.d_bases, split.DevBases) else win.d_bases
+        win.d_bases = None
+        _tick("split (device, incl. reads H2D)", t0)
+    else:
+        win = split.split_reads(reads, size_threshold, headers, nthreads=max(1, int(threads)))
+        _tick("split (host threads)", t0)
     t0 = time.perf_counter()
     b.win, b.small, b.wrong = win, win.small_reads, win.wrong_reads
     hdr = [_poa_header(headers[int(i)]) for i in win.read_index]
@@ -192,14 +212,16 @@ class _Buffers:
 
     def __init__(self, dev):
         self.dev, self.cap_bases, self.cap_win = dev, 0, 0
-        self.bases = self.cols = self.ncol = self.status = None
+        self.bases = self.cols = self.ncol = self.status = self.held = None
 
-    def fit(self, total, n):
+    def fit(self, total, n, own_bases=True):
         import torch
         if total > self.cap_bases:
             self.cap_bases = int(total * 1.25) + 4096
-            self.bases = torch.empty(self.cap_bases, dtype=torch.uint8, device=self.dev)
+            self.bases = torch.empty(self.cap_bases, dtype=torch.uint8, device=self.dev) if own_bases else None
             self.cols = torch.empty(3 * self.cap_bases + 64, dtype=torch.uint8, device=self.dev)
+        elif own_bases and self.bases is None:
+            self.bases = torch.empty(self.cap_bases, dtype=torch.uint8, device=self.dev)
         if n > self.cap_win:
             self.cap_win = int(n * 1.25) + 1024
             self.ncol = torch.empty(self.cap_win, dtype=torch.int32, device=self.dev)
@@ -256,6 +278,7 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     part_path = mergeOut if world == 1 else mergeOut + ".part%d" % rank
 
     dev = torch.device("cuda", engines[0].device)
+    splitter = _get_splitter(engines[0].device)
     bufs = [_Buffers(dev) for _ in engines]
     work = queue.Queue(maxsize=2)
     failure = []
@@ -266,7 +289,7 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             t0 = time.perf_counter()
             for first, reads, headers in _batches(reference, uncorrected, corrected, start, stop):
                 _tick("parse FASTA (reader thread)", t0)
-                work.put(_prepare(first, reads, headers, SIZE_CORRECTED_READ_THRESHOLD, threads))
+                work.put(_prepare(first, reads, headers, SIZE_CORRECTED_READ_THRESHOLD, threads, splitter))
                 t0 = time.perf_counter()
         except BaseException as e:           # noqa: BLE001 -- handed to the main thread
             failure.append(e)
@@ -351,11 +374,14 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             buf = bufs[e]
             total = int(win.off[-1])
             t0 = time.perf_counter()
-            buf.fit(total, win.n_windows)
-            buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
-            _tick("windows H2D", t0)
+            buf.fit(total, win.n_windows, own_bases=b.d_bases is None)
+            if b.d_bases is None:
+                buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
+                _tick("windows H2D", t0)
+            bases = buf.bases if b.d_bases is None else b.d_bases
+            buf.held = bases                       # the batch's own tensor lives until the context's next batch
             t0 = time.perf_counter()
-            engines[e].align_device(buf.bases, win.off, buf.cols, buf.ncol, buf.status)
+            engines[e].align_device(bases, win.off, buf.cols, buf.ncol, buf.status)
             npieces = engines[e].msa_stats_enqueue(win.n_windows, buf.cols, buf.ncol, buf.status, b.piece_first,
                                                    b.read_first)
             _tick("classify + enqueue kernels (host)", t0)

@@ -97,6 +97,7 @@ extern "C" const char *elector_strerror(int code)
     case ELECTOR_E_PARAMS: return "scoring parameters outside device limits";
     case ELECTOR_E_IO: return "matrix file unreadable or malformed";
     case ELECTOR_E_WINDOW: return "one or more windows failed (see status[])";
+    case ELECTOR_E_LIMIT: return "input beyond an on-chip limit of the device entry (use the host entry)";
     default: return "unknown error";
   }
 }
@@ -322,7 +323,9 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit,
-                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy};
+                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy,
+                    &c->d_sp_reads, &c->d_sp_off, &c->d_sp_hdr, &c->d_sp_keys, &c->d_sp_vals, &c->d_sp_ca, &c->d_sp_cb, &c->d_sp_wl,
+                    &c->d_sp_win, &c->d_sp_first, &c->d_sp_cnt, &c->d_sp_wfirst, &c->d_sp_wlen, &c->d_sp_woff, &c->d_sp_scan, &c->d_sp_bases, &c->d_sp_anc};
   for (DevBuf *b : bufs) b->release();
   for (auto &s : c->st_slot) s.release();
   for (int k = 0; k < 2; ++k) {

@@ -1,0 +1,684 @@
+// elector_amd/csrc/split_dev.hip -- the window splitter on the device.
+//
+// What bin/masterSplitter does per read (src/split/Master_Splitter.cpp:175-332: split, best_split; :396-446 the
+// read loop), restated for one workgroup per read:
+//   * 2-bit k-mer codes of every position, with the reference's two letter maps (str2num for the first k
+//     letters, :26-38; the rolling update for the rest, :41-49);
+//   * three hash tables in HBM scratch (k-mers unique in the reference read; of those, unique in the
+//     uncorrected read; of those, unique in the corrected read), filled by all threads with atomics -- "unique"
+//     does not depend on insertion order;
+//   * anchors: the greedy "more than minSize after the last one" pass over the reference positions, by one
+//     wavefront on ballots of 64 positions; the longest chain with steps < 1000 in all three reads (:79-126) as
+//     a back-to-front DP in LDS, one wavefront, the inner maximum over the <= 64 reachable successors in
+//     parallel; windows from the chain by one lane, with the reference's re-split of a missing start / end of
+//     the corrected read (:268-277,295-301) as a second, workgroup-wide pass;
+//   * best_split's loop over k = 15, 13, 11, 9 while the largest fragment shrinks (:310-332).
+// A read that does not fit the on-chip arrays (more than kMaxAnchors anchors, window list overflow) is
+// flagged and split by the host code (splitter.cpp) instead: same result, never silently different.
+// Byte / integer work, latency-bound; no MFMA.  The unsigned-conversion quirks of the reference that decide
+// which windows come out are kept (marked "ref:").
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "elector_poa.h"
+#include "elector_split.h"
+#include "ctx.h"
+
+namespace elector {
+
+constexpr int kSplitThreads = 256;
+constexpr int kMaxAnchors = 3000;          // LDS: 5 ints per anchor
+constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+constexpr int kUnset = -2;
+
+struct DSeq { int64_t base; uint32_t n; };   // base: byte offset into the reads buffer
+
+struct SplitScratch {            // per workgroup, in HBM
+  uint32_t *keys;                // [3][tab_cap]
+  int32_t *vals;                 // [3][tab_cap]
+  int32_t *ca, *cb;              // [maxlen + 2] candidate partner positions per reference position (-1: none)
+  int32_t *wl;                   // [3][maxwin][8] window lists: best, aux, tmp
+};
+
+struct SplitArgs {
+  int64_t n_reads;
+  const uint8_t *reads;
+  const int64_t *read_off;
+  const int32_t *hdr_len;
+  double thr;
+  uint32_t *keys; int32_t *vals; int32_t *ca; int32_t *cb; int32_t *wl;
+  int64_t tab_cap, maxlen, maxwin;
+  int32_t *out_win;              // [sum of caps][8]
+  const int64_t *out_first;      // per read: first window slot
+  int32_t *out_cnt, *out_kind;   // kind: 0 windows, 1 small, 2 wrong, -1 skipped, -2 host fallback
+  int32_t *anc; int64_t maxanc;  // BIG variant: anchors / chain arrays in HBM, [block][2 levels][5][maxanc]
+};
+
+// window record (8 ints): ref off, ref len, S1 off, S1 len, S2 off, S2 len, S2 is the 'N' filler, unused;
+// offsets relative to the start of the read's own sequence
+__device__ __forceinline__ int ldg(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ldgu(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stg(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ uint32_t map1(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u; }   // ref: str2num
+__device__ __forceinline__ uint32_t map2(uint8_t c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // ref: rolling update
+
+struct Tab {
+  uint32_t *keys; int32_t *vals; uint32_t mask;
+  __device__ __forceinline__ void add(uint32_t key, int pos) const
+  {
+    uint32_t h = (key * 2654435761u) & mask;
+    for (;;) {
+      const uint32_t prev = atomicCAS(keys + h, kEmptyKey, key);
+      if (prev == kEmptyKey || prev == key) break;
+      h = (h + 1) & mask;
+    }
+    const int old = atomicCAS(vals + h, kUnset, pos);
+    if (old != kUnset) stg(vals + h, -1);                    // a second occurrence: repeated
+  }
+  // position of the k-mer when it occurs exactly once, else -1
+  __device__ __forceinline__ int unique_pos(uint32_t key) const
+  {
+    uint32_t h = (key * 2654435761u) & mask;
+    for (;;) {
+      const uint32_t k = ldgu(keys + h);
+      if (k == kEmptyKey) return -1;
+      if (k == key) return ldg(vals + h);
+      h = (h + 1) & mask;
+    }
+  }
+};
+
+// anchors and chain of one split() level: five int arrays of `cap` entries -- in LDS for the usual reads, in the
+// workgroup's HBM scratch for reads with more than kMaxAnchors possible anchors (written and read by this
+// workgroup only) -- and four scalars in LDS
+struct LvlState { int n, start, nchain, fail; };
+struct Lvl {
+  int32_t *ar, *aa, *ab, *cl, *cn;
+  int cap;
+  LvlState *s;
+};
+
+struct WG {
+  const uint8_t *reads;
+  Tab tab[3];
+  int32_t *ca, *cb;
+  int32_t *wl;                     // [3][maxwin][8]
+  int64_t tab_cap, maxwin;
+};
+
+// k-mer code at position p of s (p + k <= n, or p == 0 for a sequence shorter than k): the first k letters of the
+// sequence go through map1, the others through map2
+__device__ __forceinline__ uint32_t code_at(const uint8_t *s, uint32_t n, uint32_t p, int k)
+{
+  uint32_t r = 0;
+  const uint32_t m = min(n - p, (uint32_t)k);
+  for (uint32_t i = 0; i < m; ++i) {
+    const uint32_t q = p + i;
+    r = (r << 2) | (q < (uint32_t)k ? map1(s[q]) : map2(s[q]));
+  }
+  return r & ((1u << (2 * k)) - 1u);
+}
+
+// number of k-mer positions the reference visits: the first k-mer always, then one per j with j + k < n
+__device__ __forceinline__ uint32_t n_kmers(uint32_t n, int k) { return n > (uint32_t)k ? n - (uint32_t)k + 1u : 1u; }
+
+__device__ void reset_tab(const Tab &t, int64_t cap)
+{
+  for (int64_t i = threadIdx.x; i < cap; i += kSplitThreads) { t.keys[i] = kEmptyKey; t.vals[i] = kUnset; }
+}
+
+// tables, anchors and the best chain of one split() call (ref: split :175-255, best_chain :79-126).
+// Workgroup-wide.  On return L.s->n anchors, L.s->nchain chain entries (indices of the chain in L.cl[0 .. nchain), reused).
+__device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize)
+{
+  const uint8_t *pr = g.reads + ref.base, *p1 = g.reads + S1.base, *p2 = g.reads + S2.base;
+  const int tid = threadIdx.x;
+  // table sizes: power of two >= 2 n + 2 (splitter.cpp), within the scratch
+  auto cap_for = [&](uint32_t n) { int64_t c = 64; while (c < 2 * (int64_t)n + 2) c <<= 1; return c; };
+  Tab tr = g.tab[0], t1 = g.tab[1], t2 = g.tab[2];
+  const int64_t cr = cap_for(ref.n), c1 = cap_for(S1.n), c2 = cap_for(S2.n);
+  tr.mask = (uint32_t)cr - 1; t1.mask = (uint32_t)c1 - 1; t2.mask = (uint32_t)c2 - 1;
+  reset_tab(tr, cr); reset_tab(t1, c1); reset_tab(t2, c2);
+  if (tid == 0) { L.s->n = 0; L.s->nchain = 0; L.s->start = -1; }
+  __threadfence();
+  __syncthreads();
+  // contiguous chunk of positions per thread, rolling code inside the chunk
+  auto for_kmers = [&](const uint8_t *s, uint32_t n, auto &&fn) {
+    const uint32_t np = n_kmers(n, k);
+    const uint32_t chunk = (np + kSplitThreads - 1) / kSplitThreads;
+    const uint32_t p0 = (uint32_t)tid * chunk, pe = min(np, p0 + chunk);
+    if (p0 >= pe) return;
+    uint32_t code = code_at(s, n, p0, k);
+    const uint32_t msk = (1u << (2 * k)) - 1u;
+    for (uint32_t p = p0; p < pe; ++p) {
+      fn(p, code);
+      if (p + 1 < pe) {
+        const uint32_t q = p + k;                           // the letter that enters
+        code = ((code << 2) | (q < (uint32_t)k ? map1(s[q]) : map2(s[q]))) & msk;
+      }
+    }
+  };
+  for_kmers(pr, ref.n, [&](uint32_t p, uint32_t code) { tr.add(code, (int)p); });
+  __threadfence();
+  __syncthreads();
+  for_kmers(p1, S1.n, [&](uint32_t p, uint32_t code) { if (tr.unique_pos(code) >= 0) t1.add(code, (int)p); });
+  __threadfence();
+  __syncthreads();
+  for_kmers(p2, S2.n, [&](uint32_t p, uint32_t code) { if (t1.unique_pos(code) >= 0) t2.add(code, (int)p); });
+  __threadfence();
+  __syncthreads();
+  // candidates per reference position: partner positions when the k-mer is unique in all three reads
+  for_kmers(pr, ref.n, [&](uint32_t p, uint32_t code) {
+    const int b = t2.unique_pos(code);
+    int a = -1;
+    if (b >= 0) a = t1.unique_pos(code);
+    stg(g.ca + p, b >= 0 ? a : -1);
+    stg(g.cb + p, b);
+  });
+  __threadfence();
+  __syncthreads();
+  // anchors (:234-251), wavefront 0: position 0 without a distance test, then greedily every candidate more than
+  // minSize loop steps after the last one taken (loop index j = position - 1, last_indexed starts at 0)
+  const uint32_t np = n_kmers(ref.n, k);
+  if (tid < 64) {
+    int n = 0;
+    if (tid == 0) {
+      const int a0 = ldg(g.ca), b0 = ldg(g.cb);
+      if (b0 >= 0) { L.ar[0] = 0; L.aa[0] = a0; L.ab[0] = b0; n = 1; }
+    }
+    n = __shfl(n, 0);
+    uint32_t last = 0;
+    bool fail = false;
+    for (uint32_t base = 1; base < np; base += 64) {
+      const uint32_t p = base + tid;
+      const int a = p < np ? ldg(g.ca + p) : -1;
+      const int b = a >= 0 ? ldg(g.cb + p) : -1;
+      unsigned long long m = __builtin_amdgcn_ballot_w64(a >= 0);
+      while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t j = base + l - 1;                    // loop index of this position
+        if ((uint32_t)(j - last) > minSize) {
+          const int sa = __shfl(a, l), sb = __shfl(b, l);
+          if (n < L.cap) { if (tid == 0) { L.ar[n] = (int)(j + 1); L.aa[n] = sa; L.ab[n] = sb; } }
+          else fail = true;
+          ++n;
+          last = j;
+        }
+      }
+    }
+    if (tid == 0) { L.s->n = fail ? 0 : n; if (fail) L.s->fail = 1; }
+  }
+  __syncthreads();
+  // longest chain, back to front (:79-126): wavefront 0
+  const int n = L.s->n;
+  if (tid < 64 && n > 0) {
+    for (int i = n - 1; i >= 0; --i) {
+      const int ri = L.ar[i], ai = L.aa[i], bi = L.ab[i];
+      int best = -1, nxt = -1;
+      for (int j0 = i + 1; j0 < n; j0 += 64) {
+        const int j = j0 + tid;
+        const bool near = j < n && L.ar[j] - ri < 1000 && L.ar[j] > ri;
+        const bool ok = near && L.aa[j] - ai < 1000 && L.aa[j] > ai && L.ab[j] - bi < 1000 && L.ab[j] > bi;
+        int v = ok ? L.cl[j] : -1, vj = ok ? j : 0x7fffffff;
+        for (int d = 32; d; d >>= 1) {
+          const int ov = __shfl_xor(v, d), oj = __shfl_xor(vj, d);
+          if (ov > v || (ov == v && oj < vj)) { v = ov; vj = oj; }
+        }
+        if (v > best) { best = v; nxt = vj; }                // strict: an earlier block's successor wins ties
+        // ref: the scan stops at the first anchor too far on the reference ("TOO FAR NOW", :98-101)
+        if (__builtin_amdgcn_ballot_w64(j < n && !near) != 0) break;
+      }
+      if (tid == 0) { L.cl[i] = 1 + best; L.cn[i] = best >= 0 ? nxt : -1; }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // start: the longest, the earliest among equals
+    int v = -1, vi = 0x7fffffff;
+    for (int i = tid; i < n; i += 64) if (L.cl[i] > v) { v = L.cl[i]; vi = i; }
+    for (int d = 32; d; d >>= 1) {
+      const int ov = __shfl_xor(v, d), oi = __shfl_xor(vi, d);
+      if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
+    }
+    if (tid == 0) {
+      L.s->start = vi;
+      // the chain as a list of anchor indices, written over cl (no longer needed)
+      int c = 0;
+      for (int i = vi; i != -1; i = L.cn[i]) L.cl[c++] = i;
+      L.s->nchain = c;
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ DSeq dsub(DSeq s, uint32_t pos, uint32_t len)     // std::string::substr semantics
+{
+  if (pos > s.n) pos = s.n;
+  return DSeq{s.base + pos, min(len, s.n - pos)};
+}
+__device__ __forceinline__ DSeq dsub(DSeq s, uint32_t pos) { return dsub(s, pos, 0xFFFFFFFFu); }
+
+struct WList { int32_t *w; int n; int64_t cap; bool over; };
+
+__device__ __forceinline__ void wpush(WList &o, uint32_t ro, uint32_t rl, uint32_t ao, uint32_t al, uint32_t bo, uint32_t bl, int nfill)
+{
+  if (o.n >= o.cap) { o.over = true; return; }
+  int32_t *w = o.w + 8 * (int64_t)o.n;
+  stg(w, (int)ro); stg(w + 1, (int)rl); stg(w + 2, (int)ao); stg(w + 3, (int)al); stg(w + 4, (int)bo); stg(w + 5, (int)bl);
+  stg(w + 6, nfill); stg(w + 7, 0);
+  ++o.n;
+}
+
+// one split() of the reference (:175-308) including the two re-splits of a missing start / end.  Workgroup-wide;
+// the window list `out` (in HBM) is built by thread 0; returns its length through *out_n (LDS).
+__device__ void split_read(const WG &g, const Lvl &L0, const Lvl &L1, DSeq ref, DSeq S1, DSeq S2, int k, int32_t *out, int32_t *tmp,
+                           int *sh /* LDS ints: [0] n out, [1] overflow, [2..] scratch */)
+{
+  const int tid = threadIdx.x;
+  split_core(g, L0, ref, S1, S2, k, 20u);
+  WList o{out, 0, g.maxwin, false};
+  uint32_t pred_ref = 0, pred_S1 = 0, pred_S2 = 0;
+  int i = 0;
+  const int nbl = L0.s->nchain;
+  if (tid == 0) { sh[0] = 0; sh[1] = 0; }
+  __syncthreads();
+  if (nbl == 0) {
+    if (tid == 0) { wpush(o, 0, ref.n, 0, S1.n, 0, S2.n, 0); sh[0] = o.n; sh[1] = o.over || L0.s->fail; }
+    __syncthreads();
+    return;
+  }
+  // ---- missing start (:264-277) ----
+  const int a0 = L0.cl[0];
+  const uint32_t sr = min(ref.n, (uint32_t)(L0.ar[a0] + k)), s1 = min(S1.n, (uint32_t)(L0.aa[a0] + k)), s2 = min(S2.n, (uint32_t)(L0.ab[a0] + k));
+  const bool rec_start = (uint64_t)s2 * 2 < sr && sr - s2 > 200;
+  if (rec_start) {
+    split_core(g, L1, DSeq{ref.base, sr}, DSeq{S1.base, s1}, DSeq{ref.base, sr}, k, (uint32_t)(1.2 * s2));
+    if (tid == 0) {
+      // the windows of the re-split (reference against uncorrected), by the plain rule; the corrected side
+      // is the 'N' filler except in the last one, which takes what there is of the corrected start
+      WList t{tmp, 0, g.maxwin, false};
+      const DSeq rr{0, sr}, r1{0, s1};
+      const int nb1 = L1.s->nchain;
+      if (nb1 == 0) wpush(t, 0, sr, 0, s1, 0, sr, 0);
+      else {
+        uint32_t pr_ = 0, p1_ = 0, p2_ = 0;
+        const uint32_t ms = (uint32_t)(1.2 * s2);
+        for (int q = 0; q < nb1 - 1; ++q) {
+          const int an = L1.cl[q];
+          const int size_R = (int)((uint32_t)L1.ar[an] - pr_), size_S1 = (int)((uint32_t)L1.aa[an] - p1_), size_S2 = (int)((uint32_t)L1.ab[an] - p2_);
+          if ((uint32_t)size_R > ms && (uint32_t)size_S1 > ms && (uint32_t)size_S2 > ms &&
+              abs(size_S1 - size_R) < size_R * 0.5 && abs(size_S2 - size_R) < size_R * 0.5) {
+            const DSeq wr = dsub(rr, pr_, (uint32_t)(L1.ar[an] - (int)pr_ + k)), w1 = dsub(r1, p1_, (uint32_t)(L1.aa[an] - (int)p1_ + k));
+            wpush(t, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, 0, 0, 0);
+            p1_ = (uint32_t)(L1.aa[an] + k); pr_ = (uint32_t)(L1.ar[an] + k); p2_ = (uint32_t)(L1.ab[an] + k);
+          }
+        }
+        const DSeq er = dsub(rr, pr_), e1 = dsub(r1, p1_);
+        wpush(t, (uint32_t)er.base, er.n, (uint32_t)e1.base, e1.n, 0, 0, 0);
+      }
+      for (int f = 0; f < t.n; ++f) {
+        const int32_t *w = tmp + 8 * (int64_t)f;
+        if (f + 1 < t.n || s2 == 0) wpush(o, (uint32_t)ldg(w), (uint32_t)ldg(w + 1), (uint32_t)ldg(w + 2), (uint32_t)ldg(w + 3), 0, 1, 1);
+        else wpush(o, (uint32_t)ldg(w), (uint32_t)ldg(w + 1), (uint32_t)ldg(w + 2), (uint32_t)ldg(w + 3), 0, s2, 0);
+      }
+      if (t.over || L1.s->fail) o.over = true;
+    }
+    pred_S1 = (uint32_t)(L0.aa[a0] + k); pred_ref = (uint32_t)(L0.ar[a0] + k); pred_S2 = (uint32_t)(L0.ab[a0] + k);
+    i = 1;
+  }
+  // ---- the chain (:279-293), thread 0; every thread follows the cursors (cheap, uniform) ----
+  for (; i < nbl - 1; ++i) {
+    const int an = L0.cl[i];
+    const int size_R = (int)((uint32_t)L0.ar[an] - pred_ref), size_S1 = (int)((uint32_t)L0.aa[an] - pred_S1),
+              size_S2 = (int)((uint32_t)L0.ab[an] - pred_S2);           // ref: ints from unsigned arithmetic, compared as unsigned
+    if ((uint32_t)size_R > 20u && (uint32_t)size_S1 > 20u && (uint32_t)size_S2 > 20u &&
+        abs(size_S1 - size_R) < size_R * 0.5 && abs(size_S2 - size_R) < size_R * 0.5) {
+      if (tid == 0) {
+        const DSeq wr = dsub(DSeq{0, ref.n}, pred_ref, (uint32_t)(L0.ar[an] - (int)pred_ref + k)),
+                   w1 = dsub(DSeq{0, S1.n}, pred_S1, (uint32_t)(L0.aa[an] - (int)pred_S1 + k)),
+                   w2 = dsub(DSeq{0, S2.n}, pred_S2, (uint32_t)(L0.ab[an] - (int)pred_S2 + k));
+        wpush(o, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, (uint32_t)w2.base, w2.n, 0);
+      }
+      pred_S1 = (uint32_t)(L0.aa[an] + k); pred_ref = (uint32_t)(L0.ar[an] + k); pred_S2 = (uint32_t)(L0.ab[an] + k);
+    }
+  }
+  // ---- the end (:294-306) ----
+  const DSeq er = dsub(DSeq{0, ref.n}, pred_ref), e1 = dsub(DSeq{0, S1.n}, pred_S1), e2 = dsub(DSeq{0, S2.n}, pred_S2);
+  const bool rec_end = (uint64_t)e2.n * 2 < er.n && er.n - e2.n > 200;
+  __syncthreads();              // L1 and tmp are about to be reused
+  if (rec_end) {
+    const DSeq gr{ref.base + er.base, er.n}, g1{S1.base + e1.base, e1.n};
+    split_core(g, L1, gr, g1, gr, k, (uint32_t)(1.2 * e2.n));
+    if (tid == 0) {
+      WList t{tmp, 0, g.maxwin, false};
+      const DSeq rr{0, er.n}, r1{0, e1.n};
+      const int nb1 = L1.s->nchain;
+      if (nb1 == 0) wpush(t, 0, er.n, 0, e1.n, 0, er.n, 0);
+      else {
+        uint32_t pr_ = 0, p1_ = 0, p2_ = 0;
+        const uint32_t ms = (uint32_t)(1.2 * e2.n);
+        for (int q = 0; q < nb1 - 1; ++q) {
+          const int an = L1.cl[q];
+          const int size_R = (int)((uint32_t)L1.ar[an] - pr_), size_S1 = (int)((uint32_t)L1.aa[an] - p1_), size_S2 = (int)((uint32_t)L1.ab[an] - p2_);
+          if ((uint32_t)size_R > ms && (uint32_t)size_S1 > ms && (uint32_t)size_S2 > ms &&
+              abs(size_S1 - size_R) < size_R * 0.5 && abs(size_S2 - size_R) < size_R * 0.5) {
+            const DSeq wr = dsub(rr, pr_, (uint32_t)(L1.ar[an] - (int)pr_ + k)), w1 = dsub(r1, p1_, (uint32_t)(L1.aa[an] - (int)p1_ + k));
+            wpush(t, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, 0, 0, 0);
+            p1_ = (uint32_t)(L1.aa[an] + k); pr_ = (uint32_t)(L1.ar[an] + k); p2_ = (uint32_t)(L1.ab[an] + k);
+          }
+        }
+        const DSeq xr = dsub(rr, pr_), x1 = dsub(r1, p1_);
+        wpush(t, (uint32_t)xr.base, xr.n, (uint32_t)x1.base, x1.n, 0, 0, 0);
+      }
+      for (int f = 0; f < t.n; ++f) {
+        const int32_t *w = tmp + 8 * (int64_t)f;
+        const uint32_t ro = (uint32_t)ldg(w) + (uint32_t)er.base, ao = (uint32_t)ldg(w + 2) + (uint32_t)e1.base;
+        if (f == 0 && e2.n > 0) wpush(o, ro, (uint32_t)ldg(w + 1), ao, (uint32_t)ldg(w + 3), (uint32_t)e2.base, e2.n, 0);
+        else wpush(o, ro, (uint32_t)ldg(w + 1), ao, (uint32_t)ldg(w + 3), 0, 1, 1);
+      }
+      if (t.over || L1.s->fail) o.over = true;
+    }
+  } else if (tid == 0) {
+    wpush(o, (uint32_t)er.base, er.n, (uint32_t)e1.base, e1.n, (uint32_t)e2.base, e2.n, 0);
+  }
+  if (tid == 0) { sh[0] = o.n; sh[1] = (o.over || L0.s->fail) ? 1 : 0; }
+  __syncthreads();
+}
+
+// ref: largest_fragment (:158-169) measures every LINE of the "header\nseq\n" text, header lines included
+__device__ uint32_t largest_fragment(const int32_t *wl, int n, uint32_t hdr_len)
+{
+  uint32_t res = 0;
+  for (int w = 0; w < n; ++w) {
+    res = max(res, w == 0 ? hdr_len : hdr_len + 1);
+    res = max(res, (uint32_t)ldg(wl + 8 * (int64_t)w + 1) + 1);
+  }
+  return res;
+}
+
+template <bool BIG>
+__global__ void __launch_bounds__(kSplitThreads) k_split(SplitArgs a)
+{
+  __shared__ int32_t s_anc[BIG ? 1 : 2 * 5 * kMaxAnchors];
+  __shared__ LvlState s_lvl[2];
+  __shared__ int sh[8];
+  const int tid = threadIdx.x;
+  Lvl L0, L1;
+  {
+    const int cap = BIG ? (int)a.maxanc : kMaxAnchors;
+    int32_t *base = BIG ? a.anc + (int64_t)blockIdx.x * 2 * 5 * a.maxanc : s_anc;
+    L0.ar = base; L0.aa = base + cap; L0.ab = base + 2 * cap; L0.cl = base + 3 * cap; L0.cn = base + 4 * cap;
+    base += 5 * (int64_t)cap;
+    L1.ar = base; L1.aa = base + cap; L1.ab = base + 2 * cap; L1.cl = base + 3 * cap; L1.cn = base + 4 * cap;
+    L0.cap = L1.cap = cap;
+    L0.s = &s_lvl[0]; L1.s = &s_lvl[1];
+  }
+  WG g;
+  g.reads = a.reads;
+  for (int t = 0; t < 3; ++t) {
+    g.tab[t].keys = a.keys + ((int64_t)blockIdx.x * 3 + t) * a.tab_cap;
+    g.tab[t].vals = a.vals + ((int64_t)blockIdx.x * 3 + t) * a.tab_cap;
+    g.tab[t].mask = 0;
+  }
+  g.ca = a.ca + (int64_t)blockIdx.x * (a.maxlen + 2);
+  g.cb = a.cb + (int64_t)blockIdx.x * (a.maxlen + 2);
+  g.wl = a.wl + (int64_t)blockIdx.x * 3 * a.maxwin * 8;
+  g.tab_cap = a.tab_cap; g.maxwin = a.maxwin;
+  for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const DSeq ref{a.read_off[3 * r], (uint32_t)(a.read_off[3 * r + 1] - a.read_off[3 * r])};
+    const DSeq S1{a.read_off[3 * r + 1], (uint32_t)(a.read_off[3 * r + 2] - a.read_off[3 * r + 1])};
+    const DSeq S2{a.read_off[3 * r + 2], (uint32_t)(a.read_off[3 * r + 3] - a.read_off[3 * r + 2])};
+    int kind;
+    int nout = 0;
+    int32_t *dst = a.out_win + 8 * a.out_first[r];
+    const int64_t dcap = a.out_first[r + 1] - a.out_first[r];
+    __syncthreads();
+    if (tid == 0) { L0.s->fail = 0; L1.s->fail = 0; }
+    __syncthreads();
+    if (ref.n <= 2) kind = -1;                                                   // :414
+    else if ((double)S2.n / ref.n >= a.thr) {                                   // :415
+      // best_split (:310-332): k = 15, then smaller k while the largest fragment shrinks
+      int32_t *best = g.wl, *aux = g.wl + a.maxwin * 8, *tmp = g.wl + 2 * a.maxwin * 8;
+      int kk = 15;
+      split_read(g, L0, L1, ref, S1, S2, kk, best, tmp, sh);
+      int nbest = sh[0];
+      bool over = sh[1] != 0;
+      if (tid == 0) sh[2] = (int)largest_fragment(best, nbest, (uint32_t)a.hdr_len[r]);
+      __syncthreads();
+      uint32_t largest = (uint32_t)sh[2];
+      for (;;) {
+        kk -= 2;
+        if (kk < 9 || over) break;
+        __syncthreads();
+        split_read(g, L0, L1, ref, S1, S2, kk, aux, tmp, sh);
+        const int naux = sh[0];
+        over = over || sh[1] != 0;
+        if (tid == 0) sh[3] = (int)largest_fragment(aux, naux, (uint32_t)a.hdr_len[r]);
+        __syncthreads();
+        const uint32_t la = (uint32_t)sh[3];
+        if (la < largest) { largest = la; int32_t *t = best; best = aux; aux = t; nbest = naux; }
+        else break;
+      }
+      __syncthreads();
+      if (over || nbest > dcap) kind = -2;                                        // the host code takes this read
+      else if (nbest <= 1) kind = 2;                                             // :417-423
+      else {
+        kind = 0;
+        nout = nbest;
+        for (int64_t i = tid; i < 8 * (int64_t)nbest; i += kSplitThreads) dst[i] = ldg(best + i);
+      }
+    } else kind = 1;                                                             // :425-431
+    if (tid == 0) { a.out_kind[r] = kind; a.out_cnt[r] = kind == 0 ? nout : (kind == 1 || kind == 2) ? 1 : 0; }
+  }
+}
+
+// ---- layout: windows -> the engine's input (bases of reference, corrected, uncorrected per window) ----
+struct LayoutArgs {
+  int64_t n_reads;
+  const uint8_t *reads; const int64_t *read_off;
+  const int32_t *out_win; const int64_t *out_first; const int32_t *out_cnt, *out_kind;
+  const int64_t *win_first;      // per read: index of its first emitted window (exclusive scan of out_cnt)
+  int64_t *wlen;                 // per emitted window: 3 lengths (reference, corrected, uncorrected)
+  const int64_t *woff;           // exclusive scan of wlen: byte offsets
+  uint8_t *bases;
+};
+
+__global__ void __launch_bounds__(256) k_split_lens(LayoutArgs a)
+{
+  for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const int kind = a.out_kind[r];
+    const int64_t w0 = a.win_first[r];
+    if (kind == 1 || kind == 2) { if (threadIdx.x < 3) a.wlen[3 * w0 + threadIdx.x] = 3; continue; }
+    if (kind != 0) continue;
+    const int32_t *w = a.out_win + 8 * a.out_first[r];
+    for (int i = threadIdx.x; i < a.out_cnt[r]; i += 256) {
+      a.wlen[3 * (w0 + i)] = w[8 * i + 1];            // reference
+      a.wlen[3 * (w0 + i) + 1] = w[8 * i + 5];        // corrected (S2)
+      a.wlen[3 * (w0 + i) + 2] = w[8 * i + 3];        // uncorrected (S1)
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_split_copy(LayoutArgs a)
+{
+  for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+    const int kind = a.out_kind[r];
+    const int64_t w0 = a.win_first[r];
+    if (kind == 1 || kind == 2) { if (threadIdx.x < 9) a.bases[a.woff[3 * w0] + threadIdx.x] = 'A'; continue; }
+    if (kind != 0) continue;
+    const int32_t *w = a.out_win + 8 * a.out_first[r];
+    const uint8_t *pr = a.reads + a.read_off[3 * r], *p1 = a.reads + a.read_off[3 * r + 1], *p2 = a.reads + a.read_off[3 * r + 2];
+    const int nw = a.out_cnt[r];
+    // a wavefront per window, in turn
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = wave; i < nw; i += 4) {
+      const int ro = w[8 * i], rl = w[8 * i + 1], ao = w[8 * i + 2], al = w[8 * i + 3], bo = w[8 * i + 4], bl = w[8 * i + 5], nf = w[8 * i + 6];
+      uint8_t *d = a.bases + a.woff[3 * (w0 + i)];
+      for (int j = lane; j < rl; j += 64) d[j] = pr[ro + j];
+      d += rl;
+      if (nf) { if (lane == 0) d[0] = 'N'; }
+      else for (int j = lane; j < bl; j += 64) d[j] = p2[bo + j];
+      d += bl;
+      for (int j = lane; j < al; j += 64) d[j] = p1[ao + j];
+    }
+  }
+}
+
+}  // namespace elector
+
+using namespace elector;
+
+// ------------------------------------------------------------------ host ---
+
+extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const uint8_t *reads, const int64_t *read_off,
+                                           const int32_t *hdr_len, double size_threshold, int nthreads,
+                                           elector_windows_dev *out)
+{
+  if (!c || !out) return ELECTOR_E_INVAL;
+  std::memset(out, 0, sizeof *out);
+  if (n_in < 0 || (n_in > 0 && (!reads || !read_off || !hdr_len))) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  int64_t maxlen = 1;
+  for (int64_t r = 0; r < 3 * n_in; ++r) {
+    const int64_t l = read_off[r + 1] - read_off[r];
+    if (l < 0 || l > 0x7fffffff) return elector_fail(c, ELECTOR_E_INVAL, "read offsets");
+    maxlen = std::max(maxlen, l);
+  }
+  const int64_t total = n_in ? read_off[3 * n_in] : 0;
+  // per read: room for its windows (an anchor at most every 21 bases, plus the fillers of a re-split)
+  std::vector<int64_t> first((size_t)n_in + 1, 0);
+  int64_t maxwin = 16;
+  for (int64_t r = 0; r < n_in; ++r) {
+    const int64_t cap = (read_off[3 * r + 1] - read_off[3 * r]) / 16 + 16;
+    first[(size_t)r + 1] = first[(size_t)r] + cap;
+    maxwin = std::max(maxwin, cap);
+  }
+  int64_t tab_cap = 64;
+  while (tab_cap < 2 * maxlen + 2) tab_cap <<= 1;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(n_in, 1024));
+  hipStream_t st = c->stream;
+  int rc = c->d_sp_reads.ensure((size_t)total + 64) | c->d_sp_off.ensure((size_t)(3 * n_in + 1) * 8 + 64) |
+           c->d_sp_hdr.ensure((size_t)n_in * 4 + 64) | c->d_sp_keys.ensure((size_t)blocks * 3 * tab_cap * 4) |
+           c->d_sp_vals.ensure((size_t)blocks * 3 * tab_cap * 4) | c->d_sp_ca.ensure((size_t)blocks * (maxlen + 2) * 4) |
+           c->d_sp_cb.ensure((size_t)blocks * (maxlen + 2) * 4) | c->d_sp_wl.ensure((size_t)blocks * 3 * maxwin * 8 * 4) |
+           c->d_sp_win.ensure((size_t)first[(size_t)n_in] * 8 * 4 + 64) | c->d_sp_first.ensure((size_t)(n_in + 1) * 8) |
+           c->d_sp_cnt.ensure((size_t)(n_in + 1) * 4 * 2 + 64) | c->d_sp_wfirst.ensure((size_t)(n_in + 2) * 8 * 2);
+  if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "device splitter workspace");
+  if (n_in == 0) return ELECTOR_OK;
+  HIPCHK(c, hipMemcpyAsync(c->d_sp_reads.p, reads, (size_t)total, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_sp_off.p, read_off, (size_t)(3 * n_in + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_sp_hdr.p, hdr_len, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->d_sp_first.p, first.data(), (size_t)(n_in + 1) * 8, hipMemcpyHostToDevice, st));
+  SplitArgs a;
+  a.n_reads = n_in;
+  a.reads = c->d_sp_reads.as<uint8_t>(); a.read_off = c->d_sp_off.as<int64_t>(); a.hdr_len = c->d_sp_hdr.as<int32_t>();
+  a.thr = size_threshold;
+  a.keys = c->d_sp_keys.as<uint32_t>(); a.vals = c->d_sp_vals.as<int32_t>();
+  a.ca = c->d_sp_ca.as<int32_t>(); a.cb = c->d_sp_cb.as<int32_t>(); a.wl = c->d_sp_wl.as<int32_t>();
+  a.tab_cap = tab_cap; a.maxlen = maxlen; a.maxwin = maxwin;
+  a.out_win = c->d_sp_win.as<int32_t>(); a.out_first = c->d_sp_first.as<int64_t>();
+  a.out_cnt = c->d_sp_cnt.as<int32_t>(); a.out_kind = a.out_cnt + (n_in + 1);
+  // anchors are more than 20 bases apart on the reference (the re-split of a missing end can use less: it
+  // overflows into the host path, like a window list that does not fit)
+  const int64_t maxanc = maxlen / 21 + 8;
+  const bool big = maxanc > kMaxAnchors;
+  a.anc = nullptr; a.maxanc = maxanc;
+  if (big) {
+    if (c->d_sp_anc.ensure((size_t)blocks * 2 * 5 * maxanc * 4 + 64)) return elector_fail(c, ELECTOR_E_NOMEM, "device splitter anchors");
+    a.anc = c->d_sp_anc.as<int32_t>();
+    hipLaunchKernelGGL(k_split<true>, dim3((unsigned)blocks), dim3(kSplitThreads), 0, st, a);
+  } else hipLaunchKernelGGL(k_split<false>, dim3((unsigned)blocks), dim3(kSplitThreads), 0, st, a);
+  HIPCHK(c, hipGetLastError());
+  // kinds and counts to the host: the reads the device could not take are split by the host code
+  std::vector<int32_t> cnt((size_t)n_in), kind((size_t)n_in);
+  HIPCHK(c, hipMemcpyAsync(cnt.data(), a.out_cnt, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(kind.data(), a.out_kind, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  (void)nthreads;
+  int64_t n_host = 0;
+  for (int64_t r = 0; r < n_in; ++r) n_host += kind[(size_t)r] == -2;
+  if (n_host)   // rare: a read beyond the on-chip limits (kMaxAnchors anchors, window list); the caller uses the host entry
+    return elector_fail(c, ELECTOR_E_LIMIT, "device splitter: a read exceeds the on-chip limits");
+  // emitted reads, window counts, first window per read
+  std::vector<int64_t> wfirst((size_t)n_in + 1, 0);
+  int64_t nreads = 0, nwin = 0, small = 0, wrong = 0;
+  for (int64_t r = 0; r < n_in; ++r) {
+    wfirst[(size_t)r] = nwin;
+    if (kind[(size_t)r] < 0) continue;
+    ++nreads;
+    nwin += cnt[(size_t)r];
+    small += kind[(size_t)r] == 1;
+    wrong += kind[(size_t)r] == 2;
+  }
+  wfirst[(size_t)n_in] = nwin;
+  out->read_first = (int64_t *)std::malloc((size_t)(nreads + 1) * 8);
+  out->read_index = (int64_t *)std::malloc((size_t)(nreads + 1) * 8);
+  out->off = (int64_t *)std::malloc((size_t)(3 * nwin + 1) * 8);
+  if (!out->read_first || !out->read_index || !out->off) { elector_windows_dev_free(out); return elector_fail(c, ELECTOR_E_NOMEM, "host arrays"); }
+  {
+    int64_t ri = 0;
+    for (int64_t r = 0; r < n_in; ++r)
+      if (kind[(size_t)r] >= 0) { out->read_first[ri] = wfirst[(size_t)r]; out->read_index[ri] = r; ++ri; }
+    out->read_first[ri] = nwin;
+  }
+  rc = c->d_sp_wlen.ensure((size_t)(3 * nwin + 2) * 8) | c->d_sp_woff.ensure((size_t)(3 * nwin + 2) * 8);
+  if (rc) { elector_windows_dev_free(out); return elector_fail(c, ELECTOR_E_NOMEM, "device splitter layout"); }
+  int64_t *d_wfirst = c->d_sp_wfirst.as<int64_t>();
+  HIPCHK(c, hipMemcpyAsync(d_wfirst, wfirst.data(), (size_t)(n_in + 1) * 8, hipMemcpyHostToDevice, st));
+  LayoutArgs la;
+  la.n_reads = n_in; la.reads = a.reads; la.read_off = a.read_off; la.out_win = a.out_win; la.out_first = a.out_first;
+  la.out_cnt = a.out_cnt; la.out_kind = a.out_kind; la.win_first = d_wfirst;
+  la.wlen = c->d_sp_wlen.as<int64_t>(); la.woff = c->d_sp_woff.as<int64_t>(); la.bases = nullptr;
+  HIPCHK(c, hipMemsetAsync(la.wlen, 0, (size_t)(3 * nwin + 1) * 8, st));
+  hipLaunchKernelGGL(k_split_lens, dim3((unsigned)blocks), dim3(256), 0, st, la);
+  size_t tmp_bytes = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, la.wlen, c->d_sp_woff.as<int64_t>(), (int)(3 * nwin + 1), st);
+  if (c->d_sp_scan.ensure(tmp_bytes + 64)) { elector_windows_dev_free(out); return elector_fail(c, ELECTOR_E_NOMEM, "scan scratch"); }
+  if (hipcub::DeviceScan::ExclusiveSum(c->d_sp_scan.p, tmp_bytes, la.wlen, c->d_sp_woff.as<int64_t>(), (int)(3 * nwin + 1), st) != hipSuccess) {
+    elector_windows_dev_free(out);
+    return elector_fail(c, ELECTOR_E_HIP, "scan");
+  }
+  HIPCHK(c, hipMemcpyAsync(out->off, c->d_sp_woff.p, (size_t)(3 * nwin + 1) * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const int64_t nb = out->off[3 * nwin];
+  if (c->d_sp_bases.ensure((size_t)nb + 64)) { elector_windows_dev_free(out); return elector_fail(c, ELECTOR_E_NOMEM, "window bases"); }
+  la.bases = c->d_sp_bases.as<uint8_t>();
+  hipLaunchKernelGGL(k_split_copy, dim3((unsigned)blocks), dim3(256), 0, st, la);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(st));
+  out->n_reads = nreads; out->n_windows = nwin; out->d_bases = la.bases; out->small_reads = small; out->wrong_reads = wrong;
+  return ELECTOR_OK;
+}
+
+extern "C" void elector_windows_dev_free(elector_windows_dev *w)
+{
+  if (!w) return;
+  std::free(w->off); std::free(w->read_first); std::free(w->read_index);
+  std::memset(w, 0, sizeof *w);
+}
+
+// window bases out of the splitter's workspace into a caller's device buffer (or a host buffer), after the
+// work queued on the context
+extern "C" int elector_ctx_copy(elector_ctx *c, const void *src, void *dst, int64_t bytes)
+{
+  if (!c || (bytes > 0 && (!src || !dst)) || bytes < 0) return ELECTOR_E_INVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ELECTOR_OK;
+}
+
+// test / debugging helper: device memory of this context's device to a host buffer
+extern "C" int elector_ctx_copy_to_host(elector_ctx *c, const void *d_src, void *h_dst, int64_t bytes)
+{
+  if (!c || (bytes > 0 && (!d_src || !h_dst)) || bytes < 0) return ELECTOR_E_INVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return ELECTOR_OK;
+}

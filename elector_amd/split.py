@@ -21,6 +21,14 @@ class ElectorWindows(C.Structure):
     ]
 
 
+class ElectorWindowsDev(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_int64), ("n_windows", C.c_int64), ("d_bases", C.c_void_p),
+        ("off", C.POINTER(C.c_int64)), ("read_first", C.POINTER(C.c_int64)), ("read_index", C.POINTER(C.c_int64)),
+        ("small_reads", C.c_int64), ("wrong_reads", C.c_int64),
+    ]
+
+
 class ElectorMsa(C.Structure):
     _fields_ = [
         ("n_reads", C.c_int64), ("rows", C.POINTER(C.c_uint8)),
@@ -39,6 +47,12 @@ def _lib():
                                             C.POINTER(ElectorMsa)]
         L.elector_msa_free.argtypes = [C.POINTER(ElectorMsa)]
         L.elector_msa_free.restype = None
+        L.elector_split_reads_device.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                                 C.POINTER(ElectorWindowsDev)]
+        L.elector_windows_dev_free.argtypes = [C.POINTER(ElectorWindowsDev)]
+        L.elector_windows_dev_free.restype = None
+        L.elector_ctx_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.elector_ctx_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L._split_bound = True
     return L
 
@@ -76,6 +90,97 @@ def split_reads(reads, size_threshold=0.1, headers=None, nthreads=1):
     else:
         hl = np.fromiter((len(h) for h in headers), dtype=np.int32, count=n)
     return split_packed(buf, off, hl, size_threshold, nthreads)
+
+
+class DevBases:
+    """device pointer to the window bases the device splitter left in its context (valid until that
+    context's next splitter call); quacks like a torch tensor where PoaEngine.align_device needs it"""
+
+    def __init__(self, ptr, nbytes, engine):
+        self._ptr, self.nbytes, self._engine = int(ptr or 0), int(nbytes), engine
+
+    def data_ptr(self):
+        return self._ptr
+
+    def to_tensor(self):
+        """the bases in a torch tensor of their own (device to device)"""
+        import torch
+        t = torch.empty(self.nbytes + 64, dtype=torch.uint8, device=torch.device("cuda", self._engine.device))
+        if self.nbytes:
+            rc = _lib().elector_ctx_copy(self._engine._h, self._ptr, t.data_ptr(), self.nbytes)
+            if rc:
+                raise ElectorError(rc)
+        return t
+
+    def numpy(self):
+        out = np.zeros(self.nbytes, dtype=np.uint8)
+        if self.nbytes:
+            rc = _lib().elector_ctx_copy_to_host(self._engine._h, self._ptr, out.ctypes.data, self.nbytes)
+            if rc:
+                raise ElectorError(rc)
+        return out
+
+
+class DevWindows(Windows):
+    """Windows whose bases live in device memory (`d_bases`); `.bases` fetches them (tests)."""
+    __slots__ = ("d_bases",)
+
+    @property
+    def host_bases(self):
+        return self.d_bases.numpy()
+
+
+def pack_reads(reads, headers=None):
+    """[(reference, corrected, uncorrected)] -> (buf, off, hdr_len) in masterSplitter's order
+    (reference, uncorrected, corrected per read)"""
+    n = len(reads)
+    off = np.zeros(3 * n + 1, dtype=np.int64)
+    parts = [s for (r, c, u) in reads for s in (r, u, c)]
+    lens = np.fromiter((len(s) for s in parts), dtype=np.int64, count=3 * n)
+    np.cumsum(lens, out=off[1:])
+    buf = np.frombuffer(b"".join(parts), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+    if headers is None:
+        hl = np.full(n, 2, dtype=np.int32)
+    else:
+        hl = np.fromiter((len(h) for h in headers), dtype=np.int32, count=n)
+    return buf, off, hl
+
+
+def split_reads_device(engine, reads, size_threshold=0.1, headers=None, nthreads=None):
+    """The splitter on the GPU of `engine` (include/elector_split.h: elector_split_reads_device): same windows as
+    split_reads, their bases stay in device memory.  A batch with a read beyond the kernel's on-chip limits is
+    split by the host code and uploaded, so the result is always a DevWindows."""
+    import os
+    import torch
+    L = _lib()
+    nthreads = nthreads or os.cpu_count() or 1
+    buf, off, hl = pack_reads(reads, headers)
+    n = len(reads)
+    w = ElectorWindowsDev()
+    rc = L.elector_split_reads_device(engine._h, n, buf.ctypes.data, off.ctypes.data, hl.ctypes.data,
+                                      float(size_threshold), int(nthreads), C.byref(w))
+    out = DevWindows()
+    if rc == _capi.E_LIMIT:
+        hw = split_packed(buf, off, hl, size_threshold, nthreads)
+        for k in ("n_reads", "n_windows", "off", "read_first", "read_index", "small_reads", "wrong_reads"):
+            setattr(out, k, getattr(hw, k))
+        t = torch.from_numpy(hw.bases).to(torch.device("cuda", engine.device))
+        out.bases = None
+        out.d_bases = t                      # a torch tensor has data_ptr() too
+        return out
+    if rc:
+        raise ElectorError(rc, L.elector_ctx_last_error(engine._h).decode())
+    try:
+        out.n_reads, out.n_windows = int(w.n_reads), int(w.n_windows)
+        out.off = _np(w.off, 3 * out.n_windows + 1, np.int64) if out.n_windows else np.zeros(1, dtype=np.int64)
+        out.read_first = _np(w.read_first, out.n_reads + 1, np.int64) if out.n_reads else np.zeros(1, dtype=np.int64)
+        out.read_index = _np(w.read_index, out.n_reads, np.int64)
+        out.small_reads, out.wrong_reads = int(w.small_reads), int(w.wrong_reads)
+        out.bases = None
+        out.d_bases = DevBases(w.d_bases, int(out.off[-1]), engine)
+        return out
+    finally:
+        L.elector_windows_dev_free(C.byref(w))
 
 
 def split_packed(buf, off, hdr_len, size_threshold=0.1, nthreads=1):

@@ -44,6 +44,7 @@ extern "C" {
 #define ELECTOR_E_PARAMS     (-5)   /* scoring parameters outside device limits    */
 #define ELECTOR_E_IO         (-6)   /* matrix file unreadable / malformed          */
 #define ELECTOR_E_WINDOW     (-7)   /* at least one window failed: see status[]    */
+#define ELECTOR_E_LIMIT      (-8)   /* an input exceeds an on-chip limit of a device entry; its host twin takes it */
 /* per-window status values */
 #define ELECTOR_W_OK          0
 #define ELECTOR_W_EMPTY       1     /* a sequence of the window is empty           */

@@ -19,6 +19,7 @@
 #define ELECTOR_SPLIT_H
 
 #include <stdint.h>
+#include "elector_poa.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -47,6 +48,30 @@ int  elector_split_reads(int64_t n_reads_in, const uint8_t *reads, const int64_t
                          const int32_t *hdr_len, double size_threshold, int nthreads,
                          elector_windows *out);
 void elector_windows_free(elector_windows *w);
+
+/* The same splitter on the GPU (elector_amd/csrc/split_dev.hip): one workgroup per read, the k-mer tables in
+ * HBM scratch, anchor chaining in LDS.  Same inputs as elector_split_reads (HOST buffers: the reads go to the
+ * device in one copy), same windows -- but their bases stay in device memory, already in the layout
+ * elector_poa_batch_device takes, so the windows never cross PCIe:
+ *   d_bases    device pointer, owned by the context, valid until its next splitter call
+ *   off, read_first, read_index   host arrays as in elector_windows (malloc'd; elector_windows_dev_free)
+ * Returns ELECTOR_E_LIMIT when a read exceeds the kernel's on-chip limits (more than 3,000 anchors: reads beyond
+ * ~60 kb): elector_split_reads takes such a batch. */
+typedef struct elector_windows_dev {
+  int64_t n_reads, n_windows;
+  uint8_t *d_bases;
+  int64_t *off, *read_first, *read_index;
+  int64_t small_reads, wrong_reads;
+} elector_windows_dev;
+
+int  elector_split_reads_device(elector_ctx *ctx, int64_t n_reads_in, const uint8_t *reads, const int64_t *read_off,
+                                const int32_t *hdr_len, double size_threshold, int nthreads, elector_windows_dev *out);
+void elector_windows_dev_free(elector_windows_dev *w);
+/* d_bases stays valid until the context's next splitter call: elector_ctx_copy moves it (device to device, or
+ * to the host) after the work queued on the context */
+int  elector_ctx_copy(elector_ctx *ctx, const void *src, void *dst, int64_t bytes);
+/* copies device memory of the context's device to the host (tests, debugging) */
+int  elector_ctx_copy_to_host(elector_ctx *ctx, const void *d_src, void *h_dst, int64_t bytes);
 
 /* Merged per-read MSA (what Donatello appends to msa.fa): for emitted read r the
  * three rows each have read_cols[r] columns; columns whose corrected letter is

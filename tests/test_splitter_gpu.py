@@ -1,0 +1,62 @@
+"""The device splitter (elector_split_reads_device, split_dev.hip) against the host splitter, which the CPU
+tests pin to the reference's masterSplitter (golden vectors, the real binary): identical windows, identical
+read bookkeeping, identical small / wrong counts -- on the golden reads, on every synthetic profile (whole,
+trimmed, split, extended corrected reads), and on the degenerate inputs the reference's integer quirks matter for."""
+import numpy as np
+import pytest
+
+import golden_io
+import synth
+from elector_amd import split, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def same(engine, reads, headers=None, thr=0.1):
+    host = split.split_reads(reads, thr, headers, nthreads=4)
+    dev = split.split_reads_device(engine, reads, thr, headers)
+    assert (dev.n_reads, dev.n_windows) == (host.n_reads, host.n_windows)
+    assert (dev.small_reads, dev.wrong_reads) == (host.small_reads, host.wrong_reads)
+    assert np.array_equal(dev.read_first, host.read_first) and np.array_equal(dev.read_index, host.read_index)
+    d = np.nonzero(dev.off != host.off)[0]
+    assert len(d) == 0, "window offsets differ first at window %d (read %d)" % (
+        d[0] // 3, int(np.searchsorted(host.read_first, d[0] // 3, side="right") - 1))
+    got = dev.d_bases.numpy() if hasattr(dev.d_bases, "numpy") and not hasattr(dev.d_bases, "cpu") else dev.d_bases.cpu().numpy()
+    assert np.array_equal(got, host.bases)
+    return host
+
+
+def test_golden_reads(engine):
+    reads, wins, small, wrong = golden_io.splitter()
+    h = same(engine, [r[1] for r in reads], [r[0] for r in reads])
+    assert h.triples() == [w[1] for w in wins]
+
+
+@pytest.mark.parametrize("profile,n", [("ecoli30x_simlord_lordec", 400), ("yeast50x_nanosim_consent_split", 400),
+                                       ("celegans30x_simlord_mixed", 400), ("chr1_20x_ont_50kb", 60)])
+def test_profiles(engine, profile, n):
+    triples, headers, _ = synthetic.read_pieces(profile, n, 77)
+    same(engine, triples, headers)
+    if profile != "chr1_20x_ont_50kb":       # (a read beyond ~60 kb sends its batch to the host code)
+        assert isinstance(split.split_reads_device(engine, triples, 0.1, headers).d_bases, split.DevBases)
+
+
+def test_degenerate_reads(engine):
+    rng = np.random.default_rng(5)
+    r = synth.random_seq(rng, 900)
+    reads = [
+        (b"AC", b"AC", b"AC"),                                       # skipped (:414)
+        (b"ACG", b"ACG", b"ACG"),                                    # no anchor: dummy
+        (r, r[:50], synth.mutate(rng, r, 0.1)),                      # corrected too short: small read
+        (r, r.lower(), synth.mutate(rng, r, 0.1)),                   # lower case: the two letter maps disagree
+        (r, synth.mutate(rng, r, 0.02).replace(b"A", b"N", 7), synth.mutate(rng, r, 0.12)),
+        (b"A" * 700, b"A" * 690, b"A" * 710),                        # every k-mer repeated
+        (b"ACGT" * 200, b"ACGT" * 199, b"ACGT" * 201),
+        (r[:14], r[:14], r[:14]), (r[:15], r[:15], r[:15]), (r[:16], r[:16], r[:16]),   # around k
+        (r, b"", synth.mutate(rng, r, 0.1)), (r, r, b""),
+        (r, r[300:], synth.mutate(rng, r, 0.12)), (r, r[:500], synth.mutate(rng, r, 0.12)),   # trimmed
+        (r + r, r + r, r + r),                                       # every k-mer twice
+    ]
+    same(engine, reads)
+    same(engine, reads, thr=0.6)
+    same(engine, [], None)
