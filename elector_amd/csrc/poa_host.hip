@@ -1233,9 +1233,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     for (int b = 0; b < kBins; ++b) {
       const unsigned long long *p = hs.data() + 32 * (size_t)b;
       if (p[16 + 15])
-        std::fprintf(stderr, "[elector] bin G%dxR%d  k_poa waves %llu: stage %.0f dpA %.0f tbA %.0f fus1 %.0f ord %.0f dpB %.0f tbB %.0f cols+out %.0f  (cycles per wave)\n",
-                     kClsG[b / kNT], kClsR[b / kNT], p[31], (double)p[16] / p[31], (double)p[17] / p[31], (double)p[18] / p[31],
-                     (double)p[19] / p[31], (double)p[20] / p[31], (double)p[21] / p[31], (double)p[22] / p[31], (double)p[23] / p[31]);
+        std::fprintf(stderr, "[elector] bin G%dxR%d  k_poa waves %llu: stage %.0f dpA %.0f tbA %.0f fus1 %.0f ord %.0f dpB %.0f tbB %.0f cols+out %.0f | of stage: descriptors %.0f symbols %.0f slot %.0f rest %.0f; traceback #2 rounds %.1f; alignment #2 steps %.1f, two-predecessor %.1f, virtual %.1f  (cycles per wave)\n",
+                     kClsG[b / kNT], kClsR[b / kNT], p[31], (double)(p[16] + p[24] + p[25] + p[26]) / p[31], (double)p[17] / p[31], (double)p[18] / p[31],
+                     (double)p[19] / p[31], (double)p[20] / p[31], (double)p[21] / p[31], (double)p[22] / p[31], (double)p[23] / p[31],
+                     (double)p[24] / p[31], (double)p[25] / p[31], (double)p[26] / p[31], (double)p[16] / p[31], (double)p[27] / p[31],
+                     (double)p[28] / p[31], (double)p[29] / p[31], (double)p[30] / p[31]);
       if (!p[4]) continue;
       std::fprintf(stderr, "[elector] bin G%dxR%d/%d  A waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f | B waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f  (cycles per wave)\n",
                    kClsG[b / kNT], kClsR[b / kNT], g_tier_bytes[b % kNT], p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[5] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],

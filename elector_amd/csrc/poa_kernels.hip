@@ -589,7 +589,9 @@ __global__ void __launch_bounds__(256) k_left_b(BatchArgs a, uint32_t *list, int
 // corrected and reference differ, i.e. where their graph will have its first two-predecessor node.
 // Wavefronts of k_fused_b whose windows reach such nodes at the same steps take its two-predecessor
 // path together instead of one after the other.
-constexpr int kPartBuckets = 16;        // 0..14: first difference in columns 8k..8k+7 (14: beyond), 15: trivial
+constexpr int kPartBuckets = 32;        // 0..14: first difference in columns 8k..8k+7 (14: beyond); 16..30: the same for the
+                                        // one-substitution windows k_poa settles without alignment #1 (their wavefronts
+                                        // then skip it altogether); 31: corrected equals reference
 
 __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, int one_sub_ok)
 {
@@ -604,7 +606,7 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
   for (int i = g; i < nmin && i < fd; i += 8) if (xs[i] != ys[i]) fd = i;
   for (int d = 1; d < 8; d <<= 1) fd = min(fd, __shfl_xor(fd, d, 8));
   const bool eq = a.status[w] == 0 && Lr == Lc && fd == nmin;
-  if (g == 0) { triv[w] = eq ? 1 : 0; pkey[w] = (uint8_t)(eq ? kPartBuckets - 1 : min(fd >> 3, kPartBuckets - 2)); }
+  if (g == 0) { triv[w] = eq ? 1 : 0; pkey[w] = (uint8_t)(eq ? kPartBuckets - 1 : min(fd >> 3, 14)); }
   const bool flags_only = (one_sub_ok & 2) != 0;      // k_poa builds these graphs itself, in LDS
   one_sub_ok &= 1;
   if (flags_only && eq) return;
@@ -619,7 +621,7 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
     for (int i = fd + 1 + g; i < Lr; i += 8) rest = rest && xs[i] == ys[i];
     for (int d = 1; d < 8; d <<= 1) rest = __shfl_xor(rest ? 1 : 0, d, 8) != 0 && rest;
     if (!rest) return;
-    if (flags_only) { if (g == 0) triv[w] = 2; return; }
+    if (flags_only) { if (g == 0) { triv[w] = 2; pkey[w] = (uint8_t)(16 + min(fd >> 3, 14)); } return; }
     const int e = fd, L = Lr;
     const int64_t nb = o0 + w;
     for (int i = g; i < L; i += 8) {

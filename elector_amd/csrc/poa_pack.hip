@@ -129,6 +129,13 @@ __device__ __forceinline__ uint32_t ld_moves(const uint32_t *p)
 
 __device__ __forceinline__ int pk_align_up(int x, int a) { return (x + a - 1) & ~(a - 1); }
 
+// Moves layout: [step t][64 lanes], one coalesced 256-byte row per DP step.  (A layout that keeps four steps of a
+// lane group in one 128-byte line -- [group][t / 4][lane][t % 4], written from a four-step register buffer -- halves
+// the traceback's L2 requests but costs four v_cndmask per step; the kernel is bound by VALU issue, and it was 3 %
+// slower on the bench batch.)
+template <int G>
+__device__ __forceinline__ int mv_word(int q, int t, int l) { return t * 64 + q * G + l; }
+
 template <int G>
 __device__ __forceinline__ int pk_diag_run(bool flag, int q)
 {
@@ -177,36 +184,48 @@ struct WinP {
 // ------------------------------------------------------------------ per-window phases ---
 
 // traceback of alignment #1 (align_lpo_po2.c:108-168), G cells per round (see poa_fused.hip).  Moves: bit 1 =
-// match (diagonal), bit 0 = x-insertion beats y-insertion; window half h of the word at [step][lane].
+// match (diagonal), bit 0 = x-insertion beats y-insertion; window half h of the word at [step][lane].  Both
+// windows of the lane group walk in lockstep: a round is one trip to the moves scratch (L2) for the two of them.
 template <int G, int R, typename IT>
-__device__ __forceinline__ bool traceback_a(const WinP &W, const uint32_t *mv, int h, int q, int g, IT *x2y)
+__device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&need)[2], const uint32_t *mv, int q, int g,
+                                            IT *(&x2y)[2])
 {
-  bool bad = false;
-  int x = W.Lr - 1, y = W.Lc - 1, guard = W.Lr + W.Lc + 2;
-  bool alive = W.valid && W.triv == 0;
-  while (__builtin_amdgcn_ballot_w64(alive) != 0) {
-    const int cx = x - g, cy = y - g;
-    const bool inb = alive && cx >= 0 && cy >= 0;
-    int xo = 0, yo = 0;
-    if (inb) {
-      const int rl = cy / R, rk = cy - rl * R;
-      const uint32_t two = (ld_moves(mv + (cx + 1 + rl) * 64 + q * G + rl) >> (16 * h + 2 * rk)) & 3u;
-      const int m = two >> 1, xw = two & 1;
-      xo = m | xw; yo = m | (xw ^ 1);
+  int x[2], y[2], guard[2];
+  bool alive[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { x[h] = W[h].Lr - 1; y[h] = W[h].Lc - 1; guard[h] = W[h].Lr + W[h].Lc + 2; alive[h] = need[h]; }
+  while (__builtin_amdgcn_ballot_w64(alive[0] || alive[1]) != 0) {
+    int cx[2], cy[2], rk[2];
+    bool inb[2];
+    uint32_t word[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      cx[h] = x[h] - g; cy[h] = y[h] - g;
+      inb[h] = alive[h] && cx[h] >= 0 && cy[h] >= 0;
+      const int rl = inb[h] ? cy[h] / R : 0;
+      rk[h] = cy[h] - rl * R;
+      word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(q, cx[h] + 1 + rl, rl) : 0));     // unconditional: both in flight
     }
-    const int run = pk_diag_run<G>(inb && xo && yo, q);
-    if (g < run) x2y[cx] = (IT)cy;
-    const bool stop = !inb;
-    int nx = cx - xo, ny = cy - yo, fl = stop ? 1 : 0;
-    const int src = min(run, G - 1);
-    nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
-    if (run >= G) { nx = x - G; ny = y - G; fl = 0; }
-    if (alive) {
-      x = nx; y = ny;
-      if ((fl & 1) || --guard <= 0) alive = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int xo = 0, yo = 0;
+      if (inb[h]) {
+        const uint32_t two = (word[h] >> (16 * h + 2 * rk[h])) & 3u;
+        const int m = two >> 1, xw = two & 1;
+        xo = m | xw; yo = m | (xw ^ 1);
+      }
+      const int run = pk_diag_run<G>(inb[h] && xo && yo, q);
+      if (g < run) x2y[h][cx[h]] = (IT)cy[h];
+      int nx = cx[h] - xo, ny = cy[h] - yo, fl = inb[h] ? 0 : 1;
+      const int src = min(run, G - 1);
+      nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
+      if (run >= G) { nx = x[h] - G; ny = y[h] - G; fl = 0; }
+      if (alive[h]) {
+        x[h] = nx; y[h] = ny;
+        if ((fl & 1) || --guard[h] <= 0) alive[h] = false;
+      }
     }
   }
-  return bad;
 }
 
 // fusion #1 (lpo.c:602-668 on two linear sequences) spread over the window's G lanes, as in k_fused_a; the
@@ -369,7 +388,7 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
   if (W.triv == 1) {
     for (int n = g; n < L; n += G) {
       const int fl = kFlagHasRef | kFlagHasCor | (n == 0 ? kFlagInitial : 0) | (n == L - 1 ? kFlagFinal : 0);
-      xinfo[n + 1] = ((uint32_t)xs[n] << 8) | ((uint32_t)fl << 16) | kN_NewCol | (n == 0 ? kN_Virt1 : 0u);
+      xinfo[n + 1] = ((uint32_t)xs[n] << 8) | ((uint32_t)fl << 16) | kN_NewCol;   // node 0: the virtual start is column 0, one back
     }
     W.n1 = L;
     return;
@@ -383,14 +402,13 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
       const int n = i < e ? i : i + 1;
       // after the bubble: first predecessor the reference letter's node (1 back), second the corrected letter's (2 back)
       uint32_t rec = ((uint32_t)xs[i] << 8) | ((uint32_t)(kFlagHasRef | kFlagHasCor | fl_pos) << 16) | kN_NewCol;
-      if (i == 0) rec |= kN_Virt1;
       if (i == e + 1) rec |= kN_Has2 | kN_Far2;
       xinfo[n + 1] = rec;
     } else {
       // corrected letter: predecessor one back (virtual at the window's start); opens the column
-      uint32_t rc = ((uint32_t)ys[e] << 8) | ((uint32_t)(kFlagHasCor | fl_pos) << 16) | kN_NewCol | (e == 0 ? kN_Virt1 : 0u);
+      uint32_t rc = ((uint32_t)ys[e] << 8) | ((uint32_t)(kFlagHasCor | fl_pos) << 16) | kN_NewCol;
       // reference letter: predecessor two back (the node before the bubble), same column
-      uint32_t rr = ((uint32_t)xs[e] << 8) | ((uint32_t)(kFlagHasRef | fl_pos) << 16) | kN_Far1 | kN_Far2 | (e == 0 ? kN_Virt1 : 0u);
+      uint32_t rr = ((uint32_t)xs[e] << 8) | ((uint32_t)(kFlagHasRef | fl_pos) << 16) | kN_Far1 | kN_Far2;
       xinfo[e + 1] = rc;
       xinfo[e + 2] = rr;
     }
@@ -446,44 +464,60 @@ __device__ __noinline__ int pk_columns_serial(int n1, int Lu, const uint32_t *xi
 
 
 // traceback of alignment #2 (align_lpo_po2.c:108-168), G cells per round: a cell keeps the walk on its
-// diagonal when it is a match whose chosen predecessor is the node right before it
+// diagonal when it is a match whose chosen predecessor is the node right before it.  Both windows of the lane
+// group in lockstep, as in traceback_a.
 template <int G, int R>
-__device__ __forceinline__ bool traceback_b(const WinP &W, const uint32_t *mv, int h, int q, int g, const uint32_t *xinfo,
-                                            const uint8_t *ordb, uint16_t *x2y, int bestx)
+__device__ __forceinline__ void traceback_b(const WinP (&W)[2], const uint32_t *mv, int q, int g, uint32_t *(&xinfo)[2],
+                                            uint8_t *(&ordb)[2], uint16_t *(&x2y)[2], const int (&bestx)[2],
+                                            bool (&bad)[2], int &rounds)
 {
-  bool bad = false;
-  int x = W.valid ? bestx : -1, y = W.Lu - 1, guard = W.n1 + W.Lu + 2;
-  bool alive = W.valid;
-  while (__builtin_amdgcn_ballot_w64(alive) != 0) {
-    const int cx = x - g, cy = y - g;
-    const bool inb = alive && cx >= 0 && cy >= 0;
-    int xo = 0, yo = 0, px = cx;
-    if (inb) {
-      const int rl = cy / R, rk = cy - rl * R;
-      const uint32_t rec = xinfo[cx + 1];
-      const uint32_t two = (ld_moves(mv + (cx + 1 + rl) * 64 + q * G + rl) >> (16 * h + 2 * rk)) & 3u;
-      const int m = two >> 1, xw = two & 1;
-      xo = m | xw; yo = m | (xw ^ 1);
-      if (xo) {
-        const int sec = (rec & kN_Has2) ? (ordb[(rec >> 24) * G + rl] >> rk) & 1 : 0;
-        const int far = sec ? (int)((rec >> 1) & 1u) : (int)(rec & 1u);
-        px = cx - 1 - far;                                           // < 0: the virtual start
-        if (px < -1 || (!sec && (rec & kN_Virt1))) px = -1;
+  int x[2], y[2], guard[2];
+  bool alive[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    x[h] = W[h].valid ? bestx[h] : -1; y[h] = W[h].Lu - 1; guard[h] = W[h].n1 + W[h].Lu + 2; alive[h] = W[h].valid;
+    bad[h] = false;
+  }
+  while (__builtin_amdgcn_ballot_w64(alive[0] || alive[1]) != 0) {
+    ++rounds;
+    int cx[2], cy[2], rk[2], rlv[2];
+    bool inb[2];
+    uint32_t word[2], rec[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      cx[h] = x[h] - g; cy[h] = y[h] - g;
+      inb[h] = alive[h] && cx[h] >= 0 && cy[h] >= 0;
+      const int rl = inb[h] ? cy[h] / R : 0;
+      rlv[h] = rl; rk[h] = cy[h] - rl * R;
+      word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(q, cx[h] + 1 + rl, rl) : 0));
+      rec[h] = inb[h] ? xinfo[h][cx[h] + 1] : 0u;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int xo = 0, yo = 0, px = cx[h];
+      if (inb[h]) {
+        const uint32_t two = (word[h] >> (16 * h + 2 * rk[h])) & 3u;
+        const int m = two >> 1, xw = two & 1;
+        xo = m | xw; yo = m | (xw ^ 1);
+        if (xo) {
+          const int sec = (rec[h] & kN_Has2) ? (ordb[h][(rec[h] >> 24) * G + rlv[h]] >> rk[h]) & 1 : 0;
+          const int far = sec ? (int)((rec[h] >> 1) & 1u) : (int)(rec[h] & 1u);
+          px = cx[h] - 1 - far;                                        // < 0: the virtual start
+          if (px < -1 || (!sec && (rec[h] & kN_Virt1))) px = -1;
+        }
+      }
+      const int run = pk_diag_run<G>(inb[h] && xo && yo && px == cx[h] - 1, q);
+      if (inb[h] && xo && yo && g <= run) x2y[h][cx[h]] = (uint16_t)cy[h];   // the run's pairs, and the breaker's if it is a match
+      int nx = px, ny = cy[h] - yo, fl = inb[h] ? 0 : 1;
+      const int src = min(run, G - 1);
+      nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
+      if (run >= G) { nx = x[h] - G; ny = y[h] - G; fl = 0; }
+      if (alive[h]) {
+        x[h] = nx; y[h] = ny;
+        if ((fl & 1) || --guard[h] <= 0) { if (guard[h] <= 0) bad[h] = true; alive[h] = false; }
       }
     }
-    const int run = pk_diag_run<G>(inb && xo && yo && px == cx - 1, q);
-    if (inb && xo && yo && g <= run) x2y[cx] = (uint16_t)cy;        // the run's pairs, and the breaker's if it is a match
-    const bool stop = !inb;
-    int nx = px, ny = cy - yo, fl = stop ? 1 : 0;
-    const int src = min(run, G - 1);
-    nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
-    if (run >= G) { nx = x - G; ny = y - G; fl = 0; }
-    if (alive) {
-      x = nx; y = ny;
-      if ((fl & 1) || --guard <= 0) { if (guard <= 0) bad = true; alive = false; }
-    }
   }
-  return bad;
 }
 
 // fusion #2 and the MSA columns (lpo.c:602-668 column layout rule, lpo_format.c:337-393) over the window's G
@@ -601,21 +635,19 @@ __device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *x
 
 // ------------------------------------------------------------------------ k_poa ---
 
+// window descriptor -> WinP; the loads were issued by the caller (all of both windows in flight together)
 template <int G, int R>
-__device__ __forceinline__ void load_win(WinP &W, const PackArgs &a, int64_t li, uint8_t *slot)
+__device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed, uint32_t w, int64_t o0, int64_t o1, int64_t o2,
+                                        int64_t o3, int triv, uint8_t *slot)
 {
   constexpr int RS = R * G;
   const KParams kp = a.b.kp;
-  W.valid = li < a.nlist;
-  W.w = W.valid ? a.list[li] : 0;
-  W.valid = W.valid && a.b.status[W.w] == 0 && a.done_a[W.w] == 0 && a.done_b[W.w] == 0;
-  W.o0 = 0; W.Lr = 0; W.Lc = 0; W.Lu = 0; W.n1 = 0; W.triv = 0; W.score1 = kNeg; W.k2n = 0;
-  if (W.valid) {
-    W.o0 = a.b.off[3 * (int64_t)W.w];
-    const int64_t o1 = a.b.off[3 * (int64_t)W.w + 1], o2 = a.b.off[3 * (int64_t)W.w + 2], o3 = a.b.off[3 * (int64_t)W.w + 3];
-    W.Lr = (int)(o1 - W.o0); W.Lc = (int)(o2 - o1); W.Lu = (int)(o3 - o2);
-    W.triv = a.triv ? a.triv[W.w] : 0;
-  }
+  W.valid = listed;
+  W.w = w;
+  W.o0 = listed ? o0 : 0;
+  W.Lr = listed ? (int)(o1 - o0) : 0; W.Lc = listed ? (int)(o2 - o1) : 0; W.Lu = listed ? (int)(o3 - o2) : 0;
+  W.triv = listed ? triv : 0;
+  W.n1 = 0; W.score1 = kNeg; W.k2n = 0;
   W.slot = slot;
   W.xi_cap = poa_xi_cap(W.Lr, W.Lc);
   W.off_xi = 16 + pk_align_up(W.Lu, 4);
@@ -628,7 +660,7 @@ __device__ __forceinline__ void load_win(WinP &W, const PackArgs &a, int64_t li,
 }
 
 template <int G, int R>
-__global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
+__global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NP = 64 / G;                       // pairs of windows per wave
@@ -638,40 +670,51 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
   const KParams kp = a.b.kp;
   uint8_t *chr = lds;
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
-  if (lane < 32) chr[lane] = a.b.tab->chr[lane];
 
-  WinP W[2];
-  const int64_t pi = (int64_t)blockIdx.x * NP + q;
-  bool listed[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    load_win<G, R>(W[h], a, 2 * pi + h, lds + 64 + (size_t)(2 * q + h) * a.slot_bytes);
-    listed[h] = 2 * pi + h < a.nlist && a.b.status[W[h].w] == 0 && a.done_b[W[h].w] == 0 && a.done_a[W[h].w] == 0;
-  }
-  // a listed window this kernel cannot take (slot, rows, score range) goes to the two-kernel path at once
-#pragma unroll
-  for (int h = 0; h < 2; ++h) if (listed[h] && !W[h].valid && g == 0) a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
-  if (__builtin_amdgcn_ballot_w64(W[0].valid || W[1].valid) == 0) return;
   // Moves scratch.  The moves of a wave are dead when it ends, so the scratch is a pool of slots as large as the
   // number of waves that can be resident, not one region per block: the same few dozen megabytes are written and
   // read back over and over and stay in L2 / Infinity Cache instead of streaming through HBM.  The per-XCD L2s
   // are not coherent with each other, so a slot is only ever used from one XCD: the pool is split by XCC id, and
   // every XCD has a queue of its free slot ids -- a wave takes the id at its ticket (head), gives it back at the
   // end (tail).  There are more slots than an XCD can hold waves, so a ticket's entry is filled by the time it
-  // is drawn or shortly after.
+  // is drawn or shortly after.  The ticket is drawn first thing: its trip to L2 runs beside the descriptor loads.
   uint32_t xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
-  int mslot = 0;
   int32_t *mvq = a.mv_q + (size_t)xcc * kPoolStride;
-  if (a.mv_slots <= 0) { xcc = 0; mslot = (int)blockIdx.x; }          // experiment: one scratch region per block
-  else if (lane == 0) {
-    const uint32_t t = (uint32_t)atomicAdd(mvq, 1);
-    int32_t *e = mvq + 32 + t % (uint32_t)a.mv_slots;
-    while ((mslot = atomicExch(e, -1)) < 0) __builtin_amdgcn_s_sleep(2);
+  uint32_t ticket = 0;
+  if (a.mv_slots > 0 && lane == 0) ticket = (uint32_t)atomicAdd(mvq, 1);
+
+  // ---- the descriptors of both windows: one trip for the list entries, one for everything that hangs on them ----
+  WinP W[2];
+  const int64_t pi = (int64_t)blockIdx.x * NP + q;
+  {
+    bool inl[2];
+    uint32_t w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { inl[h] = 2 * pi + h < a.nlist; w[h] = a.list[inl[h] ? 2 * pi + h : 0]; }
+    const uint8_t chr_l = a.b.tab->chr[lane & 31];
+    int st[2], da[2], db[2], tv[2];
+    int64_t o[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (!inl[h]) w[h] = 0;
+      st[h] = a.b.status[w[h]]; da[h] = a.done_a[w[h]]; db[h] = a.done_b[w[h]];
+      tv[h] = a.triv ? a.triv[w[h]] : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[h][k] = a.b.off[3 * (int64_t)w[h] + k];
+    }
+    if (lane < 32) chr[lane] = chr_l;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool listed = inl[h] & (st[h] == 0) & (da[h] == 0) & (db[h] == 0);
+      fit_win<G, R>(W[h], a, listed, w[h], o[h][0], o[h][1], o[h][2], o[h][3], tv[h], lds + 64 + (size_t)(2 * q + h) * a.slot_bytes);
+      // a listed window this kernel cannot take (slot, rows, score range) goes to the two-kernel path at once
+      if (listed && !W[h].valid && g == 0) a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
+    }
   }
-  mslot = __builtin_amdgcn_readfirstlane(mslot);
-  uint32_t *mv = a.mv_pool + ((size_t)xcc * (a.mv_slots > 0 ? a.mv_slots : 0) + mslot) * (size_t)a.mv_tw * 64;
+  const bool any_valid = __builtin_amdgcn_ballot_w64(W[0].valid || W[1].valid) != 0;
+  PK_STAMP(8);
 
   uint8_t *us[2], *U[2];
   uint32_t *xinfo[2];
@@ -682,25 +725,65 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
     U[h] = W[h].slot + W[h].off_u;
   }
   // ---- staging: the three symbol strings of both windows (contiguous in HBM; reference + corrected go to the
-  // union region, the uncorrected string to its own place); eight loads in flight per lane ----
+  // union region, the uncorrected string to its own place) as aligned dwords, all loads of a round of both
+  // windows in flight together ----
+  if (any_valid) {
+    constexpr int UB = G == 8 ? 8 : 4;                          // dwords per lane, window and round
+    const uint32_t *src4[2];
+    int mis[2], nrc[2], ntot[2], nd = 0;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint8_t *src = a.b.sym + W[h].o0;
-    const int nrc = W[h].Lr + W[h].Lc, ntot = W[h].valid ? nrc + W[h].Lu : 0;
-    int nmax = ntot;
-    for (int d = G; d < 64; d <<= 1) nmax = max(nmax, __shfl_xor(nmax, d));
-    nmax = __builtin_amdgcn_readfirstlane(nmax);
-    for (int ib = g; ib < nmax; ib += 8 * G) {
-      uint8_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = ib + u * G; v[u] = i < ntot ? src[i] : (uint8_t)0; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = ib + u * G;
-        if (i < nrc) U[h][i] = v[u];
-        else if (i < ntot) us[h][i - nrc] = v[u];
-      }
+    for (int h = 0; h < 2; ++h) {
+      const uint8_t *src = a.b.sym + W[h].o0;
+      mis[h] = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
+      src4[h] = reinterpret_cast<const uint32_t *>(src - mis[h]);
+      nrc[h] = W[h].Lr + W[h].Lc;
+      ntot[h] = W[h].valid ? nrc[h] + W[h].Lu : 0;
+      nd = max(nd, W[h].valid ? (mis[h] + ntot[h] + 3) >> 2 : 0);
     }
+    for (int d = G; d < 64; d <<= 1) nd = max(nd, __shfl_xor(nd, d));
+    nd = __builtin_amdgcn_readfirstlane(nd);
+    for (int kb = 0; kb < nd; kb += UB * G) {
+      uint32_t v[2][UB];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k = kb + g + u * G;
+          v[h][u] = 4 * k < mis[h] + ntot[h] ? src4[h][k] : 0u;       // d_sym is padded: the last dword may reach past the window
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k = kb + g + u * G;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int i = 4 * k + b - mis[h];
+            const uint8_t ch = (uint8_t)(v[h][u] >> (8 * b));
+            if (i >= 0 && i < nrc[h]) U[h][i] = ch;
+            else if (i >= nrc[h] && i < ntot[h]) us[h][i - nrc[h]] = ch;
+          }
+        }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  PK_STAMP(9);
+  int mslot = 0;
+  if (a.mv_slots <= 0) { xcc = 0; mslot = (int)blockIdx.x; }          // experiment: one scratch region per block
+  else if (lane == 0) {
+    int32_t *e = mvq + 32 + ticket % (uint32_t)a.mv_slots;
+    while ((mslot = atomicExch(e, -1)) < 0) __builtin_amdgcn_s_sleep(2);
+  }
+  mslot = __builtin_amdgcn_readfirstlane(mslot);
+  PK_STAMP(10);
+  uint32_t *mv = a.mv_pool + ((size_t)xcc * (a.mv_slots > 0 ? a.mv_slots : 0) + mslot) * (size_t)a.mv_tw * 64;
+  if (!any_valid) {                                                    // nothing for this wave: the slot goes straight back
+    if (lane == 0 && a.mv_slots > 0) {
+      const uint32_t t = (uint32_t)atomicAdd(mvq + 16, 1);
+      int32_t *e = mvq + 32 + t % (uint32_t)a.mv_slots;
+      while (atomicCAS(e, -1, mslot) != -1) __builtin_amdgcn_s_sleep(2);
+    }
+    return;
   }
   __syncthreads();
   PK_STAMP(0);
@@ -785,10 +868,10 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
     if (needA[h]) for (int i = g; i < W[h].Lr; i += G) x2y[i] = (IT)~(IT)0;
   }
   __syncthreads();
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
-    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0) traceback_a<G, R, IT>(W[h], mv, h, q, g, x2y);
+  {
+    IT *x2ya[2] = {reinterpret_cast<IT *>(U[0] + pk_align_up(W[0].Lr + W[0].Lc, 4)),
+                         reinterpret_cast<IT *>(U[1] + pk_align_up(W[1].Lr + W[1].Lc, 4))};
+    traceback_a<G, R, IT>(W, needA, mv, q, g, x2ya);
   }
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(2);
@@ -876,6 +959,7 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
     uint32_t xiA_next = (W[0].valid && g == 0 && W[0].n1 >= 1) ? xinfo[0][1] : 0u;
     uint32_t xiB_next = (W[1].valid && g == 0 && W[1].n1 >= 1) ? xinfo[1][1] : 0u;
 
+    int n_steps = 0, n_two = 0, n_virt = 0;                        // debug: steps per code path
     auto step = [&](int t, uint32_t (&Sa)[R], uint32_t (&Ea)[R], uint32_t (&Sb)[R], uint32_t (&Eb)[R]) {
       const int jj = t - g;
       const uint32_t xiA = xiA_next, xiB = xiB_next;
@@ -883,26 +967,33 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
       xiB_next = (W[1].valid && jj >= 0 && jj < W[1].n1) ? xinfo[1][jj + 1] : 0u;
       // per-half select masks: predecessor two columns back (else one)
       const uint32_t M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
-      const uint32_t M2 = bfi(0xFFFFu, 0u - ((xiA >> 1) & 1u), 0u - ((xiB >> 1) & 1u));
       const uint32_t xlp = ((xiA >> 8) & 0xFFu) | ((xiB << 8) & 0xFF0000u);
       const bool virt = __builtin_amdgcn_ballot_w64(((xiA | xiB) & kN_Virt1) != 0u) != 0;
       const bool two = virt || __builtin_amdgcn_ballot_w64(((xiA | xiB) & kN_Has2) != 0u) != 0;
-      uint32_t V1 = 0, V2 = 0, bb1 = bfi(M1, BE2, BE1), bb2 = bfi(M2, BE2, BE1);
-      if (virt) {
-        V1 = bfi(0xFFFFu, 0u - ((xiA >> 3) & 1u), 0u - ((xiB >> 3) & 1u));
-        // a node without a second predecessor repeats the first: the repeat is virtual too
-        V2 = V1 & ~bfi(0xFFFFu, 0u - ((xiA >> 2) & 1u), 0u - ((xiB >> 2) & 1u));
-        bb1 = bfi(V1, KOPENNEG, bb1);
-        bb2 = bfi(V2, KOPENNEG, bb2);
+      // a node without a second predecessor repeats the first (bit 1 = bit 0): when no lane of the wave has one,
+      // everything about the second candidate is left out
+      uint32_t M2 = M1, V1 = 0, V2 = 0, bb1 = bfi(M1, BE2, BE1);
+      uint32_t BRj = bb1;
+      if (two) {
+        M2 = bfi(0xFFFFu, 0u - ((xiA >> 1) & 1u), 0u - ((xiB >> 1) & 1u));
+        uint32_t bb2 = bfi(M2, BE2, BE1);
+        if (virt) {
+          V1 = bfi(0xFFFFu, 0u - ((xiA >> 3) & 1u), 0u - ((xiB >> 3) & 1u));
+          // the repeat of a virtual first predecessor is virtual too
+          V2 = V1 & ~bfi(0xFFFFu, 0u - ((xiA >> 2) & 1u), 0u - ((xiB >> 2) & 1u));
+          bb1 = bfi(V1, KOPENNEG, bb1);
+          bb2 = bfi(V2, KOPENNEG, bb2);
+        }
+        BRj = pk_max(bb1, bb2);
       }
-      const uint32_t BRj = pk_max(bb1, bb2);
       const uint32_t BEj = pk_subk(BRj, KEXT);
       const uint32_t up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);        // row above at column jj - 1
       const uint32_t up2 = pk_shift_in<G>(BR2, last3, g);            // ... at column jj - 2
       const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
       if (jj >= 1) {                                                 // before its first column a lane keeps column 0
         const uint32_t sv3 = Sb[R - 1];
-        uint32_t dt1 = bfi(M1, up2, up1), dt2 = bfi(M2, up2, up1), insY = upE, mvw = 0, secw = 0;
+        uint32_t dt1 = bfi(M1, up2, up1), dt2 = dt1, insY = upE, mvw = 0, secw = 0;
+        if (two) dt2 = bfi(M2, up2, up1);
         if (virt) { dt1 = bfi(V1, colAbove, dt1); dt2 = bfi(V2, colAbove, dt2); }
         auto cells = [&](auto two_tag, auto virt_tag) {
           constexpr bool TWO = decltype(two_tag)::value, VIRT = decltype(virt_tag)::value;
@@ -943,6 +1034,7 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
             Sb[k] = Sn; Eb[k] = En; insY = En;
           }
         };
+        if (a.debug & 4) { ++n_steps; n_two += two && !virt; n_virt += virt; }
         if (virt) cells(std::true_type{}, std::true_type{});
         else if (two) cells(std::true_type{}, std::false_type{});
         else cells(std::false_type{}, std::false_type{});
@@ -969,6 +1061,11 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
       step(t, S1, E1, S2, E2);
       step(t + 1, S2, E2, S1, E1);
     }
+    if ((a.debug & 4) && threadIdx.x == 0) {
+      atomicAdd(a.stamps + 12, (unsigned long long)n_steps);
+      atomicAdd(a.stamps + 13, (unsigned long long)n_two);
+      atomicAdd(a.stamps + 14, (unsigned long long)n_virt);
+    }
   }
   PK_STAMP(5);
   // best end cell to every lane of the group
@@ -981,10 +1078,9 @@ __global__ void __launch_bounds__(64, 3) k_poa(PackArgs a)
   }
   __syncthreads();
   bool badb[2] = {false, false};
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-    if (__builtin_amdgcn_ballot_w64(W[h].valid) != 0)
-      badb[h] = traceback_b<G, R>(W[h], mv, h, q, g, xinfo[h], ordb[h], x2yb[h], bestx[h]);
+  int tb_rounds = 0;
+  traceback_b<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);
+  if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 11, (unsigned long long)tb_rounds);
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(6);
 #pragma unroll
