@@ -43,9 +43,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# VALU issue peak: 256 CUs x 4 SIMD-32 per CU, one wave64 VALU instruction per 2 cycles per SIMD when
-# more than one wave shares it (MI355X_MICROARCH.md "Each CU has 4 SIMD-32 units"), 2.4 GHz
-VALU_PEAK_GINSTS = 256 * 4 * 2.4 / 2
+# VALU issue peaks, G wave64-instructions per second for the chip: 256 CUs x 4 SIMDs x 2.4 GHz.  A SIMD takes one
+# plain two-operand 32-bit instruction (v_add_u32 ...) every 2 cycles when two or more waves share it, but the
+# instructions k_poa is made of -- packed 16-bit (v_pk_max_i16, v_pk_sub_i16, v_pk_mad_i16, v_pk_min_u16),
+# three-operand (v_bfi_b32, v_lshl_or_b32) and DPP moves -- one every 4 cycles, however many waves there are
+# (tests/micro/valu_rate.hip on this GPU, profiles/r02_valu_rate.txt: 950 G/s for v_add_u32, 565-590 G/s for each
+# of the others at 4-8 waves per SIMD).  The kernel is priced against the 4-cycle peak.
+VALU_PEAK_GINSTS_SIMPLE = 256 * 4 * 2.4 / 2
+VALU_PEAK_GINSTS = 256 * 4 * 2.4 / 4
 WORKLOADS = {   # BASELINE.json configs restated as synthetic profiles (elector_amd/synthetic.py)
     "ecoli30x_simlord_lordec": "E. coli 30X SimLord-like PacBio (15% err), LoRDEC-like corrected (1% err), ~8 kb reads",
     "yeast50x_nanosim_consent": "S. cerevisiae 50X NanoSim-like ONT (12% err), CONSENT-like corrected (2% err), ~8 kb reads, whole corrected reads",
@@ -400,6 +405,9 @@ def main():
             # step from the committed PMC passes of this command, time measured live
             "roofline_valu": None if valu is None else {
                 "bound": "valu-issue", "wave_insts_per_step": valu, "peak": round(VALU_PEAK_GINSTS, 1),
+                "peak_two_operand_32bit": round(VALU_PEAK_GINSTS_SIMPLE, 1),
+                "peak_note": "packed 16-bit, three-operand and DPP instructions issue once per 4 cycles per SIMD "
+                             "(measured: tests/micro/valu_rate.hip, profiles/r02_valu_rate.txt)",
                 "unit": "G wave-insts/s per GPU",
                 "achieved": round(valu / step_s / 1e9, 1),
                 "frac": round(valu / step_s / 1e9 / VALU_PEAK_GINSTS, 4)},

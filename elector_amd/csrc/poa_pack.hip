@@ -787,6 +787,8 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
   }
   __syncthreads();
   PK_STAMP(0);
+  // instruction-count experiments (debug bits 32 .. 256): drop the windows after a phase, the rest of the kernel idles
+  if (a.debug & 32) { W[0].valid = W[1].valid = false; }
 
   // packed constants (both halves alike)
   const uint32_t ONES = 0x00010001u;
@@ -886,6 +888,7 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
   }
   __syncthreads();
   PK_STAMP(3);
+  if (a.debug & 64) { W[0].valid = W[1].valid = false; }
 
   // ---- ordinals of the two-predecessor nodes (they own a row of ordinal bytes); final fit check ----
 #pragma unroll
@@ -1068,6 +1071,7 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
     }
   }
   PK_STAMP(5);
+  if (a.debug & 128) { W[0].valid = W[1].valid = false; }
   // best end cell to every lane of the group
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1083,6 +1087,7 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
   if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 11, (unsigned long long)tb_rounds);
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(6);
+  if (a.debug & 256) { W[0].valid = W[1].valid = false; }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (__builtin_amdgcn_ballot_w64(W[h].valid) == 0) continue;

@@ -12,5 +12,5 @@ python bench.py --profile chr1_20x_ont_50kb --reads 2000 --steps 30 --no-cpu-bas
 python bench.py --serial --steps 20 --no-cpu-baseline > $O/bench_serial.json 2> $O/bench_serial.err || exit 5
 export TMPDIR=/tmp
 R=$PWD
-( cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$O/prof_serial -o serial -- python3 $R/bench.py --serial --steps 20 --no-cpu-baseline > $R/$O/prof_serial.json 2> $R/$O/prof_serial.err ) || exit 6
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_serial -o serial -- python3 $R/bench.py --serial --steps 20 --no-cpu-baseline > $R/$O/prof_serial.json 2> $R/$O/prof_serial.err ) || exit 6
 ls -R $O | head -40
