@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--end-to-end", action="store_true",
                     help="three FASTA files -> getPOA -> outputRecallPrecision with a stage table (see bench_e2e.py)")
+    if "--end-to-end" in sys.argv[1:]:              # bench_e2e.py has options of its own (--reference-sample, --no-reference)
+        return ap.parse_known_args()[0]
     return ap.parse_args()
 
 
@@ -252,6 +254,9 @@ def main():
     from elector_amd import distributed as edist
     from elector_amd._capi import ES_NCOUNTERS
 
+    # every step gathers the same number of counter rows per rank (one per piece of the rank's batch): the ranks
+    # tell each other once, the steps then need one collective each
+    gather_sizes = edist.gather_sizes(len(piece_first) - 1) if world > 1 else None
     pending = []
     turn = [0]
 
@@ -259,7 +264,7 @@ def main():
         """per-piece counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
         e, npieces = pending.pop(0)
         counters, _ = engines[e].msa_stats_collect(npieces)
-        return edist.gather_rows(counters) if world > 1 else counters
+        return edist.gather_rows(counters, sizes=gather_sizes) if world > 1 else counters
 
     def step():
         """Queue one step (windows in HBM -> POA kernels -> merge -> counters -> pinned host memory),

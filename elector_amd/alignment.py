@@ -10,7 +10,7 @@ bytes.  Where the reference spawns `masterSplitter`, 200 `poa` processes and 200
 (alignment.py:98-129), a batch here never leaves memory, and the bulk of it never
 leaves the GPU:
 
-    reader thread   three FASTA files -> batches of reads -> HBM -> windows (elector_split_reads_device: one
+    reader thread   three FASTA files -> batches of reads (elector_reads_next) -> HBM -> windows (elector_split_reads_device: one
                     workgroup per read on a splitter context of its own; ELECTOR_HOST_SPLIT=1 keeps the host
                     threads of elector_split_reads instead)
     main thread     windows (already in HBM) -> triplet MSAs (elector_poa_batch_device) -> one record per piece
@@ -120,8 +120,7 @@ def _donatello_header(h):
 class _Batch:
     """One processing batch: reads, their msa.fa header lines, and where its first read stands in the
     reference's own batch protocol."""
-    __slots__ = ("reads", "headers", "out_hdr", "first_index", "win", "piece_first", "read_first", "rec_hdr",
-                 "small", "wrong", "last", "d_bases")
+    __slots__ = ("first_index", "win", "piece_first", "read_first", "rec_hdr", "small", "wrong", "last", "d_bases")
 
 
 def _triples(reference, uncorrected, corrected, start=0, stop=None):
@@ -163,25 +162,26 @@ def _batches(reference, uncorrected, corrected, start=0, stop=None):
         yield first, cur, cur_hdr
 
 
-def _prepare(first_index, reads, headers, size_threshold, threads, splitter=None):
-    """Reader half of a batch: windows, record boundaries (Donatello's same-header rule), read boundaries."""
+def _prepare(rb, size_threshold, threads, splitter=None):
+    """Reader half of a batch (rb: split.ReadBatch): windows, record boundaries (Donatello's same-header rule),
+    read boundaries."""
     import time
     b = _Batch()
-    b.reads, b.headers, b.first_index = reads, headers, first_index
+    b.first_index = first_index = rb.first_index
     t0 = time.perf_counter()
     b.d_bases = None
     if splitter is not None:
-        win = split.split_reads_device(splitter, reads, size_threshold, headers, nthreads=max(1, int(threads)))
+        win = split.split_packed_device(splitter, rb.seq, rb.seq_off, rb.hdr_len, size_threshold, nthreads=max(1, int(threads)))
         # out of the splitter's workspace, which its next call reuses
         b.d_bases = win.d_bases.to_tensor() if isinstance(win.d_bases, split.DevBases) else win.d_bases
         win.d_bases = None
         _tick("split (device, incl. reads H2D)", t0)
     else:
-        win = split.split_reads(reads, size_threshold, headers, nthreads=max(1, int(threads)))
+        win = split.split_packed(rb.seq, rb.seq_off, rb.hdr_len, size_threshold, nthreads=max(1, int(threads)))
         _tick("split (host threads)", t0)
     t0 = time.perf_counter()
     b.win, b.small, b.wrong = win, win.small_reads, win.wrong_reads
-    hdr = [_poa_header(headers[int(i)]) for i in win.read_index]
+    hdr = [_poa_header(rb.header(int(i))) for i in win.read_index]
     # Donatello concatenates consecutive windows with the same header inside one slot file
     # (Donatello.cpp:61-84); the slot is the read's position in its reference batch // 51
     # (Master_Splitter.cpp:366-369,435).  win.read_index = position in this processing batch.
@@ -286,11 +286,17 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     def reader():
         import time
         try:
-            t0 = time.perf_counter()
-            for first, reads, headers in _batches(reference, uncorrected, corrected, start, stop):
-                _tick("parse FASTA (reader thread)", t0)
-                work.put(_prepare(first, reads, headers, SIZE_CORRECTED_READ_THRESHOLD, threads, splitter))
-                t0 = time.perf_counter()
+            rf = split.ReadsFile(reference, uncorrected, corrected)
+            try:
+                while True:
+                    t0 = time.perf_counter()
+                    rb = rf.next(READS_PER_BATCH, start, stop)
+                    _tick("parse FASTA (reader thread, native)", t0)
+                    if rb is None:
+                        break
+                    work.put(_prepare(rb, SIZE_CORRECTED_READ_THRESHOLD, threads, splitter))
+            finally:
+                rf.close()
         except BaseException as e:           # noqa: BLE001 -- handed to the main thread
             failure.append(e)
         work.put(None)
@@ -325,18 +331,11 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             drop[np.unique(np.searchsorted(b.piece_first, bad, side="right") - 1)] = True
             skipped += int(drop.sum())
             cache_ok = False                       # the counters of a read's other pieces saw the dropped one
-        rows = eng.msa_rows_fetch(piece_cols).tobytes()
-        _tick("merged rows D2H", t0)
-        t0 = time.perf_counter()
-        at = 0
-        for p in range(npieces):
-            nc = int(piece_cols[p])
-            if not drop[p]:
-                h = b.rec_hdr[p]
-                out.write(h + b"\n" + rows[at:at + nc] + b"\n" + h + b"\n" + rows[at + nc:at + 2 * nc] + b"\n" +
-                          h + b"\n" + rows[at + 2 * nc:at + 3 * nc] + b"\n")
-            at += 3 * nc
-        _tick("write msa.fa", t0)
+        # merged rows -> pinned host memory -> Donatello's records -> the file, in the library
+        out.flush()
+        split.msa_records_write(eng, piece_cols, b.rec_hdr, drop if drop.any() else None, out.fileno(),
+                                nthreads=max(1, min(16, int(threads))))
+        _tick("merged rows D2H + write msa.fa (native)", t0)
         all_hdr.extend(b.rec_hdr)
         all_cols.append(piece_cols)
         all_counters.append(counters)

@@ -97,6 +97,8 @@ struct elector_ctx {
   // are queued behind the previous batch's kernels, so the host may already prepare the next batch
   // while they are pending; a buffer is rewritten only after its copies have run (h_meta_done)
   elector::HostPinned h_meta_buf[2];
+  elector::HostPinned h_rows;          // merged rows on their way to msa.fa (elector_msa_records_write)
+  std::vector<uint8_t> h_text;         // ... and the formatted records
   hipEvent_t h_meta_done[2] = {nullptr, nullptr};
   int h_meta_cur = 0;
   // statistics workspace

@@ -1,0 +1,320 @@
+// io_host.cpp -- the file ends of call site #1 in native code: the three FASTA files in, msa.fa records out.
+//
+//   elector_reads_open / _next / _close   the record loop of masterSplitter (Master_Splitter.cpp:396-446: two
+//                                         getline calls per record and file, :414 records whose reference has
+//                                         fewer than 3 bases are skipped without counting) cut into processing
+//                                         batches by the rule of elector_amd/alignment.py (at least min_records
+//                                         records, extended to the end of the last read = run of records with one
+//                                         msa.fa header line, Donatello.cpp:61-84 / computeStats.py:45-56)
+//   elector_msa_format                    the records Donatello appends to msa.fa (Donatello.cpp:61-93: header
+//                                         line and row, three times per piece)
+//
+// Host-only, no GPU: plain C ABI (include/elector_split.h).
+#include "elector_split.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <sys/mman.h>
+
+namespace {
+
+// growable byte buffer for a batch's sequences: anonymous mapping that asks for huge pages (a fresh 250 MB batch
+// buffer otherwise costs 60,000 page faults, more than reading the files) and grows in place where it can
+struct BigBuf {
+  char *p = nullptr;
+  size_t n = 0, cap = 0;
+  ~BigBuf() { if (p) ::munmap(p, cap); }
+  bool reserve(size_t want)
+  {
+    if (want <= cap) return true;
+    size_t nc = std::max<size_t>(std::max(want, cap * 2), (size_t)32 << 20);
+    nc = (nc + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void *q = cap ? ::mremap(p, cap, nc, MREMAP_MAYMOVE)
+                  : ::mmap(nullptr, nc, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (q == MAP_FAILED) return false;
+    (void)::madvise(q, nc, MADV_HUGEPAGE);
+    p = static_cast<char *>(q);
+    cap = nc;
+    return true;
+  }
+  bool append(const char *a, size_t len)
+  {
+    if (n + len > cap && !reserve(n + len)) return false;
+    std::memcpy(p + n, a, len);
+    n += len;
+    return true;
+  }
+  size_t size() const { return n; }
+  void resize(size_t m) { n = m; }              // shrink only
+  void clear() { n = 0; }
+  char *data() { return p; }
+};
+
+struct LineFile {
+  FILE *f = nullptr;
+  std::vector<char> buf;
+  size_t pos = 0, end = 0;
+  bool eof = false, oom = false;
+  bool open(const char *path)
+  {
+    f = std::fopen(path, "rb");
+    buf.resize(8u << 20);
+    return f != nullptr;
+  }
+  void close() { if (f) std::fclose(f); f = nullptr; }
+  // one line without its '\n' appended to out; false at end of file (python's readline() returning b"")
+  template <class Buf>
+  bool append_line(Buf &out)
+  {
+    bool any = false;
+    for (;;) {
+      if (pos == end) {
+        if (eof) return any;
+        end = std::fread(buf.data(), 1, buf.size(), f);
+        pos = 0;
+        if (end == 0) { eof = true; return any; }
+      }
+      const char *p = buf.data() + pos;
+      const char *nl = static_cast<const char *>(std::memchr(p, '\n', end - pos));
+      if (nl) {
+        if (!out.append(p, (size_t)(nl - p))) { oom = true; return false; }
+        pos = (size_t)(nl - buf.data()) + 1;
+        return true;
+      }
+      if (!out.append(p, end - pos)) { oom = true; return false; }
+      any = true;
+      pos = end;
+    }
+  }
+  bool skip_line()
+  {
+    bool any = false;
+    for (;;) {
+      if (pos == end) {
+        if (eof) return any;
+        end = std::fread(buf.data(), 1, buf.size(), f);
+        pos = 0;
+        if (end == 0) { eof = true; return any; }
+      }
+      const char *p = buf.data() + pos;
+      const char *nl = static_cast<const char *>(std::memchr(p, '\n', end - pos));
+      if (nl) { pos = (size_t)(nl - buf.data()) + 1; return true; }
+      any = true;
+      pos = end;
+    }
+  }
+};
+
+inline bool is_space(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+// the header line Donatello keeps for a window whose FASTA header line is h: `poa` prints '>name title' with
+// "untitled" for an empty title (fasta_format.c:33-37, lpo_format.c:410), Donatello drops the last 11 bytes
+// when there are that many and appends a blank (Donatello.cpp:71-73).  elector_amd/alignment.py:_poa_header,
+// _donatello_header.
+void record_key(const std::string &h, std::string &key)
+{
+  size_t i = h.empty() ? 0 : 1;
+  while (i < h.size() && is_space((unsigned char)h[i])) ++i;
+  size_t j = i;
+  while (j < h.size() && !is_space((unsigned char)h[j])) ++j;
+  size_t r = j;
+  while (r < h.size() && is_space((unsigned char)h[r])) ++r;
+  key.assign(">");
+  key.append(h, i, j - i);
+  key.push_back(' ');
+  if (r < h.size()) key.append(h, r, std::string::npos); else key.append("untitled");
+  if (key.size() >= 11) key.resize(key.size() - 11);
+  key.push_back(' ');
+}
+
+// key of a header line held in a buffer
+void record_key(const char *h, size_t n, std::string &key)
+{
+  const std::string tmp(h, n);
+  record_key(tmp, key);
+}
+
+struct Reader {
+  LineFile ref, unc, cor;
+  int64_t k = 0;              // kept records read so far
+  bool done = false;
+  // the batch under construction / handed out (owned here, valid until the next call); a record read ahead of
+  // the batch's end stays at the tail of the buffers and opens the next batch
+  BigBuf seq, hdr;
+  std::vector<int64_t> seq_off, hdr_off;
+  bool has_pending = false;
+  std::string last_key, key;
+  // appends the next kept record to the buffers; false at the end of any of the three files
+  bool next()
+  {
+    for (;;) {
+      const size_t s0 = seq.size(), h0 = hdr.size();
+      if (!ref.append_line(hdr)) return false;
+      ref.append_line(seq);                         // python: a header line without a sequence line gives an empty sequence
+      if (seq.size() - s0 <= 2) {                   // Master_Splitter.cpp:414 -- skipped without counting; the other
+        seq.resize(s0); hdr.resize(h0);             // two files advance by one record all the same
+        if (!unc.skip_line()) return false;
+        unc.skip_line();
+        if (!cor.skip_line()) return false;
+        cor.skip_line();
+        continue;
+      }
+      const size_t s1 = seq.size();
+      bool ok = unc.skip_line();
+      if (ok) { unc.append_line(seq); }
+      const size_t s2 = seq.size();
+      if (ok) { ok = cor.skip_line(); if (ok) cor.append_line(seq); }
+      if (!ok) { seq.resize(s0); hdr.resize(h0); return false; }
+      seq_off.push_back((int64_t)s1); seq_off.push_back((int64_t)s2); seq_off.push_back((int64_t)seq.size());
+      hdr_off.push_back((int64_t)hdr.size());
+      return true;
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" int elector_reads_open(const char *reference, const char *uncorrected, const char *corrected, void **handle)
+{
+  if (!reference || !uncorrected || !corrected || !handle) return ELECTOR_E_INVAL;
+  Reader *rd = new (std::nothrow) Reader();
+  if (!rd) return ELECTOR_E_NOMEM;
+  if (!rd->ref.open(reference) || !rd->unc.open(uncorrected) || !rd->cor.open(corrected)) {
+    rd->ref.close(); rd->unc.close(); rd->cor.close();
+    delete rd;
+    return ELECTOR_E_INVAL;
+  }
+  rd->seq_off.push_back(0); rd->hdr_off.push_back(0);
+  *handle = rd;
+  return ELECTOR_OK;
+}
+
+extern "C" void elector_reads_close(void *handle)
+{
+  Reader *rd = static_cast<Reader *>(handle);
+  if (!rd) return;
+  rd->ref.close(); rd->unc.close(); rd->cor.close();
+  delete rd;
+}
+
+extern "C" int elector_reads_next(void *handle, int64_t min_records, int64_t start, int64_t stop, elector_reads *out)
+{
+  Reader *rd = static_cast<Reader *>(handle);
+  if (!rd || !out || min_records < 1) return ELECTOR_E_INVAL;
+  std::memset(out, 0, sizeof *out);
+  // drop the batch handed out last time; the record read ahead (if any) moves to the front
+  {
+    const size_t nrec = rd->hdr_off.size() - 1;
+    if (rd->has_pending && nrec >= 1) {
+      const int64_t s0 = rd->seq_off[3 * (nrec - 1)], h0 = rd->hdr_off[nrec - 1];
+      const int64_t so[3] = {rd->seq_off[3 * nrec - 2] - s0, rd->seq_off[3 * nrec - 1] - s0, rd->seq_off[3 * nrec] - s0};
+      const int64_t hl = rd->hdr_off[nrec] - h0;
+      std::memmove(rd->seq.data(), rd->seq.data() + s0, (size_t)so[2]);
+      std::memmove(rd->hdr.data(), rd->hdr.data() + h0, (size_t)hl);
+      rd->seq.resize((size_t)so[2]); rd->hdr.resize((size_t)hl);
+      rd->seq_off.assign({0, so[0], so[1], so[2]});
+      rd->hdr_off.assign({0, hl});
+    } else {
+      rd->seq.clear(); rd->hdr.clear();
+      rd->seq_off.assign(1, 0); rd->hdr_off.assign(1, 0);
+      rd->has_pending = false;
+    }
+  }
+  if (rd->done && !rd->has_pending) return ELECTOR_OK;
+  int64_t n = 0, first = -1;
+  bool ended = rd->done;
+  for (;;) {
+    int64_t index;
+    if (rd->has_pending) { rd->has_pending = false; index = rd->k - 1; }
+    else {
+      if (ended || !rd->next()) { ended = true; break; }
+      index = rd->k++;
+    }
+    auto drop_last = [&]() {
+      const size_t nrec = rd->hdr_off.size() - 1;
+      rd->seq.resize((size_t)rd->seq_off[3 * (nrec - 1)]); rd->hdr.resize((size_t)rd->hdr_off[nrec - 1]);
+      rd->seq_off.resize(3 * (nrec - 1) + 1); rd->hdr_off.resize(nrec);
+    };
+    if (stop >= 0 && index >= stop) { drop_last(); ended = true; break; }
+    if (index < start) { drop_last(); continue; }
+    const size_t nrec = rd->hdr_off.size() - 1;
+    record_key(rd->hdr.data() + rd->hdr_off[nrec - 1], (size_t)(rd->hdr_off[nrec] - rd->hdr_off[nrec - 1]), rd->key);
+    if (n >= min_records && rd->key != rd->last_key) {       // the batch ends before this record
+      rd->has_pending = true;
+      break;
+    }
+    if (first < 0) first = index;
+    ++n;
+    rd->last_key = rd->key;
+  }
+  if (ended) rd->done = true;
+  if (rd->ref.oom || rd->unc.oom || rd->cor.oom) return ELECTOR_E_NOMEM;
+  out->n = n;
+  out->first_index = first < 0 ? 0 : first;
+  out->seq = reinterpret_cast<uint8_t *>(rd->seq.data());
+  out->seq_off = rd->seq_off.data();
+  out->hdr = reinterpret_cast<uint8_t *>(rd->hdr.data());
+  out->hdr_off = rd->hdr_off.data();
+  return ELECTOR_OK;
+}
+
+// bytes of the records of the pieces that are not dropped
+static int64_t records_bytes(int64_t n, const int64_t *cols, const int64_t *hdr_off, const uint8_t *drop)
+{
+  int64_t t = 0;
+  for (int64_t p = 0; p < n; ++p)
+    if (!drop || !drop[p]) t += 3 * ((hdr_off[p + 1] - hdr_off[p]) + 1 + cols[p] + 1);
+  return t;
+}
+
+extern "C" int64_t elector_msa_format(int64_t n_pieces, const uint8_t *rows, const int64_t *piece_cols, const uint8_t *hdr,
+                                       const int64_t *hdr_off, const uint8_t *drop, uint8_t *out, int64_t out_cap, int nthreads)
+{
+  if (n_pieces < 0 || (n_pieces > 0 && (!rows || !piece_cols || !hdr || !hdr_off))) return ELECTOR_E_INVAL;
+  for (int64_t p = 0; p < n_pieces; ++p) if (piece_cols[p] < 0 || hdr_off[p + 1] < hdr_off[p]) return ELECTOR_E_INVAL;
+  const int64_t total = records_bytes(n_pieces, piece_cols, hdr_off, drop);
+  if (!out) return total;                                   // size query
+  if (total > out_cap) return ELECTOR_E_INVAL;
+  std::vector<int64_t> in_at((size_t)n_pieces + 1), out_at((size_t)n_pieces + 1);
+  in_at[0] = out_at[0] = 0;
+  for (int64_t p = 0; p < n_pieces; ++p) {
+    in_at[(size_t)p + 1] = in_at[(size_t)p] + 3 * piece_cols[p];
+    const bool keep = !drop || !drop[p];
+    out_at[(size_t)p + 1] = out_at[(size_t)p] + (keep ? 3 * ((hdr_off[p + 1] - hdr_off[p]) + 1 + piece_cols[p] + 1) : 0);
+  }
+  auto work = [&](int64_t p0, int64_t p1) {
+    for (int64_t p = p0; p < p1; ++p) {
+      if (drop && drop[p]) continue;
+      uint8_t *o = out + out_at[(size_t)p];
+      const int64_t hl = hdr_off[p + 1] - hdr_off[p], nc = piece_cols[p];
+      const uint8_t *h = hdr + hdr_off[p], *r = rows + in_at[(size_t)p];
+      for (int row = 0; row < 3; ++row) {
+        std::memcpy(o, h, (size_t)hl); o += hl; *o++ = '\n';
+        std::memcpy(o, r + row * nc, (size_t)nc); o += nc; *o++ = '\n';
+      }
+    }
+  };
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n_pieces / 64 + 1));
+  if (nt == 1) work(0, n_pieces);
+  else {
+    // equal output bytes per thread
+    std::vector<std::thread> th;
+    int64_t p0 = 0;
+    for (int t = 0; t < nt; ++t) {
+      const int64_t want = total * (t + 1) / nt;
+      int64_t p1 = (t == nt - 1) ? n_pieces
+                                 : (int64_t)(std::upper_bound(out_at.begin(), out_at.end(), want) - out_at.begin()) - 1;
+      p1 = std::max(p0, std::min(p1, n_pieces));
+      th.emplace_back(work, p0, p1);
+      p0 = p1;
+    }
+    for (auto &x : th) x.join();
+  }
+  return total;
+}

@@ -330,6 +330,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
   for (auto &s : c->st_slot) s.release();
   for (int k = 0; k < 2; ++k) {
     c->h_meta_buf[k].release();
+    c->h_rows.release();
     if (c->h_meta_done[k]) (void)hipEventDestroy(c->h_meta_done[k]);
   }
   if (c->aux_ready) {

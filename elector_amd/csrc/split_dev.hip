@@ -21,7 +21,11 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <thread>
 #include <vector>
 
 #include "elector_poa.h"
@@ -32,17 +36,8 @@ namespace elector {
 
 constexpr int kSplitThreads = 256;
 constexpr int kMaxAnchors = 3000;          // LDS: 5 ints per anchor
-constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
-constexpr int kUnset = -2;
 
 struct DSeq { int64_t base; uint32_t n; };   // base: byte offset into the reads buffer
-
-struct SplitScratch {            // per workgroup, in HBM
-  uint32_t *keys;                // [3][tab_cap]
-  int32_t *vals;                 // [3][tab_cap]
-  int32_t *ca, *cb;              // [maxlen + 2] candidate partner positions per reference position (-1: none)
-  int32_t *wl;                   // [3][maxwin][8] window lists: best, aux, tmp
-};
 
 struct SplitArgs {
   int64_t n_reads;
@@ -50,45 +45,78 @@ struct SplitArgs {
   const int64_t *read_off;
   const int32_t *hdr_len;
   double thr;
-  uint32_t *keys; int32_t *vals; int32_t *ca; int32_t *cb; int32_t *wl;
+  unsigned long long *ent;       // [block][3][tab_cap] table entries
+  int32_t *ca; int32_t *cb; int32_t *wl;
   int64_t tab_cap, maxlen, maxwin;
   int32_t *out_win;              // [sum of caps][8]
   const int64_t *out_first;      // per read: first window slot
   int32_t *out_cnt, *out_kind;   // kind: 0 windows, 1 small, 2 wrong, -1 skipped, -2 host fallback
-  int32_t *anc; int64_t maxanc;  // BIG variant: anchors / chain arrays in HBM, [block][2 levels][5][maxanc]
+  int32_t *anc; int64_t maxanc;
+  unsigned long long *stamps;  // BIG variant: anchors / chain arrays in HBM, [block][2 levels][5][maxanc]
 };
 
 // window record (8 ints): ref off, ref len, S1 off, S1 len, S2 off, S2 len, S2 is the 'N' filler, unused;
 // offsets relative to the start of the read's own sequence
 __device__ __forceinline__ int ldg(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t ldgu(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stg(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ uint32_t map1(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u; }   // ref: str2num
 __device__ __forceinline__ uint32_t map2(uint8_t c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // ref: rolling update
 
+constexpr int kU = 4;                         // table operations a thread keeps in flight
+constexpr unsigned long long kEmptyEnt = ~0ull;
+
+__device__ __forceinline__ unsigned long long ld64(const unsigned long long *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// open-addressing table in HBM, one 64-bit entry per slot: k-mer code in the high word, in the low word the
+// position of its only occurrence so far, or -1 once it has been seen twice.  One compare-and-swap per insertion;
+// a thread issues kU of them (or kU look-ups) before it waits for the first -- every one is a trip to L2 or HBM.
 struct Tab {
-  uint32_t *keys; int32_t *vals; uint32_t mask;
-  __device__ __forceinline__ void add(uint32_t key, int pos) const
+  unsigned long long *ent; uint32_t mask;
+  __device__ __forceinline__ static unsigned long long pack(uint32_t key, int pos) { return ((unsigned long long)key << 32) | (uint32_t)pos; }
+  __device__ __forceinline__ void add(const uint32_t (&key)[kU], const uint32_t (&pos)[kU], const bool (&on)[kU]) const
   {
-    uint32_t h = (key * 2654435761u) & mask;
-    for (;;) {
-      const uint32_t prev = atomicCAS(keys + h, kEmptyKey, key);
-      if (prev == kEmptyKey || prev == key) break;
-      h = (h + 1) & mask;
+    uint32_t h[kU];
+    unsigned long long prev[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      h[u] = (key[u] * 2654435761u) & mask;
+      prev[u] = kEmptyEnt;
+      if (on[u]) prev[u] = atomicCAS(ent + h[u], kEmptyEnt, pack(key[u], (int)pos[u]));
     }
-    const int old = atomicCAS(vals + h, kUnset, pos);
-    if (old != kUnset) stg(vals + h, -1);                    // a second occurrence: repeated
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (!on[u]) continue;
+      while (prev[u] != kEmptyEnt) {
+        if ((uint32_t)(prev[u] >> 32) == key[u]) { atomicOr(ent + h[u], 0xFFFFFFFFull); break; }   // a second occurrence: repeated
+        h[u] = (h[u] + 1) & mask;
+        prev[u] = atomicCAS(ent + h[u], kEmptyEnt, pack(key[u], (int)pos[u]));
+      }
+    }
   }
   // position of the k-mer when it occurs exactly once, else -1
-  __device__ __forceinline__ int unique_pos(uint32_t key) const
+  __device__ __forceinline__ void unique_pos(const uint32_t (&key)[kU], const bool (&on)[kU], int (&out)[kU]) const
   {
-    uint32_t h = (key * 2654435761u) & mask;
-    for (;;) {
-      const uint32_t k = ldgu(keys + h);
-      if (k == kEmptyKey) return -1;
-      if (k == key) return ldg(vals + h);
-      h = (h + 1) & mask;
+    uint32_t h[kU];
+    unsigned long long e[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      h[u] = (key[u] * 2654435761u) & mask;
+      e[u] = kEmptyEnt;
+      if (on[u]) e[u] = ld64(ent + h[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      out[u] = -1;
+      if (!on[u]) continue;
+      while (e[u] != kEmptyEnt) {
+        if ((uint32_t)(e[u] >> 32) == key[u]) { out[u] = (int)(uint32_t)e[u]; break; }
+        h[u] = (h[u] + 1) & mask;
+        e[u] = ld64(ent + h[u]);
+      }
     }
   }
 };
@@ -109,7 +137,17 @@ struct WG {
   int32_t *ca, *cb;
   int32_t *wl;                     // [3][maxwin][8]
   int64_t tab_cap, maxwin;
+  unsigned long long *stamps;     // debug (ELECTOR_DEBUG_SPLIT): cycles per phase, summed over reads
 };
+
+#define SP_STAMP(idx)                                                                      \
+  do {                                                                                     \
+    if (g.stamps && threadIdx.x == 0) {                                                    \
+      const unsigned long long now_ = __builtin_readcyclecounter();                        \
+      atomicAdd(g.stamps + (idx), now_ - sp_t_);                                           \
+      sp_t_ = now_;                                                                        \
+    }                                                                                      \
+  } while (0)
 
 // k-mer code at position p of s (p + k <= n, or p == 0 for a sequence shorter than k): the first k letters of the
 // sequence go through map1, the others through map2
@@ -129,7 +167,20 @@ __device__ __forceinline__ uint32_t n_kmers(uint32_t n, int k) { return n > (uin
 
 __device__ void reset_tab(const Tab &t, int64_t cap)
 {
-  for (int64_t i = threadIdx.x; i < cap; i += kSplitThreads) { t.keys[i] = kEmptyKey; t.vals[i] = kUnset; }
+  for (int64_t i = threadIdx.x; i < cap; i += kSplitThreads) t.ent[i] = kEmptyEnt;
+}
+
+// maximum over the wavefront, uniform (DPP row shifts + four v_readlane: no LDS traffic)
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+  // after the four shifts lane 15 of every row of 16 holds the row's maximum (a lane without a source takes 0)
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                 c = (uint32_t)__builtin_amdgcn_readlane((int)v, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  return max(max(a, b), max(c, d));
 }
 
 // tables, anchors and the best chain of one split() call (ref: split :175-255, best_chain :79-126).
@@ -143,11 +194,13 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
   Tab tr = g.tab[0], t1 = g.tab[1], t2 = g.tab[2];
   const int64_t cr = cap_for(ref.n), c1 = cap_for(S1.n), c2 = cap_for(S2.n);
   tr.mask = (uint32_t)cr - 1; t1.mask = (uint32_t)c1 - 1; t2.mask = (uint32_t)c2 - 1;
+  unsigned long long sp_t_ = g.stamps ? __builtin_readcyclecounter() : 0;
   reset_tab(tr, cr); reset_tab(t1, c1); reset_tab(t2, c2);
   if (tid == 0) { L.s->n = 0; L.s->nchain = 0; L.s->start = -1; }
   __threadfence();
   __syncthreads();
-  // contiguous chunk of positions per thread, rolling code inside the chunk
+  SP_STAMP(0);
+  // contiguous chunk of positions per thread, rolling code inside the chunk, kU positions handed out at a time
   auto for_kmers = [&](const uint8_t *s, uint32_t n, auto &&fn) {
     const uint32_t np = n_kmers(n, k);
     const uint32_t chunk = (np + kSplitThreads - 1) / kSplitThreads;
@@ -155,33 +208,63 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
     if (p0 >= pe) return;
     uint32_t code = code_at(s, n, p0, k);
     const uint32_t msk = (1u << (2 * k)) - 1u;
-    for (uint32_t p = p0; p < pe; ++p) {
-      fn(p, code);
-      if (p + 1 < pe) {
-        const uint32_t q = p + k;                           // the letter that enters
-        code = ((code << 2) | (q < (uint32_t)k ? map1(s[q]) : map2(s[q]))) & msk;
+    for (uint32_t pb = p0; pb < pe; pb += kU) {
+      uint32_t ps[kU], cs[kU];
+      bool on[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t p = pb + u;
+        on[u] = p < pe;
+        ps[u] = p; cs[u] = code;
+        if (p + 1 < pe) {
+          const uint32_t q = p + k;                           // the letter that enters
+          code = ((code << 2) | (q < (uint32_t)k ? map1(s[q]) : map2(s[q]))) & msk;
+        }
       }
+      fn(ps, cs, on);
     }
   };
-  for_kmers(pr, ref.n, [&](uint32_t p, uint32_t code) { tr.add(code, (int)p); });
+  for_kmers(pr, ref.n, [&](const uint32_t (&p)[kU], const uint32_t (&c)[kU], const bool (&on)[kU]) { tr.add(c, p, on); });
   __threadfence();
   __syncthreads();
-  for_kmers(p1, S1.n, [&](uint32_t p, uint32_t code) { if (tr.unique_pos(code) >= 0) t1.add(code, (int)p); });
-  __threadfence();
-  __syncthreads();
-  for_kmers(p2, S2.n, [&](uint32_t p, uint32_t code) { if (t1.unique_pos(code) >= 0) t2.add(code, (int)p); });
-  __threadfence();
-  __syncthreads();
-  // candidates per reference position: partner positions when the k-mer is unique in all three reads
-  for_kmers(pr, ref.n, [&](uint32_t p, uint32_t code) {
-    const int b = t2.unique_pos(code);
-    int a = -1;
-    if (b >= 0) a = t1.unique_pos(code);
-    stg(g.ca + p, b >= 0 ? a : -1);
-    stg(g.cb + p, b);
+  SP_STAMP(1);
+  for_kmers(p1, S1.n, [&](const uint32_t (&p)[kU], const uint32_t (&c)[kU], const bool (&on)[kU]) {
+    int u1[kU];
+    tr.unique_pos(c, on, u1);
+    bool on1[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) on1[u] = on[u] && u1[u] >= 0;
+    t1.add(c, p, on1);
   });
   __threadfence();
   __syncthreads();
+  SP_STAMP(2);
+  for_kmers(p2, S2.n, [&](const uint32_t (&p)[kU], const uint32_t (&c)[kU], const bool (&on)[kU]) {
+    int u1[kU];
+    t1.unique_pos(c, on, u1);
+    bool on1[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) on1[u] = on[u] && u1[u] >= 0;
+    t2.add(c, p, on1);
+  });
+  __threadfence();
+  __syncthreads();
+  SP_STAMP(3);
+  // candidates per reference position: partner positions when the k-mer is unique in all three reads
+  for_kmers(pr, ref.n, [&](const uint32_t (&p)[kU], const uint32_t (&c)[kU], const bool (&on)[kU]) {
+    int b[kU], a[kU];
+    t2.unique_pos(c, on, b);
+    bool onb[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) onb[u] = on[u] && b[u] >= 0;
+    t1.unique_pos(c, onb, a);
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (on[u]) { stg(g.ca + p[u], a[u]); stg(g.cb + p[u], b[u]); }
+  });
+  __threadfence();
+  __syncthreads();
+  SP_STAMP(4);
   // anchors (:234-251), wavefront 0: position 0 without a distance test, then greedily every candidate more than
   // minSize loop steps after the last one taken (loop index j = position - 1, last_indexed starts at 0)
   const uint32_t np = n_kmers(ref.n, k);
@@ -194,27 +277,38 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
     n = __shfl(n, 0);
     uint32_t last = 0;
     bool fail = false;
-    for (uint32_t base = 1; base < np; base += 64) {
-      const uint32_t p = base + tid;
-      const int a = p < np ? ldg(g.ca + p) : -1;
-      const int b = a >= 0 ? ldg(g.cb + p) : -1;
-      unsigned long long m = __builtin_amdgcn_ballot_w64(a >= 0);
-      while (m) {
-        const int l = __builtin_ctzll(m);
-        m &= m - 1;
-        const uint32_t j = base + l - 1;                    // loop index of this position
-        if ((uint32_t)(j - last) > minSize) {
-          const int sa = __shfl(a, l), sb = __shfl(b, l);
-          if (n < L.cap) { if (tid == 0) { L.ar[n] = (int)(j + 1); L.aa[n] = sa; L.ab[n] = sb; } }
-          else fail = true;
-          ++n;
-          last = j;
+    constexpr int kB = 4;                                   // blocks of 64 positions per trip to memory
+    for (uint32_t base0 = 1; base0 < np; base0 += 64 * kB) {
+      int av[kB], bv[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const uint32_t p = base0 + 64 * q + tid;
+        av[q] = p < np ? ldg(g.ca + p) : -1;
+        bv[q] = p < np ? ldg(g.cb + p) : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const uint32_t base = base0 + 64 * q;
+        const int a = av[q], b = a >= 0 ? bv[q] : -1;
+        unsigned long long m = __builtin_amdgcn_ballot_w64(a >= 0);
+        while (m) {
+          const int l = __builtin_ctzll(m);
+          m &= m - 1;
+          const uint32_t j = base + l - 1;                    // loop index of this position
+          if ((uint32_t)(j - last) > minSize) {
+            const int sa = __shfl(a, l), sb = __shfl(b, l);
+            if (n < L.cap) { if (tid == 0) { L.ar[n] = (int)(j + 1); L.aa[n] = sa; L.ab[n] = sb; } }
+            else fail = true;
+            ++n;
+            last = j;
+          }
         }
       }
     }
     if (tid == 0) { L.s->n = fail ? 0 : n; if (fail) L.s->fail = 1; }
   }
   __syncthreads();
+  SP_STAMP(5);
   // longest chain, back to front (:79-126): wavefront 0
   const int n = L.s->n;
   if (tid < 64 && n > 0) {
@@ -225,12 +319,13 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
         const int j = j0 + tid;
         const bool near = j < n && L.ar[j] - ri < 1000 && L.ar[j] > ri;
         const bool ok = near && L.aa[j] - ai < 1000 && L.aa[j] > ai && L.ab[j] - bi < 1000 && L.ab[j] > bi;
-        int v = ok ? L.cl[j] : -1, vj = ok ? j : 0x7fffffff;
-        for (int d = 32; d; d >>= 1) {
-          const int ov = __shfl_xor(v, d), oj = __shfl_xor(vj, d);
-          if (ov > v || (ov == v && oj < vj)) { v = ov; vj = oj; }
+        // longest first, the earlier successor among equals: one key, one reduction over the wavefront
+        const uint32_t key = ok ? (((uint32_t)L.cl[j] + 1u) << 6) | (uint32_t)(63 - tid) : 0u;
+        const uint32_t top = wave_max(key);
+        if (top) {
+          const int v = (int)(top >> 6) - 1, vj = j0 + 63 - (int)(top & 63u);
+          if (v > best) { best = v; nxt = vj; }              // strict: an earlier block's successor wins ties
         }
-        if (v > best) { best = v; nxt = vj; }                // strict: an earlier block's successor wins ties
         // ref: the scan stops at the first anchor too far on the reference ("TOO FAR NOW", :98-101)
         if (__builtin_amdgcn_ballot_w64(j < n && !near) != 0) break;
       }
@@ -253,6 +348,8 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
     }
   }
   __syncthreads();
+  SP_STAMP(6);
+  if (g.stamps && threadIdx.x == 0) atomicAdd(g.stamps + 7, 1ull);
 }
 
 __device__ __forceinline__ DSeq dsub(DSeq s, uint32_t pos, uint32_t len)     // std::string::substr semantics
@@ -403,13 +500,13 @@ __device__ uint32_t largest_fragment(const int32_t *wl, int n, uint32_t hdr_len)
 template <bool BIG>
 __global__ void __launch_bounds__(kSplitThreads) k_split(SplitArgs a)
 {
-  __shared__ int32_t s_anc[BIG ? 1 : 2 * 5 * kMaxAnchors];
+  extern __shared__ int32_t s_anc[];              // !BIG: 2 levels x 5 arrays x a.maxanc entries (sized by the batch's longest read)
   __shared__ LvlState s_lvl[2];
   __shared__ int sh[8];
   const int tid = threadIdx.x;
   Lvl L0, L1;
   {
-    const int cap = BIG ? (int)a.maxanc : kMaxAnchors;
+    const int cap = (int)a.maxanc;
     int32_t *base = BIG ? a.anc + (int64_t)blockIdx.x * 2 * 5 * a.maxanc : s_anc;
     L0.ar = base; L0.aa = base + cap; L0.ab = base + 2 * cap; L0.cl = base + 3 * cap; L0.cn = base + 4 * cap;
     base += 5 * (int64_t)cap;
@@ -420,20 +517,21 @@ __global__ void __launch_bounds__(kSplitThreads) k_split(SplitArgs a)
   WG g;
   g.reads = a.reads;
   for (int t = 0; t < 3; ++t) {
-    g.tab[t].keys = a.keys + ((int64_t)blockIdx.x * 3 + t) * a.tab_cap;
-    g.tab[t].vals = a.vals + ((int64_t)blockIdx.x * 3 + t) * a.tab_cap;
+    g.tab[t].ent = a.ent + ((int64_t)blockIdx.x * 3 + t) * a.tab_cap;
     g.tab[t].mask = 0;
   }
   g.ca = a.ca + (int64_t)blockIdx.x * (a.maxlen + 2);
   g.cb = a.cb + (int64_t)blockIdx.x * (a.maxlen + 2);
   g.wl = a.wl + (int64_t)blockIdx.x * 3 * a.maxwin * 8;
   g.tab_cap = a.tab_cap; g.maxwin = a.maxwin;
+  g.stamps = a.stamps;
   for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     const DSeq ref{a.read_off[3 * r], (uint32_t)(a.read_off[3 * r + 1] - a.read_off[3 * r])};
     const DSeq S1{a.read_off[3 * r + 1], (uint32_t)(a.read_off[3 * r + 2] - a.read_off[3 * r + 1])};
     const DSeq S2{a.read_off[3 * r + 2], (uint32_t)(a.read_off[3 * r + 3] - a.read_off[3 * r + 2])};
     int kind;
     int nout = 0;
+    unsigned long long sp_t_ = g.stamps ? __builtin_readcyclecounter() : 0;
     int32_t *dst = a.out_win + 8 * a.out_first[r];
     const int64_t dcap = a.out_first[r + 1] - a.out_first[r];
     __syncthreads();
@@ -473,6 +571,8 @@ __global__ void __launch_bounds__(kSplitThreads) k_split(SplitArgs a)
       }
     } else kind = 1;                                                             // :425-431
     if (tid == 0) { a.out_kind[r] = kind; a.out_cnt[r] = kind == 0 ? nout : (kind == 1 || kind == 2) ? 1 : 0; }
+    SP_STAMP(8);                                   // whole read (the split_core phases included)
+    if (g.stamps && tid == 0) atomicAdd(g.stamps + 9, 1ull);
   }
 }
 
@@ -560,17 +660,53 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   }
   int64_t tab_cap = 64;
   while (tab_cap < 2 * maxlen + 2) tab_cap <<= 1;
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(n_in, 1024));
+  const int max_blocks = std::getenv("ELECTOR_SPLIT_BLOCKS") ? std::max(1, std::atoi(std::getenv("ELECTOR_SPLIT_BLOCKS"))) : 1024;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(n_in, max_blocks));
   hipStream_t st = c->stream;
   int rc = c->d_sp_reads.ensure((size_t)total + 64) | c->d_sp_off.ensure((size_t)(3 * n_in + 1) * 8 + 64) |
-           c->d_sp_hdr.ensure((size_t)n_in * 4 + 64) | c->d_sp_keys.ensure((size_t)blocks * 3 * tab_cap * 4) |
-           c->d_sp_vals.ensure((size_t)blocks * 3 * tab_cap * 4) | c->d_sp_ca.ensure((size_t)blocks * (maxlen + 2) * 4) |
+           c->d_sp_hdr.ensure((size_t)n_in * 4 + 64) | c->d_sp_keys.ensure((size_t)blocks * 3 * tab_cap * 8) |
+           c->d_sp_ca.ensure((size_t)blocks * (maxlen + 2) * 4) |
            c->d_sp_cb.ensure((size_t)blocks * (maxlen + 2) * 4) | c->d_sp_wl.ensure((size_t)blocks * 3 * maxwin * 8 * 4) |
            c->d_sp_win.ensure((size_t)first[(size_t)n_in] * 8 * 4 + 64) | c->d_sp_first.ensure((size_t)(n_in + 1) * 8) |
            c->d_sp_cnt.ensure((size_t)(n_in + 1) * 4 * 2 + 64) | c->d_sp_wfirst.ensure((size_t)(n_in + 2) * 8 * 2);
   if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "device splitter workspace");
   if (n_in == 0) return ELECTOR_OK;
-  HIPCHK(c, hipMemcpyAsync(c->d_sp_reads.p, reads, (size_t)total, hipMemcpyHostToDevice, st));
+  auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+  const bool dbg = std::getenv("ELECTOR_DEBUG_SPLIT") != nullptr;
+  const double t0 = now_ms();
+  // the reads to the device through pinned staging, `nthreads` host threads filling one half while the other half's
+  // copy runs (a pageable source is otherwise staged by the runtime on one thread, several times slower)
+  {
+    constexpr size_t kChunk = (size_t)32 << 20;
+    if (c->h_rows.ensure(2 * kChunk)) return elector_fail(c, ELECTOR_E_NOMEM, "pinned staging");
+    uint8_t *stage = c->h_rows.as<uint8_t>();
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) HIPCHK(c, hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    int half = 0;
+    bool used[2] = {false, false};
+    int hip_rc = 0;
+    for (size_t at = 0; at < (size_t)total && !hip_rc; at += kChunk, half ^= 1) {
+      const size_t len = std::min(kChunk, (size_t)total - at);
+      if (used[half]) hip_rc |= hipEventSynchronize(ev[half]) != hipSuccess;
+      uint8_t *dst = stage + (size_t)half * kChunk;
+      const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, nthreads), std::min<size_t>(8, len >> 20)));
+      if (nt <= 1) std::memcpy(dst, reads + at, len);
+      else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) {
+          const size_t a0 = len * t / nt, a1 = len * (t + 1) / nt;
+          th.emplace_back([=]() { std::memcpy(dst + a0, reads + at + a0, a1 - a0); });
+        }
+        for (auto &x : th) x.join();
+      }
+      hip_rc |= hipMemcpyAsync(c->d_sp_reads.as<uint8_t>() + at, dst, len, hipMemcpyHostToDevice, st) != hipSuccess;
+      hip_rc |= hipEventRecord(ev[half], st) != hipSuccess;
+      used[half] = true;
+    }
+    for (int k = 0; k < 2; ++k) { if (used[k]) (void)hipEventSynchronize(ev[k]); (void)hipEventDestroy(ev[k]); }
+    if (hip_rc) return elector_fail(c, ELECTOR_E_HIP, "reads to the device");
+  }
+  const double t1 = now_ms();
   HIPCHK(c, hipMemcpyAsync(c->d_sp_off.p, read_off, (size_t)(3 * n_in + 1) * 8, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_sp_hdr.p, hdr_len, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_sp_first.p, first.data(), (size_t)(n_in + 1) * 8, hipMemcpyHostToDevice, st));
@@ -578,7 +714,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   a.n_reads = n_in;
   a.reads = c->d_sp_reads.as<uint8_t>(); a.read_off = c->d_sp_off.as<int64_t>(); a.hdr_len = c->d_sp_hdr.as<int32_t>();
   a.thr = size_threshold;
-  a.keys = c->d_sp_keys.as<uint32_t>(); a.vals = c->d_sp_vals.as<int32_t>();
+  a.ent = c->d_sp_keys.as<unsigned long long>();
   a.ca = c->d_sp_ca.as<int32_t>(); a.cb = c->d_sp_cb.as<int32_t>(); a.wl = c->d_sp_wl.as<int32_t>();
   a.tab_cap = tab_cap; a.maxlen = maxlen; a.maxwin = maxwin;
   a.out_win = c->d_sp_win.as<int32_t>(); a.out_first = c->d_sp_first.as<int64_t>();
@@ -588,17 +724,41 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   const int64_t maxanc = maxlen / 21 + 8;
   const bool big = maxanc > kMaxAnchors;
   a.anc = nullptr; a.maxanc = maxanc;
+  a.stamps = nullptr;
+  if (dbg) {
+    if (c->d_sp_scan.ensure(4096)) return elector_fail(c, ELECTOR_E_NOMEM, "stamps");
+    a.stamps = c->d_sp_scan.as<unsigned long long>();
+    HIPCHK(c, hipMemsetAsync(a.stamps, 0, 256, st));
+  }
   if (big) {
     if (c->d_sp_anc.ensure((size_t)blocks * 2 * 5 * maxanc * 4 + 64)) return elector_fail(c, ELECTOR_E_NOMEM, "device splitter anchors");
     a.anc = c->d_sp_anc.as<int32_t>();
-    hipLaunchKernelGGL(k_split<true>, dim3((unsigned)blocks), dim3(kSplitThreads), 0, st, a);
-  } else hipLaunchKernelGGL(k_split<false>, dim3((unsigned)blocks), dim3(kSplitThreads), 0, st, a);
+    hipLaunchKernelGGL(k_split<true>, dim3((unsigned)blocks), dim3(kSplitThreads), 16, st, a);
+  } else {
+    // the anchor arrays in LDS, as many entries as the batch's longest read can need: the usual 8-20 kb reads leave
+    // room for four workgroups per CU, whose serial stretches (anchor selection, chain) then overlap
+    static bool attr = false;
+    if (!attr) {
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * 5 * kMaxAnchors * 4));
+      attr = true;
+    }
+    hipLaunchKernelGGL(k_split<false>, dim3((unsigned)blocks), dim3(kSplitThreads), (size_t)(2 * 5 * maxanc * 4), st, a);
+  }
   HIPCHK(c, hipGetLastError());
   // kinds and counts to the host: the reads the device could not take are split by the host code
   std::vector<int32_t> cnt((size_t)n_in), kind((size_t)n_in);
   HIPCHK(c, hipMemcpyAsync(cnt.data(), a.out_cnt, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(kind.data(), a.out_kind, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  const double t2 = now_ms();
+  if (dbg) {
+    unsigned long long hs[16];
+    (void)hipMemcpy(hs, a.stamps, sizeof hs, hipMemcpyDeviceToHost);
+    const double nc = hs[7] ? (double)hs[7] : 1.0, nr = hs[9] ? (double)hs[9] : 1.0;
+    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f\n",
+                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr);
+  }
   (void)nthreads;
   int64_t n_host = 0;
   for (int64_t r = 0; r < n_in; ++r) n_host += kind[(size_t)r] == -2;
@@ -652,6 +812,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(st));
   out->n_reads = nreads; out->n_windows = nwin; out->d_bases = la.bases; out->small_reads = small; out->wrong_reads = wrong;
+  if (dbg) std::fprintf(stderr, "[elector] device splitter, host view: reads to the device %.1f ms, k_split %.1f ms, layout + window bases %.1f ms\n", t1 - t0, t2 - t1, now_ms() - t2);
   return ELECTOR_OK;
 }
 

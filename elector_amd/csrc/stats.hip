@@ -24,11 +24,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstring>
 #include <vector>
+#include <unistd.h>
 
 #include "ctx.h"
 #include "elector_stats.h"
+#include "elector_split.h"
 
 namespace elector {
 
@@ -868,6 +871,41 @@ extern "C" int elector_msa_rows_fetch(elector_ctx *c, int64_t n_pieces, const in
   HIPCHK(c, hipMemcpyAsync(rows, c->d_st_dense.p, (size_t)total, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   return ELECTOR_OK;
+}
+
+// The merged records of the context's last collected statistics job straight into msa.fa: rows device -> pinned
+// host memory, formatted as Donatello's records (elector_msa_format, io_host.cpp) by `nthreads` host threads,
+// one write() to `fd`.  Pieces with drop[p] != 0 are left out.  Returns the bytes written or a negative code.
+extern "C" int64_t elector_msa_records_write(elector_ctx *c, int64_t n_pieces, const int64_t *piece_cols, const uint8_t *hdr,
+                                              const int64_t *hdr_off, const uint8_t *drop, int fd, int nthreads)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n_pieces < 0 || (n_pieces > 0 && (!piece_cols || !hdr || !hdr_off)) || fd < 0) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  if (n_pieces == 0) return 0;
+  int64_t total = 0;
+  for (int64_t p = 0; p < n_pieces; ++p) {
+    if (piece_cols[p] < 0) return elector_fail(c, ELECTOR_E_INVAL, "negative column count");
+    total += 3 * piece_cols[p];
+  }
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->h_rows.ensure((size_t)total + 64)) return elector_fail(c, ELECTOR_E_NOMEM, "pinned rows");
+  }
+  const int rc = elector_msa_rows_fetch(c, n_pieces, piece_cols, c->h_rows.as<uint8_t>());
+  if (rc) return rc;
+  const int64_t need = elector_msa_format(n_pieces, c->h_rows.as<uint8_t>(), piece_cols, hdr, hdr_off, drop, nullptr, 0, 1);
+  if (need < 0) return elector_fail(c, (int)need, "records");
+  if ((int64_t)c->h_text.size() < need) c->h_text.resize((size_t)need + (size_t)need / 8);
+  const int64_t got = elector_msa_format(n_pieces, c->h_rows.as<uint8_t>(), piece_cols, hdr, hdr_off, drop, c->h_text.data(),
+                                         (int64_t)c->h_text.size(), nthreads);
+  if (got != need) return elector_fail(c, ELECTOR_E_INVAL, "records");
+  int64_t at = 0;
+  while (at < got) {
+    const ssize_t w = ::write(fd, c->h_text.data() + at, (size_t)(got - at));
+    if (w < 0) { if (errno == EINTR) continue; return elector_fail(c, ELECTOR_E_INVAL, "write to msa.fa failed"); }
+    at += w;
+  }
+  return got;
 }
 
 // ------------------------------------------------------- homopolymers (host) ---

@@ -41,9 +41,23 @@ def read_cell_estimate(lr, lc, lu, window=60):
     return window * (lc + lu * 1.05) + (lr - lc)
 
 
-def gather_rows(local, group=None, dst=0):
+def gather_sizes(n_local, group=None):
+    """Row counts of every rank's block, for gather_rows(sizes=...) when the same counts serve many gathers"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [int(n_local)]
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([int(n_local)], dtype=torch.int64, device=dev), group=group)
+    return [int(s.item()) for s in sizes]
+
+
+def gather_rows(local, group=None, dst=0, sizes=None):
     """Gather variable-length int64 [k_i, C] blocks from every rank to `dst`, in rank
-    order.  Returns the concatenated array on dst and None elsewhere."""
+    order.  Returns the concatenated array on dst and None elsewhere.  sizes: the ranks' row counts when the
+    caller already has them (gather_sizes) -- one collective instead of two."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -52,9 +66,11 @@ def gather_rows(local, group=None, dst=0):
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     local = np.ascontiguousarray(local, dtype=np.int64)
     ncol = local.shape[1] if local.ndim == 2 else 1
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=dev), group=group)
-    cap = int(max(int(s.item()) for s in sizes))
+    if sizes is None:
+        sizes = gather_sizes(local.shape[0], group)
+    elif len(sizes) != world or int(sizes[rank]) != local.shape[0]:
+        raise ValueError("gather_rows: sizes do not describe this rank's block")
+    cap = max(int(s) for s in sizes)
     pad = torch.zeros((cap, ncol), dtype=torch.int64, device=dev)
     if local.shape[0]:
         pad[: local.shape[0]] = torch.from_numpy(local.reshape(local.shape[0], ncol)).to(dev)
@@ -62,7 +78,7 @@ def gather_rows(local, group=None, dst=0):
     dist.gather(pad, out, dst=dst, group=group)
     if rank != dst:
         return None
-    return np.concatenate([o[: int(s.item())].cpu().numpy() for o, s in zip(out, sizes)], axis=0)
+    return np.concatenate([o[: int(s)].cpu().numpy() for o, s in zip(out, sizes)], axis=0)
 
 
 def sharded_counters(pieces, counter_fn, group=None):

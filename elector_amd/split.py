@@ -5,6 +5,7 @@ Reference: src/split/Master_Splitter.cpp (masterSplitter) and
 src/split/Donatello.cpp, spawned from elector/alignment.py:99-101,120-122.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -27,6 +28,12 @@ class ElectorWindowsDev(C.Structure):
         ("off", C.POINTER(C.c_int64)), ("read_first", C.POINTER(C.c_int64)), ("read_index", C.POINTER(C.c_int64)),
         ("small_reads", C.c_int64), ("wrong_reads", C.c_int64),
     ]
+
+
+class ElectorReads(C.Structure):
+    _fields_ = [("n", C.c_int64), ("first_index", C.c_int64),
+                ("seq", C.POINTER(C.c_uint8)), ("seq_off", C.POINTER(C.c_int64)),
+                ("hdr", C.POINTER(C.c_uint8)), ("hdr_off", C.POINTER(C.c_int64))]
 
 
 class ElectorMsa(C.Structure):
@@ -53,6 +60,16 @@ def _lib():
         L.elector_windows_dev_free.restype = None
         L.elector_ctx_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.elector_ctx_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.elector_reads_open.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.elector_reads_next.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(ElectorReads)]
+        L.elector_reads_close.argtypes = [C.c_void_p]
+        L.elector_reads_close.restype = None
+        L.elector_msa_format.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int64, C.c_int]
+        L.elector_msa_format.restype = C.c_int64
+        L.elector_msa_records_write.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int, C.c_int]
+        L.elector_msa_records_write.restype = C.c_int64
         L._split_bound = True
     return L
 
@@ -150,12 +167,20 @@ def split_reads_device(engine, reads, size_threshold=0.1, headers=None, nthreads
     """The splitter on the GPU of `engine` (include/elector_split.h: elector_split_reads_device): same windows as
     split_reads, their bases stay in device memory.  A batch with a read beyond the kernel's on-chip limits is
     split by the host code and uploaded, so the result is always a DevWindows."""
+    buf, off, hl = pack_reads(reads, headers)
+    return split_packed_device(engine, buf, off, hl, size_threshold, nthreads)
+
+
+def split_packed_device(engine, buf, off, hl, size_threshold=0.1, nthreads=None):
+    """split_reads_device on reads already packed (pack_reads / ReadsFile.next)"""
     import os
     import torch
     L = _lib()
     nthreads = nthreads or os.cpu_count() or 1
-    buf, off, hl = pack_reads(reads, headers)
-    n = len(reads)
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    hl = np.ascontiguousarray(hl, dtype=np.int32)
+    n = (len(off) - 1) // 3
     w = ElectorWindowsDev()
     rc = L.elector_split_reads_device(engine._h, n, buf.ctypes.data, off.ctypes.data, hl.ctypes.data,
                                       float(size_threshold), int(nthreads), C.byref(w))
@@ -181,6 +206,101 @@ def split_reads_device(engine, reads, size_threshold=0.1, headers=None, nthreads
         return out
     finally:
         L.elector_windows_dev_free(C.byref(w))
+
+
+class ReadBatch:
+    """reads of one processing batch as the library's reader hands them out"""
+    __slots__ = ("n", "first_index", "seq", "seq_off", "hdr", "hdr_off")
+
+    def header(self, i):
+        return self.hdr[int(self.hdr_off[i]):int(self.hdr_off[i + 1])]
+
+    @property
+    def hdr_len(self):
+        return np.diff(self.hdr_off).astype(np.int32)
+
+
+class ReadsFile:
+    """The three sorted FASTA files read as masterSplitter reads them, cut into processing batches
+    (include/elector_split.h: elector_reads_open / _next)."""
+
+    def __init__(self, reference, uncorrected, corrected):
+        self._h = C.c_void_p()
+        rc = _lib().elector_reads_open(os.fsencode(reference), os.fsencode(uncorrected), os.fsencode(corrected),
+                                       C.byref(self._h))
+        if rc:
+            raise ElectorError(rc, "cannot open the read files")
+
+    def next(self, min_records, start=0, stop=None):
+        """-> ReadBatch, or None at the end.  The batch's arrays are views of the reader's buffers: valid until
+        the next call."""
+        L = _lib()
+        r = ElectorReads()
+        rc = L.elector_reads_next(self._h, int(min_records), int(start), -1 if stop is None else int(stop), C.byref(r))
+        if rc:
+            raise ElectorError(rc)
+        if r.n == 0:
+            return None
+        b = ReadBatch()
+        b.n, b.first_index = int(r.n), int(r.first_index)
+        b.seq_off = np.ctypeslib.as_array(r.seq_off, shape=(3 * b.n + 1,))
+        total = int(b.seq_off[-1])
+        b.seq = np.ctypeslib.as_array(r.seq, shape=(max(1, total),))[:total]
+        b.hdr_off = np.ctypeslib.as_array(r.hdr_off, shape=(b.n + 1,)).copy()
+        b.hdr = C.string_at(r.hdr, int(b.hdr_off[-1]))
+        return b
+
+    def close(self):
+        if self._h:
+            _lib().elector_reads_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def msa_format(rows, piece_cols, headers, drop=None, nthreads=1):
+    """Donatello's records of the pieces (rows: per piece its three rows back to back) -> bytes"""
+    L = _lib()
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    piece_cols = np.ascontiguousarray(piece_cols, dtype=np.int64)
+    hdr, hdr_off = pack_headers(headers)
+    d = None if drop is None else np.ascontiguousarray(drop, dtype=np.uint8)
+    need = L.elector_msa_format(len(piece_cols), rows.ctypes.data, piece_cols.ctypes.data, hdr.ctypes.data, hdr_off.ctypes.data,
+                                d.ctypes.data if d is not None else None, None, 0, 1)
+    if need < 0:
+        raise ElectorError(int(need))
+    out = np.empty(max(1, int(need)), dtype=np.uint8)
+    got = L.elector_msa_format(len(piece_cols), rows.ctypes.data, piece_cols.ctypes.data, hdr.ctypes.data, hdr_off.ctypes.data,
+                               d.ctypes.data if d is not None else None, out.ctypes.data, int(need), int(nthreads))
+    if got != need:
+        raise ElectorError(int(got) if got < 0 else -1)
+    return out[:int(need)].tobytes()
+
+
+def pack_headers(headers):
+    """[bytes] -> (uint8 blob, int64 offsets)"""
+    off = np.zeros(len(headers) + 1, dtype=np.int64)
+    np.cumsum(np.fromiter((len(h) for h in headers), dtype=np.int64, count=len(headers)), out=off[1:])
+    blob = np.frombuffer(b"".join(headers) + b"\0", dtype=np.uint8)
+    return blob, off
+
+
+def msa_records_write(engine, piece_cols, headers, drop, fd, nthreads=1):
+    """The merged records of the engine's last collected statistics job appended to the file behind `fd`
+    (include/elector_split.h: elector_msa_records_write) -> bytes written"""
+    L = _lib()
+    piece_cols = np.ascontiguousarray(piece_cols, dtype=np.int64)
+    hdr, hdr_off = pack_headers(headers)
+    d = None if drop is None else np.ascontiguousarray(drop, dtype=np.uint8)
+    got = L.elector_msa_records_write(engine._h, len(piece_cols), piece_cols.ctypes.data, hdr.ctypes.data, hdr_off.ctypes.data,
+                                      d.ctypes.data if d is not None else None, int(fd), int(nthreads))
+    if got < 0:
+        raise ElectorError(int(got), L.elector_ctx_last_error(engine._h).decode())
+    return int(got)
 
 
 def split_packed(buf, off, hdr_len, size_threshold=0.1, nthreads=1):

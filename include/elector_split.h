@@ -73,6 +73,34 @@ int  elector_ctx_copy(elector_ctx *ctx, const void *src, void *dst, int64_t byte
 /* copies device memory of the context's device to the host (tests, debugging) */
 int  elector_ctx_copy_to_host(elector_ctx *ctx, const void *d_src, void *h_dst, int64_t bytes);
 
+/* ---- the file ends of call site #1 (elector_amd/csrc/io_host.cpp) -------------------------------------------
+ * The three sorted FASTA files as masterSplitter reads them (Master_Splitter.cpp:396-446: one header line and one
+ * sequence line per record; :414 records whose reference has fewer than 3 bases are skipped without counting),
+ * handed out in processing batches: at least min_records kept records, extended to the end of the last read (run
+ * of records whose msa.fa header line -- fasta_format.c:33-37, lpo_format.c:410, Donatello.cpp:71-73 -- is the
+ * same).  start / stop: range of kept-record indices to hand out (stop < 0: to the end).  A batch with n == 0
+ * is the end.  seq holds per record the reference, uncorrected and corrected sequence (the order
+ * elector_split_reads takes), hdr the reference records' header lines; the buffers belong to the handle and are
+ * valid until its next call. */
+typedef struct elector_reads {
+  int64_t n, first_index;
+  uint8_t *seq;  int64_t *seq_off;     /* 3n + 1 offsets */
+  uint8_t *hdr;  int64_t *hdr_off;     /*  n + 1 offsets */
+} elector_reads;
+int  elector_reads_open(const char *reference, const char *uncorrected, const char *corrected, void **handle);
+int  elector_reads_next(void *handle, int64_t min_records, int64_t start, int64_t stop, elector_reads *out);
+void elector_reads_close(void *handle);
+
+/* Donatello's records (Donatello.cpp:61-93): per piece "header\nrow\n" three times (reference, corrected,
+ * uncorrected row; rows = per piece the three rows of piece_cols[p] bytes back to back).  out == NULL returns the
+ * size; pieces with drop[p] != 0 (drop may be NULL) are left out.  Returns the bytes written or a negative code. */
+int64_t elector_msa_format(int64_t n_pieces, const uint8_t *rows, const int64_t *piece_cols, const uint8_t *hdr,
+                           const int64_t *hdr_off, const uint8_t *drop, uint8_t *out, int64_t out_cap, int nthreads);
+/* ... of the context's last collected statistics job (include/elector_stats.h), device rows -> pinned host
+ * memory -> records -> one write() to the file descriptor */
+int64_t elector_msa_records_write(elector_ctx *ctx, int64_t n_pieces, const int64_t *piece_cols, const uint8_t *hdr,
+                                  const int64_t *hdr_off, const uint8_t *drop, int fd, int nthreads);
+
 /* Merged per-read MSA (what Donatello appends to msa.fa): for emitted read r the
  * three rows each have read_cols[r] columns; columns whose corrected letter is
  * 'n' are dropped (Donatello.cpp:13-31). */

@@ -1,0 +1,120 @@
+"""The native file ends of call site #1 (elector_amd/csrc/io_host.cpp) against their Python restatements:
+the record loop + batch rule of elector_amd.alignment (_batches), and Donatello's record layout."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from elector_amd import alignment, split
+
+
+def _write(tmp_path, records, trailing_newline=(True, True, True), drop_last=(0, 0, 0)):
+    paths = []
+    for which, name in enumerate(("ref.fa", "unc.fa", "cor.fa")):
+        p = tmp_path / name
+        recs = records[: len(records) - drop_last[which]]
+        txt = b"".join(h + b"\n" + seqs[which] + b"\n" for h, seqs in recs)
+        if not trailing_newline[which] and txt.endswith(b"\n"):
+            txt = txt[:-1]
+        p.write_bytes(txt)
+        paths.append(str(p))
+    return paths
+
+
+def _records(n, seed, titled=False):
+    rng = random.Random(seed)
+    out = []
+    read = 0
+    while len(out) < n:
+        pieces = rng.choice((1, 1, 1, 2, 3))
+        for _ in range(pieces):
+            name = b">read%d_%s" % (read, b"x" * rng.randint(0, 14))
+            if titled and rng.random() < 0.3:
+                name += rng.choice((b" ", b"\t", b"  ")) + b"title %d" % rng.randint(0, 9)
+            lr = rng.choice((0, 1, 2, 3, 5, 40, 200))
+            seqs = tuple(bytes(rng.choice(b"ACGTacgtN") for _ in range(max(0, lr + rng.randint(-2, 2)))) for _ in range(3))
+            seqs = (bytes(rng.choice(b"ACGT") for _ in range(lr)),) + seqs[1:]
+            out.append((name, seqs))
+        read += 1
+    return out[:n]
+
+
+def _python_batches(paths, min_records, start, stop, monkeypatch):
+    monkeypatch.setattr(alignment, "READS_PER_BATCH", min_records)
+    return [(first, reads, hdrs) for first, reads, hdrs in alignment._batches(paths[0], paths[1], paths[2], start, stop)]
+
+
+def _native_batches(paths, min_records, start, stop):
+    rf = split.ReadsFile(paths[0], paths[1], paths[2])
+    out = []
+    while True:
+        b = rf.next(min_records, start, stop)
+        if b is None:
+            break
+        reads, hdrs = [], []
+        o = b.seq_off
+        raw = b.seq.tobytes()
+        for i in range(b.n):
+            ref, unc, cor = (raw[o[3 * i + j]:o[3 * i + j + 1]] for j in range(3))
+            reads.append((ref, cor, unc))
+            hdrs.append(b.header(i))
+        assert list(b.hdr_len) == [len(h) for h in hdrs]
+        out.append((b.first_index, reads, hdrs))
+    rf.close()
+    return out
+
+
+@pytest.mark.parametrize("titled", [False, True])
+@pytest.mark.parametrize("min_records", [1, 7, 64, 1000])
+def test_reader_matches_python(tmp_path, monkeypatch, titled, min_records):
+    paths = _write(tmp_path, _records(300, 5 + min_records, titled))
+    for start, stop in ((0, None), (0, 50), (13, 140), (299, None), (400, None)):
+        want = _python_batches(paths, min_records, start, stop, monkeypatch)
+        got = _native_batches(paths, min_records, start, stop)
+        assert got == want, (start, stop)
+
+
+def test_reader_ragged_files_and_missing_newlines(tmp_path, monkeypatch):
+    recs = _records(120, 77, True)
+    for k, (tn, dl) in enumerate((((False, True, True), (0, 0, 0)), ((True, False, False), (0, 0, 0)),
+                                  ((True, True, True), (0, 9, 0)), ((True, True, True), (0, 0, 31)),
+                                  ((False, False, False), (5, 0, 2)))):
+        d = tmp_path / ("c%d" % k)
+        d.mkdir()
+        paths = _write(d, recs, tn, dl)
+        assert _native_batches(paths, 16, 0, None) == _python_batches(paths, 16, 0, None, monkeypatch)
+
+
+def test_reader_empty_and_missing(tmp_path):
+    paths = _write(tmp_path, [])
+    assert _native_batches(paths, 10, 0, None) == []
+    with pytest.raises(Exception):
+        split.ReadsFile(str(tmp_path / "nope.fa"), paths[1], paths[2])
+
+
+def test_msa_format_matches_python():
+    rng = np.random.default_rng(3)
+    n = 257
+    cols = rng.integers(0, 300, n).astype(np.int64)
+    cols[5] = 0
+    rows = rng.integers(97, 123, int(3 * cols.sum()), dtype=np.uint8)
+    hdrs = [b">r%d " % i * (1 + i % 3) for i in range(n)]
+    drop = (rng.random(n) < 0.1).astype(np.uint8)
+    raw = rows.tobytes()
+
+    def python(dropv):
+        at, out = 0, []
+        for p in range(n):
+            nc = int(cols[p])
+            if dropv is None or not dropv[p]:
+                h = hdrs[p]
+                out.append(h + b"\n" + raw[at:at + nc] + b"\n" + h + b"\n" + raw[at + nc:at + 2 * nc] + b"\n" +
+                           h + b"\n" + raw[at + 2 * nc:at + 3 * nc] + b"\n")
+            at += 3 * nc
+        return b"".join(out)
+
+    for threads in (1, 4):
+        assert split.msa_format(rows, cols, hdrs, None, threads) == python(None)
+        assert split.msa_format(rows, cols, hdrs, drop, threads) == python(drop)
+    assert split.msa_format(np.zeros(0, np.uint8), np.zeros(0, np.int64), [], None, 2) == b""
