@@ -55,8 +55,9 @@ void elector_windows_free(elector_windows *w);
  * elector_poa_batch_device takes, so the windows never cross PCIe:
  *   d_bases    device pointer, owned by the context, valid until its next splitter call
  *   off, read_first, read_index   host arrays as in elector_windows (malloc'd; elector_windows_dev_free)
- * Returns ELECTOR_E_LIMIT when a read exceeds the kernel's on-chip limits (more than 3,000 anchors: reads beyond
- * ~60 kb): elector_split_reads takes such a batch. */
+ * Reads of any length are taken (the anchor arrays move from LDS to HBM beyond 3,000 possible anchors, i.e. for
+ * reads beyond ~60 kb).  Returns ELECTOR_E_LIMIT when a read's window list outgrows the room reserved for it (one
+ * window per 16 reference bases): elector_split_reads takes such a batch. */
 typedef struct elector_windows_dev {
   int64_t n_reads, n_windows;
   uint8_t *d_bases;

@@ -1,6 +1,7 @@
-"""Parity at the bench's full size through size-independent properties (the oracle would need minutes):
-the batch bench.py times (E. coli 30X SimLord-like reads cut into ~280k windows per 2000 reads) goes
-through the device entry points, then
+"""Parity at a size the oracle would need minutes for, through size-independent properties: a 2,000-read
+slice of the workload bench.py times (E. coli 30X SimLord-like reads, ~280k windows; the whole 10,001-read
+batch and the other BASELINE.json configurations are tests/test_configs_gpu.py) goes through the device entry
+points, then
   * every MSA row, with its gaps removed, is exactly the window's input sequence (a round trip that
     any misplaced, lost or duplicated letter breaks), and the column counts are consistent;
   * a second run over the same batch gives byte-identical columns (no run-to-run variation from the
