@@ -26,6 +26,7 @@
 #include <cstring>
 #include <ctime>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "elector_poa.h"
@@ -52,7 +53,8 @@ struct SplitArgs {
   const int64_t *out_first;      // per read: first window slot
   int32_t *out_cnt, *out_kind;   // kind: 0 windows, 1 small, 2 wrong, -1 skipped, -2 host fallback
   int32_t *anc; int64_t maxanc;
-  unsigned long long *stamps;  // BIG variant: anchors / chain arrays in HBM, [block][2 levels][5][maxanc]
+  unsigned long long *stamps;
+  int lds_tables;                // the dynamic LDS holds the on-chip tables behind the anchor arrays
 };
 
 // window record (8 ints): ref off, ref len, S1 off, S1 len, S2 off, S2 len, S2 is the 'N' filler, unused;
@@ -125,11 +127,35 @@ struct Tab {
 // workgroup's HBM scratch for reads with more than kMaxAnchors possible anchors (written and read by this
 // workgroup only) -- and four scalars in LDS
 struct LvlState { int n, start, nchain, fail; };
-struct Lvl {
-  int32_t *ar, *aa, *ab, *cl, *cn;
+// The anchor arrays are reached through accessors rather than plain pointers: a pointer that travels through a
+// struct into a function that is not inlined is a generic one, and every access through it a FLAT instruction --
+// for LDS several times slower than ds_read / ds_write.  LdsArr rebuilds the address from the dynamic-LDS symbol.
+template <class T>
+struct LdsArr {
+  using elem = T;
+  uint32_t off;                   // in units of T from the start of the dynamic LDS
+  __device__ __forceinline__ T &operator[](int i) const
+  {
+    extern __shared__ int32_t dyn_lds_[];
+    return reinterpret_cast<T *>(dyn_lds_)[off + (uint32_t)i];
+  }
+};
+template <class T>
+struct GlbArr {
+  using elem = T;
+  T *p;
+  __device__ __forceinline__ T &operator[](int i) const { return p[i]; }
+};
+template <class A>
+struct LvlT {                     // uint16_t entries in LDS (reads below 64 kb), int32_t in HBM
+  using elem = typename A::elem;
+  A ar, aa, ab, cl, cn;
   int cap;
   LvlState *s;
+  static constexpr int kNoNext = (int)(elem)(-1);     // end of a chain in cn
 };
+using Lvl16 = LvlT<LdsArr<uint16_t>>;
+using Lvl32 = LvlT<GlbArr<int32_t>>;
 
 struct WG {
   const uint8_t *reads;
@@ -138,6 +164,8 @@ struct WG {
   int32_t *wl;                     // [3][maxwin][8]
   int64_t tab_cap, maxwin;
   unsigned long long *stamps;     // debug (ELECTOR_DEBUG_SPLIT): cycles per phase, summed over reads
+  int lds_tab;                    // LDS tables (tables_lds): dword offset in the dynamic LDS, or -1
+  int *lds_flag;
 };
 
 #define SP_STAMP(idx)                                                                      \
@@ -170,6 +198,123 @@ __device__ void reset_tab(const Tab &t, int64_t cap)
   for (int64_t i = threadIdx.x; i < cap; i += kSplitThreads) t.ent[i] = kEmptyEnt;
 }
 
+// ---- the same three tables in LDS, for reads of up to kLdsMaxN bases ----
+// A 64-bit entry per slot does not fit on chip; a 16-bit one does: [15] seen twice, [14:0] position of the first
+// occurrence, 0xFFFF empty -- the k-mer itself is read back from a 2-bit packed copy of the sequence (16 letters
+// per dword, letter q coded as the reference codes it: first k letters by str2num, the rest by the rolling update).
+// The reference's table gets 16,384 slots (most look-ups of uncorrected k-mers miss: short probe sequences matter),
+// the other two 4,096 each -- they only hold k-mers shared with the reference, a few hundred for a noisy read --
+// which with the 16-bit anchor arrays is about 72 KB: two workgroups per CU.  When they fill beyond kLdsFill (an uncorrected read that is nearly error-free) the call falls back to the HBM tables.
+constexpr uint32_t kLdsMaxN = 12500;
+constexpr uint32_t kLdsCapRef = 16384, kLdsCapOther = 4096, kLdsFill = 3200;
+constexpr uint32_t kLdsSeqWords = kLdsMaxN / 16 + 3;
+constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4;
+
+struct LTab {
+  uint32_t *w;            // slots, two per word
+  uint32_t mask;
+  const uint32_t *seq;    // packed sequence the positions refer to
+  uint32_t kmsk;
+  __device__ __forceinline__ static uint32_t bits(const uint32_t *seq, uint32_t p, uint32_t kmsk)
+  {
+    const uint32_t bit = 2u * p, i = bit >> 5, sh = bit & 31u;
+    const unsigned long long v = ((unsigned long long)seq[i + 1] << 32) | seq[i];
+    return (uint32_t)(v >> sh) & kmsk;
+  }
+  __device__ __forceinline__ static uint32_t slot_of(uint32_t code, uint32_t mask) { return ((code * 2654435761u) >> 7) & mask; }
+  // true when the k-mer got a slot of its own (a new entry)
+  __device__ __forceinline__ bool add(uint32_t code, uint32_t pos) const
+  {
+    uint32_t h = slot_of(code, mask);
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+      uint32_t *word = w + (h >> 1);
+      const uint32_t sh = (h & 1u) * 16u;
+      for (;;) {
+        const uint32_t old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t cur = (old >> sh) & 0xFFFFu;
+        if (cur == 0xFFFFu) {
+          if (atomicCAS(word, old, (old & ~(0xFFFFu << sh)) | (pos << sh)) == old) return true;
+          continue;                                            // the word changed under us: look again
+        }
+        if (bits(seq, cur & 0x7FFFu, kmsk) == code) {          // a second occurrence: repeated
+          if (!(cur & 0x8000u)) atomicOr(word, 0x8000u << sh);
+          return false;
+        }
+        break;
+      }
+      h = (h + 1) & mask;
+    }
+    return false;
+  }
+  // position of the k-mer when it occurs exactly once, else -1
+  __device__ __forceinline__ int find(uint32_t code) const
+  {
+    uint32_t h = slot_of(code, mask);
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+      const uint32_t e = (w[h >> 1] >> ((h & 1u) * 16u)) & 0xFFFFu;
+      if (e == 0xFFFFu) return -1;
+      if (bits(seq, e & 0x7FFFu, kmsk) == code) return (e & 0x8000u) ? -1 : (int)(e & 0x7FFFu);
+      h = (h + 1) & mask;
+    }
+    return -1;
+  }
+};
+
+// the three table phases and the candidate arrays of split_core on the LDS tables; false (uniform) when a table
+// filled up: nothing has been written to ca / cb then and the HBM tables take the call
+__device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, int *flag, int32_t *ca, int32_t *cb, const uint8_t *pr, uint32_t nr,
+                           const uint8_t *p1, uint32_t n1, const uint8_t *p2, uint32_t n2, int k)
+{
+  const int tid = threadIdx.x;
+  extern __shared__ int32_t dyn_lds_[];
+  uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
+  uint32_t *wr = lds, *w1 = wr + kLdsCapRef / 2, *w2 = w1 + kLdsCapOther / 2;
+  uint32_t *sr = w2 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
+  const uint32_t kmsk = (1u << (2 * k)) - 1u;
+  auto pack = [&](const uint8_t *s, uint32_t n, uint32_t *dst) {
+    const uint32_t nw = (n + 15) / 16 + 2;
+    for (uint32_t wdx = tid; wdx < nw; wdx += kSplitThreads) {
+      uint32_t v = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t q = 16 * wdx + i;
+        if (q < n) v |= (q < (uint32_t)k ? map1(s[q]) : map2(s[q])) << (2 * i);
+      }
+      dst[wdx] = v;
+    }
+  };
+  pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2);
+  for (uint32_t i = tid; i < (kLdsCapRef + 2 * kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+  __syncthreads();
+  SP_STAMP(0);
+  const LTab tr{wr, kLdsCapRef - 1, sr, kmsk}, t1{w1, kLdsCapOther - 1, s1, kmsk}, t2{w2, kLdsCapOther - 1, s2, kmsk};
+  const uint32_t npr = n_kmers(nr, k), np1 = n_kmers(n1, k), np2 = n_kmers(n2, k);
+  for (uint32_t p = tid; p < npr; p += kSplitThreads) tr.add(LTab::bits(sr, p, kmsk), p);
+  __syncthreads();
+  SP_STAMP(1);
+  for (uint32_t p = tid; p < np1; p += kSplitThreads) {
+    const uint32_t c = LTab::bits(s1, p, kmsk);
+    if (tr.find(c) >= 0 && t1.add(c, p) && atomicAdd(&flag[0], 1) >= (int)kLdsFill) { flag[1] = 1; break; }
+  }
+  __syncthreads();
+  SP_STAMP(2);
+  if (flag[1]) return false;
+  for (uint32_t p = tid; p < np2; p += kSplitThreads) {
+    const uint32_t c = LTab::bits(s2, p, kmsk);
+    if (t1.find(c) >= 0) t2.add(c, p);                         // no more distinct k-mers than the table before holds
+  }
+  __syncthreads();
+  SP_STAMP(3);
+  for (uint32_t p = tid; p < npr; p += kSplitThreads) {
+    const uint32_t c = LTab::bits(sr, p, kmsk);
+    const int b = t2.find(c);
+    const int a = b >= 0 ? t1.find(c) : -1;
+    stg(ca + p, a); stg(cb + p, b);
+  }
+  return true;
+}
+
 // maximum over the wavefront, uniform (DPP row shifts + four v_readlane: no LDS traffic)
 __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 {
@@ -185,7 +330,8 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 
 // tables, anchors and the best chain of one split() call (ref: split :175-255, best_chain :79-126).
 // Workgroup-wide.  On return L.s->n anchors, L.s->nchain chain entries (indices of the chain in L.cl[0 .. nchain), reused).
-__device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize)
+template <class LV>
+__device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize)
 {
   const uint8_t *pr = g.reads + ref.base, *p1 = g.reads + S1.base, *p2 = g.reads + S2.base;
   const int tid = threadIdx.x;
@@ -195,8 +341,19 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
   const int64_t cr = cap_for(ref.n), c1 = cap_for(S1.n), c2 = cap_for(S2.n);
   tr.mask = (uint32_t)cr - 1; t1.mask = (uint32_t)c1 - 1; t2.mask = (uint32_t)c2 - 1;
   unsigned long long sp_t_ = g.stamps ? __builtin_readcyclecounter() : 0;
-  reset_tab(tr, cr); reset_tab(t1, c1); reset_tab(t2, c2);
   if (tid == 0) { L.s->n = 0; L.s->nchain = 0; L.s->start = -1; }
+  // (a sequence shorter than k has one k-mer whose code depends on its length: only the HBM tables' codes, built
+  // like the reference's, tell such k-mers apart the way the reference does)
+  bool on_chip = g.lds_tab >= 0 && ref.n <= kLdsMaxN && S1.n <= kLdsMaxN && S2.n <= kLdsMaxN &&
+                 ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
+  if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, g.lds_flag, g.ca, g.cb, pr, ref.n, p1, S1.n, p2, S2.n, k);
+  if (on_chip) {
+    if (g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
+    __threadfence();
+    __syncthreads();
+    SP_STAMP(4);
+  } else {
+  reset_tab(tr, cr); reset_tab(t1, c1); reset_tab(t2, c2);
   __threadfence();
   __syncthreads();
   SP_STAMP(0);
@@ -265,6 +422,7 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
   __threadfence();
   __syncthreads();
   SP_STAMP(4);
+  }
   // anchors (:234-251), wavefront 0: position 0 without a distance test, then greedily every candidate more than
   // minSize loop steps after the last one taken (loop index j = position - 1, last_indexed starts at 0)
   const uint32_t np = n_kmers(ref.n, k);
@@ -329,7 +487,7 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
         // ref: the scan stops at the first anchor too far on the reference ("TOO FAR NOW", :98-101)
         if (__builtin_amdgcn_ballot_w64(j < n && !near) != 0) break;
       }
-      if (tid == 0) { L.cl[i] = 1 + best; L.cn[i] = best >= 0 ? nxt : -1; }
+      if (tid == 0) { L.cl[i] = (typename LV::elem)(1 + best); L.cn[i] = (typename LV::elem)(best >= 0 ? nxt : -1); }
       __builtin_amdgcn_wave_barrier();
     }
     // start: the longest, the earliest among equals
@@ -343,7 +501,7 @@ __device__ void split_core(const WG &g, const Lvl &L, DSeq ref, DSeq S1, DSeq S2
       L.s->start = vi;
       // the chain as a list of anchor indices, written over cl (no longer needed)
       int c = 0;
-      for (int i = vi; i != -1; i = L.cn[i]) L.cl[c++] = i;
+      for (int i = vi; i != LV::kNoNext; i = (int)L.cn[i]) L.cl[c++] = (typename LV::elem)i;
       L.s->nchain = c;
     }
   }
@@ -372,7 +530,8 @@ __device__ __forceinline__ void wpush(WList &o, uint32_t ro, uint32_t rl, uint32
 
 // one split() of the reference (:175-308) including the two re-splits of a missing start / end.  Workgroup-wide;
 // the window list `out` (in HBM) is built by thread 0; returns its length through *out_n (LDS).
-__device__ void split_read(const WG &g, const Lvl &L0, const Lvl &L1, DSeq ref, DSeq S1, DSeq S2, int k, int32_t *out, int32_t *tmp,
+template <class LV>
+__device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DSeq S1, DSeq S2, int k, int32_t *out, int32_t *tmp,
                            int *sh /* LDS ints: [0] n out, [1] overflow, [2..] scratch */)
 {
   const int tid = threadIdx.x;
@@ -504,16 +663,25 @@ __global__ void __launch_bounds__(kSplitThreads) k_split(SplitArgs a)
   __shared__ LvlState s_lvl[2];
   __shared__ int sh[8];
   const int tid = threadIdx.x;
-  Lvl L0, L1;
+  using LV = typename std::conditional<BIG, Lvl32, Lvl16>::type;
+  using AT = typename LV::elem;
+  LV L0, L1;
   {
     const int cap = (int)a.maxanc;
-    int32_t *base = BIG ? a.anc + (int64_t)blockIdx.x * 2 * 5 * a.maxanc : s_anc;
-    L0.ar = base; L0.aa = base + cap; L0.ab = base + 2 * cap; L0.cl = base + 3 * cap; L0.cn = base + 4 * cap;
-    base += 5 * (int64_t)cap;
-    L1.ar = base; L1.aa = base + cap; L1.ab = base + 2 * cap; L1.cl = base + 3 * cap; L1.cn = base + 4 * cap;
+    if constexpr (BIG) {
+      int32_t *base = a.anc + (int64_t)blockIdx.x * 2 * 5 * a.maxanc;
+      L0.ar.p = base; L0.aa.p = base + cap; L0.ab.p = base + 2 * cap; L0.cl.p = base + 3 * cap; L0.cn.p = base + 4 * cap;
+      base += 5 * (int64_t)cap;
+      L1.ar.p = base; L1.aa.p = base + cap; L1.ab.p = base + 2 * cap; L1.cl.p = base + 3 * cap; L1.cn.p = base + 4 * cap;
+    } else {
+      const uint32_t c = (uint32_t)cap;
+      L0.ar.off = 0; L0.aa.off = c; L0.ab.off = 2 * c; L0.cl.off = 3 * c; L0.cn.off = 4 * c;
+      L1.ar.off = 5 * c; L1.aa.off = 6 * c; L1.ab.off = 7 * c; L1.cl.off = 8 * c; L1.cn.off = 9 * c;
+    }
     L0.cap = L1.cap = cap;
     L0.s = &s_lvl[0]; L1.s = &s_lvl[1];
   }
+  __shared__ int s_flag[2];
   WG g;
   g.reads = a.reads;
   for (int t = 0; t < 3; ++t) {
@@ -525,6 +693,8 @@ __global__ void __launch_bounds__(kSplitThreads) k_split(SplitArgs a)
   g.wl = a.wl + (int64_t)blockIdx.x * 3 * a.maxwin * 8;
   g.tab_cap = a.tab_cap; g.maxwin = a.maxwin;
   g.stamps = a.stamps;
+  g.lds_tab = (!BIG && a.lds_tables) ? (int)((2 * 5 * a.maxanc * sizeof(AT) + 3) / 4) : -1;
+  g.lds_flag = s_flag;
   for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     const DSeq ref{a.read_off[3 * r], (uint32_t)(a.read_off[3 * r + 1] - a.read_off[3 * r])};
     const DSeq S1{a.read_off[3 * r + 1], (uint32_t)(a.read_off[3 * r + 2] - a.read_off[3 * r + 1])};
@@ -725,6 +895,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   const bool big = maxanc > kMaxAnchors;
   a.anc = nullptr; a.maxanc = maxanc;
   a.stamps = nullptr;
+  a.lds_tables = 0;
   if (dbg) {
     if (c->d_sp_scan.ensure(4096)) return elector_fail(c, ELECTOR_E_NOMEM, "stamps");
     a.stamps = c->d_sp_scan.as<unsigned long long>();
@@ -740,10 +911,20 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     static bool attr = false;
     if (!attr) {
       HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * 5 * kMaxAnchors * 4));
+                                    160 * 1024 - 512));
       attr = true;
     }
-    hipLaunchKernelGGL(k_split<false>, dim3((unsigned)blocks), dim3(kSplitThreads), (size_t)(2 * 5 * maxanc * 4), st, a);
+    // on-chip tables when most of the batch's reads are short enough for them and they fit beside the anchors
+    size_t lds = ((size_t)(2 * 5 * maxanc * 2) + 3) & ~(size_t)3;   // 16-bit anchor arrays
+    int64_t fit = 0;
+    for (int64_t r = 0; r < n_in; ++r) {
+      const int64_t m = std::max(std::max(read_off[3 * r + 1] - read_off[3 * r], read_off[3 * r + 2] - read_off[3 * r + 1]),
+                                 read_off[3 * r + 3] - read_off[3 * r + 2]);
+      fit += m <= (int64_t)kLdsMaxN;
+    }
+    a.lds_tables = !std::getenv("ELECTOR_SPLIT_HBM_TABLES") && 2 * fit >= n_in && lds + kLdsTabBytes <= (size_t)(160 * 1024 - 512);
+    if (a.lds_tables) lds += kLdsTabBytes;
+    hipLaunchKernelGGL(k_split<false>, dim3((unsigned)blocks), dim3(kSplitThreads), lds, st, a);
   }
   HIPCHK(c, hipGetLastError());
   // kinds and counts to the host: the reads the device could not take are split by the host code
@@ -756,8 +937,8 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     unsigned long long hs[16];
     (void)hipMemcpy(hs, a.stamps, sizeof hs, hipMemcpyDeviceToHost);
     const double nc = hs[7] ? (double)hs[7] : 1.0, nr = hs[9] ? (double)hs[9] : 1.0;
-    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f\n",
-                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr);
+    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu\n",
+                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7]);
   }
   (void)nthreads;
   int64_t n_host = 0;
