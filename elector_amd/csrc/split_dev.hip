@@ -61,6 +61,13 @@ struct SplitArgs {
 // offsets relative to the start of the read's own sequence
 __device__ __forceinline__ int ldg(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stg(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the same through a pointer the compiler knows to be global memory: a store through a generic pointer is a FLAT
+// instruction, which also counts in lgkmcnt -- the next LDS read then waits for the store's trip to memory
+typedef __attribute__((address_space(1))) int32_t global_i32;
+__device__ __forceinline__ void stg_global(int32_t *p, int v)
+{
+  __hip_atomic_store((global_i32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ uint32_t map1(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u; }   // ref: str2num
 __device__ __forceinline__ uint32_t map2(uint8_t c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // ref: rolling update
@@ -274,11 +281,14 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   auto pack = [&](const uint8_t *s, uint32_t n, uint32_t *dst) {
     const uint32_t nw = (n + 15) / 16 + 2;
     for (uint32_t wdx = tid; wdx < nw; wdx += kSplitThreads) {
+      uint8_t ch[16];
+#pragma unroll
+      for (uint32_t i = 0; i < 16; ++i) { const uint32_t q = 16 * wdx + i; ch[i] = s[q < n ? q : 0]; }   // all sixteen loads in flight
       uint32_t v = 0;
 #pragma unroll
       for (uint32_t i = 0; i < 16; ++i) {
         const uint32_t q = 16 * wdx + i;
-        if (q < n) v |= (q < (uint32_t)k ? map1(s[q]) : map2(s[q])) << (2 * i);
+        if (q < n) v |= (q < (uint32_t)k ? map1(ch[i]) : map2(ch[i])) << (2 * i);
       }
       dst[wdx] = v;
     }
@@ -310,7 +320,7 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
     const uint32_t c = LTab::bits(sr, p, kmsk);
     const int b = t2.find(c);
     const int a = b >= 0 ? t1.find(c) : -1;
-    stg(ca + p, a); stg(cb + p, b);
+    stg_global(ca + p, a); stg_global(cb + p, b);
   }
   return true;
 }
@@ -449,17 +459,21 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
         const uint32_t base = base0 + 64 * q;
         const int a = av[q], b = a >= 0 ? bv[q] : -1;
         unsigned long long m = __builtin_amdgcn_ballot_w64(a >= 0);
+        // candidates at most minSize loop steps after the last anchor are out: drop them from the mask at once
+        if (m && last + minSize + 1 >= base) {
+          const uint32_t skip = last + minSize + 2 - base;    // first lane whose j = base + l - 1 exceeds last + minSize
+          m = skip >= 64 ? 0ull : m & (~0ull << skip);
+        }
         while (m) {
           const int l = __builtin_ctzll(m);
-          m &= m - 1;
           const uint32_t j = base + l - 1;                    // loop index of this position
-          if ((uint32_t)(j - last) > minSize) {
-            const int sa = __shfl(a, l), sb = __shfl(b, l);
-            if (n < L.cap) { if (tid == 0) { L.ar[n] = (int)(j + 1); L.aa[n] = sa; L.ab[n] = sb; } }
-            else fail = true;
-            ++n;
-            last = j;
-          }
+          const int sa = __builtin_amdgcn_readlane(a, l), sb = __builtin_amdgcn_readlane(b, l);
+          if (n < L.cap) { if (tid == 0) { L.ar[n] = (typename LV::elem)(j + 1); L.aa[n] = (typename LV::elem)sa; L.ab[n] = (typename LV::elem)sb; } }
+          else fail = true;
+          ++n;
+          last = j;
+          const uint32_t skip = (uint32_t)l + minSize + 1;     // the next one must sit more than minSize steps further on
+          m = skip >= 64 ? 0ull : m & (~0ull << skip);
         }
       }
     }
@@ -470,26 +484,49 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
   // longest chain, back to front (:79-126): wavefront 0
   const int n = L.s->n;
   if (tid < 64 && n > 0) {
+    // The successors an anchor can chain to lie within 1000 reference bases: at most 48 anchors, which the
+    // wavefront keeps in registers -- lane l holds anchor i + 1 + l (positions and chain length), shifted by one
+    // lane per step with the anchor just finished entering at lane 0.  No LDS read sits on the loop's critical
+    // path; the anchors themselves are fetched 64 at a time.
+    int wr = 0, wa = 0, wb = 0, wc = 0;
+    int fr = 0, fa = 0, fb = 0;
     for (int i = n - 1; i >= 0; --i) {
-      const int ri = L.ar[i], ai = L.aa[i], bi = L.ab[i];
+      if (i == n - 1 || (i & 63) == 63) {
+        const int jj = (i & ~63) + tid;
+        fr = jj < n ? (int)L.ar[jj] : 0; fa = jj < n ? (int)L.aa[jj] : 0; fb = jj < n ? (int)L.ab[jj] : 0;
+      }
+      const int ri = __builtin_amdgcn_readlane(fr, i & 63), ai = __builtin_amdgcn_readlane(fa, i & 63),
+                bi = __builtin_amdgcn_readlane(fb, i & 63);
+      const bool near = i + 1 + tid < n && wr - ri < 1000 && wr > ri;
       int best = -1, nxt = -1;
-      for (int j0 = i + 1; j0 < n; j0 += 64) {
-        const int j = j0 + tid;
-        const bool near = j < n && L.ar[j] - ri < 1000 && L.ar[j] > ri;
-        const bool ok = near && L.aa[j] - ai < 1000 && L.aa[j] > ai && L.ab[j] - bi < 1000 && L.ab[j] > bi;
+      if (__builtin_amdgcn_ballot_w64(tid == 63 && near) == 0) {
+        const bool ok = near && wa - ai < 1000 && wa > ai && wb - bi < 1000 && wb > bi;
         // longest first, the earlier successor among equals: one key, one reduction over the wavefront
-        const uint32_t key = ok ? (((uint32_t)L.cl[j] + 1u) << 6) | (uint32_t)(63 - tid) : 0u;
-        const uint32_t top = wave_max(key);
-        if (top) {
-          const int v = (int)(top >> 6) - 1, vj = j0 + 63 - (int)(top & 63u);
-          if (v > best) { best = v; nxt = vj; }              // strict: an earlier block's successor wins ties
+        const uint32_t top = wave_max(ok ? (((uint32_t)wc + 1u) << 6) | (uint32_t)(63 - tid) : 0u);
+        if (top) { best = (int)(top >> 6) - 1; nxt = i + 1 + 63 - (int)(top & 63u); }
+      } else {
+        // more than 64 successors in reach (cannot happen with anchors more than 20 bases apart): the plain scan
+        for (int j0 = i + 1; j0 < n; j0 += 64) {
+          const int j = j0 + tid;
+          const bool nr = j < n && L.ar[j] - ri < 1000 && L.ar[j] > ri;
+          const bool ok = nr && L.aa[j] - ai < 1000 && L.aa[j] > ai && L.ab[j] - bi < 1000 && L.ab[j] > bi;
+          const uint32_t top = wave_max(ok ? (((uint32_t)L.cl[j] + 1u) << 6) | (uint32_t)(63 - tid) : 0u);
+          if (top) {
+            const int v = (int)(top >> 6) - 1, vj = j0 + 63 - (int)(top & 63u);
+            if (v > best) { best = v; nxt = vj; }            // strict: an earlier block's successor wins ties
+          }
+          // ref: the scan stops at the first anchor too far on the reference ("TOO FAR NOW", :98-101)
+          if (__builtin_amdgcn_ballot_w64(j < n && !nr) != 0) break;
         }
-        // ref: the scan stops at the first anchor too far on the reference ("TOO FAR NOW", :98-101)
-        if (__builtin_amdgcn_ballot_w64(j < n && !near) != 0) break;
       }
       if (tid == 0) { L.cl[i] = (typename LV::elem)(1 + best); L.cn[i] = (typename LV::elem)(best >= 0 ? nxt : -1); }
-      __builtin_amdgcn_wave_barrier();
+      // the window moves on: lane l takes lane l - 1, lane 0 the anchor just finished (DPP wave_shr:1)
+      wr = __builtin_amdgcn_update_dpp(ri, wr, 0x138, 0xf, 0xf, false);
+      wa = __builtin_amdgcn_update_dpp(ai, wa, 0x138, 0xf, 0xf, false);
+      wb = __builtin_amdgcn_update_dpp(bi, wb, 0x138, 0xf, 0xf, false);
+      wc = __builtin_amdgcn_update_dpp(1 + best, wc, 0x138, 0xf, 0xf, false);
     }
+    __builtin_amdgcn_wave_barrier();
     // start: the longest, the earliest among equals
     int v = -1, vi = 0x7fffffff;
     for (int i = tid; i < n; i += 64) if (L.cl[i] > v) { v = L.cl[i]; vi = i; }
