@@ -152,9 +152,18 @@ def main(args=None):
         t1 = time.perf_counter()
         hit = computeStats.cached_pieces(outdir + "/msa.fa", {}) is not None
         log = io.StringIO()
+        prof = None
+        if os.environ.get("ELECTOR_E2E_PROFILE"):
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         with redirect_stdout(buf):
             tup = computeStats.outputRecallPrecision(paths[1], outdir, log, small, wrong, 5, 0.1, "sizes.txt", {})
         t2 = time.perf_counter()
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(18)
         stages = {k: round(v, 3) for k, v in alignment.STAGE_SECONDS.items()}
         # the same report from the text file (what call site #2 cost before the counters were handed over)
         alignment.MSA_CACHE.clear()

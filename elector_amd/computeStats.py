@@ -182,8 +182,12 @@ def aggregate(pieces, counters, ratios, outPerReadMetrics):
     totalCorBases = totalUncorBases = 0
     GCRateRef, GCRateCorr = [], []
     n_reads = len(pieces.read_first) - 1
+    # plain Python integers from here on (the same values, several times cheaper to index than numpy scalars)
+    read_first = np.asarray(pieces.read_first).tolist()
+    counters = np.asarray(counters).tolist()
+    per_read = []
     for r in range(n_reads):
-        p0, p1 = int(pieces.read_first[r]), int(pieces.read_first[r + 1])
+        p0, p1 = read_first[r], read_first[r + 1]
         nfrag = p1 - p0
         split = nfrag > 1
         if split:
@@ -230,9 +234,7 @@ def aggregate(pieces, counters, ratios, outPerReadMetrics):
                 missingSize.append(missingInRead)
             corBRate = cors / (cors + uncs) if (cors + uncs) != 0 else 0
             uncorCorBRate = ucors / (ucors + uuncs) if (ucors + uuncs) != 0 else 0
-            outPerReadMetrics.write(str(rec) + " recall\n")
-            outPerReadMetrics.write(str(prec) + " precision\n")
-            outPerReadMetrics.write(str(corBRate) + " correct_rate\n")
+            per_read.append(str(rec) + " recall\n" + str(prec) + " precision\n" + str(corBRate) + " correct_rate\n")
             recall.append(rec); precision.append(prec)
             corBasesRate.append(corBRate); uncorCorBasesRate.append(uncorCorBRate)
             totalCorBases += cors
@@ -245,6 +247,7 @@ def aggregate(pieces, counters, ratios, outPerReadMetrics):
             countReadTrimmed += 1
         nbReadsToDivide += 1
 
+    outPerReadMetrics.write("".join(per_read))
     GCRateRef = round(sum(GCRateRef) / len(GCRateRef), 3)
     GCRateCorr = round(sum(GCRateCorr) / len(GCRateCorr), 3)
     recall = sum(recall) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
@@ -321,16 +324,16 @@ def outputReadSizeDistribution(correctedFileName, outFileName, outDir, trimmedOr
     """computeStats.py:273-286"""
     out = open(outDir + "/" + outFileName, 'w')
     out.write("size type\n")
-    for readSize in lenAllReads:
-        out.write(str(readSize) + " reads\n")
+    out.write("".join([str(readSize) + " reads\n" for readSize in lenAllReads]))
     if trimmedOrSplit != 0:
-        cor = open(correctedFileName)
-        l = cor.readline()
-        while l != "":
-            l = cor.readline()[:-1]
-            out.write(str(len(l)) + " sequences\n")
-            l = cor.readline()
-        cor.close()
+        # the reference reads a header line, then a sequence line whose last character it drops, until a
+        # header read comes back empty; the same pairs from the file iterator, one write
+        with open(correctedFileName) as cor:
+            it = iter(cor)
+            lines = []
+            for _ in it:
+                lines.append(str(len(next(it, "")[:-1])) + " sequences\n")
+            out.write("".join(lines))
     out.close()
 
 
