@@ -37,8 +37,8 @@ def test_golden_reads(engine):
 def test_profiles(engine, profile, n):
     triples, headers, _ = synthetic.read_pieces(profile, n, 77)
     same(engine, triples, headers)
-    if profile != "chr1_20x_ont_50kb":       # (a read beyond ~60 kb sends its batch to the host code)
-        assert isinstance(split.split_reads_device(engine, triples, 0.1, headers).d_bases, split.DevBases)
+    # the device path itself took the batch (reads beyond ~60 kb included: their anchor arrays live in HBM)
+    assert isinstance(split.split_reads_device(engine, triples, 0.1, headers).d_bases, split.DevBases)
 
 
 def test_degenerate_reads(engine):
@@ -60,3 +60,22 @@ def test_degenerate_reads(engine):
     same(engine, reads)
     same(engine, reads, thr=0.6)
     same(engine, [], None)
+
+
+def test_on_chip_table_limits(engine):
+    """The k-mer tables in LDS take reads of up to 12,500 bases and uncorrected reads that share at most 3,200
+    unique k-mers with the reference; everything else in the same batch goes through the HBM tables."""
+    rng = np.random.default_rng(11)
+    reads = []
+    for n in (5000, 9000, 12499, 12500, 12501, 13000, 16000):
+        r = synth.random_seq(rng, n)
+        reads.append((r, synth.mutate(rng, r, 0.01), synth.mutate(rng, r, 0.13)))
+    r = synth.random_seq(rng, 8000)
+    reads.append((r, r, r))                                          # error-free: the second table overflows
+    reads.append((r, synth.mutate(rng, r, 0.01), synth.mutate(rng, r, 0.02)))   # nearly error-free uncorrected read
+    r = synth.random_seq(rng, 3300)
+    reads.append((r, r, r))                                          # just around the fill limit
+    for _ in range(30):                                              # the batch is mostly short reads: tables on chip
+        r = synth.random_seq(rng, int(rng.integers(3000, 11000)))
+        reads.append((r, synth.mutate(rng, r, 0.01), synth.mutate(rng, r, 0.15)))
+    same(engine, reads)
