@@ -194,7 +194,7 @@ __host__ __device__ inline int poa_slot_need(int Lr, int Lc, int Lu, int G)
 {
   const int cap = poa_xi_cap(Lr, Lc);
   const int ua = poa_union_a(Lr, Lc, G), ub = poa_union_b(cap, Lu, G);
-  return 16 + ((Lu + 3) & ~3) + 4 * (cap + 1) + (ua > ub ? ua : ub);
+  return 16 + ((Lu + 3) & ~3) + 4 * (cap + 2) + (ua > ub ? ua : ub);
 }
 
 }  // namespace elector

@@ -157,7 +157,7 @@ __device__ __forceinline__ int pk_diag_run(bool flag, int q)
 constexpr uint32_t kN_Far1 = 1u, kN_Far2 = 2u, kN_Has2 = 4u, kN_Virt1 = 8u, kN_Virt2 = 16u, kN_NewCol = 32u;
 
 // LDS slot of one window (bytes); must mirror poa_slot_need() below.
-//   [hdr 16][unc symbols][node records u32 (xi_cap + 1)][union]
+//   [hdr 16][unc symbols][node records u32 (xi_cap + 2: records 1 .. n1 between two zero guards)][union]
 //   union, alignment #1 .. fusion #1: [ref + cor symbols][x2y Lr][node_ref Lr][node_cor Lc][y2x Lc]  (one byte per
 //          entry in the 8-lane classes, whose windows have fewer than 255 nodes; two otherwise)
 //   union, alignment #2 .. output:    [x2y u16 n1][ordinal bytes k2 * G | col_y u16 Lu]
@@ -651,7 +651,7 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
   W.slot = slot;
   W.xi_cap = poa_xi_cap(W.Lr, W.Lc);
   W.off_xi = 16 + pk_align_up(W.Lu, 4);
-  W.off_u = W.off_xi + 4 * (W.xi_cap + 1);
+  W.off_u = W.off_xi + 4 * (W.xi_cap + 2);                     // records 1 .. n1 between two zero guards
   const int ua = poa_union_a(W.Lr, W.Lc, G), ub = poa_union_b(W.xi_cap, W.Lu, G);
   const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(kp.open_x, kp.ext_x));
   W.valid = W.valid && W.off_u + max(ua, ub) <= a.slot_bytes && W.Lc <= RS && W.Lu <= RS &&
@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
         }
         dg0 = upS;
         const bool actA = needA[0] && jj <= W[0].Lr, actB = needA[1] && jj <= W[1].Lr;
-        if (actA || actB) mv[t * 64 + lane] = mvw;
+        mv[t * 64 + lane] = mvw;
         if ((actA && jj == W[0].Lr && g == gstar0) || (actB && jj == W[1].Lr && g == gstar1)) {
 #pragma unroll
           for (int k = 0; k < R; ++k) {
@@ -923,6 +923,10 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       W[h].valid = false;
     }
   }
+  // zero guards either side of the node records: alignment #2 reads record clamp(jj + 1, 0, n1 + 1) without a test
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (g == 0) { xinfo[h][0] = 0u; xinfo[h][(W[h].valid ? W[h].n1 : 0) + 1] = 0u; }
   __syncthreads();
   PK_STAMP(4);
 
@@ -959,20 +963,29 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
     // the gap it offers; the origin counts as "open"
     uint32_t BR1 = 0, BR2 = 0, BE1 = pk1(-kp.open_x), BE2 = pk1(-kp.open_x);
     const int gstar0 = (W[0].Lu - 1) / R, kstar0 = (W[0].Lu - 1) % R, gstar1 = (W[1].Lu - 1) / R, kstar1 = (W[1].Lu - 1) % R;
-    uint32_t xiA_next = (W[0].valid && g == 0 && W[0].n1 >= 1) ? xinfo[0][1] : 0u;
-    uint32_t xiB_next = (W[1].valid && g == 0 && W[1].n1 >= 1) ? xinfo[1][1] : 0u;
+    const int n1c0 = (W[0].valid ? W[0].n1 : 0) + 1, n1c1 = (W[1].valid ? W[1].n1 : 0) + 1;   // index of the upper guard
+    uint32_t xiA_next = xinfo[0][min(max(1 - g, 0), n1c0)];
+    uint32_t xiB_next = xinfo[1][min(max(1 - g, 0), n1c1)];
+    // the lane that holds a window's last row watches for nodes that can end the alignment
+    const uint32_t finA_bit = (W[0].valid && g == gstar0) ? ((uint32_t)kFlagFinal << 16) : 0u;
+    const uint32_t finB_bit = (W[1].valid && g == gstar1) ? ((uint32_t)kFlagFinal << 16) : 0u;
 
     int n_steps = 0, n_two = 0, n_virt = 0;                        // debug: steps per code path
-    auto step = [&](int t, uint32_t (&Sa)[R], uint32_t (&Ea)[R], uint32_t (&Sb)[R], uint32_t (&Eb)[R]) {
+    // FIRST: the steps in which some lane has not reached its first column yet (t < G)
+    auto step = [&](auto first_tag, int t, uint32_t (&Sa)[R], uint32_t (&Ea)[R], uint32_t (&Sb)[R], uint32_t (&Eb)[R]) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       const int jj = t - g;
       const uint32_t xiA = xiA_next, xiB = xiB_next;
-      xiA_next = (W[0].valid && jj >= 0 && jj < W[0].n1) ? xinfo[0][jj + 1] : 0u;
-      xiB_next = (W[1].valid && jj >= 0 && jj < W[1].n1) ? xinfo[1][jj + 1] : 0u;
+      xiA_next = xinfo[0][min(max(jj + 1, 0), n1c0)];
+      xiB_next = xinfo[1][min(max(jj + 1, 0), n1c1)];
       // per-half select masks: predecessor two columns back (else one)
       const uint32_t M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
-      const uint32_t xlp = ((xiA >> 8) & 0xFFu) | ((xiB << 8) & 0xFF0000u);
-      const bool virt = __builtin_amdgcn_ballot_w64(((xiA | xiB) & kN_Virt1) != 0u) != 0;
-      const bool two = virt || __builtin_amdgcn_ballot_w64(((xiA | xiB) & kN_Has2) != 0u) != 0;
+      // the two letters (byte 1 of each record) to the low bytes of the two halves: one v_perm_b32
+      const uint32_t xlp = __builtin_amdgcn_perm(xiB, xiA, 0x0c050c01u);
+      // one test for the common case: no lane at a node with a second predecessor or a far virtual start
+      const uint32_t xor_ = xiA | xiB;
+      const bool two = __builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2)) != 0u) != 0;
+      const bool virt = two && __builtin_amdgcn_ballot_w64((xor_ & kN_Virt1) != 0u) != 0;
       // a node without a second predecessor repeats the first (bit 1 = bit 0): when no lane of the wave has one,
       // everything about the second candidate is left out
       uint32_t M2 = M1, V1 = 0, V2 = 0, bb1 = bfi(M1, BE2, BE1);
@@ -993,7 +1006,7 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       const uint32_t up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);        // row above at column jj - 1
       const uint32_t up2 = pk_shift_in<G>(BR2, last3, g);            // ... at column jj - 2
       const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
-      if (jj >= 1) {                                                 // before its first column a lane keeps column 0
+      if (!FIRST || jj >= 1) {                                       // before its first column a lane keeps column 0
         const uint32_t sv3 = Sb[R - 1];
         uint32_t dt1 = bfi(M1, up2, up1), dt2 = dt1, insY = upE, mvw = 0, secw = 0;
         if (two) dt2 = bfi(M2, up2, up1);
@@ -1043,14 +1056,12 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
         else cells(std::false_type{}, std::false_type{});
         last3 = sv3;
         BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
-        const bool actA = xiA != 0u, actB = xiB != 0u;
-        if (actA || actB) mv[t * 64 + lane] = mvw;
+        mv[t * 64 + lane] = mvw;                                     // every lane: a lane past its window's end writes a word nobody reads
         if (two) {
           if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
           if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
         }
-        const bool finA = actA && g == gstar0 && ((xiA >> 16) & kFlagFinal) != 0u;
-        const bool finB = actB && g == gstar1 && ((xiB >> 16) & kFlagFinal) != 0u;
+        const bool finA = (xiA & finA_bit) != 0u, finB = (xiB & finB_bit) != 0u;
         if (finA || finB) {
 #pragma unroll
           for (int k = 0; k < R; ++k) {
@@ -1060,9 +1071,16 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
         }
       }
     };
-    for (int t = 1; t <= tmax; t += 2) {
-      step(t, S1, E1, S2, E2);
-      step(t + 1, S2, E2, S1, E1);
+    {
+      int t = 1;
+      for (; t <= tmax && t < G; t += 2) {                           // G is even: the pairs line up
+        step(std::true_type{}, t, S1, E1, S2, E2);
+        step(std::true_type{}, t + 1, S2, E2, S1, E1);
+      }
+      for (; t <= tmax; t += 2) {
+        step(std::false_type{}, t, S1, E1, S2, E2);
+        step(std::false_type{}, t + 1, S2, E2, S1, E1);
+      }
     }
     if ((a.debug & 4) && threadIdx.x == 0) {
       atomicAdd(a.stamps + 12, (unsigned long long)n_steps);
