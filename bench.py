@@ -41,6 +41,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# hardware queues for the contexts' launch chains (see elector_amd/__init__.py); must precede the first HIP call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # VALU issue peaks, G wave64-instructions per second for the chip: 256 CUs x 4 SIMDs x 2.4 GHz.  A SIMD takes one
@@ -235,10 +237,10 @@ def main():
     lu = off[3::3] - off[2:-1:3]
     dev = torch.device("cuda", local)
     d_bases = torch.from_numpy(win.bases).to(dev)
-    # E engine contexts take the steps in turn (several batches in flight: the serial head and tail
+    # E engine contexts (four by default) take the steps in turn (several batches in flight: the serial head and tail
     # of one batch -- symbolize / trivial pass / list sort, merge / statistics -- run beside the
     # alignment kernels of the other).  Every context has its own output buffers.
-    n_eng = 1 if args.serial else max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "3")))
+    n_eng = 1 if args.serial else max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "4")))
     engines = [PoaEngine(local) for _ in range(n_eng)]
     if args.serial:
         engines[0].option("chains", 1)

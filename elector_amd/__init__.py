@@ -11,4 +11,11 @@ Only what the path needs lives here:
 There is no CPU fallback in this package: if the HIP library is missing or no
 gfx950 device is present, the compute entry points raise.
 """
+import os as _os
+
+# The engine contexts keep several launch chains and batches in flight, each on a HIP stream of its own.  The
+# runtime maps streams onto 4 hardware queues unless told otherwise; with 16 the chains really run side by side
+# (bench.py: +12 % with four contexts).  Only effective when set before the process' first HIP call.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 __version__ = "0.1.0"

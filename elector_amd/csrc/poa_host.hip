@@ -802,8 +802,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // geometry compete for LDS and L2 -- and a single chain pays every kernel's tail), so the four
   // launches go to TWO streams; within a chain big classes first, alignment #1 then #2 of each bin.
   // ELECTOR_CHAINS=1|4 are the alternatives for experiments (4 = one stream per group size).
+  // (with the runtime's default of 4 hardware queues two chains are best; with GPU_MAX_HW_QUEUES >= 12, which the
+  // Python package sets before the first HIP call, three: 9.3 -> 10.6 Gbases/s on the bench batch with four contexts)
+  const int hwq = std::getenv("GPU_MAX_HW_QUEUES") ? std::atoi(std::getenv("GPU_MAX_HW_QUEUES")) : 4;
   const int n_chains = c->chains > 0 ? c->chains
-                       : std::getenv("ELECTOR_CHAINS") ? std::max(1, std::min(4, std::atoi(std::getenv("ELECTOR_CHAINS")))) : 2;
+                       : std::getenv("ELECTOR_CHAINS") ? std::max(1, std::min(4, std::atoi(std::getenv("ELECTOR_CHAINS")))) : (hwq >= 12 ? 3 : 2);
   std::vector<int> bin_stream((size_t)kBins, 0), bin_order;
   {
     auto group_of = [&](int b) { const int G = kClsG[b / kNT]; return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };
