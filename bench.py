@@ -261,6 +261,7 @@ def main():
     gather_sizes = edist.gather_sizes(len(piece_first) - 1) if world > 1 else None
     pending = []
     turn = [0]
+    host_s = [0.0]                               # host time of classifying and enqueueing (the GPU work is asynchronous)
 
     def collect():
         """per-piece counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
@@ -275,8 +276,10 @@ def main():
         e = turn[0] % n_eng
         turn[0] += 1
         dc, dn, ds = outs[e]
+        th = time.perf_counter()
         engines[e].align_device(d_bases, off, dc, dn, ds)
         pending.append((e, engines[e].msa_stats_enqueue(n, dc, dn, ds, piece_first, read_first)))
+        host_s[0] += time.perf_counter() - th
         return collect() if len(pending) > n_eng else None
 
     # untimed setup, continued: grow every workspace (both halves of the double-buffered upload staging
@@ -301,6 +304,7 @@ def main():
     torch.cuda.synchronize()
     for g in engines:
         g.sync()
+    host_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -312,6 +316,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    host_ms_per_step = host_s[0] / args.steps * 1e3
 
     # ---- after the clock: serial pass for the per-kernel roofline, checks, counters, gather -----------
     serial_steps = args.steps if args.serial else max(1, args.serial_steps)
@@ -399,6 +404,7 @@ def main():
                                    "other": round(t_oth / serial_steps, 3),
                                    "merge_and_counters": round(t_st / serial_steps, 3),
                                    "serial_step_wall": round(serial_wall * 1e3, 3),
+                                   "host_classify_and_enqueue": round(host_ms_per_step, 3),
                                    "note": "HIP-event time per launch, summed per step, from %d un-overlapped steps "
                                            "(one context, one launch chain)%s"
                                            % (serial_steps, "" if args.serial else " run after the timed region")},

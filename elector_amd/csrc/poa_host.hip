@@ -515,6 +515,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   int32_t *h_bin_chunks = reinterpret_cast<int32_t *>(h_chunks + 2 * part_chunks_max);   // first chunk, #chunks per bin
 
   // window sizes -> status, coarse size key (counting sort, largest first), launch class
+  const int host_threads_max = std::getenv("ELECTOR_HOST_THREADS") ? std::max(1, std::atoi(std::getenv("ELECTOR_HOST_THREADS"))) : 16;
   constexpr int NB = 256;
   build_tiers();
   std::vector<int16_t> bin((size_t)n, -1);
@@ -544,7 +545,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   std::vector<uint8_t> wkey((size_t)n);
   std::atomic<int> bad_offsets(0);
   {
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads_max, n / 32768));
     // per thread: size keys, bin counts, generic count, then per bin the maxima of
     // alignment #1's slot need, Lr, Lc, Lu and Lr + Lc (the bound on |PO|)
     std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + 1 + 6 * kBins + 2, 0));
@@ -686,7 +687,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     for (int b = 0; b < kBins; ++b)
       if (bin_cnt[(size_t)b]) { dest_of_bin[(size_t)b] = (int)dest_first.size(); dest_first.push_back(bin_first[(size_t)b]); }
     const int gen_dest = (int)dest_first.size(), nbuckets = (gen_dest + 1) * NB;
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(16, n / 32768));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads_max, n / 32768));
     std::vector<std::vector<int64_t>> cnt((size_t)T, std::vector<int64_t>((size_t)nbuckets, 0));
     auto dest = [&](int64_t w) { const int b = bin[(size_t)w]; return b >= 0 ? dest_of_bin[(size_t)bin_final[(size_t)b]] : gen_dest; };
     auto pass = [&](int t, bool place) {
