@@ -1077,8 +1077,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       }
       // behind k_poa the two-kernel path only sees the windows handed back: its small launches go to a stream
       // of their own (after this bin's k_poa), so that the chain can start its next k_poa at once
-      const int so = use_pack ? 3 : sk;
-      if (use_pack) {
+      // (with a single chain -- bench.py --serial, every kernel alone on the chip -- they stay in line)
+      const bool hb_own = use_pack && n_chains > 1;
+      const int so = hb_own ? 3 : sk;
+      if (hb_own) {
         if (c->hb_events.size() <= (size_t)hb_used) {
           hipEvent_t e;
           HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
