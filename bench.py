@@ -260,6 +260,7 @@ def main():
     # tell each other once, the steps then need one collective each
     gather_sizes = edist.gather_sizes(len(piece_first) - 1) if world > 1 else None
     pending = []
+    gathers = []
     turn = [0]
     host_s = [0.0]                               # host time of classifying and enqueueing (the GPU work is asynchronous)
 
@@ -267,7 +268,11 @@ def main():
         """per-piece counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
         e, npieces = pending.pop(0)
         counters, _ = engines[e].msa_stats_collect(npieces)
-        return edist.gather_rows(counters, sizes=gather_sizes) if world > 1 else counters
+        if world == 1:
+            return counters
+        # the gather runs beside the next steps; at most two are in flight
+        gathers.append(edist.gather_rows_async(counters, gather_sizes))
+        return gathers.pop(0).wait() if len(gathers) > 2 else None
 
     def step():
         """Queue one step (windows in HBM -> POA kernels -> merge -> counters -> pinned host memory),
@@ -285,14 +290,18 @@ def main():
     # untimed setup, continued: grow every workspace (both halves of the double-buffered upload staging
     # and of the statistics slots) and let the HIP runtime size its queues for overlapped batches -- the
     # first batch that is enqueued while another still runs pays a one-time ~14 ms inside the runtime
+    def drain():
+        while pending:
+            collect()
+        while gathers:
+            gathers.pop(0).wait()
+
     for _ in range(3 * n_eng):
         step()
-    while pending:
-        collect()
+    drain()
     for _ in range(args.warmup):
         step()
-    while pending:
-        collect()
+    drain()
     for g in engines:
         g.sync()
         g.timing_enable(args.serial)
@@ -310,6 +319,8 @@ def main():
         step()
     while pending:
         counters = collect()                     # every step's counters are on the host before the clock stops
+    while gathers:
+        counters = gathers.pop(0).wait()         # ... and, with several ranks, on rank 0
     for g in engines:
         g.sync()
     torch.cuda.synchronize()

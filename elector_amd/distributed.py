@@ -81,6 +81,41 @@ def gather_rows(local, group=None, dst=0, sizes=None):
     return np.concatenate([o[: int(s)].cpu().numpy() for o, s in zip(out, sizes)], axis=0)
 
 
+class _Gather:
+    """a gather_rows in flight: wait() -> the concatenated rows on dst, None elsewhere"""
+
+    def __init__(self, work, pad, out, sizes, is_dst):
+        self._work, self._pad, self._out, self._sizes, self._is_dst = work, pad, out, sizes, is_dst
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if not self._is_dst:
+            return None
+        return np.concatenate([o[: int(s)].cpu().numpy() for o, s in zip(self._out, self._sizes)], axis=0)
+
+
+def gather_rows_async(local, sizes, group=None, dst=0):
+    """gather_rows without waiting for it: the collective runs while the caller goes on (bench.py: the next
+    step's kernels are already queued); sizes as from gather_sizes.  -> object with wait()."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    local = np.ascontiguousarray(local, dtype=np.int64)
+    ncol = local.shape[1] if local.ndim == 2 else 1
+    if len(sizes) != world or int(sizes[rank]) != local.shape[0]:
+        raise ValueError("gather_rows_async: sizes do not describe this rank's block")
+    cap = max(int(s) for s in sizes)
+    pad = torch.zeros((cap, ncol), dtype=torch.int64, device=dev)
+    if local.shape[0]:
+        pad[: local.shape[0]] = torch.from_numpy(local.reshape(local.shape[0], ncol)).to(dev)
+    out = [torch.zeros((cap, ncol), dtype=torch.int64, device=dev) for _ in range(world)] if rank == dst else None
+    work = dist.gather(pad, out, dst=dst, group=group, async_op=True)
+    return _Gather(work, pad, out, sizes, rank == dst)
+
+
 def sharded_counters(pieces, counter_fn, group=None):
     """Every rank computes the counters of its own contiguous range of READS with
     counter_fn(sub_pieces) -> int64[n_pieces_local, C]; rank 0 receives all rows in
