@@ -798,16 +798,13 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   };
   int64_t pool_stream[4] = {0, 0, 0, 0};
   int pool_slots[4] = {0, 0, 0, 0}, pool_tw[4] = {0, 0, 0, 0};     // per launch chain: slots per XCD, longest moves region
-  // Launch chains.  Two kernels side by side use the chip best (measured on the bench batch: 8.1 ms
-  // per step with two concurrent launch chains, 9.9 ms with four or more -- kernels of unlike
-  // geometry compete for LDS and L2 -- and a single chain pays every kernel's tail), so the four
-  // launches go to TWO streams; within a chain big classes first, alignment #1 then #2 of each bin.
-  // ELECTOR_CHAINS=1|4 are the alternatives for experiments (4 = one stream per group size).
-  // (with the runtime's default of 4 hardware queues two chains are best; with GPU_MAX_HW_QUEUES >= 12, which the
-  // Python package sets before the first HIP call, three: 9.3 -> 10.6 Gbases/s on the bench batch with four contexts)
-  const int hwq = std::getenv("GPU_MAX_HW_QUEUES") ? std::atoi(std::getenv("GPU_MAX_HW_QUEUES")) : 4;
+  // Launch chains.  Two kernels of a context side by side use the chip best: a single chain pays every kernel's
+  // tail, four and more compete for LDS and L2 (bench batch, one context: 8.1 ms per step with two chains,
+  // 9.9 ms with four or more).  With several contexts in flight and sixteen hardware queues (GPU_MAX_HW_QUEUES,
+  // set by the Python package) three chains are within +-3 % of two, box by box: two it is.  Within a chain big
+  // classes first.  ELECTOR_CHAINS=1|3|4 are the alternatives for experiments (4 = one stream per group size).
   const int n_chains = c->chains > 0 ? c->chains
-                       : std::getenv("ELECTOR_CHAINS") ? std::max(1, std::min(4, std::atoi(std::getenv("ELECTOR_CHAINS")))) : (hwq >= 12 ? 3 : 2);
+                       : std::getenv("ELECTOR_CHAINS") ? std::max(1, std::min(4, std::atoi(std::getenv("ELECTOR_CHAINS")))) : 2;
   std::vector<int> bin_stream((size_t)kBins, 0), bin_order;
   {
     auto group_of = [&](int b) { const int G = kClsG[b / kNT]; return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };
@@ -826,7 +823,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       }
       chain_of_group[0] = 0;
     }
-    // two chains: the bins, in class order, are dealt alternately -- both chains then hold about half
+    // two (or three) chains: the bins, in class order, are dealt in turn -- the chains then hold equal shares
     // of every group's work whatever the window distribution (as fast as the best hand-picked split of
     // the groups; a split by the work estimate above was 4 % slower), and the kernels that run side
     // by side are of neighbouring classes.  ELECTOR_CHAINS_BY_GROUP keeps whole groups together.
@@ -834,7 +831,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     int turn = 0;
     for (int b = kBins - 1; b >= 0; --b)
       if (bin_cnt[(size_t)b]) {
-        bin_stream[(size_t)b] = (deal && n_chains == 2) ? (turn++ & 1) : chain_of_group[group_of(b)];
+        bin_stream[(size_t)b] = (deal && (n_chains == 2 || n_chains == 3)) ? (turn++ % n_chains) : chain_of_group[group_of(b)];
         bin_order.push_back(b);
       }
     if (std::getenv("ELECTOR_DEBUG_BINS"))
