@@ -549,9 +549,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     // per thread: size keys, bin counts, generic count, then per bin the maxima of
     // alignment #1's slot need, Lr, Lc, Lu and Lr + Lc (the bound on |PO|)
     std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + 1 + 6 * kBins + 2, 0));
+    struct Memo { uint32_t key; int16_t bin; int32_t need_a, need_pack; };
+    constexpr size_t kMemo = 8192;
     auto work = [&](int t) {
       const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
       int64_t *cnt = tcnt[(size_t)t].data();
+      std::vector<Memo> memo(kMemo, Memo{0u, -1, 0, 0});
       std::memcpy(h_off + 3 * w0, off + 3 * w0, (size_t)(3 * (w1 - w0) + (w1 == n ? 1 : 0)) * 8);
       for (int64_t w = w0; w < w1; ++w) {
         const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
@@ -566,6 +569,23 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           st = ELECTOR_W_TOOLONG;
         h_status[w] = st;
         h_mv1[w] = h_mv2[w] = -1;
+        // the class search below depends on the three lengths only, and the splitter's windows repeat the same few
+        // thousand length triples over and over: a small direct-mapped memo per thread
+        const bool memo_ok = !st && use_fused && lr < 1024 && lc < 1024 && lu < 1024;
+        const uint32_t mkey = memo_ok ? (uint32_t)((lr << 20) | (lc << 10) | lu) + 1u : 0u;
+        Memo &me = memo[(size_t)((mkey * 2654435761u) >> 19) & (kMemo - 1)];
+        if (memo_ok && me.key == mkey) {
+          if (me.bin >= 0) {
+            bin[(size_t)w] = me.bin;
+            int64_t *mx = cnt + NB + kBins + 1 + me.bin;
+            mx[0] = std::max<int64_t>(mx[0], me.need_a);
+            mx[kBins] = std::max<int64_t>(mx[kBins], lr);
+            mx[2 * kBins] = std::max<int64_t>(mx[2 * kBins], lc);
+            mx[3 * kBins] = std::max<int64_t>(mx[3 * kBins], lu);
+            mx[4 * kBins] = std::max<int64_t>(mx[4 * kBins], lr + lc);
+            mx[5 * kBins] = std::max<int64_t>(mx[5 * kBins], me.need_pack);
+          }
+        } else
         if (!st && use_fused) {
           // one class for both fused kernels; |PO| is not known yet: typical growth estimate, windows
           // whose graph turns out larger are handed back by the device (k_left_b)
@@ -597,8 +617,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
             mx[2 * kBins] = std::max<int64_t>(mx[2 * kBins], lc);
             mx[3 * kBins] = std::max<int64_t>(mx[3 * kBins], lu);
             mx[4 * kBins] = std::max<int64_t>(mx[4 * kBins], lr + lc);
-            mx[5 * kBins] = std::max<int64_t>(mx[5 * kBins], poa_slot_need((int)lr, (int)lc, (int)lu, G));
+            const int need_pack = poa_slot_need((int)lr, (int)lc, (int)lu, G);
+            mx[5 * kBins] = std::max<int64_t>(mx[5 * kBins], need_pack);
+            if (memo_ok) { me.key = mkey; me.bin = (int16_t)b; me.need_a = need_a; me.need_pack = need_pack; }
           }
+          if (memo_ok && bin[(size_t)w] < 0) { me.key = mkey; me.bin = -1; me.need_a = 0; me.need_pack = 0; }
         }
         if (bin[(size_t)w] >= 0) {
           cnt[NB + bin[(size_t)w]]++;

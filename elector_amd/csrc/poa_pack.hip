@@ -216,9 +216,11 @@ __device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&nee
       }
       const int run = pk_diag_run<G>(inb[h] && xo && yo, q);
       if (g < run) x2y[h][cx[h]] = (IT)cy[h];
+      // where the walk goes on, from the lane at the end of the run: one shuffle for (x, y, stop)
       int nx = cx[h] - xo, ny = cy[h] - yo, fl = inb[h] ? 0 : 1;
       const int src = min(run, G - 1);
-      nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
+      const int nxt = __shfl(((nx + 2) & 0xFFF) | (((ny + 2) & 0xFFF) << 12) | (fl << 24), src, G);
+      nx = (nxt & 0xFFF) - 2; ny = ((nxt >> 12) & 0xFFF) - 2; fl = nxt >> 24;
       if (run >= G) { nx = x[h] - G; ny = y[h] - G; fl = 0; }
       if (alive[h]) {
         x[h] = nx; y[h] = ny;
@@ -490,8 +492,9 @@ __device__ __forceinline__ void traceback_b(const WinP (&W)[2], const uint32_t *
       const int rl = inb[h] ? cy[h] / R : 0;
       rlv[h] = rl; rk[h] = cy[h] - rl * R;
       word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(q, cx[h] + 1 + rl, rl) : 0));
-      rec[h] = inb[h] ? xinfo[h][cx[h] + 1] : 0u;
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) rec[h] = inb[h] ? xinfo[h][cx[h] + 1] : 0u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int xo = 0, yo = 0, px = cx[h];
@@ -510,7 +513,8 @@ __device__ __forceinline__ void traceback_b(const WinP (&W)[2], const uint32_t *
       if (inb[h] && xo && yo && g <= run) x2y[h][cx[h]] = (uint16_t)cy[h];   // the run's pairs, and the breaker's if it is a match
       int nx = px, ny = cy[h] - yo, fl = inb[h] ? 0 : 1;
       const int src = min(run, G - 1);
-      nx = __shfl(nx, src, G); ny = __shfl(ny, src, G); fl = __shfl(fl, src, G);
+      const int nxt = __shfl(((nx + 2) & 0xFFF) | (((ny + 2) & 0xFFF) << 12) | (fl << 24), src, G);
+      nx = (nxt & 0xFFF) - 2; ny = ((nxt >> 12) & 0xFFF) - 2; fl = nxt >> 24;
       if (run >= G) { nx = x[h] - G; ny = y[h] - G; fl = 0; }
       if (alive[h]) {
         x[h] = nx; y[h] = ny;
