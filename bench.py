@@ -395,7 +395,7 @@ def main():
             "metric": "triplet-MSA Mbases/s", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "%s: %d reads per GPU per step, cut into windows by the ELECTOR splitter rules"
                                    % (WORKLOADS[args.profile], args.reads),
                        "profile": args.profile, "reads_per_gpu": args.reads, "triples_per_gpu": n_pieces_in,
@@ -403,6 +403,8 @@ def main():
                        "filler_windows_per_gpu": int((lc == 1).sum()),
                        "parallelism": "shard-by-read x%d" % world,
                        "batches_in_flight_per_gpu": n_eng, "serial": bool(args.serial)},
+            # dtype: k_poa's recurrences run on 16-bit scores, two windows per 32-bit lane (the fall-back kernels, 0.2 %
+            # of the windows, on 32-bit ones)
             # DP cells per second.  effective: every cell the reference computes (Lr*Lc + |PO|*Lu per window);
             # computed: without alignment #1 of the windows whose corrected sequence equals the reference or
             # differs by one substitution, which the device settles without a dynamic program (k_trivial)
