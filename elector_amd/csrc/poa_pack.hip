@@ -681,13 +681,12 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
   // are not coherent with each other, so a slot is only ever used from one XCD: the pool is split by XCC id, and
   // every XCD has a queue of its free slot ids -- a wave takes the id at its ticket (head), gives it back at the
   // end (tail).  There are more slots than an XCD can hold waves, so a ticket's entry is filled by the time it
-  // is drawn or shortly after.  The ticket is drawn first thing: its trip to L2 runs beside the descriptor loads.
+  // is drawn or shortly after.
   uint32_t xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
   int32_t *mvq = a.mv_q + (size_t)xcc * kPoolStride;
   uint32_t ticket = 0;
-  if (a.mv_slots > 0 && lane == 0) ticket = (uint32_t)atomicAdd(mvq, 1);
 
   // ---- the descriptors of both windows: one trip for the list entries, one for everything that hangs on them ----
   WinP W[2];
@@ -708,6 +707,9 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[h][k] = a.b.off[3 * (int64_t)w[h] + k];
     }
+    // the ticket is drawn behind the descriptor loads: memory operations return in order, so the loads do not
+    // wait for the (slower) atomic, whose trip runs beside the symbol loads instead
+    if (a.mv_slots > 0 && lane == 0) ticket = (uint32_t)atomicAdd(mvq, 1);
     if (lane < 32) chr[lane] = chr_l;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
