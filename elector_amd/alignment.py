@@ -283,24 +283,51 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     work = queue.Queue(maxsize=2)
     failure = []
 
-    def reader():
+    # Two reader threads: one cuts the files into batches (native code), one splits them.  The reader hands out
+    # views of its two buffer sets in turn, so it may be one batch ahead of the splitter and no further: a permit
+    # per buffer set, given back when the splitter is done with a batch.
+    parsed = queue.Queue(maxsize=2)
+    permits = threading.Semaphore(2)
+
+    def parser():
         import time
         try:
             rf = split.ReadsFile(reference, uncorrected, corrected)
             try:
                 while True:
+                    permits.acquire()
                     t0 = time.perf_counter()
                     rb = rf.next(READS_PER_BATCH, start, stop)
-                    _tick("parse FASTA (reader thread, native)", t0)
+                    _tick("parse FASTA (parser thread, native)", t0)
+                    parsed.put(rb)
                     if rb is None:
                         break
-                    work.put(_prepare(rb, SIZE_CORRECTED_READ_THRESHOLD, threads, splitter))
+                # the last batches may still be in use: the file stays open until the splitter is through
+                splitter_done.wait()
             finally:
                 rf.close()
         except BaseException as e:           # noqa: BLE001 -- handed to the main thread
             failure.append(e)
+            parsed.put(None)
+
+    splitter_done = threading.Event()
+
+    def reader():
+        try:
+            while True:
+                rb = parsed.get()
+                if rb is None or failure:
+                    break
+                work.put(_prepare(rb, SIZE_CORRECTED_READ_THRESHOLD, threads, splitter))
+                permits.release()
+        except BaseException as e:           # noqa: BLE001 -- handed to the main thread
+            failure.append(e)
+        splitter_done.set()
+        permits.release()
         work.put(None)
 
+    tp = threading.Thread(target=parser, daemon=True)
+    tp.start()
     th = threading.Thread(target=reader, daemon=True)
     th.start()
 
@@ -392,6 +419,7 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
         while pending:
             finish(out)
     th.join()
+    tp.join()
     if failure:
         raise failure[0]
     if skipped:

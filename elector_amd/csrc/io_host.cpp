@@ -144,15 +144,22 @@ struct Reader {
   LineFile ref, unc, cor;
   int64_t k = 0;              // kept records read so far
   bool done = false;
-  // the batch under construction / handed out (owned here, valid until the next call); a record read ahead of
-  // the batch's end stays at the tail of the buffers and opens the next batch
-  BigBuf seq, hdr;
-  std::vector<int64_t> seq_off, hdr_off;
+  // The batch under construction / handed out lives in one of two buffer sets, used in turn: the batch handed out
+  // by a call stays valid until the call after the next one, so a caller can read batch i + 1 while another thread
+  // still works on batch i.  A record read ahead of a batch's end opens the next batch (copied across).
+  struct Set {
+    BigBuf seq, hdr;
+    std::vector<int64_t> seq_off, hdr_off;
+    void clear() { seq.clear(); hdr.clear(); seq_off.assign(1, 0); hdr_off.assign(1, 0); }
+  } set[2];
+  int cur = 0;
   bool has_pending = false;
   std::string last_key, key;
-  // appends the next kept record to the buffers; false at the end of any of the three files
+  // appends the next kept record to the current set; false at the end of any of the three files
   bool next()
   {
+    BigBuf &seq = set[cur].seq, &hdr = set[cur].hdr;
+    std::vector<int64_t> &seq_off = set[cur].seq_off, &hdr_off = set[cur].hdr_off;
     for (;;) {
       const size_t s0 = seq.size(), h0 = hdr.size();
       if (!ref.append_line(hdr)) return false;
@@ -190,7 +197,7 @@ extern "C" int elector_reads_open(const char *reference, const char *uncorrected
     delete rd;
     return ELECTOR_E_INVAL;
   }
-  rd->seq_off.push_back(0); rd->hdr_off.push_back(0);
+  rd->set[0].clear(); rd->set[1].clear();
   *handle = rd;
   return ELECTOR_OK;
 }
@@ -208,24 +215,23 @@ extern "C" int elector_reads_next(void *handle, int64_t min_records, int64_t sta
   Reader *rd = static_cast<Reader *>(handle);
   if (!rd || !out || min_records < 1) return ELECTOR_E_INVAL;
   std::memset(out, 0, sizeof *out);
-  // drop the batch handed out last time; the record read ahead (if any) moves to the front
+  // the other buffer set takes the new batch; the record read ahead (if any) is copied to its front
   {
-    const size_t nrec = rd->hdr_off.size() - 1;
+    Reader::Set &old = rd->set[rd->cur];
+    rd->cur ^= 1;
+    Reader::Set &now = rd->set[rd->cur];
+    now.clear();
+    const size_t nrec = old.hdr_off.size() - 1;
     if (rd->has_pending && nrec >= 1) {
-      const int64_t s0 = rd->seq_off[3 * (nrec - 1)], h0 = rd->hdr_off[nrec - 1];
-      const int64_t so[3] = {rd->seq_off[3 * nrec - 2] - s0, rd->seq_off[3 * nrec - 1] - s0, rd->seq_off[3 * nrec] - s0};
-      const int64_t hl = rd->hdr_off[nrec] - h0;
-      std::memmove(rd->seq.data(), rd->seq.data() + s0, (size_t)so[2]);
-      std::memmove(rd->hdr.data(), rd->hdr.data() + h0, (size_t)hl);
-      rd->seq.resize((size_t)so[2]); rd->hdr.resize((size_t)hl);
-      rd->seq_off.assign({0, so[0], so[1], so[2]});
-      rd->hdr_off.assign({0, hl});
-    } else {
-      rd->seq.clear(); rd->hdr.clear();
-      rd->seq_off.assign(1, 0); rd->hdr_off.assign(1, 0);
-      rd->has_pending = false;
-    }
+      const int64_t s0 = old.seq_off[3 * (nrec - 1)], h0 = old.hdr_off[nrec - 1];
+      const int64_t so[3] = {old.seq_off[3 * nrec - 2] - s0, old.seq_off[3 * nrec - 1] - s0, old.seq_off[3 * nrec] - s0};
+      const int64_t hl = old.hdr_off[nrec] - h0;
+      if (!now.seq.append(old.seq.data() + s0, (size_t)so[2]) || !now.hdr.append(old.hdr.data() + h0, (size_t)hl)) return ELECTOR_E_NOMEM;
+      now.seq_off.assign({0, so[0], so[1], so[2]});
+      now.hdr_off.assign({0, hl});
+    } else rd->has_pending = false;
   }
+  Reader::Set &S = rd->set[rd->cur];
   if (rd->done && !rd->has_pending) return ELECTOR_OK;
   int64_t n = 0, first = -1;
   bool ended = rd->done;
@@ -237,14 +243,14 @@ extern "C" int elector_reads_next(void *handle, int64_t min_records, int64_t sta
       index = rd->k++;
     }
     auto drop_last = [&]() {
-      const size_t nrec = rd->hdr_off.size() - 1;
-      rd->seq.resize((size_t)rd->seq_off[3 * (nrec - 1)]); rd->hdr.resize((size_t)rd->hdr_off[nrec - 1]);
-      rd->seq_off.resize(3 * (nrec - 1) + 1); rd->hdr_off.resize(nrec);
+      const size_t nrec = S.hdr_off.size() - 1;
+      S.seq.resize((size_t)S.seq_off[3 * (nrec - 1)]); S.hdr.resize((size_t)S.hdr_off[nrec - 1]);
+      S.seq_off.resize(3 * (nrec - 1) + 1); S.hdr_off.resize(nrec);
     };
     if (stop >= 0 && index >= stop) { drop_last(); ended = true; break; }
     if (index < start) { drop_last(); continue; }
-    const size_t nrec = rd->hdr_off.size() - 1;
-    record_key(rd->hdr.data() + rd->hdr_off[nrec - 1], (size_t)(rd->hdr_off[nrec] - rd->hdr_off[nrec - 1]), rd->key);
+    const size_t nrec = S.hdr_off.size() - 1;
+    record_key(S.hdr.data() + S.hdr_off[nrec - 1], (size_t)(S.hdr_off[nrec] - S.hdr_off[nrec - 1]), rd->key);
     if (n >= min_records && rd->key != rd->last_key) {       // the batch ends before this record
       rd->has_pending = true;
       break;
@@ -257,10 +263,10 @@ extern "C" int elector_reads_next(void *handle, int64_t min_records, int64_t sta
   if (rd->ref.oom || rd->unc.oom || rd->cor.oom) return ELECTOR_E_NOMEM;
   out->n = n;
   out->first_index = first < 0 ? 0 : first;
-  out->seq = reinterpret_cast<uint8_t *>(rd->seq.data());
-  out->seq_off = rd->seq_off.data();
-  out->hdr = reinterpret_cast<uint8_t *>(rd->hdr.data());
-  out->hdr_off = rd->hdr_off.data();
+  out->seq = reinterpret_cast<uint8_t *>(S.seq.data());
+  out->seq_off = S.seq_off.data();
+  out->hdr = reinterpret_cast<uint8_t *>(S.hdr.data());
+  out->hdr_off = S.hdr_off.data();
   return ELECTOR_OK;
 }
 
