@@ -10,11 +10,12 @@ bytes.  Where the reference spawns `masterSplitter`, 200 `poa` processes and 200
 (alignment.py:98-129), a batch here never leaves memory, and the bulk of it never
 leaves the GPU:
 
-    reader thread   three FASTA files -> batches of reads (elector_reads_next) -> HBM -> windows (elector_split_reads_device: one
-                    workgroup per read on a splitter context of its own; ELECTOR_HOST_SPLIT=1 keeps the host
-                    threads of elector_split_reads instead)
+    parser thread   three FASTA files -> batches of reads (elector_reads_next, native; two buffer sets in turn)
+    splitter thread batches -> HBM -> windows (elector_split_reads_device: one workgroup per read on a splitter
+                    context of its own; ELECTOR_HOST_SPLIT=1 keeps the host threads of elector_split_reads instead)
     main thread     windows (already in HBM) -> triplet MSAs (elector_poa_batch_device) -> one record per piece
-                    (k_merge) -> per-piece integer counters (k_stats) -> merged rows back for msa.fa
+                    (k_merge) -> per-piece integer counters (k_stats) -> merged rows back and into msa.fa
+                    (elector_msa_records_write)
 
 Two engine contexts take the batches in turn, so the host work of one batch
 (parsing, splitting, writing msa.fa) overlaps the kernels of the other.  The
