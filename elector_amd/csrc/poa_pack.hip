@@ -961,7 +961,9 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       S1[k] = S2[k] = pk1(v);
       E1[k] = E2[k] = pk1(v - kp.ext_x);
     }
-    uint32_t last3 = S1[R - 1];
+    // the row above at column jj - 2 is what the shift delivered as "column jj - 1" one step earlier: one DPP
+    // shift per step instead of two (before the first step: column 0 on both sides)
+    uint32_t prev_up1 = pk_shift_in<G>(0u, S1[R - 1], g);
     const uint32_t colS0 = pk1(-(kp.open_y + (R * g) * kp.ext_y));               // column 0 at this lane's first row
     const uint32_t colAbove = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // ... at the row above it (the origin for lane 0)
     const uint32_t KOPENNEG = pk1(-kp.open_x);
@@ -1010,10 +1012,10 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       }
       const uint32_t BEj = pk_subk(BRj, KEXT);
       const uint32_t up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);        // row above at column jj - 1
-      const uint32_t up2 = pk_shift_in<G>(BR2, last3, g);            // ... at column jj - 2
+      const uint32_t up2 = prev_up1;                                 // ... at column jj - 2
+      prev_up1 = up1;
       const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
       if (!FIRST || jj >= 1) {                                       // before its first column a lane keeps column 0
-        const uint32_t sv3 = Sb[R - 1];
         uint32_t dt1 = bfi(M1, up2, up1), dt2 = dt1, insY = upE, mvw = 0, secw = 0;
         if (two) dt2 = bfi(M2, up2, up1);
         if (virt) { dt1 = bfi(V1, colAbove, dt1); dt2 = bfi(V2, colAbove, dt2); }
@@ -1060,7 +1062,6 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
         if (virt) cells(std::true_type{}, std::true_type{});
         else if (two) cells(std::true_type{}, std::false_type{});
         else cells(std::false_type{}, std::false_type{});
-        last3 = sv3;
         BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
         mv[t * 64 + lane] = mvw;                                     // every lane: a lane past its window's end writes a word nobody reads
         if (two) {
