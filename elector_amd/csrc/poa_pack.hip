@@ -107,6 +107,14 @@ __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b)
 // pair's bits in a register of its own)
 __device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
 
+// clamp(x, lo, hi) in one instruction (lo <= hi)
+__device__ __forceinline__ int med3(int x, int lo, int hi)
+{
+  int d;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(lo), "v"(hi));
+  return d;
+}
+
 __device__ __forceinline__ int dpp_row_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xF, 0xF, false); }
 __device__ __forceinline__ int dpp_wave_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xF, 0xF, false); }
 
@@ -984,8 +992,8 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       constexpr bool FIRST = decltype(first_tag)::value;
       const int jj = t - g;
       const uint32_t xiA = xiA_next, xiB = xiB_next;
-      xiA_next = xinfo[0][min(max(jj + 1, 0), n1c0)];
-      xiB_next = xinfo[1][min(max(jj + 1, 0), n1c1)];
+      xiA_next = xinfo[0][med3(jj + 1, 0, n1c0)];
+      xiB_next = xinfo[1][med3(jj + 1, 0, n1c1)];
       // per-half select masks: predecessor two columns back (else one)
       const uint32_t M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
       // the two letters (byte 1 of each record) to the low bytes of the two halves: one v_perm_b32
@@ -1068,8 +1076,8 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
           if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
           if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
         }
-        const bool finA = (xiA & finA_bit) != 0u, finB = (xiB & finB_bit) != 0u;
-        if (finA || finB) {
+        if (((xiA & finA_bit) | (xiB & finB_bit)) != 0u) {
+          const bool finA = (xiA & finA_bit) != 0u, finB = (xiB & finB_bit) != 0u;
 #pragma unroll
           for (int k = 0; k < R; ++k) {
             if (finA && k == kstar0) { const int v = pk_half(Sb[k], 0); if (v > best[0]) { best[0] = v; bestx[0] = jj - 1; } }
