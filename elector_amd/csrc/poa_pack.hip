@@ -831,6 +831,7 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
     int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? xsA[0] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? xsB[0] : 0;
     const int gstar0 = (W[0].Lc - 1) / R, kstar0 = (W[0].Lc - 1) % R, gstar1 = (W[1].Lc - 1) / R, kstar1 = (W[1].Lc - 1) % R;
     uint32_t bS = pk1(-kp.open_x);                             // row -1 at column t: -(open_x + (t - 1) ext_x)
+    const int capA = (needA[0] && g == gstar0) ? W[0].Lr : -1, capB = (needA[1] && g == gstar1) ? W[1].Lr : -1;   // column to watch, or none
     for (int t = 1; t <= tmax; ++t) {
       const uint32_t upS = pk_shift_in<G>(bS, S[R - 1], g);
       const uint32_t upE = pk_shift_in<G>(pk_subk(bS, KEXT), E[R - 1], g);
@@ -857,13 +858,14 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
           diag = oldS; insY = E[k];
         }
         dg0 = upS;
-        const bool actA = needA[0] && jj <= W[0].Lr, actB = needA[1] && jj <= W[1].Lr;
         mv[t * 64 + lane] = mvw;
-        if ((actA && jj == W[0].Lr && g == gstar0) || (actB && jj == W[1].Lr && g == gstar1)) {
+        // the alignment's score: last column, last row -- the lane that holds that row watches for its column
+        const bool endA = jj == capA, endB = jj == capB;
+        if (endA || endB) {
 #pragma unroll
           for (int k = 0; k < R; ++k) {
-            if (actA && jj == W[0].Lr && g == gstar0 && k == kstar0) W[0].score1 = pk_half(S[k], 0);
-            if (actB && jj == W[1].Lr && g == gstar1 && k == kstar1) W[1].score1 = pk_half(S[k], 1);
+            if (endA && k == kstar0) W[0].score1 = pk_half(S[k], 0);
+            if (endB && k == kstar1) W[1].score1 = pk_half(S[k], 1);
           }
         }
       }
