@@ -831,15 +831,17 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
     int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? xsA[0] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? xsB[0] : 0;
     const int gstar0 = (W[0].Lc - 1) / R, kstar0 = (W[0].Lc - 1) % R, gstar1 = (W[1].Lc - 1) / R, kstar1 = (W[1].Lc - 1) % R;
     uint32_t bS = pk1(-kp.open_x);                             // row -1 at column t: -(open_x + (t - 1) ext_x)
+    const int lastA = max(W[0].Lr - 1, 0), lastB = max(W[1].Lr - 1, 0);
     const int capA = (needA[0] && g == gstar0) ? W[0].Lr : -1, capB = (needA[1] && g == gstar1) ? W[1].Lr : -1;   // column to watch, or none
     for (int t = 1; t <= tmax; ++t) {
       const uint32_t upS = pk_shift_in<G>(bS, S[R - 1], g);
       const uint32_t upE = pk_shift_in<G>(pk_subk(bS, KEXT), E[R - 1], g);
       bS = pk_subk(bS, KEXT);
       const int jj = t - g;
-      const uint32_t xlp = pk2(xa_next, xb_next);
-      xa_next = (needA[0] && jj >= 0 && jj < W[0].Lr) ? xsA[jj] : 0;
-      xb_next = (needA[1] && jj >= 0 && jj < W[1].Lr) ? xsB[jj] : 0;
+      const uint32_t xlp = (uint32_t)xa_next | ((uint32_t)xb_next << 16);
+      // (clamped, no test: past the window's last column a lane computes cells nobody reads)
+      xa_next = xsA[med3(jj, 0, lastA)];
+      xb_next = xsB[med3(jj, 0, lastB)];
       if (jj >= 1 && jj <= lrmax) {
         uint32_t diag = dg0, insY = upE, mvw = 0;
 #pragma unroll
