@@ -827,13 +827,14 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
     int tmax = max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0) + G - 1;
     for (int d = G; d < 64; d <<= 1) tmax = max(tmax, __shfl_xor(tmax, d));
     tmax = __builtin_amdgcn_readfirstlane(tmax);
-    const int lrmax = max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0);
     int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? xsA[0] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? xsB[0] : 0;
     const int gstar0 = (W[0].Lc - 1) / R, kstar0 = (W[0].Lc - 1) % R, gstar1 = (W[1].Lc - 1) / R, kstar1 = (W[1].Lc - 1) % R;
     uint32_t bS = pk1(-kp.open_x);                             // row -1 at column t: -(open_x + (t - 1) ext_x)
     const int lastA = max(W[0].Lr - 1, 0), lastB = max(W[1].Lr - 1, 0);
     const int capA = (needA[0] && g == gstar0) ? W[0].Lr : -1, capB = (needA[1] && g == gstar1) ? W[1].Lr : -1;   // column to watch, or none
-    for (int t = 1; t <= tmax; ++t) {
+    // FIRST: the steps in which some lane has not reached its first column yet (t < G)
+    auto stepA = [&](auto first_tag, int t) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       const uint32_t upS = pk_shift_in<G>(bS, S[R - 1], g);
       const uint32_t upE = pk_shift_in<G>(pk_subk(bS, KEXT), E[R - 1], g);
       bS = pk_subk(bS, KEXT);
@@ -842,7 +843,7 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       // (clamped, no test: past the window's last column a lane computes cells nobody reads)
       xa_next = xsA[med3(jj, 0, lastA)];
       xb_next = xsB[med3(jj, 0, lastB)];
-      if (jj >= 1 && jj <= lrmax) {
+      if (!FIRST || jj >= 1) {                                     // (past its window's last column a lane computes on: nobody reads it)
         uint32_t diag = dg0, insY = upE, mvw = 0;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -871,6 +872,11 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
           }
         }
       }
+    };
+    {
+      int t = 1;
+      for (; t <= tmax && t < G; ++t) stepA(std::true_type{}, t);
+      for (; t <= tmax; ++t) stepA(std::false_type{}, t);
     }
   }
   // the score sits with the lane that holds the corrected read's last row
