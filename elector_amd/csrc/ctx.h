@@ -54,7 +54,7 @@ struct StatsSlot {
   DevBuf rows, rowoff, cols, first, clips, cnt, mask, woff;
   HostPinned h;                 // [overflow flag, pad to 16][counters][cols][inputs]
   hipEvent_t done = nullptr;
-  int64_t n_pieces = 0, n_reads = 0, total = 0, last_piece = 0;
+  int64_t n_pieces = 0, n_reads = 0, total = 0, last_piece = 0, max_windows = 0;
   bool has_clips = false;
   void release()
   {

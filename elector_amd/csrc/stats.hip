@@ -12,12 +12,14 @@
 // k_stats: one 256-thread block per READ walks the read's pieces and produces the
 // integer counters of include/elector_stats.h.  It replaces the per-column Python
 // loops of the reference (elector/computeStats.py:61-189, 291-328, 371-440,
-// 472-498, 712-752).  The per-column work (counters, masks, the search for long
-// gap runs) is spread over the block; the few inherently sequential pieces (the
-// end-gap scans, which stop after a handful of columns, and the interval list
-// logic of findGapStretches, which sees one entry per run of >= 5 corrected gaps)
-// run on single lanes.  Byte-per-column work, HBM/latency bound.  Floats never
-// appear here.
+// 472-498, 712-752).  One pass over the letters turns the piece into six bit rows
+// in LDS (gap in reference / corrected / uncorrected, letters pairwise equal: one
+// ballot per 64 columns); the end-gap scans, the search for runs of corrected gaps,
+// the interval list logic of findGapStretches (one entry per run of >= 5 corrected
+// gaps, on single lanes), the mask and the masked counters (population counts of
+// word combinations) work on those words.  Pieces beyond the LDS budget keep
+// reading the letters from HBM (the first form of this kernel).  Latency bound.
+// Floats never appear here.
 //
 // elector_homopolymer_pairs: host-side integer state machine for the one read
 // whose homopolymer ratio the reference reports (computeStats.py:671-674).
@@ -25,6 +27,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <unistd.h>
@@ -54,37 +57,63 @@ struct MergeArgs {
   int32_t *woff;                // scratch, one per window
 };
 
+constexpr int kMergeWin = 1024;          // windows of a piece whose descriptors and offsets stay in LDS
+
 __global__ void __launch_bounds__(kStatsThreads) k_merge(MergeArgs a)
 {
   __shared__ int s_wave[kStatsThreads / 64];
   __shared__ int64_t s_carry;
+  __shared__ int s_nc[kMergeWin], s_wo[kMergeWin];
+  __shared__ int64_t s_src[kMergeWin];
   const int64_t p = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t w0 = a.piece_first[p], w1 = a.piece_first[p + 1];
-  // surviving columns per window (Donatello.cpp:13-31).  The kernel is bound by the latency of its
-  // dependent loads (window descriptor -> columns), so every wave works on FOUR windows at a time, 16
-  // lanes each, and fetches 64 columns of a window (nearly always all of it) before it looks at them.
-  constexpr int kGroups = 4 * (kStatsThreads / 64);            // windows in flight per block
-  const int grp = tid >> 4, gl = tid & 15, gshift = (lane >> 4) * 16;
-  for (int64_t w = w0 + grp; w < w1; w += kGroups) {
-    const int nc = a.status[w] == 0 ? a.ncol[w] : 0;
-    const uint8_t *src = a.cols_in + 3 * a.off[3 * w];
-    int cnt = 0;
-    for (int c0 = 0; c0 < nc; c0 += 64) {
-      uint8_t y[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int c = c0 + 16 * u + gl; y[u] = c < nc ? src[3 * c + 1] : (uint8_t)'n'; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) cnt += __popcll((__ballot(y[u] != 'n') >> gshift) & 0xFFFFull);
-    }
-    if (gl == 0) a.woff[w] = cnt;
+  const int64_t w0 = a.piece_first[p], W = a.piece_first[p + 1] - w0;
+  // The kernel is bound by the latency of its dependent loads (window descriptor -> columns).  The descriptors
+  // of all windows are fetched first, one window per thread; then every wave works on FOUR windows at a time,
+  // 16 lanes each, with the first 64 columns (nearly always all of them) of TWO windows per lane group in
+  // flight before it looks at any.
+  for (int64_t i = tid; i < W && i < kMergeWin; i += kStatsThreads) {
+    const int64_t w = w0 + i;
+    s_nc[i] = a.status[w] == 0 ? a.ncol[w] : 0;
+    s_src[i] = 3 * a.off[3 * w];
   }
   if (tid == 0) s_carry = 0;
   __syncthreads();
+  auto win_nc = [&](int64_t i) { return i < kMergeWin ? s_nc[i] : (a.status[w0 + i] == 0 ? a.ncol[w0 + i] : 0); };
+  auto win_src = [&](int64_t i) { return a.cols_in + (i < kMergeWin ? s_src[i] : 3 * a.off[3 * (w0 + i)]); };
+  auto get_wo = [&](int64_t i) { return i < kMergeWin ? s_wo[i] : a.woff[w0 + i]; };
+  auto set_wo = [&](int64_t i, int v) { if (i < kMergeWin) s_wo[i] = v; else a.woff[w0 + i] = v; };
+  constexpr int kGroups = 4 * (kStatsThreads / 64);            // windows in flight per block and turn
+  const int grp = tid >> 4, gl = tid & 15, gshift = (lane >> 4) * 16;
+  // surviving columns per window (Donatello.cpp:13-31)
+  auto load_y = [&](const uint8_t *src, int nc, int c0, uint8_t (&y)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int c = c0 + 16 * u + gl; y[u] = c < nc ? src[3 * c + 1] : (uint8_t)'n'; }
+  };
+  auto count_y = [&](const uint8_t (&y)[4]) {
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cnt += __popcll((__ballot(y[u] != 'n') >> gshift) & 0xFFFFull);
+    return cnt;
+  };
+  for (int64_t i = grp; i < W; i += 2 * kGroups) {
+    const int64_t i2 = i + kGroups;
+    const bool two = i2 < W;
+    const int nc1 = win_nc(i), nc2 = two ? win_nc(i2) : 0;
+    const uint8_t *src1 = win_src(i), *src2 = two ? win_src(i2) : src1;
+    uint8_t y1[4], y2[4];
+    load_y(src1, nc1, 0, y1);
+    load_y(src2, nc2, 0, y2);
+    int cnt1 = count_y(y1), cnt2 = count_y(y2);
+    for (int c0 = 64; c0 < nc1; c0 += 64) { load_y(src1, nc1, c0, y1); cnt1 += count_y(y1); }
+    for (int c0 = 64; c0 < nc2; c0 += 64) { load_y(src2, nc2, c0, y2); cnt2 += count_y(y2); }
+    if (gl == 0) { set_wo(i, cnt1); if (two) set_wo(i2, cnt2); }
+  }
+  __syncthreads();
   // exclusive scan of the counts over the piece's windows
-  for (int64_t base = w0; base < w1; base += kStatsThreads) {
-    const int64_t w = base + tid;
-    const int v = w < w1 ? a.woff[w] : 0;
+  for (int64_t base = 0; base < W; base += kStatsThreads) {
+    const int64_t i = base + tid;
+    const int v = i < W ? get_wo(i) : 0;
     int inc = v;
     for (int d = 1; d < 64; d <<= 1) {
       const int t = __shfl_up(inc, d);
@@ -98,7 +127,7 @@ __global__ void __launch_bounds__(kStatsThreads) k_merge(MergeArgs a)
       total += s_wave[k];
     }
     const int64_t carry = s_carry;
-    if (w < w1) a.woff[w] = (int32_t)(carry + before + inc - v);
+    if (i < W) set_wo(i, (int32_t)(carry + before + inc - v));
     __syncthreads();
     if (tid == 0) s_carry = carry + total;
     __syncthreads();
@@ -107,29 +136,40 @@ __global__ void __launch_bounds__(kStatsThreads) k_merge(MergeArgs a)
   const int64_t rb = 3 * a.off[3 * w0];
   if (tid == 0) { a.row_off[p] = rb; a.cols[p] = n; }
   uint8_t *d0 = a.rows + rb, *d1 = d0 + n, *d2 = d1 + n;
-  for (int64_t w = w0 + grp; w < w1; w += kGroups) {
-    const int nc = a.status[w] == 0 ? a.ncol[w] : 0;
-    const uint8_t *src = a.cols_in + 3 * a.off[3 * w];
-    int64_t k = a.woff[w];
-    for (int c0 = 0; c0 < nc; c0 += 64) {
-      uint8_t x[4], y[4], z[4];
+  auto load_xyz = [&](const uint8_t *src, int nc, int c0, uint8_t (&x)[4], uint8_t (&y)[4], uint8_t (&z)[4]) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = c0 + 16 * u + gl;
-        x[u] = 0; y[u] = 'n'; z[u] = 0;
-        if (c < nc) { x[u] = src[3 * c]; y[u] = src[3 * c + 1]; z[u] = src[3 * c + 2]; }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool keep = y[u] != 'n';
-        const unsigned long long m = (__ballot(keep) >> gshift) & 0xFFFFull;
-        if (keep) {
-          const int64_t at = k + __popcll(m & ((1ull << gl) - 1ull));
-          d0[at] = x[u]; d1[at] = y[u]; d2[at] = z[u];
-        }
-        k += __popcll(m);
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + 16 * u + gl;
+      x[u] = 0; y[u] = 'n'; z[u] = 0;
+      if (c < nc) { x[u] = src[3 * c]; y[u] = src[3 * c + 1]; z[u] = src[3 * c + 2]; }
     }
+  };
+  auto store_xyz = [&](int64_t k, const uint8_t (&x)[4], const uint8_t (&y)[4], const uint8_t (&z)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool keep = y[u] != 'n';
+      const unsigned long long m = (__ballot(keep) >> gshift) & 0xFFFFull;
+      if (keep) {
+        const int64_t at = k + __popcll(m & ((1ull << gl) - 1ull));
+        d0[at] = x[u]; d1[at] = y[u]; d2[at] = z[u];
+      }
+      k += __popcll(m);
+    }
+    return k;
+  };
+  for (int64_t i = grp; i < W; i += 2 * kGroups) {
+    const int64_t i2 = i + kGroups;
+    const bool two = i2 < W;
+    const int nc1 = win_nc(i), nc2 = two ? win_nc(i2) : 0;
+    const uint8_t *src1 = win_src(i), *src2 = two ? win_src(i2) : src1;
+    int64_t k1 = get_wo(i), k2 = two ? get_wo(i2) : 0;
+    uint8_t x1[4], y1[4], z1[4], x2[4], y2[4], z2[4];
+    load_xyz(src1, nc1, 0, x1, y1, z1);
+    load_xyz(src2, nc2, 0, x2, y2, z2);
+    k1 = store_xyz(k1, x1, y1, z1);
+    k2 = store_xyz(k2, x2, y2, z2);
+    for (int c0 = 64; c0 < nc1; c0 += 64) { load_xyz(src1, nc1, c0, x1, y1, z1); k1 = store_xyz(k1, x1, y1, z1); }
+    for (int c0 = 64; c0 < nc2; c0 += 64) { load_xyz(src2, nc2, c0, x2, y2, z2); k2 = store_xyz(k2, x2, y2, z2); }
   }
 }
 
@@ -164,6 +204,7 @@ struct StatsArgs {
   unsigned long long pool_cap; // in int32 units
   unsigned long long *pool_used;
   int32_t *overflow;           // set when the pool ran out: the host grows it and runs again
+  int bit_words;               // 64-column words per bit row in LDS; longer pieces read their letters from HBM throughout
 };
 
 // computeStats.py:61-77
@@ -342,19 +383,153 @@ __device__ inline int block_sum(int v, int *red)
 
 enum { kAccN = 18 };
 
+// ---- shared state of k_stats (file scope, so that the per-piece helpers address it as LDS) ----
+constexpr int kLdsRuns = 64;             // gap runs of a piece whose interval lists stay in LDS
+constexpr int kBitArrays = 6;
+enum { kGx = 0, kGc = 1, kGu = 2, kExc = 3, kExu = 4, kEuc = 5, kMk = kGu /* the mask takes the place of Gu */ };
+__shared__ int s_red[kStatsThreads / 64];
+__shared__ int s_end[4];                 // end-gap scans: left ref, left unc, right ref, right unc
+__shared__ int s_acc[kAccN];
+__shared__ int s_long[3];               // block_gap_run: end of the run, first and last hit
+__shared__ int s_n[8];                   // 0: run starts filled  1: stretches kept  2: clip left  3: clip right  4: earliest qualifying run end  5: union size  6: run starts filled (pool)
+__shared__ int32_t *s_lists;
+__shared__ uint8_t *s_uni;
+__shared__ int32_t s_lst[14 * (kLdsRuns + 2)];
+__shared__ int32_t s_start[kLdsRuns];
+// Bit rows of the piece at hand (dynamic LDS; StatsArgs::bit_words words per row and a zero guard word either
+// side): bit i of row kGx/kGc/kGu = "reference / corrected / uncorrected has a gap in column i", of
+// kExc/kExu/kEuc = "the two letters are equal".  Everything after the one pass that reads the letters --
+// end scans, gap runs, interval lists, mask, the masked counters -- works on these words.
+extern __shared__ unsigned long long s_bits[];
+
+__device__ __forceinline__ unsigned long long bwr(int arr, int W2, int j) { return s_bits[arr * W2 + 1 + j]; }
+__device__ __forceinline__ void bww(int arr, int W2, int j, unsigned long long v) { s_bits[arr * W2 + 1 + j] = v; }
+__device__ __forceinline__ bool bbit(int arr, int W2, int i) { return (bwr(arr, W2, i >> 6) >> (i & 63)) & 1ull; }
+
+// the bits of word j that stand for columns lo..hi
+__device__ __forceinline__ unsigned long long range_word(int j, int lo, int hi)
+{
+  int x = lo - 64 * j, y = hi - 64 * j;
+  if (y < 0 || x > 63 || hi < lo) return 0;
+  x = max(x, 0); y = min(y, 63);
+  return (~0ull << x) & (~0ull >> (63 - y));
+}
+
+// set bits of a row in columns lo..hi; every thread gets the result
+__device__ int count_range(int arr, int W2, int lo, int hi)
+{
+  int v = 0;
+  if (hi >= lo)
+    for (int j = (lo >> 6) + (int)threadIdx.x; j <= (hi >> 6); j += kStatsThreads) v += __popcll(bwr(arr, W2, j) & range_word(j, lo, hi));
+  return block_sum(v, s_red);
+}
+
+// left_gaps / right_gaps on a bit row
+__device__ int left_gaps_bits(int arr, int W2, int n)
+{
+  int gaps = 0, nts = 0, total = 0;
+  unsigned long long w = 0;
+  for (int i = 0; i < n && nts <= kThresh; ++i) {
+    if ((i & 63) == 0) w = bwr(arr, W2, i >> 6);
+    if ((w >> (i & 63)) & 1ull) { ++gaps; nts = 0; }
+    else { if (gaps >= kThresh) total = i; gaps = 0; ++nts; }
+  }
+  return total;
+}
+
+__device__ int right_gaps_bits(int arr, int W2, int n)
+{
+  int gaps = 0, nts = 0, total = 0;
+  unsigned long long w = bwr(arr, W2, (n - 1) >> 6);
+  for (int i = n - 1; i >= 0 && nts <= kThresh; --i) {
+    if ((i & 63) == 63) w = bwr(arr, W2, i >> 6);
+    if ((w >> (i & 63)) & 1ull) { ++gaps; nts = 0; }
+    else { if (gaps >= kThresh) total = n - i; gaps = 0; ++nts; }
+  }
+  return total;
+}
+
+// walk_gap_run on the bit rows
+__device__ void walk_gap_run_bits(int W2, int n, int s, int32_t *first_hit, int32_t *last_hit)
+{
+  int rb = s;
+  while (rb > 0 && bbit(kGx, W2, rb - 1)) --rb;
+  int cgr = 0;
+  auto step = [&](int x) {
+    const bool rgap = bbit(kGx, W2, x);
+    if (x == 0) { if (rgap) cgr = 1; }
+    else if (bbit(kGc, W2, x - 1) && rgap) cgr = cgr > 0 ? cgr + 1 : 2;
+    if (!rgap) cgr = 0;
+  };
+  for (int x = rb; x < s; ++x) step(x);
+  const int entry = cgr;
+  int fh = -1, lh = -1;
+  for (int x = s; x < n && bbit(kGc, W2, x); ++x) {
+    if (x - s >= kWalkCap) { *first_hit = kRunLong; *last_hit = entry; return; }
+    step(x);
+    if (x - s + 1 >= kThresh && cgr < kThresh2) { if (fh < 0) fh = x; lh = x; }
+  }
+  *first_hit = fh;
+  *last_hit = lh;
+}
+
+// block_gap_run on the bit rows
+__device__ void block_gap_run_bits(int W2, int n, int s, int entry, int *first_hit, int *last_hit)
+{
+  const int tid = threadIdx.x;
+  int end = -1;
+  for (int base = s; end < 0; base += kStatsThreads) {
+    __syncthreads();
+    if (tid == 0) s_long[0] = 0x7fffffff;
+    __syncthreads();
+    const int x = base + tid;
+    if (x >= n || !bbit(kGc, W2, x)) atomicMin(&s_long[0], x);
+    __syncthreads();
+    if (s_long[0] != 0x7fffffff) end = s_long[0] - 1;
+  }
+  __syncthreads();
+  if (tid == 0) { s_long[1] = 0x7fffffff; s_long[2] = -1; }
+  __syncthreads();
+  const int c0 = s == 0 ? 1 : entry;
+  int fh = 0x7fffffff, lh = -1;
+  for (int x = s + kThresh - 1 + tid; x <= end; x += kStatsThreads) {
+    int cgr;
+    if (!bbit(kGx, W2, x)) cgr = 0;
+    else {
+      int a = -1;
+      for (int j = 1; j <= kThresh2 && a < 0; ++j) {
+        if (x - j < s) a = s;
+        else if (!bbit(kGx, W2, x - j)) a = x - j + 1;
+      }
+      if (a < 0) cgr = kThresh2;
+      else if (a > s) cgr = 2 + (x - a);
+      else cgr = c0 > 0 ? c0 + (x - s) : x - s + 1;
+    }
+    if (cgr < kThresh2) { fh = min(fh, x); lh = max(lh, x); }
+  }
+  if (lh >= 0) { atomicMin(&s_long[1], fh); atomicMax(&s_long[2], lh); }
+  __syncthreads();
+  *first_hit = s_long[2] >= 0 ? s_long[1] : -1;
+  *last_hit = s_long[2];
+  __syncthreads();
+}
+
+// starts of the runs of >= THRESH corrected gaps in word j of kGc
+__device__ __forceinline__ unsigned long long long_run_starts(int W2, int j, unsigned long long *first_out)
+{
+  const unsigned long long g = bwr(kGc, W2, j), gp = bwr(kGc, W2, j - 1) >> 63, gn = bwr(kGc, W2, j + 1);
+  const unsigned long long first = g & ~((g << 1) | gp);
+  *first_out = first;
+  return first & ((g >> 1) | (gn << 63)) & ((g >> 2) | (gn << 62)) & ((g >> 3) | (gn << 61)) & ((g >> 4) | (gn << 60));
+}
+
 __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
 {
-  __shared__ int s_red[kStatsThreads / 64];
-  __shared__ int s_end[4];                 // end-gap scans: left ref, left unc, right ref, right unc
-  __shared__ int s_acc[kAccN];
-  __shared__ int s_long[3];               // block_gap_run: end of the run, first and last hit
-  __shared__ int s_n[8];                   // 0: long-run fill  1: stretches kept  2: clip left  3: clip right  4: earliest qualifying run end
-  __shared__ int32_t *s_lists;
-  __shared__ uint8_t *s_uni;
   const int64_t r = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t p0 = a.read_first[r], p1 = a.read_first[r + 1];
   const int nfrag = (int)(p1 - p0);
+  const int W2 = a.bit_words + 2;
 
   // realNotMissing of a split read (:589-591): one byte per column of its longest piece
   int ucap = 0;
@@ -388,149 +563,332 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
     }
     const uint8_t *ref = a.rows + a.row_off[p], *cor = ref + n, *unc = cor + n;
     uint8_t *mask = a.mask + a.row_off[p] / 3;
-
-    // ---- gapsAndExtensions (:472-498): the four end scans on four lanes ----
-    if (tid == 0) s_end[0] = left_gaps(ref, n);
-    if (tid == 64) s_end[1] = left_gaps(unc, n);
-    if (tid == 128) s_end[2] = right_gaps(ref, n);
-    if (tid == 192) s_end[3] = right_gaps(unc, n);
-    if (tid < kAccN) s_acc[tid] = 0;
-    if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = n - 1; s_n[4] = 0x7fffffff; s_lists = nullptr; }
-    __syncthreads();
-    const int gl = min(s_end[0], s_end[1]), gr = min(s_end[2], s_end[3]);
+    const int nw = (n + 63) >> 6;
+    const bool fast = nw <= a.bit_words;
+    int gl, gr;
     int64_t ext_left = -1, ext_right = -1;
-    if (gl >= kThresh && gl >= kThresh2) {
-      int dots = 0;
-      for (int i = tid; i < gl; i += kStatsThreads) dots += cor[i] == '.';
-      ext_left = gl - block_sum(dots, s_red);
-    }
-    if (gr >= kThresh && gr >= kThresh2) {
-      int dots = 0;
-      for (int i = n - gr + 1 + tid; i < n; i += kStatsThreads) dots += cor[i] == '.';
-      ext_right = gr - block_sum(dots, s_red);
-    }
-
-    // ---- findGapStretches (:104-189) ----
-    // pass 1: runs of >= THRESH corrected gaps, and the ends of runs that leave countGapsCor > 0
-    int nlong = 0, nq = 0, qmin = 0x7fffffff;
-    for (int i = tid; i < n; i += kStatsThreads) {
-      if (cor[i] != '.') continue;
-      const bool first = i == 0 || cor[i - 1] != '.';
-      if (first && i + kThresh - 1 < n) {
-        bool all = true;
-        for (int k = 1; k < kThresh; ++k) all = all && cor[i + k] == '.';
-        nlong += all;
-      }
-      if (i + 1 < n && cor[i + 1] != '.' && (i == 0 || !first)) { ++nq; qmin = min(qmin, i + 1); }
-    }
-    const int m = block_sum(nlong, s_red);
-    nq = block_sum(nq, s_red);
-    int nd = 0;
-    int32_t *dict = nullptr;
-    if (m > 0) {
-      atomicMin(&s_n[4], qmin);
-      if (tid == 0) s_lists = pool_take(a, 14ull * (unsigned long long)(m + 2));
-      __syncthreads();
-      int32_t *lists = s_lists;
-      if (!lists) return;                                             // uniform: the host runs again with a larger pool
-      int32_t *runs = lists, *tmp = runs + 2 * (m + 2), *mrg = tmp + 4 * (m + 2);
-      dict = mrg + 4 * (m + 2);
-      // pass 2: the run starts, in any order, then sorted by rank
-      for (int i = tid; i < n; i += kStatsThreads) {
-        if (cor[i] != '.' || !(i == 0 || cor[i - 1] != '.') || i + kThresh - 1 >= n) continue;
-        bool all = true;
-        for (int k = 1; k < kThresh; ++k) all = all && cor[i + k] == '.';
-        if (all) tmp[atomicAdd(&s_n[0], 1)] = i;
-      }
-      __syncthreads();
-      for (int e = tid; e < m; e += kStatsThreads) {
-        const int v = tmp[e];
-        int rank = 0;
-        for (int x = 0; x < m; ++x) rank += tmp[x] < v;
-        runs[rank] = v;
-      }
-      __syncthreads();
-      for (int e = tid; e < m; e += kStatsThreads) walk_gap_run(cor, ref, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1]);
-      __syncthreads();
-      for (int e = 0; e < m; ++e) {                                   // long runs: all threads together
-        if (mrg[2 * e] != kRunLong) continue;
-        int fh, lh;
-        block_gap_run(cor, ref, n, runs[e], mrg[2 * e + 1], s_long, &fh, &lh);
-        if (tid == 0) { mrg[2 * e] = fh; mrg[2 * e + 1] = lh; }
-        __syncthreads();
-      }
-      if (tid == 0) {
-        int n_ne = 0, first_hit = 0x7fffffff;
-        for (int e = 0; e < m; ++e) {
-          const int fh = mrg[2 * e], lh = mrg[2 * e + 1];
-          if (fh < 0) continue;
-          if (n_ne == 0) first_hit = fh;
-          runs[2 * n_ne] = fh - kThresh + 1;
-          runs[2 * n_ne + 1] = lh;
-          ++n_ne;
+    if (fast) {
+      // ---- the one pass over the letters: bit rows, G/C counts ----
+      if (tid < kBitArrays) { bww(tid, W2, -1, 0); bww(tid, W2, nw, 0); }
+      if (tid < kAccN) s_acc[tid] = 0;
+      if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = n - 1; s_n[4] = 0x7fffffff; s_n[6] = 0; s_lists = nullptr; }
+      int gcx = 0, gcc = 0;
+      constexpr int kU = 8;                                           // 24 byte loads in flight per thread
+      for (int c0 = 0; c0 < n; c0 += kU * kStatsThreads) {
+        uint8_t x[kU], c[kU], u[kU];
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+          const int i = min(c0 + k * kStatsThreads + tid, n - 1);
+          x[k] = ref[i]; c[k] = cor[i]; u[k] = unc[i];
         }
-        // the reference's list also holds one empty entry per ended run; the very first hit opens the
-        // list itself when no run has ended before it (:134-137)
-        const int n_total = nq + ((n_ne > 0 && s_n[4] > first_hit) ? 1 : 0);
-        s_n[1] = stretch_intervals(runs, n_ne, n_total, n, tmp, mrg, dict);
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+          const bool v = c0 + k * kStatsThreads + tid < n;
+          const unsigned long long bx = __ballot(v && x[k] == '.'), bc = __ballot(v && c[k] == '.'), bu = __ballot(v && u[k] == '.'),
+                                   exc = __ballot(v && x[k] == c[k]), exu = __ballot(v && x[k] == u[k]), euc = __ballot(v && u[k] == c[k]);
+          gcx += __popcll(__ballot(v && is_gc(x[k])));
+          gcc += __popcll(__ballot(v && is_gc(c[k])));
+          const int j = ((c0 + k * kStatsThreads) >> 6) + wave;
+          if (lane == 0 && j < nw) {
+            bww(kGx, W2, j, bx); bww(kGc, W2, j, bc); bww(kGu, W2, j, bu);
+            bww(kExc, W2, j, exc); bww(kExu, W2, j, exu); bww(kEuc, W2, j, euc);
+          }
+        }
       }
       __syncthreads();
-      nd = s_n[1];
-    }
-    for (int k = 0; k < nd; ++k) {
-      const int s0 = dict[2 * k], s1 = dict[2 * k + 1];
-      int dots = 0;
-      for (int i = s0 + tid; i <= s1; i += kStatsThreads) dots += ref[i] == '.';
-      missing += s1 - s0 - block_sum(dots, s_red);
-    }
-    missing -= gl + gr;
-    if (missing < 0) missing = 0;
+      if (lane == 0) { atomicAdd(&s_acc[7], gcx); atomicAdd(&s_acc[8], gcc); }
 
-    // ---- getCorrectedPositions (:712-752): soft clips walk the corrected row from both ends ----
-    if (a.clips && tid == 0) {
-      const int lc = a.clips[2 * p], rc = a.clips[2 * p + 1];
-      int i = 0, j = 0;
-      while (j < lc && i < n) { if (cor[i] != '.') ++j; ++i; }
-      s_n[2] = i;                                                     // columns < i are clipped
-      if (lc != 0 || rc != 0) {
-        const int right_clip = n - rc;
-        i = n - 1; j = n - 1;
-        while (j >= right_clip && i >= 0) { if (cor[i] != '.') --j; --i; }
-        s_n[3] = i;                                                   // columns > i are clipped
+      // ---- gapsAndExtensions (:472-498) ----
+      if (tid == 0) s_end[0] = left_gaps_bits(kGx, W2, n);
+      if (tid == 64) s_end[1] = left_gaps_bits(kGu, W2, n);
+      if (tid == 128) s_end[2] = right_gaps_bits(kGx, W2, n);
+      if (tid == 192) s_end[3] = right_gaps_bits(kGu, W2, n);
+      __syncthreads();
+      gl = min(s_end[0], s_end[1]); gr = min(s_end[2], s_end[3]);
+      if (gl >= kThresh && gl >= kThresh2) ext_left = gl - count_range(kGc, W2, 0, gl - 1);
+      if (gr >= kThresh && gr >= kThresh2) ext_right = gr - count_range(kGc, W2, n - gr + 1, n - 1);
+
+      // ---- findGapStretches (:104-189) ----
+      int nlong = 0, nq = 0, qmin = 0x7fffffff;
+      for (int j = tid; j < nw; j += kStatsThreads) {
+        unsigned long long first;
+        unsigned long long ls = long_run_starts(W2, j, &first);
+        nlong += __popcll(ls);
+        const unsigned long long g = bwr(kGc, W2, j), e1 = (g >> 1) | (bwr(kGc, W2, j + 1) << 63);
+        const int rem = n - 1 - 64 * j;                                 // columns i of this word with i + 1 < n
+        const unsigned long long valid1 = rem >= 64 ? ~0ull : rem <= 0 ? 0ull : ((1ull << rem) - 1ull);
+        const unsigned long long q = g & ~e1 & valid1 & (~first | (j == 0 ? 1ull : 0ull));
+        nq += __popcll(q);
+        if (q) qmin = min(qmin, 64 * j + (int)__builtin_ctzll(q) + 1);
+        while (ls) {
+          const int b = (int)__builtin_ctzll(ls);
+          ls &= ls - 1;
+          const int at = atomicAdd(&s_n[0], 1);
+          if (at < kLdsRuns) s_start[at] = 64 * j + b;
+        }
       }
-    }
-    __syncthreads();
-    const int clip_l = s_n[2], clip_r = s_n[3];
+      const int m = block_sum(nlong, s_red);
+      nq = block_sum(nq, s_red);
+      int nd = 0;
+      int32_t *dict = nullptr;
+      if (m > 0) {
+        atomicMin(&s_n[4], qmin);
+        if (tid == 0) s_lists = m <= kLdsRuns ? s_lst : pool_take(a, 14ull * (unsigned long long)(m + 2));
+        __syncthreads();
+        int32_t *lists = s_lists;
+        if (!lists) return;                                             // uniform: the host runs again with a larger pool
+        int32_t *runs = lists, *tmp = runs + 2 * (m + 2), *mrg = tmp + 4 * (m + 2);
+        dict = mrg + 4 * (m + 2);
+        if (m <= kLdsRuns) {
+          for (int e = tid; e < m; e += kStatsThreads) tmp[e] = s_start[e];
+        } else {
+          for (int j = tid; j < nw; j += kStatsThreads) {
+            unsigned long long first;
+            unsigned long long ls = long_run_starts(W2, j, &first);
+            while (ls) {
+              const int b = (int)__builtin_ctzll(ls);
+              ls &= ls - 1;
+              tmp[atomicAdd(&s_n[6], 1)] = 64 * j + b;
+            }
+          }
+        }
+        __syncthreads();
+        for (int e = tid; e < m; e += kStatsThreads) {
+          const int v = tmp[e];
+          int rank = 0;
+          for (int x = 0; x < m; ++x) rank += tmp[x] < v;
+          runs[rank] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < m; e += kStatsThreads) walk_gap_run_bits(W2, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1]);
+        __syncthreads();
+        for (int e = 0; e < m; ++e) {                                   // long runs: all threads together
+          if (mrg[2 * e] != kRunLong) continue;
+          int fh, lh;
+          block_gap_run_bits(W2, n, runs[e], mrg[2 * e + 1], &fh, &lh);
+          if (tid == 0) { mrg[2 * e] = fh; mrg[2 * e + 1] = lh; }
+          __syncthreads();
+        }
+        if (tid == 0) {
+          int n_ne = 0, first_hit = 0x7fffffff;
+          for (int e = 0; e < m; ++e) {
+            const int fh = mrg[2 * e], lh = mrg[2 * e + 1];
+            if (fh < 0) continue;
+            if (n_ne == 0) first_hit = fh;
+            runs[2 * n_ne] = fh - kThresh + 1;
+            runs[2 * n_ne + 1] = lh;
+            ++n_ne;
+          }
+          const int n_total = nq + ((n_ne > 0 && s_n[4] > first_hit) ? 1 : 0);
+          s_n[1] = stretch_intervals(runs, n_ne, n_total, n, tmp, mrg, dict);
+        }
+        __syncthreads();
+        nd = s_n[1];
+      }
+      for (int k = 0; k < nd; ++k) {
+        const int s0 = dict[2 * k], s1 = dict[2 * k + 1];
+        missing += s1 - s0 - count_range(kGx, W2, s0, s1);
+      }
+      missing -= gl + gr;
+      if (missing < 0) missing = 0;
 
-    // ---- per-column counters (:399-440 with :291-328 and :371-393) ----
-    int acc[kAccN];
+      // ---- getCorrectedPositions (:712-752) ----
+      if (a.clips && tid == 0) {
+        const int lc = a.clips[2 * p], rc = a.clips[2 * p + 1];
+        int i = 0, j = 0;
+        while (j < lc && i < n) { if (!bbit(kGc, W2, i)) ++j; ++i; }
+        s_n[2] = i;
+        if (lc != 0 || rc != 0) {
+          const int right_clip = n - rc;
+          i = n - 1; j = n - 1;
+          while (j >= right_clip && i >= 0) { if (!bbit(kGc, W2, i)) --j; --i; }
+          s_n[3] = i;
+        }
+      }
+      __syncthreads();
+      const int clip_l = s_n[2], clip_r = s_n[3];
+
+      // ---- the mask and the masked counters (:399-440 with :291-328 and :371-393), 64 columns per step ----
+      const int lo = max(clip_l, gl >= kThresh ? gl : 0), hi = min(clip_r, gr >= kThresh ? n - gr : n - 1);
+      int acc[kAccN];
 #pragma unroll
-    for (int k = 0; k < kAccN; ++k) acc[k] = 0;
-    for (int i = tid; i < n; i += kStatsThreads) {
-      const uint8_t x = ref[i], c = cor[i], u = unc[i];
-      bool mk = i >= clip_l && i <= clip_r;
-      if (gl >= kThresh && i < gl) mk = false;
-      if (gr >= kThresh && i > n - gr) mk = false;
-      for (int k = 0; k < nd; ++k) if (i >= dict[2 * k] && i <= dict[2 * k + 1]) mk = false;
-      mask[i] = mk ? 1 : 0;
-      acc[7] += is_gc(x); acc[8] += is_gc(c);
-      acc[15] += x != '.'; acc[16] += c != '.'; acc[17] += u != '.';
-      if (!mk) continue;
-      if (c != x) { if (x == '.') ++acc[12]; else if (c != '.') ++acc[14]; else ++acc[13]; }
-      if (u != x) { if (x == '.') ++acc[9]; else if (u != '.') ++acc[11]; else ++acc[10]; }
-      if (x == u) { if (u != c) { ++acc[1]; ++acc[4]; } else { ++acc[0]; ++acc[3]; } ++acc[5]; }
-      else { if (x == c) { ++acc[0]; ++acc[3]; } else { if (u == c) { ++acc[2]; ++acc[1]; } ++acc[4]; } ++acc[6]; }
-    }
+      for (int k = 0; k < kAccN; ++k) acc[k] = 0;
+      for (int j = tid; j < nw; j += kStatsThreads) {
+        unsigned long long M = range_word(j, lo, hi);
+        for (int k = 0; k < nd; ++k) M &= ~range_word(j, dict[2 * k], dict[2 * k + 1]);
+        const unsigned long long gx = bwr(kGx, W2, j), gc = bwr(kGc, W2, j), gu = bwr(kGu, W2, j),
+                                 exc = bwr(kExc, W2, j), exu = bwr(kExu, W2, j), euc = bwr(kEuc, W2, j);
+        bww(kMk, W2, j, M);
+        acc[15] += __popcll(gx); acc[16] += __popcll(gc); acc[17] += __popcll(gu);
+        const unsigned long long dc = M & ~exc, du = M & ~exu, eq = M & exu;
+        acc[12] += __popcll(dc & gx); acc[14] += __popcll(dc & ~gx & ~gc); acc[13] += __popcll(dc & ~gx & gc);
+        acc[9] += __popcll(du & gx); acc[11] += __popcll(du & ~gx & ~gu); acc[10] += __popcll(du & ~gx & gu);
+        int t = __popcll(eq & ~euc); acc[1] += t; acc[4] += t;
+        t = __popcll(eq & euc); acc[0] += t; acc[3] += t;
+        acc[5] += __popcll(eq);
+        acc[6] += __popcll(du);
+        t = __popcll(du & exc); acc[0] += t; acc[3] += t;
+        acc[4] += __popcll(du & ~exc);
+        t = __popcll(du & ~exc & euc); acc[2] += t; acc[1] += t;
+      }
 #pragma unroll
-    for (int k = 0; k < kAccN; ++k) {
-      int v = acc[k];
-      for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
-      if (lane == 0 && v) atomicAdd(&s_acc[k], v);
+      for (int k = 0; k < kAccN; ++k) {
+        int v = acc[k];
+        for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0 && v) atomicAdd(&s_acc[k], v);
+      }
+      __syncthreads();
+      if (tid == 0) { s_acc[15] = n - s_acc[15]; s_acc[16] = n - s_acc[16]; s_acc[17] = n - s_acc[17]; }
+      for (int i = tid; i < n; i += kStatsThreads) {
+        const uint8_t mk = bbit(kMk, W2, i) ? 1 : 0;
+        mask[i] = mk;
+        if (nfrag > 1) uni[i] |= mk;                                          // realNotMissing (:589-591)
+      }
+    } else {
+
+      // ---- gapsAndExtensions (:472-498): the four end scans on four lanes ----
+      if (tid == 0) s_end[0] = left_gaps(ref, n);
+      if (tid == 64) s_end[1] = left_gaps(unc, n);
+      if (tid == 128) s_end[2] = right_gaps(ref, n);
+      if (tid == 192) s_end[3] = right_gaps(unc, n);
+      if (tid < kAccN) s_acc[tid] = 0;
+      if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = n - 1; s_n[4] = 0x7fffffff; s_lists = nullptr; }
+      __syncthreads();
+      gl = min(s_end[0], s_end[1]); gr = min(s_end[2], s_end[3]);
+      if (gl >= kThresh && gl >= kThresh2) {
+        int dots = 0;
+        for (int i = tid; i < gl; i += kStatsThreads) dots += cor[i] == '.';
+        ext_left = gl - block_sum(dots, s_red);
+      }
+      if (gr >= kThresh && gr >= kThresh2) {
+        int dots = 0;
+        for (int i = n - gr + 1 + tid; i < n; i += kStatsThreads) dots += cor[i] == '.';
+        ext_right = gr - block_sum(dots, s_red);
+      }
+
+      // ---- findGapStretches (:104-189) ----
+      // pass 1: runs of >= THRESH corrected gaps, and the ends of runs that leave countGapsCor > 0
+      int nlong = 0, nq = 0, qmin = 0x7fffffff;
+      for (int i = tid; i < n; i += kStatsThreads) {
+        if (cor[i] != '.') continue;
+        const bool first = i == 0 || cor[i - 1] != '.';
+        if (first && i + kThresh - 1 < n) {
+          bool all = true;
+          for (int k = 1; k < kThresh; ++k) all = all && cor[i + k] == '.';
+          nlong += all;
+        }
+        if (i + 1 < n && cor[i + 1] != '.' && (i == 0 || !first)) { ++nq; qmin = min(qmin, i + 1); }
+      }
+      const int m = block_sum(nlong, s_red);
+      nq = block_sum(nq, s_red);
+      int nd = 0;
+      int32_t *dict = nullptr;
+      if (m > 0) {
+        atomicMin(&s_n[4], qmin);
+        if (tid == 0) s_lists = pool_take(a, 14ull * (unsigned long long)(m + 2));
+        __syncthreads();
+        int32_t *lists = s_lists;
+        if (!lists) return;                                             // uniform: the host runs again with a larger pool
+        int32_t *runs = lists, *tmp = runs + 2 * (m + 2), *mrg = tmp + 4 * (m + 2);
+        dict = mrg + 4 * (m + 2);
+        // pass 2: the run starts, in any order, then sorted by rank
+        for (int i = tid; i < n; i += kStatsThreads) {
+          if (cor[i] != '.' || !(i == 0 || cor[i - 1] != '.') || i + kThresh - 1 >= n) continue;
+          bool all = true;
+          for (int k = 1; k < kThresh; ++k) all = all && cor[i + k] == '.';
+          if (all) tmp[atomicAdd(&s_n[0], 1)] = i;
+        }
+        __syncthreads();
+        for (int e = tid; e < m; e += kStatsThreads) {
+          const int v = tmp[e];
+          int rank = 0;
+          for (int x = 0; x < m; ++x) rank += tmp[x] < v;
+          runs[rank] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < m; e += kStatsThreads) walk_gap_run(cor, ref, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1]);
+        __syncthreads();
+        for (int e = 0; e < m; ++e) {                                   // long runs: all threads together
+          if (mrg[2 * e] != kRunLong) continue;
+          int fh, lh;
+          block_gap_run(cor, ref, n, runs[e], mrg[2 * e + 1], s_long, &fh, &lh);
+          if (tid == 0) { mrg[2 * e] = fh; mrg[2 * e + 1] = lh; }
+          __syncthreads();
+        }
+        if (tid == 0) {
+          int n_ne = 0, first_hit = 0x7fffffff;
+          for (int e = 0; e < m; ++e) {
+            const int fh = mrg[2 * e], lh = mrg[2 * e + 1];
+            if (fh < 0) continue;
+            if (n_ne == 0) first_hit = fh;
+            runs[2 * n_ne] = fh - kThresh + 1;
+            runs[2 * n_ne + 1] = lh;
+            ++n_ne;
+          }
+          // the reference's list also holds one empty entry per ended run; the very first hit opens the
+          // list itself when no run has ended before it (:134-137)
+          const int n_total = nq + ((n_ne > 0 && s_n[4] > first_hit) ? 1 : 0);
+          s_n[1] = stretch_intervals(runs, n_ne, n_total, n, tmp, mrg, dict);
+        }
+        __syncthreads();
+        nd = s_n[1];
+      }
+      for (int k = 0; k < nd; ++k) {
+        const int s0 = dict[2 * k], s1 = dict[2 * k + 1];
+        int dots = 0;
+        for (int i = s0 + tid; i <= s1; i += kStatsThreads) dots += ref[i] == '.';
+        missing += s1 - s0 - block_sum(dots, s_red);
+      }
+      missing -= gl + gr;
+      if (missing < 0) missing = 0;
+
+      // ---- getCorrectedPositions (:712-752): soft clips walk the corrected row from both ends ----
+      if (a.clips && tid == 0) {
+        const int lc = a.clips[2 * p], rc = a.clips[2 * p + 1];
+        int i = 0, j = 0;
+        while (j < lc && i < n) { if (cor[i] != '.') ++j; ++i; }
+        s_n[2] = i;                                                     // columns < i are clipped
+        if (lc != 0 || rc != 0) {
+          const int right_clip = n - rc;
+          i = n - 1; j = n - 1;
+          while (j >= right_clip && i >= 0) { if (cor[i] != '.') --j; --i; }
+          s_n[3] = i;                                                   // columns > i are clipped
+        }
+      }
+      __syncthreads();
+      const int clip_l = s_n[2], clip_r = s_n[3];
+
+      // ---- per-column counters (:399-440 with :291-328 and :371-393) ----
+      int acc[kAccN];
+  #pragma unroll
+      for (int k = 0; k < kAccN; ++k) acc[k] = 0;
+      for (int i = tid; i < n; i += kStatsThreads) {
+        const uint8_t x = ref[i], c = cor[i], u = unc[i];
+        bool mk = i >= clip_l && i <= clip_r;
+        if (gl >= kThresh && i < gl) mk = false;
+        if (gr >= kThresh && i > n - gr) mk = false;
+        for (int k = 0; k < nd; ++k) if (i >= dict[2 * k] && i <= dict[2 * k + 1]) mk = false;
+        mask[i] = mk ? 1 : 0;
+        acc[7] += is_gc(x); acc[8] += is_gc(c);
+        acc[15] += x != '.'; acc[16] += c != '.'; acc[17] += u != '.';
+        if (!mk) continue;
+        if (c != x) { if (x == '.') ++acc[12]; else if (c != '.') ++acc[14]; else ++acc[13]; }
+        if (u != x) { if (x == '.') ++acc[9]; else if (u != '.') ++acc[11]; else ++acc[10]; }
+        if (x == u) { if (u != c) { ++acc[1]; ++acc[4]; } else { ++acc[0]; ++acc[3]; } ++acc[5]; }
+        else { if (x == c) { ++acc[0]; ++acc[3]; } else { if (u == c) { ++acc[2]; ++acc[1]; } ++acc[4]; } ++acc[6]; }
+      }
+  #pragma unroll
+      for (int k = 0; k < kAccN; ++k) {
+        int v = acc[k];
+        for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0 && v) atomicAdd(&s_acc[k], v);
+      }
+      __syncthreads();
+      if (nfrag > 1)
+        for (int i = tid; i < n; i += kStatsThreads) uni[i] |= mask[i];      // realNotMissing (:589-591)
     }
-    __syncthreads();
     int64_t missing_last = -1;
     if (nfrag > 1) {
-      for (int i = tid; i < n; i += kStatsThreads) uni[i] |= mask[i];      // realNotMissing (:589-591)
       if (p == p1 - 1) {                                                    // last piece (:595-599)
         __syncthreads();
         int miss = 0;
@@ -572,9 +930,30 @@ int pool_prepare(elector_ctx *c, unsigned long long ints, PoolView *v)
   return 0;
 }
 
+// k_stats with bit rows for pieces of up to `max_cols` columns (as far as LDS goes)
+constexpr int kBitWordsMax = 2560;       // 163,840 columns: 6 rows = 123 KB, one workgroup per CU
+int launch_stats(elector_ctx *c, StatsArgs a, int64_t max_cols, hipStream_t st)
+{
+  const char *force = std::getenv("ELECTOR_STATS_BITWORDS");            // tests: 0 = every piece on the HBM path
+  int64_t words = (std::max<int64_t>(max_cols, 1) + 63) / 64;
+  words = std::min<int64_t>(std::max<int64_t>(words, 64), kBitWordsMax);
+  if (force) words = std::min<int64_t>(std::max(0, std::atoi(force)), kBitWordsMax);
+  a.bit_words = (int)words;
+  const size_t lds = (size_t)kBitArrays * (size_t)(words + 2) * 8;
+  static bool big_ok = false;
+  if (lds > 48 * 1024 && !big_ok) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)((size_t)kBitArrays * (kBitWordsMax + 2) * 8));
+    if (e != hipSuccess) return elector_fail(c, ELECTOR_E_HIP, "hipFuncSetAttribute(k_stats)", e);
+    big_ok = true;
+  }
+  hipLaunchKernelGGL(k_stats, dim3((unsigned)a.n_reads), dim3(kStatsThreads), lds, st, a);
+  return 0;
+}
+
 // runs k_stats, growing the pool to the worst case once if the first size was too small;
 // total_cols bounds the sum of the pieces' columns
-int run_stats(elector_ctx *c, StatsArgs a, int64_t n_pieces, int64_t total_cols)
+int run_stats(elector_ctx *c, StatsArgs a, int64_t n_pieces, int64_t total_cols, int64_t max_cols)
 {
   hipStream_t st = c->stream;
   unsigned long long want = std::max<unsigned long long>(1ull << 20, (unsigned long long)total_cols / 4);   // pool_first_size
@@ -584,7 +963,7 @@ int run_stats(elector_ctx *c, StatsArgs a, int64_t n_pieces, int64_t total_cols)
     HIPCHK(c, hipMemsetAsync(c->d_st_scr.p, 0, 16, st));
     a.pool = pv.ints; a.pool_cap = pv.cap; a.pool_used = pv.used; a.overflow = pv.overflow;
     timed_begin(c, 3, st);
-    hipLaunchKernelGGL(k_stats, dim3((unsigned)a.n_reads), dim3(kStatsThreads), 0, st, a);
+    if (launch_stats(c, a, max_cols, st)) return ELECTOR_E_HIP;
     timed_end(c, st);
     HIPCHK(c, hipGetLastError());
     int32_t over = 0;
@@ -644,7 +1023,9 @@ extern "C" int elector_stats_batch(elector_ctx *c, int64_t n_reads, const int64_
   a.clips = clips ? c->d_st_clips.as<int32_t>() : nullptr;
   a.counters = c->d_st_cnt.as<int64_t>();
   a.mask = c->d_st_mask.as<uint8_t>();
-  rc = run_stats(c, a, n_pieces, total_cols);
+  int64_t max_cols = 0;
+  for (int64_t p = 0; p < n_pieces; ++p) max_cols = std::max(max_cols, cols[p]);
+  rc = run_stats(c, a, n_pieces, total_cols, max_cols);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(counters, c->d_st_cnt.p, (size_t)n_pieces * ES_NCOUNTERS * 8, hipMemcpyDeviceToHost, st));
   if (last_mask) {
@@ -693,7 +1074,8 @@ int enqueue_stats(elector_ctx *c, elector::StatsSlot &s, unsigned long long ints
   StatsArgs a = slot_args(s);
   a.pool = pv.ints; a.pool_cap = pv.cap; a.pool_used = pv.used; a.overflow = pv.overflow;
   timed_begin(c, 3, st);
-  hipLaunchKernelGGL(k_stats, dim3((unsigned)a.n_reads), dim3(kStatsThreads), 0, st, a);
+  // columns of the longest piece, unknown on the host: 96 per window (the splitter's windows average 57 bases)
+  if (launch_stats(c, a, 96 * s.max_windows, st)) return ELECTOR_E_HIP;
   timed_end(c, st);
   HIPCHK(c, hipGetLastError());
   uint8_t *h = s.h.as<uint8_t>();
@@ -729,6 +1111,8 @@ extern "C" int elector_msa_stats_enqueue(elector_ctx *c, int64_t n_windows, cons
   if (!s.done) HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   s.n_pieces = n_pieces; s.n_reads = n_reads; s.total = c->last_total; s.has_clips = clips != nullptr;
   s.last_piece = n_reads > 0 ? read_first[n_reads - 1] : 0;
+  s.max_windows = 0;
+  for (int64_t p = 0; p < n_pieces; ++p) s.max_windows = std::max(s.max_windows, piece_first[p + 1] - piece_first[p]);
   const int64_t total = s.total;            // bases of the batch: an upper bound of its MSA columns
   if (n_pieces > 0 && n_reads > 0) {
     // both slots grow together: the second job of a pipelined caller must not pay for allocations

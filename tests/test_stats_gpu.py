@@ -209,3 +209,76 @@ def test_long_gap_runs_block_walk(tmp_path, engine):
     exp = oracle_counter_array(pieces, oracle_pieces)
     got, _ = cs.stats_counters(pieces, None, engine)
     assert np.array_equal(got, exp), np.argwhere(got != exp)
+
+
+def _gappy_records(seed, sizes, split_every=3):
+    """Three-row records made directly (no POA): gap runs of every length in all rows, gap stretches at the
+    ends, many short corrected-gap runs (more than the kernel keeps in LDS), pieces of split reads."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"acgt", dtype=np.uint8)
+    dot = ord(".")
+
+    def runs(row, n, count, lens):
+        for _ in range(count):
+            k = int(rng.choice(lens))
+            s = int(rng.integers(0, max(1, n - k)))
+            row[s:s + k] = dot
+
+    recs, clips = [], {}
+    for idx, n in enumerate(sizes):
+        ref = acgt[rng.integers(0, 4, n)].copy()
+        cor = ref.copy()
+        unc = ref.copy()
+        sub = rng.random(n) < 0.02
+        cor[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        sub = rng.random(n) < 0.12
+        unc[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        runs(ref, n, n // 40, [1, 1, 2, 3, 5, 8, 19, 20, 21, 30])
+        runs(unc, n, n // 60, [1, 2, 4, 6, 25])
+        runs(cor, n, n // (25 if idx % 2 else 120), [1, 2, 4, 5, 6, 7, 9, 22, 40])
+        if idx % 4 == 1 and n >= 4000:
+            runs(cor, n, 3, [250, 700, 1500])
+        kind = idx % 5 if n >= 400 else 0
+        if kind == 1:
+            cor[: n // 5] = dot                                   # trimmed left
+        elif kind == 2:
+            cor[n - n // 4:] = dot                                # trimmed right
+        elif kind == 3:
+            ref[:37] = dot; unc[:41] = dot                        # corrected read extends to the left
+            ref[n - 33:] = dot; unc[n - 29:] = dot
+        name = "r%d" % (idx // split_every if idx % (2 * split_every) >= split_every else 1000 + idx)
+        recs.append((name, ref.tobytes().decode(), cor.tobytes().decode(), unc.tobytes().decode()))
+        if idx % 3 == 0:
+            clips[">" + name + " "] = (int(rng.integers(0, 60)), int(rng.integers(0, 60)))
+    return recs, clips
+
+
+@pytest.mark.parametrize("seed,sizes", [(61, [700, 90, 3000, 12, 5000, 64, 128, 4097, 2048, 11, 1500, 333]),
+                                         (62, [20000, 70000, 9000, 30000, 8000, 2500])])
+def test_bit_rows_path_equals_hbm_path_and_oracle(tmp_path, engine, monkeypatch, seed, sizes):
+    """k_stats on bit rows in LDS (the default) against the same kernel reading letters from HBM throughout
+    (ELECTOR_STATS_BITWORDS=0, also what pieces too long for LDS get) and against the oracle; with a small LDS
+    budget both paths meet inside one launch."""
+    recs, clips = _gappy_records(seed, sizes)
+    txt = "".join(">%s \n%s\n>%s \n%s\n>%s \n%s\n" % (h, a, h, b, h, c) for h, a, b, c in recs)
+    path = tmp_path / "msa.fa"
+    path.write_text(txt)
+    pieces = cs.parse_msa(str(path), cs.getSplit(str(path)))
+    for use_clips in (None, clips):
+        _, oracle_pieces = stats_oracle.compute_metrics(txt, 5, use_clips)
+        exp = oracle_counter_array(pieces, oracle_pieces)
+        proc = exp[:, cs.ES_PROCESSED] == 1
+        results = []
+        for words in (None, "0", "40"):
+            if words is None:
+                monkeypatch.delenv("ELECTOR_STATS_BITWORDS", raising=False)
+            else:
+                monkeypatch.setenv("ELECTOR_STATS_BITWORDS", words)
+            got, last_mask = cs.stats_counters(pieces, use_clips, engine)
+            results.append((got, last_mask))
+            assert np.array_equal(got[:, cs.ES_PROCESSED], exp[:, cs.ES_PROCESSED])
+            assert np.array_equal(got[proc], exp[proc]), (words, np.argwhere(got[proc] != exp[proc])[:8])
+        for got, last_mask in results[1:]:
+            assert np.array_equal(got, results[0][0])
+            assert np.array_equal(last_mask, results[0][1])
+    monkeypatch.delenv("ELECTOR_STATS_BITWORDS", raising=False)
