@@ -449,9 +449,15 @@ __device__ int right_gaps_bits(int arr, int W2, int n)
   return total;
 }
 
-// walk_gap_run on the bit rows
-__device__ void walk_gap_run_bits(int W2, int n, int s, int32_t *first_hit, int32_t *last_hit)
+// walk_gap_run on the bit rows.  The run's end comes from the words first, so that a long run (the part of
+// the reference a trimmed or split piece does not cover) is recognised without walking its first kWalkCap
+// columns; *run_end = its last column.
+__device__ void walk_gap_run_bits(int W2, int n, int s, int32_t *first_hit, int32_t *last_hit, int32_t *run_end)
 {
+  int j = s >> 6;
+  unsigned long long w = ~bwr(kGc, W2, j) & (~0ull << (s & 63));
+  while (!w) { ++j; w = ~bwr(kGc, W2, j); }                              // the guard word after the row ends the search
+  const int e = min(64 * j + (int)__builtin_ctzll(w), n);                // first column after the run
   int rb = s;
   while (rb > 0 && bbit(kGx, W2, rb - 1)) --rb;
   int cgr = 0;
@@ -462,10 +468,10 @@ __device__ void walk_gap_run_bits(int W2, int n, int s, int32_t *first_hit, int3
     if (!rgap) cgr = 0;
   };
   for (int x = rb; x < s; ++x) step(x);
-  const int entry = cgr;
+  *run_end = e - 1;
+  if (e - s > kWalkCap) { *first_hit = kRunLong; *last_hit = cgr; return; }
   int fh = -1, lh = -1;
-  for (int x = s; x < n && bbit(kGc, W2, x); ++x) {
-    if (x - s >= kWalkCap) { *first_hit = kRunLong; *last_hit = entry; return; }
+  for (int x = s; x < e; ++x) {
     step(x);
     if (x - s + 1 >= kThresh && cgr < kThresh2) { if (fh < 0) fh = x; lh = x; }
   }
@@ -473,20 +479,10 @@ __device__ void walk_gap_run_bits(int W2, int n, int s, int32_t *first_hit, int3
   *last_hit = lh;
 }
 
-// block_gap_run on the bit rows
-__device__ void block_gap_run_bits(int W2, int n, int s, int entry, int *first_hit, int *last_hit)
+// block_gap_run on the bit rows, for the run s..end
+__device__ void block_gap_run_bits(int W2, int s, int end, int entry, int *first_hit, int *last_hit)
 {
   const int tid = threadIdx.x;
-  int end = -1;
-  for (int base = s; end < 0; base += kStatsThreads) {
-    __syncthreads();
-    if (tid == 0) s_long[0] = 0x7fffffff;
-    __syncthreads();
-    const int x = base + tid;
-    if (x >= n || !bbit(kGc, W2, x)) atomicMin(&s_long[0], x);
-    __syncthreads();
-    if (s_long[0] != 0x7fffffff) end = s_long[0] - 1;
-  }
   __syncthreads();
   if (tid == 0) { s_long[1] = 0x7fffffff; s_long[2] = -1; }
   __syncthreads();
@@ -660,12 +656,12 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
           runs[rank] = v;
         }
         __syncthreads();
-        for (int e = tid; e < m; e += kStatsThreads) walk_gap_run_bits(W2, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1]);
+        for (int e = tid; e < m; e += kStatsThreads) walk_gap_run_bits(W2, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1], &tmp[e]);
         __syncthreads();
         for (int e = 0; e < m; ++e) {                                   // long runs: all threads together
           if (mrg[2 * e] != kRunLong) continue;
           int fh, lh;
-          block_gap_run_bits(W2, n, runs[e], mrg[2 * e + 1], &fh, &lh);
+          block_gap_run_bits(W2, runs[e], tmp[e], mrg[2 * e + 1], &fh, &lh);
           if (tid == 0) { mrg[2 * e] = fh; mrg[2 * e + 1] = lh; }
           __syncthreads();
         }
