@@ -169,20 +169,36 @@ def pmc_file(profile, reads):
 
 def skipped_alignment1(win, lr, lc):
     """Windows whose alignment #1 the device skips (k_trivial, poa_kernels.hip): corrected equals the
-    reference, or differs from it by exactly one substitution.  Host-side count for the `gcups` split."""
+    reference, or differs from it by exactly one substitution, one inserted or one deleted letter.
+    Host-side count for the `gcups` split."""
     import numpy as np
-    same = np.nonzero(lr == lc)[0]
-    if len(same) == 0:
-        return np.zeros(len(lr), dtype=bool)
-    off = win.off
-    L = lr[same]
-    ends = np.cumsum(L)
-    idx = np.repeat(off[3 * same] - (ends - L), L) + np.arange(int(ends[-1]), dtype=np.int64)
-    mism = win.bases[idx] != win.bases[idx + np.repeat(L, L)]
-    starts = ends - L
-    nmis = np.add.reduceat(mism.astype(np.int64), starts)
     out = np.zeros(len(lr), dtype=bool)
-    out[same[nmis <= 1]] = True
+    off = win.off
+    same = np.nonzero((lr == lc) & (lr > 0))[0]
+    if len(same):
+        L = lr[same]
+        ends = np.cumsum(L)
+        idx = np.repeat(off[3 * same] - (ends - L), L) + np.arange(int(ends[-1]), dtype=np.int64)
+        mism = win.bases[idx] != win.bases[idx + np.repeat(L, L)]
+        nmis = np.add.reduceat(mism.astype(np.int64), ends - L)
+        out[same[nmis <= 1]] = True
+    # one indel: the strings agree up to the first difference fd and, shifted by one, from fd on
+    for d in (-1, 1):                                  # lc = lr + d
+        sel = np.nonzero((lc == lr + d) & (np.minimum(lr, lc) >= 1))[0]
+        if len(sel) == 0:
+            continue
+        m = np.minimum(lr[sel], lc[sel])
+        ends = np.cumsum(m)
+        starts = ends - m
+        pos = np.arange(int(ends[-1]), dtype=np.int64) - np.repeat(starts, m)
+        xi = np.repeat(off[3 * sel], m) + pos
+        yi = np.repeat(off[3 * sel + 1], m) + pos
+        direct = win.bases[xi] != win.bases[yi]
+        shifted = (win.bases[xi + 1] != win.bases[yi]) if d < 0 else (win.bases[xi] != win.bases[yi + 1])
+        big = np.int64(1 << 40)
+        first_direct = np.minimum.reduceat(np.where(direct, pos, big), starts)
+        last_shift = np.maximum.reduceat(np.where(shifted, pos, -1), starts)
+        out[sel[last_shift < first_direct]] = True
     return out
 
 
@@ -407,7 +423,7 @@ def main():
             # of the windows, on 32-bit ones)
             # DP cells per second.  effective: every cell the reference computes (Lr*Lc + |PO|*Lu per window);
             # computed: without alignment #1 of the windows whose corrected sequence equals the reference or
-            # differs by one substitution, which the device settles without a dynamic program (k_trivial)
+            # differs by one substitution or one indel, which the device settles without a dynamic program (k_trivial)
             "gcups_effective": round(cells_all * args.steps / dt_max / 1e9, 3),
             "gcups_computed": round(cells_comp_all * args.steps / dt_max / 1e9, 3),
             "alignment1_skipped_windows_frac": round(float(skipped.mean()), 4),

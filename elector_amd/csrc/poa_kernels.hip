@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) k_left_b(BatchArgs a, uint32_t *list, int
 // Wavefronts of k_fused_b whose windows reach such nodes at the same steps take its two-predecessor
 // path together instead of one after the other.
 constexpr int kPartBuckets = 32;        // 0..14: first difference in columns 8k..8k+7 (14: beyond); 16..30: the same for the
-                                        // one-substitution windows k_poa settles without alignment #1 (their wavefronts
+                                        // one-substitution / one-indel windows k_poa settles without alignment #1 (their wavefronts
                                         // then skip it altogether); 31: corrected equals reference
 
 __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, int one_sub_ok)
@@ -608,6 +608,7 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
   const bool eq = a.status[w] == 0 && Lr == Lc && fd == nmin;
   if (g == 0) { triv[w] = eq ? 1 : 0; pkey[w] = (uint8_t)(eq ? kPartBuckets - 1 : min(fd >> 3, 14)); }
   const bool flags_only = (one_sub_ok & 2) != 0;      // k_poa builds these graphs itself, in LDS
+  const bool indel_ok = (one_sub_ok & 4) != 0;
   one_sub_ok &= 1;
   if (flags_only && eq) return;
   if (!eq) {
@@ -616,7 +617,23 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
     // strictly best predecessor of every diagonal cell as long as |mismatch| < open + extension, so the
     // pairs are again letter i with letter i; the fusion puts the corrected letter in a node of its own
     // right before the reference letter's, both in one ring (lpo.c:449-450,647-649).  No dynamic program.
-    if (!one_sub_ok || a.status[w] != 0 || Lr != Lc) return;
+    if (!one_sub_ok || a.status[w] != 0) return;
+    if (Lr != Lc) {
+      // One inserted or one deleted letter and nothing else (the strings agree up to fd and, shifted by one,
+      // after it): one gap of length 1 and no mismatch beats every other alignment (mismatch < match, and any
+      // other gap layout opens at least two more gap positions); the gap may sit anywhere in the run of equal
+      // letters that ends at fd, and the traceback's tie rule (a gap step wins against the diagonal on the way
+      // back from the end, align_lpo_po2.c:108-168) puts it at the run's last letter, fd itself.  k_poa builds
+      // the graph (poa_pack.hip trivial_graph); the other paths run the dynamic program.
+      if (!flags_only || !indel_ok || nmin < 1 || (Lc != Lr - 1 && Lc != Lr + 1)) return;
+      const bool del = Lc == Lr - 1;
+      bool rest = true;
+      if (del) { for (int i = fd + g; i < Lc; i += 8) rest = rest && xs[i + 1] == ys[i]; }
+      else { for (int i = fd + g; i < Lr; i += 8) rest = rest && xs[i] == ys[i + 1]; }
+      for (int d = 1; d < 8; d <<= 1) rest = __shfl_xor(rest ? 1 : 0, d, 8) != 0 && rest;
+      if (rest && g == 0) { triv[w] = del ? 3 : 4; pkey[w] = (uint8_t)(16 + min(fd >> 3, 14)); }
+      return;
+    }
     bool rest = true;
     for (int i = fd + 1 + g; i < Lr; i += 8) rest = rest && xs[i] == ys[i];
     for (int d = 1; d < 8; d <<= 1) rest = __shfl_xor(rest ? 1 : 0, d, 8) != 0 && rest;
@@ -833,8 +850,11 @@ void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t 
   const int one_sub_ok = !std::getenv("ELECTOR_NO_ONESUB") &&
                          (a.kp.match - a.kp.mismatch) < (a.kp.open_x < a.kp.open_y ? a.kp.open_x : a.kp.open_y) +
                                                          (a.kp.ext_x < a.kp.ext_y ? a.kp.ext_x : a.kp.ext_y);
+  // the one-insertion / one-deletion shortcut: a mismatch must cost something, gap penalties alike in both directions
+  const int indel_ok = !std::getenv("ELECTOR_NO_ONEINDEL") && a.kp.mismatch < a.kp.match && a.kp.open_x == a.kp.open_y &&
+                       a.kp.ext_x == a.kp.ext_y;
   hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv, pkey,
-                     one_sub_ok | (flags_only ? 2 : 0));
+                     one_sub_ok | (flags_only ? 2 : 0) | (indel_ok ? 4 : 0));
 }
 
 int partition_buckets() { return kPartBuckets; }

@@ -403,9 +403,44 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
     W.n1 = L;
     return;
   }
-  int e = L;
-  for (int i = g; i < L && i < e; i += G) if (xs[i] != ys[i]) e = i;
+  const int Lc = W.Lc, nm = min(L, Lc);
+  int e = nm;
+  for (int i = g; i < nm && i < e; i += G) if (xs[i] != ys[i]) e = i;
   for (int d = 1; d < G; d <<= 1) e = min(e, __shfl_xor(e, d, G));
+  if (W.triv == 3) {
+    // one deleted letter, reference letter e (k_trivial): the chain of the reference with letter e on its own;
+    // the node after it has the corrected read's edge from two nodes back as its second predecessor -- or, when
+    // e = 0, the virtual start (two columns back) first and node 0 second (what fusion_1's emit makes of it)
+    for (int i = g; i < L; i += G) {
+      int fl = kFlagHasRef | (i == 0 ? kFlagInitial : 0) | (i == L - 1 ? kFlagFinal : 0);
+      if (i != e) { const int y = i < e ? i : i - 1; fl |= kFlagHasCor | (y == 0 ? kFlagInitial : 0) | (y == Lc - 1 ? kFlagFinal : 0); }
+      uint32_t rec = ((uint32_t)xs[i] << 8) | ((uint32_t)fl << 16) | kN_NewCol;
+      if (i == e + 1) rec |= e == 0 ? (kN_Far1 | kN_Has2) : (kN_Has2 | kN_Far2);
+      xinfo[i + 1] = rec;
+    }
+    W.n1 = L;
+    return;
+  }
+  if (W.triv == 4) {
+    // one inserted letter, corrected letter e: a node of its own at index e; the reference letter after it
+    // (node e + 1) has the node before the insertion (two back; the virtual start when e = 0) first and the
+    // inserted letter's node second
+    for (int n = g; n < L + 1; n += G) {
+      uint32_t rec;
+      if (n == e) {
+        const int fl = kFlagHasCor | (e == 0 ? kFlagInitial : 0) | (e == Lc - 1 ? kFlagFinal : 0);
+        rec = ((uint32_t)ys[e] << 8) | ((uint32_t)fl << 16) | kN_NewCol;
+      } else {
+        const int ix = n < e ? n : n - 1;                               // fused with corrected letter n
+        const int fl = kFlagHasRef | kFlagHasCor | ((ix == 0 || n == 0) ? kFlagInitial : 0) | ((ix == L - 1 || n == Lc - 1) ? kFlagFinal : 0);
+        rec = ((uint32_t)xs[ix] << 8) | ((uint32_t)fl << 16) | kN_NewCol;
+        if (n == e + 1) rec |= kN_Far1 | kN_Has2;
+      }
+      xinfo[n + 1] = rec;
+    }
+    W.n1 = L + 1;
+    return;
+  }
   for (int i = g; i < L; i += G) {
     const int fl_pos = (i == 0 ? kFlagInitial : 0) | (i == L - 1 ? kFlagFinal : 0);
     if (i != e) {
@@ -909,6 +944,7 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
     trivial_graph<G>(W[h], g, U[h], U[h] + W[h].Lr, xinfo[h]);
     if (W[h].valid && W[h].triv == 1) W[h].score1 = W[h].Lr * kp.match;
     if (W[h].valid && W[h].triv == 2) W[h].score1 = (W[h].Lr - 1) * kp.match + kp.mismatch;
+    if (W[h].valid && W[h].triv >= 3) W[h].score1 = min(W[h].Lr, W[h].Lc) * kp.match - kp.open_x;
   }
   __syncthreads();
   PK_STAMP(3);
