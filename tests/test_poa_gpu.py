@@ -210,3 +210,55 @@ def test_tiled_general_matrix(monkeypatch):
             assert got == exp_rows and np.array_equal(scores, exp_scores)
         finally:
             eng.close()
+
+
+def one_indel_triples(seed):
+    """Windows whose corrected sequence is the reference with ONE letter inserted or deleted -- settled
+    without a dynamic program (k_trivial / trivial_graph): every position including both ends, inside runs
+    of equal letters (where the gap's place is the traceback's tie rule), inserted letters equal to the left
+    or the right neighbour, short windows, and the same next to windows that do need alignment #1."""
+    rng = np.random.default_rng(seed)
+    acgt = b"ACGT"
+    out = []
+
+    def unc_of(ref):
+        return synth.mutate(rng, ref, 0.15) or ref
+
+    for L in (2, 3, 5, 9, 31, 62, 64, 100, 130, 250):
+        ref = synth.random_seq(rng, L)
+        # a run of equal letters in the middle and at both ends of some windows
+        if L >= 9:
+            ref = ref[:L // 2] + b"AAAA" + ref[L // 2 + 4:]
+        if L >= 31:
+            ref = b"CCC" + ref[3:-3] + b"GGG"
+        pos = range(L + 1) if L <= 64 else sorted(set(int(x) for x in rng.integers(0, L + 1, 24)) | {0, 1, L - 1, L})
+        for p in pos:
+            if p < L:
+                out.append((ref, ref[:p] + ref[p + 1:], unc_of(ref)))                   # deletion of letter p
+            for b in acgt:
+                out.append((ref, ref[:p] + bytes([b]) + ref[p:], unc_of(ref)))          # insertion in front of letter p
+    # neighbours that need the dynamic program, so that wavefronts mix both kinds
+    mixed = []
+    for k, t in enumerate(out):
+        mixed.append(t)
+        if k % 7 == 0:
+            ref = t[0]
+            mixed.append((ref, synth.mutate(rng, ref, 0.2) or ref, unc_of(ref)))
+    return [t for t in mixed if len(t[1]) >= 1]
+
+
+def test_one_indel_windows(engine):
+    triples = one_indel_triples(77)
+    assert len(triples) > 1200
+    check(engine, triples)
+
+
+def test_one_indel_shortcut_equals_dynamic_program(engine, monkeypatch):
+    """the same windows with the shortcut switched off (ELECTOR_NO_ONEINDEL): identical rows and scores"""
+    triples = one_indel_triples(78)[:1500]
+    got, scores = engine.align(triples, want_scores=True)
+    monkeypatch.setenv("ELECTOR_NO_ONEINDEL", "1")
+    got2, scores2 = engine.align(triples, want_scores=True)
+    monkeypatch.delenv("ELECTOR_NO_ONEINDEL")
+    assert got == got2
+    assert np.array_equal(scores, scores2)
