@@ -417,6 +417,10 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             w0 = int(b.piece_first[p0])
             last_cap = int(win.off[-1] - win.off[3 * w0]) + 16
             pending.append((e, b, npieces, last_cap))
+            # while the splitter is still busy with the next batch, the oldest jobs' records go to the file
+            # (their kernels are short against a split); otherwise every write would wait for the end
+            while pending and work.empty():
+                finish(out)
         while pending:
             finish(out)
     th.join()
