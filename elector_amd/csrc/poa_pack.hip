@@ -1040,17 +1040,24 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       const uint32_t xiA = xiA_next, xiB = xiB_next;
       xiA_next = xinfo[0][med3(jj + 1, 0, n1c0)];
       xiB_next = xinfo[1][med3(jj + 1, 0, n1c1)];
-      // per-half select masks: predecessor two columns back (else one)
-      const uint32_t M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
       // the two letters (byte 1 of each record) to the low bytes of the two halves: one v_perm_b32
       const uint32_t xlp = __builtin_amdgcn_perm(xiB, xiA, 0x0c050c01u);
-      // one test for the common case: no lane at a node with a second predecessor or a far virtual start
+      // one test for the common case: every lane at a node whose only predecessor is the node before it (a
+      // stretch of plain chain in all windows of the wave): the column one back is the predecessor, nothing to
+      // select.  Otherwise: is some lane at a node with a second predecessor or a far virtual start?
       const uint32_t xor_ = xiA | xiB;
-      const bool two = __builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2)) != 0u) != 0;
+      const bool any = (a.debug & 1024) != 0 || __builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1)) != 0u) != 0;   // debug bit 1024: never the plain-chain variant (A/B)
+      const bool two = any && __builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2)) != 0u) != 0;
       const bool virt = two && __builtin_amdgcn_ballot_w64((xor_ & kN_Virt1) != 0u) != 0;
+      // per-half select masks: predecessor two columns back (else one)
+      uint32_t M1 = 0, bb1 = BE1;
+      if (any) {
+        M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
+        bb1 = bfi(M1, BE2, BE1);
+      }
       // a node without a second predecessor repeats the first (bit 1 = bit 0): when no lane of the wave has one,
       // everything about the second candidate is left out
-      uint32_t M2 = M1, V1 = 0, V2 = 0, bb1 = bfi(M1, BE2, BE1);
+      uint32_t M2 = M1, V1 = 0, V2 = 0;
       uint32_t BRj = bb1;
       if (two) {
         M2 = bfi(0xFFFFu, 0u - ((xiA >> 1) & 1u), 0u - ((xiB >> 1) & 1u));
@@ -1070,15 +1077,17 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       prev_up1 = up1;
       const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
       if (!FIRST || jj >= 1) {                                       // before its first column a lane keeps column 0
-        uint32_t dt1 = bfi(M1, up2, up1), dt2 = dt1, insY = upE, mvw = 0, secw = 0;
+        uint32_t dt1 = up1, dt2, insY = upE, mvw = 0, secw = 0;
+        if (any) dt1 = bfi(M1, up2, up1);
+        dt2 = dt1;
         if (two) dt2 = bfi(M2, up2, up1);
         if (virt) { dt1 = bfi(V1, colAbove, dt1); dt2 = bfi(V2, colAbove, dt2); }
-        auto cells = [&](auto two_tag, auto virt_tag) {
-          constexpr bool TWO = decltype(two_tag)::value, VIRT = decltype(virt_tag)::value;
+        auto cells = [&](auto two_tag, auto virt_tag, auto near_tag) {
+          constexpr bool TWO = decltype(two_tag)::value, VIRT = decltype(virt_tag)::value, NEAR = decltype(near_tag)::value;
           uint32_t vcS = colS0;                                        // column 0 at this lane's rows, top down
 #pragma unroll
           for (int k = 0; k < R; ++k) {
-            uint32_t c1S = bfi(M1, Sb[k], Sa[k]), c1E = bfi(M1, Eb[k], Ea[k]);
+            uint32_t c1S = NEAR ? Sa[k] : bfi(M1, Sb[k], Sa[k]), c1E = NEAR ? Ea[k] : bfi(M1, Eb[k], Ea[k]);
             uint32_t insX = c1E, dmax = dt1, c2S = c1S;
             if (VIRT) {
               if (k > 0) vcS = pk_subk(vcS, KEXT);
@@ -1113,9 +1122,10 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
           }
         };
         if (a.debug & 4) { ++n_steps; n_two += two && !virt; n_virt += virt; }
-        if (virt) cells(std::true_type{}, std::true_type{});
-        else if (two) cells(std::true_type{}, std::false_type{});
-        else cells(std::false_type{}, std::false_type{});
+        if (virt) cells(std::true_type{}, std::true_type{}, std::false_type{});
+        else if (two) cells(std::true_type{}, std::false_type{}, std::false_type{});
+        else if (any) cells(std::false_type{}, std::false_type{}, std::false_type{});
+        else cells(std::false_type{}, std::false_type{}, std::true_type{});
         BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
         mv[t * 64 + lane] = mvw;                                     // every lane: a lane past its window's end writes a word nobody reads
         if (two) {
