@@ -107,6 +107,46 @@ __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b)
 // pair's bits in a register of its own)
 __device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
 
+// One row (two cells, one per half) of the affine-gap recurrence in ONE block.  The compiler has to assume that
+// an inline-asm result may be a partial-register write (the dst_sel forwarding hazard of this chip) and puts a
+// wait state in front of every instruction that reads one: with one statement per instruction that was six
+// `s_nop 0` per row.  In: the letters' comparison operands, the x-gap / y-gap offers, the best diagonal
+// predecessor.  Out: score Sn, what the cell offers a y-gap below it (En), the "match wins" bit, and the row's
+// two move bits OR-ed into mvw at bit SH.
+template <int SH>
+__device__ __forceinline__ void pk_row(uint32_t xlp, uint32_t ylp, uint32_t insX, uint32_t insY, uint32_t dmax, uint32_t ONES,
+                                       uint32_t KSUB, uint32_t KEXT, uint32_t KDELTA, uint32_t &Sn, uint32_t &En,
+                                       uint32_t &mbit, uint32_t &mvw)
+{
+  uint32_t t0, mx;
+  asm("v_xor_b32 %[t0], %[xl], %[yl]\n\t"
+      "v_pk_max_i16 %[mx], %[ix], %[iy]\n\t"
+      "v_pk_min_u16 %[t0], %[t0], %[one]\n\t"
+      "v_pk_mad_i16 %[t0], %[t0], %[ksub], %[dm]\n\t"
+      "v_pk_max_i16 %[sn], %[t0], %[mx]\n\t"
+      "v_pk_sub_i16 %[t0], %[sn], %[mx]\n\t"
+      "v_pk_sub_i16 %[mx], %[mx], %[iy]\n\t"
+      "v_pk_sub_i16 %[en], %[sn], %[kext]\n\t"
+      "v_pk_min_u16 %[mb], %[t0], %[one]\n\t"
+      "v_pk_min_u16 %[mx], %[mx], %[one]\n\t"
+      "v_pk_mad_i16 %[en], %[mb], %[kdelta], %[en]\n\t"
+      "v_lshl_or_b32 %[mx], %[mb], 1, %[mx]\n\t"
+      "v_lshl_or_b32 %[mv], %[mx], %[sh], %[mv]"
+      : [sn] "=&v"(Sn), [en] "=&v"(En), [mb] "=&v"(mbit), [mv] "+v"(mvw), [t0] "=&v"(t0), [mx] "=&v"(mx)
+      : [xl] "v"(xlp), [yl] "v"(ylp), [ix] "v"(insX), [iy] "v"(insY), [dm] "v"(dmax), [one] "s"(ONES), [ksub] "s"(KSUB),
+        [kext] "s"(KEXT), [kdelta] "s"(KDELTA), [sh] "n"(SH));
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
 // clamp(x, lo, hi) in one instruction (lo <= hi)
 __device__ __forceinline__ int med3(int x, int lo, int hi)
 {
@@ -1042,96 +1082,95 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       xiB_next = xinfo[1][med3(jj + 1, 0, n1c1)];
       // the two letters (byte 1 of each record) to the low bytes of the two halves: one v_perm_b32
       const uint32_t xlp = __builtin_amdgcn_perm(xiB, xiA, 0x0c050c01u);
-      // one test for the common case: every lane at a node whose only predecessor is the node before it (a
-      // stretch of plain chain in all windows of the wave): the column one back is the predecessor, nothing to
-      // select.  Otherwise: is some lane at a node with a second predecessor or a far virtual start?
+      // Four forms of the step, each a straight piece of code of its own (chosen by wave-wide tests on the records'
+      // low bits): NEAR -- every lane at a node whose only predecessor is the node before it (a stretch of plain
+      // chain in all windows of the wave): the column one back is the predecessor, nothing to select; plain -- some
+      // lane's predecessor lies two columns back; TWO -- some lane at a node with a second predecessor; VIRT -- some
+      // lane's first predecessor is the virtual start more than two columns back.
       const uint32_t xor_ = xiA | xiB;
-      const bool any = (a.debug & 1024) != 0 || __builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1)) != 0u) != 0;   // debug bit 1024: never the plain-chain variant (A/B)
-      const bool two = any && __builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2)) != 0u) != 0;
-      const bool virt = two && __builtin_amdgcn_ballot_w64((xor_ & kN_Virt1) != 0u) != 0;
-      // per-half select masks: predecessor two columns back (else one)
-      uint32_t M1 = 0, bb1 = BE1;
-      if (any) {
-        M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
-        bb1 = bfi(M1, BE2, BE1);
-      }
-      // a node without a second predecessor repeats the first (bit 1 = bit 0): when no lane of the wave has one,
-      // everything about the second candidate is left out
-      uint32_t M2 = M1, V1 = 0, V2 = 0;
-      uint32_t BRj = bb1;
-      if (two) {
-        M2 = bfi(0xFFFFu, 0u - ((xiA >> 1) & 1u), 0u - ((xiB >> 1) & 1u));
-        uint32_t bb2 = bfi(M2, BE2, BE1);
-        if (virt) {
-          V1 = bfi(0xFFFFu, 0u - ((xiA >> 3) & 1u), 0u - ((xiB >> 3) & 1u));
-          // the repeat of a virtual first predecessor is virtual too
-          V2 = V1 & ~bfi(0xFFFFu, 0u - ((xiA >> 2) & 1u), 0u - ((xiB >> 2) & 1u));
-          bb1 = bfi(V1, KOPENNEG, bb1);
-          bb2 = bfi(V2, KOPENNEG, bb2);
+      const bool active = !FIRST || jj >= 1;                         // before its first column a lane keeps column 0
+      uint32_t BRj, BEj, mvw = 0;
+      auto variant = [&](auto near_tag, auto two_tag, auto virt_tag) {
+        constexpr bool NEAR = decltype(near_tag)::value, TWO = decltype(two_tag)::value, VIRT = decltype(virt_tag)::value;
+        // per-half select masks: predecessor two columns back (else one)
+        uint32_t M1 = 0, M2 = 0, V1 = 0, V2 = 0, bb1 = BE1;
+        if (!NEAR) {
+          M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
+          bb1 = bfi(M1, BE2, BE1);
         }
-        BRj = pk_max(bb1, bb2);
-      }
-      const uint32_t BEj = pk_subk(BRj, KEXT);
-      const uint32_t up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);        // row above at column jj - 1
-      const uint32_t up2 = prev_up1;                                 // ... at column jj - 2
-      prev_up1 = up1;
-      const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
-      if (!FIRST || jj >= 1) {                                       // before its first column a lane keeps column 0
-        uint32_t dt1 = up1, dt2, insY = upE, mvw = 0, secw = 0;
-        if (any) dt1 = bfi(M1, up2, up1);
-        dt2 = dt1;
-        if (two) dt2 = bfi(M2, up2, up1);
-        if (virt) { dt1 = bfi(V1, colAbove, dt1); dt2 = bfi(V2, colAbove, dt2); }
-        auto cells = [&](auto two_tag, auto virt_tag, auto near_tag) {
-          constexpr bool TWO = decltype(two_tag)::value, VIRT = decltype(virt_tag)::value, NEAR = decltype(near_tag)::value;
-          uint32_t vcS = colS0;                                        // column 0 at this lane's rows, top down
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
-            uint32_t c1S = NEAR ? Sa[k] : bfi(M1, Sb[k], Sa[k]), c1E = NEAR ? Ea[k] : bfi(M1, Eb[k], Ea[k]);
-            uint32_t insX = c1E, dmax = dt1, c2S = c1S;
-            if (VIRT) {
-              if (k > 0) vcS = pk_subk(vcS, KEXT);
-              c1S = bfi(V1, vcS, c1S);
-              c1E = bfi(V1, pk_subk(vcS, KEXT), c1E);
-              insX = c1E;
-            }
-            if (TWO) {
-              c2S = bfi(M2, Sb[k], Sa[k]);
-              uint32_t c2E = bfi(M2, Eb[k], Ea[k]);
-              if (VIRT) { c2S = bfi(V2, vcS, c2S); c2E = bfi(V2, pk_subk(vcS, KEXT), c2E); }
-              insX = pk_max(c1E, c2E);                                // first maximum wins (:361-371)
-              dmax = pk_max(dt1, dt2);                                // (:348-357)
-            }
-            const uint32_t ne = pk_bit(xlp ^ ylp[k], ONES);
-            const uint32_t mat = pk_mad(ne, KSUB, dmax);
-            const uint32_t mx = pk_max(insX, insY);
-            const uint32_t Sn = pk_max(mat, mx);
-            const uint32_t mbit = pk_bit(pk_sub(Sn, mx), ONES);
-            const uint32_t xbit = pk_bit(pk_sub(mx, insY), ONES);
-            mvw |= ((mbit << 1) | xbit) << (2 * k);
-            pin(mvw);
-            if (TWO) {
-              const uint32_t pm = pk_bit(pk_sub(dmax, dt1), ONES);   // second predecessor strictly better on the diagonal
-              const uint32_t px = pk_bit(pk_sub(insX, c1E), ONES);   // ... for the x-insertion
-              secw |= bfi(pk_sub(0u, mbit), pm, px) << k;
-              pin(secw);
-            }
-            const uint32_t En = pk_mad(mbit, KDELTA, pk_subk(Sn, KEXT));
-            dt1 = c1S; dt2 = c2S;
-            Sb[k] = Sn; Eb[k] = En; insY = En;
+        BRj = bb1;
+        // a node without a second predecessor repeats the first (bit 1 = bit 0): when no lane of the wave has one,
+        // everything about the second candidate is left out
+        if (TWO) {
+          M2 = bfi(0xFFFFu, 0u - ((xiA >> 1) & 1u), 0u - ((xiB >> 1) & 1u));
+          uint32_t bb2 = bfi(M2, BE2, BE1);
+          if (VIRT) {
+            V1 = bfi(0xFFFFu, 0u - ((xiA >> 3) & 1u), 0u - ((xiB >> 3) & 1u));
+            // the repeat of a virtual first predecessor is virtual too
+            V2 = V1 & ~bfi(0xFFFFu, 0u - ((xiA >> 2) & 1u), 0u - ((xiB >> 2) & 1u));
+            bb1 = bfi(V1, KOPENNEG, bb1);
+            bb2 = bfi(V2, KOPENNEG, bb2);
           }
-        };
-        if (a.debug & 4) { ++n_steps; n_two += two && !virt; n_virt += virt; }
-        if (virt) cells(std::true_type{}, std::true_type{}, std::false_type{});
-        else if (two) cells(std::true_type{}, std::false_type{}, std::false_type{});
-        else if (any) cells(std::false_type{}, std::false_type{}, std::false_type{});
-        else cells(std::false_type{}, std::false_type{}, std::true_type{});
-        BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
-        mv[t * 64 + lane] = mvw;                                     // every lane: a lane past its window's end writes a word nobody reads
-        if (two) {
+          BRj = pk_max(bb1, bb2);
+        }
+        BEj = pk_subk(BRj, KEXT);
+        const uint32_t up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);        // row above at column jj - 1
+        const uint32_t up2 = prev_up1;                                 // ... at column jj - 2
+        prev_up1 = up1;
+        const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
+        if (!active) return;
+        uint32_t dt1 = up1, dt2, insY = upE, secw = 0;
+        if (!NEAR) dt1 = bfi(M1, up2, up1);
+        dt2 = dt1;
+        if (TWO) dt2 = bfi(M2, up2, up1);
+        if (VIRT) { dt1 = bfi(V1, colAbove, dt1); dt2 = bfi(V2, colAbove, dt2); }
+        uint32_t vcS = colS0;                                          // column 0 at this lane's rows, top down
+        static_for<R>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          uint32_t c1S = NEAR ? Sa[k] : bfi(M1, Sb[k], Sa[k]), c1E = NEAR ? Ea[k] : bfi(M1, Eb[k], Ea[k]);
+          uint32_t insX = c1E, dmax = dt1, c2S = c1S;
+          if (VIRT) {
+            if (k > 0) vcS = pk_subk(vcS, KEXT);
+            c1S = bfi(V1, vcS, c1S);
+            c1E = bfi(V1, pk_subk(vcS, KEXT), c1E);
+            insX = c1E;
+          }
+          if (TWO) {
+            c2S = bfi(M2, Sb[k], Sa[k]);
+            uint32_t c2E = bfi(M2, Eb[k], Ea[k]);
+            if (VIRT) { c2S = bfi(V2, vcS, c2S); c2E = bfi(V2, pk_subk(vcS, KEXT), c2E); }
+            insX = pk_max(c1E, c2E);                                // first maximum wins (:361-371)
+            dmax = pk_max(dt1, dt2);                                // (:348-357)
+          }
+          uint32_t Sn, En, mbit;
+          pk_row<2 * k>(xlp, ylp[k], insX, insY, dmax, ONES, KSUB, KEXT, KDELTA, Sn, En, mbit, mvw);
+          if (TWO) {
+            const uint32_t pm = pk_bit(pk_sub(dmax, dt1), ONES);   // second predecessor strictly better on the diagonal
+            const uint32_t px = pk_bit(pk_sub(insX, c1E), ONES);   // ... for the x-insertion
+            secw |= bfi(pk_sub(0u, mbit), pm, px) << k;
+            pin(secw);
+          }
+          dt1 = c1S; dt2 = c2S;
+          Sb[k] = Sn; Eb[k] = En; insY = En;
+        });
+        if (a.debug & 4) { ++n_steps; n_two += TWO && !VIRT; n_virt += VIRT; }
+        if (TWO) {
           if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
           if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
         }
+      };
+      // debug bit 1024: never the plain-chain form (A/B)
+      if (!(a.debug & 1024) && __builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1)) != 0u) == 0)
+        variant(std::true_type{}, std::false_type{}, std::false_type{});
+      else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2)) != 0u) == 0)
+        variant(std::false_type{}, std::false_type{}, std::false_type{});
+      else if (__builtin_amdgcn_ballot_w64((xor_ & kN_Virt1) != 0u) == 0)
+        variant(std::false_type{}, std::true_type{}, std::false_type{});
+      else
+        variant(std::false_type{}, std::true_type{}, std::true_type{});
+      if (active) {
+        BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
+        mv[t * 64 + lane] = mvw;                                     // every lane: a lane past its window's end writes a word nobody reads
         if (((xiA & finA_bit) | (xiB & finB_bit)) != 0u) {
           const bool finA = (xiA & finA_bit) != 0u, finB = (xiB & finB_bit) != 0u;
 #pragma unroll
