@@ -840,17 +840,19 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
           const int k = kb + g + u * G;
           v[h][u] = 4 * k < mis[h] + ntot[h] ? src4[h][k] : 0u;       // d_sym is padded: the last dword may reach past the window
         }
+      // Dword k holds the string's bytes i0 .. i0 + 3: reference + corrected live in U, the uncorrected string in
+      // us.  Whole (unaligned) dwords are stored; the one that straddles the border goes to both places.  Bytes
+      // that fall outside a region land in its slack -- the slot's 16-byte header in front of us, the node
+      // records' guards either side, the map area behind the strings in U -- all of which is written later.
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           const int k = kb + g + u * G;
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int i = 4 * k + b - mis[h];
-            const uint8_t ch = (uint8_t)(v[h][u] >> (8 * b));
-            if (i >= 0 && i < nrc[h]) U[h][i] = ch;
-            else if (i >= nrc[h] && i < ntot[h]) us[h][i - nrc[h]] = ch;
+          const int i0 = 4 * k - mis[h];
+          if (i0 < ntot[h]) {
+            if (i0 < nrc[h]) __builtin_memcpy(U[h] + i0, &v[h][u], 4);
+            if (i0 + 3 >= nrc[h]) __builtin_memcpy(us[h] + (i0 - nrc[h]), &v[h][u], 4);
           }
         }
     }
