@@ -922,21 +922,17 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
       xb_next = xsB[med3(jj, 0, lastB)];
       if (!FIRST || jj >= 1) {                                     // (past its window's last column a lane computes on: nobody reads it)
         uint32_t diag = dg0, insY = upE, mvw = 0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
+        static_for<R>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
           const uint32_t oldS = S[k];
-          const uint32_t ne = pk_bit(xlp ^ ylp[k], ONES);
-          const uint32_t mat = pk_mad(ne, KSUB, diag);
-          const uint32_t mx = pk_max(E[k], insY);
-          const uint32_t Sn = pk_max(mat, mx);
-          const uint32_t mbit = pk_bit(pk_sub(Sn, mx), ONES);          // match strictly best (align_lpo_po2.c:384)
-          const uint32_t xbit = pk_bit(pk_sub(mx, insY), ONES);        // x-insertion strictly above y-insertion (:392)
-          mvw |= ((mbit << 1) | xbit) << (2 * k);
-          pin(mvw);
+          // move bits: match strictly best (align_lpo_po2.c:384), x-insertion strictly above y-insertion (:392);
+          // En = Sn - (match ? open : ext)
+          uint32_t Sn, En, mbit;
+          pk_row<2 * k>(xlp, ylp[k], E[k], insY, diag, ONES, KSUB, KEXT, KDELTA, Sn, En, mbit, mvw);
           S[k] = Sn;
-          E[k] = pk_mad(mbit, KDELTA, pk_subk(Sn, KEXT));              // Sn - (match ? open : ext)
-          diag = oldS; insY = E[k];
-        }
+          E[k] = En;
+          diag = oldS; insY = En;
+        });
         dg0 = upS;
         mv[t * 64 + lane] = mvw;
         // the alignment's score: last column, last row -- the lane that holds that row watches for its column
