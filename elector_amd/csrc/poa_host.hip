@@ -829,6 +829,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const int n_chains = c->chains > 0 ? c->chains
                        : std::getenv("ELECTOR_CHAINS") ? std::max(1, std::min(4, std::atoi(std::getenv("ELECTOR_CHAINS")))) : 2;
   std::vector<int> bin_stream((size_t)kBins, 0), bin_order;
+  int n_used = n_chains;                               // auxiliary streams that carry launch chains
   {
     auto group_of = [&](int b) { const int G = kClsG[b / kNT]; return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };
     int64_t gwork[4] = {0, 0, 0, 0};
@@ -857,6 +858,17 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         bin_stream[(size_t)b] = (deal && (n_chains == 2 || n_chains == 3)) ? (turn++ % n_chains) : chain_of_group[group_of(b)];
         bin_order.push_back(b);
       }
+    // ELECTOR_CHAINS_SMALL=<waves> (experiment): with two chains, the launches of fewer wavefronts than that -- long
+    // windows, a few hundred wavefronts that live long and leave the chip nearly empty -- form a third chain, so
+    // that they run beside the large launches from the start instead of one after the other at the chains' ends
+    static const int small_waves = std::getenv("ELECTOR_CHAINS_SMALL") ? std::atoi(std::getenv("ELECTOR_CHAINS_SMALL")) : 0;
+    if (n_chains == 2 && small_waves > 0 && use_pack) {
+      for (int b = 0; b < kBins; ++b) {
+        if (!bin_cnt[(size_t)b]) continue;
+        const int64_t waves = bin_cnt[(size_t)b] / (2 * (64 / kClsG[b / kNT])) + 1;
+        if (waves < small_waves) { bin_stream[(size_t)b] = 2; n_used = 3; }
+      }
+    }
     if (std::getenv("ELECTOR_DEBUG_BINS"))
       std::fprintf(stderr, "[elector] chains: G64->%d G32->%d G16->%d G8->%d (work %lld %lld %lld %lld)\n", chain_of_group[0],
                    chain_of_group[1], chain_of_group[2], chain_of_group[3], (long long)gwork[0], (long long)gwork[1],
@@ -1056,7 +1068,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // ---- fused classes: launch chains on the auxiliary streams (A then B of each bin) ----
   if (use_fused && n > n_generic) {
     HIPCHK(c, hipEventRecord(c->fork, st));
-    const int used = n_chains;                         // launch chains = auxiliary streams in use
+    const int used = n_used;                           // launch chains = auxiliary streams in use
     for (int k = 0; k < used; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
     if (use_pack && used <= 3) HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->fork, 0));
     // ELECTOR_LAUNCH_ORDER=ab (experiment): per stream all alignment #1 launches first, then all #2
