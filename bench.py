@@ -96,9 +96,63 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(windows, ref_bases_per_window, seconds):
+def compare_with_reference(path, lo, hi, off, cols, ncol):
+    """The file one reference `poa` process wrote for the windows [lo, hi) (lpo_format.c:398-426: per window
+    `>name title` + row, three times, reference / corrected / uncorrected) against the device's column-interleaved
+    MSA of the same windows.  -> number of windows whose header lines, row lengths or row bytes differ."""
+    import numpy as np
+    try:
+        data = np.fromfile(path, dtype=np.uint8)
+    except OSError:
+        return hi - lo
+    nl = np.flatnonzero(data == 10)
+    nw = hi - lo
+    if len(nl) != 6 * nw:
+        return nw
+    starts = np.concatenate([[0], nl[:-1] + 1]).reshape(nw, 6)
+    ends = nl.reshape(nw, 6)
+    nc = ncol[lo:hi].astype(np.int64)
+    bad = np.zeros(nw, dtype=bool)
+    for r in range(3):
+        bad |= (ends[:, 2 * r + 1] - starts[:, 2 * r + 1]) != nc
+    # header lines: `>w<index> untitled` three times (fasta_format.c:33-37)
+    hdr = b"".join(b">w%d untitled" % w for w in range(lo, hi))
+    hlen = np.fromiter((len(b">w%d untitled" % w) for w in range(lo, hi)), dtype=np.int64, count=nw)
+    hoff = np.cumsum(hlen) - hlen
+    hb = np.frombuffer(hdr, dtype=np.uint8)
+    for r in range(3):
+        bad |= (ends[:, 2 * r] - starts[:, 2 * r]) != hlen
+    ok = np.flatnonzero(~bad)
+    if len(ok):
+        n_ok = nc[ok]
+        tot = int(n_ok.sum())
+        first = np.cumsum(n_ok) - n_ok
+        c = np.arange(tot, dtype=np.int64) - np.repeat(first, n_ok)          # column within its window
+        wrep = np.repeat(np.arange(len(ok)), n_ok)
+        dev_at = np.repeat(3 * off[3 * (lo + ok)], n_ok) + 3 * c
+        differs = np.zeros(len(ok), dtype=np.int64)
+        for r in range(3):
+            ref_at = np.repeat(starts[ok, 2 * r + 1], n_ok) + c
+            np.add.at(differs, wrep[data[ref_at] != cols[dev_at + r]], 1)
+        hl = hlen[ok]
+        htot = int(hl.sum())
+        hfirst = np.cumsum(hl) - hl
+        hc = np.arange(htot, dtype=np.int64) - np.repeat(hfirst, hl)
+        hrep = np.repeat(np.arange(len(ok)), hl)
+        want = hb[np.repeat(hoff[ok], hl) + hc]
+        for r in range(3):
+            np.add.at(differs, hrep[data[np.repeat(starts[ok, 2 * r], hl) + hc] != want], 1)
+        bad[ok[differs > 0]] = True
+    return int(bad.sum())
+
+
+def cpu_baseline(windows, ref_bases_per_window, seconds, device_msa=None):
     """Reference poaV2 (or the oracle port) on this host's cores over a bounded
-    sample of the same window stream.  Test infrastructure: uses oracle/."""
+    sample of the same window stream.  Test infrastructure: uses oracle/.
+
+    device_msa = (cols uint8, ncol): the column-interleaved MSA the timed kernels left in HBM for this very batch,
+    brought to the host.  Every window the reference binary aligned is then compared with it byte by byte
+    -> second return value {"windows": compared, "differing": d} (None without the reference binary)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -137,10 +191,22 @@ def cpu_baseline(windows, ref_bases_per_window, seconds):
             for p in procs:
                 p.wait()
             dt = time.perf_counter() - t0
+            parity = None
+            if device_msa is not None:
+                # after the clock: what the reference just wrote against what the timed kernels wrote
+                from concurrent.futures import ThreadPoolExecutor
+                cols, ncol = device_msa
+                spans = [(os.path.join(d, "smsa%d" % p), p * per, min(ns, (p + 1) * per)) for p in range(len(cmds))]
+                with ThreadPoolExecutor(max_workers=min(32, ncores)) as ex:
+                    bad = list(ex.map(lambda a: compare_with_reference(a[0], a[1], a[2], off, cols, ncol), spans))
+                parity = {"windows": ns, "differing": int(sum(bad)),
+                          "against": "reference poa (oracle/_ref/poa built from the reference's sources), every window of "
+                                     "the %s: header lines and the three rows, byte by byte"
+                                     % ("timed batch" if ns == nwin else "sample")}
         nb = float(cum[ns - 1])
         return {"value": round(nb / dt / 1e6, 4), "unit": "Mbases/s", "cores": len(cmds), "kind": "reference",
                 "sample": "%d windows (%d reference bases) of the step's window stream, one reference poa "
-                          "process per core as elector/alignment.py's Pool does, wall %.2f s" % (ns, int(nb), dt)}
+                          "process per core as elector/alignment.py's Pool does, wall %.2f s" % (ns, int(nb), dt)}, parity
     # port: single-threaded C oracle
     target_bases = 0.4e6 * seconds
     cum = np.cumsum(ref_bases_per_window)
@@ -150,7 +216,7 @@ def cpu_baseline(windows, ref_bases_per_window, seconds):
     dt = time.perf_counter() - t0
     nb = float(cum[ns - 1])
     return {"value": round(nb / dt / 1e6, 4), "unit": "Mbases/s", "cores": 1, "kind": "port",
-            "sample": "%d windows (%d reference bases), oracle/poa_oracle.c single thread, wall %.2f s" % (ns, int(nb), dt)}
+            "sample": "%d windows (%d reference bases), oracle/poa_oracle.c single thread, wall %.2f s" % (ns, int(nb), dt)}, None
 
 
 def pmc_file(profile, reads):
@@ -345,6 +411,13 @@ def main():
     dt = time.perf_counter() - t0
     host_ms_per_step = host_s[0] / args.steps * 1e3
 
+    # the MSA the timed kernels wrote (context 0's last timed step), for the every-window comparison with the
+    # reference binary behind the clock
+    cols_timed = ncol_timed = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cols_timed = outs[0][0].cpu().numpy()
+        ncol_timed = outs[0][1].cpu().numpy()
+    exit_code = 0
     # ---- after the clock: serial pass for the per-kernel roofline, checks, counters, gather -----------
     serial_steps = args.steps if args.serial else max(1, args.serial_steps)
     serial_wall = dt / args.steps
@@ -456,13 +529,23 @@ def main():
             "pieces_gathered": int(counters.shape[0]),
             "counters_checksum": int(counters[:, :ES_NCOUNTERS - 1].sum()),
         }
+        parity = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(win, lr, args.cpu_seconds)
+            # the MSA columns of the batch the timed region worked on, as the last timed step of context 0 left them
+            out["cpu_baseline"], parity = cpu_baseline(win, lr, args.cpu_seconds, (cols_timed, ncol_timed))
+            if parity is not None:
+                out["parity_vs_reference"] = parity
         print(json.dumps(out), flush=True)
+        if parity is not None and parity["differing"]:
+            sys.stderr.write("bench.py: %d of %d windows differ from the reference poa's output\n"
+                             % (parity["differing"], parity["windows"]))
+            exit_code = 1
     for g in engines:
         g.close()
     if world > 1:
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -229,20 +229,51 @@ class _Buffers:
             self.status = torch.empty(self.cap_win, dtype=torch.int32, device=self.dev)
 
 
-def _shard(reference, uncorrected, corrected, world):
+def _shard(reference, uncorrected, corrected, world, rank=0, dist=None, device=None):
     """Contiguous ranges of kept records per rank, cut at read boundaries and balanced by the DP cells the
-    reads will cost (elector_amd.distributed.read_cell_estimate).  One pass over the three files."""
+    reads will cost (elector_amd.distributed.read_cell_estimate).  ONE pass over the three files, in native code
+    (elector_reads_scan), on rank 0; the world + 1 bounds are broadcast."""
+    import torch
     from .distributed import read_cell_estimate, shard_bounds
-    keys, lr, lc, lu = [], [], [], []
-    for k, href, ref, cor, unc in _triples(reference, uncorrected, corrected):
-        keys.append(_donatello_header(_poa_header(href)))
-        lr.append(len(ref)); lc.append(len(cor)); lu.append(len(unc))
-    n = len(keys)
-    starts = [0] + [i for i in range(1, n) if keys[i] != keys[i - 1]] + [n]
-    w = read_cell_estimate(np.asarray(lr), np.asarray(lc), np.asarray(lu)) if n else np.zeros(0)
-    wr = np.add.reduceat(w, starts[:-1]) if n else np.zeros(0)
-    b = shard_bounds(wr, world)
-    return [int(starts[int(x)]) for x in b]
+    bounds = None
+    if rank == 0:
+        lr, lu, lc, fresh = split.scan_reads(reference, uncorrected, corrected)
+        n = len(lr)
+        starts = np.concatenate([np.nonzero(fresh)[0], [n]]).astype(np.int64) if n else np.zeros(1, dtype=np.int64)
+        wr = np.add.reduceat(read_cell_estimate(lr, lc, lu), starts[:-1]) if n else np.zeros(0)
+        bounds = starts[shard_bounds(wr, world)]
+    if dist is None or world == 1:
+        return [int(x) for x in bounds]
+    t = torch.zeros(world + 1, dtype=torch.int64, device=device)
+    if rank == 0:
+        t.copy_(torch.from_numpy(np.ascontiguousarray(bounds, dtype=np.int64)))
+    dist.broadcast(t, src=0)
+    return [int(x) for x in t.cpu().tolist()]
+
+
+def _append_file(out, path):
+    """the bytes of `path` appended to the open file `out` inside the kernel (copy_file_range / sendfile) where the
+    platform offers it"""
+    out.flush()
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        done = 0
+        try:
+            while done < size:
+                k = os.sendfile(out.fileno(), f.fileno(), done, min(size - done, 1 << 30))
+                if k <= 0:
+                    break
+                done += k
+        except OSError:
+            pass
+        if done < size:
+            f.seek(done)
+            while True:
+                chunk = f.read(1 << 24)
+                if not chunk:
+                    break
+                out.write(chunk)
+            out.flush()
 
 
 def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_READ_THRESHOLD, soft=None,
@@ -272,13 +303,16 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             rank, world = dist.get_rank(), dist.get_world_size()
     except ImportError:
         dist = None
+    dev = torch.device("cuda", engines[0].device)
+    cdev = dev if world > 1 and dist.get_backend() == "nccl" else torch.device("cpu")     # where collectives live
     start, stop = 0, None
     if world > 1:
-        bounds = _shard(reference, uncorrected, corrected, world)
+        bounds = _shard(reference, uncorrected, corrected, world, rank, dist, cdev)
         start, stop = bounds[rank], bounds[rank + 1]
+    # a rank's part of the output is a file of its own, written from scratch (a part left behind by an aborted run
+    # must not be appended to); rank 0 appends the parts to msa.fa in rank order, as Donatello appends
     part_path = mergeOut if world == 1 else mergeOut + ".part%d" % rank
 
-    dev = torch.device("cuda", engines[0].device)
     splitter = _get_splitter(engines[0].device)
     bufs = [_Buffers(dev) for _ in engines]
     work = queue.Queue(maxsize=2)
@@ -289,19 +323,30 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     # per buffer set, given back when the splitter is done with a batch.
     parsed = queue.Queue(maxsize=2)
     permits = threading.Semaphore(2)
+    stop_all = threading.Event()                   # set when the main thread gives up: both threads wind down
+
+    def put(q, item):
+        """q.put that gives up when the run is being abandoned"""
+        while not stop_all.is_set():
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def parser():
         import time
         try:
             rf = split.ReadsFile(reference, uncorrected, corrected)
             try:
-                while True:
-                    permits.acquire()
+                while not stop_all.is_set():
+                    if not permits.acquire(timeout=0.2):
+                        continue
                     t0 = time.perf_counter()
                     rb = rf.next(READS_PER_BATCH, start, stop)
                     _tick("parse FASTA (parser thread, native)", t0)
-                    parsed.put(rb)
-                    if rb is None:
+                    if not put(parsed, rb) or rb is None:
                         break
                 # the last batches may still be in use: the file stays open until the splitter is through
                 splitter_done.wait()
@@ -309,23 +354,27 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
                 rf.close()
         except BaseException as e:           # noqa: BLE001 -- handed to the main thread
             failure.append(e)
-            parsed.put(None)
+            put(parsed, None)
 
     splitter_done = threading.Event()
 
     def reader():
         try:
-            while True:
-                rb = parsed.get()
+            while not stop_all.is_set():
+                try:
+                    rb = parsed.get(timeout=0.2)
+                except queue.Empty:
+                    continue
                 if rb is None or failure:
                     break
-                work.put(_prepare(rb, SIZE_CORRECTED_READ_THRESHOLD, threads, splitter))
+                if not put(work, _prepare(rb, SIZE_CORRECTED_READ_THRESHOLD, threads, splitter)):
+                    break
                 permits.release()
         except BaseException as e:           # noqa: BLE001 -- handed to the main thread
             failure.append(e)
         splitter_done.set()
         permits.release()
-        work.put(None)
+        put(work, None)
 
     tp = threading.Thread(target=parser, daemon=True)
     tp.start()
@@ -334,7 +383,9 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
 
     small_reads = wrongly_cor_reads = 0
     skipped = 0
-    existed = os.path.exists(part_path) and os.path.getsize(part_path) > 0
+    # records already in the output file (append semantics, Donatello.cpp:48) are not this run's: call site #2
+    # then parses the whole file instead of taking this run's device counters
+    existed = os.path.exists(mergeOut) and os.path.getsize(mergeOut) > 0
     all_hdr, all_cols, all_counters, all_read_first = [], [], [], [0]
     last_rows = last_mask = None
     cache_ok = not existed
@@ -380,51 +431,60 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
         sys.stdout.flush()
 
     turn = 0
-    with open(part_path, "ab") as out:
-        while True:
-            b = work.get()
-            if failure:
-                raise failure[0]
-            if b is None:
-                break
-            small_reads += b.small
-            wrongly_cor_reads += b.wrong
-            win = b.win
-            if win.n_windows == 0:
-                continue
-            e = turn % len(engines)
-            turn += 1
-            # one job per context at a time: its buffers and its statistics slot are busy until collected
-            while any(p[0] == e for p in pending):
+    try:
+        with open(part_path, "ab" if world == 1 else "wb") as out:
+            while True:
+                b = work.get()
+                if failure:
+                    raise failure[0]
+                if b is None:
+                    break
+                small_reads += b.small
+                wrongly_cor_reads += b.wrong
+                win = b.win
+                if win.n_windows == 0:
+                    continue
+                e = turn % len(engines)
+                turn += 1
+                # one job per context at a time: its buffers and its statistics slot are busy until collected
+                while any(p[0] == e for p in pending):
+                    finish(out)
+                import time
+                buf = bufs[e]
+                total = int(win.off[-1])
+                t0 = time.perf_counter()
+                buf.fit(total, win.n_windows, own_bases=b.d_bases is None)
+                if b.d_bases is None:
+                    buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
+                    _tick("windows H2D", t0)
+                bases = buf.bases if b.d_bases is None else b.d_bases
+                buf.held = bases                       # the batch's own tensor lives until the context's next batch
+                t0 = time.perf_counter()
+                engines[e].align_device(bases, win.off, buf.cols, buf.ncol, buf.status)
+                npieces = engines[e].msa_stats_enqueue(win.n_windows, buf.cols, buf.ncol, buf.status, b.piece_first,
+                                                       b.read_first)
+                _tick("classify + enqueue kernels (host)", t0)
+                # rows + mask of the batch's last read, for the homopolymer ratio of the run's last read
+                p0 = int(b.read_first[-2])
+                w0 = int(b.piece_first[p0])
+                last_cap = int(win.off[-1] - win.off[3 * w0]) + 16
+                pending.append((e, b, npieces, last_cap))
+                # while the splitter is still busy with the next batch, the oldest jobs' records go to the file
+                # (their kernels are short against a split); otherwise every write would wait for the end
+                while pending and work.empty():
+                    finish(out)
+            while pending:
                 finish(out)
-            import time
-            buf = bufs[e]
-            total = int(win.off[-1])
-            t0 = time.perf_counter()
-            buf.fit(total, win.n_windows, own_bases=b.d_bases is None)
-            if b.d_bases is None:
-                buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
-                _tick("windows H2D", t0)
-            bases = buf.bases if b.d_bases is None else b.d_bases
-            buf.held = bases                       # the batch's own tensor lives until the context's next batch
-            t0 = time.perf_counter()
-            engines[e].align_device(bases, win.off, buf.cols, buf.ncol, buf.status)
-            npieces = engines[e].msa_stats_enqueue(win.n_windows, buf.cols, buf.ncol, buf.status, b.piece_first,
-                                                   b.read_first)
-            _tick("classify + enqueue kernels (host)", t0)
-            # rows + mask of the batch's last read, for the homopolymer ratio of the run's last read
-            p0 = int(b.read_first[-2])
-            w0 = int(b.piece_first[p0])
-            last_cap = int(win.off[-1] - win.off[3 * w0]) + 16
-            pending.append((e, b, npieces, last_cap))
-            # while the splitter is still busy with the next batch, the oldest jobs' records go to the file
-            # (their kernels are short against a split); otherwise every write would wait for the end
-            while pending and work.empty():
-                finish(out)
-        while pending:
-            finish(out)
-    th.join()
-    tp.join()
+    finally:
+        # whatever happened, the two threads end and give their buffers, files and device memory back
+        stop_all.set()
+        th.join()
+        tp.join()
+        for e, *_ in pending:
+            try:
+                engines[e].sync()
+            except ElectorError:
+                pass
     if failure:
         raise failure[0]
     if skipped:
@@ -433,32 +493,26 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     counters = np.concatenate(all_counters) if all_counters else np.zeros((0, ES_NCOUNTERS), dtype=np.int64)
     piece_cols = np.concatenate(all_cols) if all_cols else np.zeros(0, dtype=np.int64)
     if world > 1:
-        # one gather of integer counters to rank 0; msa.fa = the ranks' parts in rank order
+        # one gather of integer counters to rank 0; msa.fa = what it held + the ranks' parts in rank order
         from .distributed import gather_rows
         meta = np.concatenate([counters, piece_cols[:, None]], axis=1) if len(piece_cols) else \
             np.zeros((0, ES_NCOUNTERS + 1), dtype=np.int64)
         meta = gather_rows(meta)
-        tot = torch.tensor([small_reads, wrongly_cor_reads], dtype=torch.int64,
-                           device=dev if dist.get_backend() == "nccl" else "cpu")
+        tot = torch.tensor([small_reads, wrongly_cor_reads], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         small_reads, wrongly_cor_reads = int(tot[0]), int(tot[1])
-        hdr_all = [None] * world
-        dist.all_gather_object(hdr_all, (all_hdr, all_read_first, cache_ok,
-                                         None if last_rows is None else (last_rows.tobytes(), last_mask.tobytes())))
-        dist.barrier()
+        mine = (all_hdr, all_read_first, cache_ok,
+                None if last_rows is None else (last_rows.tobytes(), last_mask.tobytes()))
+        hdr_all = [None] * world if rank == 0 else None
+        dist.gather_object(mine, hdr_all, dst=0)          # every part is on disk before rank 0 goes on
         if rank == 0:
             with open(mergeOut, "ab") as out:
                 for r in range(world):
                     part = mergeOut + ".part%d" % r
-                    with open(part, "rb") as f:
-                        while True:
-                            chunk = f.read(1 << 24)
-                            if not chunk:
-                                break
-                            out.write(chunk)
+                    _append_file(out, part)
                     os.remove(part)
             counters, piece_cols = meta[:, :ES_NCOUNTERS], meta[:, ES_NCOUNTERS]
-            all_hdr, all_read_first, cache_ok = [], [0], not existed
+            all_hdr, all_read_first = [], [0]
             for hs, rf, ok, lr in hdr_all:
                 base = all_read_first[-1]
                 all_hdr.extend(hs)

@@ -270,6 +270,68 @@ extern "C" int elector_reads_next(void *handle, int64_t min_records, int64_t sta
   return ELECTOR_OK;
 }
 
+// One pass over the three files for the multi-GPU shard bounds (elector_amd/alignment.py: rank 0 scans, the bounds
+// are broadcast): per kept record the three sequence lengths and whether its msa.fa header line differs from the
+// previous record's (= a new read).  Nothing but the reference's header lines is copied.
+namespace {
+struct CountBuf {                      // a sink that only measures
+  size_t n = 0;
+  bool append(const char *, size_t len) { n += len; return true; }
+};
+struct StrBuf {
+  std::string s;
+  bool append(const char *a, size_t len) { s.append(a, len); return true; }
+};
+}  // namespace
+
+extern "C" int elector_reads_scan(const char *reference, const char *uncorrected, const char *corrected, elector_reads_index *out)
+{
+  if (!reference || !uncorrected || !corrected || !out) return ELECTOR_E_INVAL;
+  std::memset(out, 0, sizeof *out);
+  LineFile ref, unc, cor;
+  if (!ref.open(reference) || !unc.open(uncorrected) || !cor.open(corrected)) {
+    ref.close(); unc.close(); cor.close();
+    return ELECTOR_E_INVAL;
+  }
+  std::vector<int64_t> len;
+  std::vector<uint8_t> fresh;
+  StrBuf hdr;
+  std::string key, last;
+  bool first = true;
+  for (;;) {
+    hdr.s.clear();
+    if (!ref.append_line(hdr)) break;
+    CountBuf r, u, c;
+    ref.append_line(r);
+    // the other two files advance by one record whether the reference record is kept or not (Master_Splitter.cpp:407-414)
+    if (!unc.skip_line()) break;
+    unc.append_line(u);
+    if (!cor.skip_line()) break;
+    cor.append_line(c);
+    if (r.n <= 2) continue;
+    record_key(hdr.s, key);
+    len.push_back((int64_t)r.n); len.push_back((int64_t)u.n); len.push_back((int64_t)c.n);
+    fresh.push_back(first || key != last ? 1 : 0);
+    first = false;
+    last.swap(key);
+  }
+  ref.close(); unc.close(); cor.close();
+  const size_t n = fresh.size();
+  out->n = (int64_t)n;
+  out->len = static_cast<int64_t *>(std::malloc(std::max<size_t>(1, 3 * n) * sizeof(int64_t)));
+  out->new_read = static_cast<uint8_t *>(std::malloc(std::max<size_t>(1, n)));
+  if (!out->len || !out->new_read) { std::free(out->len); std::free(out->new_read); std::memset(out, 0, sizeof *out); return ELECTOR_E_NOMEM; }
+  if (n) { std::memcpy(out->len, len.data(), 3 * n * sizeof(int64_t)); std::memcpy(out->new_read, fresh.data(), n); }
+  return ELECTOR_OK;
+}
+
+extern "C" void elector_reads_index_free(elector_reads_index *ix)
+{
+  if (!ix) return;
+  std::free(ix->len); std::free(ix->new_read);
+  std::memset(ix, 0, sizeof *ix);
+}
+
 // bytes of the records of the pieces that are not dropped
 static int64_t records_bytes(int64_t n, const int64_t *cols, const int64_t *hdr_off, const uint8_t *drop)
 {

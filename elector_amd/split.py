@@ -36,6 +36,10 @@ class ElectorReads(C.Structure):
                 ("hdr", C.POINTER(C.c_uint8)), ("hdr_off", C.POINTER(C.c_int64))]
 
 
+class ElectorReadsIndex(C.Structure):
+    _fields_ = [("n", C.c_int64), ("len", C.POINTER(C.c_int64)), ("new_read", C.POINTER(C.c_uint8))]
+
+
 class ElectorMsa(C.Structure):
     _fields_ = [
         ("n_reads", C.c_int64), ("rows", C.POINTER(C.c_uint8)),
@@ -64,6 +68,9 @@ def _lib():
         L.elector_reads_next.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(ElectorReads)]
         L.elector_reads_close.argtypes = [C.c_void_p]
         L.elector_reads_close.restype = None
+        L.elector_reads_scan.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(ElectorReadsIndex)]
+        L.elector_reads_index_free.argtypes = [C.POINTER(ElectorReadsIndex)]
+        L.elector_reads_index_free.restype = None
         L.elector_msa_format.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int64, C.c_int]
         L.elector_msa_format.restype = C.c_int64
@@ -260,6 +267,23 @@ class ReadsFile:
             self.close()
         except Exception:       # noqa: BLE001 -- interpreter shutdown
             pass
+
+
+def scan_reads(reference, uncorrected, corrected):
+    """One native pass over the three files (include/elector_split.h: elector_reads_scan) -> (lr, lu, lc, new_read):
+    per kept record its three sequence lengths and whether it opens a new read (its msa.fa header line differs
+    from the previous record's)."""
+    L = _lib()
+    ix = ElectorReadsIndex()
+    rc = L.elector_reads_scan(os.fsencode(reference), os.fsencode(uncorrected), os.fsencode(corrected), C.byref(ix))
+    if rc:
+        raise ElectorError(rc, "cannot scan the read files")
+    try:
+        n = int(ix.n)
+        lens = _np(ix.len, 3 * n, np.int64).reshape(n, 3)
+        return lens[:, 0], lens[:, 1], lens[:, 2], _np(ix.new_read, n, np.uint8).astype(bool)
+    finally:
+        L.elector_reads_index_free(C.byref(ix))
 
 
 def msa_format(rows, piece_cols, headers, drop=None, nthreads=1):

@@ -21,6 +21,13 @@ ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 # shapes: full = the corrector returns the whole read; trim = one or both ends missing; split = 2-3
 # pieces with uncorrected stretches between them dropped; ext = extended beyond the reference's ends.
 PROFILES = {
+    # configs[0]: the bundled E. coli ~10X example restated (the example's own inputs are
+    # absent from the checkout): 459 reads, mean 9.5 kb, uncorrected 10.3 % with insertions : deletions :
+    # substitutions = 1:1:1, corrected 0.6 %, 8 % of the reads trimmed or split -- plus what the README's log of
+    # that run shows beside them (README.md:136-160): a few reads extended by the corrector and a few corrected
+    # reads shorter than a tenth of their reference (the splitter's "small reads")
+    "ecoli10x_c1": dict(mean=9500, sd=0.20, length="normal", eu=0.103, su=(1 / 3, 1 / 3, 1 / 3),
+                        ec=0.006, sc=(1 / 3, 1 / 3, 1 / 3), shapes=dict(full=0.87, trim=0.04, split=0.04, ext=0.01, small=0.04)),
     # configs[1]: E. coli 30X SimLord PacBio 15 % error (-pi .22 -pd .08 -ps .01 shares), LoRDEC-like 1 %
     "ecoli30x_simlord_lordec": dict(mean=8000, sd=0.20, length="normal", eu=0.15, su=(0.01 / 0.31, 0.22 / 0.31, 0.08 / 0.31),
                                     ec=0.01, sc=(0.3, 0.4, 0.3), shapes=dict(full=1.0)),
@@ -93,6 +100,10 @@ def _pieces(rng, cor, shape):
                 out.append(cor[start:end])
             start = int(c)
         return out or [cor]
+    if shape == "small":                                     # a stub of 2-8 % of the read: below SIZE_CORRECTED_READ_THRESHOLD
+        m = max(12, int(n * rng.uniform(0.02, 0.08)))
+        a = int(rng.integers(0, max(1, n - m)))
+        return [cor[a:a + m]]
     if shape == "ext":
         left = rng.integers(0, 4, size=int(rng.integers(25, 120))).astype(np.uint8)
         right = rng.integers(0, 4, size=int(rng.integers(0, 120))).astype(np.uint8)

@@ -92,6 +92,19 @@ int  elector_reads_open(const char *reference, const char *uncorrected, const ch
 int  elector_reads_next(void *handle, int64_t min_records, int64_t start, int64_t stop, elector_reads *out);
 void elector_reads_close(void *handle);
 
+/* One pass over the same three files without keeping the sequences: per kept record (same skipping rule as
+ * elector_reads_next) the lengths of its reference, uncorrected and corrected sequence and whether its msa.fa header
+ * line differs from the previous kept record's (a new read).  What a multi-GPU run needs to cut the records into
+ * per-rank ranges at read boundaries (elector/alignment.py:117-119 is the fan-out this replaces): one rank scans,
+ * the bounds are broadcast.  Arrays are malloc'd; elector_reads_index_free releases them. */
+typedef struct elector_reads_index {
+  int64_t n;
+  int64_t *len;          /* 3n: reference, uncorrected, corrected */
+  uint8_t *new_read;     /*  n */
+} elector_reads_index;
+int  elector_reads_scan(const char *reference, const char *uncorrected, const char *corrected, elector_reads_index *out);
+void elector_reads_index_free(elector_reads_index *ix);
+
 /* Donatello's records (Donatello.cpp:61-93): per piece "header\nrow\n" three times (reference, corrected,
  * uncorrected row; rows = per piece the three rows of piece_cols[p] bytes back to back).  out == NULL returns the
  * size; pieces with drop[p] != 0 (drop may be NULL) are left out.  Returns the bytes written or a negative code. */

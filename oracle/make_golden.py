@@ -283,9 +283,9 @@ def make_pipeline_golden():
     json.dump(edges, open(os.path.join(GOLD, "pipeline_edges.json"), "w"), indent=0)
 
 
-def run_reference_chain(reads, d):
+def run_reference_chain(reads, d, jobs=1):
     """[(header, ref, cor, unc)] -> (msa.fa text, small, wrong) through the real masterSplitter / poa / Donatello
-    exactly as elector/alignment.py:98-122 drives them."""
+    exactly as elector/alignment.py:98-122 drives them (jobs = the Pool's width there)."""
     for fn, k in (("ref.fa", 1), ("cor.fa", 2), ("unc.fa", 3)):
         with open(os.path.join(d, fn), "wb") as f:
             for r in reads:
@@ -299,13 +299,19 @@ def run_reference_chain(reads, d):
                             stdout=subprocess.DEVNULL).returncode
         small += int(open(d + "/small_reads.txt").readline())
         wrong += int(open(d + "/wrongly_cor_reads.txt").readline())
+        running = []
         for i in range(200):
             if os.stat(d + "/out3%d" % i).st_size != 0:
-                subprocess.run([os.path.join(REF, "poa"), "-pir", d + "/smsa%d" % i, "-preserve_seqorder",
-                                "-corrected_reads_fasta", d + "/out3%d" % i, "-reference_reads_fasta",
-                                d + "/out1%d" % i, "-uncorrected_reads_fasta", d + "/out2%d" % i,
-                                "-preserve_seqorder", "-threads", "1", "-pathMatrix", MATRIX],
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                running.append(subprocess.Popen(
+                    [os.path.join(REF, "poa"), "-pir", d + "/smsa%d" % i, "-preserve_seqorder",
+                     "-corrected_reads_fasta", d + "/out3%d" % i, "-reference_reads_fasta",
+                     d + "/out1%d" % i, "-uncorrected_reads_fasta", d + "/out2%d" % i,
+                     "-preserve_seqorder", "-threads", "1", "-pathMatrix", MATRIX],
+                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+                while len(running) >= jobs:
+                    running.pop(0).wait()
+        for p in running:
+            p.wait()
         for i in range(200):
             subprocess.run([os.path.join(REF, "Donatello"), d + "/smsa%d" % i, msa])
         for f in os.listdir(d):
@@ -316,3 +322,38 @@ def run_reference_chain(reads, d):
 
 if __name__ == "__main__" and ("--pipeline-only" in sys.argv or len(sys.argv) == 1):
     make_pipeline_golden()
+
+
+def make_c1_golden():
+    """tests/golden/c1_chain.json: BASELINE config 1 restated (elector_amd/synthetic.py profile ecoli10x_c1, 459
+    reads regenerated from their seed on the GPU box) through the WHOLE real chain -- masterSplitter -> poa per
+    slot -> Donatello per slot (elector/alignment.py:98-122) -> the imported reference computeStats
+    (elector/__main__.py:141) -- digest and size of msa.fa, the two counters, the 19-tuple, stdout, the log text
+    and the two side files."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_import
+    from elector_amd import synthetic
+    profile, n_reads, seed = "ecoli10x_c1", 459, 1
+    triples, headers, read_of = synthetic.read_pieces(profile, n_reads, seed)
+    reads = [(h, r, c, u) for h, (r, c, u) in zip(headers, triples)]
+    with tempfile.TemporaryDirectory() as d:
+        msa_txt, small, wrong = run_reference_chain(reads, d, jobs=os.cpu_count() or 1)
+        digests = {fn: hashlib.sha256(open(os.path.join(d, fn), "rb").read()).hexdigest() for fn in ("ref.fa", "cor.fa", "unc.fa")}
+        tup, out, log = ref_import.run_reference(d + "/msa.fa", d + "/cor.fa", d, small, wrong)
+        per = open(d + "/per_read_metrics.txt").read()
+        sizes = open(d + "/read_size_distribution.txt").read()
+    gold = {"profile": profile, "n_reads": n_reads, "seed": seed, "n_pieces": len(reads), "inputs_sha256": digests,
+            "msa_sha256": hashlib.sha256(msa_txt.encode()).hexdigest(), "msa_bytes": len(msa_txt),
+            "msa_records": msa_txt.count(">") // 3, "small": small, "wrong": wrong,
+            "tuple": json.loads(json.dumps(tup)), "stdout": out, "log": log, "per_read": per,
+            "read_size_distribution_sha256": hashlib.sha256(sizes.encode()).hexdigest(),
+            "read_size_distribution_lines": sizes.count("\n")}
+    json.dump(gold, open(os.path.join(GOLD, "c1_chain.json"), "w"), indent=0)
+    print("c1 chain:", len(reads), "pieces ->", len(msa_txt), "bytes of msa.fa,", gold["msa_records"], "records, small", small,
+          "wrong", wrong)
+    print(out)
+
+
+if __name__ == "__main__" and ("--c1-only" in sys.argv or len(sys.argv) == 1):
+    make_c1_golden()

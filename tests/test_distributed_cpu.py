@@ -9,6 +9,7 @@ import tempfile
 import numpy as np
 import pytest
 import torch.multiprocessing as mp
+from portutil import free_port
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
@@ -65,7 +66,7 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     msa = str(tmp_path / "msa.fa")
     open(msa, "w").write(txt)
     res = str(tmp_path / "counters.npy")
-    mp.spawn(_worker, args=(2, 29517, msa, res), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, free_port(), msa, res), nprocs=2, join=True)
     got = np.load(res)
     pieces = cs.parse_msa(msa, cs.getSplit(msa))
     exp = _oracle_counter_fn(pieces)
@@ -96,7 +97,7 @@ def test_empty_shard_gathers(tmp_path):
     msa = str(tmp_path / "msa.fa")
     open(msa, "w").write(txt)
     res = str(tmp_path / "counters.npy")
-    mp.spawn(_worker, args=(2, 29519, msa, res), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, free_port(), msa, res), nprocs=2, join=True)
     got = np.load(res)
     pieces = cs.parse_msa(msa, cs.getSplit(msa))
     assert np.array_equal(got, _oracle_counter_fn(pieces))

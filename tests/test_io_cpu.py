@@ -118,3 +118,50 @@ def test_msa_format_matches_python():
         assert split.msa_format(rows, cols, hdrs, None, threads) == python(None)
         assert split.msa_format(rows, cols, hdrs, drop, threads) == python(drop)
     assert split.msa_format(np.zeros(0, np.uint8), np.zeros(0, np.int64), [], None, 2) == b""
+
+
+def _python_scan(paths):
+    lr, lu, lc, fresh, last = [], [], [], [], None
+    for k, href, ref, cor, unc in alignment._triples(paths[0], paths[1], paths[2]):
+        key = alignment._donatello_header(alignment._poa_header(href))
+        lr.append(len(ref)); lu.append(len(unc)); lc.append(len(cor))
+        fresh.append(key != last)
+        last = key
+    return lr, lu, lc, fresh
+
+
+def test_scan_matches_python(tmp_path):
+    """elector_reads_scan (the one native pass behind the multi-GPU shard bounds) against the Python record loop:
+    same kept records, same lengths, same read boundaries -- also on ragged files and missing final newlines."""
+    recs = _records(300, 91, True)
+    for k, (tn, dl) in enumerate((((True, True, True), (0, 0, 0)), ((False, False, False), (0, 0, 0)),
+                                  ((True, True, True), (0, 9, 0)), ((True, False, True), (0, 0, 31)),
+                                  ((True, True, True), (300, 0, 0)))):
+        d = tmp_path / ("s%d" % k)
+        d.mkdir()
+        paths = _write(d, recs, tn, dl)
+        lr, lu, lc, fresh = split.scan_reads(paths[0], paths[1], paths[2])
+        want = _python_scan(paths)
+        assert (lr.tolist(), lu.tolist(), lc.tolist(), fresh.tolist()) == (want[0], want[1], want[2], want[3]), k
+    with pytest.raises(Exception):
+        split.scan_reads(str(tmp_path / "nope.fa"), paths[1], paths[2])
+
+
+def test_shard_bounds_cut_at_read_boundaries(tmp_path):
+    """alignment._shard: contiguous record ranges, never inside a run of records with one header line, the empty
+    shard of a world larger than the number of reads, a read that outweighs all others"""
+    recs = [(b">big_0", (b"ACGT" * 5000, b"ACGT" * 5000, b"ACGT" * 5000))]
+    for i in range(6):
+        for j in range(1 + i % 3):
+            recs.append((b">r%d_%d" % (i, j), (b"ACGTA" * 40, b"ACGTA" * 40, b"ACGTA" * 40)))
+    paths = _write(tmp_path, recs)
+    _, _, _, fresh = split.scan_reads(paths[0], paths[1], paths[2])
+    read_starts = set(np.nonzero(fresh)[0].tolist()) | {len(recs)}
+    for world in (1, 2, 4, 8, 16):
+        b = alignment._shard(paths[0], paths[1], paths[2], world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == len(recs) and all(x <= y for x, y in zip(b, b[1:]))
+        assert set(b) <= read_starts
+        if world > 1:
+            assert (0, 1) in set(zip(b, b[1:]))                 # the dominant read is a shard of its own
+        if world == 16:
+            assert any(x == y for x, y in zip(b, b[1:]))        # more ranks than reads: some shard is empty

@@ -154,7 +154,7 @@ def test_getpoa_skip_mode(tmp_path, engine, capsys):
 
 
 def _rank_getpoa(rank, world, port, d, result):
-    """one rank of the two-rank getPOA: gloo rendezvous, both ranks on this box's GPU"""
+    """one rank of the multi-rank getPOA: gloo rendezvous, all ranks on this box's GPU"""
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -193,9 +193,72 @@ def test_getpoa_two_ranks_equal_one(tmp_path, engine, capsys):
                                              "sizes.txt", {})
     capsys.readouterr()
     res = str(tmp_path / "two.json")
-    mp.spawn(_rank_getpoa, args=(2, 29533, str(tmp_path), res), nprocs=2, join=True)
+    from portutil import free_port
+    mp.spawn(_rank_getpoa, args=(2, free_port(), str(tmp_path), res), nprocs=2, join=True)
     two = json.load(open(res))
     assert (tmp_path / "out2" / "msa.fa").read_bytes() == (tmp_path / "out1" / "msa.fa").read_bytes()
     assert not [f for f in os.listdir(tmp_path / "out2") if ".part" in f]
     assert (two["small"], two["wrong"]) == (small, wrong) and two["hit"]
     assert two["tuple"] == json.loads(json.dumps(tup)) and two["log"] == log.getvalue()
+
+
+def test_getpoa_two_ranks_into_a_used_directory(tmp_path, engine, capsys):
+    """Append semantics with several ranks (Donatello.cpp:48 appends): msa.fa already holds records and a part
+    file of an aborted run lies around.  The new records are appended once, the stale part is not copied, and
+    call site #2 reports on the WHOLE file (the device counters only cover this run's records)."""
+    import msa_gen
+    import torch.multiprocessing as mp
+    from portutil import free_port
+    reads = msa_gen.make_reads(95, 24, 800)
+    _write_reads(tmp_path, reads)
+    (tmp_path / "out1").mkdir()
+    (tmp_path / "out2").mkdir()
+    for _ in range(2):                                     # one process, run twice: the reference's own behaviour
+        small, wrong = alignment.getPOA(str(tmp_path / "cor.fa"), str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"), 8,
+                                        str(tmp_path / "out1"), 0.1, engine=engine)
+    computeStats._engine = engine
+    log = io.StringIO()
+    tup = computeStats.outputRecallPrecision(str(tmp_path / "cor.fa"), str(tmp_path / "out1"), log, small, wrong, 5, 0.1,
+                                             "sizes.txt", {})
+    capsys.readouterr()
+    once = (tmp_path / "out1" / "msa.fa").read_bytes()[: (tmp_path / "out1" / "msa.fa").stat().st_size // 2]
+    (tmp_path / "out2" / "msa.fa").write_bytes(once)
+    (tmp_path / "out2" / "msa.fa.part1").write_bytes(b">stale \nacgt\n>stale \nacgt\n>stale \nacgt\n")
+    res = str(tmp_path / "two.json")
+    mp.spawn(_rank_getpoa, args=(2, free_port(), str(tmp_path), res), nprocs=2, join=True)
+    two = json.load(open(res))
+    assert (tmp_path / "out2" / "msa.fa").read_bytes() == once + once == (tmp_path / "out1" / "msa.fa").read_bytes()
+    assert not [f for f in os.listdir(tmp_path / "out2") if ".part" in f]
+    assert not two["hit"]                                   # the file held foreign records: no counters from the cache
+    assert two["tuple"] == json.loads(json.dumps(tup)) and two["log"] == log.getvalue()
+
+
+def test_getpoa_four_ranks_empty_shard_and_dominant_read(tmp_path, engine, capsys):
+    """World size 4 with a read that outweighs all others together (a shard of its own, another rank's shard
+    empty) and a split read at a shard boundary: same msa.fa bytes, counters and report as a single process."""
+    import msa_gen
+    import numpy as np
+    import synth
+    import torch.multiprocessing as mp
+    from portutil import free_port
+    rng = np.random.default_rng(97)
+    big = synth.random_seq(rng, 60000)
+    reads = [(b">big_0", big, synth.mutate(rng, big, 0.01), synth.mutate(rng, big, 0.12))] + msa_gen.make_reads(96, 12, 700)
+    _write_reads(tmp_path, reads)
+    bounds = alignment._shard(str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"), str(tmp_path / "cor.fa"), 4)
+    assert any(a == b for a, b in zip(bounds, bounds[1:])) and (0, 1) in set(zip(bounds, bounds[1:]))
+    (tmp_path / "out1").mkdir()
+    (tmp_path / "out2").mkdir()
+    small, wrong = alignment.getPOA(str(tmp_path / "cor.fa"), str(tmp_path / "ref.fa"), str(tmp_path / "unc.fa"), 8,
+                                    str(tmp_path / "out1"), 0.1, engine=engine)
+    computeStats._engine = engine
+    log = io.StringIO()
+    tup = computeStats.outputRecallPrecision(str(tmp_path / "cor.fa"), str(tmp_path / "out1"), log, small, wrong, 5, 0.1,
+                                             "sizes.txt", {})
+    capsys.readouterr()
+    res = str(tmp_path / "four.json")
+    mp.spawn(_rank_getpoa, args=(4, free_port(), str(tmp_path), res), nprocs=4, join=True)
+    four = json.load(open(res))
+    assert (tmp_path / "out2" / "msa.fa").read_bytes() == (tmp_path / "out1" / "msa.fa").read_bytes()
+    assert (four["small"], four["wrong"]) == (small, wrong) and four["hit"]
+    assert four["tuple"] == json.loads(json.dumps(tup)) and four["log"] == log.getvalue()
