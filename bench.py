@@ -73,7 +73,9 @@ def parse():
     ap.add_argument("--profile", default="ecoli30x_simlord_lordec", choices=sorted(WORKLOADS))
     ap.add_argument("--serial", action="store_true",
                     help="one engine context, one launch chain: every kernel runs alone on the chip (per-kernel times add up to the step)")
-    ap.add_argument("--serial-steps", type=int, default=5, help="steps of the serial pass behind the timed region")
+    ap.add_argument("--serial-steps", type=int, default=10, help="steps of the serial pass behind the timed region")
+    ap.add_argument("--no-rows-to-host", action="store_true",
+                    help="skip the second timed loop (the same steps plus the merged MSA rows copied to pinned host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--end-to-end", action="store_true",
@@ -220,17 +222,23 @@ def cpu_baseline(windows, ref_bases_per_window, seconds, device_msa=None):
 
 
 def pmc_file(profile, reads):
-    """The committed PMC passes over this very command (profiles/pmc_traffic.json, written by
-    tests/_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, gfx950 correction
-    applied, SQ_INSTS_VALU); None when they were taken on another workload."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        if int(t["reads_per_gpu"]) != int(reads) or t.get("profile", "ecoli30x_simlord_lordec") != profile:
-            return None
-        return t
-    except (OSError, KeyError, ValueError):
-        return None
+    """The committed PMC passes over `bench.py --serial` on this workload (profiles/pmc_traffic_<profile>.json,
+    written by tests/_pmc_traffic.py from tests/_r3_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes,
+    gfx950 correction applied, SQ_INSTS_VALU) -> (dict, provenance text); (None, None) when there is none for this
+    workload and batch size.  Counters cannot be read from inside the process being measured: the bench line
+    REPLAYS them and says so."""
+    for name in ("pmc_traffic_%s.json" % profile, "pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if int(t["reads_per_gpu"]) != int(reads) or t.get("profile", "ecoli30x_simlord_lordec") != profile:
+                continue
+            return t, "replayed from profiles/%s (%s; counters of `%s`), not measured in this run" % (
+                name, t.get("collected", "round 2"), t.get("command", "rocprofv3 --pmc"))
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def skipped_alignment1(win, lr, lc):
@@ -418,30 +426,94 @@ def main():
         cols_timed = outs[0][0].cpu().numpy()
         ncol_timed = outs[0][1].cpu().numpy()
     exit_code = 0
-    # ---- after the clock: serial pass for the per-kernel roofline, checks, counters, gather -----------
+    status = d_status.cpu().numpy()
+    ncol = d_ncol.cpu().numpy().astype(np.int64)
+    if status.any():
+        raise SystemExit("bench: %d windows failed on device" % int((status != 0).sum()))
+    po = eng.last_po_sizes(n).astype(np.int64)
+
+    # ---- second timed loop: the same steps, and every step's merged MSA rows (the body of msa.fa, Donatello.cpp:86-91)
+    # copied to pinned host memory as well -- SURVEY.md 8(d) words the metric "MSA rows + per-read counters back on
+    # host"; `value` keeps the rows in HBM (call site #2 needs the counters only, 8(f2)), this figure brings them over
+    # PCIe.  One helper thread per context collects the counters and fetches the rows (the library releases the GIL),
+    # so the copies of one context run beside the kernels of the others.
+    dt_rows = None
+    rows_bytes = 0
+    if not args.no_rows_to_host and not args.serial:
+        from concurrent.futures import ThreadPoolExecutor
+        cap = 3 * int(off[-1]) + 64
+        pinned = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(n_eng)]
+        pool = ThreadPoolExecutor(max_workers=n_eng)
+        futs = [None] * n_eng
+        fetched = [0]
+
+        def finish_rows(e, npieces):
+            c, pc = engines[e].msa_stats_collect(npieces)
+            fetched[0] = engines[e].msa_rows_fetch_into(pc, pinned[e].data_ptr(), cap)
+            return c
+
+        def step_rows():
+            e = turn[0] % n_eng
+            turn[0] += 1
+            if futs[e] is not None:
+                futs[e].result()                     # this context's previous step is on the host, rows included
+            dc, dn, ds = outs[e]
+            engines[e].align_device(d_bases, off, dc, dn, ds)
+            futs[e] = pool.submit(finish_rows, e, engines[e].msa_stats_enqueue(n, dc, dn, ds, piece_first, read_first))
+
+        def drain_rows():
+            for e in range(n_eng):
+                if futs[e] is not None:
+                    futs[e].result()
+                    futs[e] = None
+
+        for _ in range(n_eng + 1):
+            step_rows()
+        drain_rows()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_rows()
+        drain_rows()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_rows = time.perf_counter() - t0
+        rows_bytes = int(fetched[0])
+        pool.shutdown()
+        del pinned
+
+    # ---- after the clock: serial pass for the per-kernel roofline -------------------------------------------
+    # A context of its own with ONE launch chain from its first step on, after the timed contexts are gone: exactly
+    # what `bench.py --serial` times and what profiles/*_serial_kernel_stats.csv (rocprofv3 over that command) shows,
+    # so the figures below can be recomputed from the committed profile.  (Up to round 2 this pass reused a timed
+    # context switched to one chain: its moves pool kept the two-chain size, twice the slots in rotation and a lower
+    # hit rate in L2 / Infinity Cache -- k_poa came out 13 % slower than in the profile.)
     serial_steps = args.steps if args.serial else max(1, args.serial_steps)
     serial_wall = dt / args.steps
     if not args.serial:
+        for g in engines[1:]:
+            g.close()
+        engines[0].close()
+        eng = PoaEngine(local)
+        engines = [eng]
         eng.option("chains", 1)
-        eng.timing_enable(True)
-        eng.timing_reset()
+
         def serial_step():
             eng.align_device(d_bases, off, d_cols, d_ncol, d_status)
             eng.msa_stats_collect(eng.msa_stats_enqueue(n, d_cols, d_ncol, d_status, piece_first, read_first))
-        for _ in range(2):                       # the single-chain scratch layout differs: grow it first
+        for _ in range(4):                       # grow the workspace, settle the clocks
             serial_step()
         eng.sync()
+        eng.timing_enable(True)
         eng.timing_reset()
         ts = time.perf_counter()
         for _ in range(serial_steps):
             serial_step()
         eng.sync()
         serial_wall = (time.perf_counter() - ts) / serial_steps
-    status = d_status.cpu().numpy()
-    ncol = d_ncol.cpu().numpy().astype(np.int64)
-    if status.any():
-        raise SystemExit("bench: %d windows failed on device" % int((status != 0).sum()))
-    po = eng.last_po_sizes(n).astype(np.int64)
     skipped = skipped_alignment1(win, lr, lc)
     cells1, cells2 = int((lr * lc).sum()), int((po * lu).sum())
     cells1_computed = int((lr * lc)[~skipped].sum())
@@ -451,12 +523,20 @@ def main():
     t_st = eng.timing_read(3)[0]
     t_poa, k_poa = eng.timing_read(4)
     rdev = dev if backend == "nccl" else torch.device("cpu")
-    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    tmax = torch.tensor([dt, dt_rows or 0.0], dtype=torch.float64, device=rdev)
     tot = torch.tensor([piece_bases, n, cells1 + cells2, cells1_computed + cells2], dtype=torch.int64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt_max = float(tmax.item())
+    dt_max, dt_rows_max = float(tmax[0].item()), float(tmax[1].item())
+    # what the process group actually spans: one entry per rank, gathered over it (RCCL when the backend is nccl)
+    props = torch.cuda.get_device_properties(local)
+    me = {"rank": rank, "local_rank": local, "device": props.name, "uuid": str(getattr(props, "uuid", "")),
+          "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "host": socket.gethostname()}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
     bases_all, windows_all, cells_all, cells_comp_all = (int(x) for x in tot.tolist())
 
     if rank == 0:
@@ -471,7 +551,7 @@ def main():
         avg_ms = dom[1] / launches
         bytes_per_launch = alg_bytes * serial_steps / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        pmc = pmc_file(args.profile, args.reads)
+        pmc, pmc_prov = pmc_file(args.profile, args.reads)
         traffic = valu = None
         if pmc:
             try:
@@ -491,7 +571,19 @@ def main():
                        "windows_per_gpu": n, "ref_bases_per_gpu": piece_bases,
                        "filler_windows_per_gpu": int((lc == 1).sum()),
                        "parallelism": "shard-by-read x%d" % world,
-                       "batches_in_flight_per_gpu": n_eng, "serial": bool(args.serial)},
+                       "batches_in_flight_per_gpu": n_eng, "serial": bool(args.serial),
+                       # `value`: per-read counters back on the host, the merged MSA rows stay in HBM (SURVEY.md 8(f2):
+                       # call site #2 is served from the device counters); `value_rows_to_host` adds the rows
+                       "rows_to_host": False},
+            "value_rows_to_host": None if not dt_rows_max else round(bases_all * args.steps / dt_rows_max / 1e6, 3),
+            "rows_to_host": None if not dt_rows_max else {
+                "ms_per_step": round(dt_rows_max / args.steps * 1e3, 3), "bytes_per_step_per_gpu": rows_bytes,
+                "pcie_gbs_per_gpu": round(rows_bytes * args.steps / dt_rows_max / 1e9, 2),
+                "note": "the same %d steps timed again with every step's merged rows (3 x columns bytes per piece) copied "
+                        "to pinned host memory by a helper thread per context" % args.steps},
+            "ranks": {"world": world, "backend": backend if world > 1 else None,
+                      "distinct_devices": len({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks}),
+                      "devices": ranks},
             # dtype: k_poa's recurrences run on 16-bit scores, two windows per 32-bit lane (the fall-back kernels, 0.2 %
             # of the windows, on 32-bit ones)
             # DP cells per second.  effective: every cell the reference computes (Lr*Lc + |PO|*Lu per window);
@@ -509,17 +601,18 @@ def main():
                                    "host_classify_and_enqueue": round(host_ms_per_step, 3),
                                    "note": "HIP-event time per launch, summed per step, from %d un-overlapped steps "
                                            "(one context, one launch chain)%s"
-                                           % (serial_steps, "" if args.serial else " run after the timed region")},
+                                           % (serial_steps, "" if args.serial else
+                                              " in a fresh context after the timed region, = what `bench.py --serial` times")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_provenance": pmc_prov if traffic is not None else None,
                          "launches": int(launches), "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "whole_step_frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 6)},
             # what actually binds: VALU issue + latency.  Per GPU: wave-instructions per
             # step from the committed PMC passes of this command, time measured live
             "roofline_valu": None if valu is None else {
-                "bound": "valu-issue", "wave_insts_per_step": valu, "peak": round(VALU_PEAK_GINSTS, 1),
+                "bound": "valu-issue", "wave_insts_per_step": valu, "provenance": pmc_prov, "peak": round(VALU_PEAK_GINSTS, 1),
                 "peak_two_operand_32bit": round(VALU_PEAK_GINSTS_SIMPLE, 1),
                 "peak_note": "packed 16-bit, three-operand and DPP instructions issue once per 4 cycles per SIMD "
                              "(measured: tests/micro/valu_rate.hip, profiles/r02_valu_rate.txt)",

@@ -176,6 +176,16 @@ class PoaEngine:
                                                      rows.ctypes.data))
         return rows[:-1]
 
+    def msa_rows_fetch_into(self, piece_cols, host_ptr, capacity):
+        """msa_rows_fetch into caller-owned host memory (pinned memory makes it one asynchronous DMA): `host_ptr`
+        an address with room for `capacity` bytes.  -> bytes written."""
+        piece_cols = np.ascontiguousarray(piece_cols, dtype=np.int64)
+        need = 3 * int(piece_cols.sum())
+        if need > int(capacity):
+            raise ValueError("msa_rows_fetch_into: %d bytes needed, %d offered" % (need, capacity))
+        self._check(self._lib.elector_msa_rows_fetch(self._h, len(piece_cols), piece_cols.ctypes.data, C.c_void_p(int(host_ptr))))
+        return need
+
     # ---- a12: heaviest-bundle consensus (optional output) -------------------
     def keep_graph(self, on=True):
         """Make the following batches keep the graph data the bundle search needs."""

@@ -32,6 +32,9 @@ def test_bench_contract_one_gpu():
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
     assert j["gcups_computed"] <= j["gcups_effective"]
+    # the second figure: the same steps with the merged rows brought to the host (SURVEY.md 8(d)'s literal definition)
+    assert j["config"]["rows_to_host"] is False and 0 < j["value_rows_to_host"] and j["rows_to_host"]["bytes_per_step_per_gpu"] > 0
+    assert j["ranks"]["world"] == 1 and j["ranks"]["distinct_devices"] == 1 and len(j["ranks"]["devices"]) == 1
     # un-overlapped: the per-kernel times of a step add up to no more than the serial step's wall time
     k = j["kernel_ms_per_step"]
     assert k["k_poa"] + k["alignment1_stage"] + k["alignment2_stage"] + k["other"] + k["merge_and_counters"] <= 1.05 * k["serial_step_wall"]
@@ -43,3 +46,6 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "shard-by-read x2"
     # weak scaling: every rank brings its own 300 reads; rank 0 gathered both ranks' counter rows
     assert two["pieces_gathered"] > 1.8 * one["pieces_gathered"] and two["pieces_gathered"] >= 600
+    # what the process group saw: two ranks, ONE device here (they share it); the 8-GPU node must show N distinct ones
+    assert two["ranks"]["world"] == 2 and two["ranks"]["backend"] == "gloo" and two["ranks"]["distinct_devices"] == 1
+    assert sorted(r["rank"] for r in two["ranks"]["devices"]) == [0, 1]
