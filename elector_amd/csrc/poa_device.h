@@ -55,6 +55,25 @@ struct KParams {
   int open_x, ext_x, open_y, ext_y, match, mismatch;   // used when !GEN
 };
 
+// Largest |score| (plus the headroom the recurrences need around it) that a live cell of a DP over nx columns and ny
+// rows can hold under simple scoring: every cell is at least as good as the path made of one x-gap and one y-gap
+// (open_x + open_y + the extensions), and at most min(nx, ny) matches good; the offers built from a cell (score less a
+// gap penalty, score plus a substitution score) reach three penalties further.  The 16-bit kernels take a window when
+// this stays below 16000.  (Up to round 2 the test was maxpen x (nx + ny): twice as strict as needed with the shipped
+// extension penalty of 5 against an opening penalty of 10, and the long un-anchored windows of trimmed / split reads
+// -- 700 x 700 letters -- fell to the one-wave generic kernels.)
+__host__ __device__ inline int64_t score_span(const KParams &kp, int64_t nx, int64_t ny)
+{
+  auto ab = [](int64_t v) { return v < 0 ? -v : v; };
+  const int64_t ext = ab(kp.ext_x) > ab(kp.ext_y) ? ab(kp.ext_x) : ab(kp.ext_y);
+  const int64_t open = ab(kp.open_x) > ab(kp.open_y) ? ab(kp.open_x) : ab(kp.open_y);
+  const int64_t sub = ab(kp.match) > ab(kp.mismatch) ? ab(kp.match) : ab(kp.mismatch);
+  const int64_t pen = open > sub ? (open > ext ? open : ext) : (sub > ext ? sub : ext);
+  const int64_t down = 2 * open + ext * (nx + ny);                 // the all-gap path
+  const int64_t up = (kp.match > 0 ? kp.match : 0) * (nx < ny ? nx : ny);
+  return (down > up ? down : up) + 3 * pen;
+}
+
 // dwords of move storage per strip for an alignment with Lx columns
 __host__ __device__ inline int mv_tw(int Lx) { return (Lx + 71) >> 3; }
 __host__ __device__ inline int n_strips(int Ly) { return (Ly + kStripRows - 1) / kStripRows; }

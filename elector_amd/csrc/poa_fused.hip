@@ -559,8 +559,7 @@ __device__ __forceinline__ WinB load_win_b(const FusedArgs &a, int64_t li)
   v.off_b1 = v.off_b0 + align_up(2 * (v.n1 + 1), 4);
   v.off_region = align_up(v.off_b1 + (v.ns > 1 ? 2 * (v.n1 + 1) : 0), 4);
   const int region_min = fused_b_cols_bytes(v.n1, v.Lu);
-  const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(max(kp.open_x, kp.open_y), max(kp.ext_x, kp.ext_y)));
-  v.valid = v.valid && (v.off_region + region_min <= a.slot_bytes) && (maxpen * (v.n1 + v.Lu + 4) < 16000) &&
+  v.valid = v.valid && (v.off_region + region_min <= a.slot_bytes) && (score_span(kp, v.n1 + G, v.ns * RS) < 16000) &&
             v.ns <= a.mv_ns && v.n1 + G <= a.mv_tw;
   return v;
 }

@@ -525,8 +525,6 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)6 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc, k_poa's slot need
   int64_t *bin_max_lr = bin_need_a.data() + kBins, *bin_max_lc = bin_max_lr + kBins, *bin_max_lu = bin_max_lc + kBins,
           *bin_max_po = bin_max_lu + kBins, *bin_need_pack = bin_max_po + kBins;
-  const int maxpen = std::max(std::max(std::abs(c->kp.mismatch), std::abs(c->kp.match)),
-                              std::max(std::max(c->kp.open_x, c->kp.open_y), std::max(c->kp.ext_x, c->kp.ext_y)));
   int pen_abs_max = 1;                       // largest |score| or gap penalty of the parameter set
   for (int i = 0; i < c->params.nsymbol; ++i)
     for (int j = 0; j < c->params.nsymbol; ++j) pen_abs_max = std::max(pen_abs_max, std::abs(c->params.score[i][j]));
@@ -536,12 +534,6 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   for (int ci = 0; ci < kNC; ++ci) cls_max_slot[ci] = class_max_slot(ci);
   // testing knob: every window into one geometry class (multi-strip paths of the small classes)
   const int force_cls = std::getenv("ELECTOR_FORCE_CLASS") ? std::atoi(std::getenv("ELECTOR_FORCE_CLASS")) : -1;
-  auto key = [&](int64_t w) {
-    const int64_t m = std::max(off[3 * w + 1] - off[3 * w], off[3 * w + 3] - off[3 * w + 2]);
-    int k = (int)(m >> 3);
-    if (k >= NB) k = NB - 1;
-    return NB - 1 - k;
-  };
   std::vector<uint8_t> wkey((size_t)n);
   std::atomic<int> bad_offsets(0);
   {
@@ -596,7 +588,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           for (int ci = c0; ci < kNC && bin[(size_t)w] < 0; ++ci) {
             const int G = kClsG[ci], R = kClsR[ci];
             // k_fused_b's 16-bit ring cells hold scores up to about +-16000 (it hands larger windows back)
-            if ((int64_t)maxpen * (lr + lr / 16 + 6 + lu + 4) >= 16000) break;
+            if (score_span(c->kp, lr + lr / 16 + 6 + G, ((lu + G * R - 1) / (G * R)) * (int64_t)(G * R)) >= 16000) continue;
             const int need_a = fused_a_slot_need((int)lr, (int)lc, G, R);
             const int need = std::max(need_a, fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G, R));
             if (need > cls_max_slot[ci]) {
@@ -629,8 +621,13 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           cnt[NB + kBins + 1 + 6 * kBins] += (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64;
         } else cnt[NB + kBins]++;                         // generic (incl. failed windows)
         if (!st) cnt[NB + kBins + 2 + 6 * kBins] = std::max(cnt[NB + kBins + 2 + 6 * kBins], lr + lc);
-        const int64_t mlen = std::max(lr, lu);
-        int k = (int)(mlen >> 3);
+        // Size key of the lists (largest first).  Inside a geometry class the rows per lane are fixed and a
+        // wavefront runs for as many steps as its longest window has columns: the exact reference length as the
+        // key makes the wavefronts of a list homogeneous in steps (the device's stable partition by the
+        // trivial-window key keeps this order inside each of its buckets).  Long windows share keys 16 apart;
+        // with ELECTOR_SORT_COARSE the key is max(Lr, Lu) / 8 as up to round 2 (A/B).
+        static const bool coarse = std::getenv("ELECTOR_SORT_COARSE") != nullptr;
+        int k = coarse ? (int)(std::max(lr, lu) >> 3) : lr < 192 ? (int)lr : 192 + (int)std::min<int64_t>(63, (lr - 192) >> 4);
         if (k >= NB) k = NB - 1;
         wkey[(size_t)w] = (uint8_t)(NB - 1 - k);
         cnt[NB - 1 - k]++;

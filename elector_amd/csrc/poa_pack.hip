@@ -10,7 +10,7 @@
 //   * a group of G lanes works on TWO windows at once: every score register holds window A's value in its low
 //     half and window B's in its high half, and the recurrence runs on v_pk_max_i16 / v_pk_add_i16 /
 //     v_pk_sub_i16 / v_pk_mad_i16 / v_pk_min_u16 -- one instruction, two cells.  Scores fit 16 bits for the
-//     windows taken here (|score| <= 10 (Lx + Ly) < 16000);
+//     windows taken here (score_span() of poa_device.h < 16000);
 //   * alignment #2 needs no score ring in LDS: a window is taken when every predecessor of its graph lies at
 //     most two nodes back (99.8 % of the windows of well-corrected reads), so the predecessor columns are the
 //     two columns the lane computed last, held in registers; which of the two, per window, is a bit-field
@@ -740,10 +740,9 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
   W.off_xi = 16 + pk_align_up(W.Lu, 4);
   W.off_u = W.off_xi + 4 * (W.xi_cap + 2);                     // records 1 .. n1 between two zero guards
   const int ua = poa_union_a(W.Lr, W.Lc, G), ub = poa_union_b(W.xi_cap, W.Lu, G);
-  const int maxpen = max(max(abs(kp.mismatch), abs(kp.match)), max(kp.open_x, kp.ext_x));
   W.valid = W.valid && W.off_u + max(ua, ub) <= a.slot_bytes && W.Lc <= RS && W.Lu <= RS &&
             (poa_idx_bytes(G) > 1 || W.Lr + W.Lc <= 254) &&
-            max(W.Lr, W.xi_cap) + G + 2 <= a.mv_tw && maxpen * (W.Lr + W.Lc + W.Lu + 8) < 16000;
+            max(W.Lr, W.xi_cap) + G + 2 <= a.mv_tw && score_span(kp, max(W.Lr, W.xi_cap) + G, RS) < 16000;
 }
 
 template <int G, int R>

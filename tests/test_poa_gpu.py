@@ -262,3 +262,28 @@ def test_one_indel_shortcut_equals_dynamic_program(engine, monkeypatch):
     monkeypatch.delenv("ELECTOR_NO_ONEINDEL")
     assert got == got2
     assert np.array_equal(scores, scores2)
+
+
+def score_range_triples(seed):
+    """Windows between the old 16-bit admission rule (10 x the three lengths < 16000) and the proven score span
+    (poa_device.h: score_span): the long un-anchored windows of trimmed / split reads, with the corrected side a
+    lone `N` filler (Master_Splitter.cpp:139-154,268-277) or a real sequence -- and the worst cases for the span:
+    unrelated sequences (every cell near the all-gap bound), all-mismatch pairs, one side much longer."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for lr in (530, 640, 746, 900, 1100, 1400, 1560):
+        ref = synth.random_seq(rng, lr)
+        unc = synth.mutate(rng, ref, 0.12)
+        cor = synth.mutate(rng, ref, 0.02)
+        out.append((ref, b"N", unc))                                    # filler window
+        out.append((ref, cor, unc))
+        out.append((ref, cor, synth.random_seq(rng, lr)))               # unrelated uncorrected read
+        out.append((ref, synth.random_seq(rng, lr // 2), unc))          # unrelated, shorter corrected read
+        out.append((b"A" * lr, b"C" * (lr // 3), b"G" * lr))            # nothing matches anywhere
+        out.append((ref, cor, unc[: lr // 5]))
+        out.append((ref[: lr // 4], cor, unc))
+    return out
+
+
+def test_windows_up_to_the_score_span(engine):
+    check(engine, score_range_triples(71))
