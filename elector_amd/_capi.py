@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libelector_poa.so")
+# ELECTOR_LIB: another build of the same library (same-box A/B measurements of two builds; never a different ABI)
+LIB_PATH = os.environ.get("ELECTOR_LIB") or os.path.join(HERE, "lib", "libelector_poa.so")
 
 ELECTOR_MAX_SYMBOL = 32
 ELECTOR_MAX_GAPTAB = 64

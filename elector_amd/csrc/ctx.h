@@ -87,7 +87,7 @@ struct elector_ctx {
   // per-batch workspace
   elector::DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
       d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_fmv, d_tstate, d_tlist, d_gring,
-      d_hand, d_mvpool, d_mvbusy;
+      d_hand, d_mvpool, d_mvbusy, d_pdesc, d_psym;
   // device splitter (split_dev.hip)
   elector::DevBuf d_sp_reads, d_sp_off, d_sp_hdr, d_sp_keys, d_sp_vals, d_sp_ca, d_sp_cb, d_sp_wl, d_sp_win, d_sp_first,
       d_sp_cnt, d_sp_wfirst, d_sp_wlen, d_sp_woff, d_sp_scan, d_sp_bases, d_sp_anc;

@@ -57,6 +57,9 @@ struct PackArgs {
   BatchArgs b;
   const uint32_t *list;
   int64_t nlist;
+  const uint4 *pdesc;
+  const uint32_t *psym;
+  int pstride;
   int slot_bytes;
   uint8_t *done_a;
   uint8_t *done_b;
@@ -70,6 +73,18 @@ struct PackArgs {
   int debug;
   unsigned long long *stamps;
 };
+struct GatherArgs {
+  const uint32_t *list;
+  int64_t nlist;
+  const int64_t *off;
+  const uint8_t *sym;
+  const int32_t *status;
+  const uint8_t *done_a, *done_b, *triv;
+  uint4 *pdesc;
+  uint32_t *psym;
+  int pstride;
+};
+void launch_gather(const GatherArgs &a, hipStream_t st);
 int launch_poa(const PackArgs &a, int G, int R, hipStream_t st);
 void launch_poa_pool_init(int32_t *q, int nq, int slots, hipStream_t st);
 int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
@@ -323,7 +338,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit,
-                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy,
+                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy, &c->d_pdesc, &c->d_psym,
                     &c->d_sp_reads, &c->d_sp_off, &c->d_sp_hdr, &c->d_sp_keys, &c->d_sp_vals, &c->d_sp_ca, &c->d_sp_cb, &c->d_sp_wl,
                     &c->d_sp_win, &c->d_sp_first, &c->d_sp_cnt, &c->d_sp_wfirst, &c->d_sp_wlen, &c->d_sp_woff, &c->d_sp_scan, &c->d_sp_bases, &c->d_sp_anc};
   for (DevBuf *b : bufs) b->release();
@@ -903,8 +918,18 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
        c->d_rowinit.ensure(1024 + 256 * (size_t)kBins) |
        c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256) |
        c->d_gring.ensure((size_t)deep_blocks * (size_t)gring_block * 4 + 256);
+  // k_poa's inputs in list order (k_gather): a 32-byte descriptor per fused-routed window and its symbols at the
+  // bin's stride (dwords; the sum of the bin's three length maxima bounds every window's total)
+  std::vector<int64_t> psym_first((size_t)kBins + 1, 0);
+  std::vector<int> pstride((size_t)kBins, 0);
+  if (use_pack)
+    for (int b = 0; b < kBins; ++b) {
+      if (bin_cnt[(size_t)b]) pstride[(size_t)b] = (int)(((bin_max_lr[b] + bin_max_lc[b] + bin_max_lu[b] + 3) / 4 + 3) & ~(int64_t)3);
+      psym_first[(size_t)b + 1] = psym_first[(size_t)b] + bin_cnt[(size_t)b] * pstride[(size_t)b];
+    }
   if (!rc && use_pack)
-    rc = c->d_hand.ensure((size_t)n * 4 + (size_t)kBins * 4 + 64) |
+    rc = c->d_pdesc.ensure((size_t)(n - n_generic) * 32 + 64) | c->d_psym.ensure((size_t)psym_first[(size_t)kBins] * 4 + 256) |
+         c->d_hand.ensure((size_t)n * 4 + (size_t)kBins * 4 + 64) |
          c->d_mvpool.ensure((size_t)(pool_stream[0] + pool_stream[1] + pool_stream[2] + pool_stream[3]) * 4 + 256) |
          c->d_mvbusy.ensure((size_t)4 * 8 * kPoolStride * 4);
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device workspace");
@@ -1083,10 +1108,24 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       if (use_pack && (!split_ab || pass == 0)) {
         // the whole window in one kernel; what it cannot take lands on the bin's hand-back list
         const PackGeom pg = pack_geom(b);
+        GatherArgs ga;
+        ga.list = d_fused_lists + bin_first[(size_t)b];
+        ga.nlist = bin_cnt[(size_t)b];
+        ga.off = a.off; ga.sym = a.sym; ga.status = d_status;
+        ga.done_a = d_done_a; ga.done_b = d_done_b; ga.triv = d_triv;
+        ga.pdesc = c->d_pdesc.as<uint4>() + 2 * bin_first[(size_t)b];
+        ga.psym = c->d_psym.as<uint32_t>() + psym_first[(size_t)b];
+        ga.pstride = pstride[(size_t)b];
+        timed_begin(c, 2, sx);
+        launch_gather(ga, sx);
+        timed_end(c, sx);
         PackArgs pa;
         pa.b = a;
-        pa.list = d_fused_lists + bin_first[(size_t)b];
+        pa.list = ga.list;
         pa.nlist = bin_cnt[(size_t)b];
+        pa.pdesc = ga.pdesc;
+        pa.psym = ga.psym;
+        pa.pstride = ga.pstride;
         pa.slot_bytes = pg.slot;
         pa.done_a = d_done_a;
         pa.done_b = d_done_b;

@@ -36,6 +36,9 @@ struct PackArgs {
   BatchArgs b;
   const uint32_t *list;     // window ids of this bin, in processing order; entries 2p, 2p+1 form pair p
   int64_t nlist;
+  const uint4 *pdesc;       // k_gather's output for this bin: two uint4 per list entry (PackDesc)
+  const uint32_t *psym;     // ... and the entry's three symbol strings back to back, pstride dwords per entry
+  int pstride;
   int slot_bytes;           // LDS bytes per window slot
   uint8_t *done_a;
   uint8_t *done_b;
@@ -720,19 +723,74 @@ __device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *x
   return ncol;
 }
 
+// ------------------------------------------------------------------------ k_gather ---
+// What a wavefront of k_poa needs of its 16 .. 2 windows, laid out in LIST order: a 32-byte descriptor per list
+// entry and the entry's three symbol strings (reference, corrected, uncorrected back to back) at a fixed stride.
+// k_poa then stages a wavefront's windows with loads whose addresses depend on nothing but the block index -- one
+// trip to memory for descriptors and symbols together, whole cache lines -- instead of three dependent trips
+// (list entry -> offsets / flags scattered over the batch's arrays -> symbols) to some eighty different lines.
+// The random accesses move here, into a kernel that has nothing to wait for but memory and hides it with
+// occupancy.  8 lanes per list entry.
+struct PackDesc { uint32_t w, Lr, Lc, Lu; uint32_t o0_lo, o0_hi, triv_ok, pad; };   // triv | ok << 8
+
+struct GatherArgs {
+  const uint32_t *list;
+  int64_t nlist;
+  const int64_t *off;
+  const uint8_t *sym;
+  const int32_t *status;
+  const uint8_t *done_a, *done_b, *triv;
+  uint4 *pdesc;
+  uint32_t *psym;
+  int pstride;               // dwords per entry
+};
+
+__global__ void __launch_bounds__(256) k_gather(GatherArgs a)
+{
+  const int64_t p = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int g = threadIdx.x & 7;
+  if (p >= a.nlist) return;
+  const uint32_t w = a.list[p];
+  const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
+  const int64_t total = o3 - o0;
+  const bool ok = a.status[w] == 0 && a.done_a[w] == 0 && a.done_b[w] == 0 && total <= 4 * (int64_t)a.pstride;
+  if (g == 0) {
+    a.pdesc[2 * p] = make_uint4(w, (uint32_t)(o1 - o0), (uint32_t)(o2 - o1), (uint32_t)(o3 - o2));
+    a.pdesc[2 * p + 1] = make_uint4((uint32_t)((uint64_t)o0 & 0xFFFFFFFFu), (uint32_t)((uint64_t)o0 >> 32),
+                                    (uint32_t)a.triv[w] | (ok ? 0x100u : 0u), 0u);
+  }
+  if (!ok) return;
+  const uint8_t *src = a.sym + o0;
+  const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
+  const uint32_t *src4 = reinterpret_cast<const uint32_t *>(src - mis);
+  uint32_t *dst = a.psym + p * (int64_t)a.pstride;
+  const int nd = (int)((total + 3) >> 2);
+  for (int k = g; k < nd; k += 8) {
+    // (d_sym is padded: the dword behind the window's last may be read)
+    const uint32_t lo = src4[k], hi = src4[k + 1];
+    dst[k] = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * mis));
+  }
+}
+
+void launch_gather(const GatherArgs &a, hipStream_t st)
+{
+  if (a.nlist <= 0) return;
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)((a.nlist + 31) / 32)), dim3(256), 0, st, a);
+}
+
 // ------------------------------------------------------------------------ k_poa ---
 
 // window descriptor -> WinP; the loads were issued by the caller (all of both windows in flight together)
 template <int G, int R>
-__device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed, uint32_t w, int64_t o0, int64_t o1, int64_t o2,
-                                        int64_t o3, int triv, uint8_t *slot)
+__device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed, uint32_t w, int64_t o0, int Lr, int Lc, int Lu,
+                                        int triv, uint8_t *slot)
 {
   constexpr int RS = R * G;
   const KParams kp = a.b.kp;
   W.valid = listed;
   W.w = w;
   W.o0 = listed ? o0 : 0;
-  W.Lr = listed ? (int)(o1 - o0) : 0; W.Lc = listed ? (int)(o2 - o1) : 0; W.Lu = listed ? (int)(o3 - o2) : 0;
+  W.Lr = listed ? Lr : 0; W.Lc = listed ? Lc : 0; W.Lu = listed ? Lu : 0;
   W.triv = listed ? triv : 0;
   W.n1 = 0; W.score1 = kNeg; W.k2n = 0;
   W.slot = slot;
@@ -770,90 +828,94 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
   int32_t *mvq = a.mv_q + (size_t)xcc * kPoolStride;
   uint32_t ticket = 0;
 
-  // ---- the descriptors of both windows: one trip for the list entries, one for everything that hangs on them ----
+  // ---- descriptors and symbols of both windows in ONE trip: k_gather laid them out in list order, so every address
+  // below follows from the block index.  The symbol loads of the first round are issued before the descriptors
+  // have arrived (a fixed number of dwords per entry, the class's stride); what lies behind a window's end is read
+  // and dropped. ----
   WinP W[2];
   const int64_t pi = (int64_t)blockIdx.x * NP + q;
+  uint8_t *us[2], *U[2];
+  uint32_t *xinfo[2];
+  bool any_valid;
   {
+    constexpr int UB = G == 8 ? 8 : 4;                          // dwords per lane, window and round
     bool inl[2];
-    uint32_t w[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) { inl[h] = 2 * pi + h < a.nlist; w[h] = a.list[inl[h] ? 2 * pi + h : 0]; }
-    const uint8_t chr_l = a.b.tab->chr[lane & 31];
-    int st[2], da[2], db[2], tv[2];
-    int64_t o[2][4];
+    const uint32_t *src4[2];
+    uint4 d0[2], d1[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (!inl[h]) w[h] = 0;
-      st[h] = a.b.status[w[h]]; da[h] = a.done_a[w[h]]; db[h] = a.done_b[w[h]];
-      tv[h] = a.triv ? a.triv[w[h]] : 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[h][k] = a.b.off[3 * (int64_t)w[h] + k];
+      inl[h] = 2 * pi + h < a.nlist;
+      const int64_t e = inl[h] ? 2 * pi + h : 0;
+      d0[h] = a.pdesc[2 * e];
+      d1[h] = a.pdesc[2 * e + 1];
+      src4[h] = a.psym + e * (int64_t)a.pstride;
     }
-    // the ticket is drawn behind the descriptor loads: memory operations return in order, so the loads do not
-    // wait for the (slower) atomic, whose trip runs beside the symbol loads instead
+    const uint8_t chr_l = a.b.tab->chr[lane & 31];
+    const int nd = a.pstride;
+    uint32_t v[2][UB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int k = g + u * G;
+        v[h][u] = k < nd ? src4[h][k] : 0u;
+      }
+    // the ticket is drawn behind the loads: memory operations return in order, so the loads do not wait for the
+    // (slower) atomic
     if (a.mv_slots > 0 && lane == 0) ticket = (uint32_t)atomicAdd(mvq, 1);
     if (lane < 32) chr[lane] = chr_l;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const bool listed = inl[h] & (st[h] == 0) & (da[h] == 0) & (db[h] == 0);
-      fit_win<G, R>(W[h], a, listed, w[h], o[h][0], o[h][1], o[h][2], o[h][3], tv[h], lds + 64 + (size_t)(2 * q + h) * a.slot_bytes);
+      const bool listed = inl[h] && ((d1[h].z >> 8) & 1u) != 0u;
+      const int64_t o0 = (int64_t)(((uint64_t)d1[h].y << 32) | d1[h].x);
+      fit_win<G, R>(W[h], a, listed, d0[h].x, o0, (int)d0[h].y, (int)d0[h].z, (int)d0[h].w, (int)(d1[h].z & 0xFFu),
+                    lds + 64 + (size_t)(2 * q + h) * a.slot_bytes);
       // a listed window this kernel cannot take (slot, rows, score range) goes to the two-kernel path at once
       if (listed && !W[h].valid && g == 0) a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
     }
-  }
-  const bool any_valid = __builtin_amdgcn_ballot_w64(W[0].valid || W[1].valid) != 0;
-  PK_STAMP(8);
-
-  uint8_t *us[2], *U[2];
-  uint32_t *xinfo[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    us[h] = W[h].slot + 16;
-    xinfo[h] = reinterpret_cast<uint32_t *>(W[h].slot + W[h].off_xi);
-    U[h] = W[h].slot + W[h].off_u;
-  }
-  // ---- staging: the three symbol strings of both windows (contiguous in HBM; reference + corrected go to the
-  // union region, the uncorrected string to its own place) as aligned dwords, all loads of a round of both
-  // windows in flight together ----
-  if (any_valid) {
-    constexpr int UB = G == 8 ? 8 : 4;                          // dwords per lane, window and round
-    const uint32_t *src4[2];
-    int mis[2], nrc[2], ntot[2], nd = 0;
+    any_valid = __builtin_amdgcn_ballot_w64(W[0].valid || W[1].valid) != 0;
+    PK_STAMP(8);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint8_t *src = a.b.sym + W[h].o0;
-      mis[h] = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
-      src4[h] = reinterpret_cast<const uint32_t *>(src - mis[h]);
-      nrc[h] = W[h].Lr + W[h].Lc;
-      ntot[h] = W[h].valid ? nrc[h] + W[h].Lu : 0;
-      nd = max(nd, W[h].valid ? (mis[h] + ntot[h] + 3) >> 2 : 0);
+      us[h] = W[h].slot + 16;
+      xinfo[h] = reinterpret_cast<uint32_t *>(W[h].slot + W[h].off_xi);
+      U[h] = W[h].slot + W[h].off_u;
     }
-    for (int d = G; d < 64; d <<= 1) nd = max(nd, __shfl_xor(nd, d));
-    nd = __builtin_amdgcn_readfirstlane(nd);
-    for (int kb = 0; kb < nd; kb += UB * G) {
-      uint32_t v[2][UB];
+    if (any_valid) {
+      int nrc[2], ntot[2], ndw = 0;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
+        nrc[h] = W[h].Lr + W[h].Lc;
+        ntot[h] = W[h].valid ? nrc[h] + W[h].Lu : 0;
+        ndw = max(ndw, (ntot[h] + 3) >> 2);
+      }
+      for (int d = G; d < 64; d <<= 1) ndw = max(ndw, __shfl_xor(ndw, d));
+      ndw = __builtin_amdgcn_readfirstlane(ndw);
+      for (int kb = 0; kb < ndw; kb += UB * G) {
+        if (kb > 0) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int k = kb + g + u * G;
-          v[h][u] = 4 * k < mis[h] + ntot[h] ? src4[h][k] : 0u;       // d_sym is padded: the last dword may reach past the window
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+              const int k = kb + g + u * G;
+              v[h][u] = k < nd ? src4[h][k] : 0u;
+            }
         }
-      // Dword k holds the string's bytes i0 .. i0 + 3: reference + corrected live in U, the uncorrected string in
-      // us.  Whole (unaligned) dwords are stored; the one that straddles the border goes to both places.  Bytes
-      // that fall outside a region land in its slack -- the slot's 16-byte header in front of us, the node
-      // records' guards either side, the map area behind the strings in U -- all of which is written later.
+        // Dword k holds the string's bytes 4k .. 4k + 3: reference + corrected live in U, the uncorrected string in
+        // us.  Whole (unaligned) dwords are stored; the one that straddles the border goes to both places.  Bytes
+        // that fall outside a region land in its slack -- the slot's 16-byte header in front of us, the node
+        // records' guards either side, the map area behind the strings in U -- all of which is written later.
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int k = kb + g + u * G;
-          const int i0 = 4 * k - mis[h];
-          if (i0 < ntot[h]) {
-            if (i0 < nrc[h]) __builtin_memcpy(U[h] + i0, &v[h][u], 4);
-            if (i0 + 3 >= nrc[h]) __builtin_memcpy(us[h] + (i0 - nrc[h]), &v[h][u], 4);
+          for (int u = 0; u < UB; ++u) {
+            const int i0 = 4 * (kb + g + u * G);
+            if (i0 < ntot[h]) {
+              if (i0 < nrc[h]) __builtin_memcpy(U[h] + i0, &v[h][u], 4);
+              if (i0 + 3 >= nrc[h]) __builtin_memcpy(us[h] + (i0 - nrc[h]), &v[h][u], 4);
+            }
           }
-        }
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
