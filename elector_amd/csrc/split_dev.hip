@@ -35,7 +35,10 @@
 
 namespace elector {
 
-constexpr int kSplitThreads = 256;
+#ifndef ELECTOR_SPLIT_THREADS
+#define ELECTOR_SPLIT_THREADS 512
+#endif
+constexpr int kSplitThreads = ELECTOR_SPLIT_THREADS;
 constexpr int kMaxAnchors = 3000;          // LDS: 5 ints per anchor
 
 struct DSeq { int64_t base; uint32_t n; };   // base: byte offset into the reads buffer
@@ -215,7 +218,8 @@ __device__ void reset_tab(const Tab &t, int64_t cap)
 constexpr uint32_t kLdsMaxN = 12500;
 constexpr uint32_t kLdsCapRef = 16384, kLdsCapOther = 4096, kLdsFill = 3200;
 constexpr uint32_t kLdsSeqWords = kLdsMaxN / 16 + 3;
-constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4;
+constexpr uint32_t kLdsBitWords = 2 * ((kLdsMaxN + 63) / 64 + 1);       // candidate bitmap: one bit per reference position, as dwords
+constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4;
 
 struct LTab {
   uint32_t *w;            // slots, two per word
@@ -229,10 +233,16 @@ struct LTab {
     return (uint32_t)(v >> sh) & kmsk;
   }
   __device__ __forceinline__ static uint32_t slot_of(uint32_t code, uint32_t mask) { return ((code * 2654435761u) >> 7) & mask; }
+  // Double hashing: the probe sequence of a k-mer advances by an odd step of its own (the table sizes are powers of
+  // two, so it visits every slot).  With linear probing at half load the probe chains cluster, and a wavefront
+  // waits for the longest chain among its 64 look-ups -- which of the k-mers are unique does not depend on the
+  // probe order, so this changes no result.
+  __device__ __forceinline__ static uint32_t step_of(uint32_t code) { return ((code * 0x9E3779B1u) >> 15) | 1u; }
   // true when the k-mer got a slot of its own (a new entry)
   __device__ __forceinline__ bool add(uint32_t code, uint32_t pos) const
   {
     uint32_t h = slot_of(code, mask);
+    const uint32_t step = step_of(code);
     for (uint32_t probes = 0; probes <= mask; ++probes) {
       uint32_t *word = w + (h >> 1);
       const uint32_t sh = (h & 1u) * 16u;
@@ -249,7 +259,7 @@ struct LTab {
         }
         break;
       }
-      h = (h + 1) & mask;
+      h = (h + step) & mask;
     }
     return false;
   }
@@ -257,11 +267,12 @@ struct LTab {
   __device__ __forceinline__ int find(uint32_t code) const
   {
     uint32_t h = slot_of(code, mask);
+    const uint32_t step = step_of(code);
     for (uint32_t probes = 0; probes <= mask; ++probes) {
       const uint32_t e = (w[h >> 1] >> ((h & 1u) * 16u)) & 0xFFFFu;
       if (e == 0xFFFFu) return -1;
       if (bits(seq, e & 0x7FFFu, kmsk) == code) return (e & 0x8000u) ? -1 : (int)(e & 0x7FFFu);
-      h = (h + 1) & mask;
+      h = (h + step) & mask;
     }
     return -1;
   }
@@ -269,7 +280,7 @@ struct LTab {
 
 // the three table phases and the candidate arrays of split_core on the LDS tables; false (uniform) when a table
 // filled up: nothing has been written to ca / cb then and the HBM tables take the call
-__device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, int *flag, int32_t *ca, int32_t *cb, const uint8_t *pr, uint32_t nr,
+__device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, int *flag, const uint8_t *pr, uint32_t nr,
                            const uint8_t *p1, uint32_t n1, const uint8_t *p2, uint32_t n2, int k)
 {
   const int tid = threadIdx.x;
@@ -316,13 +327,101 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   }
   __syncthreads();
   SP_STAMP(3);
-  for (uint32_t p = tid; p < npr; p += kSplitThreads) {
-    const uint32_t c = LTab::bits(sr, p, kmsk);
-    const int b = t2.find(c);
-    const int a = b >= 0 ? t1.find(c) : -1;
-    stg_global(ca + p, a); stg_global(cb + p, b);
+  // candidates: the reference positions whose k-mer is unique in all three reads, one bit each (a wavefront covers 64
+  // consecutive positions per round: its ballot is the bitmap's word); the partner positions are looked up again for
+  // the few positions that become anchors (anchors_lds)
+  uint32_t *bm = s2 + kLdsSeqWords;
+  for (uint32_t p0 = 0; p0 < npr; p0 += kSplitThreads) {
+    const uint32_t p = p0 + tid;
+    bool hit = false;
+    if (p < npr) {
+      const uint32_t c = LTab::bits(sr, p, kmsk);
+      hit = t2.find(c) >= 0 && t1.find(c) >= 0;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if ((tid & 63) == 0 && p < npr) { bm[2 * (p >> 6)] = (uint32_t)m; bm[2 * (p >> 6) + 1] = (uint32_t)(m >> 32); }
   }
   return true;
+}
+
+// anchors of a split() level from the candidate bitmap of tables_lds (:234-251): position 0 without a distance test,
+// then greedily every candidate more than minSize loop steps after the last one taken (loop index j = position - 1,
+// last_indexed starts at 0).  Wavefront 0 holds the bitmap in registers and walks it with scalar code; all threads
+// then look the anchors' partner positions up in the two on-chip tables.  Workgroup-wide.
+template <class LV>
+__device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minSize, int k)
+{
+  const int tid = threadIdx.x;
+  extern __shared__ int32_t dyn_lds_[];
+  uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
+  uint32_t *w1 = lds + kLdsCapRef / 2, *w2 = w1 + kLdsCapOther / 2;
+  uint32_t *sr = w2 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
+  const uint32_t *bm = s2 + kLdsSeqWords;
+  const uint32_t kmsk = (1u << (2 * k)) - 1u;
+  if (tid < 64) {
+    constexpr int kW = (int)(kLdsBitWords / 2 + 63) / 64;            // 64-bit bitmap words per lane
+    const uint32_t nwords = (np + 63) >> 6;
+    uint32_t lo[kW], hi[kW];
+#pragma unroll
+    for (int q = 0; q < kW; ++q) {
+      const uint32_t wd = (uint32_t)q * 64u + (uint32_t)tid;
+      lo[q] = wd < nwords ? bm[2 * wd] : 0u;
+      hi[q] = wd < nwords ? bm[2 * wd + 1] : 0u;
+    }
+    auto word = [&](uint32_t wd) -> unsigned long long {             // uniform wd
+      uint32_t a = 0, b = 0;
+#pragma unroll
+      for (int q = 0; q < kW; ++q)
+        if ((int)(wd >> 6) == q) { a = (uint32_t)__builtin_amdgcn_readlane((int)lo[q], (int)(wd & 63u)); b = (uint32_t)__builtin_amdgcn_readlane((int)hi[q], (int)(wd & 63u)); }
+      return ((unsigned long long)b << 32) | a;
+    };
+    int n = 0;
+    bool fail = false;
+    unsigned long long cur = word(0);
+    if (cur & 1ull) { if (tid == 0) L.ar[0] = 0; n = 1; }
+    // the walk starts behind loop index 0 + minSize whether position 0 was taken or not (last_indexed = 0): the
+    // first candidate that counts has j = p - 1 > minSize
+    const unsigned long long from0 = (unsigned long long)minSize + 2ull;
+    uint32_t from = from0 >= (unsigned long long)np ? np : (uint32_t)from0;
+    uint32_t wd = from >> 6;
+    cur = wd < nwords ? word(wd) & (~0ull << (from & 63u)) : 0ull;
+    while (wd < nwords) {
+      if (cur == 0ull) {
+        ++wd;
+        if (wd >= nwords) break;
+        cur = word(wd);
+        const uint32_t base = wd << 6;
+        if (from > base) cur = from - base >= 64u ? 0ull : cur & (~0ull << (from - base));
+        continue;
+      }
+      const uint32_t p = (wd << 6) + (uint32_t)__builtin_ctzll(cur);
+      if (p >= np) break;
+      // taken: loop index j = p - 1; the next one must have j' > j + minSize, i.e. p' >= p + minSize + 1
+      if (n < L.cap) { if (tid == 0) L.ar[n] = (typename LV::elem)p; }
+      else fail = true;
+      ++n;
+      const unsigned long long next64 = (unsigned long long)p + minSize + 1ull;
+      if (next64 >= (unsigned long long)np) break;
+      from = (uint32_t)next64;
+      if ((from >> 6) == wd) cur &= ~0ull << (from & 63u);
+      else {
+        wd = from >> 6;
+        if (wd >= nwords) break;
+        cur = word(wd) & (~0ull << (from & 63u));
+      }
+    }
+    if (tid == 0) { L.s->n = fail ? 0 : n; if (fail) L.s->fail = 1; }
+  }
+  __syncthreads();
+  // partner positions of the anchors: the k-mer's only occurrence in the uncorrected / corrected read
+  const int n = L.s->n;
+  const LTab t1{w1, kLdsCapOther - 1, s1, kmsk}, t2{w2, kLdsCapOther - 1, s2, kmsk};
+  for (int i = tid; i < n; i += kSplitThreads) {
+    const uint32_t c = LTab::bits(sr, (uint32_t)L.ar[i], kmsk);
+    L.aa[i] = (typename LV::elem)t1.find(c);
+    L.ab[i] = (typename LV::elem)t2.find(c);
+  }
+  __syncthreads();
 }
 
 // maximum over the wavefront, uniform (DPP row shifts + four v_readlane: no LDS traffic)
@@ -356,12 +455,13 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
   // like the reference's, tell such k-mers apart the way the reference does)
   bool on_chip = g.lds_tab >= 0 && ref.n <= kLdsMaxN && S1.n <= kLdsMaxN && S2.n <= kLdsMaxN &&
                  ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
-  if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, g.lds_flag, g.ca, g.cb, pr, ref.n, p1, S1.n, p2, S2.n, k);
+  if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, g.lds_flag, pr, ref.n, p1, S1.n, p2, S2.n, k);
   if (on_chip) {
     if (g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
-    __threadfence();
     __syncthreads();
     SP_STAMP(4);
+    anchors_lds(L, g.lds_tab, n_kmers(ref.n, k), minSize, k);
+    SP_STAMP(5);
   } else {
   reset_tab(tr, cr); reset_tab(t1, c1); reset_tab(t2, c2);
   __threadfence();
@@ -436,6 +536,7 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
   // anchors (:234-251), wavefront 0: position 0 without a distance test, then greedily every candidate more than
   // minSize loop steps after the last one taken (loop index j = position - 1, last_indexed starts at 0)
   const uint32_t np = n_kmers(ref.n, k);
+  if (!on_chip) {
   if (tid < 64) {
     int n = 0;
     if (tid == 0) {
@@ -481,6 +582,7 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
   }
   __syncthreads();
   SP_STAMP(5);
+  }
   // longest chain, back to front (:79-126): wavefront 0
   const int n = L.s->n;
   if (tid < 64 && n > 0) {
@@ -694,7 +796,7 @@ __device__ uint32_t largest_fragment(const int32_t *wl, int n, uint32_t hdr_len)
 }
 
 template <bool BIG>
-__global__ void __launch_bounds__(kSplitThreads) k_split(SplitArgs a)
+__global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 512 ? 4 : 2)) k_split(SplitArgs a)
 {
   extern __shared__ int32_t s_anc[];              // !BIG: 2 levels x 5 arrays x a.maxanc entries (sized by the batch's longest read)
   __shared__ LvlState s_lvl[2];
