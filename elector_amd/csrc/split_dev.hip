@@ -219,6 +219,8 @@ constexpr uint32_t kLdsMaxN = 12500;
 constexpr uint32_t kLdsCapRef = 16384, kLdsCapOther = 4096, kLdsFill = 3200;
 constexpr uint32_t kLdsSeqWords = kLdsMaxN / 16 + 3;
 constexpr uint32_t kLdsBitWords = 2 * ((kLdsMaxN + 63) / 64 + 1);       // candidate bitmap: one bit per reference position, as dwords
+constexpr uint32_t kLdsAncTab = 6 * (kLdsBitWords / 2);                   // per bitmap word: the anchor walk's exit table (anchors_lds),
+static_assert(kLdsAncTab * 4 <= kLdsCapRef * 2, "the exit tables overlay the reference's k-mer table");   // which is dead by then
 constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4;
 
 struct LTab {
@@ -358,9 +360,37 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
   uint32_t *sr = w2 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
   const uint32_t *bm = s2 + kLdsSeqWords;
   const uint32_t kmsk = (1u << (2 * k)) - 1u;
+  constexpr int kW = (int)(kLdsBitWords / 2 + 63) / 64;              // 64-bit bitmap words per lane of wavefront 0
+  const uint32_t nwords = (np + 63) >> 6;
+  // The usual case, minSize = 20 (any minSize up to 29): the walk as a chain of small functions.  What the walk does
+  // inside one 64-bit word of the bitmap depends on the word and on ONE number, the first position of the word it may
+  // take (0 .. minSize + 2: what the anchor before left over); what it hands to the next word is again such a number
+  // (0 .. minSize).  Every thread tabulates that function for one word (32 entries of 5 bits); wavefront 0 then only
+  // chains the tables -- a dozen scalar instructions per WORD instead of some forty per ANCHOR -- and its lanes write
+  // the anchors of their words, at offsets from a prefix sum of their counts.
+  const bool chained = minSize <= 29u;
+  uint32_t *atab = lds;                                  // over the reference's k-mer table: nothing reads it any more
+  if (chained) {
+    for (uint32_t w = (uint32_t)tid; w < nwords; w += kSplitThreads) {
+      const unsigned long long B = ((unsigned long long)bm[2 * w + 1] << 32) | bm[2 * w];
+      unsigned long long t64[3] = {0ull, 0ull, 0ull};
+      for (uint32_t e = 0; e <= minSize + 2u; ++e) {
+        unsigned long long x = B & (~0ull << e);
+        int t = -1;
+        while (x) {
+          t = __builtin_ctzll(x);
+          const uint32_t nx = (uint32_t)t + minSize + 1u;
+          x = nx >= 64u ? 0ull : x & (~0ull << nx);
+        }
+        const uint32_t ex = t >= 0 ? (uint32_t)max(0, t + (int)minSize + 1 - 64) : 0u;
+        t64[e / 12u] |= (unsigned long long)ex << (5u * (e % 12u));
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { atab[6 * w + 2 * d] = (uint32_t)t64[d]; atab[6 * w + 2 * d + 1] = (uint32_t)(t64[d] >> 32); }
+    }
+    __syncthreads();
+  }
   if (tid < 64) {
-    constexpr int kW = (int)(kLdsBitWords / 2 + 63) / 64;            // 64-bit bitmap words per lane
-    const uint32_t nwords = (np + 63) >> 6;
     uint32_t lo[kW], hi[kW];
 #pragma unroll
     for (int q = 0; q < kW; ++q) {
@@ -368,6 +398,58 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
       lo[q] = wd < nwords ? bm[2 * wd] : 0u;
       hi[q] = wd < nwords ? bm[2 * wd + 1] : 0u;
     }
+    int n = 0;
+    bool fail = false;
+    const uint32_t w0bits = (uint32_t)__builtin_amdgcn_readlane((int)lo[0], 0);
+    if (w0bits & 1u) { if (tid == 0) L.ar[0] = 0; n = 1; }
+    // the walk starts behind loop index 0 + minSize whether position 0 was taken or not (last_indexed = 0): the
+    // first candidate that counts has j = p - 1 > minSize
+    const unsigned long long from0 = (unsigned long long)minSize + 2ull;
+    if (chained) {
+      uint32_t st = (uint32_t)from0;                       // <= 31: inside word 0
+      uint32_t ent[kW];
+#pragma unroll
+      for (int q = 0; q < kW; ++q) {
+        ent[q] = 0;
+        const uint32_t wd = (uint32_t)q * 64u + (uint32_t)tid;
+        unsigned long long T[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          T[d] = wd < nwords ? (((unsigned long long)atab[6 * wd + 2 * d + 1] << 32) | atab[6 * wd + 2 * d]) : 0ull;
+        const uint32_t wq = nwords > 64u * (uint32_t)q ? min(64u, nwords - 64u * (uint32_t)q) : 0u;
+        for (uint32_t l = 0; l < wq; ++l) {
+          if ((uint32_t)tid == l) ent[q] = st;
+          const uint32_t sel = (st >= 12u ? 1u : 0u) + (st >= 24u ? 1u : 0u), sh = 5u * (st - 12u * sel);
+          const unsigned long long tv = sel == 0u ? T[0] : sel == 1u ? T[1] : T[2];
+          st = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)(tv >> sh) & 31u), (int)l);
+        }
+      }
+      // every lane: the anchors of its words, counted, placed behind the lanes (words) before it, written
+      int base = n;
+#pragma unroll
+      for (int q = 0; q < kW; ++q) {
+        const unsigned long long B = ((unsigned long long)hi[q] << 32) | lo[q];
+        const unsigned long long x0 = B & (~0ull << ent[q]);
+        int c = 0;
+        for (unsigned long long x = x0; x;) {
+          const uint32_t nx = (uint32_t)__builtin_ctzll(x) + minSize + 1u;
+          ++c;
+          x = nx >= 64u ? 0ull : x & (~0ull << nx);
+        }
+        int inc = c;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (tid >= d) inc += t; }
+        int at = base + inc - c;
+        for (unsigned long long x = x0; x;) {
+          const uint32_t t = (uint32_t)__builtin_ctzll(x), nx = t + minSize + 1u;
+          if (at < L.cap) L.ar[at] = (typename LV::elem)(64u * ((uint32_t)q * 64u + (uint32_t)tid) + t);
+          ++at;
+          x = nx >= 64u ? 0ull : x & (~0ull << nx);
+        }
+        base += __shfl(inc, 63);
+      }
+      n = base;
+      if (n > L.cap) fail = true;
+    } else {
     auto word = [&](uint32_t wd) -> unsigned long long {             // uniform wd
       uint32_t a = 0, b = 0;
 #pragma unroll
@@ -375,16 +457,9 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
         if ((int)(wd >> 6) == q) { a = (uint32_t)__builtin_amdgcn_readlane((int)lo[q], (int)(wd & 63u)); b = (uint32_t)__builtin_amdgcn_readlane((int)hi[q], (int)(wd & 63u)); }
       return ((unsigned long long)b << 32) | a;
     };
-    int n = 0;
-    bool fail = false;
-    unsigned long long cur = word(0);
-    if (cur & 1ull) { if (tid == 0) L.ar[0] = 0; n = 1; }
-    // the walk starts behind loop index 0 + minSize whether position 0 was taken or not (last_indexed = 0): the
-    // first candidate that counts has j = p - 1 > minSize
-    const unsigned long long from0 = (unsigned long long)minSize + 2ull;
     uint32_t from = from0 >= (unsigned long long)np ? np : (uint32_t)from0;
     uint32_t wd = from >> 6;
-    cur = wd < nwords ? word(wd) & (~0ull << (from & 63u)) : 0ull;
+    unsigned long long cur = wd < nwords ? word(wd) & (~0ull << (from & 63u)) : 0ull;
     while (wd < nwords) {
       if (cur == 0ull) {
         ++wd;
@@ -409,6 +484,7 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
         if (wd >= nwords) break;
         cur = word(wd) & (~0ull << (from & 63u));
       }
+    }
     }
     if (tid == 0) { L.s->n = fail ? 0 : n; if (fail) L.s->fail = 1; }
   }
@@ -661,9 +737,11 @@ struct WList { int32_t *w; int n; int64_t cap; bool over; };
 __device__ __forceinline__ void wpush(WList &o, uint32_t ro, uint32_t rl, uint32_t ao, uint32_t al, uint32_t bo, uint32_t bl, int nfill)
 {
   if (o.n >= o.cap) { o.over = true; return; }
+  // (through a pointer known to be global memory: FLAT stores would also count as LDS operations, and the next read
+  // of the anchor arrays would wait for their trip to memory)
   int32_t *w = o.w + 8 * (int64_t)o.n;
-  stg(w, (int)ro); stg(w + 1, (int)rl); stg(w + 2, (int)ao); stg(w + 3, (int)al); stg(w + 4, (int)bo); stg(w + 5, (int)bl);
-  stg(w + 6, nfill); stg(w + 7, 0);
+  stg_global(w, (int)ro); stg_global(w + 1, (int)rl); stg_global(w + 2, (int)ao); stg_global(w + 3, (int)al);
+  stg_global(w + 4, (int)bo); stg_global(w + 5, (int)bl); stg_global(w + 6, nfill); stg_global(w + 7, 0);
   ++o.n;
 }
 
