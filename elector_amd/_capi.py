@@ -16,6 +16,7 @@ ELECTOR_MAX_GAPTAB = 64
 ELECTOR_MAX_SEQ = 524000
 ES_NCOUNTERS = 25          # include/elector_stats.h
 
+E_IO = -6
 E_WINDOW = -7
 E_LIMIT = -8
 W_OK, W_EMPTY, W_TOOLONG, W_INTERNAL = 0, 1, 2, 3
@@ -45,6 +46,7 @@ EXPORTS = [
     "elector_split_reads_device", "elector_windows_dev_free", "elector_ctx_copy", "elector_ctx_copy_to_host",
     "elector_reads_open", "elector_reads_next", "elector_reads_close", "elector_reads_scan", "elector_reads_index_free",
     "elector_msa_format", "elector_msa_records_write",
+    "elector_report_aggregate", "elector_report_free", "elector_read_size_lines",
 ]
 
 _lib = None

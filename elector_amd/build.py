@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("poa_kernels.hip", "poa_fused.hip", "poa_pack.hip", "poa_host.hip", "stats.hip", "bundle.hip", "split_dev.hip", "splitter.cpp", "io_host.cpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("poa_kernels.hip", "poa_fused.hip", "poa_pack.hip", "poa_host.hip", "stats.hip", "bundle.hip", "split_dev.hip", "splitter.cpp", "io_host.cpp", "report_host.cpp")]
 HDR = [os.path.join(HERE, "csrc", "poa_device.h"), os.path.join(HERE, "csrc", "ctx.h"), os.path.join(HERE, "csrc", "poa_serial.h"),
        os.path.join(ROOT, "include", "elector_poa.h"), os.path.join(ROOT, "include", "elector_stats.h"),
        os.path.join(ROOT, "include", "elector_split.h")]

@@ -170,99 +170,56 @@ def homopolymer_ratios(pieces, last_mask, threshold):
     return [round(int(c) * 1.0 / int(r), 2) for c, r in pairs[:n]]
 
 
-def aggregate(pieces, counters, ratios, outPerReadMetrics):
-    """The host half of computeMetrics (computeStats.py:519-675): per-read ratios in
-    read order from the integer counters."""
-    nbReadsToDivide = 0
-    countReadSplit = countReadExtended = countReadTrimmed = 0
-    extendedBasesCount, missingSize = [], []
-    indelsubsCorr, indelsubsUncorr = [0, 0, 0], [0, 0, 0]
-    allLenCorrected, allLenUncorrected = [], []
-    precision, recall, corBasesRate, uncorCorBasesRate = [], [], [], []
-    totalCorBases = totalUncorBases = 0
-    GCRateRef, GCRateCorr = [], []
-    n_reads = len(pieces.read_first) - 1
-    # plain Python integers from here on (the same values, several times cheaper to index than numpy scalars)
-    read_first = np.asarray(pieces.read_first).tolist()
-    counters = np.asarray(counters).tolist()
-    per_read = []
-    for r in range(n_reads):
-        p0, p1 = read_first[r], read_first[r + 1]
-        nfrag = p1 - p0
-        split = nfrag > 1
-        if split:
-            countReadSplit += 1
-        isExtended = isTrimmed = False
-        TPs = FPs = FNs = cors = uncs = ucors = uuncs = 0
-        any_piece = False
-        gcr = gcc = 0
-        emitted = False
-        missingInRead = 0
-        for k, p in enumerate(range(p0, p1)):
-            c = counters[p]
-            if not c[ES_PROCESSED]:
-                continue
-            any_piece = True
-            if k == 0 or not split:
-                allLenUncorrected.append(int(c[ES_LEN_UNC]))
-            for side in (ES_EXT_LEFT, ES_EXT_RIGHT):
-                if c[side] >= 0:
-                    isExtended = True
-                    extendedBasesCount.append(int(c[side]))
-            missingInRead = int(c[ES_MISSING])
-            if missingInRead > THRESH:
-                isTrimmed = True
-            indelsubsCorr[0] += int(c[ES_INS_C]); indelsubsCorr[1] += int(c[ES_DEL_C]); indelsubsCorr[2] += int(c[ES_SUB_C])
-            indelsubsUncorr[0] += int(c[ES_INS_U]); indelsubsUncorr[1] += int(c[ES_DEL_U]); indelsubsUncorr[2] += int(c[ES_SUB_U])
-            TPs += int(c[ES_TP]); FPs += int(c[ES_FP]); FNs += int(c[ES_FN])
-            cors += int(c[ES_COR]); uncs += int(c[ES_UNC]); ucors += int(c[ES_UCOR]); uuncs += int(c[ES_UUNC])
-            allLenCorrected.append(int(c[ES_LEN_COR]))
-            gcr = round(int(c[ES_GC_REF]) * 1.0 / int(c[ES_LEN_REF]), 3)
-            gcc = round(int(c[ES_GC_COR]) * 1.0 / int(c[ES_LEN_COR]), 3)
-            if split and p == p1 - 1:
-                missingInRead = int(c[ES_MISSING_LAST])
-                emitted = True
-            elif not split:
-                emitted = True
-        if not emitted:
-            continue
-        # outputMetrics (computeStats.py:444-468); a processed piece always left entries in the lists
-        if any_piece:
-            rec = TPs / (TPs + FNs) if (TPs + FNs) != 0 else 0
-            prec = TPs / (TPs + FPs) if (TPs + FPs) != 0 else 0
-            if missingInRead != 0:
-                missingSize.append(missingInRead)
-            corBRate = cors / (cors + uncs) if (cors + uncs) != 0 else 0
-            uncorCorBRate = ucors / (ucors + uuncs) if (ucors + uuncs) != 0 else 0
-            per_read.append(str(rec) + " recall\n" + str(prec) + " precision\n" + str(corBRate) + " correct_rate\n")
-            recall.append(rec); precision.append(prec)
-            corBasesRate.append(corBRate); uncorCorBasesRate.append(uncorCorBRate)
-            totalCorBases += cors
-            totalUncorBases += uncs
-        GCRateRef.append(gcr)
-        GCRateCorr.append(gcc)
-        if isExtended:
-            countReadExtended += 1
-        if isTrimmed and not split:
-            countReadTrimmed += 1
-        nbReadsToDivide += 1
+class ElectorReport(C.Structure):
+    _fields_ = [("nb_reads", C.c_int64), ("throughput", C.c_int64), ("uncor_throughput", C.c_int64),
+                ("precision", C.c_double), ("recall", C.c_double), ("cor_bases_rate", C.c_double), ("error_rate", C.c_double),
+                ("uncor_cor_bases_rate", C.c_double), ("uncor_error_rate", C.c_double), ("gc_ref", C.c_double), ("gc_cor", C.c_double),
+                ("indelsubs_unc", C.c_int64 * 3), ("indelsubs_cor", C.c_int64 * 3),
+                ("count_split", C.c_int64), ("count_trimmed", C.c_int64), ("count_extended", C.c_int64),
+                ("n_missing", C.c_int64), ("n_len_cor", C.c_int64), ("n_extended", C.c_int64),
+                ("missing_size", C.POINTER(C.c_int64)), ("len_corrected", C.POINTER(C.c_int64)),
+                ("extended_bases", C.POINTER(C.c_int64)), ("per_read_text", C.POINTER(C.c_char)),
+                ("per_read_bytes", C.c_int64), ("flags", C.c_int32), ("pad", C.c_int32)]
 
-    outPerReadMetrics.write("".join(per_read))
-    GCRateRef = round(sum(GCRateRef) / len(GCRateRef), 3)
-    GCRateCorr = round(sum(GCRateCorr) / len(GCRateCorr), 3)
-    recall = sum(recall) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
-    precision = sum(precision) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
-    corBasesRate = sum(corBasesRate) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
-    uncorCorBasesRate = sum(uncorCorBasesRate) * 1.0 / nbReadsToDivide if nbReadsToDivide != 0 else 0
-    throughput = sum(allLenCorrected)
-    uncorThroughput = sum(allLenUncorrected)
-    errorRate = 1 - (totalCorBases / (totalCorBases + totalUncorBases))
-    uncorErrorRate = 1 - (totalUncorBases / (totalCorBases + totalUncorBases))
-    meanRatioHomopolymers = statistics.mean(ratios) if len(ratios) > 1 else 1
-    return (nbReadsToDivide, throughput, uncorThroughput, precision, recall, corBasesRate, errorRate,
-            uncorCorBasesRate, uncorErrorRate, missingSize, GCRateRef, GCRateCorr, indelsubsUncorr, indelsubsCorr,
-            meanRatioHomopolymers, allLenCorrected, countReadSplit, countReadTrimmed, countReadExtended,
-            extendedBasesCount)
+
+def aggregate(pieces, counters, ratios, outPerReadMetrics):
+    """The host half of computeMetrics (computeStats.py:519-675): per-read ratios in read order from the integer
+    counters -- in the library (elector_report_aggregate, report_host.cpp); same return tuple as the reference's
+    computeMetrics, the lines of per_read_metrics.txt written to outPerReadMetrics."""
+    L = _capi.lib()
+    if not getattr(L, "_report_bound", False):
+        L.elector_report_aggregate.argtypes = [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(ElectorReport)]
+        L.elector_report_free.argtypes = [C.POINTER(ElectorReport)]
+        L.elector_report_free.restype = None
+        L.elector_read_size_lines.argtypes = [C.c_char_p, C.c_int]
+        L.elector_read_size_lines.restype = C.c_int64
+        L._report_bound = True
+    read_first = np.ascontiguousarray(pieces.read_first, dtype=np.int64)
+    counters = np.ascontiguousarray(counters, dtype=np.int64)
+    n_reads = len(read_first) - 1
+    n_pieces = counters.shape[0] if counters.ndim == 2 else 0
+    rep = ElectorReport()
+    rc = L.elector_report_aggregate(n_reads, read_first.ctypes.data, n_pieces, counters.ctypes.data, C.byref(rep))
+    if rc:
+        raise ElectorError(rc)
+    try:
+        if rep.flags & 3:
+            # what the reference's own arithmetic does with no assessed read or a piece without letters
+            raise ZeroDivisionError("division by zero")
+        outPerReadMetrics.write(C.string_at(rep.per_read_text, rep.per_read_bytes).decode("ascii"))
+
+        def lst(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).tolist() if n else []
+        zero = bool(rep.flags & 4)
+        meanRatioHomopolymers = statistics.mean(ratios) if len(ratios) > 1 else 1
+        return (rep.nb_reads, rep.throughput, rep.uncor_throughput, 0 if zero else rep.precision, 0 if zero else rep.recall,
+                0 if zero else rep.cor_bases_rate, rep.error_rate, 0 if zero else rep.uncor_cor_bases_rate,
+                rep.uncor_error_rate, lst(rep.missing_size, rep.n_missing), rep.gc_ref, rep.gc_cor,
+                list(rep.indelsubs_unc), list(rep.indelsubs_cor), meanRatioHomopolymers,
+                lst(rep.len_corrected, rep.n_len_cor), rep.count_split, rep.count_trimmed, rep.count_extended,
+                lst(rep.extended_bases, rep.n_extended))
+    finally:
+        L.elector_report_free(C.byref(rep))
 
 
 def cached_pieces(fileName, clipsNb):
@@ -322,19 +279,19 @@ def computeMetrics(fileName, outPerReadMetrics, correctedFileName, reportedThres
 
 def outputReadSizeDistribution(correctedFileName, outFileName, outDir, trimmedOrSplit, lenAllReads):
     """computeStats.py:273-286"""
-    out = open(outDir + "/" + outFileName, 'w')
-    out.write("size type\n")
-    out.write("".join([str(readSize) + " reads\n" for readSize in lenAllReads]))
-    if trimmedOrSplit != 0:
-        # the reference reads a header line, then a sequence line whose last character it drops, until a
-        # header read comes back empty; the same pairs from the file iterator, one write
-        with open(correctedFileName) as cor:
-            it = iter(cor)
-            lines = []
-            for _ in it:
-                lines.append(str(len(next(it, "")[:-1])) + " sequences\n")
-            out.write("".join(lines))
-    out.close()
+    with open(outDir + "/" + outFileName, 'w') as out:
+        out.write("size type\n")
+        out.write("".join([str(readSize) + " reads\n" for readSize in lenAllReads]))
+        if trimmedOrSplit != 0:
+            # the reference reads a header line, then a sequence line whose last character it drops, until a header
+            # read comes back empty: one pass over the file in the library (elector_read_size_lines)
+            out.flush()
+            L = _capi.lib()
+            L.elector_read_size_lines.argtypes = [C.c_char_p, C.c_int]
+            L.elector_read_size_lines.restype = C.c_int64
+            n = L.elector_read_size_lines(os.fsencode(correctedFileName), out.fileno())
+            if n < 0:
+                raise FileNotFoundError(correctedFileName) if n == _capi.E_IO else ElectorError(int(n))
 
 
 def outputRecallPrecision(correctedFileName, outDir, logFile, smallReadNumber, wronglyCorrectedReadsNumber,

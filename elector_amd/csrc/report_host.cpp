@@ -1,0 +1,246 @@
+// report_host.cpp -- the host half of call site #2 in native code: per-read ratios, means and the text of
+// `per_read_metrics.txt` from the per-piece integer counters the device computed (include/elector_stats.h).
+//
+// Restates the bookkeeping of the reference's computeMetrics / outputMetrics (elector/computeStats.py:519-675,
+// 444-468) and outputReadSizeDistribution (:273-286): which pieces of a read count, in which order the lists grow,
+// where an int 0 stands instead of a float, sequential double sums in read order.  Everything here is a function of
+// integers gathered on rank 0, so the report does not depend on how the reads were sharded over GPUs.
+// The Python mirror (elector_amd/computeStats.py) prints the report from what this returns; tests/agg_ref.py holds
+// the same logic as plain Python loops, and the tests compare the two on random counters.
+//
+// Host-only, no GPU: plain C ABI.
+#include "elector_stats.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <unistd.h>
+
+namespace {
+
+constexpr int kThresh = 5;      // computeStats.py:40
+
+// repr(float) of CPython (the shortest string that reads back as the same double; exponent form when the decimal
+// exponent is below -4 or at least 16, ".0" behind an integral mantissa in fixed form)
+int py_repr(double x, char *out)
+{
+  if (x == 0.0) { std::memcpy(out, std::signbit(x) ? "-0.0" : "0.0", std::signbit(x) ? 4 : 3); return std::signbit(x) ? 4 : 3; }
+  if (x != x) { std::memcpy(out, "nan", 3); return 3; }
+  char sci[40];
+  const auto r = std::to_chars(sci, sci + sizeof sci - 1, x, std::chars_format::scientific);   // d[.ddd]e[+-]XX, shortest
+  const int len = (int)(r.ptr - sci);
+  sci[len] = 0;
+  int i = 0, o = 0;
+  if (sci[0] == '-') { out[o++] = '-'; i = 1; }
+  if (len - i >= 3 && sci[i] == 'i') { std::memcpy(out + o, "inf", 3); return o + 3; }
+  char digits[24];
+  int nd = 0;
+  digits[nd++] = sci[i++];
+  if (sci[i] == '.') { ++i; while (sci[i] != 'e') digits[nd++] = sci[i++]; }
+  ++i;                                                     // 'e'
+  const int e10 = std::atoi(sci + i);
+  if (e10 < -4 || e10 >= 16) {
+    out[o++] = digits[0];
+    if (nd > 1) { out[o++] = '.'; std::memcpy(out + o, digits + 1, (size_t)nd - 1); o += nd - 1; }
+    out[o++] = 'e';
+    out[o++] = e10 < 0 ? '-' : '+';
+    const int a = e10 < 0 ? -e10 : e10;
+    o += std::snprintf(out + o, 8, "%02d", a);
+    return o;
+  }
+  if (e10 < 0) {                                           // 0.000ddd
+    out[o++] = '0'; out[o++] = '.';
+    for (int k = 0; k < -e10 - 1; ++k) out[o++] = '0';
+    std::memcpy(out + o, digits, (size_t)nd); o += nd;
+    return o;
+  }
+  // e10 + 1 digits in front of the point
+  for (int k = 0; k <= e10; ++k) out[o++] = k < nd ? digits[k] : '0';
+  out[o++] = '.';
+  if (nd > e10 + 1) { std::memcpy(out + o, digits + e10 + 1, (size_t)(nd - e10 - 1)); o += nd - e10 - 1; }
+  else out[o++] = '0';
+  return o;
+}
+
+// round(x, 3) of CPython: the correctly rounded three-decimal string of the exact binary value, read back
+double py_round3(double x)
+{
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "%.3f", x);
+  return std::strtod(buf, nullptr);
+}
+
+template <class T>
+T *to_malloc(const std::vector<T> &v)
+{
+  T *p = static_cast<T *>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+  if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+
+}  // namespace
+
+extern "C" int elector_report_aggregate(int64_t n_reads, const int64_t *read_first, int64_t n_pieces, const int64_t *counters,
+                                        elector_report *out)
+{
+  if (!out || n_reads < 0 || n_pieces < 0 || !read_first || (n_pieces > 0 && !counters)) return ELECTOR_E_INVAL;
+  std::memset(out, 0, sizeof *out);
+  if (read_first[0] != 0 || read_first[n_reads] != n_pieces) return ELECTOR_E_INVAL;
+  std::vector<int64_t> missing, len_cor, ext;
+  std::string text;
+  text.reserve((size_t)n_reads * 64);
+  int64_t nb = 0, n_split = 0, n_ext = 0, n_trim = 0, total_cor = 0, total_unc = 0, len_unc_sum = 0, len_cor_sum = 0;
+  double s_rec = 0, s_prec = 0, s_cbr = 0, s_ucbr = 0, s_gcr = 0, s_gcc = 0;
+  int64_t n_gc = 0;
+  int64_t isu[3] = {0, 0, 0}, isc[3] = {0, 0, 0};
+  char num[40];
+  auto put = [&](bool is_int0, double v, const char *label) {
+    if (is_int0) text.push_back('0');
+    else text.append(num, (size_t)py_repr(v, num));
+    text.append(label);
+  };
+  for (int64_t r = 0; r < n_reads; ++r) {
+    const int64_t p0 = read_first[r], p1 = read_first[r + 1];
+    if (p1 < p0) return ELECTOR_E_INVAL;
+    const bool split = p1 - p0 > 1;
+    if (split) ++n_split;
+    bool extended = false, trimmed = false, any = false, emitted = false;
+    int64_t TP = 0, FP = 0, FN = 0, cors = 0, uncs = 0, ucors = 0, uuncs = 0, miss = 0;
+    double gcr = 0, gcc = 0;
+    for (int64_t p = p0; p < p1; ++p) {
+      const int64_t *c = counters + p * ES_NCOUNTERS;
+      if (!c[ES_PROCESSED]) continue;
+      any = true;
+      if (p == p0 || !split) len_unc_sum += c[ES_LEN_UNC];
+      if (c[ES_EXT_LEFT] >= 0) { extended = true; ext.push_back(c[ES_EXT_LEFT]); }
+      if (c[ES_EXT_RIGHT] >= 0) { extended = true; ext.push_back(c[ES_EXT_RIGHT]); }
+      miss = c[ES_MISSING];
+      if (miss > kThresh) trimmed = true;
+      isc[0] += c[ES_INS_C]; isc[1] += c[ES_DEL_C]; isc[2] += c[ES_SUB_C];
+      isu[0] += c[ES_INS_U]; isu[1] += c[ES_DEL_U]; isu[2] += c[ES_SUB_U];
+      TP += c[ES_TP]; FP += c[ES_FP]; FN += c[ES_FN];
+      cors += c[ES_COR]; uncs += c[ES_UNC]; ucors += c[ES_UCOR]; uuncs += c[ES_UUNC];
+      len_cor.push_back(c[ES_LEN_COR]);
+      len_cor_sum += c[ES_LEN_COR];
+      if (c[ES_LEN_REF] == 0 || c[ES_LEN_COR] == 0) { out->flags |= 2; continue; }     // the reference divides by zero here
+      gcr = py_round3((double)c[ES_GC_REF] * 1.0 / (double)c[ES_LEN_REF]);
+      gcc = py_round3((double)c[ES_GC_COR] * 1.0 / (double)c[ES_LEN_COR]);
+      if (split && p == p1 - 1) { miss = c[ES_MISSING_LAST]; emitted = true; }
+      else if (!split) emitted = true;
+    }
+    if (!emitted) continue;
+    if (any) {
+      const bool r0 = TP + FN == 0, q0 = TP + FP == 0, c0 = cors + uncs == 0, u0 = ucors + uuncs == 0;
+      const double rec = r0 ? 0.0 : (double)TP / (double)(TP + FN), prec = q0 ? 0.0 : (double)TP / (double)(TP + FP);
+      const double cbr = c0 ? 0.0 : (double)cors / (double)(cors + uncs), ucbr = u0 ? 0.0 : (double)ucors / (double)(ucors + uuncs);
+      if (miss != 0) missing.push_back(miss);
+      put(r0, rec, " recall\n"); put(q0, prec, " precision\n"); put(c0, cbr, " correct_rate\n");
+      s_rec += rec; s_prec += prec; s_cbr += cbr; s_ucbr += ucbr;
+      total_cor += cors; total_unc += uncs;
+    }
+    s_gcr += gcr; s_gcc += gcc; ++n_gc;
+    if (extended) ++n_ext;
+    if (trimmed && !split) ++n_trim;
+    ++nb;
+  }
+  out->nb_reads = nb;
+  out->throughput = len_cor_sum;
+  out->uncor_throughput = len_unc_sum;
+  out->count_split = n_split; out->count_trimmed = n_trim; out->count_extended = n_ext;
+  for (int k = 0; k < 3; ++k) { out->indelsubs_unc[k] = isu[k]; out->indelsubs_cor[k] = isc[k]; }
+  if (n_gc == 0) out->flags |= 1;                          // round(sum([]) / len([]), 3): ZeroDivisionError in the reference
+  else { out->gc_ref = py_round3(s_gcr / (double)n_gc); out->gc_cor = py_round3(s_gcc / (double)n_gc); }
+  if (nb != 0) {
+    out->recall = s_rec * 1.0 / (double)nb; out->precision = s_prec * 1.0 / (double)nb;
+    out->cor_bases_rate = s_cbr * 1.0 / (double)nb; out->uncor_cor_bases_rate = s_ucbr * 1.0 / (double)nb;
+  } else out->flags |= 4;                                  // the four means are the int 0
+  if (total_cor + total_unc == 0) out->flags |= 1;
+  else {
+    out->error_rate = 1 - ((double)total_cor / (double)(total_cor + total_unc));
+    out->uncor_error_rate = 1 - ((double)total_unc / (double)(total_cor + total_unc));
+  }
+  out->n_missing = (int64_t)missing.size(); out->n_len_cor = (int64_t)len_cor.size(); out->n_extended = (int64_t)ext.size();
+  out->missing_size = to_malloc(missing); out->len_corrected = to_malloc(len_cor); out->extended_bases = to_malloc(ext);
+  out->per_read_bytes = (int64_t)text.size();
+  out->per_read_text = static_cast<char *>(std::malloc(std::max<size_t>(1, text.size())));
+  if (!out->missing_size || !out->len_corrected || !out->extended_bases || !out->per_read_text) {
+    elector_report_free(out);
+    return ELECTOR_E_NOMEM;
+  }
+  std::memcpy(out->per_read_text, text.data(), text.size());
+  return ELECTOR_OK;
+}
+
+extern "C" void elector_report_free(elector_report *r)
+{
+  if (!r) return;
+  std::free(r->missing_size); std::free(r->len_corrected); std::free(r->extended_bases); std::free(r->per_read_text);
+  r->missing_size = r->len_corrected = r->extended_bases = nullptr;
+  r->per_read_text = nullptr;
+}
+
+// The second half of outputReadSizeDistribution (computeStats.py:279-285): the corrected FASTA file again, one line
+// "<n> sequences\n" per record, n = the length of the record's second line less its last character (the newline --
+// or the last base of a file that ends without one); a record whose second line is missing counts 0.  The text goes
+// to `fd`.  Returns the records seen or a negative code.
+extern "C" int64_t elector_read_size_lines(const char *corrected_fasta, int fd)
+{
+  if (!corrected_fasta || fd < 0) return ELECTOR_E_INVAL;
+  std::FILE *f = std::fopen(corrected_fasta, "rb");
+  if (!f) return ELECTOR_E_IO;
+  std::vector<char> buf((size_t)8 << 20);
+  std::string out;
+  out.reserve((size_t)1 << 20);
+  int64_t records = 0, cur = 0;            // cur: bytes of the current line so far (newline included when seen)
+  bool in_seq = false, have_line = false;  // which line of the record we are in; whether the current line has any byte
+  auto flush = [&]() -> bool {
+    size_t at = 0;
+    while (at < out.size()) {
+      const ssize_t w = ::write(fd, out.data() + at, out.size() - at);
+      if (w < 0) return false;
+      at += (size_t)w;
+    }
+    out.clear();
+    return true;
+  };
+  auto end_line = [&](bool with_newline) {
+    // a line ended: cur bytes including the newline when there was one
+    (void)with_newline;
+    if (in_seq) {
+      char num[32];
+      const int64_t n = cur > 0 ? cur - 1 : 0;             // [:-1]
+      out.append(num, (size_t)std::snprintf(num, sizeof num, "%lld sequences\n", (long long)n));
+      ++records;
+    }
+    in_seq = !in_seq;
+    cur = 0;
+    have_line = false;
+  };
+  bool ok = true;
+  for (;;) {
+    const size_t got = std::fread(buf.data(), 1, buf.size(), f);
+    if (got == 0) break;
+    size_t pos = 0;
+    while (pos < got) {
+      const char *nl = static_cast<const char *>(std::memchr(buf.data() + pos, '\n', got - pos));
+      if (!nl) { cur += (int64_t)(got - pos); have_line = true; pos = got; break; }
+      cur += (int64_t)(nl - (buf.data() + pos)) + 1;
+      pos = (size_t)(nl - buf.data()) + 1;
+      end_line(true);
+    }
+    if (out.size() > ((size_t)1 << 20) - 64 && !(ok = flush())) break;
+  }
+  // the file's last line without a newline; a header line without a sequence line behind it counts 0
+  if (ok && have_line) end_line(false);
+  if (ok && in_seq) { cur = 0; end_line(false); }
+  std::fclose(f);
+  if (ok) ok = flush();
+  return ok ? records : (int64_t)ELECTOR_E_IO;
+}

@@ -105,6 +105,34 @@ int64_t elector_homopolymer_pairs(int64_t n_pieces, const uint8_t *rows, const i
                                   const int64_t *cols, const uint8_t *mask, int32_t threshold,
                                   int32_t *pairs, int64_t cap);
 
+/* The host half of call site #2 (elector_amd/csrc/report_host.cpp): what computeMetrics / outputMetrics
+ * (elector/computeStats.py:519-675, 444-468) derive from the per-piece counters -- per-read ratios, their means
+ * (sequential double sums in read order), the totals, the three lists the report needs and the text of
+ * `per_read_metrics.txt` behind its header line (three lines per assessed read, floats printed as Python's repr,
+ * an int 0 where the reference has one).  counters: n_pieces x ES_NCOUNTERS as the statistics entries return them;
+ * read r owns pieces [read_first[r], read_first[r+1]).  flags: bit 0 -- no read was assessed (the reference divides
+ * by zero); bit 1 -- a processed piece without reference or corrected letters (likewise); bit 2 -- nb_reads is 0 (the
+ * four means are the integer 0).  The arrays and the text are malloc'd; elector_report_free releases them. */
+typedef struct elector_report {
+  int64_t nb_reads, throughput, uncor_throughput;
+  double precision, recall, cor_bases_rate, error_rate, uncor_cor_bases_rate, uncor_error_rate;
+  double gc_ref, gc_cor;                       /* round(mean, 3) */
+  int64_t indelsubs_unc[3], indelsubs_cor[3];
+  int64_t count_split, count_trimmed, count_extended;
+  int64_t n_missing, n_len_cor, n_extended;
+  int64_t *missing_size, *len_corrected, *extended_bases;
+  char *per_read_text;
+  int64_t per_read_bytes;
+  int32_t flags, pad;
+} elector_report;
+int  elector_report_aggregate(int64_t n_reads, const int64_t *read_first, int64_t n_pieces, const int64_t *counters,
+                              elector_report *out);
+void elector_report_free(elector_report *r);
+/* The corrected-read lines of the read-size file (outputReadSizeDistribution, computeStats.py:279-285): one line
+ * "<n> sequences\n" per record of the corrected FASTA file, n = length of the record's second line less its last
+ * character, written to `fd`.  Returns the number of records or a negative code. */
+int64_t elector_read_size_lines(const char *corrected_fasta, int fd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,122 @@
+"""The native host half of call site #2 (elector_amd/csrc/report_host.cpp) against its plain-Python restatement
+(tests/agg_ref.py, the loops of computeStats.py:519-675): same tuple -- floats bit for bit, the int 0s where the
+reference has them -- and the same per_read_metrics text (Python's repr of every ratio) on random counters of every
+shape the statistics kernel can return; the read-size lines against the reference's read loop."""
+import io
+import random
+
+import numpy as np
+import pytest
+
+import agg_ref
+from elector_amd import computeStats as cs
+
+
+def random_case(rng, n_reads, p_split=0.3, p_unprocessed=0.15, zeros=False):
+    read_first = [0]
+    rows = []
+    for _ in range(n_reads):
+        nfrag = rng.choice((2, 3, 4)) if rng.random() < p_split else 1
+        for k in range(nfrag):
+            c = [0] * cs.ES_NCOUNTERS
+            big = rng.choice((30, 1000, 10 ** 6, 10 ** 9))
+            for i in (cs.ES_TP, cs.ES_FP, cs.ES_FN, cs.ES_COR, cs.ES_UNC, cs.ES_UCOR, cs.ES_UUNC, cs.ES_INS_U, cs.ES_DEL_U,
+                      cs.ES_SUB_U, cs.ES_INS_C, cs.ES_DEL_C, cs.ES_SUB_C):
+                c[i] = 0 if (zeros and rng.random() < 0.5) else rng.randrange(0, big)
+            c[cs.ES_LEN_REF] = rng.randrange(1, big); c[cs.ES_LEN_COR] = rng.randrange(1, big); c[cs.ES_LEN_UNC] = rng.randrange(1, big)
+            c[cs.ES_GC_REF] = rng.randrange(0, c[cs.ES_LEN_REF] + 1); c[cs.ES_GC_COR] = rng.randrange(0, c[cs.ES_LEN_COR] + 1)
+            c[cs.ES_EXT_LEFT] = rng.choice((-1, -1, -1, 0, 7, 300)); c[cs.ES_EXT_RIGHT] = rng.choice((-1, -1, 0, 12))
+            c[cs.ES_MISSING] = rng.choice((0, 0, 3, 5, 6, 2500)); c[cs.ES_MISSING_LAST] = rng.choice((-1, 0, 9, 44))
+            c[cs.ES_PROCESSED] = 0 if rng.random() < p_unprocessed else 1
+            rows.append(c)
+        read_first.append(len(rows))
+    p = cs.Pieces()
+    p.read_first = np.asarray(read_first, dtype=np.int64)
+    return p, np.asarray(rows, dtype=np.int64).reshape(len(rows), cs.ES_NCOUNTERS)
+
+
+def both(pieces, counters, ratios):
+    a, b = io.StringIO(), io.StringIO()
+    got = cs.aggregate(pieces, counters, ratios, a)
+    exp = agg_ref.aggregate_python(pieces, counters, ratios, b)
+    return got, a.getvalue(), exp, b.getvalue()
+
+
+def same(x, y):
+    if isinstance(y, (list, tuple)):
+        return type(x) is type(y) and len(x) == len(y) and all(same(a, b) for a, b in zip(x, y))
+    return type(x) is type(y) and x == y
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_native_aggregate_equals_python(seed):
+    rng = random.Random(seed)
+    pieces, counters = random_case(rng, rng.choice((1, 2, 50, 3000)), zeros=seed % 2 == 1)
+    ratios = [round(rng.random() * 2, 2) for _ in range(rng.choice((0, 1, 5)))]
+    try:
+        exp = None
+        b = io.StringIO()
+        exp = agg_ref.aggregate_python(pieces, counters, ratios, b)
+    except ZeroDivisionError:
+        with pytest.raises(ZeroDivisionError):
+            cs.aggregate(pieces, counters, ratios, io.StringIO())
+        return
+    a = io.StringIO()
+    got = cs.aggregate(pieces, counters, ratios, a)
+    assert len(got) == len(exp) == 20
+    for i, (x, y) in enumerate(zip(got, exp)):
+        assert same(x, y), (i, x, y)
+    assert a.getvalue() == b.getvalue()
+
+
+def test_float_text_is_pythons_repr():
+    """ratios across the whole range of magnitudes: one read each, recall = TP / (TP + FN)"""
+    rng = random.Random(99)
+    rows, first = [], [0]
+    for _ in range(20000):
+        c = [0] * cs.ES_NCOUNTERS
+        e = rng.randrange(0, 16)                      # sums stay below 2**53: int / int and double / double agree
+        c[cs.ES_TP] = rng.randrange(1, 10 ** rng.randrange(1, 8)); c[cs.ES_FN] = rng.randrange(0, 10 ** e + 1)
+        c[cs.ES_FP] = rng.randrange(0, 3); c[cs.ES_COR] = rng.randrange(0, 10 ** 6); c[cs.ES_UNC] = rng.randrange(0, 4)
+        c[cs.ES_LEN_REF] = c[cs.ES_LEN_COR] = c[cs.ES_LEN_UNC] = 100
+        c[cs.ES_EXT_LEFT] = c[cs.ES_EXT_RIGHT] = c[cs.ES_MISSING_LAST] = -1
+        c[cs.ES_PROCESSED] = 1
+        rows.append(c); first.append(len(rows))
+    p = cs.Pieces()
+    p.read_first = np.asarray(first, dtype=np.int64)
+    got, ta, exp, tb = both(p, np.asarray(rows, dtype=np.int64), [])
+    assert ta == tb and "e-" in ta
+    assert all(same(x, y) for x, y in zip(got, exp))
+
+
+def test_no_assessed_read_divides_by_zero_like_the_reference():
+    p = cs.Pieces()
+    p.read_first = np.asarray([0, 1], dtype=np.int64)
+    c = np.zeros((1, cs.ES_NCOUNTERS), dtype=np.int64)
+    with pytest.raises(ZeroDivisionError):
+        agg_ref.aggregate_python(p, c, [], io.StringIO())
+    with pytest.raises(ZeroDivisionError):
+        cs.aggregate(p, c, [], io.StringIO())
+
+
+def reference_size_lines(path):
+    """the loop of computeStats.py:279-285"""
+    out = []
+    cor = open(path)
+    l = cor.readline()
+    while l != "":
+        l = cor.readline()[:-1]
+        out.append(str(len(l)) + " sequences\n")
+        l = cor.readline()
+    cor.close()
+    return "".join(out)
+
+
+@pytest.mark.parametrize("text", ["", ">a\nACGT\n>b\nAC\n", ">a\nACGT\n>b\nAC", ">a\nACGT\n>b", ">a\nACGT\n>b\n", ">a\n\n>b\n\n",
+                                  ">x\n" + "ACGT" * 5000000 + "\n>y\nA\n", "\n"])
+def test_read_size_distribution(tmp_path, text):
+    (tmp_path / "cor.fa").write_text(text)
+    cs.outputReadSizeDistribution(str(tmp_path / "cor.fa"), "sizes.txt", str(tmp_path), 1, [5, 17])
+    assert (tmp_path / "sizes.txt").read_text() == "size type\n5 reads\n17 reads\n" + reference_size_lines(str(tmp_path / "cor.fa"))
+    cs.outputReadSizeDistribution(str(tmp_path / "cor.fa"), "sizes0.txt", str(tmp_path), 0, [5])
+    assert (tmp_path / "sizes0.txt").read_text() == "size type\n5 reads\n"
