@@ -32,13 +32,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def write_fasta(d, triples, headers):
+def write_fasta(d, triples, headers, repeat=1):
+    """the three sorted files; repeat > 1 writes the reads that many times over under distinct names (longer runs
+    without generating more synthetic reads)"""
     paths = [os.path.join(d, n) for n in ("ref.fa", "cor.fa", "unc.fa")]
     with open(paths[0], "wb") as fr, open(paths[1], "wb") as fc, open(paths[2], "wb") as fu:
-        for (r, c, u), h in zip(triples, headers):
-            fr.write(h + b"\n" + r + b"\n")
-            fc.write(h + b"\n" + c + b"\n")
-            fu.write(h + b"\n" + u + b"\n")
+        for k in range(repeat):
+            tag = b">" if repeat == 1 else b">x%d" % k
+            for (r, c, u), h in zip(triples, headers):
+                hk = tag + h[1:]
+                fr.write(hk + b"\n" + r + b"\n")
+                fc.write(hk + b"\n" + c + b"\n")
+                fu.write(hk + b"\n" + u + b"\n")
     return paths
 
 
@@ -118,16 +123,18 @@ def main(args=None):
     ap.add_argument("--no-reference", action="store_true")
     ap.add_argument("--end-to-end", action="store_true")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--repeat", type=int, default=1, help="write the synthetic reads this many times over (distinct names): "
+                                                          "--reads 40004 --repeat 5 is twenty batches")
     a, _ = ap.parse_known_args()
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench_e2e.py needs a GPU: the HIP path has no CPU fallback")
     from elector_amd import alignment, computeStats, synthetic
     triples, headers, read_of = synthetic.read_pieces(a.profile, a.reads, seed=2000)
-    bases = int(sum(len(t[0]) for t in triples))
+    bases = int(sum(len(t[0]) for t in triples)) * max(1, a.repeat)
     work = tempfile.mkdtemp(prefix="elector_e2e_")
     try:
-        paths = write_fasta(work, triples, headers)
+        paths = write_fasta(work, triples, headers, max(1, a.repeat))
         del triples
         # warm-up on the first batch: context creation, workspace growth to the batch size, first-launch costs
         wdir = os.path.join(work, "warm")
@@ -165,19 +172,23 @@ def main(args=None):
             prof.disable()
             pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(18)
         stages = {k: round(v, 3) for k, v in alignment.STAGE_SECONDS.items()}
-        # the same report from the text file (what call site #2 cost before the counters were handed over)
-        alignment.MSA_CACHE.clear()
-        with redirect_stdout(buf):
-            tup2 = computeStats.outputRecallPrecision(paths[1], outdir, io.StringIO(), small, wrong, 5, 0.1, "sizes.txt", {})
-        t3 = time.perf_counter()
-        assert tup == tup2, "device counters and parsed msa.fa disagree"
+        # the same report from the text file (what call site #2 cost before the counters were handed over); left out
+        # on long runs (the text of twenty batches is 5 GB)
+        t3 = None
+        if a.repeat <= 1 and a.reads <= 50000:
+            alignment.MSA_CACHE.clear()
+            with redirect_stdout(buf):
+                tup2 = computeStats.outputRecallPrecision(paths[1], outdir, io.StringIO(), small, wrong, 5, 0.1, "sizes.txt", {})
+            t3 = time.perf_counter()
+            assert tup == tup2, "device counters and parsed msa.fa disagree"
         out = {
             "metric": "end-to-end Mbases/s: three FASTA files -> getPOA -> outputRecallPrecision (19-tuple)",
             "value": round(bases / (t2 - t0) / 1e6, 3), "unit": "Mbases/s", "n_gpus": 1,
-            "config": {"workload": a.profile, "reads": a.reads, "triples": len(headers), "ref_bases": bases,
+            "config": {"workload": a.profile, "reads": a.reads * max(1, a.repeat), "triples": len(headers) * max(1, a.repeat), "ref_bases": bases,
+                       "batches": (len(headers) * max(1, a.repeat) + 10000) // 10001,
                        "host_threads": a.threads, "msa_fa_bytes": os.path.getsize(outdir + "/msa.fa")},
             "seconds": {"getPOA (wall)": round(t1 - t0, 3), "outputRecallPrecision (wall, device counters)": round(t2 - t1, 3),
-                        "outputRecallPrecision from the text file instead": round(t3 - t2, 3)},
+                        "outputRecallPrecision from the text file instead": None if t3 is None else round(t3 - t2, 3)},
             "getPOA_stage_seconds": stages,
             "device_counters_used": hit,
             "recall": tup[3], "precision": tup[2], "assessed_reads": tup[0],

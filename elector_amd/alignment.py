@@ -78,13 +78,13 @@ def _get_pool(matrix_path=None, n=2):
     return _pool
 
 
-def _get_splitter(device):
-    """the reader thread's engine context: the device splitter works on its own streams and workspace"""
+def _get_splitter(device, k=0):
+    """a splitter thread's engine context: the device splitter works on its own streams and workspace"""
     if os.environ.get("ELECTOR_HOST_SPLIT", "0") not in ("", "0"):
         return None
-    if device not in _splitters:
-        _splitters[device] = PoaEngine(device)
-    return _splitters[device]
+    if (device, k) not in _splitters:
+        _splitters[(device, k)] = PoaEngine(device)
+    return _splitters[(device, k)]
 
 
 def _records(path):
@@ -182,27 +182,40 @@ def _prepare(rb, size_threshold, threads, splitter=None):
         _tick("split (host threads)", t0)
     t0 = time.perf_counter()
     b.win, b.small, b.wrong = win, win.small_reads, win.wrong_reads
-    hdr = [_poa_header(rb.header(int(i))) for i in win.read_index]
+    ridx = np.asarray(win.read_index, dtype=np.int64)
+    ho = np.asarray(rb.hdr_off).tolist()
+    raw = [rb.hdr[ho[i]:ho[i + 1]] for i in ridx.tolist()]
+    # what `poa` prints for the header line; without a blank or tab in the batch's header lines that is the line plus
+    # " untitled" for every read, and two lines are equal exactly when the raw lines are
+    plain = not any(ws in rb.hdr for ws in (b" ", b"\t", b"\r", b"\v", b"\f"))
+    hdr = None if plain else [_poa_header(h) for h in raw]
+    key = raw if plain else hdr
+    n_r = win.n_reads
     # Donatello concatenates consecutive windows with the same header inside one slot file
     # (Donatello.cpp:61-84); the slot is the read's position in its reference batch // 51
     # (Master_Splitter.cpp:366-369,435).  win.read_index = position in this processing batch.
-    groups = [0]
-    for r in range(1, win.n_reads):
-        ka, kb = first_index + int(win.read_index[r - 1]), first_index + int(win.read_index[r])
-        same_slot = (ka // READS_PER_BATCH == kb // READS_PER_BATCH and
-                     (ka % READS_PER_BATCH) // READS_PER_SLOT == (kb % READS_PER_BATCH) // READS_PER_SLOT)
-        if not (same_slot and hdr[r] == hdr[r - 1]):
-            groups.append(r)
-    groups.append(win.n_reads)
-    b.piece_first = np.asarray([win.read_first[g] for g in groups], dtype=np.int64)
-    b.rec_hdr = [_donatello_header(hdr[g]) for g in groups[:-1]]
+    if n_r > 1:
+        k = first_index + ridx
+        same_slot = (k[1:] // READS_PER_BATCH == k[:-1] // READS_PER_BATCH) & \
+                    ((k[1:] % READS_PER_BATCH) // READS_PER_SLOT == (k[:-1] % READS_PER_BATCH) // READS_PER_SLOT)
+        same_hdr = np.fromiter((key[r] == key[r - 1] for r in range(1, n_r)), dtype=bool, count=n_r - 1)
+        groups = np.concatenate([[0], np.nonzero(~(same_slot & same_hdr))[0] + 1, [n_r]]).astype(np.int64)
+    else:
+        groups = np.asarray([0, n_r], dtype=np.int64) if n_r else np.zeros(1, dtype=np.int64)
+    b.piece_first = np.asarray(win.read_first, dtype=np.int64)[groups]
+    if plain:
+        # (">name untitled")[:-11] + " " = the raw line less its last two bytes; a line of one byte is kept whole
+        b.rec_hdr = [(raw[g][:-2] if len(raw[g]) >= 2 else raw[g] + b" untitled") + b" " for g in groups[:-1].tolist()]
+    else:
+        b.rec_hdr = [_donatello_header(hdr[g]) for g in groups[:-1].tolist()]
     # reads for the statistics: runs of records with one header line (computeStats.py:45-56)
-    rf = [0]
-    for p in range(1, len(b.rec_hdr)):
-        if b.rec_hdr[p] != b.rec_hdr[p - 1]:
-            rf.append(p)
-    rf.append(len(b.rec_hdr))
-    b.read_first = np.asarray(rf, dtype=np.int64)
+    rh = b.rec_hdr
+    n_rec = len(rh)
+    if n_rec > 1:
+        diff = np.fromiter((rh[p] != rh[p - 1] for p in range(1, n_rec)), dtype=bool, count=n_rec - 1)
+        b.read_first = np.concatenate([[0], np.nonzero(diff)[0] + 1, [n_rec]]).astype(np.int64)
+    else:
+        b.read_first = np.asarray([0, n_rec], dtype=np.int64) if n_rec else np.zeros(1, dtype=np.int64)
     b.last = False
     _tick("record / read boundaries (host)", t0)
     return b
@@ -313,17 +326,20 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     # must not be appended to); rank 0 appends the parts to msa.fa in rank order, as Donatello appends
     part_path = mergeOut if world == 1 else mergeOut + ".part%d" % rank
 
-    splitter = _get_splitter(engines[0].device)
+    n_split = max(1, int(os.environ.get("ELECTOR_SPLITTERS", "2")))
+    splitters = [_get_splitter(engines[0].device, k) for k in range(n_split)]
     bufs = [_Buffers(dev) for _ in engines]
-    work = queue.Queue(maxsize=2)
+    work = queue.Queue(maxsize=2 * n_split)
     failure = []
 
-    # Two reader threads: one cuts the files into batches (native code), one splits them.  The reader hands out
-    # views of its two buffer sets in turn, so it may be one batch ahead of the splitter and no further: a permit
-    # per buffer set, given back when the splitter is done with a batch.
+    # Threads in front of the main thread: one cuts the files into batches (native code), two split them, each with a
+    # splitter context of its own -- the host's share of a split (reads into pinned staging, waiting for the kernel,
+    # window offsets back, record boundaries) is as long as the kernel, and two batches in flight hide it.  The
+    # batches carry sequence numbers; the main thread takes them in order.  The reader hands out views of its two
+    # buffer sets in turn, so batch i may only be read when batch i - 2 has been split.
     parsed = queue.Queue(maxsize=2)
-    permits = threading.Semaphore(2)
-    stop_all = threading.Event()                   # set when the main thread gives up: both threads wind down
+    split_done = {}                                # sequence number -> Event: the batch's reads are no longer needed
+    stop_all = threading.Event()                   # set when the main thread gives up: the threads wind down
 
     def put(q, item):
         """q.put that gives up when the run is being abandoned"""
@@ -335,51 +351,73 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
                 pass
         return False
 
+    def wait_for(ev):
+        while not stop_all.is_set():
+            if ev.wait(timeout=0.2):
+                return True
+        return False
+
+    readers_left = [n_split]
+    readers_lock = threading.Lock()
+    splitter_done = threading.Event()
+
     def parser():
         import time
         try:
             rf = split.ReadsFile(reference, uncorrected, corrected)
             try:
+                seq = 0
                 while not stop_all.is_set():
-                    if not permits.acquire(timeout=0.2):
-                        continue
+                    if seq >= 2 and not wait_for(split_done[seq - 2]):
+                        break
                     t0 = time.perf_counter()
                     rb = rf.next(READS_PER_BATCH, start, stop)
                     _tick("parse FASTA (parser thread, native)", t0)
-                    if not put(parsed, rb) or rb is None:
+                    if rb is None:
                         break
-                # the last batches may still be in use: the file stays open until the splitter is through
+                    split_done[seq] = threading.Event()
+                    if not put(parsed, (seq, rb)):
+                        break
+                    seq += 1
+                for _ in range(n_split):
+                    put(parsed, None)
+                # the last batches may still be in use: the file stays open until the splitters are through
                 splitter_done.wait()
             finally:
                 rf.close()
         except BaseException as e:           # noqa: BLE001 -- handed to the main thread
             failure.append(e)
-            put(parsed, None)
+            for _ in range(n_split):
+                put(parsed, None)
 
-    splitter_done = threading.Event()
-
-    def reader():
+    def reader(k):
         try:
             while not stop_all.is_set():
                 try:
-                    rb = parsed.get(timeout=0.2)
+                    item = parsed.get(timeout=0.2)
                 except queue.Empty:
                     continue
-                if rb is None or failure:
+                if item is None or failure:
                     break
-                if not put(work, _prepare(rb, SIZE_CORRECTED_READ_THRESHOLD, threads, splitter)):
+                seq, rb = item
+                b = _prepare(rb, SIZE_CORRECTED_READ_THRESHOLD, threads, splitters[k])
+                split_done[seq].set()
+                if not put(work, (seq, b)):
                     break
-                permits.release()
         except BaseException as e:           # noqa: BLE001 -- handed to the main thread
             failure.append(e)
-        splitter_done.set()
-        permits.release()
+            stop_all.set()
+        with readers_lock:
+            readers_left[0] -= 1
+            if readers_left[0] == 0:
+                splitter_done.set()
         put(work, None)
 
     tp = threading.Thread(target=parser, daemon=True)
     tp.start()
-    th = threading.Thread(target=reader, daemon=True)
-    th.start()
+    ths = [threading.Thread(target=reader, args=(k,), daemon=True) for k in range(n_split)]
+    for t_ in ths:
+        t_.start()
 
     small_reads = wrongly_cor_reads = 0
     skipped = 0
@@ -389,100 +427,181 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     all_hdr, all_cols, all_counters, all_read_first = [], [], [], [0]
     last_rows = last_mask = None
     cache_ok = not existed
-    pending = []                                   # (engine index, batch, n_pieces, last_cap)
+    # A batch's second half -- wait for its kernels, merged rows to the host, the records into the file -- belongs
+    # to a writer thread: the main thread only classifies and enqueues, so the next batch's kernels are queued while
+    # the previous batch's 265 MB of records are still on their way to the page cache.  One writer, jobs in batch
+    # order: the file is written in order.  A context takes its next batch when its previous job is through
+    # (its output buffers and its statistics slot are busy until then).
+    jobs = queue.Queue()
+    job_done = [None] * len(engines)                # per context: Event of its job in flight
+    write_at = [0]                                   # end of the output file (the descriptor is not in append mode)
 
-    def finish(out):
+    write_turn = [0]                                 # job number whose place in the file is assigned next
+    write_cv = threading.Condition()
+
+    def finish(fd, jno, e, b, npieces, last_cap):
         nonlocal skipped, last_rows, last_mask, cache_ok
         import time
-        e, b, npieces, last_cap = pending.pop(0)
         eng = engines[e]
         t0 = time.perf_counter()
         counters, piece_cols, lrows, lmask = eng.msa_stats_collect(npieces, last_cap)
         status = bufs[e].status[: b.win.n_windows].cpu().numpy()
-        _tick("wait for the GPU (kernels not hidden behind host work)", t0)
-        t0 = time.perf_counter()
+        _tick("wait for the GPU (writer threads)", t0)
         drop = np.zeros(npieces, dtype=bool)
-        if status.any():
-            bad = np.nonzero(status)[0]
-            if parity != "skip":
-                raise ElectorError(-7, "window %d of the batch starting at read %d: status %d"
-                                   % (int(bad[0]), b.first_index, int(status[bad[0]])))
+        bad = np.nonzero(status)[0] if status.any() else None
+        if bad is not None and parity == "skip":
             drop[np.unique(np.searchsorted(b.piece_first, bad, side="right") - 1)] = True
-            skipped += int(drop.sum())
-            cache_ok = False                       # the counters of a read's other pieces saw the dropped one
+        # the records' place in the file and the run's bookkeeping, in job order; the bytes themselves -- rows to the
+        # host, formatting, the copy into the page cache -- need no order and overlap with the next job's
+        hl = np.fromiter((len(h) for h in b.rec_hdr), dtype=np.int64, count=npieces)
+        nbytes = int((3 * (hl + piece_cols + 2))[~drop].sum())
+        with write_cv:
+            while write_turn[0] != jno and not stop_all.is_set():
+                write_cv.wait(timeout=0.2)
+            try:
+                if bad is not None and parity != "skip":
+                    raise ElectorError(-7, "window %d of the batch starting at read %d: status %d"
+                                       % (int(bad[0]), b.first_index, int(status[bad[0]])))
+                at = write_at[0]
+                write_at[0] += nbytes
+                if drop.any():
+                    skipped += int(drop.sum())
+                    cache_ok = False               # the counters of a read's other pieces saw the dropped one
+                all_hdr.extend(b.rec_hdr)
+                all_cols.append(piece_cols)
+                all_counters.append(counters)
+                base = all_read_first[-1]
+                all_read_first.extend((base + b.read_first[1:]).tolist())
+                if lrows is not None and npieces:
+                    nl = int(piece_cols[int(b.read_first[-2]):].sum())          # columns of the batch's last read
+                    last_rows, last_mask = lrows[:3 * nl].copy(), lmask[:nl].copy()
+                with open(outDir + "/small_reads.txt", "w") as f:
+                    f.write(str(b.small) + "\n")
+                with open(outDir + "/wrongly_cor_reads.txt", "w") as f:
+                    f.write(str(b.wrong) + "\n")
+            finally:
+                write_turn[0] = jno + 1
+                write_cv.notify_all()
+        t0 = time.perf_counter()
         # merged rows -> pinned host memory -> Donatello's records -> the file, in the library
-        out.flush()
-        split.msa_records_write(eng, piece_cols, b.rec_hdr, drop if drop.any() else None, out.fileno(),
-                                nthreads=max(1, min(16, int(threads))))
-        _tick("merged rows D2H + write msa.fa (native)", t0)
-        all_hdr.extend(b.rec_hdr)
-        all_cols.append(piece_cols)
-        all_counters.append(counters)
-        base = all_read_first[-1]
-        all_read_first.extend((base + b.read_first[1:]).tolist())
-        if lrows is not None and npieces:
-            nl = int(piece_cols[int(b.read_first[-2]):].sum())          # columns of the batch's last read
-            last_rows, last_mask = lrows[:3 * nl].copy(), lmask[:nl].copy()
-        with open(outDir + "/small_reads.txt", "w") as f:
-            f.write(str(b.small) + "\n")
-        with open(outDir + "/wrongly_cor_reads.txt", "w") as f:
-            f.write(str(b.wrong) + "\n")
+        got = split.msa_records_pwrite(eng, piece_cols, b.rec_hdr, drop if drop.any() else None, fd, at,
+                                       nthreads=max(1, min(16, int(threads))))
+        if got != nbytes:
+            raise ElectorError(-1, "msa.fa: %d bytes written where %d were reserved" % (got, nbytes))
+        _tick("merged rows D2H + write msa.fa (writer threads, native)", t0)
         sys.stdout.write('-' * 200)
         sys.stdout.flush()
 
+    def writer(fd):
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            done = job[-1]
+            try:
+                if not failure:
+                    finish(fd, *job[:-1])
+                else:
+                    with write_cv:                # keep the turn moving for the jobs behind
+                        write_turn[0] = max(write_turn[0], job[0] + 1)
+                        write_cv.notify_all()
+            except BaseException as e:       # noqa: BLE001 -- handed to the main thread
+                failure.append(e)
+                stop_all.set()
+            finally:
+                done.set()
+
+    # Donatello appends (Donatello.cpp:48); a rank's part of a multi-rank run starts from scratch
+    fd = os.open(part_path, os.O_WRONLY | os.O_CREAT | (os.O_TRUNC if world > 1 else 0), 0o666)
+    write_at[0] = os.fstat(fd).st_size
+    n_writers = max(1, min(len(engines), int(os.environ.get("ELECTOR_WRITERS", "2"))))
+    tws = [threading.Thread(target=writer, args=(fd,), daemon=True) for _ in range(n_writers)]
+    for t_ in tws:
+        t_.start()
+    n_jobs = 0
     turn = 0
-    try:
-        with open(part_path, "ab" if world == 1 else "wb") as out:
-            while True:
-                b = work.get()
+    ready, next_seq, ended = {}, 0, 0
+
+    def batches_in_order():
+        """the split batches as the files hold them, whichever splitter thread finished first"""
+        nonlocal next_seq, ended
+        while True:
+            while next_seq in ready:
+                yield ready.pop(next_seq)
+                next_seq += 1
+            if ended == n_split:
+                if ready:
+                    raise RuntimeError("getPOA: a batch went missing between the splitter threads")
+                return
+            try:
+                item = work.get(timeout=0.2)
+            except queue.Empty:
                 if failure:
                     raise failure[0]
-                if b is None:
-                    break
-                small_reads += b.small
-                wrongly_cor_reads += b.wrong
-                win = b.win
-                if win.n_windows == 0:
-                    continue
-                e = turn % len(engines)
-                turn += 1
-                # one job per context at a time: its buffers and its statistics slot are busy until collected
-                while any(p[0] == e for p in pending):
-                    finish(out)
+                continue
+            if failure:
+                raise failure[0]
+            if item is None:
+                ended += 1
+            else:
+                ready[item[0]] = item[1]
+
+    try:
+        for b in batches_in_order():
+            if failure:
+                raise failure[0]
+            small_reads += b.small
+            wrongly_cor_reads += b.wrong
+            win = b.win
+            if win.n_windows == 0:
+                continue
+            e = turn % len(engines)
+            turn += 1
+            # one job per context at a time: its buffers and its statistics slot are busy until the writer is through
+            if job_done[e] is not None:
                 import time
-                buf = bufs[e]
-                total = int(win.off[-1])
                 t0 = time.perf_counter()
-                buf.fit(total, win.n_windows, own_bases=b.d_bases is None)
-                if b.d_bases is None:
-                    buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
-                    _tick("windows H2D", t0)
-                bases = buf.bases if b.d_bases is None else b.d_bases
-                buf.held = bases                       # the batch's own tensor lives until the context's next batch
-                t0 = time.perf_counter()
-                engines[e].align_device(bases, win.off, buf.cols, buf.ncol, buf.status)
-                npieces = engines[e].msa_stats_enqueue(win.n_windows, buf.cols, buf.ncol, buf.status, b.piece_first,
-                                                       b.read_first)
-                _tick("classify + enqueue kernels (host)", t0)
-                # rows + mask of the batch's last read, for the homopolymer ratio of the run's last read
-                p0 = int(b.read_first[-2])
-                w0 = int(b.piece_first[p0])
-                last_cap = int(win.off[-1] - win.off[3 * w0]) + 16
-                pending.append((e, b, npieces, last_cap))
-                # while the splitter is still busy with the next batch, the oldest jobs' records go to the file
-                # (their kernels are short against a split); otherwise every write would wait for the end
-                while pending and work.empty():
-                    finish(out)
-            while pending:
-                finish(out)
+                job_done[e].wait()
+                _tick("wait for the writer (main thread)", t0)
+                if failure:
+                    raise failure[0]
+            import time
+            buf = bufs[e]
+            total = int(win.off[-1])
+            t0 = time.perf_counter()
+            buf.fit(total, win.n_windows, own_bases=b.d_bases is None)
+            if b.d_bases is None:
+                buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
+                _tick("windows H2D", t0)
+            bases = buf.bases if b.d_bases is None else b.d_bases
+            buf.held = bases                       # the batch's own tensor lives until the context's next batch
+            t0 = time.perf_counter()
+            engines[e].align_device(bases, win.off, buf.cols, buf.ncol, buf.status)
+            npieces = engines[e].msa_stats_enqueue(win.n_windows, buf.cols, buf.ncol, buf.status, b.piece_first,
+                                                   b.read_first)
+            _tick("classify + enqueue kernels (host)", t0)
+            # rows + mask of the batch's last read, for the homopolymer ratio of the run's last read
+            p0 = int(b.read_first[-2])
+            w0 = int(b.piece_first[p0])
+            last_cap = int(win.off[-1] - win.off[3 * w0]) + 16
+            job_done[e] = threading.Event()
+            jobs.put((n_jobs, e, b, npieces, last_cap, job_done[e]))
+            n_jobs += 1
     finally:
-        # whatever happened, the two threads end and give their buffers, files and device memory back
+        # whatever happened, the threads end and give their buffers, files and device memory back
+        for _ in tws:
+            jobs.put(None)
+        for t_ in tws:
+            t_.join()
+        os.close(fd)
         stop_all.set()
-        th.join()
+        splitter_done.set()
+        for t_ in ths:
+            t_.join()
         tp.join()
-        for e, *_ in pending:
+        for g in engines:
             try:
-                engines[e].sync()
+                g.sync()
             except ElectorError:
                 pass
     if failure:

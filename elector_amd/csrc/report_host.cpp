@@ -20,7 +20,11 @@
 #include <string>
 #include <vector>
 
+#include <thread>
+
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 namespace {
@@ -189,58 +193,90 @@ extern "C" void elector_report_free(elector_report *r)
 // The second half of outputReadSizeDistribution (computeStats.py:279-285): the corrected FASTA file again, one line
 // "<n> sequences\n" per record, n = the length of the record's second line less its last character (the newline --
 // or the last base of a file that ends without one); a record whose second line is missing counts 0.  The text goes
-// to `fd`.  Returns the records seen or a negative code.
+// to `fd`.  The file is mapped and cut into ranges for a handful of threads: a first pass counts the line ends of
+// every range (which line of a record a range starts in follows from the counts before it), a second pass prints the
+// sequence lines that END in the range.  Returns the records seen or a negative code.
 extern "C" int64_t elector_read_size_lines(const char *corrected_fasta, int fd)
 {
   if (!corrected_fasta || fd < 0) return ELECTOR_E_INVAL;
-  std::FILE *f = std::fopen(corrected_fasta, "rb");
-  if (!f) return ELECTOR_E_IO;
-  std::vector<char> buf((size_t)8 << 20);
-  std::string out;
-  out.reserve((size_t)1 << 20);
-  int64_t records = 0, cur = 0;            // cur: bytes of the current line so far (newline included when seen)
-  bool in_seq = false, have_line = false;  // which line of the record we are in; whether the current line has any byte
-  auto flush = [&]() -> bool {
+  const int in = ::open(corrected_fasta, O_RDONLY);
+  if (in < 0) return ELECTOR_E_IO;
+  struct stat st;
+  if (::fstat(in, &st) != 0) { ::close(in); return ELECTOR_E_IO; }
+  const int64_t size = (int64_t)st.st_size;
+  if (size == 0) { ::close(in); return 0; }
+  void *map = ::mmap(nullptr, (size_t)size, PROT_READ, MAP_PRIVATE, in, 0);
+  ::close(in);
+  if (map == MAP_FAILED) return ELECTOR_E_IO;
+  const char *data = static_cast<const char *>(map);
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, (int64_t)std::thread::hardware_concurrency()), size >> 24));
+  std::vector<int64_t> cut((size_t)nt + 1), nls((size_t)nt, 0);
+  for (int t = 0; t <= nt; ++t) cut[(size_t)t] = size * t / nt;
+  auto count = [&](int t) {
+    int64_t c = 0;
+    const char *p = data + cut[(size_t)t], *e = data + cut[(size_t)t + 1];
+    while (p < e) {
+      const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(e - p)));
+      if (!nl) break;
+      ++c;
+      p = nl + 1;
+    }
+    nls[(size_t)t] = c;
+  };
+  auto run = [&](auto &&fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (auto &x : th) x.join();
+  };
+  run(count);
+  std::vector<int64_t> before((size_t)nt + 1, 0);        // line ends in front of a range = index of the line it starts in
+  for (int t = 0; t < nt; ++t) before[(size_t)t + 1] = before[(size_t)t] + nls[(size_t)t];
+  std::vector<std::string> parts((size_t)nt);
+  auto emit = [&](int t) {
+    std::string &out = parts[(size_t)t];
+    out.reserve((size_t)nls[(size_t)t] * 10 + 64);
+    int64_t line = before[(size_t)t];                      // 0-based index of the line that contains the range's first byte
+    const char *p = data + cut[(size_t)t], *e = data + cut[(size_t)t + 1];
+    // start of that line: behind the last line end in front of the range
+    const char *ls = p;
+    while (ls > data && ls[-1] != '\n') --ls;
+    char num[32];
+    while (p < e) {
+      const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(e - p)));
+      if (!nl) break;
+      if (line & 1) {                                      // a record's second line: its length with the newline, less one
+        const int64_t n = (int64_t)(nl - ls);
+        out.append(num, (size_t)std::snprintf(num, sizeof num, "%lld sequences\n", (long long)n));
+      }
+      ++line;
+      p = ls = nl + 1;
+    }
+  };
+  run(emit);
+  int64_t records = before[(size_t)nt] / 2;
+  // the file's tail behind its last line end: a sequence line without a newline loses its last base instead; a header
+  // line without a sequence line behind it counts 0
+  {
+    const int64_t lines = before[(size_t)nt];
+    const char *ls = data + size;
+    while (ls > data && ls[-1] != '\n') --ls;
+    const int64_t tail = (int64_t)(data + size - ls);
+    char num[32];
+    std::string &out = parts[(size_t)nt - 1];
+    if (tail > 0) {
+      if (lines & 1) { out.append(num, (size_t)std::snprintf(num, sizeof num, "%lld sequences\n", (long long)(tail - 1))); ++records; }
+      else { out.append("0 sequences\n"); ++records; }   // a header, nothing behind it
+    } else if (lines & 1) { out.append("0 sequences\n"); ++records; }   // the last line was a header line
+  }
+  ::munmap(map, (size_t)size);
+  for (const std::string &o : parts) {
     size_t at = 0;
-    while (at < out.size()) {
-      const ssize_t w = ::write(fd, out.data() + at, out.size() - at);
-      if (w < 0) return false;
+    while (at < o.size()) {
+      const ssize_t w = ::write(fd, o.data() + at, o.size() - at);
+      if (w < 0) return ELECTOR_E_IO;
       at += (size_t)w;
     }
-    out.clear();
-    return true;
-  };
-  auto end_line = [&](bool with_newline) {
-    // a line ended: cur bytes including the newline when there was one
-    (void)with_newline;
-    if (in_seq) {
-      char num[32];
-      const int64_t n = cur > 0 ? cur - 1 : 0;             // [:-1]
-      out.append(num, (size_t)std::snprintf(num, sizeof num, "%lld sequences\n", (long long)n));
-      ++records;
-    }
-    in_seq = !in_seq;
-    cur = 0;
-    have_line = false;
-  };
-  bool ok = true;
-  for (;;) {
-    const size_t got = std::fread(buf.data(), 1, buf.size(), f);
-    if (got == 0) break;
-    size_t pos = 0;
-    while (pos < got) {
-      const char *nl = static_cast<const char *>(std::memchr(buf.data() + pos, '\n', got - pos));
-      if (!nl) { cur += (int64_t)(got - pos); have_line = true; pos = got; break; }
-      cur += (int64_t)(nl - (buf.data() + pos)) + 1;
-      pos = (size_t)(nl - buf.data()) + 1;
-      end_line(true);
-    }
-    if (out.size() > ((size_t)1 << 20) - 64 && !(ok = flush())) break;
   }
-  // the file's last line without a newline; a header line without a sequence line behind it counts 0
-  if (ok && have_line) end_line(false);
-  if (ok && in_seq) { cur = 0; end_line(false); }
-  std::fclose(f);
-  if (ok) ok = flush();
-  return ok ? records : (int64_t)ELECTOR_E_IO;
+  return records;
 }

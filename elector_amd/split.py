@@ -77,6 +77,9 @@ def _lib():
         L.elector_msa_records_write.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_int]
         L.elector_msa_records_write.restype = C.c_int64
+        L.elector_msa_records_pwrite.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_int, C.c_int64, C.c_int]
+        L.elector_msa_records_pwrite.restype = C.c_int64
         L._split_bound = True
     return L
 
@@ -322,6 +325,20 @@ def msa_records_write(engine, piece_cols, headers, drop, fd, nthreads=1):
     d = None if drop is None else np.ascontiguousarray(drop, dtype=np.uint8)
     got = L.elector_msa_records_write(engine._h, len(piece_cols), piece_cols.ctypes.data, hdr.ctypes.data, hdr_off.ctypes.data,
                                       d.ctypes.data if d is not None else None, int(fd), int(nthreads))
+    if got < 0:
+        raise ElectorError(int(got), L.elector_ctx_last_error(engine._h).decode())
+    return int(got)
+
+
+def msa_records_pwrite(engine, piece_cols, headers, drop, fd, offset, nthreads=1):
+    """msa_records_write at byte `offset` of a descriptor opened without O_APPEND, the page-cache copy on `nthreads`
+    threads (include/elector_split.h: elector_msa_records_pwrite) -> bytes written"""
+    L = _lib()
+    piece_cols = np.ascontiguousarray(piece_cols, dtype=np.int64)
+    hdr, hdr_off = pack_headers(headers)
+    d = None if drop is None else np.ascontiguousarray(drop, dtype=np.uint8)
+    got = L.elector_msa_records_pwrite(engine._h, len(piece_cols), piece_cols.ctypes.data, hdr.ctypes.data, hdr_off.ctypes.data,
+                                       d.ctypes.data if d is not None else None, int(fd), int(offset), int(nthreads))
     if got < 0:
         raise ElectorError(int(got), L.elector_ctx_last_error(engine._h).decode())
     return int(got)

@@ -115,6 +115,11 @@ int64_t elector_msa_format(int64_t n_pieces, const uint8_t *rows, const int64_t 
 int64_t elector_msa_records_write(elector_ctx *ctx, int64_t n_pieces, const int64_t *piece_cols, const uint8_t *hdr,
                                   const int64_t *hdr_off, const uint8_t *drop, int fd, int nthreads);
 
+/* ... at byte `offset` of a descriptor opened without O_APPEND (the caller keeps the end-of-file position), the copy
+ * into the page cache spread over `nthreads` threads (one pwrite each) */
+int64_t elector_msa_records_pwrite(elector_ctx *ctx, int64_t n_pieces, const int64_t *piece_cols, const uint8_t *hdr,
+                                   const int64_t *hdr_off, const uint8_t *drop, int fd, int64_t offset, int nthreads);
+
 /* Merged per-read MSA (what Donatello appends to msa.fa): for emitted read r the
  * three rows each have read_cols[r] columns; columns whose corrected letter is
  * 'n' are dropped (Donatello.cpp:13-31). */

@@ -120,3 +120,16 @@ def test_read_size_distribution(tmp_path, text):
     assert (tmp_path / "sizes.txt").read_text() == "size type\n5 reads\n17 reads\n" + reference_size_lines(str(tmp_path / "cor.fa"))
     cs.outputReadSizeDistribution(str(tmp_path / "cor.fa"), "sizes0.txt", str(tmp_path), 0, [5])
     assert (tmp_path / "sizes0.txt").read_text() == "size type\n5 reads\n"
+
+
+def test_read_size_distribution_large_file_many_threads(tmp_path):
+    """a file large enough for the scan to run on several threads (16 MB per thread), lines of every small length,
+    no newline at the end"""
+    rng = random.Random(5)
+    rec = [">r%d\n%s\n" % (i, "ACGT" * rng.randrange(0, 12) + "A" * rng.randrange(0, 4)) for i in range(20000)]
+    text = "".join(rec) * 90
+    text = text[:-1]
+    assert len(text) > 48 << 20
+    (tmp_path / "cor.fa").write_text(text)
+    cs.outputReadSizeDistribution(str(tmp_path / "cor.fa"), "sizes.txt", str(tmp_path), 3, [])
+    assert (tmp_path / "sizes.txt").read_text() == "size type\n" + reference_size_lines(str(tmp_path / "cor.fa"))
