@@ -20,7 +20,10 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 
@@ -52,6 +55,7 @@ struct BigBuf {
   }
   size_t size() const { return n; }
   void resize(size_t m) { n = m; }              // shrink only
+  void resize_to(size_t m) { n = m; }           // after reserve(m): the bytes are written by the caller
   void clear() { n = 0; }
   char *data() { return p; }
 };
@@ -140,46 +144,76 @@ void record_key(const char *h, size_t n, std::string &key)
   record_key(tmp, key);
 }
 
+// a file mapped read-only and walked line by line: the lines are handed out as spans of the mapping, nothing is copied
+struct MapFile {
+  const char *data = nullptr;
+  size_t size = 0, pos = 0;
+  bool open(const char *path)
+  {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) != 0) { ::close(fd); return false; }
+    size = (size_t)st.st_size;
+    if (size) {
+      void *m = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { ::close(fd); return false; }
+      (void)::madvise(m, size, MADV_SEQUENTIAL);
+      data = static_cast<const char *>(m);
+    }
+    ::close(fd);
+    return true;
+  }
+  void close() { if (data) ::munmap(const_cast<char *>(data), size); data = nullptr; size = pos = 0; }
+  // the next line without its '\n'; false at the end of the file (python's readline() returning b"")
+  bool line(const char *&p, size_t &n)
+  {
+    if (pos >= size) { p = data + size; n = 0; return false; }
+    const char *b = data + pos;
+    const char *nl = static_cast<const char *>(std::memchr(b, '\n', size - pos));
+    p = b;
+    if (nl) { n = (size_t)(nl - b); pos = (size_t)(nl - data) + 1; }
+    else { n = size - pos; pos = size; }
+    return true;
+  }
+  bool skip_line() { const char *p; size_t n; return line(p, n); }
+};
+
 struct Reader {
-  LineFile ref, unc, cor;
+  MapFile ref, unc, cor;
   int64_t k = 0;              // kept records read so far
   bool done = false;
-  // The batch under construction / handed out lives in one of two buffer sets, used in turn: the batch handed out
-  // by a call stays valid until the call after the next one, so a caller can read batch i + 1 while another thread
-  // still works on batch i.  A record read ahead of a batch's end opens the next batch (copied across).
+  // a kept record: its reference header line and the three sequence lines, as spans of the mappings
+  struct Rec { const char *h, *s[3]; size_t hl, sl[3]; };
+  // The batch handed out lives in one of two buffer sets, used in turn: the batch handed out by a call stays valid
+  // until the call after the next one, so a caller can read batch i + 1 while another thread still works on batch i.
+  // A record read ahead of a batch's end opens the next batch.
   struct Set {
     BigBuf seq, hdr;
     std::vector<int64_t> seq_off, hdr_off;
-    void clear() { seq.clear(); hdr.clear(); seq_off.assign(1, 0); hdr_off.assign(1, 0); }
   } set[2];
   int cur = 0;
   bool has_pending = false;
+  Rec pending;
+  std::vector<Rec> recs;      // the batch under construction
   std::string last_key, key;
-  // appends the next kept record to the current set; false at the end of any of the three files
-  bool next()
+  // the next kept record; false at the end of any of the three files
+  bool next(Rec &r)
   {
-    BigBuf &seq = set[cur].seq, &hdr = set[cur].hdr;
-    std::vector<int64_t> &seq_off = set[cur].seq_off, &hdr_off = set[cur].hdr_off;
     for (;;) {
-      const size_t s0 = seq.size(), h0 = hdr.size();
-      if (!ref.append_line(hdr)) return false;
-      ref.append_line(seq);                         // python: a header line without a sequence line gives an empty sequence
-      if (seq.size() - s0 <= 2) {                   // Master_Splitter.cpp:414 -- skipped without counting; the other
-        seq.resize(s0); hdr.resize(h0);             // two files advance by one record all the same
-        if (!unc.skip_line()) return false;
+      if (!ref.line(r.h, r.hl)) return false;
+      if (!ref.line(r.s[0], r.sl[0])) { r.s[0] = ref.data + ref.size; r.sl[0] = 0; }   // python: a header line without a sequence line gives an empty sequence
+      if (r.sl[0] <= 2) {                             // Master_Splitter.cpp:414 -- skipped without counting; the other
+        if (!unc.skip_line()) return false;           // two files advance by one record all the same
         unc.skip_line();
         if (!cor.skip_line()) return false;
         cor.skip_line();
         continue;
       }
-      const size_t s1 = seq.size();
-      bool ok = unc.skip_line();
-      if (ok) { unc.append_line(seq); }
-      const size_t s2 = seq.size();
-      if (ok) { ok = cor.skip_line(); if (ok) cor.append_line(seq); }
-      if (!ok) { seq.resize(s0); hdr.resize(h0); return false; }
-      seq_off.push_back((int64_t)s1); seq_off.push_back((int64_t)s2); seq_off.push_back((int64_t)seq.size());
-      hdr_off.push_back((int64_t)hdr.size());
+      if (!unc.skip_line()) return false;
+      if (!unc.line(r.s[1], r.sl[1])) { r.s[1] = unc.data + unc.size; r.sl[1] = 0; }
+      if (!cor.skip_line()) return false;
+      if (!cor.line(r.s[2], r.sl[2])) { r.s[2] = cor.data + cor.size; r.sl[2] = 0; }
       return true;
     }
   }
@@ -197,7 +231,6 @@ extern "C" int elector_reads_open(const char *reference, const char *uncorrected
     delete rd;
     return ELECTOR_E_INVAL;
   }
-  rd->set[0].clear(); rd->set[1].clear();
   *handle = rd;
   return ELECTOR_OK;
 }
@@ -215,53 +248,71 @@ extern "C" int elector_reads_next(void *handle, int64_t min_records, int64_t sta
   Reader *rd = static_cast<Reader *>(handle);
   if (!rd || !out || min_records < 1) return ELECTOR_E_INVAL;
   std::memset(out, 0, sizeof *out);
-  // the other buffer set takes the new batch; the record read ahead (if any) is copied to its front
-  {
-    Reader::Set &old = rd->set[rd->cur];
-    rd->cur ^= 1;
-    Reader::Set &now = rd->set[rd->cur];
-    now.clear();
-    const size_t nrec = old.hdr_off.size() - 1;
-    if (rd->has_pending && nrec >= 1) {
-      const int64_t s0 = old.seq_off[3 * (nrec - 1)], h0 = old.hdr_off[nrec - 1];
-      const int64_t so[3] = {old.seq_off[3 * nrec - 2] - s0, old.seq_off[3 * nrec - 1] - s0, old.seq_off[3 * nrec] - s0};
-      const int64_t hl = old.hdr_off[nrec] - h0;
-      if (!now.seq.append(old.seq.data() + s0, (size_t)so[2]) || !now.hdr.append(old.hdr.data() + h0, (size_t)hl)) return ELECTOR_E_NOMEM;
-      now.seq_off.assign({0, so[0], so[1], so[2]});
-      now.hdr_off.assign({0, hl});
-    } else rd->has_pending = false;
-  }
+  rd->cur ^= 1;                                    // the other buffer set takes the new batch
   Reader::Set &S = rd->set[rd->cur];
+  S.seq.clear(); S.hdr.clear(); S.seq_off.assign(1, 0); S.hdr_off.assign(1, 0);
   if (rd->done && !rd->has_pending) return ELECTOR_OK;
-  int64_t n = 0, first = -1;
+  // ---- which records: the sequential part, on spans (no byte is copied here) ----
+  std::vector<Reader::Rec> &recs = rd->recs;
+  recs.clear();
+  int64_t first = -1;
   bool ended = rd->done;
   for (;;) {
+    Reader::Rec r;
     int64_t index;
-    if (rd->has_pending) { rd->has_pending = false; index = rd->k - 1; }
+    if (rd->has_pending) { rd->has_pending = false; r = rd->pending; index = rd->k - 1; }
     else {
-      if (ended || !rd->next()) { ended = true; break; }
+      if (ended || !rd->next(r)) { ended = true; break; }
       index = rd->k++;
     }
-    auto drop_last = [&]() {
-      const size_t nrec = S.hdr_off.size() - 1;
-      S.seq.resize((size_t)S.seq_off[3 * (nrec - 1)]); S.hdr.resize((size_t)S.hdr_off[nrec - 1]);
-      S.seq_off.resize(3 * (nrec - 1) + 1); S.hdr_off.resize(nrec);
-    };
-    if (stop >= 0 && index >= stop) { drop_last(); ended = true; break; }
-    if (index < start) { drop_last(); continue; }
-    const size_t nrec = S.hdr_off.size() - 1;
-    record_key(S.hdr.data() + S.hdr_off[nrec - 1], (size_t)(S.hdr_off[nrec] - S.hdr_off[nrec - 1]), rd->key);
-    if (n >= min_records && rd->key != rd->last_key) {       // the batch ends before this record
+    if (stop >= 0 && index >= stop) { ended = true; break; }
+    if (index < start) continue;
+    record_key(r.h, r.hl, rd->key);
+    if ((int64_t)recs.size() >= min_records && rd->key != rd->last_key) {       // the batch ends before this record
       rd->has_pending = true;
+      rd->pending = r;
       break;
     }
     if (first < 0) first = index;
-    ++n;
+    recs.push_back(r);
     rd->last_key = rd->key;
   }
   if (ended) rd->done = true;
-  if (rd->ref.oom || rd->unc.oom || rd->cor.oom) return ELECTOR_E_NOMEM;
-  out->n = n;
+  // ---- the bytes: offsets by a prefix sum, the copies on several threads (equal shares of the bytes) ----
+  const size_t n = recs.size();
+  S.seq_off.resize(3 * n + 1);
+  S.hdr_off.resize(n + 1);
+  size_t at = 0, hat = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const Reader::Rec &r = recs[i];
+    S.hdr_off[i] = (int64_t)hat; hat += r.hl;
+    for (int q = 0; q < 3; ++q) { S.seq_off[3 * i + q] = (int64_t)at; at += r.sl[q]; }
+  }
+  S.seq_off[3 * n] = (int64_t)at;
+  S.hdr_off[n] = (int64_t)hat;
+  if (!S.seq.reserve(at + 1) || !S.hdr.reserve(hat + 1)) return ELECTOR_E_NOMEM;
+  S.seq.resize_to(at); S.hdr.resize_to(hat);
+  char *sd = S.seq.data(), *hd = S.hdr.data();
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::thread::hardware_concurrency()), at >> 22));
+  auto copy = [&](int t) {
+    // records whose sequence bytes start inside this thread's share
+    const size_t b0 = at * (size_t)t / (size_t)nt, b1 = at * ((size_t)t + 1) / (size_t)nt;
+    size_t i = (size_t)(std::lower_bound(S.seq_off.begin(), S.seq_off.begin() + (ptrdiff_t)(3 * n), (int64_t)b0) - S.seq_off.begin());
+    i = (i + 2) / 3;                                  // first record that starts at or behind b0
+    for (; i < n && (size_t)S.seq_off[3 * i] < b1; ++i) {
+      const Reader::Rec &r = recs[i];
+      for (int q = 0; q < 3; ++q) std::memcpy(sd + S.seq_off[3 * i + q], r.s[q], r.sl[q]);
+      std::memcpy(hd + S.hdr_off[i], r.h, r.hl);
+    }
+  };
+  if (nt <= 1) copy(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(copy, t);
+    copy(0);
+    for (auto &x : th) x.join();
+  }
+  out->n = (int64_t)n;
   out->first_index = first < 0 ? 0 : first;
   out->seq = reinterpret_cast<uint8_t *>(S.seq.data());
   out->seq_off = S.seq_off.data();
