@@ -123,6 +123,7 @@ def main(args=None):
     ap.add_argument("--no-reference", action="store_true")
     ap.add_argument("--end-to-end", action="store_true")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--workdir", default=None, help="directory for the input files and msa.fa (default: the system's temporary directory)")
     ap.add_argument("--repeat", type=int, default=1, help="write the synthetic reads this many times over (distinct names): "
                                                           "--reads 40004 --repeat 5 is twenty batches")
     a, _ = ap.parse_known_args()
@@ -132,7 +133,10 @@ def main(args=None):
     from elector_amd import alignment, computeStats, synthetic
     triples, headers, read_of = synthetic.read_pieces(a.profile, a.reads, seed=2000)
     bases = int(sum(len(t[0]) for t in triples)) * max(1, a.repeat)
-    work = tempfile.mkdtemp(prefix="elector_e2e_")
+    # the three input files and msa.fa (3.3 x the input).  Measured on the GPU box: the default temporary directory
+    # (page cache of the container's overlay file system) takes the records at ~10 GB/s until write-back throttling sets
+    # in; /dev/shm (tmpfs) at ~2.5 GB/s -- shared-memory pages are allocated and zeroed under one lock
+    work = tempfile.mkdtemp(prefix="elector_e2e_", dir=a.workdir)
     try:
         paths = write_fasta(work, triples, headers, max(1, a.repeat))
         del triples
@@ -172,6 +176,20 @@ def main(args=None):
             prof.disable()
             pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(18)
         stages = {k: round(v, 3) for k, v in alignment.STAGE_SECONDS.items()}
+        if alignment.STAGE_TRACE is not None:
+            # a text Gantt chart of getPOA: one row per thread, one column per 10 ms
+            tr = [x for x in alignment.STAGE_TRACE if x[2] >= t0]
+            names = sorted({x[1] for x in tr})
+            width = int((t1 - t0) / 0.01) + 1
+            for nm in names:
+                row = [" "] * width
+                for stage, th_, a_, b_ in tr:
+                    if th_ != nm:
+                        continue
+                    ch = stage[0].upper() if not stage.startswith("wait") else "."
+                    for c in range(int((a_ - t0) / 0.01), min(width, int((b_ - t0) / 0.01) + 1)):
+                        row[c] = ch
+                sys.stderr.write("%-12s|%s|\n" % (nm[:12], "".join(row)))
         # the same report from the text file (what call site #2 cost before the counters were handed over); left out
         # on long runs (the text of twenty batches is 5 GB)
         t3 = None
@@ -186,7 +204,8 @@ def main(args=None):
             "value": round(bases / (t2 - t0) / 1e6, 3), "unit": "Mbases/s", "n_gpus": 1,
             "config": {"workload": a.profile, "reads": a.reads * max(1, a.repeat), "triples": len(headers) * max(1, a.repeat), "ref_bases": bases,
                        "batches": (len(headers) * max(1, a.repeat) + 10000) // 10001,
-                       "host_threads": a.threads, "msa_fa_bytes": os.path.getsize(outdir + "/msa.fa")},
+                       "host_threads": a.threads, "msa_fa_bytes": os.path.getsize(outdir + "/msa.fa"),
+                       "workdir": os.path.dirname(work)},
             "seconds": {"getPOA (wall)": round(t1 - t0, 3), "outputRecallPrecision (wall, device counters)": round(t2 - t1, 3),
                         "outputRecallPrecision from the text file instead": None if t3 is None else round(t3 - t2, 3)},
             "getPOA_stage_seconds": stages,

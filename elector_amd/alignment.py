@@ -61,9 +61,15 @@ _splitters = {}
 STAGE_SECONDS = {}
 
 
+STAGE_TRACE = [] if os.environ.get("ELECTOR_STAGE_TRACE") else None      # (stage, thread, start, end) of every stage instance
+
+
 def _tick(stage, t0):
     import time
-    STAGE_SECONDS[stage] = STAGE_SECONDS.get(stage, 0.0) + (time.perf_counter() - t0)
+    t1 = time.perf_counter()
+    STAGE_SECONDS[stage] = STAGE_SECONDS.get(stage, 0.0) + (t1 - t0)
+    if STAGE_TRACE is not None:
+        STAGE_TRACE.append((stage, threading.current_thread().name, t0, t1))
 
 
 # msa path -> what outputRecallPrecision needs instead of the text file (see computeStats.cached_pieces)
