@@ -287,3 +287,81 @@ def score_range_triples(seed):
 
 def test_windows_up_to_the_score_span(engine):
     check(engine, score_range_triples(71))
+
+
+def alphabet_shortcut_triples(seed):
+    """The windows alignment #1 is settled for without a dynamic program (corrected = reference, one substitution,
+    one inserted or deleted letter: k_trivial / trivial_graph) over the WHOLE input alphabet of a2 (create_seq.c:121-132,
+    seq_util.c:37-52,253-263): lower case, `n` / `N`, letters outside the alphabet (they all become symbol 0 and print
+    as `A`, so two different unknown letters are EQUAL), and the splitter's `N` filler next to them.  The comparisons
+    of the shortcut are on symbols; the rows print letters -- both must come out as the reference's."""
+    rng = np.random.default_rng(seed)
+    unknown = b"RYKMSWBDHV-*.x"
+    out = []
+
+    def case(s, p):
+        b = bytearray(s)
+        for i in range(len(b)):
+            if rng.random() < p:
+                b[i] = b[i] ^ 0x20 if chr(b[i]).isalpha() else b[i]
+        return bytes(b)
+
+    def unc_of(ref):
+        u = synth.mutate(rng, ref.upper().replace(b"N", b"A"), 0.15) or b"A"
+        return case(u, 0.3)
+
+    for L in (2, 3, 8, 17, 40, 63, 64, 90, 140):
+        for rep in range(6):
+            ref = bytearray(synth.random_seq(rng, L))
+            # `N` runs, lone unknown letters and a homopolymer inside the window
+            if L >= 8:
+                a = int(rng.integers(0, L - 3))
+                ref[a:a + 3] = rng.choice([b"NNN", b"nnn", b"NnN", b"RRY", b"AAA", b"aAa"])
+            if L >= 17:
+                ref[int(rng.integers(0, L))] = int(rng.choice(np.frombuffer(unknown, dtype=np.uint8)))
+            ref = bytes(ref)
+            cor_same = case(ref, 0.5)                                        # equal up to case
+            # equal up to WHICH unknown letter stands there
+            cor_unk = bytes(int(rng.choice(np.frombuffer(unknown, dtype=np.uint8))) if c in unknown else c for c in ref)
+            out.append((case(ref, 0.2), cor_same, unc_of(ref)))
+            out.append((ref, cor_unk, unc_of(ref)))
+            pos = sorted(set(int(x) for x in rng.integers(0, L + 1, 10)) | {0, L - 1, L})
+            for p in pos:
+                for sub in (b"N", b"n", b"R", b"a", b"C", b"-"):
+                    if p < L:
+                        out.append((ref, case(ref[:p] + sub + ref[p + 1:], 0.3), unc_of(ref)))      # one substitution (or none, on symbols)
+                    out.append((ref, case(ref[:p] + sub + ref[p:], 0.3), unc_of(ref)))              # one inserted letter
+                if p < L and L > 1:
+                    out.append((case(ref, 0.3), ref[:p] + ref[p + 1:], unc_of(ref)))                # one deleted letter
+    # the `N` filler as the corrected side (Master_Splitter.cpp:139-154), next to windows of the kinds above
+    for L in (1, 2, 30, 64, 200):
+        ref = synth.random_seq(rng, L)
+        out += [(ref, b"N", unc_of(ref)), (case(ref, 0.5), b"n", unc_of(ref)), (b"N" * L, b"N", b"N" * max(1, L - 1)),
+                (ref[:L // 2] + b"N" + ref[L // 2:], b"N", unc_of(ref))]
+    return [t for t in out if len(t[1]) >= 1 and len(t[2]) >= 1]
+
+
+def test_shortcut_windows_over_the_whole_alphabet(engine, monkeypatch):
+    triples = alphabet_shortcut_triples(81)
+    assert len(triples) > 4000
+    check(engine, triples)
+    # and the same with both shortcuts switched off: the dynamic program says the same
+    got, scores = engine.align(triples, want_scores=True)
+    monkeypatch.setenv("ELECTOR_NO_ONEINDEL", "1")
+    monkeypatch.setenv("ELECTOR_NO_TRIVIAL", "1")
+    got2, scores2 = engine.align(triples, want_scores=True)
+    assert got == got2 and np.array_equal(scores, scores2)
+
+
+def test_soak_slice(engine):
+    """A bounded slice of the builder's parity soak (tests/_r2_soak.py) inside the driver's own run: random windows of
+    the four length / error mixes, most corrected sequences within one edit of the reference, rows and both scores
+    bit-exact against the oracle."""
+    total = 0
+    for seed in (211, 212, 213):
+        for (n, lo, hi, eu, ec) in ((30000, 20, 90, 0.15, 0.01), (20000, 30, 140, 0.12, 0.02), (6000, 100, 400, 0.15, 0.015),
+                                    (20000, 5, 40, 0.2, 0.03)):
+            triples = synth.window_triples(seed, n, lo, hi, err_unc=eu, err_cor=ec)
+            check(engine, triples)
+            total += len(triples)
+    assert total == 228000
