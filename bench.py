@@ -87,12 +87,10 @@ def parse():
 
 def self_launch(args):
     """--gpus N without a launcher: start the N ranks as fresh processes (this process has not
-    touched a GPU and never will) and pass rank 0's line through."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    touched a GPU and never will) and pass rank 0's line through.  --standalone lets the launcher pick and hold a
+    free rendezvous port itself (a port chosen here could be taken between the choice and its use)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode

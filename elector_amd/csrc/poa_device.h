@@ -26,6 +26,7 @@
 // jj = t - l.  Lane 0 does not compute: it replays the previous strip's last
 // row (or the virtual row) so that lane 1 can read it like any other neighbour.
 #pragma once
+#include <atomic>
 #include <stdint.h>
 
 namespace elector {
@@ -215,5 +216,18 @@ __host__ __device__ inline int poa_slot_need(int Lr, int Lc, int Lu, int G)
   const int ua = poa_union_a(Lr, Lc, G), ub = poa_union_b(cap, Lu, G);
   return 16 + ((Lu + 3) & ~3) + 4 * (cap + 2) + (ua > ub ? ua : ub);
 }
+
+// "has this kernel's dynamic-LDS limit been raised on the CURRENT device yet?" -- hipFuncSetAttribute is per device, a
+// process may hold contexts on several (one bit per device id; setting the attribute twice from two threads is harmless)
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  int dev = 0;
+  bool need()
+  {
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return (mask.load(std::memory_order_acquire) & (1ull << (dev & 63))) == 0;
+  }
+  void done() { mask.fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
 
 }  // namespace elector

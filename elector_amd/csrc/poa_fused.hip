@@ -1083,12 +1083,12 @@ template <int G, int R>
 static int launch_a_t(const FusedArgs &a, hipStream_t st)
 {
   constexpr int NB = 64 / G;     // windows per block (one wave)
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce once;
+  if (once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_a<G, R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
-    attr = true;
+    once.done();
   }
   hipLaunchKernelGGL((k_fused_a<G, R, 1>), dim3((unsigned)fused_grid(a, NB)), dim3(64), NB * a.slot_bytes, st, a);
   return 0;
@@ -1098,12 +1098,12 @@ template <int G, int R, int D>
 static int launch_b_t(const FusedArgs &a, hipStream_t st)
 {
   constexpr int NB = 64 / G;
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce once;
+  if (once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_b<G, R, D, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
-    attr = true;
+    once.done();
   }
   hipLaunchKernelGGL((k_fused_b<G, R, D, 1>), dim3((unsigned)fused_grid(a, NB)), dim3(64),
                      64 + NB * a.slot_bytes + fused_ring_bytes(R, D), st, a);

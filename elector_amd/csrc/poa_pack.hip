@@ -1331,12 +1331,12 @@ template <int G, int R>
 static int launch_poa_t(const PackArgs &a, hipStream_t st)
 {
   constexpr int NW = 2 * (64 / G);     // windows per block (one wave)
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce once;
+  if (once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_poa<G, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
-    attr = true;
+    once.done();
   }
   hipLaunchKernelGGL((k_poa<G, R>), dim3((unsigned)((a.nlist + NW - 1) / NW)), dim3(64), 64 + NW * a.slot_bytes, st, a);
   return 0;

@@ -1048,7 +1048,12 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   int64_t tab_cap = 64;
   while (tab_cap < 2 * maxlen + 2) tab_cap <<= 1;
   const int max_blocks = std::getenv("ELECTOR_SPLIT_BLOCKS") ? std::max(1, std::atoi(std::getenv("ELECTOR_SPLIT_BLOCKS"))) : 1024;
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(n_in, max_blocks));
+  // per-block scratch (three hash tables of 64-bit slots, two candidate arrays) grows with the batch's LONGEST read: a
+  // single 300 kb read would ask for 25 GB at 1024 blocks.  The blocks are capped by a byte budget (a block loops over
+  // reads anyway), and a workspace that still cannot be had sends the batch to the host splitter (ELECTOR_E_LIMIT).
+  const int64_t per_block = 3 * tab_cap * 8 + 2 * (maxlen + 2) * 4 + 3 * maxwin * 8 * 4;
+  const int64_t budget = (int64_t)8 << 30;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_in, max_blocks), std::max<int64_t>(64, budget / per_block)));
   hipStream_t st = c->stream;
   int rc = c->d_sp_reads.ensure((size_t)total + 64) | c->d_sp_off.ensure((size_t)(3 * n_in + 1) * 8 + 64) |
            c->d_sp_hdr.ensure((size_t)n_in * 4 + 64) | c->d_sp_keys.ensure((size_t)blocks * 3 * tab_cap * 8) |
@@ -1056,7 +1061,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
            c->d_sp_cb.ensure((size_t)blocks * (maxlen + 2) * 4) | c->d_sp_wl.ensure((size_t)blocks * 3 * maxwin * 8 * 4) |
            c->d_sp_win.ensure((size_t)first[(size_t)n_in] * 8 * 4 + 64) | c->d_sp_first.ensure((size_t)(n_in + 1) * 8) |
            c->d_sp_cnt.ensure((size_t)(n_in + 1) * 4 * 2 + 64) | c->d_sp_wfirst.ensure((size_t)(n_in + 2) * 8 * 2);
-  if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "device splitter workspace");
+  if (rc) return elector_fail(c, ELECTOR_E_LIMIT, "device splitter workspace does not fit device memory: the host splitter takes this batch");
   if (n_in == 0) return ELECTOR_OK;
   auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
   const bool dbg = std::getenv("ELECTOR_DEBUG_SPLIT") != nullptr;
@@ -1125,11 +1130,11 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   } else {
     // the anchor arrays in LDS, as many entries as the batch's longest read can need: the usual 8-20 kb reads leave
     // room for four workgroups per CU, whose serial stretches (anchor selection, chain) then overlap
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce once;
+    if (once.need()) {
       HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 512));
-      attr = true;
+      once.done();
     }
     // on-chip tables when most of the batch's reads are short enough for them and they fit beside the anchors
     size_t lds = ((size_t)(2 * 5 * maxanc * 2) + 3) & ~(size_t)3;   // 16-bit anchor arrays

@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 export FB_DEBUGS=0
 rm -rf gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d gpurun_out/pmc1 -- python3 tests/_fbench.py > gpurun_out/pmc1.log 2>&1

@@ -1,4 +1,5 @@
 # PMC passes over bench.py (separate passes: FETCH_SIZE and WRITE_SIZE cannot share one), kernel-trace only.
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # Usage: gpurun -- 'bash tests/_pmc_bench.sh TAG'
 TAG=${1:-pmc}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 TAG=${1:-pmcsq}
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 CMD="python3 bench.py --no-cpu-baseline --steps 3 --warmup 1"

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: default bench under a few engine-context / launch-chain settings (A/B on one box)
 O=gpurun_out/${1:-r2ab}; mkdir -p $O
 run() { tag=$1; shift; env "$@" python bench.py --steps 50 --no-cpu-baseline > $O/$tag.json 2> $O/$tag.err || { tail -3 $O/$tag.err; return; }

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: A/B of a debug bit of k_poa on one box, alternating (ELECTOR_DEBUG_FUSED=$2 against unset)
 O=gpurun_out/${1:-r2ab2}; mkdir -p $O
 for i in 1 2 3; do

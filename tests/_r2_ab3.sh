@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: A/B of two builds of the library (ab_libs/old.so, ab_libs/new.so) on one box, alternating
 O=gpurun_out/${1:-r2ab3}; mkdir -p $O
 for i in 1 2 3; do

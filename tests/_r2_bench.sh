@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: bench lines of every workload + the un-overlapped rocprof pass (kept under profiles/ by hand)
 set -o pipefail
 O=gpurun_out/${1:-r2b}

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: VALU / SALU / LDS instruction counts of k_poa with the windows dropped after a phase
 # (ELECTOR_DEBUG_FUSED bits 32 .. 256): the differences are the phases' instruction counts
 TAG=${1:-r2insts}

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: per-kernel times of the serial bench (rocprofv3 --stats), top lines
 O=gpurun_out/${1:-r2ks}; mkdir -p $O
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: SQ counters of the serial bench (per kernel family), two passes; plus FETCH/WRITE passes with $2=traffic
 TAG=${1:-r2pmc}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

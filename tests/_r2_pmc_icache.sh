@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: instruction-cache and branch counters of the alignment kernels, pipelined and serial bench
 TAG=${1:-r2ic}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: memory-pipeline counters of the serial bench (TA / TCP / TCC), one pass per group
 TAG=${1:-r2mem}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: un-overlapped kernel-trace summaries (CSV) per workload + phase stamps of the fused kernels
 set -o pipefail
 O=gpurun_out/${1:-r2c}

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: serial bench lines of the given profiles (kernel ms per step), small step count
 O=gpurun_out/${1:-r2q}; shift
 mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 # GPU-box helper: per-kernel totals and the longest dispatches of one serial bench run
 P=${1:-yeast50x_nanosim_consent_split}; RD=${2:-10001}; O=gpurun_out/${3:-r2t}
 mkdir -p $O; export TMPDIR=/tmp; R=$PWD

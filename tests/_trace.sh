@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+: ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 mkdir -p gpurun_out/trace
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace/p -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/trace/log 2>&1
 f=$(find gpurun_out/trace/p -name "*kernel_trace.csv" | head -1)
