@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="one engine context, one launch chain: every kernel runs alone on the chip (per-kernel times add up to the step)")
     ap.add_argument("--serial-steps", type=int, default=10, help="steps of the serial pass behind the timed region")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: steps whose counters travel to rank 0 in one RCCL gather")
     ap.add_argument("--no-rows-to-host", action="store_true",
                     help="skip the second timed loop (the same steps plus the merged MSA rows copied to pinned host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -302,7 +304,10 @@ def main():
     if backend != "nccl":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if world > 1:
+    # ELECTOR_BENCH_FORCE_DIST=1 (under a launcher with one rank): the process group and every collective of the N > 1
+    # path run with a world of one -- RCCL's own code paths on a box with a single GPU
+    dist_on = world > 1 or (os.environ.get("ELECTOR_BENCH_FORCE_DIST", "0") not in ("", "0") and world_env is not None)
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -346,21 +351,57 @@ def main():
 
     # every step gathers the same number of counter rows per rank (one per piece of the rank's batch): the ranks
     # tell each other once, the steps then need one collective each
-    gather_sizes = edist.gather_sizes(len(piece_first) - 1) if world > 1 else None
+    gather_sizes = edist.gather_sizes(len(piece_first) - 1) if dist_on else None
     pending = []
     gathers = []
+    held = []
+    gather_every = max(1, args.gather_every)
+    gather_cap = gather_every * max(gather_sizes) if gather_sizes else 0       # rows of the largest block a gather carries
+    gpool = None
+    if dist_on:
+        from concurrent.futures import ThreadPoolExecutor as _TPE
+        gpool = _TPE(max_workers=1)
     turn = [0]
     host_s = [0.0]                               # host time of classifying and enqueueing (the GPU work is asynchronous)
+    gather_s = [0.0]                             # host time of starting a step's gather and taking in an earlier one
 
     def collect():
         """per-piece counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
         e, npieces = pending.pop(0)
         counters, _ = engines[e].msa_stats_collect(npieces)
-        if world == 1:
+        if not dist_on:
             return counters
-        # the gather runs beside the next steps; at most two are in flight
-        gathers.append(edist.gather_rows_async(counters, gather_sizes))
-        return gathers.pop(0).wait() if len(gathers) > 2 else None
+        # Fewer, larger collectives: the counters of `gather_every` steps travel together (every step's counters
+        # still reach rank 0 inside the timed region).  An RCCL collective holds compute units while it runs and its
+        # small copies queue up behind whole launch chains of the alignment kernels: one gather per step cost 19 % of
+        # the step rate in a one-rank rehearsal on RCCL, one per eight steps costs nothing measurable.  The staging,
+        # the collective and taking its result in run on a helper thread; up to three are in flight.
+        tg = time.perf_counter()
+        held.append(counters)
+        res = flush_gather(False)
+        gather_s[0] += time.perf_counter() - tg
+        return res
+
+    def flush_gather(force):
+        """-> the last step's rows of the oldest finished gather (rank 0), or None"""
+        res = None
+        if held and (force or len(held) >= gather_every):
+            k = len(held)
+            block = np.concatenate(held) if k > 1 else held[0]
+            held.clear()
+            sizes = [x * k for x in gather_sizes]
+            gathers.append((k, gpool.submit(lambda c=block, z=sizes: edist.gather_rows_async(c, z, cap=gather_cap).wait())))
+        while gathers and (force or len(gathers) > 3):
+            k, fut = gathers.pop(0)
+            got = fut.result()
+            if got is not None:
+                # rows arrive rank by rank, each rank's k steps back to back: the last step of every rank
+                parts, at = [], 0
+                for x in gather_sizes:
+                    parts.append(got[at + (k - 1) * x: at + k * x])
+                    at += k * x
+                res = np.concatenate(parts) if len(parts) > 1 else parts[0]
+        return res
 
     def step():
         """Queue one step (windows in HBM -> POA kernels -> merge -> counters -> pinned host memory),
@@ -381,8 +422,7 @@ def main():
     def drain():
         while pending:
             collect()
-        while gathers:
-            gathers.pop(0).wait()
+        flush_gather(True)
 
     for _ in range(3 * n_eng):
         step()
@@ -396,26 +436,29 @@ def main():
         g.timing_reset()
 
     # ---- timed region ----------------------------------------------------
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     for g in engines:
         g.sync()
     host_s[0] = 0.0
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     while pending:
         counters = collect()                     # every step's counters are on the host before the clock stops
-    while gathers:
-        counters = gathers.pop(0).wait()         # ... and, with several ranks, on rank 0
+    if dist_on:
+        last = flush_gather(True)                # ... and, with several ranks, on rank 0
+        counters = last if last is not None else counters
     for g in engines:
         g.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
     host_ms_per_step = host_s[0] / args.steps * 1e3
+    gather_ms_per_step = gather_s[0] / args.steps * 1e3
 
     # the MSA the timed kernels wrote (context 0's last timed step), for the every-window comparison with the
     # reference binary behind the clock
@@ -468,7 +511,7 @@ def main():
         for _ in range(n_eng + 1):
             step_rows()
         drain_rows()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -476,7 +519,7 @@ def main():
             step_rows()
         drain_rows()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         dt_rows = time.perf_counter() - t0
         rows_bytes = int(fetched[0])
@@ -523,7 +566,7 @@ def main():
     rdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([dt, dt_rows or 0.0], dtype=torch.float64, device=rdev)
     tot = torch.tensor([piece_bases, n, cells1 + cells2, cells1_computed + cells2], dtype=torch.int64, device=rdev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt_max, dt_rows_max = float(tmax[0].item()), float(tmax[1].item())
@@ -532,7 +575,7 @@ def main():
     me = {"rank": rank, "local_rank": local, "device": props.name, "uuid": str(getattr(props, "uuid", "")),
           "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "host": socket.gethostname()}
     ranks = [me]
-    if world > 1:
+    if dist_on:
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
     bases_all, windows_all, cells_all, cells_comp_all = (int(x) for x in tot.tolist())
@@ -579,7 +622,7 @@ def main():
                 "pcie_gbs_per_gpu": round(rows_bytes * args.steps / dt_rows_max / 1e9, 2),
                 "note": "the same %d steps timed again with every step's merged rows (3 x columns bytes per piece) copied "
                         "to pinned host memory by a helper thread per context" % args.steps},
-            "ranks": {"world": world, "backend": backend if world > 1 else None,
+            "ranks": {"world": world, "backend": backend if dist_on else None,
                       "distinct_devices": len({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks}),
                       "devices": ranks},
             # dtype: k_poa's recurrences run on 16-bit scores, two windows per 32-bit lane (the fall-back kernels, 0.2 %
@@ -597,6 +640,7 @@ def main():
                                    "merge_and_counters": round(t_st / serial_steps, 3),
                                    "serial_step_wall": round(serial_wall * 1e3, 3),
                                    "host_classify_and_enqueue": round(host_ms_per_step, 3),
+                                   "host_counters_gather": round(gather_ms_per_step, 3),
                                    "note": "HIP-event time per launch, summed per step, from %d un-overlapped steps "
                                            "(one context, one launch chain)%s"
                                            % (serial_steps, "" if args.serial else
@@ -633,7 +677,7 @@ def main():
             exit_code = 1
     for g in engines:
         g.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     if exit_code:
         sys.exit(exit_code)

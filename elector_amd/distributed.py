@@ -84,36 +84,108 @@ def gather_rows(local, group=None, dst=0, sizes=None):
 class _Gather:
     """a gather_rows in flight: wait() -> the concatenated rows on dst, None elsewhere"""
 
-    def __init__(self, work, pad, out, sizes, is_dst):
-        self._work, self._pad, self._out, self._sizes, self._is_dst = work, pad, out, sizes, is_dst
+    def __init__(self, pipe, slot, sizes, is_dst):
+        self._pipe, self._slot, self._sizes, self._is_dst = pipe, slot, sizes, is_dst
 
     def wait(self):
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
+        s = self._slot
+        s["done"].synchronize()                    # the collective and (on dst) the copy to pinned memory have run
+        s["busy"] = False
         if not self._is_dst:
             return None
-        return np.concatenate([o[: int(s)].cpu().numpy() for o, s in zip(self._out, self._sizes)], axis=0)
+        host = s["host"].numpy()
+        return np.concatenate([host[r, : int(n)] for r, n in enumerate(self._sizes)], axis=0)
 
 
-def gather_rows_async(local, sizes, group=None, dst=0):
+class GatherPipe:
+    """Repeated gathers of int64 [k_i, C] blocks to one rank without stalling the caller: a few buffer sets (pinned
+    staging, device block, the receive blocks and a pinned landing area on dst) are reused, every transfer and the
+    collective itself are queued on a stream of the pipe's own, and nothing waits before _Gather.wait().  With the
+    nccl backend (RCCL over xGMI) the blocks travel device to device; with gloo everything stays on the host.
+    cap: rows a rank's block may have (the buffers are allocated once, for that)."""
+
+    def __init__(self, cap, ncol, group=None, dst=0, depth=4):
+        import torch
+        import torch.distributed as dist
+        self.group, self.dst, self.ncol = group, dst, int(ncol)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.nccl = dist.get_backend(group) == "nccl"
+        self.cap = max(int(cap), 1)
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.nccl else torch.device("cpu")
+        self.stream = torch.cuda.Stream() if self.nccl else None
+        self.slots = []
+        for _ in range(depth):
+            s = {"busy": False}
+            s["stage"] = torch.zeros((self.cap, self.ncol), dtype=torch.int64)
+            if self.nccl:
+                s["stage"] = s["stage"].pin_memory()
+                s["pad"] = torch.zeros((self.cap, self.ncol), dtype=torch.int64, device=dev)
+            else:
+                s["pad"] = s["stage"]
+            if self.rank == dst:
+                s["out"] = [torch.zeros((self.cap, self.ncol), dtype=torch.int64, device=dev) for _ in range(self.world)]
+                s["host"] = torch.zeros((self.world, self.cap, self.ncol), dtype=torch.int64)
+                if self.nccl:
+                    s["host"] = s["host"].pin_memory()
+            s["done"] = torch.cuda.Event() if self.nccl else _HostDone()
+            self.slots.append(s)
+        self.turn = 0
+
+    def start(self, local, sizes):
+        import torch
+        import torch.distributed as dist
+        local = np.ascontiguousarray(local, dtype=np.int64).reshape(-1, self.ncol)
+        sizes = [int(x) for x in sizes]
+        if len(sizes) != self.world or local.shape[0] != sizes[self.rank] or max(sizes) > self.cap:
+            raise ValueError("GatherPipe: sizes %r do not describe this rank's block of %d rows (room for %d)"
+                             % (sizes, local.shape[0], self.cap))
+        s = self.slots[self.turn % len(self.slots)]
+        self.turn += 1
+        if s["busy"]:
+            raise RuntimeError("GatherPipe: more gathers in flight than buffer sets; wait() for the oldest first")
+        s["busy"] = True
+        s["stage"].numpy()[: local.shape[0]] = local
+        is_dst = self.rank == self.dst
+        if self.nccl:
+            with torch.cuda.stream(self.stream):
+                s["pad"].copy_(s["stage"], non_blocking=True)
+                dist.gather(s["pad"], s["out"] if is_dst else None, dst=self.dst, group=self.group, async_op=True).wait()
+                if is_dst:
+                    for r in range(self.world):
+                        s["host"][r].copy_(s["out"][r], non_blocking=True)
+                s["done"].record(self.stream)
+        else:
+            work = dist.gather(s["pad"], s["out"] if is_dst else None, dst=self.dst, group=self.group, async_op=True)
+            s["done"].set(work, s if is_dst else None)
+        return _Gather(self, s, sizes, is_dst)
+
+
+class _HostDone:
+    """the gloo side of GatherPipe's completion event"""
+
+    def set(self, work, slot):
+        self._work, self._slot = work, slot
+
+    def synchronize(self):
+        self._work.wait()
+        if self._slot is not None:
+            for r, o in enumerate(self._slot["out"]):
+                self._slot["host"][r].copy_(o)
+
+
+def gather_rows_async(local, sizes, group=None, dst=0, cap=None, _pipes={}):
     """gather_rows without waiting for it: the collective runs while the caller goes on (bench.py: the next
-    step's kernels are already queued); sizes as from gather_sizes.  -> object with wait()."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    steps' kernels are already queued); sizes as from gather_sizes.  -> object with wait().  The calls of a process
+    share one GatherPipe per row width (at most four gathers in flight); cap: rows to make room for when the pipe is
+    created or has to grow (growing allocates pinned memory: callers that know their largest block say so up front)."""
     local = np.ascontiguousarray(local, dtype=np.int64)
     ncol = local.shape[1] if local.ndim == 2 else 1
-    if len(sizes) != world or int(sizes[rank]) != local.shape[0]:
-        raise ValueError("gather_rows_async: sizes do not describe this rank's block")
-    cap = max(int(s) for s in sizes)
-    pad = torch.zeros((cap, ncol), dtype=torch.int64, device=dev)
-    if local.shape[0]:
-        pad[: local.shape[0]] = torch.from_numpy(local.reshape(local.shape[0], ncol)).to(dev)
-    out = [torch.zeros((cap, ncol), dtype=torch.int64, device=dev) for _ in range(world)] if rank == dst else None
-    work = dist.gather(pad, out, dst=dst, group=group, async_op=True)
-    return _Gather(work, pad, out, sizes, rank == dst)
+    need = max(max(int(x) for x in sizes), int(cap or 0), 1)
+    key = (ncol, id(group), dst)
+    pipe = _pipes.get(key)
+    if pipe is None or pipe.cap < need:
+        pipe = _pipes[key] = GatherPipe(need, ncol, group, dst)
+    return pipe.start(local, sizes)
 
 
 def sharded_counters(pieces, counter_fn, group=None):
