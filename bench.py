@@ -243,7 +243,8 @@ def pmc_file(profile, reads):
 
 def skipped_alignment1(win, lr, lc):
     """Windows whose alignment #1 the device skips (k_trivial, poa_kernels.hip): corrected equals the
-    reference, or differs from it by exactly one substitution, one inserted or one deleted letter.
+    reference, differs from it by exactly one substitution, one inserted or one deleted letter, or is the one-letter
+    filler of a stretch the corrected read does not cover.
     Host-side count for the `gcups` split."""
     import numpy as np
     out = np.zeros(len(lr), dtype=bool)
@@ -256,6 +257,14 @@ def skipped_alignment1(win, lr, lc):
         mism = win.bases[idx] != win.bases[idx + np.repeat(L, L)]
         nmis = np.add.reduceat(mism.astype(np.int64), ends - L)
         out[same[nmis <= 1]] = True
+    # the splitter's one-letter filler that occurs nowhere in the reference window (graph written directly)
+    fill = np.nonzero((lc == 1) & (lr >= 2))[0]
+    if len(fill):
+        L = lr[fill]
+        ends = np.cumsum(L)
+        idx = np.repeat(off[3 * fill] - (ends - L), L) + np.arange(int(ends[-1]), dtype=np.int64)
+        hit = win.bases[idx] == np.repeat(win.bases[off[3 * fill + 1]], L)
+        out[fill[np.add.reduceat(hit.astype(np.int64), ends - L) == 0]] = True
     # one indel: the strings agree up to the first difference fd and, shifted by one, from fd on
     for d in (-1, 1):                                  # lc = lr + d
         sel = np.nonzero((lc == lr + d) & (np.minimum(lr, lc) >= 1))[0]

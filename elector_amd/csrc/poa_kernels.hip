@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(256) k_left_b(BatchArgs a, uint32_t *list, int
 // path together instead of one after the other.
 constexpr int kPartBuckets = 32;        // 0..14: first difference in columns 8k..8k+7 (14: beyond); 16..30: the same for the
                                         // one-substitution / one-indel windows k_poa settles without alignment #1 (their wavefronts
-                                        // then skip it altogether); 31: corrected equals reference
+                                        // then skip it altogether; 30 also takes the one-letter fillers); 31: corrected equals reference
 
 __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, int one_sub_ok)
 {
@@ -609,8 +609,24 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
   if (g == 0) { triv[w] = eq ? 1 : 0; pkey[w] = (uint8_t)(eq ? kPartBuckets - 1 : min(fd >> 3, 14)); }
   const bool flags_only = (one_sub_ok & 2) != 0;      // k_poa builds these graphs itself, in LDS
   const bool indel_ok = (one_sub_ok & 4) != 0;
+  const bool filler_ok = (one_sub_ok & 8) != 0;
   one_sub_ok &= 1;
   if (flags_only && eq) return;
+  if (flags_only && filler_ok && Lc == 1 && Lr >= 2 && a.status[w] == 0) {
+    // The splitter's filler: a corrected window of ONE letter (`N`) that occurs nowhere in the reference window
+    // (Master_Splitter.cpp:139-154,268-277).  With the shipped scores (mismatch -10, opening 10, extension 5) cell
+    // 0 of the single row is a mismatch (-10), and in every later cell j the three offers tie at -(15 + 5 j): the
+    // gap state is shared between the two directions (align_lpo_po2.c:374-407), so the x-gap behind the mismatch
+    // opens (-10 - 10) exactly where the diagonal (-(10 + 5 (j - 1)) - 10) and the y-gap from the border row
+    // (-(10 + 5 j) - 5) stand; no strict winner means "y-insertion" (:384-407), the traceback from the last cell
+    // leaves the matrix at once, the letter stays unaligned and the fusion appends it behind the reference's
+    // chain (lpo.c:602-668).  k_poa writes that graph (trivial_graph); no dynamic program of Lr steps for one row.
+    bool any = false;
+    for (int i = g; i < Lr; i += 8) any = any || xs[i] == ys[0];
+    for (int d = 1; d < 8; d <<= 1) any = __shfl_xor(any ? 1 : 0, d, 8) != 0 || any;
+    if (!any && g == 0) { triv[w] = 5; pkey[w] = (uint8_t)(16 + 14); }
+    if (!any) return;
+  }
   if (!eq) {
     // One substitution and nothing else (same length, the strings agree after position fd): the diagonal
     // with its one mismatch beats every alignment with gaps (two gap openings at least) and is the
@@ -853,8 +869,11 @@ void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t 
   // the one-insertion / one-deletion shortcut: a mismatch must cost something, gap penalties alike in both directions
   const int indel_ok = !std::getenv("ELECTOR_NO_ONEINDEL") && a.kp.mismatch < a.kp.match && a.kp.open_x == a.kp.open_y &&
                        a.kp.ext_x == a.kp.ext_y;
+  // the one-letter filler shortcut is derived for the shipped numbers only
+  const int filler_ok = !std::getenv("ELECTOR_NO_FILLER") && a.kp.match == 0 && a.kp.mismatch == -10 && a.kp.open_x == 10 &&
+                        a.kp.open_y == 10 && a.kp.ext_x == 5 && a.kp.ext_y == 5;
   hipLaunchKernelGGL(k_trivial, dim3((unsigned)((a.n + 7) / 8)), dim3(64), 0, st, a, done_a, triv, pkey,
-                     one_sub_ok | (flags_only ? 2 : 0) | (indel_ok ? 4 : 0));
+                     one_sub_ok | (flags_only ? 2 : 0) | (indel_ok ? 4 : 0) | (filler_ok ? 8 : 0));
 }
 
 int partition_buckets() { return kPartBuckets; }

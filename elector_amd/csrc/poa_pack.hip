@@ -446,6 +446,18 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
     W.n1 = L;
     return;
   }
+  if (W.triv == 5) {
+    // the one-letter filler that occurs nowhere in the reference (k_trivial): the reference's chain, then the
+    // letter, unaligned, as a node of its own whose only predecessor is the virtual start -- far behind it
+    for (int n = g; n < L; n += G) {
+      const int fl = kFlagHasRef | (n == 0 ? kFlagInitial : 0) | (n == L - 1 ? kFlagFinal : 0);
+      xinfo[n + 1] = ((uint32_t)xs[n] << 8) | ((uint32_t)fl << 16) | kN_NewCol;
+    }
+    if (g == 0)
+      xinfo[L + 1] = ((uint32_t)ys[0] << 8) | ((uint32_t)(kFlagHasCor | kFlagInitial | kFlagFinal) << 16) | kN_NewCol | kN_Virt1;
+    W.n1 = L + 1;
+    return;
+  }
   const int Lc = W.Lc, nm = min(L, Lc);
   int e = nm;
   for (int i = g; i < nm && i < e; i += G) if (xs[i] != ys[i]) e = i;
@@ -1043,7 +1055,8 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
     trivial_graph<G>(W[h], g, U[h], U[h] + W[h].Lr, xinfo[h]);
     if (W[h].valid && W[h].triv == 1) W[h].score1 = W[h].Lr * kp.match;
     if (W[h].valid && W[h].triv == 2) W[h].score1 = (W[h].Lr - 1) * kp.match + kp.mismatch;
-    if (W[h].valid && W[h].triv >= 3) W[h].score1 = min(W[h].Lr, W[h].Lc) * kp.match - kp.open_x;
+    if (W[h].valid && (W[h].triv == 3 || W[h].triv == 4)) W[h].score1 = min(W[h].Lr, W[h].Lc) * kp.match - kp.open_x;
+    if (W[h].valid && W[h].triv == 5) W[h].score1 = -(kp.open_x + kp.ext_x * W[h].Lr);
   }
   __syncthreads();
   PK_STAMP(3);

@@ -1,12 +1,13 @@
-"""profiles/pmc_traffic.json from a PMC summary (tests/_r2_pmc.sh TAG traffic -> tests/_pmc_summary.py).
-Usage: python tests/_pmc_traffic.py gpurun_out/TAG/summary.json [reads_per_gpu] [profile]"""
+"""profiles/pmc_traffic_<profile>.json from a PMC summary (tests/_r3_pmc.sh -> tests/_pmc_summary.py).
+Usage: python tests/_pmc_traffic.py gpurun_out/TAG/summary.json [reads_per_gpu] [profile] [collected]"""
 import json, os, sys
 src = sys.argv[1]
 reads = int(sys.argv[2]) if len(sys.argv) > 2 else 10001
 profile = sys.argv[3] if len(sys.argv) > 3 else "ecoli30x_simlord_lordec"
+collected = sys.argv[4] if len(sys.argv) > 4 else "round 3"
 d = json.load(open(src))
 out = {}
-for k in ("k_poa", "k_fused_a", "k_fused_b", "k_symbolize", "k_trivial", "k_merge", "k_stats"):
+for k in ("k_poa", "k_gather", "k_fused_a", "k_fused_b", "k_symbolize", "k_trivial", "k_merge", "k_stats", "k_dp2", "k_fuse2"):
     if k not in d or "FETCH_SIZE" not in d[k]:
         continue
     f, w = d[k]["FETCH_SIZE"], d[k]["WRITE_SIZE"]
@@ -19,8 +20,17 @@ align = [k for k in ("k_poa", "k_fused_a", "k_fused_b") if k in d and "SQ_INSTS_
 valu = sum(d[k]["SQ_INSTS_VALU"]["total"] / d[k]["SQ_INSTS_VALU"]["launches"] * (d[k]["SQ_INSTS_VALU"]["launches"] // max(1, steps))
            for k in align)
 traffic_step = sum(v["traffic_bytes_per_launch"] * (v["launches"] // max(1, steps)) for v in out.values())
-meta = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* (separate passes) -- python3 bench.py --serial --no-cpu-baseline --steps 3 --warmup 1",
+sq = {}
+if "k_poa" in d:
+    for name in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY",
+                 "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_SCA"):
+        if name in d["k_poa"]:
+            sq[name] = d["k_poa"][name]["total"]
+meta = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* (separate passes) -- python3 bench.py --serial --no-cpu-baseline --steps 3 --warmup 1 --profile " + profile,
+        "collected": collected,
         "profile": profile, "reads_per_gpu": reads,
+        "k_poa_sq_counters": sq,
+        "k_poa_valu_active_of_wave_cycles": round(sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], 4) if sq.get("SQ_WAVE_CYCLES") else None,
         "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024: gfx950 FETCH_SIZE counts half of the bytes of wide streaming reads "
                       "(MI355X_MICROARCH.md, HBM); verified in this very run on k_symbolize, which reads and writes the window bases once "
                       "(FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB per launch). For the narrower loads of the alignment kernels the factor 2 "
@@ -30,5 +40,5 @@ meta = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_
         "traffic_bytes_per_step": int(traffic_step),
         "kernels": out}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-json.dump(meta, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
+json.dump(meta, open(os.path.join(root, "profiles", "pmc_traffic_%s.json" % profile), "w"), indent=1)
 print(json.dumps(meta, indent=1))
