@@ -887,6 +887,40 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
                    (long long)gwork[2], (long long)gwork[3]);
   }
   auto stream_of = [&](int b) { return bin_stream[(size_t)b]; };
+  // Behind k_poa the two-kernel path sees what was handed back, about one window in a hundred: one launch pair per
+  // geometry class was thirty-odd launches of a few dozen wavefronts each, every one of them all latency.  The
+  // classes of one lane-group size share a hand-back list instead (their regions of d_hand are neighbours) and ONE
+  // launch pair with 8 rows per lane, which holds every window of the group's classes.
+  struct HandGroup { int G = 0, first_bin = -1, ci8 = 0, slot_a = 0, slot_b = 0, tw_a = 0, ns_a = 0, tw_b = 0, ns_b = 0;
+                     int64_t cnt = 0, blocks = 0; std::vector<int> bins; };
+  HandGroup hgrp[4];
+  const bool merge_hand = use_pack && !std::getenv("ELECTOR_HAND_PER_BIN") && !std::getenv("ELECTOR_LAUNCH_ORDER");
+  if (merge_hand) {
+    for (int b = 0; b < kBins; ++b) {
+      if (!bin_cnt[(size_t)b]) continue;
+      const int ci = b / kNT, G = kClsG[ci];
+      HandGroup &hg = hgrp[G == 8 ? 0 : G == 16 ? 1 : G == 32 ? 2 : 3];
+      if (hg.first_bin < 0) { hg.first_bin = b; hg.G = G; }
+      hg.bins.push_back(b);
+      hg.cnt += bin_cnt[(size_t)b];
+      hg.slot_a = std::max<int>(hg.slot_a, (int)((bin_need_a[(size_t)b] + 127) & ~(int64_t)127));
+      hg.slot_b = std::max(hg.slot_b, g_tier_bytes[b % kNT]);
+      hg.tw_a = std::max<int>(hg.tw_a, (int)bin_max_lr[b] + G);
+      hg.tw_b = std::max<int>(hg.tw_b, (int)bin_max_po[b] + G);
+      hg.ns_a = std::max<int>(hg.ns_a, (int)((bin_max_lc[b] + G * 8 - 1) / (G * 8)));
+      hg.ns_b = std::max<int>(hg.ns_b, (int)((bin_max_lu[b] + G * 8 - 1) / (G * 8)));
+    }
+    for (HandGroup &hg : hgrp) {
+      if (hg.first_bin < 0) continue;
+      for (int ci = 0; ci < kNC; ++ci) if (kClsG[ci] == hg.G && kClsR[ci] == 8) hg.ci8 = ci;
+      hg.slot_a = std::min(hg.slot_a, cls_max_slot[hg.ci8]);
+      hg.slot_b = std::min(hg.slot_b, cls_max_slot[hg.ci8]);
+      const int64_t full = (hg.cnt + 64 / hg.G - 1) / (64 / hg.G);
+      hg.blocks = std::min<int64_t>(full, std::max<int64_t>(256, full / 16));
+      const int64_t bytes = hg.blocks * std::max<int64_t>((int64_t)hg.ns_a * hg.tw_a, (int64_t)hg.ns_b * hg.tw_b) * 64 * fused_mv_bytes(8);
+      fmv_stream[3] = std::max(fmv_stream[3], bytes);
+    }
+  }
   if (use_fused)
     for (int b = 0; b < kBins; ++b) {
       if (!bin_cnt[(size_t)b]) continue;
@@ -1103,8 +1137,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       const int sk = stream_of(b);
       hipStream_t sx = c->aux[sk];
       const int fdebug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
-      uint32_t *d_hand_list = use_pack ? c->d_hand.as<uint32_t>() + bin_first[(size_t)b] : nullptr;
-      int32_t *d_hand_cnt = use_pack ? reinterpret_cast<int32_t *>(c->d_hand.as<uint32_t>() + n) + bin_slot[(size_t)b] : nullptr;
+      // the hand-back list of this bin -- or, merged, of the bin's lane-group size (the region of the group's first bin,
+      // which its neighbours' regions follow)
+      HandGroup *hg = merge_hand ? &hgrp[bG == 8 ? 0 : bG == 16 ? 1 : bG == 32 ? 2 : 3] : nullptr;
+      const int hb = hg ? hg->first_bin : b;
+      uint32_t *d_hand_list = use_pack ? c->d_hand.as<uint32_t>() + bin_first[(size_t)hb] : nullptr;
+      int32_t *d_hand_cnt = use_pack ? reinterpret_cast<int32_t *>(c->d_hand.as<uint32_t>() + n) + bin_slot[(size_t)hb] : nullptr;
       if (use_pack && (!split_ab || pass == 0)) {
         // the whole window in one kernel; what it cannot take lands on the bin's hand-back list
         const PackGeom pg = pack_geom(b);
@@ -1148,6 +1186,43 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       // (with a single chain -- bench.py --serial, every kernel alone on the chip -- they stay in line)
       const bool hb_own = use_pack && n_chains > 1;
       const int so = hb_own ? 3 : sk;
+      if (hg) {
+        // merged: remember where this bin's k_poa ends; the group's launch pair follows its last bin
+        if (hb_own) {
+          if (c->hb_events.size() <= (size_t)hb_used) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->hb_events.push_back(e);
+          }
+          HIPCHK(c, hipEventRecord(c->hb_events[(size_t)hb_used], sx));
+          HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->hb_events[(size_t)hb_used], 0));
+          ++hb_used;
+        }
+        if (b != hg->bins.front()) continue;          // bin_order runs from the last bin down: the group's first bin comes last
+        hipStream_t sg = hb_own ? c->aux[3] : sx;
+        FusedArgs fa;
+        fa.b = a;
+        fa.grid_blocks = hg->blocks;
+        fa.list = d_hand_list;
+        fa.nlist_dev = d_hand_cnt;
+        fa.nlist = hg->cnt;
+        fa.done_a = d_done_a;
+        fa.done_b = d_done_b;
+        fa.rowinit = reinterpret_cast<int32_t *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)hb);
+        fa.debug = fdebug;
+        fa.keep_map = c->keep_graph ? 1 : 0;
+        fa.triv = nullptr;
+        fa.mv_pool = c->d_fmv.as<uint8_t>() + fmv_stream[0] + fmv_stream[1] + fmv_stream[2];   // region 3: the merged launches' own
+        fa.slot_bytes = hg->slot_a; fa.mv_tw = hg->tw_a; fa.mv_ns = hg->ns_a;
+        timed_begin(c, 0, sg);
+        if (launch_fused_a(fa, hg->G, 8, sg)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+        timed_end(c, sg);
+        fa.slot_bytes = hg->slot_b; fa.mv_tw = hg->tw_b; fa.mv_ns = hg->ns_b;
+        timed_begin(c, 1, sg);
+        if (launch_fused_b(fa, hg->G, 8, 8, sg)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+        timed_end(c, sg);
+        continue;
+      }
       if (hb_own) {
         if (c->hb_events.size() <= (size_t)hb_used) {
           hipEvent_t e;
