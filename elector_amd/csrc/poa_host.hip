@@ -1310,6 +1310,21 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       launch_left_b(a, d_leftb, d_counters, d_done_b, c->d_mv2.as<int64_t>(),
                     reinterpret_cast<unsigned long long *>(d_counters + 2), (unsigned long long)max_dwords,
                     (unsigned long long)bump_dwords, round, round + 1 >= std::max(1, left_rounds) ? 1 : 0, st);
+      if (std::getenv("ELECTOR_DEBUG_BINS")) {
+        (void)hipStreamSynchronize(st);
+        int32_t hc[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(hc, d_counters, sizeof hc, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[elector] round %d: %d windows left for the generic alignment #2\n", round, hc[0]);
+        if (hc[0] > 0) {
+          std::vector<uint32_t> lw((size_t)std::min(hc[0], 12));
+          (void)hipMemcpy(lw.data(), d_leftb, lw.size() * 4, hipMemcpyDeviceToHost);
+          std::vector<uint8_t> cls((size_t)n);
+          (void)hipMemcpy(cls.data(), c->d_cls.p, (size_t)n, hipMemcpyDeviceToHost);
+          for (uint32_t w : lw)
+            std::fprintf(stderr, "[elector]   window %u: Lr %lld Lc %lld Lu %lld class byte %d\n", w, (long long)(off[3 * w + 1] - off[3 * w]),
+                         (long long)(off[3 * w + 2] - off[3 * w + 1]), (long long)(off[3 * w + 3] - off[3 * w + 2]), (int)cls[w]);
+        }
+      }
       a.perm = d_leftb;
       a.count_ptr = d_counters;
       a.mark_b = d_done_b;
