@@ -444,6 +444,7 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
       xinfo[n + 1] = ((uint32_t)xs[n] << 8) | ((uint32_t)fl << 16) | kN_NewCol;   // node 0: the virtual start is column 0, one back
     }
     W.n1 = L;
+    W.k2n = 0;
     return;
   }
   if (W.triv == 5) {
@@ -456,6 +457,7 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
     if (g == 0)
       xinfo[L + 1] = ((uint32_t)ys[0] << 8) | ((uint32_t)(kFlagHasCor | kFlagInitial | kFlagFinal) << 16) | kN_NewCol | kN_Virt1;
     W.n1 = L + 1;
+    W.k2n = 0;
     return;
   }
   const int Lc = W.Lc, nm = min(L, Lc);
@@ -474,6 +476,7 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
       xinfo[i + 1] = rec;
     }
     W.n1 = L;
+    W.k2n = e + 1 < L ? 1 : 0;                       // the one two-predecessor node, ordinal 0 (the record's ordinal bits are 0)
     return;
   }
   if (W.triv == 4) {
@@ -494,6 +497,7 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
       xinfo[n + 1] = rec;
     }
     W.n1 = L + 1;
+    W.k2n = e + 1 <= L ? 1 : 0;
     return;
   }
   for (int i = g; i < L; i += G) {
@@ -514,6 +518,7 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
     }
   }
   W.n1 = L + 1;
+  W.k2n = e + 1 < L ? 1 : 0;
 }
 
 // the column layout rule in its plain serial form (one lane): the fallback of the parallel version in k_poa
@@ -1066,17 +1071,21 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const bool on = W[h].valid && keep[h];
+    const bool cnt_on = on && W[h].triv == 0;           // the directly written graphs have at most one such node, ordinal 0
     const int n1 = W[h].n1;
     const int cn = (n1 + G - 1) / G;
-    int cnmax = on ? cn : 0;
+    int cnmax = cnt_on ? cn : 0;
     for (int d = G; d < 64; d <<= 1) cnmax = max(cnmax, __shfl_xor(cnmax, d));
     cnmax = __builtin_amdgcn_readfirstlane(cnmax);
-    const int j0 = 1 + g * cn, j1 = on ? min(n1 + 1, j0 + cn) : 0;
+    const int j0 = 1 + g * cn, j1 = cnt_on ? min(n1 + 1, j0 + cn) : 0;
     int cnt = 0;
     for (int it = 0; it < cnmax; ++it) { const int jj = j0 + it; if (jj < j1) cnt += (xinfo[h][jj] & kN_Has2) != 0; }
-    int sc = cnt;
-    for (int d = 1; d < G; d <<= 1) { const int t = __shfl_up(sc, d, G); if (g >= d) sc += t; }
-    const int k2n = __shfl(sc, G - 1, G);
+    int sc = cnt, scl = 0;
+    if (cnmax > 0) {                                   // (wave-uniform: no window of this wavefront came out of fusion #1)
+      for (int d = 1; d < G; d <<= 1) { const int t = __shfl_up(sc, d, G); if (g >= d) sc += t; }
+      scl = __shfl(sc, G - 1, G);
+    }
+    const int k2n = cnt_on ? scl : W[h].k2n;
     int k = sc - cnt;
     for (int it = 0; it < cnmax; ++it) {
       const int jj = j0 + it;
