@@ -54,6 +54,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_GINSTS_SIMPLE = 256 * 4 * 2.4 / 2
 VALU_PEAK_GINSTS = 256 * 4 * 2.4 / 4
 WORKLOADS = {   # BASELINE.json configs restated as synthetic profiles (elector_amd/synthetic.py)
+    "ecoli10x_c1": "E. coli ~10X example restated (configs[0]): 459 reads of ~9.5 kb, uncorrected 10.3% err (1:1:1), corrected 0.6%, "
+                   "8% trimmed / split, a few extended and a few stubs (run it with --reads 459; the whole real reference chain "
+                   "on these reads is pinned in tests/golden/c1_chain.json)",
     "ecoli30x_simlord_lordec": "E. coli 30X SimLord-like PacBio (15% err), LoRDEC-like corrected (1% err), ~8 kb reads",
     "yeast50x_nanosim_consent": "S. cerevisiae 50X NanoSim-like ONT (12% err), CONSENT-like corrected (2% err), ~8 kb reads, whole corrected reads",
     "yeast50x_nanosim_consent_split": "S. cerevisiae 50X NanoSim-like ONT (12% err), CONSENT-like corrected (2% err) with -split: 33% of the reads in 2-3 pieces, 10% trimmed, ~8 kb reads",
