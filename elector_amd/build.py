@@ -15,6 +15,7 @@ HDR = [os.path.join(HERE, "csrc", "poa_device.h"), os.path.join(HERE, "csrc", "c
        os.path.join(ROOT, "include", "elector_poa.h"), os.path.join(ROOT, "include", "elector_stats.h"),
        os.path.join(ROOT, "include", "elector_split.h")]
 OUT = os.path.join(HERE, "lib", "libelector_poa.so")
+POA_BIN = os.path.join(HERE, "bin", "poa")
 
 
 def hipcc_path():
@@ -28,7 +29,7 @@ def up_to_date():
     if not os.path.exists(OUT):
         return False
     t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(p) <= t for p in SRC + HDR)
+    return os.path.exists(POA_BIN) and all(os.path.getmtime(p) <= t for p in SRC + HDR + [os.path.join(HERE, "csrc", "poa_main.cpp")])
 
 
 def build(force=False, verbose=False):
@@ -38,6 +39,13 @@ def build(force=False, verbose=False):
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
            "-o", OUT] + SRC
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    # the `poa`-compatible executable on top of the library (elector_amd/bin/poa; finds the library through its rpath)
+    os.makedirs(os.path.dirname(POA_BIN), exist_ok=True)
+    cmd = [hipcc_path(), "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", POA_BIN,
+           os.path.join(HERE, "csrc", "poa_main.cpp"), "-L" + os.path.dirname(OUT), "-lelector_poa", "-Wl,-rpath,$ORIGIN/../lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
