@@ -627,6 +627,75 @@ __device__ __forceinline__ void traceback_b(const WinP (&W)[2], const uint32_t *
   }
 }
 
+// The same walk with the per-lane work of a round as straight code: everything is computed for every lane on
+// clamped addresses and merged with selects; the one rarely needed look-up (which of two predecessors a cell took:
+// one node per window has two) sits behind a wave-wide test.  The compiler turned the nested conditions of
+// traceback_b into some 250 instructions per round, most of them exec-mask bookkeeping.
+template <int G, int R>
+__device__ __forceinline__ void traceback_b2(const WinP (&W)[2], const uint32_t *mv, int q, int g, uint32_t *(&xinfo)[2],
+                                             uint8_t *(&ordb)[2], uint16_t *(&x2y)[2], const int (&bestx)[2],
+                                             bool (&bad)[2], int &rounds)
+{
+  int x[2], y[2], guard[2];
+  bool alive[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    x[h] = W[h].valid ? bestx[h] : -1; y[h] = W[h].Lu - 1; guard[h] = W[h].n1 + W[h].Lu + 2; alive[h] = W[h].valid;
+    bad[h] = false;
+  }
+  while (__builtin_amdgcn_ballot_w64(alive[0] || alive[1]) != 0) {
+    ++rounds;
+    int cx[2], cy[2], rk[2], rlv[2];
+    bool inb[2];
+    uint32_t word[2], rec[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      cx[h] = x[h] - g; cy[h] = y[h] - g;
+      inb[h] = alive[h] && (cx[h] | cy[h]) >= 0;
+      const int cyc = inb[h] ? cy[h] : 0, cxc = inb[h] ? cx[h] : -1;
+      const int rl = cyc / R;
+      rlv[h] = rl; rk[h] = cyc - rl * R;
+      word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(q, cxc + 1 + rl, rl) : 0));
+      rec[h] = xinfo[h][cxc + 1];                                        // record 0 is the zero guard
+    }
+    // which of two predecessors: only cells at the (rare) two-predecessor nodes that step along x ask
+    int sec[2] = {0, 0};
+    {
+      bool ask[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) ask[h] = inb[h] && (rec[h] & kN_Has2) != 0u;
+      if (__builtin_amdgcn_ballot_w64(ask[0] || ask[1]) != 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (ask[h]) sec[h] = (ordb[h][(rec[h] >> 24) * G + rlv[h]] >> rk[h]) & 1;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t two = inb[h] ? (word[h] >> (16 * h + 2 * rk[h])) & 3u : 0u;
+      const int m = (int)(two >> 1), xw = (int)(two & 1u);
+      const int xo = inb[h] ? (m | xw) : 0, yo = inb[h] ? (m | (xw ^ 1)) : 0;
+      const int far = (int)((rec[h] >> sec[h]) & 1u);                   // bit 0: first predecessor two back, bit 1: second
+      int px = cx[h] - 1 - far;                                        // < 0: the virtual start
+      const bool virt = px < -1 || (sec[h] == 0 && (rec[h] & kN_Virt1) != 0u);
+      px = xo ? (virt ? -1 : px) : cx[h];
+      const bool diag = xo && yo;                                      // (inb is in both)
+      const int run = pk_diag_run<G>(diag && px == cx[h] - 1, q);
+      if (diag && g <= run) x2y[h][cx[h]] = (uint16_t)cy[h];           // the run's pairs, and the breaker's if it is a match
+      const int nxp = ((px + 2) & 0xFFF) | (((cy[h] - yo + 2) & 0xFFF) << 12) | (inb[h] ? 0 : 1 << 24);
+      const int nxt = __shfl(nxp, min(run, G - 1), G);
+      const bool whole = run >= G;
+      const int nx = whole ? x[h] - G : (nxt & 0xFFF) - 2, ny = whole ? y[h] - G : ((nxt >> 12) & 0xFFF) - 2;
+      const bool stop = !whole && (nxt >> 24) != 0;
+      if (alive[h]) {
+        x[h] = nx; y[h] = ny;
+        if (stop) alive[h] = false;
+        else if (--guard[h] <= 0) { bad[h] = true; alive[h] = false; }
+      }
+    }
+  }
+}
+
 // fusion #2 and the MSA columns (lpo.c:602-668 column layout rule, lpo_format.c:337-393) over the window's G
 // lanes, as in k_fused_b: every ring of the (ref + cor) graph is one column, an uncorrected letter aligned to
 // one of the ring's nodes joins it, every other uncorrected letter gets a column of its own just before the
@@ -1292,7 +1361,8 @@ __global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
   __syncthreads();
   bool badb[2] = {false, false};
   int tb_rounds = 0;
-  traceback_b<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);
+  if (a.debug & 2048) traceback_b<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);      // round 2's form (A/B)
+  else traceback_b2<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);
   if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 11, (unsigned long long)tb_rounds);
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(6);
