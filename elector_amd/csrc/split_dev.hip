@@ -803,22 +803,36 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
     pred_S1 = (uint32_t)(L0.aa[a0] + k); pred_ref = (uint32_t)(L0.ar[a0] + k); pred_S2 = (uint32_t)(L0.ab[a0] + k);
     i = 1;
   }
-  // ---- the chain (:279-293), thread 0; every thread follows the cursors (cheap, uniform) ----
-  for (; i < nbl - 1; ++i) {
-    const int an = L0.cl[i];
-    const int size_R = (int)((uint32_t)L0.ar[an] - pred_ref), size_S1 = (int)((uint32_t)L0.aa[an] - pred_S1),
-              size_S2 = (int)((uint32_t)L0.ab[an] - pred_S2);           // ref: ints from unsigned arithmetic, compared as unsigned
-    if ((uint32_t)size_R > 20u && (uint32_t)size_S1 > 20u && (uint32_t)size_S2 > 20u &&
-        abs(size_S1 - size_R) < size_R * 0.5 && abs(size_S2 - size_R) < size_R * 0.5) {
-      if (tid == 0) {
-        const DSeq wr = dsub(DSeq{0, ref.n}, pred_ref, (uint32_t)(L0.ar[an] - (int)pred_ref + k)),
-                   w1 = dsub(DSeq{0, S1.n}, pred_S1, (uint32_t)(L0.aa[an] - (int)pred_S1 + k)),
-                   w2 = dsub(DSeq{0, S2.n}, pred_S2, (uint32_t)(L0.ab[an] - (int)pred_S2 + k));
-        wpush(o, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, (uint32_t)w2.base, w2.n, 0);
+  // ---- the chain (:279-293): wavefront 0 fetches the chain's anchors 64 at a time (two dependent LDS reads per
+  // anchor, all in flight together) and walks them out of registers -- the walk itself is serial (a window is cut
+  // against the end of the window before it), its loads need not be; thread 0 writes the windows ----
+  if (tid < 64) {
+    for (int base = i; base < nbl - 1; base += 64) {
+      const int idx = base + tid;
+      const bool in = idx < nbl - 1;
+      const int anl = in ? (int)L0.cl[idx] : 0;
+      const int vr = in ? (int)L0.ar[anl] : 0, va = in ? (int)L0.aa[anl] : 0, vb = in ? (int)L0.ab[anl] : 0;
+      const int cnt = min(64, nbl - 1 - base);
+      for (int l = 0; l < cnt; ++l) {
+        const int ar_ = __builtin_amdgcn_readlane(vr, l), aa_ = __builtin_amdgcn_readlane(va, l), ab_ = __builtin_amdgcn_readlane(vb, l);
+        const int size_R = (int)((uint32_t)ar_ - pred_ref), size_S1 = (int)((uint32_t)aa_ - pred_S1),
+                  size_S2 = (int)((uint32_t)ab_ - pred_S2);             // ref: ints from unsigned arithmetic, compared as unsigned
+        if ((uint32_t)size_R > 20u && (uint32_t)size_S1 > 20u && (uint32_t)size_S2 > 20u &&
+            abs(size_S1 - size_R) < size_R * 0.5 && abs(size_S2 - size_R) < size_R * 0.5) {
+          if (tid == 0) {
+            const DSeq wr = dsub(DSeq{0, ref.n}, pred_ref, (uint32_t)(ar_ - (int)pred_ref + k)),
+                       w1 = dsub(DSeq{0, S1.n}, pred_S1, (uint32_t)(aa_ - (int)pred_S1 + k)),
+                       w2 = dsub(DSeq{0, S2.n}, pred_S2, (uint32_t)(ab_ - (int)pred_S2 + k));
+            wpush(o, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, (uint32_t)w2.base, w2.n, 0);
+          }
+          pred_S1 = (uint32_t)(aa_ + k); pred_ref = (uint32_t)(ar_ + k); pred_S2 = (uint32_t)(ab_ + k);
+        }
       }
-      pred_S1 = (uint32_t)(L0.aa[an] + k); pred_ref = (uint32_t)(L0.ar[an] + k); pred_S2 = (uint32_t)(L0.ab[an] + k);
     }
+    if (tid == 0) { sh[4] = (int)pred_ref; sh[5] = (int)pred_S1; sh[6] = (int)pred_S2; }
   }
+  __syncthreads();
+  pred_ref = (uint32_t)sh[4]; pred_S1 = (uint32_t)sh[5]; pred_S2 = (uint32_t)sh[6];
   // ---- the end (:294-306) ----
   const DSeq er = dsub(DSeq{0, ref.n}, pred_ref), e1 = dsub(DSeq{0, S1.n}, pred_S1), e2 = dsub(DSeq{0, S2.n}, pred_S2);
   const bool rec_end = (uint64_t)e2.n * 2 < er.n && er.n - e2.n > 200;
@@ -862,14 +876,21 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   __syncthreads();
 }
 
-// ref: largest_fragment (:158-169) measures every LINE of the "header\nseq\n" text, header lines included
-__device__ uint32_t largest_fragment(const int32_t *wl, int n, uint32_t hdr_len)
+// ref: largest_fragment (:158-169) measures every LINE of the "header\nseq\n" text, header lines included.
+// Workgroup-wide: the window list sits in HBM (thread 0 wrote it), and one thread reading its few hundred lengths
+// one after the other was a quarter of a read's time -- every thread takes a share, the maximum goes through LDS.
+__device__ uint32_t largest_fragment(const int32_t *wl, int n, uint32_t hdr_len, int *slot)
 {
-  uint32_t res = 0;
-  for (int w = 0; w < n; ++w) {
-    res = max(res, w == 0 ? hdr_len : hdr_len + 1);
-    res = max(res, (uint32_t)ldg(wl + 8 * (int64_t)w + 1) + 1);
-  }
+  const int tid = threadIdx.x;
+  if (tid == 0) *slot = 0;
+  __syncthreads();
+  uint32_t r = 0;
+  for (int w = tid; w < n; w += kSplitThreads) r = max(r, (uint32_t)ldg(wl + 8 * (int64_t)w + 1) + 1);
+  r = wave_max(r);
+  if ((tid & 63) == 0 && r) atomicMax(slot, (int)r);
+  __syncthreads();
+  uint32_t res = (uint32_t)*slot;
+  if (n >= 1) res = max(res, n >= 2 ? hdr_len + 1 : hdr_len);
   return res;
 }
 
@@ -932,9 +953,7 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 512 ? 4 : 2))
       split_read(g, L0, L1, ref, S1, S2, kk, best, tmp, sh);
       int nbest = sh[0];
       bool over = sh[1] != 0;
-      if (tid == 0) sh[2] = (int)largest_fragment(best, nbest, (uint32_t)a.hdr_len[r]);
-      __syncthreads();
-      uint32_t largest = (uint32_t)sh[2];
+      uint32_t largest = largest_fragment(best, nbest, (uint32_t)a.hdr_len[r], &sh[2]);
       for (;;) {
         kk -= 2;
         if (kk < 9 || over) break;
@@ -942,9 +961,7 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 512 ? 4 : 2))
         split_read(g, L0, L1, ref, S1, S2, kk, aux, tmp, sh);
         const int naux = sh[0];
         over = over || sh[1] != 0;
-        if (tid == 0) sh[3] = (int)largest_fragment(aux, naux, (uint32_t)a.hdr_len[r]);
-        __syncthreads();
-        const uint32_t la = (uint32_t)sh[3];
+        const uint32_t la = largest_fragment(aux, naux, (uint32_t)a.hdr_len[r], &sh[3]);
         if (la < largest) { largest = la; int32_t *t = best; best = aux; aux = t; nbest = naux; }
         else break;
       }
