@@ -43,6 +43,20 @@ constexpr int kMaxAnchors = 3000;          // LDS: 5 ints per anchor
 
 struct DSeq { int64_t base; uint32_t n; };   // base: byte offset into the reads buffer
 
+// v, known to be the same in every lane of the wavefront, as a value the compiler knows to be uniform
+template <class T>
+__device__ __forceinline__ T uniform(const T &v)
+{
+  static_assert(sizeof(T) % 4 == 0, "uniform(): whole dwords");
+  uint32_t w[sizeof(T) / 4];
+  __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i]);
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+
 struct SplitArgs {
   int64_t n_reads;
   const uint8_t *reads;
@@ -175,7 +189,6 @@ struct WG {
   int64_t tab_cap, maxwin;
   unsigned long long *stamps;     // debug (ELECTOR_DEBUG_SPLIT): cycles per phase, summed over reads
   int lds_tab;                    // LDS tables (tables_lds): dword offset in the dynamic LDS, or -1
-  int *lds_flag;
 };
 
 #define SP_STAMP(idx)                                                                      \
@@ -221,7 +234,7 @@ constexpr uint32_t kLdsSeqWords = kLdsMaxN / 16 + 3;
 constexpr uint32_t kLdsBitWords = 2 * ((kLdsMaxN + 63) / 64 + 1);       // candidate bitmap: one bit per reference position, as dwords
 constexpr uint32_t kLdsAncTab = 6 * (kLdsBitWords / 2);                   // per bitmap word: the anchor walk's exit table (anchors_lds),
 static_assert(kLdsAncTab * 4 <= kLdsCapRef * 2, "the exit tables overlay the reference's k-mer table");   // which is dead by then
-constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4;
+constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4 + 8;   // + the fill counter and flag
 
 struct LTab {
   uint32_t *w;            // slots, two per word
@@ -280,9 +293,101 @@ struct LTab {
   }
 };
 
+// Table phases as FLAT loops.  A thread has some sixteen k-mers to look up per phase; written as "for every k-mer:
+// probe until found", a wavefront stays in the inner loop until the longest of its 64 probe chains ends (about seven
+// probes at half load) before any lane may take its next k-mer: sixteen times seven probe rounds.  Here every lane is
+// a small state machine -- one probe per loop turn, and a lane whose look-up ends takes its next k-mer in that very
+// turn -- so a wavefront runs for the longest SUM of probe chains among its lanes, about sixteen times two.  For the
+// same reason a phase that looks up and then inserts does so in two loops: an insertion nested in the look-up's turn
+// (a probe loop of its own, with a CAS) was paid by the whole wavefront in nearly every turn.
+// A lane's k-mers are those at positions tid + q * kSplitThreads; which of them a loop handles is a mask over q.
+static_assert(kLdsMaxN <= 32u * (uint32_t)kSplitThreads, "a lane's positions as one 32-bit mask");
+__device__ __forceinline__ uint32_t lane_positions(uint32_t np)
+{
+  const uint32_t tid = threadIdx.x;
+  if (tid >= np) return 0u;
+  const uint32_t nq = (np - tid + (uint32_t)kSplitThreads - 1u) / (uint32_t)kSplitThreads;
+  return nq >= 32u ? 0xFFFFFFFFu : (1u << nq) - 1u;
+}
+
+// the lane's k-mers of seq named by todo that occur exactly once in t -> mask of the same kind
+__device__ __forceinline__ uint32_t flat_find(const LTab &t, const uint32_t *seq, uint32_t todo, uint32_t kmsk, unsigned long long *turns = nullptr)
+{
+  const uint32_t tid = threadIdx.x;
+  uint32_t hits = 0, nturn = 0;
+  bool active = todo != 0u;
+  uint32_t q = active ? (uint32_t)__builtin_ctz(todo) : 0u;
+  uint32_t code = active ? LTab::bits(seq, tid + q * kSplitThreads, kmsk) : 0u;
+  // the code of the lane's next k-mer is fetched a look-up ahead: its LDS read is not on the path of the turn that
+  // ends a look-up
+  uint32_t rest = todo & (todo - 1u);
+  uint32_t code_next = rest ? LTab::bits(seq, tid + (uint32_t)__builtin_ctz(rest) * kSplitThreads, kmsk) : 0u;
+  uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0;
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    ++nturn;
+    if (active) {
+      const uint32_t e = (t.w[h >> 1] >> ((h & 1u) * 16u)) & 0xFFFFu;
+      int res = -2;                                                  // -2: go on probing
+      if (e == 0xFFFFu || probes > t.mask) res = -1;
+      else if (LTab::bits(t.seq, e & 0x7FFFu, t.kmsk) == code) res = (e & 0x8000u) ? -1 : (int)(e & 0x7FFFu);
+      if (res == -2) { h = (h + step) & t.mask; ++probes; }
+      else {
+        if (res >= 0) hits |= 1u << q;
+        todo = rest;
+        active = todo != 0u;
+        q = active ? (uint32_t)__builtin_ctz(todo) : 0u;
+        code = code_next;
+        h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
+        rest = todo & (todo - 1u);
+        code_next = rest ? LTab::bits(seq, tid + (uint32_t)__builtin_ctz(rest) * kSplitThreads, kmsk) : 0u;
+      }
+    }
+  }
+  if (turns && threadIdx.x == 0) atomicAdd(turns, (unsigned long long)nturn);
+  return hits;
+}
+
+// the lane's k-mers of t's own sequence named by todo into t (LTab::add as a flat loop).  fill (LDS) counts the new
+// entries when given; once it passes limit every lane stops (the caller then gives the tables up), looked at every
+// eighth turn -- at most a few hundred entries late, and a table that has filled up meanwhile only costs those turns.
+__device__ __forceinline__ void flat_add(const LTab &t, uint32_t todo, int *fill = nullptr, int limit = 0)
+{
+  const uint32_t tid = threadIdx.x;
+  bool active = todo != 0u;
+  uint32_t p = active ? tid + (uint32_t)__builtin_ctz(todo) * kSplitThreads : 0u;
+  uint32_t code = active ? LTab::bits(t.seq, p, t.kmsk) : 0u;
+  uint32_t rest = todo & (todo - 1u);
+  uint32_t code_next = rest ? LTab::bits(t.seq, tid + (uint32_t)__builtin_ctz(rest) * kSplitThreads, t.kmsk) : 0u;
+  uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0, nturn = 0;
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    if (active) {
+      uint32_t *word = t.w + (h >> 1);
+      const uint32_t sh = (h & 1u) * 16u;
+      const uint32_t old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t cur = (old >> sh) & 0xFFFFu;
+      bool fin = false;
+      if (cur == 0xFFFFu) {
+        fin = atomicCAS(word, old, (old & ~(0xFFFFu << sh)) | (p << sh)) == old;   // lost the race: look at the slot again
+        if (fin && fill) atomicAdd(fill, 1);
+      } else if (LTab::bits(t.seq, cur & 0x7FFFu, t.kmsk) == code) { if (!(cur & 0x8000u)) atomicOr(word, 0x8000u << sh); fin = true; }
+      else { h = (h + step) & t.mask; fin = ++probes > t.mask; }
+      if (fin) {
+        todo = rest;
+        active = todo != 0u;
+        p = active ? tid + (uint32_t)__builtin_ctz(todo) * kSplitThreads : 0u;
+        code = code_next;
+        h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
+        rest = todo & (todo - 1u);
+        code_next = rest ? LTab::bits(t.seq, tid + (uint32_t)__builtin_ctz(rest) * kSplitThreads, t.kmsk) : 0u;
+      }
+    }
+    if (fill && (++nturn & 7u) == 0u && __builtin_amdgcn_readfirstlane(*(volatile int *)fill) > limit) break;
+  }
+}
+
 // the three table phases and the candidate arrays of split_core on the LDS tables; false (uniform) when a table
 // filled up: nothing has been written to ca / cb then and the HBM tables take the call
-__device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, int *flag, const uint8_t *pr, uint32_t nr,
+__device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, const uint8_t *pr, uint32_t nr,
                            const uint8_t *p1, uint32_t n1, const uint8_t *p2, uint32_t n2, int k)
 {
   const int tid = threadIdx.x;
@@ -306,42 +411,35 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
       dst[wdx] = v;
     }
   };
+  uint32_t *bm = s2 + kLdsSeqWords;
+  // the fill counter and the "table full" flag live behind the bitmap, in the dynamic LDS like everything else here:
+  // through a plain pointer to a __shared__ variable the counter's atomicAdd became a FLAT atomic (the compiler no
+  // longer knows the address space), a far slower path than ds_add, once per k-mer that enters the second table
+  int *flag = reinterpret_cast<int *>(bm + kLdsBitWords);
   pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2);
+  for (uint32_t i = tid; i < kLdsBitWords; i += kSplitThreads) bm[i] = 0u;
   for (uint32_t i = tid; i < (kLdsCapRef + 2 * kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
-  if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+  if (tid == 0) flag[0] = 0;
   __syncthreads();
   SP_STAMP(0);
   const LTab tr{wr, kLdsCapRef - 1, sr, kmsk}, t1{w1, kLdsCapOther - 1, s1, kmsk}, t2{w2, kLdsCapOther - 1, s2, kmsk};
   const uint32_t npr = n_kmers(nr, k), np1 = n_kmers(n1, k), np2 = n_kmers(n2, k);
-  for (uint32_t p = tid; p < npr; p += kSplitThreads) tr.add(LTab::bits(sr, p, kmsk), p);
+  const uint32_t all_r = lane_positions(npr), all_1 = lane_positions(np1), all_2 = lane_positions(np2);
+  flat_add(tr, all_r);
   __syncthreads();
   SP_STAMP(1);
-  for (uint32_t p = tid; p < np1; p += kSplitThreads) {
-    const uint32_t c = LTab::bits(s1, p, kmsk);
-    if (tr.find(c) >= 0 && t1.add(c, p) && atomicAdd(&flag[0], 1) >= (int)kLdsFill) { flag[1] = 1; break; }
-  }
+  flat_add(t1, flat_find(tr, s1, all_1, kmsk, g.stamps ? g.stamps + 13 : nullptr), flag, (int)kLdsFill);
   __syncthreads();
   SP_STAMP(2);
-  if (flag[1]) return false;
-  for (uint32_t p = tid; p < np2; p += kSplitThreads) {
-    const uint32_t c = LTab::bits(s2, p, kmsk);
-    if (t1.find(c) >= 0) t2.add(c, p);                         // no more distinct k-mers than the table before holds
-  }
+  if (flag[0] > (int)kLdsFill) return false;
+  flat_add(t2, flat_find(t1, s2, all_2, kmsk));                // no more distinct k-mers than the table before holds
   __syncthreads();
   SP_STAMP(3);
-  // candidates: the reference positions whose k-mer is unique in all three reads, one bit each (a wavefront covers 64
-  // consecutive positions per round: its ballot is the bitmap's word); the partner positions are looked up again for
-  // the few positions that become anchors (anchors_lds)
-  uint32_t *bm = s2 + kLdsSeqWords;
-  for (uint32_t p0 = 0; p0 < npr; p0 += kSplitThreads) {
-    const uint32_t p = p0 + tid;
-    bool hit = false;
-    if (p < npr) {
-      const uint32_t c = LTab::bits(sr, p, kmsk);
-      hit = t2.find(c) >= 0 && t1.find(c) >= 0;
-    }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-    if ((tid & 63) == 0 && p < npr) { bm[2 * (p >> 6)] = (uint32_t)m; bm[2 * (p >> 6) + 1] = (uint32_t)(m >> 32); }
+  // candidates: the reference positions whose k-mer is unique in all three reads, one bit each in the (cleared)
+  // bitmap; the partner positions are looked up again for the few positions that become anchors (anchors_lds)
+  for (uint32_t c = flat_find(t1, sr, flat_find(t2, sr, all_r, kmsk), kmsk); c; c &= c - 1u) {
+    const uint32_t p = (uint32_t)tid + (uint32_t)__builtin_ctz(c) * kSplitThreads;
+    atomicOr(bm + (p >> 5), 1u << (p & 31u));
   }
   return true;
 }
@@ -516,8 +614,18 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // tables, anchors and the best chain of one split() call (ref: split :175-255, best_chain :79-126).
 // Workgroup-wide.  On return L.s->n anchors, L.s->nchain chain entries (indices of the chain in L.cl[0 .. nchain), reused).
 template <class LV>
-__device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize)
+__device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize)
 {
+  // This function is not inlined (three call sites, a long body): behind the references its arguments live in the
+  // caller's scratch memory, and every use of a member after a store the compiler cannot tell apart from it is a
+  // FLAT load from there -- once per anchor in the chain loop below, on its critical path.  Copies in registers.
+  // The arguments of such a function also arrive in vector registers, and the compiler must take everything computed
+  // from them for divergent: loop counters, addresses and branch conditions that are the same in all lanes went
+  // through the vector ALU and exec-mask loops.  uniform() (v_readfirstlane) says what they are.
+  const WG g = uniform(g_in);
+  const LV L = uniform(L_in);
+  ref = uniform(ref); S1 = uniform(S1); S2 = uniform(S2);
+  k = uniform(k); minSize = uniform(minSize);
   const uint8_t *pr = g.reads + ref.base, *p1 = g.reads + S1.base, *p2 = g.reads + S2.base;
   const int tid = threadIdx.x;
   // table sizes: power of two >= 2 n + 2 (splitter.cpp), within the scratch
@@ -531,7 +639,8 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
   // like the reference's, tell such k-mers apart the way the reference does)
   bool on_chip = g.lds_tab >= 0 && ref.n <= kLdsMaxN && S1.n <= kLdsMaxN && S2.n <= kLdsMaxN &&
                  ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
-  if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, g.lds_flag, pr, ref.n, p1, S1.n, p2, S2.n, k);
+  if (g.stamps && tid == 0) { atomicAdd(g.stamps + 11, (unsigned long long)ref.n); atomicAdd(g.stamps + 12, (unsigned long long)S1.n); }
+  if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, pr, ref.n, p1, S1.n, p2, S2.n, k);
   if (on_chip) {
     if (g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
     __syncthreads();
@@ -660,7 +769,8 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
   SP_STAMP(5);
   }
   // longest chain, back to front (:79-126): wavefront 0
-  const int n = L.s->n;
+  const int n = uniform(L.s->n);
+  if (g.stamps && tid == 0) atomicAdd(g.stamps + 14, (unsigned long long)n);
   if (tid < 64 && n > 0) {
     // The successors an anchor can chain to lie within 1000 reference bases: at most 48 anchors, which the
     // wavefront keeps in registers -- lane l holds anchor i + 1 + l (positions and chain length), shifted by one
@@ -668,6 +778,49 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
     // path; the anchors themselves are fetched 64 at a time.
     int wr = 0, wa = 0, wb = 0, wc = 0;
     int fr = 0, fa = 0, fb = 0;
+    if (minSize >= 15u && n <= 0xFFFF) {
+      // The usual case (anchors at least 16 bases apart: fewer than 63 within 1000 bases) the other way round: not
+      // "anchor i looks at its successors" -- a maximum over the wavefront per anchor, on the critical path -- but
+      // "anchor i, once its chain length is known, offers itself to its predecessors".  Lane l keeps the one
+      // anchor with index = l (mod 64) that is still waiting (indices i - 63 .. i) and the best offer it has had;
+      // anchors finish in descending order, so when i's turn comes every successor in reach has made its offer:
+      // one readlane instead of a reduction, and each lane updates its own maximum.  Later offers come from
+      // earlier anchors: the key (length, 0xFFFF - index) keeps the longest and, among equals, the earliest.
+      using E = typename LV::elem;
+      const int lane = tid;
+      auto fetch = [&](int b, int &r, int &a, int &bb) {
+        const int j = b * 64 + lane;
+        const bool v = b >= 0 && j < n;
+        r = v ? (int)L.ar[j] : 0x7fffffff; a = v ? (int)L.aa[j] : 0; bb = v ? (int)L.ab[j] : 0;   // (no offer passes the test of an empty lane)
+      };
+      const int c0 = (n - 1) & 63, b0 = (n - 1) >> 6;
+      int nr, na, nb, pr, pa, pb;
+      fetch(b0 - 1, nr, na, nb);                              // what enters a lane when its anchor has finished: the block below
+      fetch(b0, pr, pa, pb);
+      if (lane > c0) { pr = nr; pa = na; pb = nb; }
+      uint32_t offer = 0;
+      int rcl = 0, rcn = 0;
+      for (int i = n - 1; i >= 0; --i) {
+        const int c = i & 63;
+        if (c == 63 && i != n - 1) fetch((i >> 6) - 1, nr, na, nb);     // the lanes now hold exactly block i / 64
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)offer, c);
+        const int sr = __builtin_amdgcn_readlane(pr, c), sa = __builtin_amdgcn_readlane(pa, c), sb = __builtin_amdgcn_readlane(pb, c);
+        const int cl_i = (int)(key >> 16);                                // 1 + the successor's length, 0 without one
+        const int cn_i = key ? 0xFFFF - (int)(key & 0xFFFFu) : -1;
+        const bool here = lane == c;
+        rcl = here ? cl_i : rcl; rcn = here ? cn_i : rcn;
+        pr = here ? nr : pr; pa = here ? na : pa; pb = here ? nb : pb;    // anchor i - 64 takes the lane
+        offer = here ? 0u : offer;
+        const uint32_t mine = ((uint32_t)(cl_i + 1) << 16) | (uint32_t)(0xFFFF - i);
+        // (ref :98-110) a successor lies less than 1000 further on in all three reads, and further on at all
+        const bool ok = (uint32_t)(sr - pr - 1) < 999u && (uint32_t)(sa - pa - 1) < 999u && (uint32_t)(sb - pb - 1) < 999u;
+        offer = max(offer, ok ? mine : 0u);
+        if (c == 0) {                                                    // a block is complete: its results go to the arrays
+          const int j = i + lane;
+          if (j < n) { L.cl[j] = (E)rcl; L.cn[j] = (E)rcn; }
+        }
+      }
+    } else
     for (int i = n - 1; i >= 0; --i) {
       if (i == n - 1 || (i & 63) == 63) {
         const int jj = (i & ~63) + tid;
@@ -712,12 +865,24 @@ __device__ void split_core(const WG &g, const LV &L, DSeq ref, DSeq S1, DSeq S2,
       const int ov = __shfl_xor(v, d), oi = __shfl_xor(vi, d);
       if (ov > v || (ov == v && oi < vi)) { v = ov; vi = oi; }
     }
-    if (tid == 0) {
-      L.s->start = vi;
-      // the chain as a list of anchor indices, written over cl (no longer needed)
-      int c = 0;
-      for (int i = vi; i != LV::kNoNext; i = (int)L.cn[i]) L.cl[c++] = (typename LV::elem)i;
-      L.s->nchain = c;
+    // the chain as a list of anchor indices, written over cl (no longer needed).  The chain only moves forward, so
+    // the walk goes block by block: a block's 64 successors in a register, the steps inside the block by readlane
+    // (no LDS read per step), the visited anchors as a mask whose lanes then write their list entries together.
+    {
+      int i = uniform(vi), c = 0;
+      while (i != LV::kNoNext) {
+        const int blk = i >> 6;
+        const int j = blk * 64 + tid;
+        const int nx = j < n ? (int)L.cn[j] : (int)LV::kNoNext;
+        unsigned long long seen = 0;
+        do {
+          seen |= 1ull << (i & 63);
+          i = __builtin_amdgcn_readlane(nx, i & 63);
+        } while (i != LV::kNoNext && (i >> 6) == blk);
+        if ((seen >> tid) & 1ull) L.cl[c + __builtin_popcountll(seen & ((1ull << tid) - 1ull))] = (typename LV::elem)j;
+        c += __builtin_popcountll(seen);
+      }
+      if (tid == 0) { L.s->start = vi; L.s->nchain = c; }
     }
   }
   __syncthreads();
@@ -919,7 +1084,6 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 512 ? 4 : 2))
     L0.cap = L1.cap = cap;
     L0.s = &s_lvl[0]; L1.s = &s_lvl[1];
   }
-  __shared__ int s_flag[2];
   WG g;
   g.reads = a.reads;
   for (int t = 0; t < 3; ++t) {
@@ -932,7 +1096,6 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 512 ? 4 : 2))
   g.tab_cap = a.tab_cap; g.maxwin = a.maxwin;
   g.stamps = a.stamps;
   g.lds_tab = (!BIG && a.lds_tables) ? (int)((2 * 5 * a.maxanc * sizeof(AT) + 3) / 4) : -1;
-  g.lds_flag = s_flag;
   for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     const DSeq ref{a.read_off[3 * r], (uint32_t)(a.read_off[3 * r + 1] - a.read_off[3 * r])};
     const DSeq S1{a.read_off[3 * r + 1], (uint32_t)(a.read_off[3 * r + 2] - a.read_off[3 * r + 1])};
@@ -1176,8 +1339,8 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     unsigned long long hs[16];
     (void)hipMemcpy(hs, a.stamps, sizeof hs, hipMemcpyDeviceToHost);
     const double nc = hs[7] ? (double)hs[7] : 1.0, nr = hs[9] ? (double)hs[9] : 1.0;
-    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu\n",
-                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7]);
+    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu; per pass: ref %.0f bases, unc %.0f, look-up turns of wavefront 0 in the unc phase %.1f, anchors %.1f\n",
+                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7], hs[11] / nc, hs[12] / nc, hs[13] / nc, hs[14] / nc);
   }
   (void)nthreads;
   int64_t n_host = 0;
