@@ -918,6 +918,7 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
 {
   const int tid = threadIdx.x;
   split_core(g, L0, ref, S1, S2, k, 20u);
+  unsigned long long sp_t_ = g.stamps ? __builtin_readcyclecounter() : 0;
   WList o{out, 0, g.maxwin, false};
   uint32_t pred_ref = 0, pred_S1 = 0, pred_S2 = 0;
   int i = 0;
@@ -934,7 +935,9 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   const uint32_t sr = min(ref.n, (uint32_t)(L0.ar[a0] + k)), s1 = min(S1.n, (uint32_t)(L0.aa[a0] + k)), s2 = min(S2.n, (uint32_t)(L0.ab[a0] + k));
   const bool rec_start = (uint64_t)s2 * 2 < sr && sr - s2 > 200;
   if (rec_start) {
+    SP_STAMP(15);
     split_core(g, L1, DSeq{ref.base, sr}, DSeq{S1.base, s1}, DSeq{ref.base, sr}, k, (uint32_t)(1.2 * s2));
+    if (g.stamps) sp_t_ = __builtin_readcyclecounter();
     if (tid == 0) {
       // the windows of the re-split (reference against uncorrected), by the plain rule; the corrected side
       // is the 'N' filler except in the last one, which takes what there is of the corrected start
@@ -972,28 +975,50 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   // anchor, all in flight together) and walks them out of registers -- the walk itself is serial (a window is cut
   // against the end of the window before it), its loads need not be; thread 0 writes the windows ----
   if (tid < 64) {
+    // Which anchors cut a window is decided one after the other (each against the end of the window before), in
+    // scalar integer code on values read out of the lanes -- |size_S - size_R| < size_R * 0.5 is 2 |d| < size_R, exactly;
+    // the windows themselves are then written by all accepted lanes at once: a lane finds the window before its own
+    // through the mask of accepted anchors.
+    uint32_t pr_ = uniform(pred_ref), p1_ = uniform(pred_S1), p2_ = uniform(pred_S2);
+    int on = uniform(o.n);
     for (int base = i; base < nbl - 1; base += 64) {
       const int idx = base + tid;
       const bool in = idx < nbl - 1;
       const int anl = in ? (int)L0.cl[idx] : 0;
       const int vr = in ? (int)L0.ar[anl] : 0, va = in ? (int)L0.aa[anl] : 0, vb = in ? (int)L0.ab[anl] : 0;
       const int cnt = min(64, nbl - 1 - base);
+      const uint32_t pr0 = pr_, p10 = p1_, p20 = p2_;
+      unsigned long long acc = 0;
       for (int l = 0; l < cnt; ++l) {
         const int ar_ = __builtin_amdgcn_readlane(vr, l), aa_ = __builtin_amdgcn_readlane(va, l), ab_ = __builtin_amdgcn_readlane(vb, l);
-        const int size_R = (int)((uint32_t)ar_ - pred_ref), size_S1 = (int)((uint32_t)aa_ - pred_S1),
-                  size_S2 = (int)((uint32_t)ab_ - pred_S2);             // ref: ints from unsigned arithmetic, compared as unsigned
+        const int size_R = (int)((uint32_t)ar_ - pr_), size_S1 = (int)((uint32_t)aa_ - p1_),
+                  size_S2 = (int)((uint32_t)ab_ - p2_);                 // ref: ints from unsigned arithmetic, compared as unsigned
         if ((uint32_t)size_R > 20u && (uint32_t)size_S1 > 20u && (uint32_t)size_S2 > 20u &&
-            abs(size_S1 - size_R) < size_R * 0.5 && abs(size_S2 - size_R) < size_R * 0.5) {
-          if (tid == 0) {
-            const DSeq wr = dsub(DSeq{0, ref.n}, pred_ref, (uint32_t)(ar_ - (int)pred_ref + k)),
-                       w1 = dsub(DSeq{0, S1.n}, pred_S1, (uint32_t)(aa_ - (int)pred_S1 + k)),
-                       w2 = dsub(DSeq{0, S2.n}, pred_S2, (uint32_t)(ab_ - (int)pred_S2 + k));
-            wpush(o, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, (uint32_t)w2.base, w2.n, 0);
-          }
-          pred_S1 = (uint32_t)(aa_ + k); pred_ref = (uint32_t)(ar_ + k); pred_S2 = (uint32_t)(ab_ + k);
+            2ll * llabs((long long)size_S1 - size_R) < (long long)size_R && 2ll * llabs((long long)size_S2 - size_R) < (long long)size_R) {
+          acc |= 1ull << l;
+          p1_ = (uint32_t)(aa_ + k); pr_ = (uint32_t)(ar_ + k); p2_ = (uint32_t)(ab_ + k);
         }
       }
+      const unsigned long long below = acc & ((1ull << tid) - 1ull);
+      const int prev = below ? 63 - __builtin_clzll(below) : 0;
+      const int qr = __shfl(vr, prev), qa = __shfl(va, prev), qb = __shfl(vb, prev);
+      if ((acc >> tid) & 1ull) {
+        const uint32_t mr = below ? (uint32_t)(qr + k) : pr0, m1 = below ? (uint32_t)(qa + k) : p10, m2 = below ? (uint32_t)(qb + k) : p20;
+        const int slot = on + __builtin_popcountll(below);
+        if (slot < o.cap) {
+          const DSeq wr = dsub(DSeq{0, ref.n}, mr, (uint32_t)(vr - (int)mr + k)),
+                     w1 = dsub(DSeq{0, S1.n}, m1, (uint32_t)(va - (int)m1 + k)),
+                     w2 = dsub(DSeq{0, S2.n}, m2, (uint32_t)(vb - (int)m2 + k));
+          int32_t *w = o.w + 8 * (int64_t)slot;
+          stg_global(w, (int)wr.base); stg_global(w + 1, (int)wr.n); stg_global(w + 2, (int)w1.base); stg_global(w + 3, (int)w1.n);
+          stg_global(w + 4, (int)w2.base); stg_global(w + 5, (int)w2.n); stg_global(w + 6, 0); stg_global(w + 7, 0);
+        }
+      }
+      on += __builtin_popcountll(acc);
     }
+    if (on > o.cap) { o.over = true; on = (int)o.cap; }
+    o.n = on;
+    pred_ref = pr_; pred_S1 = p1_; pred_S2 = p2_;
     if (tid == 0) { sh[4] = (int)pred_ref; sh[5] = (int)pred_S1; sh[6] = (int)pred_S2; }
   }
   __syncthreads();
@@ -1004,7 +1029,9 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   __syncthreads();              // L1 and tmp are about to be reused
   if (rec_end) {
     const DSeq gr{ref.base + er.base, er.n}, g1{S1.base + e1.base, e1.n};
+    SP_STAMP(15);
     split_core(g, L1, gr, g1, gr, k, (uint32_t)(1.2 * e2.n));
+    if (g.stamps) sp_t_ = __builtin_readcyclecounter();
     if (tid == 0) {
       WList t{tmp, 0, g.maxwin, false};
       const DSeq rr{0, er.n}, r1{0, e1.n};
@@ -1039,6 +1066,7 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   }
   if (tid == 0) { sh[0] = o.n; sh[1] = (o.over || L0.s->fail) ? 1 : 0; }
   __syncthreads();
+  SP_STAMP(15);
 }
 
 // ref: largest_fragment (:158-169) measures every LINE of the "header\nseq\n" text, header lines included.
@@ -1336,11 +1364,11 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   HIPCHK(c, hipStreamSynchronize(st));
   const double t2 = now_ms();
   if (dbg) {
-    unsigned long long hs[16];
+    unsigned long long hs[24];
     (void)hipMemcpy(hs, a.stamps, sizeof hs, hipMemcpyDeviceToHost);
     const double nc = hs[7] ? (double)hs[7] : 1.0, nr = hs[9] ? (double)hs[9] : 1.0;
-    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu; per pass: ref %.0f bases, unc %.0f, look-up turns of wavefront 0 in the unc phase %.1f, anchors %.1f\n",
-                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7], hs[11] / nc, hs[12] / nc, hs[13] / nc, hs[14] / nc);
+    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu; per pass: ref %.0f bases, unc %.0f, look-up turns of wavefront 0 in the unc phase %.1f, anchors %.1f; window lists (cycles per read) %.0f\n",
+                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7], hs[11] / nc, hs[12] / nc, hs[13] / nc, hs[14] / nc, hs[15] / nr);
   }
   (void)nthreads;
   int64_t n_host = 0;
