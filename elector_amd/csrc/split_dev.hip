@@ -232,7 +232,7 @@ constexpr uint32_t kLdsMaxN = 12500;
 constexpr uint32_t kLdsCapRef = 16384, kLdsCapOther = 4096, kLdsFill = 3200;
 constexpr uint32_t kLdsSeqWords = kLdsMaxN / 16 + 3;
 constexpr uint32_t kLdsBitWords = 2 * ((kLdsMaxN + 63) / 64 + 1);       // candidate bitmap: one bit per reference position, as dwords
-constexpr uint32_t kLdsAncTab = 6 * (kLdsBitWords / 2);                   // per bitmap word: the anchor walk's exit table (anchors_lds),
+constexpr uint32_t kLdsAncTab = 6 * (kLdsBitWords / 2);                   // per bitmap word: the anchor walk's exit table (anchors_lds), six dwords,
 static_assert(kLdsAncTab * 4 <= kLdsCapRef * 2, "the exit tables overlay the reference's k-mer table");   // which is dead by then
 constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4 + 8;   // + the fill counter and flag
 
@@ -449,8 +449,11 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
 // last_indexed starts at 0).  Wavefront 0 holds the bitmap in registers and walks it with scalar code; all threads
 // then look the anchors' partner positions up in the two on-chip tables.  Workgroup-wide.
 template <class LV>
-__device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minSize, int k)
+__device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minSize, int k, unsigned long long *stamps = nullptr)
 {
+  unsigned long long st_t_ = stamps ? __builtin_readcyclecounter() : 0;
+#define AN_STAMP(idx) do { if (stamps && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(stamps + (idx), now_ - st_t_); st_t_ = now_; } } while (0)
+
   const int tid = threadIdx.x;
   extern __shared__ int32_t dyn_lds_[];
   uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
@@ -468,11 +471,16 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
   // the anchors of their words, at offsets from a prefix sum of their counts.
   const bool chained = minSize <= 29u;
   uint32_t *atab = lds;                                  // over the reference's k-mer table: nothing reads it any more
+  // exit tables: six 5-bit entries to a dword, six dwords to a word of the bitmap; a thread per dword
+  const uint32_t ne = minSize + 3u, nd = (ne + 5u) / 6u;
   if (chained) {
-    for (uint32_t w = (uint32_t)tid; w < nwords; w += kSplitThreads) {
+    for (uint32_t idx = (uint32_t)tid; idx < nwords * nd; idx += kSplitThreads) {
+      const uint32_t w = idx / nd, d = idx - w * nd;
       const unsigned long long B = ((unsigned long long)bm[2 * w + 1] << 32) | bm[2 * w];
-      unsigned long long t64[3] = {0ull, 0ull, 0ull};
-      for (uint32_t e = 0; e <= minSize + 2u; ++e) {
+      uint32_t v = 0;
+      for (uint32_t j = 0; j < 6u; ++j) {
+        const uint32_t e = 6u * d + j;
+        if (e >= ne) break;
         unsigned long long x = B & (~0ull << e);
         int t = -1;
         while (x) {
@@ -481,13 +489,13 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
           x = nx >= 64u ? 0ull : x & (~0ull << nx);
         }
         const uint32_t ex = t >= 0 ? (uint32_t)max(0, t + (int)minSize + 1 - 64) : 0u;
-        t64[e / 12u] |= (unsigned long long)ex << (5u * (e % 12u));
+        v |= ex << (5u * j);
       }
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { atab[6 * w + 2 * d] = (uint32_t)t64[d]; atab[6 * w + 2 * d + 1] = (uint32_t)(t64[d] >> 32); }
+      atab[6 * w + d] = v;
     }
     __syncthreads();
   }
+  AN_STAMP(16);
   if (tid < 64) {
     uint32_t lo[kW], hi[kW];
 #pragma unroll
@@ -504,28 +512,44 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
     // first candidate that counts has j = p - 1 > minSize
     const unsigned long long from0 = (unsigned long long)minSize + 2ull;
     if (chained) {
+      // Chaining the tables looks serial -- a word's entry state is the exit state of the word before -- but nearly
+      // every word that holds a candidate forgets how it was entered.  So every lane guesses, applies its word's
+      // table, takes its neighbour's exit state as the new entry state, and the wavefront repeats that until no
+      // lane's entry state changes any more: correct for lanes 0 .. t after t rounds whatever the guesses were,
+      // and in practice done after two or three.
       uint32_t st = (uint32_t)from0;                       // <= 31: inside word 0
       uint32_t ent[kW];
 #pragma unroll
       for (int q = 0; q < kW; ++q) {
         ent[q] = 0;
         const uint32_t wd = (uint32_t)q * 64u + (uint32_t)tid;
-        unsigned long long T[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-          T[d] = wd < nwords ? (((unsigned long long)atab[6 * wd + 2 * d + 1] << 32) | atab[6 * wd + 2 * d]) : 0ull;
         const uint32_t wq = nwords > 64u * (uint32_t)q ? min(64u, nwords - 64u * (uint32_t)q) : 0u;
-        for (uint32_t l = 0; l < wq; ++l) {
-          if ((uint32_t)tid == l) ent[q] = st;
-          const uint32_t sel = (st >= 12u ? 1u : 0u) + (st >= 24u ? 1u : 0u), sh = 5u * (st - 12u * sel);
-          const unsigned long long tv = sel == 0u ? T[0] : sel == 1u ? T[1] : T[2];
-          st = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)(tv >> sh) & 31u), (int)l);
+        if (wq == 0u) continue;
+        uint32_t T[6];
+#pragma unroll
+        for (uint32_t d = 0; d < 6u; ++d) T[d] = wd < nwords && d < nd ? atab[6 * wd + d] : 0u;
+        auto exit_of = [&](uint32_t e) {
+          const uint32_t sel = (e * 43u) >> 8;              // e / 6, e < 64
+          const uint32_t tv = sel == 0u ? T[0] : sel == 1u ? T[1] : sel == 2u ? T[2] : sel == 3u ? T[3] : sel == 4u ? T[4] : T[5];
+          return (tv >> (5u * (e - 6u * sel))) & 31u;
+        };
+        uint32_t in = tid == 0 ? st : 0u, out = exit_of(in);
+        for (;;) {
+          uint32_t prev = (uint32_t)__shfl_up((int)out, 1);
+          if (tid == 0) prev = st;
+          if (__builtin_amdgcn_ballot_w64((uint32_t)tid < wq && prev != in) == 0) break;
+          in = prev;
+          out = exit_of(in);
         }
+        ent[q] = in;
+        st = (uint32_t)__builtin_amdgcn_readlane((int)out, (int)(wq - 1u));
       }
+      AN_STAMP(17);
       // every lane: the anchors of its words, counted, placed behind the lanes (words) before it, written
       int base = n;
 #pragma unroll
       for (int q = 0; q < kW; ++q) {
+        if (nwords <= 64u * (uint32_t)q) continue;
         const unsigned long long B = ((unsigned long long)hi[q] << 32) | lo[q];
         const unsigned long long x0 = B & (~0ull << ent[q]);
         int c = 0;
@@ -587,6 +611,7 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
     if (tid == 0) { L.s->n = fail ? 0 : n; if (fail) L.s->fail = 1; }
   }
   __syncthreads();
+  AN_STAMP(18);
   // partner positions of the anchors: the k-mer's only occurrence in the uncorrected / corrected read
   const int n = L.s->n;
   const LTab t1{w1, kLdsCapOther - 1, s1, kmsk}, t2{w2, kLdsCapOther - 1, s2, kmsk};
@@ -645,7 +670,7 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
     if (g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
     __syncthreads();
     SP_STAMP(4);
-    anchors_lds(L, g.lds_tab, n_kmers(ref.n, k), minSize, k);
+    anchors_lds(L, g.lds_tab, n_kmers(ref.n, k), minSize, k, g.stamps);
     SP_STAMP(5);
   } else {
   reset_tab(tr, cr); reset_tab(t1, c1); reset_tab(t2, c2);
@@ -1088,7 +1113,7 @@ __device__ uint32_t largest_fragment(const int32_t *wl, int n, uint32_t hdr_len,
 }
 
 template <bool BIG>
-__global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 512 ? 4 : 2)) k_split(SplitArgs a)
+__global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 1024 ? 8 : kSplitThreads >= 768 ? 6 : kSplitThreads >= 512 ? 4 : 2)) k_split(SplitArgs a)
 {
   extern __shared__ int32_t s_anc[];              // !BIG: 2 levels x 5 arrays x a.maxanc entries (sized by the batch's longest read)
   __shared__ LvlState s_lvl[2];
@@ -1367,8 +1392,8 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     unsigned long long hs[24];
     (void)hipMemcpy(hs, a.stamps, sizeof hs, hipMemcpyDeviceToHost);
     const double nc = hs[7] ? (double)hs[7] : 1.0, nr = hs[9] ? (double)hs[9] : 1.0;
-    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu; per pass: ref %.0f bases, unc %.0f, look-up turns of wavefront 0 in the unc phase %.1f, anchors %.1f; window lists (cycles per read) %.0f\n",
-                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7], hs[11] / nc, hs[12] / nc, hs[13] / nc, hs[14] / nc, hs[15] / nr);
+    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu; per pass: ref %.0f bases, unc %.0f, look-up turns of wavefront 0 in the unc phase %.1f, anchors %.1f; window lists (cycles per read) %.0f; inside anchors: exit tables %.0f, chaining %.0f, writing %.0f\n",
+                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7], hs[11] / nc, hs[12] / nc, hs[13] / nc, hs[14] / nc, hs[15] / nr, hs[16] / nc, hs[17] / nc, hs[18] / nc);
   }
   (void)nthreads;
   int64_t n_host = 0;
