@@ -999,6 +999,7 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   // ---- the chain (:279-293): wavefront 0 fetches the chain's anchors 64 at a time (two dependent LDS reads per
   // anchor, all in flight together) and walks them out of registers -- the walk itself is serial (a window is cut
   // against the end of the window before it), its loads need not be; thread 0 writes the windows ----
+  SP_STAMP(19);
   if (tid < 64) {
     // Which anchors cut a window is decided one after the other (each against the end of the window before), in
     // scalar integer code on values read out of the lanes -- |size_S - size_R| < size_R * 0.5 is 2 |d| < size_R, exactly;
@@ -1013,16 +1014,29 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
       const int vr = in ? (int)L0.ar[anl] : 0, va = in ? (int)L0.aa[anl] : 0, vb = in ? (int)L0.ab[anl] : 0;
       const int cnt = min(64, nbl - 1 - base);
       const uint32_t pr0 = pr_, p10 = p1_, p20 = p2_;
+      // Which anchor cuts the next window depends only on the anchor that cut the last one.  Every lane works out,
+      // for its own anchor, which later anchor of the block would follow it (a few trials each, all lanes at once);
+      // the wavefront then only has to hop along these links from the first anchor the carried-in window end
+      // admits -- one readlane per window instead of a test per anchor.
+      auto cuts = [&](uint32_t er, uint32_t e1, uint32_t e2, int r, int a, int b) {      // window ends before, anchor
+        const int size_R = (int)((uint32_t)r - er), size_S1 = (int)((uint32_t)a - e1),
+                  size_S2 = (int)((uint32_t)b - e2);                    // ref: ints from unsigned arithmetic, compared as unsigned
+        return (uint32_t)size_R > 20u && (uint32_t)size_S1 > 20u && (uint32_t)size_S2 > 20u &&
+               2ll * llabs((long long)size_S1 - size_R) < (long long)size_R && 2ll * llabs((long long)size_S2 - size_R) < (long long)size_R;
+      };
+      int nxt = 64;                                                    // none in this block
+      for (int d = 1; __builtin_amdgcn_ballot_w64(nxt == 64 && tid + d < cnt) != 0; ++d) {
+        const int src = min(tid + d, 63);
+        const int cr = __shfl(vr, src), ca = __shfl(va, src), cb = __shfl(vb, src);
+        if (nxt == 64 && tid + d < cnt && cuts((uint32_t)(vr + k), (uint32_t)(va + k), (uint32_t)(vb + k), cr, ca, cb)) nxt = tid + d;
+      }
       unsigned long long acc = 0;
-      for (int l = 0; l < cnt; ++l) {
-        const int ar_ = __builtin_amdgcn_readlane(vr, l), aa_ = __builtin_amdgcn_readlane(va, l), ab_ = __builtin_amdgcn_readlane(vb, l);
-        const int size_R = (int)((uint32_t)ar_ - pr_), size_S1 = (int)((uint32_t)aa_ - p1_),
-                  size_S2 = (int)((uint32_t)ab_ - p2_);                 // ref: ints from unsigned arithmetic, compared as unsigned
-        if ((uint32_t)size_R > 20u && (uint32_t)size_S1 > 20u && (uint32_t)size_S2 > 20u &&
-            2ll * llabs((long long)size_S1 - size_R) < (long long)size_R && 2ll * llabs((long long)size_S2 - size_R) < (long long)size_R) {
-          acc |= 1ull << l;
-          p1_ = (uint32_t)(aa_ + k); pr_ = (uint32_t)(ar_ + k); p2_ = (uint32_t)(ab_ + k);
-        }
+      const unsigned long long first = __builtin_amdgcn_ballot_w64(tid < cnt && cuts(pr_, p1_, p2_, vr, va, vb));
+      if (first) {
+        int l = __builtin_ctzll(first), last = l;
+        while (l < 64) { acc |= 1ull << l; last = l; l = __builtin_amdgcn_readlane(nxt, l); }
+        pr_ = (uint32_t)(__builtin_amdgcn_readlane(vr, last) + k); p1_ = (uint32_t)(__builtin_amdgcn_readlane(va, last) + k);
+        p2_ = (uint32_t)(__builtin_amdgcn_readlane(vb, last) + k);
       }
       const unsigned long long below = acc & ((1ull << tid) - 1ull);
       const int prev = below ? 63 - __builtin_clzll(below) : 0;
@@ -1047,6 +1061,7 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
     if (tid == 0) { sh[4] = (int)pred_ref; sh[5] = (int)pred_S1; sh[6] = (int)pred_S2; }
   }
   __syncthreads();
+  SP_STAMP(20);
   pred_ref = (uint32_t)sh[4]; pred_S1 = (uint32_t)sh[5]; pred_S2 = (uint32_t)sh[6];
   // ---- the end (:294-306) ----
   const DSeq er = dsub(DSeq{0, ref.n}, pred_ref), e1 = dsub(DSeq{0, S1.n}, pred_S1), e2 = dsub(DSeq{0, S2.n}, pred_S2);
@@ -1392,8 +1407,8 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     unsigned long long hs[24];
     (void)hipMemcpy(hs, a.stamps, sizeof hs, hipMemcpyDeviceToHost);
     const double nc = hs[7] ? (double)hs[7] : 1.0, nr = hs[9] ? (double)hs[9] : 1.0;
-    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu; per pass: ref %.0f bases, unc %.0f, look-up turns of wavefront 0 in the unc phase %.1f, anchors %.1f; window lists (cycles per read) %.0f; inside anchors: exit tables %.0f, chaining %.0f, writing %.0f\n",
-                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7], hs[11] / nc, hs[12] / nc, hs[13] / nc, hs[14] / nc, hs[15] / nr, hs[16] / nc, hs[17] / nc, hs[18] / nc);
+    std::fprintf(stderr, "[elector] k_split: %llu reads, %.2f split() passes per read; cycles per pass: reset %.0f, table ref %.0f, table unc %.0f, table cor %.0f, candidates %.0f, anchors %.0f, chain %.0f; whole read %.0f; passes on the LDS tables %llu of %llu; per pass: ref %.0f bases, unc %.0f, look-up turns of wavefront 0 in the unc phase %.1f, anchors %.1f; window lists (cycles per read) %.0f; inside anchors: exit tables %.0f, chaining %.0f, writing %.0f; window lists: before the walk %.0f, walk %.0f\n",
+                 hs[9], nc / nr, hs[0] / nc, hs[1] / nc, hs[2] / nc, hs[3] / nc, hs[4] / nc, hs[5] / nc, hs[6] / nc, hs[8] / nr, hs[10], hs[7], hs[11] / nc, hs[12] / nc, hs[13] / nc, hs[14] / nc, hs[15] / nr, hs[16] / nc, hs[17] / nc, hs[18] / nc, hs[19] / nr, hs[20] / nr);
   }
   (void)nthreads;
   int64_t n_host = 0;
