@@ -140,19 +140,26 @@ def main(args=None):
     try:
         paths = write_fasta(work, triples, headers, max(1, a.repeat))
         del triples
-        # warm-up on the first batch: context creation, workspace growth to the batch size, first-launch costs
+        # warm-up on the first batches, one per engine context and splitter thread: context creation, workspace
+        # growth to the batch size, pinned buffers, first-launch costs
+        n_warm = max(int(os.environ.get("ELECTOR_ENGINES", "3")), int(os.environ.get("ELECTOR_SPLITTERS", "2"))) + 1
         wdir = os.path.join(work, "warm")
         os.mkdir(wdir)
         small_paths = []
         for p in paths:
             q = os.path.join(wdir, os.path.basename(p))
             with open(p, "rb") as f, open(q, "wb") as g:
-                for _ in range(2 * 10001):
+                for _ in range(2 * 10001 * n_warm):
                     g.write(f.readline())
             small_paths.append(q)
         with redirect_stdout(io.StringIO()):
             alignment.getPOA(small_paths[1], small_paths[0], small_paths[2], a.threads, wdir, 0.1)
         alignment.STAGE_SECONDS.clear()
+        # the input files have only just been written and the warm-up left records of its own: their dirty pages
+        # would count against the run's write-back budget (the last batches' records were throttled to a third of the
+        # page cache's rate) -- a user's reads are on disk before ELECTOR starts
+        shutil.rmtree(wdir, ignore_errors=True)
+        os.sync()
 
         outdir = os.path.join(work, "out")
         os.mkdir(outdir)

@@ -76,10 +76,15 @@ def _tick(stage, t0):
 MSA_CACHE = {}
 
 
-def _get_pool(matrix_path=None, n=2):
+def _get_pool(matrix_path=None, n=None):
     global _pool
     if _pool is None:
         params = read_params(matrix_path) if matrix_path else default_params()
+        if n is None:
+            # a context is busy from a batch's first kernel until its records are in the page cache (its output
+            # buffers, its pinned rows and its text buffer): with two, the writers' ~70 ms per batch paced the whole
+            # pipeline at one batch per 35 ms
+            n = int(os.environ.get("ELECTOR_ENGINES", "3"))
         _pool = EnginePool(int(os.environ.get("LOCAL_RANK", "0")), n, params)
     return _pool
 
@@ -520,7 +525,7 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     # Donatello appends (Donatello.cpp:48); a rank's part of a multi-rank run starts from scratch
     fd = os.open(part_path, os.O_WRONLY | os.O_CREAT | (os.O_TRUNC if world > 1 else 0), 0o666)
     write_at[0] = os.fstat(fd).st_size
-    n_writers = max(1, min(len(engines), int(os.environ.get("ELECTOR_WRITERS", "2"))))
+    n_writers = max(1, min(len(engines), int(os.environ.get("ELECTOR_WRITERS", str(len(engines))))))
     tws = [threading.Thread(target=writer, args=(fd,), daemon=True) for _ in range(n_writers)]
     for t_ in tws:
         t_.start()

@@ -17,6 +17,7 @@ There is no CPU fallback: without the HIP library / a gfx950 device this raises.
 """
 import ctypes as C
 import os
+import sys
 import statistics
 
 import numpy as np
@@ -210,6 +211,7 @@ def aggregate(pieces, counters, ratios, outPerReadMetrics):
 
         def lst(ptr, n):
             return np.ctypeslib.as_array(ptr, shape=(n,)).tolist() if n else []
+
         zero = bool(rep.flags & 4)
         meanRatioHomopolymers = statistics.mean(ratios) if len(ratios) > 1 else 1
         return (rep.nb_reads, rep.throughput, rep.uncor_throughput, 0 if zero else rep.precision, 0 if zero else rep.recall,
@@ -281,12 +283,17 @@ def outputReadSizeDistribution(correctedFileName, outFileName, outDir, trimmedOr
     """computeStats.py:273-286"""
     with open(outDir + "/" + outFileName, 'w') as out:
         out.write("size type\n")
-        out.write("".join([str(readSize) + " reads\n" for readSize in lenAllReads]))
+        L = _capi.lib()
+        arr = np.ascontiguousarray(np.asarray(lenAllReads, dtype=np.int64).reshape(-1))
+        out.flush()
+        L.elector_write_count_lines.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int]
+        L.elector_write_count_lines.restype = C.c_int64
+        n = L.elector_write_count_lines(arr.ctypes.data, len(arr), b" reads", out.fileno())
+        if n < 0:
+            raise ElectorError(int(n))
         if trimmedOrSplit != 0:
             # the reference reads a header line, then a sequence line whose last character it drops, until a header
             # read comes back empty: one pass over the file in the library (elector_read_size_lines)
-            out.flush()
-            L = _capi.lib()
             L.elector_read_size_lines.argtypes = [C.c_char_p, C.c_int]
             L.elector_read_size_lines.restype = C.c_int64
             n = L.elector_read_size_lines(os.fsencode(correctedFileName), out.fileno())
@@ -306,14 +313,20 @@ def outputRecallPrecision(correctedFileName, outDir, logFile, smallReadNumber, w
         outMetrics = open(outDir + "/per_read_metrics.txt", 'w')
         msa = outDir + "/msa.fa"
     outMetrics.write("score metric\n")
+    import time
+    t_report = time.perf_counter()
     (nbReads, throughput, uncorThroughput, precision, recall, corBasesRate, errorRate, uncorCorBasesRate,
      uncorErrorRate, missingSize, GCRateRef, GCRateCorr, indelsubsUncorr, indelsubsCorr, ratioHomopolymers,
      lenAllCorrectedReads, countReadSplit, countReadTrimmed, countReadExtended, extendedBasesCount) = \
         computeMetrics(msa, outMetrics, correctedFileName, reportedHomopolThreshold, clipsNb)
 
+    t_metrics = time.perf_counter()
     outputReadSizeDistribution(correctedFileName, fileSizeName, outDir, countReadSplit + countReadTrimmed,
                                lenAllCorrectedReads)
     outMetrics.close()
+    if os.environ.get("ELECTOR_DEBUG_HOST"):
+        sys.stderr.write("[elector] report: metrics %.1f ms, read size distribution %.1f ms\n"
+                         % (1e3 * (t_metrics - t_report), 1e3 * (time.perf_counter() - t_metrics)))
     meanMissingSize = 0
     if countReadSplit + countReadTrimmed > 0:
         meanMissingSize = round(sum(missingSize) / (countReadSplit + countReadTrimmed), 1)

@@ -132,6 +132,9 @@ void elector_report_free(elector_report *r);
  * "<n> sequences\n" per record of the corrected FASTA file, n = length of the record's second line less its last
  * character, written to `fd`.  Returns the number of records or a negative code. */
 int64_t elector_read_size_lines(const char *corrected_fasta, int fd);
+/* The other lines of that file (computeStats.py:276-278): "<value><suffix>\n" per value (the lengths of the
+ * corrected reads the report counted, suffix " reads"), written to `fd`.  Returns n or a negative code. */
+int64_t elector_write_count_lines(const int64_t *values, int64_t n, const char *suffix, int fd);
 
 #ifdef __cplusplus
 }
