@@ -234,7 +234,9 @@ constexpr uint32_t kLdsSeqWords = kLdsMaxN / 16 + 3;
 constexpr uint32_t kLdsBitWords = 2 * ((kLdsMaxN + 63) / 64 + 1);       // candidate bitmap: one bit per reference position, as dwords
 constexpr uint32_t kLdsAncTab = 6 * (kLdsBitWords / 2);                   // per bitmap word: the anchor walk's exit table (anchors_lds), six dwords,
 static_assert(kLdsAncTab * 4 <= kLdsCapRef * 2, "the exit tables overlay the reference's k-mer table");   // which is dead by then
-constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4 + 8;   // + the fill counter and flag
+constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4 + 8 + 40;   // + the fill counter, a spare word and the key of the packed sequences
+
+constexpr uint32_t kLdsKeyWord = (kLdsCapRef + 2 * kLdsCapOther) / 2 + 3 * kLdsSeqWords + kLdsBitWords + 2;   // dwords from the tables' start
 
 struct LTab {
   uint32_t *w;            // slots, two per word
@@ -416,11 +418,36 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   // through a plain pointer to a __shared__ variable the counter's atomicAdd became a FLAT atomic (the compiler no
   // longer knows the address space), a far slower path than ds_add, once per k-mer that enters the second table
   int *flag = reinterpret_cast<int *>(bm + kLdsBitWords);
-  pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2);
+  // best_split runs the same three sequences through here with k = 15, 13, 11, 9: their packed form only differs in
+  // the first word (which letters go through map1), so a pass that finds its sequences packed -- the key names them
+  // -- redoes that word alone and skips two thirds of this phase's trips to memory.  (A re-split packs other ranges
+  // and the key with them; k_split clears it at every read.)
+  uint32_t *key = lds + kLdsKeyWord;
+  const uint32_t want[9] = {(uint32_t)(uintptr_t)pr, (uint32_t)((uintptr_t)pr >> 32), nr, (uint32_t)(uintptr_t)p1, (uint32_t)((uintptr_t)p1 >> 32), n1,
+                            (uint32_t)(uintptr_t)p2, (uint32_t)((uintptr_t)p2 >> 32), n2};
+  bool packed = true;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) packed = packed && key[i] == want[i];
+  packed = __builtin_amdgcn_readfirstlane((int)packed) != 0;
+  if (packed) {
+    if (tid < 3) {
+      const uint8_t *s = tid == 0 ? pr : tid == 1 ? p1 : p2;
+      const uint32_t n = tid == 0 ? nr : tid == 1 ? n1 : n2;
+      uint32_t *dst = tid == 0 ? sr : tid == 1 ? s1 : s2;
+      uint32_t v = 0;
+      for (uint32_t i = 0; i < 16; ++i)
+        if (i < n) v |= (i < (uint32_t)k ? map1(s[i]) : map2(s[i])) << (2 * i);
+      dst[0] = v;
+    }
+  } else { pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2); }
   for (uint32_t i = tid; i < kLdsBitWords; i += kSplitThreads) bm[i] = 0u;
   for (uint32_t i = tid; i < (kLdsCapRef + 2 * kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
   if (tid == 0) flag[0] = 0;
   __syncthreads();
+  if (!packed && tid == 0) {                                 // (read by the next pass, barriers away)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) key[i] = want[i];
+  }
   SP_STAMP(0);
   const LTab tr{wr, kLdsCapRef - 1, sr, kmsk}, t1{w1, kLdsCapOther - 1, s1, kmsk}, t2{w2, kLdsCapOther - 1, s2, kmsk};
   const uint32_t npr = n_kmers(nr, k), np1 = n_kmers(n1, k), np2 = n_kmers(n2, k);
@@ -1174,7 +1201,10 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 1024 ? 8 : kS
     int32_t *dst = a.out_win + 8 * a.out_first[r];
     const int64_t dcap = a.out_first[r + 1] - a.out_first[r];
     __syncthreads();
-    if (tid == 0) { L0.s->fail = 0; L1.s->fail = 0; }
+    if (tid == 0) {
+      L0.s->fail = 0; L1.s->fail = 0;
+      if (g.lds_tab >= 0) s_anc[g.lds_tab + (int)kLdsKeyWord + 2] = 0;        // no sequence is packed yet (tables_lds: a length of 0 matches none)
+    }
     __syncthreads();
     if (ref.n <= 2) kind = -1;                                                   // :414
     else if ((double)S2.n / ref.n >= a.thr) {                                   // :415
