@@ -850,26 +850,24 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
       fetch(b0 - 1, nr, na, nb);                              // what enters a lane when its anchor has finished: the block below
       fetch(b0, pr, pa, pb);
       if (lane > c0) { pr = nr; pa = na; pb = nb; }
-      uint32_t offer = 0;
-      int rcl = 0, rcn = 0;
-      for (int i = n - 1; i >= 0; --i) {
+      uint32_t offer = 0, rkey = 0;
+      uint32_t back = 0xFFFFu - (uint32_t)(n - 1);                     // 0xFFFF - i
+      for (int i = n - 1; i >= 0; --i, ++back) {
         const int c = i & 63;
         if (c == 63 && i != n - 1) fetch((i >> 6) - 1, nr, na, nb);     // the lanes now hold exactly block i / 64
-        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)offer, c);
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)offer, c);   // (1 + the successor's length) << 16 | 0xFFFF - successor, 0 without one
         const int sr = __builtin_amdgcn_readlane(pr, c), sa = __builtin_amdgcn_readlane(pa, c), sb = __builtin_amdgcn_readlane(pb, c);
-        const int cl_i = (int)(key >> 16);                                // 1 + the successor's length, 0 without one
-        const int cn_i = key ? 0xFFFF - (int)(key & 0xFFFFu) : -1;
         const bool here = lane == c;
-        rcl = here ? cl_i : rcl; rcn = here ? cn_i : rcn;
+        rkey = here ? key : rkey;
         pr = here ? nr : pr; pa = here ? na : pa; pb = here ? nb : pb;    // anchor i - 64 takes the lane
         offer = here ? 0u : offer;
-        const uint32_t mine = ((uint32_t)(cl_i + 1) << 16) | (uint32_t)(0xFFFF - i);
+        const uint32_t mine = ((key & 0xFFFF0000u) + 0x10000u) | back;
         // (ref :98-110) a successor lies less than 1000 further on in all three reads, and further on at all
-        const bool ok = (uint32_t)(sr - pr - 1) < 999u && (uint32_t)(sa - pa - 1) < 999u && (uint32_t)(sb - pb - 1) < 999u;
-        offer = max(offer, ok ? mine : 0u);
+        const uint32_t far = max(max((uint32_t)(sr - pr - 1), (uint32_t)(sa - pa - 1)), (uint32_t)(sb - pb - 1));
+        offer = max(offer, far < 999u ? mine : 0u);
         if (c == 0) {                                                    // a block is complete: its results go to the arrays
           const int j = i + lane;
-          if (j < n) { L.cl[j] = (E)rcl; L.cn[j] = (E)rcn; }
+          if (j < n) { L.cl[j] = (E)(rkey >> 16); L.cn[j] = (E)(rkey ? 0xFFFF - (int)(rkey & 0xFFFFu) : -1); }
         }
       }
     } else
