@@ -226,17 +226,19 @@ __device__ void reset_tab(const Tab &t, int64_t cap)
 // occurrence, 0xFFFF empty -- the k-mer itself is read back from a 2-bit packed copy of the sequence (16 letters
 // per dword, letter q coded as the reference codes it: first k letters by str2num, the rest by the rolling update).
 // The reference's table gets 16,384 slots (most look-ups of uncorrected k-mers miss: short probe sequences matter),
-// the other two 4,096 each -- they only hold k-mers shared with the reference, a few hundred for a noisy read --
-// which with the 16-bit anchor arrays is about 72 KB: two workgroups per CU.  When they fill beyond kLdsFill (an uncorrected read that is nearly error-free) the call falls back to the HBM tables.
+// the other two 8,192 each -- they only hold k-mers shared with the reference -- and the third lives where the first
+// was (nothing looks the reference's k-mers up once the second table is built), which with the 16-bit anchor arrays
+// is about 72 KB: two workgroups per CU.  When they fill beyond kLdsFill (an uncorrected read that is nearly
+// error-free) the call falls back to the HBM tables.
 constexpr uint32_t kLdsMaxN = 12500;
-constexpr uint32_t kLdsCapRef = 16384, kLdsCapOther = 4096, kLdsFill = 3200;
+constexpr uint32_t kLdsCapRef = 16384, kLdsCapOther = 8192, kLdsFill = 6400;
 constexpr uint32_t kLdsSeqWords = kLdsMaxN / 16 + 3;
 constexpr uint32_t kLdsBitWords = 2 * ((kLdsMaxN + 63) / 64 + 1);       // candidate bitmap: one bit per reference position, as dwords
 constexpr uint32_t kLdsAncTab = 6 * (kLdsBitWords / 2);                   // per bitmap word: the anchor walk's exit table (anchors_lds), six dwords,
-static_assert(kLdsAncTab * 4 <= kLdsCapRef * 2, "the exit tables overlay the reference's k-mer table");   // which is dead by then
-constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + 2 * kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4 + 8 + 40;   // + the fill counter, a spare word and the key of the packed sequences
+static_assert(kLdsCapOther * 2 + kLdsAncTab * 4 <= kLdsCapRef * 2, "the third table and the exit tables overlay the reference's k-mer table");   // which is dead by then
+constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4 + 8 + 40;   // + the fill counter, a spare word and the key of the packed sequences
 
-constexpr uint32_t kLdsKeyWord = (kLdsCapRef + 2 * kLdsCapOther) / 2 + 3 * kLdsSeqWords + kLdsBitWords + 2;   // dwords from the tables' start
+constexpr uint32_t kLdsKeyWord = (kLdsCapRef + kLdsCapOther) / 2 + 3 * kLdsSeqWords + kLdsBitWords + 2;   // dwords from the tables' start
 
 struct LTab {
   uint32_t *w;            // slots, two per word
@@ -395,8 +397,8 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   const int tid = threadIdx.x;
   extern __shared__ int32_t dyn_lds_[];
   uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
-  uint32_t *wr = lds, *w1 = wr + kLdsCapRef / 2, *w2 = w1 + kLdsCapOther / 2;
-  uint32_t *sr = w2 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
+  uint32_t *wr = lds, *w1 = wr + kLdsCapRef / 2, *w2 = wr;     // the third table takes the place of the first, which is dead by then
+  uint32_t *sr = w1 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
   const uint32_t kmsk = (1u << (2 * k)) - 1u;
   auto pack = [&](const uint8_t *s, uint32_t n, uint32_t *dst) {
     const uint32_t nw = (n + 15) / 16 + 2;
@@ -441,7 +443,7 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
     }
   } else { pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2); }
   for (uint32_t i = tid; i < kLdsBitWords; i += kSplitThreads) bm[i] = 0u;
-  for (uint32_t i = tid; i < (kLdsCapRef + 2 * kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+  for (uint32_t i = tid; i < (kLdsCapRef + kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
   if (tid == 0) flag[0] = 0;
   __syncthreads();
   if (!packed && tid == 0) {                                 // (read by the next pass, barriers away)
@@ -459,6 +461,8 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   __syncthreads();
   SP_STAMP(2);
   if (flag[0] > (int)kLdsFill) return false;
+  for (uint32_t i = tid; i < kLdsCapOther / 2; i += kSplitThreads) w2[i] = 0xFFFFFFFFu;     // nobody looks the reference's k-mers up any more
+  __syncthreads();
   flat_add(t2, flat_find(t1, s2, all_2, kmsk));                // no more distinct k-mers than the table before holds
   __syncthreads();
   SP_STAMP(3);
@@ -484,8 +488,8 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
   const int tid = threadIdx.x;
   extern __shared__ int32_t dyn_lds_[];
   uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
-  uint32_t *w1 = lds + kLdsCapRef / 2, *w2 = w1 + kLdsCapOther / 2;
-  uint32_t *sr = w2 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
+  uint32_t *w1 = lds + kLdsCapRef / 2, *w2 = lds;
+  uint32_t *sr = w1 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
   const uint32_t *bm = s2 + kLdsSeqWords;
   const uint32_t kmsk = (1u << (2 * k)) - 1u;
   constexpr int kW = (int)(kLdsBitWords / 2 + 63) / 64;              // 64-bit bitmap words per lane of wavefront 0
@@ -497,7 +501,7 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
   // chains the tables -- a dozen scalar instructions per WORD instead of some forty per ANCHOR -- and its lanes write
   // the anchors of their words, at offsets from a prefix sum of their counts.
   const bool chained = minSize <= 29u;
-  uint32_t *atab = lds;                                  // over the reference's k-mer table: nothing reads it any more
+  uint32_t *atab = lds + kLdsCapOther / 2;               // over the reference's k-mer table, behind the third table: nothing reads it any more
   // exit tables: six 5-bit entries to a dword, six dwords to a word of the bitmap; a thread per dword
   const uint32_t ne = minSize + 3u, nd = (ne + 5u) / 6u;
   if (chained) {
