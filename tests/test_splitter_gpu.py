@@ -79,3 +79,26 @@ def test_on_chip_table_limits(engine):
         r = synth.random_seq(rng, int(rng.integers(3000, 11000)))
         reads.append((r, synth.mutate(rng, r, 0.01), synth.mutate(rng, r, 0.15)))
     same(engine, reads)
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+def test_soak(engine, seed):
+    """More reads per profile than test_profiles, other seeds: the serial stretches of k_split (anchor walk by
+    fixed-point rounds, chain lengths by offers, window cuts by links) see re-splits of many start / end lengths
+    (minSize below and above the limits of their fast forms) and chains of every length."""
+    for profile, n in (("yeast50x_nanosim_consent_split", 1200), ("celegans30x_simlord_mixed", 1200), ("ecoli10x_c1", 459)):
+        triples, headers, _ = synthetic.read_pieces(profile, n, seed)
+        same(engine, triples, headers)
+    # corrected reads that cover only a stretch of the reference, at both ends and in the middle: re-splits with
+    # minSize = 1.2 x (what is left of the corrected read), from 0 upwards
+    rng = np.random.default_rng(seed)
+    reads = []
+    for _ in range(60):
+        r = synth.random_seq(rng, int(rng.integers(1500, 9000)))
+        u = synth.mutate(rng, r, 0.12)
+        c = synth.mutate(rng, r, 0.01)
+        a, b = sorted(int(x) for x in rng.integers(0, len(c), 2))
+        cut = int(rng.integers(0, 40))
+        reads.append((r, c[a:b] if b - a > 50 else c[cut:], u))
+        reads.append((r, c[:max(60, len(c) - a)], u))
+    same(engine, reads)
