@@ -951,108 +951,50 @@ __device__ __forceinline__ DSeq dsub(DSeq s, uint32_t pos, uint32_t len)     // 
 }
 __device__ __forceinline__ DSeq dsub(DSeq s, uint32_t pos) { return dsub(s, pos, 0xFFFFFFFFu); }
 
-struct WList { int32_t *w; int n; int64_t cap; bool over; };
-
-__device__ __forceinline__ void wpush(WList &o, uint32_t ro, uint32_t rl, uint32_t ao, uint32_t al, uint32_t bo, uint32_t bl, int nfill)
-{
-  if (o.n >= o.cap) { o.over = true; return; }
-  // (through a pointer known to be global memory: FLAT stores would also count as LDS operations, and the next read
-  // of the anchor arrays would wait for their trip to memory)
-  int32_t *w = o.w + 8 * (int64_t)o.n;
-  stg_global(w, (int)ro); stg_global(w + 1, (int)rl); stg_global(w + 2, (int)ao); stg_global(w + 3, (int)al);
-  stg_global(w + 4, (int)bo); stg_global(w + 5, (int)bl); stg_global(w + 6, nfill); stg_global(w + 7, 0);
-  ++o.n;
-}
-
 // one split() of the reference (:175-308) including the two re-splits of a missing start / end.  Workgroup-wide;
-// the window list `out` (in HBM) is built by thread 0; returns its length through *out_n (LDS).
+// the window list `out` (in HBM) is built by wavefront 0; returns its length through sh[0] (LDS).
 template <class LV>
 __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DSeq S1, DSeq S2, int k, int32_t *out, int32_t *tmp,
                            int *sh /* LDS ints: [0] n out, [1] overflow, [2..] scratch */)
 {
+  (void)tmp;
   const int tid = threadIdx.x;
   split_core(g, L0, ref, S1, S2, k, 20u);
   unsigned long long sp_t_ = g.stamps ? __builtin_readcyclecounter() : 0;
-  WList o{out, 0, g.maxwin, false};
-  uint32_t pred_ref = 0, pred_S1 = 0, pred_S2 = 0;
-  int i = 0;
-  const int nbl = L0.s->nchain;
-  if (tid == 0) { sh[0] = 0; sh[1] = 0; }
-  __syncthreads();
-  if (nbl == 0) {
-    if (tid == 0) { wpush(o, 0, ref.n, 0, S1.n, 0, S2.n, 0); sh[0] = o.n; sh[1] = o.over || L0.s->fail; }
-    __syncthreads();
-    return;
-  }
-  // ---- missing start (:264-277) ----
-  const int a0 = L0.cl[0];
-  const uint32_t sr = min(ref.n, (uint32_t)(L0.ar[a0] + k)), s1 = min(S1.n, (uint32_t)(L0.aa[a0] + k)), s2 = min(S2.n, (uint32_t)(L0.ab[a0] + k));
-  const bool rec_start = (uint64_t)s2 * 2 < sr && sr - s2 > 200;
-  if (rec_start) {
-    SP_STAMP(15);
-    split_core(g, L1, DSeq{ref.base, sr}, DSeq{S1.base, s1}, DSeq{ref.base, sr}, k, (uint32_t)(1.2 * s2));
-    if (g.stamps) sp_t_ = __builtin_readcyclecounter();
-    if (tid == 0) {
-      // the windows of the re-split (reference against uncorrected), by the plain rule; the corrected side
-      // is the 'N' filler except in the last one, which takes what there is of the corrected start
-      WList t{tmp, 0, g.maxwin, false};
-      const DSeq rr{0, sr}, r1{0, s1};
-      const int nb1 = L1.s->nchain;
-      if (nb1 == 0) wpush(t, 0, sr, 0, s1, 0, sr, 0);
-      else {
-        uint32_t pr_ = 0, p1_ = 0, p2_ = 0;
-        const uint32_t ms = (uint32_t)(1.2 * s2);
-        for (int q = 0; q < nb1 - 1; ++q) {
-          const int an = L1.cl[q];
-          const int size_R = (int)((uint32_t)L1.ar[an] - pr_), size_S1 = (int)((uint32_t)L1.aa[an] - p1_), size_S2 = (int)((uint32_t)L1.ab[an] - p2_);
-          if ((uint32_t)size_R > ms && (uint32_t)size_S1 > ms && (uint32_t)size_S2 > ms &&
-              abs(size_S1 - size_R) < size_R * 0.5 && abs(size_S2 - size_R) < size_R * 0.5) {
-            const DSeq wr = dsub(rr, pr_, (uint32_t)(L1.ar[an] - (int)pr_ + k)), w1 = dsub(r1, p1_, (uint32_t)(L1.aa[an] - (int)p1_ + k));
-            wpush(t, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, 0, 0, 0);
-            p1_ = (uint32_t)(L1.aa[an] + k); pr_ = (uint32_t)(L1.ar[an] + k); p2_ = (uint32_t)(L1.ab[an] + k);
-          }
-        }
-        const DSeq er = dsub(rr, pr_), e1 = dsub(r1, p1_);
-        wpush(t, (uint32_t)er.base, er.n, (uint32_t)e1.base, e1.n, 0, 0, 0);
-      }
-      for (int f = 0; f < t.n; ++f) {
-        const int32_t *w = tmp + 8 * (int64_t)f;
-        if (f + 1 < t.n || s2 == 0) wpush(o, (uint32_t)ldg(w), (uint32_t)ldg(w + 1), (uint32_t)ldg(w + 2), (uint32_t)ldg(w + 3), 0, 1, 1);
-        else wpush(o, (uint32_t)ldg(w), (uint32_t)ldg(w + 1), (uint32_t)ldg(w + 2), (uint32_t)ldg(w + 3), 0, s2, 0);
-      }
-      if (t.over || L1.s->fail) o.over = true;
-    }
-    pred_S1 = (uint32_t)(L0.aa[a0] + k); pred_ref = (uint32_t)(L0.ar[a0] + k); pred_S2 = (uint32_t)(L0.ab[a0] + k);
-    i = 1;
-  }
-  // ---- the chain (:279-293): wavefront 0 fetches the chain's anchors 64 at a time (two dependent LDS reads per
-  // anchor, all in flight together) and walks them out of registers -- the walk itself is serial (a window is cut
-  // against the end of the window before it), its loads need not be; thread 0 writes the windows ----
-  SP_STAMP(19);
-  if (tid < 64) {
-    // Which anchors cut a window is decided one after the other (each against the end of the window before), in
-    // scalar integer code on values read out of the lanes -- |size_S - size_R| < size_R * 0.5 is 2 |d| < size_R, exactly;
-    // the windows themselves are then written by all accepted lanes at once: a lane finds the window before its own
-    // through the mask of accepted anchors.
-    uint32_t pr_ = uniform(pred_ref), p1_ = uniform(pred_S1), p2_ = uniform(pred_S2);
-    int on = uniform(o.n);
-    for (int base = i; base < nbl - 1; base += 64) {
+  const int64_t cap = g.maxwin;
+  // the list's length and overflow flag: the same in all lanes of wavefront 0, which is the only one that uses them
+  int on = 0;
+  bool over = false;
+  auto wstore = [&](int slot, uint32_t ro, uint32_t rl, uint32_t ao, uint32_t al, uint32_t bo, uint32_t bl, int nfill) {
+    if (slot >= cap) return;                      // (counted all the same: the caller sees on > cap)
+    // (through a pointer known to be global memory: FLAT stores would also count as LDS operations, and the next read
+    // of the anchor arrays would wait for their trip to memory)
+    int32_t *w = out + 8 * (int64_t)slot;
+    stg_global(w, (int)ro); stg_global(w + 1, (int)rl); stg_global(w + 2, (int)ao); stg_global(w + 3, (int)al);
+    stg_global(w + 4, (int)bo); stg_global(w + 5, (int)bl); stg_global(w + 6, nfill); stg_global(w + 7, 0);
+  };
+  // ---- the walk along a chain (:279-293, and the same rule inside the re-splits): anchors i0 .. n_end - 1 of L's chain
+  // list, a window cut at every anchor that lies more than thr behind the end of the window before in all three
+  // sequences with sizes within a factor 1.5.  Wavefront 0.  Which anchor cuts the next window depends only on the
+  // anchor that cut the last one: every lane works out, for its own anchor, which later anchor of the block would
+  // follow it (a few trials each, all lanes at once), the wavefront then hops along these links from the first
+  // anchor the carried-in window end admits -- one readlane per window instead of a test per anchor -- and the
+  // accepted lanes write their windows together: emit(slot, ends of the window before, the lane's anchor).
+  // |size_S - size_R| < size_R * 0.5 is 2 |d| < size_R, exactly.
+  auto walk = [&](const LV &L, int i0, int n_end, uint32_t thr, uint32_t &pr_, uint32_t &p1_, uint32_t &p2_, auto &&emit) {
+    auto cuts = [&](uint32_t er, uint32_t e1, uint32_t e2, int r, int a, int b) {      // window ends before, anchor
+      const int size_R = (int)((uint32_t)r - er), size_S1 = (int)((uint32_t)a - e1),
+                size_S2 = (int)((uint32_t)b - e2);                    // ref: ints from unsigned arithmetic, compared as unsigned
+      return (uint32_t)size_R > thr && (uint32_t)size_S1 > thr && (uint32_t)size_S2 > thr &&
+             2ll * llabs((long long)size_S1 - size_R) < (long long)size_R && 2ll * llabs((long long)size_S2 - size_R) < (long long)size_R;
+    };
+    for (int base = i0; base < n_end; base += 64) {
       const int idx = base + tid;
-      const bool in = idx < nbl - 1;
-      const int anl = in ? (int)L0.cl[idx] : 0;
-      const int vr = in ? (int)L0.ar[anl] : 0, va = in ? (int)L0.aa[anl] : 0, vb = in ? (int)L0.ab[anl] : 0;
-      const int cnt = min(64, nbl - 1 - base);
+      const bool in = idx < n_end;
+      const int anl = in ? (int)L.cl[idx] : 0;
+      const int vr = in ? (int)L.ar[anl] : 0, va = in ? (int)L.aa[anl] : 0, vb = in ? (int)L.ab[anl] : 0;
+      const int cnt = min(64, n_end - base);
       const uint32_t pr0 = pr_, p10 = p1_, p20 = p2_;
-      // Which anchor cuts the next window depends only on the anchor that cut the last one.  Every lane works out,
-      // for its own anchor, which later anchor of the block would follow it (a few trials each, all lanes at once);
-      // the wavefront then only has to hop along these links from the first anchor the carried-in window end
-      // admits -- one readlane per window instead of a test per anchor.
-      auto cuts = [&](uint32_t er, uint32_t e1, uint32_t e2, int r, int a, int b) {      // window ends before, anchor
-        const int size_R = (int)((uint32_t)r - er), size_S1 = (int)((uint32_t)a - e1),
-                  size_S2 = (int)((uint32_t)b - e2);                    // ref: ints from unsigned arithmetic, compared as unsigned
-        return (uint32_t)size_R > 20u && (uint32_t)size_S1 > 20u && (uint32_t)size_S2 > 20u &&
-               2ll * llabs((long long)size_S1 - size_R) < (long long)size_R && 2ll * llabs((long long)size_S2 - size_R) < (long long)size_R;
-      };
       int nxt = 64;                                                    // none in this block
       for (int d = 1; __builtin_amdgcn_ballot_w64(nxt == 64 && tid + d < cnt) != 0; ++d) {
         const int src = min(tid + d, 63);
@@ -1072,20 +1014,61 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
       const int qr = __shfl(vr, prev), qa = __shfl(va, prev), qb = __shfl(vb, prev);
       if ((acc >> tid) & 1ull) {
         const uint32_t mr = below ? (uint32_t)(qr + k) : pr0, m1 = below ? (uint32_t)(qa + k) : p10, m2 = below ? (uint32_t)(qb + k) : p20;
-        const int slot = on + __builtin_popcountll(below);
-        if (slot < o.cap) {
-          const DSeq wr = dsub(DSeq{0, ref.n}, mr, (uint32_t)(vr - (int)mr + k)),
-                     w1 = dsub(DSeq{0, S1.n}, m1, (uint32_t)(va - (int)m1 + k)),
-                     w2 = dsub(DSeq{0, S2.n}, m2, (uint32_t)(vb - (int)m2 + k));
-          int32_t *w = o.w + 8 * (int64_t)slot;
-          stg_global(w, (int)wr.base); stg_global(w + 1, (int)wr.n); stg_global(w + 2, (int)w1.base); stg_global(w + 3, (int)w1.n);
-          stg_global(w + 4, (int)w2.base); stg_global(w + 5, (int)w2.n); stg_global(w + 6, 0); stg_global(w + 7, 0);
-        }
+        emit(on + __builtin_popcountll(below), mr, m1, m2, vr, va, vb);
       }
       on += __builtin_popcountll(acc);
     }
-    if (on > o.cap) { o.over = true; on = (int)o.cap; }
-    o.n = on;
+  };
+  // a re-split's windows (:264-277, :294-306): reference against uncorrected by the plain rule with minSize ms; the
+  // corrected side is the 'N' filler except in ONE window (`special`: the re-split's last window at the start of a
+  // read, its first at the end), which takes what there is of the corrected read (co, cl_) -- when there is any
+  auto resplit_windows = [&](uint32_t rn, uint32_t un, uint32_t roff, uint32_t uoff, uint32_t ms, bool special_last, uint32_t co, uint32_t cl_) {
+    const DSeq rr{0, rn}, r1{0, un};
+    const int nb1 = uniform(L1.s->nchain);
+    const int on0 = on;
+    uint32_t a_ = 0, b_ = 0, c_ = 0;
+    auto put = [&](int slot, bool special, DSeq wr, DSeq w1) {
+      if (special && cl_ > 0) wstore(slot, (uint32_t)wr.base + roff, wr.n, (uint32_t)w1.base + uoff, w1.n, co, cl_, 0);
+      else wstore(slot, (uint32_t)wr.base + roff, wr.n, (uint32_t)w1.base + uoff, w1.n, 0, 1, 1);
+    };
+    walk(L1, 0, nb1 - 1, ms, a_, b_, c_, [&](int slot, uint32_t mr, uint32_t m1, uint32_t, int vr, int va, int) {
+      put(slot, !special_last && slot == on0, dsub(rr, mr, (uint32_t)(vr - (int)mr + k)), dsub(r1, m1, (uint32_t)(va - (int)m1 + k)));
+    });
+    if (tid == 0) put(on, special_last || on == on0, dsub(rr, a_), dsub(r1, b_));       // what is left behind the last cut
+    ++on;
+    if (uniform(L1.s->fail)) over = true;
+  };
+  uint32_t pred_ref = 0, pred_S1 = 0, pred_S2 = 0;
+  int i = 0;
+  const int nbl = L0.s->nchain;
+  if (tid == 0) { sh[0] = 0; sh[1] = 0; }
+  __syncthreads();
+  if (nbl == 0) {
+    if (tid == 0) { wstore(0, 0, ref.n, 0, S1.n, 0, S2.n, 0); sh[0] = cap >= 1 ? 1 : 0; sh[1] = cap < 1 || L0.s->fail; }
+    __syncthreads();
+    return;
+  }
+  // ---- missing start (:264-277) ----
+  const int a0 = L0.cl[0];
+  const uint32_t sr = min(ref.n, (uint32_t)(L0.ar[a0] + k)), s1 = min(S1.n, (uint32_t)(L0.aa[a0] + k)), s2 = min(S2.n, (uint32_t)(L0.ab[a0] + k));
+  const bool rec_start = (uint64_t)s2 * 2 < sr && sr - s2 > 200;
+  if (rec_start) {
+    SP_STAMP(15);
+    split_core(g, L1, DSeq{ref.base, sr}, DSeq{S1.base, s1}, DSeq{ref.base, sr}, k, (uint32_t)(1.2 * s2));
+    if (g.stamps) sp_t_ = __builtin_readcyclecounter();
+    if (tid < 64) resplit_windows(sr, s1, 0u, 0u, (uint32_t)(1.2 * s2), true, 0u, s2);
+    pred_S1 = (uint32_t)(L0.aa[a0] + k); pred_ref = (uint32_t)(L0.ar[a0] + k); pred_S2 = (uint32_t)(L0.ab[a0] + k);
+    i = 1;
+  }
+  SP_STAMP(19);
+  if (tid < 64) {
+    uint32_t pr_ = uniform(pred_ref), p1_ = uniform(pred_S1), p2_ = uniform(pred_S2);
+    walk(L0, i, nbl - 1, 20u, pr_, p1_, p2_, [&](int slot, uint32_t mr, uint32_t m1, uint32_t m2, int vr, int va, int vb) {
+      const DSeq wr = dsub(DSeq{0, ref.n}, mr, (uint32_t)(vr - (int)mr + k)),
+                 w1 = dsub(DSeq{0, S1.n}, m1, (uint32_t)(va - (int)m1 + k)),
+                 w2 = dsub(DSeq{0, S2.n}, m2, (uint32_t)(vb - (int)m2 + k));
+      wstore(slot, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, (uint32_t)w2.base, w2.n, 0);
+    });
     pred_ref = pr_; pred_S1 = p1_; pred_S2 = p2_;
     if (tid == 0) { sh[4] = (int)pred_ref; sh[5] = (int)pred_S1; sh[6] = (int)pred_S2; }
   }
@@ -1095,45 +1078,21 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   // ---- the end (:294-306) ----
   const DSeq er = dsub(DSeq{0, ref.n}, pred_ref), e1 = dsub(DSeq{0, S1.n}, pred_S1), e2 = dsub(DSeq{0, S2.n}, pred_S2);
   const bool rec_end = (uint64_t)e2.n * 2 < er.n && er.n - e2.n > 200;
-  __syncthreads();              // L1 and tmp are about to be reused
+  __syncthreads();              // L1 is about to be reused
   if (rec_end) {
     const DSeq gr{ref.base + er.base, er.n}, g1{S1.base + e1.base, e1.n};
     SP_STAMP(15);
     split_core(g, L1, gr, g1, gr, k, (uint32_t)(1.2 * e2.n));
     if (g.stamps) sp_t_ = __builtin_readcyclecounter();
-    if (tid == 0) {
-      WList t{tmp, 0, g.maxwin, false};
-      const DSeq rr{0, er.n}, r1{0, e1.n};
-      const int nb1 = L1.s->nchain;
-      if (nb1 == 0) wpush(t, 0, er.n, 0, e1.n, 0, er.n, 0);
-      else {
-        uint32_t pr_ = 0, p1_ = 0, p2_ = 0;
-        const uint32_t ms = (uint32_t)(1.2 * e2.n);
-        for (int q = 0; q < nb1 - 1; ++q) {
-          const int an = L1.cl[q];
-          const int size_R = (int)((uint32_t)L1.ar[an] - pr_), size_S1 = (int)((uint32_t)L1.aa[an] - p1_), size_S2 = (int)((uint32_t)L1.ab[an] - p2_);
-          if ((uint32_t)size_R > ms && (uint32_t)size_S1 > ms && (uint32_t)size_S2 > ms &&
-              abs(size_S1 - size_R) < size_R * 0.5 && abs(size_S2 - size_R) < size_R * 0.5) {
-            const DSeq wr = dsub(rr, pr_, (uint32_t)(L1.ar[an] - (int)pr_ + k)), w1 = dsub(r1, p1_, (uint32_t)(L1.aa[an] - (int)p1_ + k));
-            wpush(t, (uint32_t)wr.base, wr.n, (uint32_t)w1.base, w1.n, 0, 0, 0);
-            p1_ = (uint32_t)(L1.aa[an] + k); pr_ = (uint32_t)(L1.ar[an] + k); p2_ = (uint32_t)(L1.ab[an] + k);
-          }
-        }
-        const DSeq xr = dsub(rr, pr_), x1 = dsub(r1, p1_);
-        wpush(t, (uint32_t)xr.base, xr.n, (uint32_t)x1.base, x1.n, 0, 0, 0);
-      }
-      for (int f = 0; f < t.n; ++f) {
-        const int32_t *w = tmp + 8 * (int64_t)f;
-        const uint32_t ro = (uint32_t)ldg(w) + (uint32_t)er.base, ao = (uint32_t)ldg(w + 2) + (uint32_t)e1.base;
-        if (f == 0 && e2.n > 0) wpush(o, ro, (uint32_t)ldg(w + 1), ao, (uint32_t)ldg(w + 3), (uint32_t)e2.base, e2.n, 0);
-        else wpush(o, ro, (uint32_t)ldg(w + 1), ao, (uint32_t)ldg(w + 3), 0, 1, 1);
-      }
-      if (t.over || L1.s->fail) o.over = true;
-    }
-  } else if (tid == 0) {
-    wpush(o, (uint32_t)er.base, er.n, (uint32_t)e1.base, e1.n, (uint32_t)e2.base, e2.n, 0);
+    if (tid < 64) resplit_windows(er.n, e1.n, (uint32_t)er.base, (uint32_t)e1.base, (uint32_t)(1.2 * e2.n), false, (uint32_t)e2.base, e2.n);
+  } else if (tid < 64) {
+    if (tid == 0) wstore(on, (uint32_t)er.base, er.n, (uint32_t)e1.base, e1.n, (uint32_t)e2.base, e2.n, 0);
+    ++on;
   }
-  if (tid == 0) { sh[0] = o.n; sh[1] = (o.over || L0.s->fail) ? 1 : 0; }
+  if (tid == 0) {
+    if (on > cap) { over = true; on = (int)cap; }
+    sh[0] = on; sh[1] = (over || L0.s->fail) ? 1 : 0;
+  }
   __syncthreads();
   SP_STAMP(15);
 }
