@@ -889,8 +889,11 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
             max(W.Lr, W.xi_cap) + G + 2 <= a.mv_tw && score_span(kp, max(W.Lr, W.xi_cap) + G, RS) < 16000;
 }
 
+#ifndef ELECTOR_POA_WAVES
+#define ELECTOR_POA_WAVES (R <= 6 ? 4 : 3)
+#endif
 template <int G, int R>
-__global__ void __launch_bounds__(64, (R <= 6 ? 4 : 3)) k_poa(PackArgs a)
+__global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NP = 64 / G;                       // pairs of windows per wave
