@@ -72,6 +72,7 @@ struct SplitArgs {
   int32_t *anc; int64_t maxanc;
   unsigned long long *stamps;
   int lds_tables;                // the dynamic LDS holds the on-chip tables behind the anchor arrays
+  int lds_long;                  // the dynamic LDS holds the long reads' on-chip tables (tables_long)
 };
 
 // window record (8 ints): ref off, ref len, S1 off, S1 len, S2 off, S2 len, S2 is the 'N' filler, unused;
@@ -189,6 +190,7 @@ struct WG {
   int64_t tab_cap, maxwin;
   unsigned long long *stamps;     // debug (ELECTOR_DEBUG_SPLIT): cycles per phase, summed over reads
   int lds_tab;                    // LDS tables (tables_lds): dword offset in the dynamic LDS, or -1
+  int lds_long;                   // LDS tables for reads of up to 65,535 bases (tables_long): dword offset, or -1
 };
 
 #define SP_STAMP(idx)                                                                      \
@@ -387,6 +389,208 @@ __device__ __forceinline__ void flat_add(const LTab &t, uint32_t todo, int *fill
     }
     if (fill && (++nturn & 7u) == 0u && __builtin_amdgcn_readfirstlane(*(volatile int *)fill) > limit) break;
   }
+}
+
+// ---- on-chip tables for reads of up to 65,535 bases ----
+// The HBM tables cost a read of 50 kb some ten million cycles per split() pass: a million outstanding compare-and-swaps on
+// random 64-byte lines.  Which k-mers are shared and unique can be decided one PARTITION of the k-mer space at a time
+// -- a k-mer belongs to one partition (a hash of its code), and the three tables of a partition never meet another
+// partition's k-mers -- so the whole pipeline (reference table, uncorrected look-ups -> second table, corrected
+// look-ups -> third table, candidates) runs P times over tables that fit in LDS, P chosen so that a partition holds
+// at most ~6,000 k-mers of a read.  32-bit slots ([31] seen twice, [30:0] position, all ones empty), the k-mer read
+// back from the 2-bit packed sequences, which also live in LDS (3 x 16 KB); the candidates go to the dense arrays
+// ca / cb in HBM that the HBM tables write, and everything behind (anchor walk, chain) is shared with that path.
+// One workgroup per CU (148 KB of LDS).
+constexpr uint32_t kLongMaxN = 65535;
+constexpr uint32_t kLongCapRef = 16384, kLongCapOther = 8192, kLongFill = 7200, kLongPart = 6000;
+constexpr uint32_t kLongSeqWords = kLongMaxN / 16 + 3;
+constexpr uint32_t kLongDwords = kLongCapRef + kLongCapOther + 3 * kLongSeqWords + 2;
+constexpr size_t kLongBytes = (size_t)kLongDwords * 4;
+static_assert(kLongMaxN <= 128u * (uint32_t)kSplitThreads, "a lane's positions as one 128-bit mask");
+
+struct Mask128 {
+  uint32_t m[4];
+  __device__ __forceinline__ bool any() const { return (m[0] | m[1] | m[2] | m[3]) != 0u; }
+  __device__ __forceinline__ uint32_t first() const                    // index of the lowest bit (any())
+  {
+    return m[0] ? (uint32_t)__builtin_ctz(m[0]) : m[1] ? 32u + (uint32_t)__builtin_ctz(m[1]) : m[2] ? 64u + (uint32_t)__builtin_ctz(m[2]) : 96u + (uint32_t)__builtin_ctz(m[3]);
+  }
+  __device__ __forceinline__ void drop_first()
+  {
+    if (m[0]) m[0] &= m[0] - 1u; else if (m[1]) m[1] &= m[1] - 1u; else if (m[2]) m[2] &= m[2] - 1u; else m[3] &= m[3] - 1u;
+  }
+  __device__ __forceinline__ void set(uint32_t q)
+  {
+    const uint32_t b = 1u << (q & 31u);
+    if (q < 32u) m[0] |= b; else if (q < 64u) m[1] |= b; else if (q < 96u) m[2] |= b; else m[3] |= b;
+  }
+};
+
+struct LTab32 {
+  uint32_t *w;            // one slot per word
+  uint32_t mask;
+  const uint32_t *seq;    // packed sequence the positions refer to
+  uint32_t kmsk;
+  __device__ __forceinline__ int find(uint32_t code) const              // position of the k-mer when it occurs exactly once, else -1
+  {
+    uint32_t h = LTab::slot_of(code, mask);
+    const uint32_t step = LTab::step_of(code);
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+      const uint32_t e = w[h];
+      if (e == 0xFFFFFFFFu) return -1;
+      if (LTab::bits(seq, e & 0x7FFFFFFFu, kmsk) == code) return (e & 0x80000000u) ? -1 : (int)e;
+      h = (h + step) & mask;
+    }
+    return -1;
+  }
+};
+
+// which partition of the k-mer space a code belongs to (lg: log2 of the number of partitions); a multiplier of its
+// own, so that the slots of a partition's k-mers are spread over the whole table
+__device__ __forceinline__ uint32_t part_of(uint32_t code, uint32_t lg) { return lg ? (code * 0x85EBCA6Bu) >> (32u - lg) : 0u; }
+
+// the lane's positions (tid + q * kSplitThreads) of seq whose k-mer lies in partition part
+__device__ __forceinline__ Mask128 lane_positions_of(const uint32_t *seq, uint32_t np, uint32_t kmsk, uint32_t part, uint32_t lg)
+{
+  Mask128 r{{0u, 0u, 0u, 0u}};
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (uint32_t wd = 0; wd < 4u; ++wd) {
+    uint32_t bitsw = 0;
+    for (uint32_t b = 0; b < 32u; ++b) {
+      const uint32_t p = tid + (32u * wd + b) * (uint32_t)kSplitThreads;
+      if (p >= np) break;
+      if (part_of(LTab::bits(seq, p, kmsk), lg) == part) bitsw |= 1u << b;
+    }
+    r.m[wd] = bitsw;
+  }
+  return r;
+}
+
+// flat loops (see flat_find / flat_add) on a 32-bit table and a 128-bit position mask
+__device__ __forceinline__ Mask128 flat_find32(const LTab32 &t, const uint32_t *seq, Mask128 todo, uint32_t kmsk)
+{
+  const uint32_t tid = threadIdx.x;
+  Mask128 hits{{0u, 0u, 0u, 0u}};
+  bool active = todo.any();
+  uint32_t q = active ? todo.first() : 0u;
+  uint32_t code = active ? LTab::bits(seq, tid + q * kSplitThreads, kmsk) : 0u;
+  uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0;
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    if (active) {
+      const uint32_t e = t.w[h];
+      int res = -2;                                                  // -2: go on probing
+      if (e == 0xFFFFFFFFu || probes > t.mask) res = -1;
+      else if (LTab::bits(t.seq, e & 0x7FFFFFFFu, t.kmsk) == code) res = (e & 0x80000000u) ? -1 : 0;
+      if (res == -2) { h = (h + step) & t.mask; ++probes; }
+      else {
+        if (res >= 0) hits.set(q);
+        todo.drop_first();
+        active = todo.any();
+        q = active ? todo.first() : 0u;
+        code = active ? LTab::bits(seq, tid + q * kSplitThreads, kmsk) : 0u;
+        h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
+      }
+    }
+  }
+  return hits;
+}
+
+__device__ __forceinline__ void flat_add32(const LTab32 &t, Mask128 todo, int *fill = nullptr, int limit = 0)
+{
+  const uint32_t tid = threadIdx.x;
+  bool active = todo.any();
+  uint32_t p = active ? tid + todo.first() * kSplitThreads : 0u;
+  uint32_t code = active ? LTab::bits(t.seq, p, t.kmsk) : 0u;
+  uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0, nturn = 0;
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    if (active) {
+      uint32_t *word = t.w + h;
+      const uint32_t cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      bool fin = false;
+      if (cur == 0xFFFFFFFFu) {
+        fin = atomicCAS(word, 0xFFFFFFFFu, p) == 0xFFFFFFFFu;        // lost the race: look at the slot again
+        if (fin && fill) atomicAdd(fill, 1);
+      } else if (LTab::bits(t.seq, cur & 0x7FFFFFFFu, t.kmsk) == code) { if (!(cur & 0x80000000u)) atomicOr(word, 0x80000000u); fin = true; }
+      else { h = (h + step) & t.mask; fin = ++probes > t.mask; }
+      if (fin) {
+        todo.drop_first();
+        active = todo.any();
+        p = active ? tid + todo.first() * kSplitThreads : 0u;
+        code = active ? LTab::bits(t.seq, p, t.kmsk) : 0u;
+        h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
+      }
+    }
+    if (fill && (++nturn & 7u) == 0u && __builtin_amdgcn_readfirstlane(*(volatile int *)fill) > limit) break;
+  }
+}
+
+// the table phases of split_core for a read of up to kLongMaxN bases: ca / cb filled as the HBM tables fill them;
+// false (uniform) when a partition's second table filled up (the HBM tables then take the call)
+__device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off, const uint8_t *pr, uint32_t nr,
+                            const uint8_t *p1, uint32_t n1, const uint8_t *p2, uint32_t n2, int k)
+{
+  const int tid = threadIdx.x;
+  extern __shared__ int32_t dyn_lds_[];
+  uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
+  uint32_t *wr = lds, *w1 = wr + kLongCapRef, *w2 = wr;          // the third table takes the place of the first, which is dead by then
+  uint32_t *sr = w1 + kLongCapOther, *s1 = sr + kLongSeqWords, *s2 = s1 + kLongSeqWords;
+  int *flag = reinterpret_cast<int *>(s2 + kLongSeqWords);
+  const uint32_t kmsk = (1u << (2 * k)) - 1u;
+  auto pack = [&](const uint8_t *s, uint32_t n, uint32_t *dst) {
+    const uint32_t nw = (n + 15) / 16 + 2;
+    for (uint32_t wdx = tid; wdx < nw; wdx += kSplitThreads) {
+      uint8_t ch[16];
+#pragma unroll
+      for (uint32_t i = 0; i < 16; ++i) { const uint32_t q = 16 * wdx + i; ch[i] = s[q < n ? q : 0]; }   // all sixteen loads in flight
+      uint32_t v = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t q = 16 * wdx + i;
+        if (q < n) v |= (q < (uint32_t)k ? map1(ch[i]) : map2(ch[i])) << (2 * i);
+      }
+      dst[wdx] = v;
+    }
+  };
+  pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2);
+  const uint32_t npr = n_kmers(nr, k), np1 = n_kmers(n1, k), np2 = n_kmers(n2, k);
+  for (uint32_t p = tid; p < npr; p += kSplitThreads) { stg_global(g.ca + p, -1); stg_global(g.cb + p, -1); }
+  uint32_t lg = 0;
+  while (max(max(npr, np1), np2) > (kLongPart << lg)) ++lg;          // at most 16 partitions
+  const LTab32 tr{wr, kLongCapRef - 1, sr, kmsk}, t1{w1, kLongCapOther - 1, s1, kmsk}, t2{w2, kLongCapOther - 1, s2, kmsk};
+  __syncthreads();
+  SP_STAMP(0);
+  for (uint32_t part = 0; part < (1u << lg); ++part) {
+    for (uint32_t i = tid; i < kLongCapRef + kLongCapOther; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    SP_STAMP(0);
+    const Mask128 mine_r = lane_positions_of(sr, npr, kmsk, part, lg);
+    flat_add32(tr, mine_r);
+    __syncthreads();
+    SP_STAMP(1);
+    flat_add32(t1, flat_find32(tr, s1, lane_positions_of(s1, np1, kmsk, part, lg), kmsk), flag, (int)kLongFill);
+    __syncthreads();
+    SP_STAMP(2);
+    if (flag[0] > (int)kLongFill) return false;
+    for (uint32_t i = tid; i < kLongCapOther; i += kSplitThreads) w2[i] = 0xFFFFFFFFu;   // nobody looks the reference's k-mers up any more
+    __syncthreads();
+    flat_add32(t2, flat_find32(t1, s2, lane_positions_of(s2, np2, kmsk, part, lg), kmsk));   // no more distinct k-mers than the table before holds
+    __syncthreads();
+    SP_STAMP(3);
+    // candidates: the reference positions whose k-mer is unique in all three reads, with their partner positions
+    for (Mask128 c = flat_find32(t2, sr, mine_r, kmsk); c.any(); c.drop_first()) {
+      const uint32_t p = (uint32_t)tid + c.first() * kSplitThreads;
+      const uint32_t code = LTab::bits(sr, p, kmsk);
+      const int b = t2.find(code), a = t1.find(code);               // (a k-mer only enters the third table when it is unique in the second)
+      if (a >= 0 && b >= 0) { stg_global(g.ca + p, a); stg_global(g.cb + p, b); }
+    }
+    __syncthreads();
+    SP_STAMP(4);
+  }
+  __threadfence();
+  __syncthreads();
+  return true;
 }
 
 // the three table phases and the candidate arrays of split_core on the LDS tables; false (uniform) when a table
@@ -697,13 +901,17 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
                  ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
   if (g.stamps && tid == 0) { atomicAdd(g.stamps + 11, (unsigned long long)ref.n); atomicAdd(g.stamps + 12, (unsigned long long)S1.n); }
   if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, pr, ref.n, p1, S1.n, p2, S2.n, k);
+  bool long_chip = !on_chip && g.lds_long >= 0 && ref.n <= kLongMaxN && S1.n <= kLongMaxN && S2.n <= kLongMaxN &&
+                   ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
+  if (long_chip) long_chip = tables_long(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k);
+  if (long_chip && g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
   if (on_chip) {
     if (g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
     __syncthreads();
     SP_STAMP(4);
     anchors_lds(L, g.lds_tab, n_kmers(ref.n, k), minSize, k, g.stamps);
     SP_STAMP(5);
-  } else {
+  } else if (!long_chip) {
   reset_tab(tr, cr); reset_tab(t1, c1); reset_tab(t2, c2);
   __threadfence();
   __syncthreads();
@@ -1152,6 +1360,7 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 1024 ? 8 : kS
   g.tab_cap = a.tab_cap; g.maxwin = a.maxwin;
   g.stamps = a.stamps;
   g.lds_tab = (!BIG && a.lds_tables) ? (int)((2 * 5 * a.maxanc * sizeof(AT) + 3) / 4) : -1;
+  g.lds_long = (BIG && a.lds_long) ? 0 : -1;                       // (the anchor arrays of such a batch are in HBM)
   for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     const DSeq ref{a.read_off[3 * r], (uint32_t)(a.read_off[3 * r + 1] - a.read_off[3 * r])};
     const DSeq S1{a.read_off[3 * r + 1], (uint32_t)(a.read_off[3 * r + 2] - a.read_off[3 * r + 1])};
@@ -1292,7 +1501,21 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   // reads anyway), and a workspace that still cannot be had sends the batch to the host splitter (ELECTOR_E_LIMIT).
   const int64_t per_block = 3 * tab_cap * 8 + 2 * (maxlen + 2) * 4 + 3 * maxwin * 8 * 4;
   const int64_t budget = (int64_t)8 << 30;
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_in, max_blocks), std::max<int64_t>(64, budget / per_block)));
+  int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_in, max_blocks), std::max<int64_t>(64, budget / per_block)));
+  // A batch of mostly long reads (beyond the 12.5 kb of the small on-chip tables, within the 65,535 bases of the
+  // partitioned ones, tables_long): 148 KB of LDS per workgroup, one workgroup per CU, anchor arrays in HBM.
+  int64_t n_long = 0;
+  for (int64_t r = 0; r < n_in; ++r) {
+    const int64_t m = std::max(std::max(read_off[3 * r + 1] - read_off[3 * r], read_off[3 * r + 2] - read_off[3 * r + 1]),
+                               read_off[3 * r + 3] - read_off[3 * r + 2]);
+    n_long += m > (int64_t)kLdsMaxN && m <= (int64_t)kLongMaxN;
+  }
+  const bool use_long = !std::getenv("ELECTOR_SPLIT_HBM_TABLES") && !std::getenv("ELECTOR_SPLIT_NO_LONG") && 2 * n_long >= n_in && n_in > 0;
+  if (use_long) {
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    blocks = std::min(blocks, std::max(1, dev_cus));
+  }
   hipStream_t st = c->stream;
   int rc = c->d_sp_reads.ensure((size_t)total + 64) | c->d_sp_off.ensure((size_t)(3 * n_in + 1) * 8 + 64) |
            c->d_sp_hdr.ensure((size_t)n_in * 4 + 64) | c->d_sp_keys.ensure((size_t)blocks * 3 * tab_cap * 8) |
@@ -1353,10 +1576,11 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   // anchors are more than 20 bases apart on the reference (the re-split of a missing end can use less: it
   // overflows into the host path, like a window list that does not fit)
   const int64_t maxanc = maxlen / 21 + 8;
-  const bool big = maxanc > kMaxAnchors;
+  const bool big = maxanc > kMaxAnchors || use_long;
   a.anc = nullptr; a.maxanc = maxanc;
   a.stamps = nullptr;
   a.lds_tables = 0;
+  a.lds_long = use_long ? 1 : 0;
   if (dbg) {
     if (c->d_sp_scan.ensure(4096)) return elector_fail(c, ELECTOR_E_NOMEM, "stamps");
     a.stamps = c->d_sp_scan.as<unsigned long long>();
@@ -1365,7 +1589,13 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   if (big) {
     if (c->d_sp_anc.ensure((size_t)blocks * 2 * 5 * maxanc * 4 + 64)) return elector_fail(c, ELECTOR_E_NOMEM, "device splitter anchors");
     a.anc = c->d_sp_anc.as<int32_t>();
-    hipLaunchKernelGGL(k_split<true>, dim3((unsigned)blocks), dim3(kSplitThreads), 16, st, a);
+    static DeviceOnce once_big;
+    if (use_long && once_big.need()) {
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 512));
+      once_big.done();
+    }
+    hipLaunchKernelGGL(k_split<true>, dim3((unsigned)blocks), dim3(kSplitThreads), use_long ? kLongBytes : (size_t)16, st, a);
   } else {
     // the anchor arrays in LDS, as many entries as the batch's longest read can need: the usual 8-20 kb reads leave
     // room for four workgroups per CU, whose serial stretches (anchor selection, chain) then overlap
