@@ -404,7 +404,10 @@ __device__ __forceinline__ void flat_add(const LTab &t, uint32_t todo, int *fill
 constexpr uint32_t kLongMaxN = 65535;
 constexpr uint32_t kLongCapRef = 16384, kLongCapOther = 8192, kLongFill = 7200, kLongPart = 6000;
 constexpr uint32_t kLongSeqWords = kLongMaxN / 16 + 3;
-constexpr uint32_t kLongDwords = kLongCapRef + kLongCapOther + 3 * kLongSeqWords + 2;
+constexpr uint32_t kLongBitWords = 2 * ((kLongMaxN + 63) / 64 + 1);      // candidate bitmap, as dwords
+constexpr uint32_t kLongDwords = kLongCapRef + kLongCapOther + 3 * kLongSeqWords + 2 + kLongBitWords;
+static_assert(6 * (kLongBitWords / 2) <= kLongCapRef, "the exit tables of the anchor walk overlay the reference's table");
+static_assert(kLongDwords * 4 <= 160 * 1024 - 1024, "one workgroup's LDS");
 constexpr size_t kLongBytes = (size_t)kLongDwords * 4;
 static_assert(kLongMaxN <= 128u * (uint32_t)kSplitThreads, "a lane's positions as one 128-bit mask");
 
@@ -536,6 +539,7 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
   uint32_t *wr = lds, *w1 = wr + kLongCapRef, *w2 = wr;          // the third table takes the place of the first, which is dead by then
   uint32_t *sr = w1 + kLongCapOther, *s1 = sr + kLongSeqWords, *s2 = s1 + kLongSeqWords;
   int *flag = reinterpret_cast<int *>(s2 + kLongSeqWords);
+  uint32_t *bm = reinterpret_cast<uint32_t *>(flag + 2);          // the candidates as a bitmap, for the anchor walk
   const uint32_t kmsk = (1u << (2 * k)) - 1u;
   auto pack = [&](const uint8_t *s, uint32_t n, uint32_t *dst) {
     const uint32_t nw = (n + 15) / 16 + 2;
@@ -554,7 +558,7 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
   };
   pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2);
   const uint32_t npr = n_kmers(nr, k), np1 = n_kmers(n1, k), np2 = n_kmers(n2, k);
-  for (uint32_t p = tid; p < npr; p += kSplitThreads) { stg_global(g.ca + p, -1); stg_global(g.cb + p, -1); }
+  for (uint32_t i = tid; i < 2 * ((npr + 63) / 64 + 1); i += kSplitThreads) bm[i] = 0u;
   uint32_t lg = 0;
   while (max(max(npr, np1), np2) > (kLongPart << lg)) ++lg;          // at most 16 partitions
   const LTab32 tr{wr, kLongCapRef - 1, sr, kmsk}, t1{w1, kLongCapOther - 1, s1, kmsk}, t2{w2, kLongCapOther - 1, s2, kmsk};
@@ -583,7 +587,7 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
       const uint32_t p = (uint32_t)tid + c.first() * kSplitThreads;
       const uint32_t code = LTab::bits(sr, p, kmsk);
       const int b = t2.find(code), a = t1.find(code);               // (a k-mer only enters the third table when it is unique in the second)
-      if (a >= 0 && b >= 0) { stg_global(g.ca + p, a); stg_global(g.cb + p, b); }
+      if (a >= 0 && b >= 0) { stg_global(g.ca + p, a); stg_global(g.cb + p, b); atomicOr(bm + (p >> 5), 1u << (p & 31u)); }
     }
     __syncthreads();
     SP_STAMP(4);
@@ -683,29 +687,24 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
 // then greedily every candidate more than minSize loop steps after the last one taken (loop index j = position - 1,
 // last_indexed starts at 0).  Wavefront 0 holds the bitmap in registers and walks it with scalar code; all threads
 // then look the anchors' partner positions up in the two on-chip tables.  Workgroup-wide.
-template <class LV>
-__device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minSize, int k, unsigned long long *stamps = nullptr)
+// bm: the candidate bitmap (LDS, one bit per reference position, 64-bit words as dword pairs); atab: room for six
+// dwords per bitmap word (LDS, dead memory); partner(position, a, b): the anchor's positions in the other two reads.
+template <class LV, class Partner>
+__device__ void anchors_bitmap(const LV &L, const uint32_t *bm, uint32_t *atab, uint32_t np, uint32_t minSize, Partner &&partner,
+                               unsigned long long *stamps = nullptr)
 {
   unsigned long long st_t_ = stamps ? __builtin_readcyclecounter() : 0;
 #define AN_STAMP(idx) do { if (stamps && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(stamps + (idx), now_ - st_t_); st_t_ = now_; } } while (0)
 
   const int tid = threadIdx.x;
-  extern __shared__ int32_t dyn_lds_[];
-  uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
-  uint32_t *w1 = lds + kLdsCapRef / 2, *w2 = lds;
-  uint32_t *sr = w1 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
-  const uint32_t *bm = s2 + kLdsSeqWords;
-  const uint32_t kmsk = (1u << (2 * k)) - 1u;
-  constexpr int kW = (int)(kLdsBitWords / 2 + 63) / 64;              // 64-bit bitmap words per lane of wavefront 0
   const uint32_t nwords = (np + 63) >> 6;
   // The usual case, minSize = 20 (any minSize up to 29): the walk as a chain of small functions.  What the walk does
   // inside one 64-bit word of the bitmap depends on the word and on ONE number, the first position of the word it may
   // take (0 .. minSize + 2: what the anchor before left over); what it hands to the next word is again such a number
-  // (0 .. minSize).  Every thread tabulates that function for one word (32 entries of 5 bits); wavefront 0 then only
-  // chains the tables -- a dozen scalar instructions per WORD instead of some forty per ANCHOR -- and its lanes write
-  // the anchors of their words, at offsets from a prefix sum of their counts.
+  // (0 .. minSize).  The threads tabulate that function for every word (32 entries of 5 bits); wavefront 0 then only
+  // chains the tables, 64 words at a time, and its lanes write the anchors of their words, at offsets from a prefix
+  // sum of their counts.
   const bool chained = minSize <= 29u;
-  uint32_t *atab = lds + kLdsCapOther / 2;               // over the reference's k-mer table, behind the third table: nothing reads it any more
   // exit tables: six 5-bit entries to a dword, six dwords to a word of the bitmap; a thread per dword
   const uint32_t ne = minSize + 3u, nd = (ne + 5u) / 6u;
   if (chained) {
@@ -732,17 +731,9 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
   }
   AN_STAMP(16);
   if (tid < 64) {
-    uint32_t lo[kW], hi[kW];
-#pragma unroll
-    for (int q = 0; q < kW; ++q) {
-      const uint32_t wd = (uint32_t)q * 64u + (uint32_t)tid;
-      lo[q] = wd < nwords ? bm[2 * wd] : 0u;
-      hi[q] = wd < nwords ? bm[2 * wd + 1] : 0u;
-    }
     int n = 0;
     bool fail = false;
-    const uint32_t w0bits = (uint32_t)__builtin_amdgcn_readlane((int)lo[0], 0);
-    if (w0bits & 1u) { if (tid == 0) L.ar[0] = 0; n = 1; }
+    if (bm[0] & 1u) { if (tid == 0) L.ar[0] = 0; n = 1; }
     // the walk starts behind loop index 0 + minSize whether position 0 was taken or not (last_indexed = 0): the
     // first candidate that counts has j = p - 1 > minSize
     const unsigned long long from0 = (unsigned long long)minSize + 2ull;
@@ -751,15 +742,12 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
       // every word that holds a candidate forgets how it was entered.  So every lane guesses, applies its word's
       // table, takes its neighbour's exit state as the new entry state, and the wavefront repeats that until no
       // lane's entry state changes any more: correct for lanes 0 .. t after t rounds whatever the guesses were,
-      // and in practice done after two or three.
+      // and in practice done after two or three.  Then every lane: the anchors of its word, counted, placed behind
+      // the lanes (words) before it, written.
       uint32_t st = (uint32_t)from0;                       // <= 31: inside word 0
-      uint32_t ent[kW];
-#pragma unroll
-      for (int q = 0; q < kW; ++q) {
-        ent[q] = 0;
-        const uint32_t wd = (uint32_t)q * 64u + (uint32_t)tid;
-        const uint32_t wq = nwords > 64u * (uint32_t)q ? min(64u, nwords - 64u * (uint32_t)q) : 0u;
-        if (wq == 0u) continue;
+      for (uint32_t q0 = 0; q0 < nwords; q0 += 64u) {
+        const uint32_t wd = q0 + (uint32_t)tid;
+        const uint32_t wq = min(64u, nwords - q0);
         uint32_t T[6];
 #pragma unroll
         for (uint32_t d = 0; d < 6u; ++d) T[d] = wd < nwords && d < nd ? atab[6 * wd + d] : 0u;
@@ -776,17 +764,9 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
           in = prev;
           out = exit_of(in);
         }
-        ent[q] = in;
         st = (uint32_t)__builtin_amdgcn_readlane((int)out, (int)(wq - 1u));
-      }
-      AN_STAMP(17);
-      // every lane: the anchors of its words, counted, placed behind the lanes (words) before it, written
-      int base = n;
-#pragma unroll
-      for (int q = 0; q < kW; ++q) {
-        if (nwords <= 64u * (uint32_t)q) continue;
-        const unsigned long long B = ((unsigned long long)hi[q] << 32) | lo[q];
-        const unsigned long long x0 = B & (~0ull << ent[q]);
+        const unsigned long long B = wd < nwords ? (((unsigned long long)bm[2 * wd + 1] << 32) | bm[2 * wd]) : 0ull;
+        const unsigned long long x0 = B & (~0ull << in);
         int c = 0;
         for (unsigned long long x = x0; x;) {
           const uint32_t nx = (uint32_t)__builtin_ctzll(x) + minSize + 1u;
@@ -795,25 +775,19 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
         }
         int inc = c;
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (tid >= d) inc += t; }
-        int at = base + inc - c;
+        int at = n + inc - c;
         for (unsigned long long x = x0; x;) {
           const uint32_t t = (uint32_t)__builtin_ctzll(x), nx = t + minSize + 1u;
-          if (at < L.cap) L.ar[at] = (typename LV::elem)(64u * ((uint32_t)q * 64u + (uint32_t)tid) + t);
+          if (at < L.cap) L.ar[at] = (typename LV::elem)(64u * wd + t);
           ++at;
           x = nx >= 64u ? 0ull : x & (~0ull << nx);
         }
-        base += __shfl(inc, 63);
+        n += __shfl(inc, 63);
       }
-      n = base;
+      AN_STAMP(17);
       if (n > L.cap) fail = true;
     } else {
-    auto word = [&](uint32_t wd) -> unsigned long long {             // uniform wd
-      uint32_t a = 0, b = 0;
-#pragma unroll
-      for (int q = 0; q < kW; ++q)
-        if ((int)(wd >> 6) == q) { a = (uint32_t)__builtin_amdgcn_readlane((int)lo[q], (int)(wd & 63u)); b = (uint32_t)__builtin_amdgcn_readlane((int)hi[q], (int)(wd & 63u)); }
-      return ((unsigned long long)b << 32) | a;
-    };
+    auto word = [&](uint32_t wd) -> unsigned long long { return ((unsigned long long)bm[2 * wd + 1] << 32) | bm[2 * wd]; };   // uniform wd: one broadcast read
     uint32_t from = from0 >= (unsigned long long)np ? np : (uint32_t)from0;
     uint32_t wd = from >> 6;
     unsigned long long cur = wd < nwords ? word(wd) & (~0ull << (from & 63u)) : 0ull;
@@ -849,13 +823,32 @@ __device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minS
   AN_STAMP(18);
   // partner positions of the anchors: the k-mer's only occurrence in the uncorrected / corrected read
   const int n = L.s->n;
-  const LTab t1{w1, kLdsCapOther - 1, s1, kmsk}, t2{w2, kLdsCapOther - 1, s2, kmsk};
   for (int i = tid; i < n; i += kSplitThreads) {
-    const uint32_t c = LTab::bits(sr, (uint32_t)L.ar[i], kmsk);
-    L.aa[i] = (typename LV::elem)t1.find(c);
-    L.ab[i] = (typename LV::elem)t2.find(c);
+    int a, b;
+    partner((uint32_t)L.ar[i], a, b);
+    L.aa[i] = (typename LV::elem)a;
+    L.ab[i] = (typename LV::elem)b;
   }
   __syncthreads();
+}
+
+// the anchors of a pass that went through tables_lds: bitmap, exit tables (over the dead reference table, behind the
+// third table) and the two tables the partner positions are looked up in
+template <class LV>
+__device__ void anchors_lds(const LV &L, int lds_off, uint32_t np, uint32_t minSize, int k, unsigned long long *stamps = nullptr)
+{
+  extern __shared__ int32_t dyn_lds_[];
+  uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
+  uint32_t *w1 = lds + kLdsCapRef / 2, *w2 = lds;
+  uint32_t *sr = w1 + kLdsCapOther / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
+  const uint32_t *bm = s2 + kLdsSeqWords;
+  const uint32_t kmsk = (1u << (2 * k)) - 1u;
+  const LTab t1{w1, kLdsCapOther - 1, s1, kmsk}, t2{w2, kLdsCapOther - 1, s2, kmsk};
+  anchors_bitmap(L, bm, lds + kLdsCapOther / 2, np, minSize, [&](uint32_t p, int &a, int &b) {
+    const uint32_t c = LTab::bits(sr, p, kmsk);
+    a = t1.find(c);
+    b = t2.find(c);
+  }, stamps);
 }
 
 // maximum over the wavefront, uniform (DPP row shifts + four v_readlane: no LDS traffic)
@@ -901,17 +894,28 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
                  ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
   if (g.stamps && tid == 0) { atomicAdd(g.stamps + 11, (unsigned long long)ref.n); atomicAdd(g.stamps + 12, (unsigned long long)S1.n); }
   if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, pr, ref.n, p1, S1.n, p2, S2.n, k);
-  bool long_chip = !on_chip && g.lds_long >= 0 && ref.n <= kLongMaxN && S1.n <= kLongMaxN && S2.n <= kLongMaxN &&
-                   ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
-  if (long_chip) long_chip = tables_long(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k);
-  if (long_chip && g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
+  bool long_chip = false;
+  if constexpr (std::is_same<LV, Lvl32>::value) {               // (only the kernel of the long batches carries that code)
+    long_chip = !on_chip && g.lds_long >= 0 && ref.n <= kLongMaxN && S1.n <= kLongMaxN && S2.n <= kLongMaxN &&
+                ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
+    if (long_chip) long_chip = tables_long(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k);
+    if (long_chip && g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
+  }
   if (on_chip) {
     if (g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
     __syncthreads();
     SP_STAMP(4);
     anchors_lds(L, g.lds_tab, n_kmers(ref.n, k), minSize, k, g.stamps);
     SP_STAMP(5);
-  } else if (!long_chip) {
+  } else if (long_chip) {
+    // the anchors from the bitmap tables_long left in LDS (exit tables over its dead tables), their partner positions
+    // from the dense arrays -- only the anchors' entries of those are ever read
+    extern __shared__ int32_t dyn_lds_[];
+    uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + g.lds_long;
+    const uint32_t *bm = lds + kLongCapRef + kLongCapOther + 3 * kLongSeqWords + 2;
+    anchors_bitmap(L, bm, lds, n_kmers(ref.n, k), minSize, [&](uint32_t p, int &a, int &b) { a = ldg(g.ca + p); b = ldg(g.cb + p); }, g.stamps);
+    SP_STAMP(5);
+  } else {
   reset_tab(tr, cr); reset_tab(t1, c1); reset_tab(t2, c2);
   __threadfence();
   __syncthreads();
@@ -985,7 +989,7 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
   // anchors (:234-251), wavefront 0: position 0 without a distance test, then greedily every candidate more than
   // minSize loop steps after the last one taken (loop index j = position - 1, last_indexed starts at 0)
   const uint32_t np = n_kmers(ref.n, k);
-  if (!on_chip) {
+  if (!on_chip && !long_chip) {
   if (tid < 64) {
     int n = 0;
     if (tid == 0) {
