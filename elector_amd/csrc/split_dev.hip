@@ -72,7 +72,9 @@ struct SplitArgs {
   int32_t *anc; int64_t maxanc;
   unsigned long long *stamps;
   int lds_tables;                // the dynamic LDS holds the on-chip tables behind the anchor arrays
-  int lds_long;                  // the dynamic LDS holds the long reads' on-chip tables (tables_long)
+  int lds_long;                  // the dynamic LDS holds the long reads' on-chip tables (tables_long): 1 first size only, 2 both
+  const int32_t *order;          // the reads, longest first: the order the workgroups take them in
+  int32_t *next;                 // ... through this counter
 };
 
 // window record (8 ints): ref off, ref len, S1 off, S1 len, S2 off, S2 len, S2 is the 'N' filler, unused;
@@ -191,6 +193,7 @@ struct WG {
   unsigned long long *stamps;     // debug (ELECTOR_DEBUG_SPLIT): cycles per phase, summed over reads
   int lds_tab;                    // LDS tables (tables_lds): dword offset in the dynamic LDS, or -1
   int lds_long;                   // LDS tables for reads of up to 65,535 bases (tables_long): dword offset, or -1
+  int long_b;                     // ... and the second size, up to 122,879 bases
 };
 
 #define SP_STAMP(idx)                                                                      \
@@ -401,31 +404,57 @@ __device__ __forceinline__ void flat_add(const LTab &t, uint32_t todo, int *fill
 // back from the 2-bit packed sequences, which also live in LDS (3 x 16 KB); the candidates go to the dense arrays
 // ca / cb in HBM that the HBM tables write, and everything behind (anchor walk, chain) is shared with that path.
 // One workgroup per CU (148 KB of LDS).
-constexpr uint32_t kLongMaxN = 65535;
-constexpr uint32_t kLongCapRef = 16384, kLongCapOther = 8192, kLongFill = 7200, kLongPart = 6000;
-constexpr uint32_t kLongSeqWords = kLongMaxN / 16 + 3;
-constexpr uint32_t kLongBitWords = 2 * ((kLongMaxN + 63) / 64 + 1);      // candidate bitmap, as dwords
-constexpr uint32_t kLongDwords = kLongCapRef + kLongCapOther + 3 * kLongSeqWords + 2 + kLongBitWords;
-static_assert(6 * (kLongBitWords / 2) <= kLongCapRef, "the exit tables of the anchor walk overlay the reference's table");
-static_assert(kLongDwords * 4 <= 160 * 1024 - 1024, "one workgroup's LDS");
-constexpr size_t kLongBytes = (size_t)kLongDwords * 4;
-static_assert(kLongMaxN <= 128u * (uint32_t)kSplitThreads, "a lane's positions as one 128-bit mask");
+// Two sizes: reads of up to 65,535 bases with tables of 16,384 / 8,192 slots (a partition holds up to ~6,000 k-mers),
+// reads of up to 122,879 bases with half the tables and twice the partitions -- the packed sequences take the room.
+template <int NW_, uint32_t MAXN_, uint32_t CAPREF_, uint32_t CAPOTHER_, uint32_t FILL_, uint32_t PART_>
+struct LongCfg {
+  static constexpr int NW = NW_;                                   // 32-bit words of a lane's position mask
+  static constexpr uint32_t kMaxN = MAXN_, kCapRef = CAPREF_, kCapOther = CAPOTHER_, kFill = FILL_, kPart = PART_;
+  static constexpr uint32_t kSeqWords = MAXN_ / 16 + 3;
+  static constexpr uint32_t kBitWords = 2 * ((MAXN_ + 63) / 64 + 1);                  // candidate bitmap, as dwords
+  static constexpr uint32_t kBmWord = CAPREF_ + CAPOTHER_ + 3 * kSeqWords + 2;        // dwords from the region's start
+  static constexpr uint32_t kDwords = kBmWord + kBitWords;
+  static_assert(MAXN_ <= 32u * NW_ * (uint32_t)kSplitThreads, "a lane's positions as one mask");
+  static_assert(6 * (kBitWords / 2) <= CAPREF_ + CAPOTHER_, "the exit tables of the anchor walk overlay the dead tables");
+  static_assert(kDwords * 4 <= 160 * 1024 - 1024, "one workgroup's LDS");
+};
+using LongA = LongCfg<4, 65535u, 16384u, 8192u, 7200u, 6000u>;
+using LongB = LongCfg<8, 122879u, 8192u, 4096u, 3600u, 3000u>;
+constexpr uint32_t kLongMaxN = LongB::kMaxN;
+constexpr size_t kLongBytes = (size_t)(LongA::kDwords > LongB::kDwords ? LongA::kDwords : LongB::kDwords) * 4;
 
-struct Mask128 {
-  uint32_t m[4];
-  __device__ __forceinline__ bool any() const { return (m[0] | m[1] | m[2] | m[3]) != 0u; }
+template <int NW>
+struct MaskN {
+  uint32_t m[NW];
+  __device__ __forceinline__ bool any() const
+  {
+    uint32_t o = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) o |= m[w];
+    return o != 0u;
+  }
   __device__ __forceinline__ uint32_t first() const                    // index of the lowest bit (any())
   {
-    return m[0] ? (uint32_t)__builtin_ctz(m[0]) : m[1] ? 32u + (uint32_t)__builtin_ctz(m[1]) : m[2] ? 64u + (uint32_t)__builtin_ctz(m[2]) : 96u + (uint32_t)__builtin_ctz(m[3]);
+    uint32_t r = 0;
+#pragma unroll
+    for (int w = NW - 1; w >= 0; --w) if (m[w]) r = 32u * (uint32_t)w + (uint32_t)__builtin_ctz(m[w]);
+    return r;
   }
   __device__ __forceinline__ void drop_first()
   {
-    if (m[0]) m[0] &= m[0] - 1u; else if (m[1]) m[1] &= m[1] - 1u; else if (m[2]) m[2] &= m[2] - 1u; else m[3] &= m[3] - 1u;
+    bool done = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const bool here = !done && m[w] != 0u;
+      if (here) m[w] &= m[w] - 1u;
+      done = done || here;
+    }
   }
   __device__ __forceinline__ void set(uint32_t q)
   {
     const uint32_t b = 1u << (q & 31u);
-    if (q < 32u) m[0] |= b; else if (q < 64u) m[1] |= b; else if (q < 96u) m[2] |= b; else m[3] |= b;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) if ((q >> 5) == (uint32_t)w) m[w] |= b;
   }
 };
 
@@ -453,15 +482,16 @@ struct LTab32 {
 __device__ __forceinline__ uint32_t part_of(uint32_t code, uint32_t lg) { return lg ? (code * 0x85EBCA6Bu) >> (32u - lg) : 0u; }
 
 // the lane's positions (tid + q * kSplitThreads) of seq whose k-mer lies in partition part
-__device__ __forceinline__ Mask128 lane_positions_of(const uint32_t *seq, uint32_t np, uint32_t kmsk, uint32_t part, uint32_t lg)
+template <int NW>
+__device__ __forceinline__ MaskN<NW> lane_positions_of(const uint32_t *seq, uint32_t np, uint32_t kmsk, uint32_t part, uint32_t lg)
 {
-  Mask128 r{{0u, 0u, 0u, 0u}};
+  MaskN<NW> r;
   const uint32_t tid = threadIdx.x;
 #pragma unroll
-  for (uint32_t wd = 0; wd < 4u; ++wd) {
+  for (int wd = 0; wd < NW; ++wd) {
     uint32_t bitsw = 0;
     for (uint32_t b = 0; b < 32u; ++b) {
-      const uint32_t p = tid + (32u * wd + b) * (uint32_t)kSplitThreads;
+      const uint32_t p = tid + (32u * (uint32_t)wd + b) * (uint32_t)kSplitThreads;
       if (p >= np) break;
       if (part_of(LTab::bits(seq, p, kmsk), lg) == part) bitsw |= 1u << b;
     }
@@ -470,11 +500,14 @@ __device__ __forceinline__ Mask128 lane_positions_of(const uint32_t *seq, uint32
   return r;
 }
 
-// flat loops (see flat_find / flat_add) on a 32-bit table and a 128-bit position mask
-__device__ __forceinline__ Mask128 flat_find32(const LTab32 &t, const uint32_t *seq, Mask128 todo, uint32_t kmsk)
+// flat loops (see flat_find / flat_add) on a 32-bit table and a lane's position mask
+template <int NW>
+__device__ __forceinline__ MaskN<NW> flat_find32(const LTab32 &t, const uint32_t *seq, MaskN<NW> todo, uint32_t kmsk)
 {
   const uint32_t tid = threadIdx.x;
-  Mask128 hits{{0u, 0u, 0u, 0u}};
+  MaskN<NW> hits;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) hits.m[w] = 0u;
   bool active = todo.any();
   uint32_t q = active ? todo.first() : 0u;
   uint32_t code = active ? LTab::bits(seq, tid + q * kSplitThreads, kmsk) : 0u;
@@ -499,7 +532,8 @@ __device__ __forceinline__ Mask128 flat_find32(const LTab32 &t, const uint32_t *
   return hits;
 }
 
-__device__ __forceinline__ void flat_add32(const LTab32 &t, Mask128 todo, int *fill = nullptr, int limit = 0)
+template <int NW>
+__device__ __forceinline__ void flat_add32(const LTab32 &t, MaskN<NW> todo, int *fill = nullptr, int limit = 0)
 {
   const uint32_t tid = threadIdx.x;
   bool active = todo.any();
@@ -528,18 +562,21 @@ __device__ __forceinline__ void flat_add32(const LTab32 &t, Mask128 todo, int *f
   }
 }
 
-// the table phases of split_core for a read of up to kLongMaxN bases: ca / cb filled as the HBM tables fill them;
-// false (uniform) when a partition's second table filled up (the HBM tables then take the call)
+// the table phases of split_core for a read of up to C::kMaxN bases: ca / cb written for the candidates as the HBM
+// tables write them, the candidates as a bitmap in LDS for the anchor walk; false (uniform) when a partition's
+// second table filled up (the HBM tables then take the call)
+template <class C>
 __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off, const uint8_t *pr, uint32_t nr,
                             const uint8_t *p1, uint32_t n1, const uint8_t *p2, uint32_t n2, int k)
 {
+  constexpr int NW = C::NW;
   const int tid = threadIdx.x;
   extern __shared__ int32_t dyn_lds_[];
   uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
-  uint32_t *wr = lds, *w1 = wr + kLongCapRef, *w2 = wr;          // the third table takes the place of the first, which is dead by then
-  uint32_t *sr = w1 + kLongCapOther, *s1 = sr + kLongSeqWords, *s2 = s1 + kLongSeqWords;
-  int *flag = reinterpret_cast<int *>(s2 + kLongSeqWords);
-  uint32_t *bm = reinterpret_cast<uint32_t *>(flag + 2);          // the candidates as a bitmap, for the anchor walk
+  uint32_t *wr = lds, *w1 = wr + C::kCapRef, *w2 = wr;           // the third table takes the place of the first, which is dead by then
+  uint32_t *sr = w1 + C::kCapOther, *s1 = sr + C::kSeqWords, *s2 = s1 + C::kSeqWords;
+  int *flag = reinterpret_cast<int *>(s2 + C::kSeqWords);
+  uint32_t *bm = lds + C::kBmWord;                                // the candidates as a bitmap, for the anchor walk
   const uint32_t kmsk = (1u << (2 * k)) - 1u;
   auto pack = [&](const uint8_t *s, uint32_t n, uint32_t *dst) {
     const uint32_t nw = (n + 15) / 16 + 2;
@@ -560,30 +597,30 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
   const uint32_t npr = n_kmers(nr, k), np1 = n_kmers(n1, k), np2 = n_kmers(n2, k);
   for (uint32_t i = tid; i < 2 * ((npr + 63) / 64 + 1); i += kSplitThreads) bm[i] = 0u;
   uint32_t lg = 0;
-  while (max(max(npr, np1), np2) > (kLongPart << lg)) ++lg;          // at most 16 partitions
-  const LTab32 tr{wr, kLongCapRef - 1, sr, kmsk}, t1{w1, kLongCapOther - 1, s1, kmsk}, t2{w2, kLongCapOther - 1, s2, kmsk};
+  while (max(max(npr, np1), np2) > (C::kPart << lg)) ++lg;
+  const LTab32 tr{wr, C::kCapRef - 1, sr, kmsk}, t1{w1, C::kCapOther - 1, s1, kmsk}, t2{w2, C::kCapOther - 1, s2, kmsk};
   __syncthreads();
   SP_STAMP(0);
   for (uint32_t part = 0; part < (1u << lg); ++part) {
-    for (uint32_t i = tid; i < kLongCapRef + kLongCapOther; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < C::kCapRef + C::kCapOther; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
     if (tid == 0) flag[0] = 0;
     __syncthreads();
     SP_STAMP(0);
-    const Mask128 mine_r = lane_positions_of(sr, npr, kmsk, part, lg);
-    flat_add32(tr, mine_r);
+    const MaskN<NW> mine_r = lane_positions_of<NW>(sr, npr, kmsk, part, lg);
+    flat_add32<NW>(tr, mine_r);
     __syncthreads();
     SP_STAMP(1);
-    flat_add32(t1, flat_find32(tr, s1, lane_positions_of(s1, np1, kmsk, part, lg), kmsk), flag, (int)kLongFill);
+    flat_add32<NW>(t1, flat_find32<NW>(tr, s1, lane_positions_of<NW>(s1, np1, kmsk, part, lg), kmsk), flag, (int)C::kFill);
     __syncthreads();
     SP_STAMP(2);
-    if (flag[0] > (int)kLongFill) return false;
-    for (uint32_t i = tid; i < kLongCapOther; i += kSplitThreads) w2[i] = 0xFFFFFFFFu;   // nobody looks the reference's k-mers up any more
+    if (flag[0] > (int)C::kFill) return false;
+    for (uint32_t i = tid; i < C::kCapOther; i += kSplitThreads) w2[i] = 0xFFFFFFFFu;   // nobody looks the reference's k-mers up any more
     __syncthreads();
-    flat_add32(t2, flat_find32(t1, s2, lane_positions_of(s2, np2, kmsk, part, lg), kmsk));   // no more distinct k-mers than the table before holds
+    flat_add32<NW>(t2, flat_find32<NW>(t1, s2, lane_positions_of<NW>(s2, np2, kmsk, part, lg), kmsk));   // no more distinct k-mers than the table before holds
     __syncthreads();
     SP_STAMP(3);
     // candidates: the reference positions whose k-mer is unique in all three reads, with their partner positions
-    for (Mask128 c = flat_find32(t2, sr, mine_r, kmsk); c.any(); c.drop_first()) {
+    for (MaskN<NW> c = flat_find32<NW>(t2, sr, mine_r, kmsk); c.any(); c.drop_first()) {
       const uint32_t p = (uint32_t)tid + c.first() * kSplitThreads;
       const uint32_t code = LTab::bits(sr, p, kmsk);
       const int b = t2.find(code), a = t1.find(code);               // (a k-mer only enters the third table when it is unique in the second)
@@ -894,11 +931,13 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
                  ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
   if (g.stamps && tid == 0) { atomicAdd(g.stamps + 11, (unsigned long long)ref.n); atomicAdd(g.stamps + 12, (unsigned long long)S1.n); }
   if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, pr, ref.n, p1, S1.n, p2, S2.n, k);
-  bool long_chip = false;
+  bool long_chip = false, long_small = true;
   if constexpr (std::is_same<LV, Lvl32>::value) {               // (only the kernel of the long batches carries that code)
-    long_chip = !on_chip && g.lds_long >= 0 && ref.n <= kLongMaxN && S1.n <= kLongMaxN && S2.n <= kLongMaxN &&
-                ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
-    if (long_chip) long_chip = tables_long(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k);
+    const uint32_t longest = max(max(ref.n, S1.n), S2.n);
+    long_chip = !on_chip && g.lds_long >= 0 && longest <= (g.long_b ? LongB::kMaxN : LongA::kMaxN) && ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
+    long_small = longest <= LongA::kMaxN;
+    if (long_chip) long_chip = long_small ? tables_long<LongA>(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k)
+                                          : tables_long<LongB>(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k);
     if (long_chip && g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
   }
   if (on_chip) {
@@ -912,7 +951,7 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
     // from the dense arrays -- only the anchors' entries of those are ever read
     extern __shared__ int32_t dyn_lds_[];
     uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + g.lds_long;
-    const uint32_t *bm = lds + kLongCapRef + kLongCapOther + 3 * kLongSeqWords + 2;
+    const uint32_t *bm = lds + (long_small ? LongA::kBmWord : LongB::kBmWord);
     anchors_bitmap(L, bm, lds, n_kmers(ref.n, k), minSize, [&](uint32_t p, int &a, int &b) { a = ldg(g.ca + p); b = ldg(g.cb + p); }, g.stamps);
     SP_STAMP(5);
   } else {
@@ -1365,7 +1404,16 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 1024 ? 8 : kS
   g.stamps = a.stamps;
   g.lds_tab = (!BIG && a.lds_tables) ? (int)((2 * 5 * a.maxanc * sizeof(AT) + 3) / 4) : -1;
   g.lds_long = (BIG && a.lds_long) ? 0 : -1;                       // (the anchor arrays of such a batch are in HBM)
-  for (int64_t r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
+  g.long_b = a.lds_long >= 2;
+  // A read's cost grows faster than its length and the lengths of a batch differ by an order of magnitude: the
+  // workgroups draw the reads from a counter, longest first (a fixed stride left the chip a third idle on long reads).
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) sh[7] = atomicAdd(a.next, 1);
+    __syncthreads();
+    const int64_t turn = sh[7];
+    if (turn >= a.n_reads) break;
+    const int64_t r = a.order[turn];
     const DSeq ref{a.read_off[3 * r], (uint32_t)(a.read_off[3 * r + 1] - a.read_off[3 * r])};
     const DSeq S1{a.read_off[3 * r + 1], (uint32_t)(a.read_off[3 * r + 2] - a.read_off[3 * r + 1])};
     const DSeq S2{a.read_off[3 * r + 2], (uint32_t)(a.read_off[3 * r + 3] - a.read_off[3 * r + 2])};
@@ -1584,7 +1632,20 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   a.anc = nullptr; a.maxanc = maxanc;
   a.stamps = nullptr;
   a.lds_tables = 0;
-  a.lds_long = use_long ? 1 : 0;
+  {
+    // the order the reads are taken in: by the cells of their tables, i.e. by length, longest first
+    std::vector<int32_t> order((size_t)n_in + 2, 0);
+    for (int64_t r = 0; r < n_in; ++r) order[(size_t)r + 2] = (int32_t)r;
+    std::sort(order.begin() + 2, order.end(), [&](int32_t x, int32_t y) {
+      const int64_t lx = read_off[3 * (int64_t)x + 3] - read_off[3 * (int64_t)x], ly = read_off[3 * (int64_t)y + 3] - read_off[3 * (int64_t)y];
+      return lx != ly ? lx > ly : x < y;
+    });
+    HIPCHK(c, hipMemcpyAsync(c->d_sp_wfirst.p, order.data(), ((size_t)n_in + 2) * 4, hipMemcpyHostToDevice, st));   // [counter, pad][order]
+    HIPCHK(c, hipStreamSynchronize(st));                               // (the vector goes out of scope)
+    a.next = c->d_sp_wfirst.as<int32_t>();
+    a.order = a.next + 2;
+  }
+  a.lds_long = use_long ? (std::getenv("ELECTOR_SPLIT_LONG") ? std::atoi(std::getenv("ELECTOR_SPLIT_LONG")) : 2) : 0;
   if (dbg) {
     if (c->d_sp_scan.ensure(4096)) return elector_fail(c, ELECTOR_E_NOMEM, "stamps");
     a.stamps = c->d_sp_scan.as<unsigned long long>();
