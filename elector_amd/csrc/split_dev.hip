@@ -903,7 +903,9 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 
 // tables, anchors and the best chain of one split() call (ref: split :175-255, best_chain :79-126).
 // Workgroup-wide.  On return L.s->n anchors, L.s->nchain chain entries (indices of the chain in L.cl[0 .. nchain), reused).
-template <class LV>
+// ROOMY: the copy of this function that the kernel of long batches calls (one workgroup per CU there: twice the
+// registers, and the long reads' on-chip tables)
+template <bool ROOMY, class LV>
 __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize)
 {
   // This function is not inlined (three call sites, a long body): behind the references its arguments live in the
@@ -932,7 +934,7 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
   if (g.stamps && tid == 0) { atomicAdd(g.stamps + 11, (unsigned long long)ref.n); atomicAdd(g.stamps + 12, (unsigned long long)S1.n); }
   if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, pr, ref.n, p1, S1.n, p2, S2.n, k);
   bool long_chip = false, long_small = true;
-  if constexpr (std::is_same<LV, Lvl32>::value) {               // (only the kernel of the long batches carries that code)
+  if constexpr (ROOMY) {                                        // (only the kernel of the long batches carries that code)
     const uint32_t longest = max(max(ref.n, S1.n), S2.n);
     long_chip = !on_chip && g.lds_long >= 0 && longest <= (g.long_b ? LongB::kMaxN : LongA::kMaxN) && ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
     long_small = longest <= LongA::kMaxN;
@@ -1204,13 +1206,13 @@ __device__ __forceinline__ DSeq dsub(DSeq s, uint32_t pos) { return dsub(s, pos,
 
 // one split() of the reference (:175-308) including the two re-splits of a missing start / end.  Workgroup-wide;
 // the window list `out` (in HBM) is built by wavefront 0; returns its length through sh[0] (LDS).
-template <class LV>
+template <bool ROOMY, class LV>
 __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DSeq S1, DSeq S2, int k, int32_t *out, int32_t *tmp,
                            int *sh /* LDS ints: [0] n out, [1] overflow, [2..] scratch */)
 {
   (void)tmp;
   const int tid = threadIdx.x;
-  split_core(g, L0, ref, S1, S2, k, 20u);
+  split_core<ROOMY>(g, L0, ref, S1, S2, k, 20u);
   unsigned long long sp_t_ = g.stamps ? __builtin_readcyclecounter() : 0;
   const int64_t cap = g.maxwin;
   // the list's length and overflow flag: the same in all lanes of wavefront 0, which is the only one that uses them
@@ -1305,7 +1307,7 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   const bool rec_start = (uint64_t)s2 * 2 < sr && sr - s2 > 200;
   if (rec_start) {
     SP_STAMP(15);
-    split_core(g, L1, DSeq{ref.base, sr}, DSeq{S1.base, s1}, DSeq{ref.base, sr}, k, (uint32_t)(1.2 * s2));
+    split_core<ROOMY>(g, L1, DSeq{ref.base, sr}, DSeq{S1.base, s1}, DSeq{ref.base, sr}, k, (uint32_t)(1.2 * s2));
     if (g.stamps) sp_t_ = __builtin_readcyclecounter();
     if (tid < 64) resplit_windows(sr, s1, 0u, 0u, (uint32_t)(1.2 * s2), true, 0u, s2);
     pred_S1 = (uint32_t)(L0.aa[a0] + k); pred_ref = (uint32_t)(L0.ar[a0] + k); pred_S2 = (uint32_t)(L0.ab[a0] + k);
@@ -1333,7 +1335,7 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   if (rec_end) {
     const DSeq gr{ref.base + er.base, er.n}, g1{S1.base + e1.base, e1.n};
     SP_STAMP(15);
-    split_core(g, L1, gr, g1, gr, k, (uint32_t)(1.2 * e2.n));
+    split_core<ROOMY>(g, L1, gr, g1, gr, k, (uint32_t)(1.2 * e2.n));
     if (g.stamps) sp_t_ = __builtin_readcyclecounter();
     if (tid < 64) resplit_windows(er.n, e1.n, (uint32_t)er.base, (uint32_t)e1.base, (uint32_t)(1.2 * e2.n), false, (uint32_t)e2.base, e2.n);
   } else if (tid < 64) {
@@ -1366,8 +1368,8 @@ __device__ uint32_t largest_fragment(const int32_t *wl, int n, uint32_t hdr_len,
   return res;
 }
 
-template <bool BIG>
-__global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 1024 ? 8 : kSplitThreads >= 768 ? 6 : kSplitThreads >= 512 ? 4 : 2)) k_split(SplitArgs a)
+template <bool BIG, bool ROOMY = false>
+__global__ void __launch_bounds__(kSplitThreads, (ROOMY ? kSplitThreads / 256 : kSplitThreads >= 1024 ? 8 : kSplitThreads >= 768 ? 6 : kSplitThreads >= 512 ? 4 : 2)) k_split(SplitArgs a)
 {
   extern __shared__ int32_t s_anc[];              // !BIG: 2 levels x 5 arrays x a.maxanc entries (sized by the batch's longest read)
   __shared__ LvlState s_lvl[2];
@@ -1433,7 +1435,7 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 1024 ? 8 : kS
       // best_split (:310-332): k = 15, then smaller k while the largest fragment shrinks
       int32_t *best = g.wl, *aux = g.wl + a.maxwin * 8, *tmp = g.wl + 2 * a.maxwin * 8;
       int kk = 15;
-      split_read(g, L0, L1, ref, S1, S2, kk, best, tmp, sh);
+      split_read<ROOMY>(g, L0, L1, ref, S1, S2, kk, best, tmp, sh);
       int nbest = sh[0];
       bool over = sh[1] != 0;
       uint32_t largest = largest_fragment(best, nbest, (uint32_t)a.hdr_len[r], &sh[2]);
@@ -1441,7 +1443,7 @@ __global__ void __launch_bounds__(kSplitThreads, (kSplitThreads >= 1024 ? 8 : kS
         kk -= 2;
         if (kk < 9 || over) break;
         __syncthreads();
-        split_read(g, L0, L1, ref, S1, S2, kk, aux, tmp, sh);
+        split_read<ROOMY>(g, L0, L1, ref, S1, S2, kk, aux, tmp, sh);
         const int naux = sh[0];
         over = over || sh[1] != 0;
         const uint32_t la = largest_fragment(aux, naux, (uint32_t)a.hdr_len[r], &sh[3]);
@@ -1656,11 +1658,12 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     a.anc = c->d_sp_anc.as<int32_t>();
     static DeviceOnce once_big;
     if (use_long && once_big.need()) {
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024 - 512));
       once_big.done();
     }
-    hipLaunchKernelGGL(k_split<true>, dim3((unsigned)blocks), dim3(kSplitThreads), use_long ? kLongBytes : (size_t)16, st, a);
+    if (use_long) hipLaunchKernelGGL((k_split<true, true>), dim3((unsigned)blocks), dim3(kSplitThreads), kLongBytes, st, a);
+    else hipLaunchKernelGGL((k_split<true, false>), dim3((unsigned)blocks), dim3(kSplitThreads), (size_t)16, st, a);
   } else {
     // the anchor arrays in LDS, as many entries as the batch's longest read can need: the usual 8-20 kb reads leave
     // room for four workgroups per CU, whose serial stretches (anchor selection, chain) then overlap
