@@ -102,3 +102,23 @@ def test_soak(engine, seed):
         reads.append((r, c[a:b] if b - a > 50 else c[cut:], u))
         reads.append((r, c[:max(60, len(c) - a)], u))
     same(engine, reads)
+
+
+def test_long_read_tables(engine):
+    """A batch of mostly long reads takes the partitioned on-chip tables (reads of up to 65,535 and of up to 122,879
+    bases: two table sizes), longer reads and partitions whose second table fills up (a nearly error-free
+    uncorrected read) the HBM tables -- in one launch, the reads drawn longest first."""
+    rng = np.random.default_rng(23)
+    reads = []
+    for n in (20000, 40000, 65535, 65536, 70000, 122879, 122880, 131000):
+        r = synth.random_seq(rng, n)
+        reads.append((r, synth.mutate(rng, r, 0.01), synth.mutate(rng, r, 0.13)))
+    r = synth.random_seq(rng, 30000)
+    reads.append((r, r, r))                                          # error-free: a partition's second table overflows
+    reads.append((r, synth.mutate(rng, r, 0.02)[5000:21000], synth.mutate(rng, r, 0.12)))   # re-splits at both ends
+    r = synth.random_seq(rng, 90000)
+    reads.append((r, synth.mutate(rng, r, 0.02)[:50000], synth.mutate(rng, r, 0.12)))
+    for n in (800, 9000):                                            # a few short ones in the same batch
+        r = synth.random_seq(rng, n)
+        reads.append((r, synth.mutate(rng, r, 0.01), synth.mutate(rng, r, 0.15)))
+    same(engine, reads)
