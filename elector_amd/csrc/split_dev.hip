@@ -481,19 +481,26 @@ struct LTab32 {
 // own, so that the slots of a partition's k-mers are spread over the whole table
 __device__ __forceinline__ uint32_t part_of(uint32_t code, uint32_t lg) { return lg ? (code * 0x85EBCA6Bu) >> (32u - lg) : 0u; }
 
-// the lane's positions (tid + q * kSplitThreads) of seq whose k-mer lies in partition part
+// In the long reads' tables a lane's positions are CONTIGUOUS (base .. base + cnt - 1, bit q of a mask is position
+// base + q): which of them lie in partition part is then a matter of sliding a window over the packed sequence -- a
+// shift, a multiply and a compare per position, one LDS read per eight -- instead of two LDS reads per position and
+// pass; with P partitions every position is looked at P times.
 template <int NW>
-__device__ __forceinline__ MaskN<NW> lane_positions_of(const uint32_t *seq, uint32_t np, uint32_t kmsk, uint32_t part, uint32_t lg)
+__device__ __forceinline__ MaskN<NW> lane_positions_of(const uint32_t *seq, uint32_t base, uint32_t cnt, uint32_t kmsk, uint32_t part, uint32_t lg)
 {
   MaskN<NW> r;
-  const uint32_t tid = threadIdx.x;
 #pragma unroll
   for (int wd = 0; wd < NW; ++wd) {
     uint32_t bitsw = 0;
-    for (uint32_t b = 0; b < 32u; ++b) {
-      const uint32_t p = tid + (32u * (uint32_t)wd + b) * (uint32_t)kSplitThreads;
-      if (p >= np) break;
-      if (part_of(LTab::bits(seq, p, kmsk), lg) == part) bitsw |= 1u << b;
+    for (uint32_t b0 = 0; b0 < 32u && 32u * (uint32_t)wd + b0 < cnt; b0 += 8u) {
+      const uint32_t p0 = base + 32u * (uint32_t)wd + b0, bit = 2u * p0, i = bit >> 5, sh = bit & 31u;
+      // 46 bits from position p0 on: eight positions of up to 30 bits each, two bits apart
+      unsigned long long win = ((((unsigned long long)seq[i + 1] << 32) | seq[i]) >> sh) | (sh ? (unsigned long long)seq[i + 2] << (64u - sh) : 0ull);
+#pragma unroll
+      for (uint32_t j = 0; j < 8u; ++j) {
+        if (32u * (uint32_t)wd + b0 + j < cnt && part_of((uint32_t)win & kmsk, lg) == part) bitsw |= 1u << (b0 + j);
+        win >>= 2;
+      }
     }
     r.m[wd] = bitsw;
   }
@@ -502,15 +509,14 @@ __device__ __forceinline__ MaskN<NW> lane_positions_of(const uint32_t *seq, uint
 
 // flat loops (see flat_find / flat_add) on a 32-bit table and a lane's position mask
 template <int NW>
-__device__ __forceinline__ MaskN<NW> flat_find32(const LTab32 &t, const uint32_t *seq, MaskN<NW> todo, uint32_t kmsk)
+__device__ __forceinline__ MaskN<NW> flat_find32(const LTab32 &t, const uint32_t *seq, uint32_t base, MaskN<NW> todo, uint32_t kmsk)
 {
-  const uint32_t tid = threadIdx.x;
   MaskN<NW> hits;
 #pragma unroll
   for (int w = 0; w < NW; ++w) hits.m[w] = 0u;
   bool active = todo.any();
   uint32_t q = active ? todo.first() : 0u;
-  uint32_t code = active ? LTab::bits(seq, tid + q * kSplitThreads, kmsk) : 0u;
+  uint32_t code = active ? LTab::bits(seq, base + q, kmsk) : 0u;
   uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0;
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
     if (active) {
@@ -524,7 +530,7 @@ __device__ __forceinline__ MaskN<NW> flat_find32(const LTab32 &t, const uint32_t
         todo.drop_first();
         active = todo.any();
         q = active ? todo.first() : 0u;
-        code = active ? LTab::bits(seq, tid + q * kSplitThreads, kmsk) : 0u;
+        code = active ? LTab::bits(seq, base + q, kmsk) : 0u;
         h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
       }
     }
@@ -533,11 +539,10 @@ __device__ __forceinline__ MaskN<NW> flat_find32(const LTab32 &t, const uint32_t
 }
 
 template <int NW>
-__device__ __forceinline__ void flat_add32(const LTab32 &t, MaskN<NW> todo, int *fill = nullptr, int limit = 0)
+__device__ __forceinline__ void flat_add32(const LTab32 &t, uint32_t base, MaskN<NW> todo, int *fill = nullptr, int limit = 0)
 {
-  const uint32_t tid = threadIdx.x;
   bool active = todo.any();
-  uint32_t p = active ? tid + todo.first() * kSplitThreads : 0u;
+  uint32_t p = active ? base + todo.first() : 0u;
   uint32_t code = active ? LTab::bits(t.seq, p, t.kmsk) : 0u;
   uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0, nturn = 0;
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
@@ -553,7 +558,7 @@ __device__ __forceinline__ void flat_add32(const LTab32 &t, MaskN<NW> todo, int 
       if (fin) {
         todo.drop_first();
         active = todo.any();
-        p = active ? tid + todo.first() * kSplitThreads : 0u;
+        p = active ? base + todo.first() : 0u;
         code = active ? LTab::bits(t.seq, p, t.kmsk) : 0u;
         h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
       }
@@ -596,6 +601,14 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
   pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2);
   const uint32_t npr = n_kmers(nr, k), np1 = n_kmers(n1, k), np2 = n_kmers(n2, k);
   for (uint32_t i = tid; i < 2 * ((npr + 63) / 64 + 1); i += kSplitThreads) bm[i] = 0u;
+  // a lane's share of a sequence's positions: a contiguous run (lane_positions_of)
+  auto share = [&](uint32_t np, uint32_t &base, uint32_t &cnt) {
+    const uint32_t per = (np + (uint32_t)kSplitThreads - 1u) / (uint32_t)kSplitThreads;
+    base = min((uint32_t)tid * per, np);
+    cnt = min(per, np - base);
+  };
+  uint32_t br, cr, b1, c1, b2, c2;
+  share(npr, br, cr); share(np1, b1, c1); share(np2, b2, c2);
   uint32_t lg = 0;
   while (max(max(npr, np1), np2) > (C::kPart << lg)) ++lg;
   const LTab32 tr{wr, C::kCapRef - 1, sr, kmsk}, t1{w1, C::kCapOther - 1, s1, kmsk}, t2{w2, C::kCapOther - 1, s2, kmsk};
@@ -606,22 +619,22 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
     if (tid == 0) flag[0] = 0;
     __syncthreads();
     SP_STAMP(0);
-    const MaskN<NW> mine_r = lane_positions_of<NW>(sr, npr, kmsk, part, lg);
-    flat_add32<NW>(tr, mine_r);
+    const MaskN<NW> mine_r = lane_positions_of<NW>(sr, br, cr, kmsk, part, lg);
+    flat_add32<NW>(tr, br, mine_r);
     __syncthreads();
     SP_STAMP(1);
-    flat_add32<NW>(t1, flat_find32<NW>(tr, s1, lane_positions_of<NW>(s1, np1, kmsk, part, lg), kmsk), flag, (int)C::kFill);
+    flat_add32<NW>(t1, b1, flat_find32<NW>(tr, s1, b1, lane_positions_of<NW>(s1, b1, c1, kmsk, part, lg), kmsk), flag, (int)C::kFill);
     __syncthreads();
     SP_STAMP(2);
     if (flag[0] > (int)C::kFill) return false;
     for (uint32_t i = tid; i < C::kCapOther; i += kSplitThreads) w2[i] = 0xFFFFFFFFu;   // nobody looks the reference's k-mers up any more
     __syncthreads();
-    flat_add32<NW>(t2, flat_find32<NW>(t1, s2, lane_positions_of<NW>(s2, np2, kmsk, part, lg), kmsk));   // no more distinct k-mers than the table before holds
+    flat_add32<NW>(t2, b2, flat_find32<NW>(t1, s2, b2, lane_positions_of<NW>(s2, b2, c2, kmsk, part, lg), kmsk));   // no more distinct k-mers than the table before holds
     __syncthreads();
     SP_STAMP(3);
     // candidates: the reference positions whose k-mer is unique in all three reads, with their partner positions
-    for (MaskN<NW> c = flat_find32<NW>(t2, sr, mine_r, kmsk); c.any(); c.drop_first()) {
-      const uint32_t p = (uint32_t)tid + c.first() * kSplitThreads;
+    for (MaskN<NW> c = flat_find32<NW>(t2, sr, br, mine_r, kmsk); c.any(); c.drop_first()) {
+      const uint32_t p = br + c.first();
       const uint32_t code = LTab::bits(sr, p, kmsk);
       const int b = t2.find(code), a = t1.find(code);               // (a k-mer only enters the third table when it is unique in the second)
       if (a >= 0 && b >= 0) { stg_global(g.ca + p, a); stg_global(g.cb + p, b); atomicOr(bm + (p >> 5), 1u << (p & 31u)); }
