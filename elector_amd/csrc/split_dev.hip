@@ -1560,36 +1560,63 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     first[(size_t)r + 1] = first[(size_t)r] + cap;
     maxwin = std::max(maxwin, cap);
   }
-  int64_t tab_cap = 64;
-  while (tab_cap < 2 * maxlen + 2) tab_cap <<= 1;
-  const int max_blocks = std::getenv("ELECTOR_SPLIT_BLOCKS") ? std::max(1, std::atoi(std::getenv("ELECTOR_SPLIT_BLOCKS"))) : 1024;
-  // per-block scratch (three hash tables of 64-bit slots, two candidate arrays) grows with the batch's LONGEST read: a
-  // single 300 kb read would ask for 25 GB at 1024 blocks.  The blocks are capped by a byte budget (a block loops over
-  // reads anyway), and a workspace that still cannot be had sends the batch to the host splitter (ELECTOR_E_LIMIT).
-  const int64_t per_block = 3 * tab_cap * 8 + 2 * (maxlen + 2) * 4 + 3 * maxwin * 8 * 4;
-  const int64_t budget = (int64_t)8 << 30;
-  int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n_in, max_blocks), std::max<int64_t>(64, budget / per_block)));
-  // A batch of mostly long reads (beyond the 12.5 kb of the small on-chip tables, within the 65,535 bases of the
-  // partitioned ones, tables_long): 148 KB of LDS per workgroup, one workgroup per CU, anchor arrays in HBM.
-  int64_t n_long = 0;
+  // The batch goes to the device in up to two launches.  Reads within the small on-chip tables (12.5 kb) take the
+  // kernel with the anchor arrays in LDS, two workgroups per CU; longer ones the kernel of the partitioned on-chip
+  // tables (tables_long: one workgroup per CU, 153 KB of LDS, anchor arrays in HBM), which also holds the HBM-table
+  // path for what is longer still.  A PacBio batch whose lengths straddle 12.5 kb thus keeps both kinds on chip.
+  // (ELECTOR_SPLIT_NO_LONG / ELECTOR_SPLIT_HBM_TABLES: one launch as before, HBM tables for the long reads.)
+  struct Launch {
+    std::vector<int32_t> reads;                 // longest first: the order the workgroups take them in
+    int64_t maxlen = 1, maxwin = 16, tab_cap = 64, maxanc = 8, per_block = 0;
+    int blocks = 0;
+    bool roomy = false, big = false;
+  };
+  Launch part[2];
+  const bool no_long = std::getenv("ELECTOR_SPLIT_HBM_TABLES") || std::getenv("ELECTOR_SPLIT_NO_LONG");
   for (int64_t r = 0; r < n_in; ++r) {
     const int64_t m = std::max(std::max(read_off[3 * r + 1] - read_off[3 * r], read_off[3 * r + 2] - read_off[3 * r + 1]),
                                read_off[3 * r + 3] - read_off[3 * r + 2]);
-    n_long += m > (int64_t)kLdsMaxN && m <= (int64_t)kLongMaxN;
+    Launch &L = part[!no_long && m > (int64_t)kLdsMaxN ? 1 : 0];
+    L.reads.push_back((int32_t)r);
+    L.maxlen = std::max(L.maxlen, m);
+    L.maxwin = std::max(L.maxwin, (read_off[3 * r + 1] - read_off[3 * r]) / 16 + 16);
   }
-  const bool use_long = !std::getenv("ELECTOR_SPLIT_HBM_TABLES") && !std::getenv("ELECTOR_SPLIT_NO_LONG") && 2 * n_long >= n_in && n_in > 0;
-  if (use_long) {
-    int dev_cus = 256;
-    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    blocks = std::min(blocks, std::max(1, dev_cus));
+  const int max_blocks = std::getenv("ELECTOR_SPLIT_BLOCKS") ? std::max(1, std::atoi(std::getenv("ELECTOR_SPLIT_BLOCKS"))) : 1024;
+  int dev_cus = 256;
+  (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+  // per-block scratch (three hash tables of 64-bit slots, two candidate arrays) grows with the launch's LONGEST read: a
+  // single 300 kb read would ask for 25 GB at 1024 blocks.  The blocks are capped by a byte budget (a block loops over
+  // reads anyway), and a workspace that still cannot be had sends the batch to the host splitter (ELECTOR_E_LIMIT).
+  const int64_t budget = (int64_t)8 << 30;
+  size_t need_keys = 0, need_ca = 0, need_wl = 0, need_anc = 0;
+  for (int k = 0; k < 2; ++k) {
+    Launch &L = part[k];
+    if (L.reads.empty()) continue;
+    std::sort(L.reads.begin(), L.reads.end(), [&](int32_t x, int32_t y) {
+      const int64_t lx = read_off[3 * (int64_t)x + 3] - read_off[3 * (int64_t)x], ly = read_off[3 * (int64_t)y + 3] - read_off[3 * (int64_t)y];
+      return lx != ly ? lx > ly : x < y;
+    });
+    while (L.tab_cap < 2 * L.maxlen + 2) L.tab_cap <<= 1;
+    // anchors are more than 20 bases apart on the reference (the re-split of a missing end can use less: it
+    // overflows into the host path, like a window list that does not fit)
+    L.maxanc = L.maxlen / 21 + 8;
+    L.roomy = k == 1;
+    L.big = L.roomy || L.maxanc > kMaxAnchors;
+    L.per_block = 3 * L.tab_cap * 8 + 2 * (L.maxlen + 2) * 4 + 3 * L.maxwin * 8 * 4;
+    L.blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)L.reads.size(), L.roomy ? std::max(1, dev_cus) : max_blocks),
+                                                             std::max<int64_t>(64, budget / L.per_block)));
+    need_keys = std::max(need_keys, (size_t)L.blocks * 3 * (size_t)L.tab_cap * 8);
+    need_ca = std::max(need_ca, (size_t)L.blocks * (size_t)(L.maxlen + 2) * 4);
+    need_wl = std::max(need_wl, (size_t)L.blocks * 3 * (size_t)L.maxwin * 8 * 4);
+    if (L.big) need_anc = std::max(need_anc, (size_t)L.blocks * 2 * 5 * (size_t)L.maxanc * 4 + 64);
   }
   hipStream_t st = c->stream;
   int rc = c->d_sp_reads.ensure((size_t)total + 64) | c->d_sp_off.ensure((size_t)(3 * n_in + 1) * 8 + 64) |
-           c->d_sp_hdr.ensure((size_t)n_in * 4 + 64) | c->d_sp_keys.ensure((size_t)blocks * 3 * tab_cap * 8) |
-           c->d_sp_ca.ensure((size_t)blocks * (maxlen + 2) * 4) |
-           c->d_sp_cb.ensure((size_t)blocks * (maxlen + 2) * 4) | c->d_sp_wl.ensure((size_t)blocks * 3 * maxwin * 8 * 4) |
+           c->d_sp_hdr.ensure((size_t)n_in * 4 + 64) | c->d_sp_keys.ensure(need_keys + 64) |
+           c->d_sp_ca.ensure(need_ca + 64) | c->d_sp_cb.ensure(need_ca + 64) | c->d_sp_wl.ensure(need_wl + 64) |
            c->d_sp_win.ensure((size_t)first[(size_t)n_in] * 8 * 4 + 64) | c->d_sp_first.ensure((size_t)(n_in + 1) * 8) |
-           c->d_sp_cnt.ensure((size_t)(n_in + 1) * 4 * 2 + 64) | c->d_sp_wfirst.ensure((size_t)(n_in + 2) * 8 * 2);
+           c->d_sp_cnt.ensure((size_t)(n_in + 1) * 4 * 2 + 64) | c->d_sp_wfirst.ensure((size_t)(n_in + 2) * 8 * 2) |
+           (need_anc ? c->d_sp_anc.ensure(need_anc) : 0);
   if (rc) return elector_fail(c, ELECTOR_E_LIMIT, "device splitter workspace does not fit device memory: the host splitter takes this batch");
   if (n_in == 0) return ELECTOR_OK;
   auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -1632,78 +1659,109 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   HIPCHK(c, hipMemcpyAsync(c->d_sp_hdr.p, hdr_len, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->d_sp_first.p, first.data(), (size_t)(n_in + 1) * 8, hipMemcpyHostToDevice, st));
   SplitArgs a;
-  a.n_reads = n_in;
   a.reads = c->d_sp_reads.as<uint8_t>(); a.read_off = c->d_sp_off.as<int64_t>(); a.hdr_len = c->d_sp_hdr.as<int32_t>();
   a.thr = size_threshold;
   a.ent = c->d_sp_keys.as<unsigned long long>();
   a.ca = c->d_sp_ca.as<int32_t>(); a.cb = c->d_sp_cb.as<int32_t>(); a.wl = c->d_sp_wl.as<int32_t>();
-  a.tab_cap = tab_cap; a.maxlen = maxlen; a.maxwin = maxwin;
   a.out_win = c->d_sp_win.as<int32_t>(); a.out_first = c->d_sp_first.as<int64_t>();
   a.out_cnt = c->d_sp_cnt.as<int32_t>(); a.out_kind = a.out_cnt + (n_in + 1);
-  // anchors are more than 20 bases apart on the reference (the re-split of a missing end can use less: it
-  // overflows into the host path, like a window list that does not fit)
-  const int64_t maxanc = maxlen / 21 + 8;
-  const bool big = maxanc > kMaxAnchors || use_long;
-  a.anc = nullptr; a.maxanc = maxanc;
   a.stamps = nullptr;
-  a.lds_tables = 0;
-  {
-    // the order the reads are taken in: by the cells of their tables, i.e. by length, longest first
-    std::vector<int32_t> order((size_t)n_in + 2, 0);
-    for (int64_t r = 0; r < n_in; ++r) order[(size_t)r + 2] = (int32_t)r;
-    std::sort(order.begin() + 2, order.end(), [&](int32_t x, int32_t y) {
-      const int64_t lx = read_off[3 * (int64_t)x + 3] - read_off[3 * (int64_t)x], ly = read_off[3 * (int64_t)y + 3] - read_off[3 * (int64_t)y];
-      return lx != ly ? lx > ly : x < y;
-    });
-    HIPCHK(c, hipMemcpyAsync(c->d_sp_wfirst.p, order.data(), ((size_t)n_in + 2) * 4, hipMemcpyHostToDevice, st));   // [counter, pad][order]
-    HIPCHK(c, hipStreamSynchronize(st));                               // (the vector goes out of scope)
-    a.next = c->d_sp_wfirst.as<int32_t>();
-    a.order = a.next + 2;
-  }
-  a.lds_long = use_long ? (std::getenv("ELECTOR_SPLIT_LONG") ? std::atoi(std::getenv("ELECTOR_SPLIT_LONG")) : 2) : 0;
   if (dbg) {
     if (c->d_sp_scan.ensure(4096)) return elector_fail(c, ELECTOR_E_NOMEM, "stamps");
     a.stamps = c->d_sp_scan.as<unsigned long long>();
     HIPCHK(c, hipMemsetAsync(a.stamps, 0, 256, st));
   }
-  if (big) {
-    if (c->d_sp_anc.ensure((size_t)blocks * 2 * 5 * maxanc * 4 + 64)) return elector_fail(c, ELECTOR_E_NOMEM, "device splitter anchors");
-    a.anc = c->d_sp_anc.as<int32_t>();
-    static DeviceOnce once_big;
-    if (use_long && once_big.need()) {
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 512));
-      once_big.done();
-    }
-    if (use_long) hipLaunchKernelGGL((k_split<true, true>), dim3((unsigned)blocks), dim3(kSplitThreads), kLongBytes, st, a);
-    else hipLaunchKernelGGL((k_split<true, false>), dim3((unsigned)blocks), dim3(kSplitThreads), (size_t)16, st, a);
-  } else {
-    // the anchor arrays in LDS, as many entries as the batch's longest read can need: the usual 8-20 kb reads leave
-    // room for four workgroups per CU, whose serial stretches (anchor selection, chain) then overlap
-    static DeviceOnce once;
-    if (once.need()) {
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024 - 512));
-      once.done();
-    }
-    // on-chip tables when most of the batch's reads are short enough for them and they fit beside the anchors
-    size_t lds = ((size_t)(2 * 5 * maxanc * 2) + 3) & ~(size_t)3;   // 16-bit anchor arrays
-    int64_t fit = 0;
-    for (int64_t r = 0; r < n_in; ++r) {
-      const int64_t m = std::max(std::max(read_off[3 * r + 1] - read_off[3 * r], read_off[3 * r + 2] - read_off[3 * r + 1]),
-                                 read_off[3 * r + 3] - read_off[3 * r + 2]);
-      fit += m <= (int64_t)kLdsMaxN;
-    }
-    a.lds_tables = !std::getenv("ELECTOR_SPLIT_HBM_TABLES") && 2 * fit >= n_in && lds + kLdsTabBytes <= (size_t)(160 * 1024 - 512);
-    if (a.lds_tables) lds += kLdsTabBytes;
-    hipLaunchKernelGGL(k_split<false>, dim3((unsigned)blocks), dim3(kSplitThreads), lds, st, a);
+  {
+    // the counters the workgroups draw their reads from, and the two launches' reads behind them
+    std::vector<int32_t> order((size_t)n_in + 4, 0);
+    std::copy(part[0].reads.begin(), part[0].reads.end(), order.begin() + 4);
+    std::copy(part[1].reads.begin(), part[1].reads.end(), order.begin() + 4 + (ptrdiff_t)part[0].reads.size());
+    HIPCHK(c, hipMemcpyAsync(c->d_sp_wfirst.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));                               // (the vector goes out of scope)
   }
-  HIPCHK(c, hipGetLastError());
+  auto launch = [&](const Launch &L, int k, int64_t order_at) -> int {
+    if (L.reads.empty()) return 0;
+    a.n_reads = (int64_t)L.reads.size();
+    a.next = c->d_sp_wfirst.as<int32_t>() + 2 * k;
+    a.order = c->d_sp_wfirst.as<int32_t>() + 4 + order_at;
+    a.tab_cap = L.tab_cap; a.maxlen = L.maxlen; a.maxwin = L.maxwin;
+    a.anc = nullptr; a.maxanc = L.maxanc;
+    a.lds_tables = 0;
+    a.lds_long = L.roomy ? (std::getenv("ELECTOR_SPLIT_LONG") ? std::atoi(std::getenv("ELECTOR_SPLIT_LONG")) : 2) : 0;
+    if (L.big) {
+      a.anc = c->d_sp_anc.as<int32_t>();
+      static DeviceOnce once_big;
+      if (L.roomy && once_big.need()) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 512));
+        once_big.done();
+      }
+      if (L.roomy) hipLaunchKernelGGL((k_split<true, true>), dim3((unsigned)L.blocks), dim3(kSplitThreads), kLongBytes, st, a);
+      else hipLaunchKernelGGL((k_split<true, false>), dim3((unsigned)L.blocks), dim3(kSplitThreads), (size_t)16, st, a);
+    } else {
+      // the anchor arrays in LDS, as many entries as the launch's longest read can need
+      static DeviceOnce once;
+      if (once.need()) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 512));
+        once.done();
+      }
+      // on-chip tables when most of the launch's reads are short enough for them and they fit beside the anchors
+      size_t lds = ((size_t)(2 * 5 * L.maxanc * 2) + 3) & ~(size_t)3;   // 16-bit anchor arrays
+      int64_t fit = 0;
+      for (const int32_t r : L.reads) {
+        const int64_t m = std::max(std::max(read_off[3 * (int64_t)r + 1] - read_off[3 * (int64_t)r], read_off[3 * (int64_t)r + 2] - read_off[3 * (int64_t)r + 1]),
+                                   read_off[3 * (int64_t)r + 3] - read_off[3 * (int64_t)r + 2]);
+        fit += m <= (int64_t)kLdsMaxN;
+      }
+      a.lds_tables = !std::getenv("ELECTOR_SPLIT_HBM_TABLES") && 2 * fit >= (int64_t)L.reads.size() && lds + kLdsTabBytes <= (size_t)(160 * 1024 - 512);
+      if (a.lds_tables) lds += kLdsTabBytes;
+      hipLaunchKernelGGL(k_split<false>, dim3((unsigned)L.blocks), dim3(kSplitThreads), lds, st, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  };
+  if ((rc = launch(part[1], 1, (int64_t)part[0].reads.size())) != 0) return rc;      // the long reads first
+  if ((rc = launch(part[0], 0, 0)) != 0) return rc;
   // kinds and counts to the host: the reads the device could not take are split by the host code
   std::vector<int32_t> cnt((size_t)n_in), kind((size_t)n_in);
-  HIPCHK(c, hipMemcpyAsync(cnt.data(), a.out_cnt, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(kind.data(), a.out_kind, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));
+  auto fetch_kinds = [&]() -> int {
+    HIPCHK(c, hipMemcpyAsync(cnt.data(), a.out_cnt, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(kind.data(), a.out_kind, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return 0;
+  };
+  if ((rc = fetch_kinds()) != 0) return rc;
+  {
+    // A read whose anchors did not fit the arrays sized for its launch (a re-split with a tiny minSize can take an
+    // anchor every other base) gets a second try with room for an anchor per base, in HBM -- before the whole batch
+    // is handed to the host splitter for its sake.
+    Launch again;
+    for (int64_t r = 0; r < n_in; ++r)
+      if (kind[(size_t)r] == -2) {
+        again.reads.push_back((int32_t)r);
+        for (int q = 0; q < 3; ++q) again.maxlen = std::max(again.maxlen, read_off[3 * r + q + 1] - read_off[3 * r + q]);
+        again.maxwin = std::max(again.maxwin, (read_off[3 * r + 1] - read_off[3 * r]) / 16 + 16);
+      }
+    if (!again.reads.empty() && !no_long && (int64_t)again.reads.size() <= 4096) {
+      while (again.tab_cap < 2 * again.maxlen + 2) again.tab_cap <<= 1;
+      again.maxanc = again.maxlen + 8;
+      again.roomy = again.big = true;
+      again.blocks = (int)std::min<int64_t>((int64_t)again.reads.size(), std::max(1, dev_cus));
+      if (c->d_sp_keys.ensure((size_t)again.blocks * 3 * (size_t)again.tab_cap * 8 + 64) | c->d_sp_ca.ensure((size_t)again.blocks * (size_t)(again.maxlen + 2) * 4 + 64) |
+          c->d_sp_cb.ensure((size_t)again.blocks * (size_t)(again.maxlen + 2) * 4 + 64) | c->d_sp_wl.ensure((size_t)again.blocks * 3 * (size_t)again.maxwin * 8 * 4 + 64) |
+          c->d_sp_anc.ensure((size_t)again.blocks * 2 * 5 * (size_t)again.maxanc * 4 + 64))
+        return elector_fail(c, ELECTOR_E_LIMIT, "device splitter workspace does not fit device memory: the host splitter takes this batch");
+      a.ent = c->d_sp_keys.as<unsigned long long>();
+      a.ca = c->d_sp_ca.as<int32_t>(); a.cb = c->d_sp_cb.as<int32_t>(); a.wl = c->d_sp_wl.as<int32_t>();
+      std::vector<int32_t> order(again.reads.size() + 4, 0);
+      std::copy(again.reads.begin(), again.reads.end(), order.begin() + 4);
+      HIPCHK(c, hipMemcpyAsync(c->d_sp_wfirst.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipStreamSynchronize(st));
+      if ((rc = launch(again, 0, 0)) != 0) return rc;
+      if ((rc = fetch_kinds()) != 0) return rc;
+    }
+  }
   const double t2 = now_ms();
   if (dbg) {
     unsigned long long hs[24];
@@ -1743,6 +1801,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   if (rc) { elector_windows_dev_free(out); return elector_fail(c, ELECTOR_E_NOMEM, "device splitter layout"); }
   int64_t *d_wfirst = c->d_sp_wfirst.as<int64_t>();
   HIPCHK(c, hipMemcpyAsync(d_wfirst, wfirst.data(), (size_t)(n_in + 1) * 8, hipMemcpyHostToDevice, st));
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(n_in, 1024));     // of the layout kernels (a block per read, in turn)
   LayoutArgs la;
   la.n_reads = n_in; la.reads = a.reads; la.read_off = a.read_off; la.out_win = a.out_win; la.out_first = a.out_first;
   la.out_cnt = a.out_cnt; la.out_kind = a.out_kind; la.win_first = d_wfirst;
