@@ -122,3 +122,20 @@ def test_long_read_tables(engine):
         r = synth.random_seq(rng, n)
         reads.append((r, synth.mutate(rng, r, 0.01), synth.mutate(rng, r, 0.15)))
     same(engine, reads)
+
+
+def test_dense_resplit_gets_a_second_try(engine):
+    """A corrected read that only covers the END of a 12 kb reference, an accurate uncorrected read: the re-split
+    of the missing start runs with a minSize of about a dozen bases and takes an anchor every dozen bases -- more
+    than the anchor arrays sized for the launch (one per 21 bases) hold.  The read is split again with room for an
+    anchor per base; the batch still comes back from the device, identical to the host splitter's."""
+    rng = np.random.default_rng(31)
+    reads = []
+    for n, a, b in ((12000, 11000, 11900), (12400, 200, 1100), (9000, 8000, 8990)):
+        r = synth.random_seq(rng, n)
+        reads.append((r, synth.mutate(rng, r, 0.004)[a:b], synth.mutate(rng, r, 0.01)))
+    for _ in range(20):
+        r = synth.random_seq(rng, int(rng.integers(3000, 9000)))
+        reads.append((r, synth.mutate(rng, r, 0.01), synth.mutate(rng, r, 0.12)))
+    same(engine, reads)
+    assert isinstance(split.split_reads_device(engine, reads, 0.1, None).d_bases, split.DevBases)
