@@ -647,6 +647,34 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
   return true;
 }
 
+// every k-mer of t's own sequence into t by SOME of the workgroup's threads (thread `me` of `stride`): flat_add for
+// the wavefronts that prepare the next pass's reference table while wavefront 0 works on the chain
+__device__ __forceinline__ void flat_add_by(const LTab &t, uint32_t np, uint32_t me, uint32_t stride)
+{
+  bool active = me < np;
+  uint32_t p = me;
+  uint32_t code = active ? LTab::bits(t.seq, p, t.kmsk) : 0u;
+  uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0;
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    if (active) {
+      uint32_t *word = t.w + (h >> 1);
+      const uint32_t sh = (h & 1u) * 16u;
+      const uint32_t old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t cur = (old >> sh) & 0xFFFFu;
+      bool fin = false;
+      if (cur == 0xFFFFu) fin = atomicCAS(word, old, (old & ~(0xFFFFu << sh)) | (p << sh)) == old;   // lost the race: look at the slot again
+      else if (LTab::bits(t.seq, cur & 0x7FFFu, t.kmsk) == code) { if (!(cur & 0x8000u)) atomicOr(word, 0x8000u << sh); fin = true; }
+      else { h = (h + step) & t.mask; fin = ++probes > t.mask; }
+      if (fin) {
+        p += stride;
+        active = p < np;
+        code = active ? LTab::bits(t.seq, p, t.kmsk) : 0u;
+        h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
+      }
+    }
+  }
+}
+
 // the three table phases and the candidate arrays of split_core on the LDS tables; false (uniform) when a table
 // filled up: nothing has been written to ca / cb then and the HBM tables take the call
 __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, const uint8_t *pr, uint32_t nr,
@@ -689,7 +717,12 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
 #pragma unroll
   for (int i = 0; i < 9; ++i) packed = packed && key[i] == want[i];
   packed = __builtin_amdgcn_readfirstlane((int)packed) != 0;
-  if (packed) {
+  // ... and when the pass before ran on the same sequences, the wavefronts that had nothing to do during its chain
+  // phase have already cleared the tables, fitted the first words to this k and entered the reference's k-mers
+  // (split_core): flag[1] says for which k
+  const bool prepared = packed && __builtin_amdgcn_readfirstlane(flag[1]) == k;
+  if (prepared) {
+  } else if (packed) {
     if (tid < 3) {
       const uint8_t *s = tid == 0 ? pr : tid == 1 ? p1 : p2;
       const uint32_t n = tid == 0 ? nr : tid == 1 ? n1 : n2;
@@ -700,10 +733,13 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
       dst[0] = v;
     }
   } else { pack(pr, nr, sr); pack(p1, n1, s1); pack(p2, n2, s2); }
-  for (uint32_t i = tid; i < kLdsBitWords; i += kSplitThreads) bm[i] = 0u;
-  for (uint32_t i = tid; i < (kLdsCapRef + kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+  if (!prepared) {
+    for (uint32_t i = tid; i < kLdsBitWords; i += kSplitThreads) bm[i] = 0u;
+    for (uint32_t i = tid; i < (kLdsCapRef + kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+  }
   if (tid == 0) flag[0] = 0;
   __syncthreads();
+  if (tid == 0) flag[1] = 0;                                 // (whatever was prepared is used up, or was not for this pass)
   if (!packed && tid == 0) {                                 // (read by the next pass, barriers away)
 #pragma unroll
     for (int i = 0; i < 9; ++i) key[i] = want[i];
@@ -712,7 +748,7 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   const LTab tr{wr, kLdsCapRef - 1, sr, kmsk}, t1{w1, kLdsCapOther - 1, s1, kmsk}, t2{w2, kLdsCapOther - 1, s2, kmsk};
   const uint32_t npr = n_kmers(nr, k), np1 = n_kmers(n1, k), np2 = n_kmers(n2, k);
   const uint32_t all_r = lane_positions(npr), all_1 = lane_positions(np1), all_2 = lane_positions(np2);
-  flat_add(tr, all_r);
+  if (!prepared) flat_add(tr, all_r);
   __syncthreads();
   SP_STAMP(1);
   flat_add(t1, flat_find(tr, s1, all_1, kmsk, g.stamps ? g.stamps + 13 : nullptr), flag, (int)kLdsFill);
@@ -919,7 +955,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // ROOMY: the copy of this function that the kernel of long batches calls (one workgroup per CU there: twice the
 // registers, and the long reads' on-chip tables)
 template <bool ROOMY, class LV>
-__device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize)
+__device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize, int next_k = 0)
 {
   // This function is not inlined (three call sites, a long body): behind the references its arguments live in the
   // caller's scratch memory, and every use of a member after a store the compiler cannot tell apart from it is a
@@ -930,7 +966,7 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
   const WG g = uniform(g_in);
   const LV L = uniform(L_in);
   ref = uniform(ref); S1 = uniform(S1); S2 = uniform(S2);
-  k = uniform(k); minSize = uniform(minSize);
+  k = uniform(k); minSize = uniform(minSize); next_k = uniform(next_k);
   const uint8_t *pr = g.reads + ref.base, *p1 = g.reads + S1.base, *p2 = g.reads + S2.base;
   const int tid = threadIdx.x;
   // table sizes: power of two >= 2 n + 2 (splitter.cpp), within the scratch
@@ -1093,6 +1129,34 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
   // longest chain, back to front (:79-126): wavefront 0
   const int n = uniform(L.s->n);
   if (g.stamps && tid == 0) atomicAdd(g.stamps + 14, (unsigned long long)n);
+  // The chain is one wavefront's work, a third of the pass, and the tables are dead by now.  When the caller knows
+  // that the same three sequences come again with a smaller k (best_split's next round), the other wavefronts use
+  // the time: tables and bitmap cleared, the first words of the packed sequences fitted to that k (by all, before
+  // the chain starts), then the reference's k-mers entered -- the next pass (tables_lds) finds that done.  Should a
+  // re-split come in between, or best_split stop, the work was for nothing and nobody relies on it.
+  if (on_chip && next_k > 0) {
+    extern __shared__ int32_t dyn_lds_[];
+    uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + g.lds_tab;
+    uint32_t *wr = lds, *sr = wr + (kLdsCapRef + kLdsCapOther) / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
+    uint32_t *bm = s2 + kLdsSeqWords;
+    int *flag = reinterpret_cast<int *>(bm + kLdsBitWords);
+    for (uint32_t i = tid; i < kLdsBitWords; i += kSplitThreads) bm[i] = 0u;
+    for (uint32_t i = tid; i < (kLdsCapRef + kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+    if (tid < 3) {
+      const uint8_t *sq = tid == 0 ? pr : tid == 1 ? p1 : p2;
+      const uint32_t nn = tid == 0 ? ref.n : tid == 1 ? S1.n : S2.n;
+      uint32_t v = 0;
+      for (uint32_t i = 0; i < 16; ++i)
+        if (i < nn) v |= (i < (uint32_t)next_k ? map1(sq[i]) : map2(sq[i])) << (2 * i);
+      (tid == 0 ? sr : tid == 1 ? s1 : s2)[0] = v;
+    }
+    __syncthreads();
+    if (tid >= 64) {
+      const uint32_t kmsk_n = (1u << (2 * next_k)) - 1u;
+      flat_add_by(LTab{wr, kLdsCapRef - 1, sr, kmsk_n}, n_kmers(ref.n, next_k), (uint32_t)tid - 64u, (uint32_t)kSplitThreads - 64u);
+      if (tid == 64) flag[1] = next_k;
+    }
+  }
   if (tid < 64 && n > 0) {
     // The successors an anchor can chain to lie within 1000 reference bases: at most 48 anchors, which the
     // wavefront keeps in registers -- lane l holds anchor i + 1 + l (positions and chain length), shifted by one
@@ -1221,11 +1285,11 @@ __device__ __forceinline__ DSeq dsub(DSeq s, uint32_t pos) { return dsub(s, pos,
 // the window list `out` (in HBM) is built by wavefront 0; returns its length through sh[0] (LDS).
 template <bool ROOMY, class LV>
 __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DSeq S1, DSeq S2, int k, int32_t *out, int32_t *tmp,
-                           int *sh /* LDS ints: [0] n out, [1] overflow, [2..] scratch */)
+                           int *sh /* LDS ints: [0] n out, [1] overflow, [2..] scratch */, int next_k = 0 /* the k of best_split's next round, if any */)
 {
   (void)tmp;
   const int tid = threadIdx.x;
-  split_core<ROOMY>(g, L0, ref, S1, S2, k, 20u);
+  split_core<ROOMY>(g, L0, ref, S1, S2, k, 20u, next_k);
   unsigned long long sp_t_ = g.stamps ? __builtin_readcyclecounter() : 0;
   const int64_t cap = g.maxwin;
   // the list's length and overflow flag: the same in all lanes of wavefront 0, which is the only one that uses them
@@ -1440,7 +1504,7 @@ __global__ void __launch_bounds__(kSplitThreads, (ROOMY ? kSplitThreads / 256 : 
     __syncthreads();
     if (tid == 0) {
       L0.s->fail = 0; L1.s->fail = 0;
-      if (g.lds_tab >= 0) s_anc[g.lds_tab + (int)kLdsKeyWord + 2] = 0;        // no sequence is packed yet (tables_lds: a length of 0 matches none)
+      if (g.lds_tab >= 0) { s_anc[g.lds_tab + (int)kLdsKeyWord + 2] = 0; s_anc[g.lds_tab + (int)kLdsKeyWord - 1] = 0; }   // no sequence is packed yet (tables_lds: a length of 0 matches none), nothing prepared
     }
     __syncthreads();
     if (ref.n <= 2) kind = -1;                                                   // :414
@@ -1448,7 +1512,7 @@ __global__ void __launch_bounds__(kSplitThreads, (ROOMY ? kSplitThreads / 256 : 
       // best_split (:310-332): k = 15, then smaller k while the largest fragment shrinks
       int32_t *best = g.wl, *aux = g.wl + a.maxwin * 8, *tmp = g.wl + 2 * a.maxwin * 8;
       int kk = 15;
-      split_read<ROOMY>(g, L0, L1, ref, S1, S2, kk, best, tmp, sh);
+      split_read<ROOMY>(g, L0, L1, ref, S1, S2, kk, best, tmp, sh, kk - 2);
       int nbest = sh[0];
       bool over = sh[1] != 0;
       uint32_t largest = largest_fragment(best, nbest, (uint32_t)a.hdr_len[r], &sh[2]);
@@ -1456,7 +1520,7 @@ __global__ void __launch_bounds__(kSplitThreads, (ROOMY ? kSplitThreads / 256 : 
         kk -= 2;
         if (kk < 9 || over) break;
         __syncthreads();
-        split_read<ROOMY>(g, L0, L1, ref, S1, S2, kk, aux, tmp, sh);
+        split_read<ROOMY>(g, L0, L1, ref, S1, S2, kk, aux, tmp, sh, kk - 2 >= 9 ? kk - 2 : 0);
         const int naux = sh[0];
         over = over || sh[1] != 0;
         const uint32_t la = largest_fragment(aux, naux, (uint32_t)a.hdr_len[r], &sh[3]);
