@@ -241,9 +241,9 @@ constexpr uint32_t kLdsSeqWords = kLdsMaxN / 16 + 3;
 constexpr uint32_t kLdsBitWords = 2 * ((kLdsMaxN + 63) / 64 + 1);       // candidate bitmap: one bit per reference position, as dwords
 constexpr uint32_t kLdsAncTab = 6 * (kLdsBitWords / 2);                   // per bitmap word: the anchor walk's exit table (anchors_lds), six dwords,
 static_assert(kLdsCapOther * 2 + kLdsAncTab * 4 <= kLdsCapRef * 2, "the third table and the exit tables overlay the reference's k-mer table");   // which is dead by then
-constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4 + 8 + 40;   // + the fill counter, a spare word and the key of the packed sequences
+constexpr size_t kLdsTabBytes = (size_t)(kLdsCapRef + kLdsCapOther) * 2 + 3 * (size_t)kLdsSeqWords * 4 + (size_t)kLdsBitWords * 4 + 16 + 40;   // + four words (fill counter, what is prepared for which k, a barrier count, how far) and the key of the packed sequences
 
-constexpr uint32_t kLdsKeyWord = (kLdsCapRef + kLdsCapOther) / 2 + 3 * kLdsSeqWords + kLdsBitWords + 2;   // dwords from the tables' start
+constexpr uint32_t kLdsKeyWord = (kLdsCapRef + kLdsCapOther) / 2 + 3 * kLdsSeqWords + kLdsBitWords + 4;   // dwords from the tables' start
 
 struct LTab {
   uint32_t *w;            // slots, two per word
@@ -311,26 +311,28 @@ struct LTab {
 // (a probe loop of its own, with a CAS) was paid by the whole wavefront in nearly every turn.
 // A lane's k-mers are those at positions tid + q * kSplitThreads; which of them a loop handles is a mask over q.
 static_assert(kLdsMaxN <= 32u * (uint32_t)kSplitThreads, "a lane's positions as one 32-bit mask");
-__device__ __forceinline__ uint32_t lane_positions(uint32_t np)
+// (me, stride: the thread's number among the threads that share the work and how many they are -- the whole
+// workgroup, or the seven wavefronts that prepare the next pass during the chain phase)
+__device__ __forceinline__ uint32_t lane_positions(uint32_t np, uint32_t me, uint32_t stride)
 {
-  const uint32_t tid = threadIdx.x;
-  if (tid >= np) return 0u;
-  const uint32_t nq = (np - tid + (uint32_t)kSplitThreads - 1u) / (uint32_t)kSplitThreads;
+  if (me >= np) return 0u;
+  const uint32_t nq = (np - me + stride - 1u) / stride;
   return nq >= 32u ? 0xFFFFFFFFu : (1u << nq) - 1u;
 }
+__device__ __forceinline__ uint32_t lane_positions(uint32_t np) { return lane_positions(np, threadIdx.x, (uint32_t)kSplitThreads); }
 
 // the lane's k-mers of seq named by todo that occur exactly once in t -> mask of the same kind
-__device__ __forceinline__ uint32_t flat_find(const LTab &t, const uint32_t *seq, uint32_t todo, uint32_t kmsk, unsigned long long *turns = nullptr)
+__device__ __forceinline__ uint32_t flat_find(const LTab &t, const uint32_t *seq, uint32_t todo, uint32_t kmsk, unsigned long long *turns = nullptr,
+                                             uint32_t tid = threadIdx.x, uint32_t stride = (uint32_t)kSplitThreads)
 {
-  const uint32_t tid = threadIdx.x;
   uint32_t hits = 0, nturn = 0;
   bool active = todo != 0u;
   uint32_t q = active ? (uint32_t)__builtin_ctz(todo) : 0u;
-  uint32_t code = active ? LTab::bits(seq, tid + q * kSplitThreads, kmsk) : 0u;
+  uint32_t code = active ? LTab::bits(seq, tid + q * stride, kmsk) : 0u;
   // the code of the lane's next k-mer is fetched a look-up ahead: its LDS read is not on the path of the turn that
   // ends a look-up
   uint32_t rest = todo & (todo - 1u);
-  uint32_t code_next = rest ? LTab::bits(seq, tid + (uint32_t)__builtin_ctz(rest) * kSplitThreads, kmsk) : 0u;
+  uint32_t code_next = rest ? LTab::bits(seq, tid + (uint32_t)__builtin_ctz(rest) * stride, kmsk) : 0u;
   uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0;
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
     ++nturn;
@@ -348,7 +350,7 @@ __device__ __forceinline__ uint32_t flat_find(const LTab &t, const uint32_t *seq
         code = code_next;
         h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
         rest = todo & (todo - 1u);
-        code_next = rest ? LTab::bits(seq, tid + (uint32_t)__builtin_ctz(rest) * kSplitThreads, kmsk) : 0u;
+        code_next = rest ? LTab::bits(seq, tid + (uint32_t)__builtin_ctz(rest) * stride, kmsk) : 0u;
       }
     }
   }
@@ -359,14 +361,14 @@ __device__ __forceinline__ uint32_t flat_find(const LTab &t, const uint32_t *seq
 // the lane's k-mers of t's own sequence named by todo into t (LTab::add as a flat loop).  fill (LDS) counts the new
 // entries when given; once it passes limit every lane stops (the caller then gives the tables up), looked at every
 // eighth turn -- at most a few hundred entries late, and a table that has filled up meanwhile only costs those turns.
-__device__ __forceinline__ void flat_add(const LTab &t, uint32_t todo, int *fill = nullptr, int limit = 0)
+__device__ __forceinline__ void flat_add(const LTab &t, uint32_t todo, int *fill = nullptr, int limit = 0, uint32_t tid = threadIdx.x,
+                                         uint32_t stride = (uint32_t)kSplitThreads)
 {
-  const uint32_t tid = threadIdx.x;
   bool active = todo != 0u;
-  uint32_t p = active ? tid + (uint32_t)__builtin_ctz(todo) * kSplitThreads : 0u;
+  uint32_t p = active ? tid + (uint32_t)__builtin_ctz(todo) * stride : 0u;
   uint32_t code = active ? LTab::bits(t.seq, p, t.kmsk) : 0u;
   uint32_t rest = todo & (todo - 1u);
-  uint32_t code_next = rest ? LTab::bits(t.seq, tid + (uint32_t)__builtin_ctz(rest) * kSplitThreads, t.kmsk) : 0u;
+  uint32_t code_next = rest ? LTab::bits(t.seq, tid + (uint32_t)__builtin_ctz(rest) * stride, t.kmsk) : 0u;
   uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0, nturn = 0;
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
     if (active) {
@@ -383,11 +385,11 @@ __device__ __forceinline__ void flat_add(const LTab &t, uint32_t todo, int *fill
       if (fin) {
         todo = rest;
         active = todo != 0u;
-        p = active ? tid + (uint32_t)__builtin_ctz(todo) * kSplitThreads : 0u;
+        p = active ? tid + (uint32_t)__builtin_ctz(todo) * stride : 0u;
         code = code_next;
         h = LTab::slot_of(code, t.mask); step = LTab::step_of(code); probes = 0;
         rest = todo & (todo - 1u);
-        code_next = rest ? LTab::bits(t.seq, tid + (uint32_t)__builtin_ctz(rest) * kSplitThreads, t.kmsk) : 0u;
+        code_next = rest ? LTab::bits(t.seq, tid + (uint32_t)__builtin_ctz(rest) * stride, t.kmsk) : 0u;
       }
     }
     if (fill && (++nturn & 7u) == 0u && __builtin_amdgcn_readfirstlane(*(volatile int *)fill) > limit) break;
@@ -720,7 +722,8 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   // ... and when the pass before ran on the same sequences, the wavefronts that had nothing to do during its chain
   // phase have already cleared the tables, fitted the first words to this k and entered the reference's k-mers
   // (split_core): flag[1] says for which k
-  const bool prepared = packed && __builtin_amdgcn_readfirstlane(flag[1]) == k;
+  const bool prepared = packed && __builtin_amdgcn_readfirstlane(flag[1]) == k && __builtin_amdgcn_readfirstlane(flag[3]) >= 1;
+  const bool prepared2 = prepared && __builtin_amdgcn_readfirstlane(flag[3]) >= 2;      // ... and the second table built from the uncorrected read's
   if (prepared) {
   } else if (packed) {
     if (tid < 3) {
@@ -739,7 +742,7 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   }
   if (tid == 0) flag[0] = 0;
   __syncthreads();
-  if (tid == 0) flag[1] = 0;                                 // (whatever was prepared is used up, or was not for this pass)
+  if (tid == 0) { flag[1] = 0; flag[3] = 0; }                // (whatever was prepared is used up, or was not for this pass)
   if (!packed && tid == 0) {                                 // (read by the next pass, barriers away)
 #pragma unroll
     for (int i = 0; i < 9; ++i) key[i] = want[i];
@@ -751,7 +754,7 @@ __device__ bool tables_lds(const WG &g, unsigned long long &sp_t_, int lds_off, 
   if (!prepared) flat_add(tr, all_r);
   __syncthreads();
   SP_STAMP(1);
-  flat_add(t1, flat_find(tr, s1, all_1, kmsk, g.stamps ? g.stamps + 13 : nullptr), flag, (int)kLdsFill);
+  if (!prepared2) flat_add(t1, flat_find(tr, s1, all_1, kmsk, g.stamps ? g.stamps + 13 : nullptr), flag, (int)kLdsFill);
   __syncthreads();
   SP_STAMP(2);
   if (flag[0] > (int)kLdsFill) return false;
@@ -1134,7 +1137,10 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
   // the time: tables and bitmap cleared, the first words of the packed sequences fitted to that k (by all, before
   // the chain starts), then the reference's k-mers entered -- the next pass (tables_lds) finds that done.  Should a
   // re-split come in between, or best_split stop, the work was for nothing and nobody relies on it.
-  if (on_chip && next_k > 0) {
+  // (Worth it when the chain is long enough to hide the work: some 430 cycles per anchor against 35 k cycles for the
+  // reference's table and 60 k more for the second.)
+  const int kPrepOne = 60, kPrepTwo = 140;
+  if (on_chip && next_k > 0 && n >= kPrepOne) {
     extern __shared__ int32_t dyn_lds_[];
     uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + g.lds_tab;
     uint32_t *wr = lds, *sr = wr + (kLdsCapRef + kLdsCapOther) / 2, *s1 = sr + kLdsSeqWords, *s2 = s1 + kLdsSeqWords;
@@ -1142,6 +1148,7 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
     int *flag = reinterpret_cast<int *>(bm + kLdsBitWords);
     for (uint32_t i = tid; i < kLdsBitWords; i += kSplitThreads) bm[i] = 0u;
     for (uint32_t i = tid; i < (kLdsCapRef + kLdsCapOther) / 2; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+    if (tid == 0) { flag[2] = 0; flag[3] = 0; }
     if (tid < 3) {
       const uint8_t *sq = tid == 0 ? pr : tid == 1 ? p1 : p2;
       const uint32_t nn = tid == 0 ? ref.n : tid == 1 ? S1.n : S2.n;
@@ -1152,9 +1159,33 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
     }
     __syncthreads();
     if (tid >= 64) {
-      const uint32_t kmsk_n = (1u << (2 * next_k)) - 1u;
-      flat_add_by(LTab{wr, kLdsCapRef - 1, sr, kmsk_n}, n_kmers(ref.n, next_k), (uint32_t)tid - 64u, (uint32_t)kSplitThreads - 64u);
-      if (tid == 64) flag[1] = next_k;
+      const uint32_t kmsk_n = (1u << (2 * next_k)) - 1u, me = (uint32_t)tid - 64u, others = (uint32_t)kSplitThreads - 64u;
+      const LTab trn{wr, kLdsCapRef - 1, sr, kmsk_n}, t1n{wr + kLdsCapRef / 2, kLdsCapOther - 1, s1, kmsk_n};
+      flat_add_by(trn, n_kmers(ref.n, next_k), me, others);
+      if (tid == 64) { flag[1] = next_k; flag[3] = 1; }
+      if (n >= kPrepTwo) {
+      // ... and, the chain being as long as it is, the second table too.  Its look-ups need the reference's table
+      // complete: the seven wavefronts meet at a counter in LDS (they are all resident: they can wait for each other
+      // without the eighth).
+      __threadfence_block();
+      if ((tid & 63) == 0) atomicAdd(&flag[2], 1);
+      while (__hip_atomic_load(&flag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (kSplitThreads - 64) / 64) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      if (tid == 64) flag[0] = 0;                            // (nobody counts before the second meeting)
+      const uint32_t mine = lane_positions(n_kmers(S1.n, next_k), me, others);
+      const uint32_t hits = flat_find(trn, s1, mine, kmsk_n, nullptr, me, others);
+      __threadfence_block();
+      if ((tid & 63) == 0) atomicAdd(&flag[2], 1);
+      while (__hip_atomic_load(&flag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * ((kSplitThreads - 64) / 64)) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      flat_add(t1n, hits, flag, (int)kLdsFill, me, others);
+      __threadfence_block();
+      if ((tid & 63) == 0) atomicAdd(&flag[2], 1);
+      while (__hip_atomic_load(&flag[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 3 * ((kSplitThreads - 64) / 64)) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      // (a second table that filled up is left half built: the next pass then starts from scratch)
+      if (tid == 64) flag[3] = __hip_atomic_load(&flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= (int)kLdsFill ? 2 : -1;
+      }
     }
   }
   if (tid < 64 && n > 0) {
@@ -1504,7 +1535,7 @@ __global__ void __launch_bounds__(kSplitThreads, (ROOMY ? kSplitThreads / 256 : 
     __syncthreads();
     if (tid == 0) {
       L0.s->fail = 0; L1.s->fail = 0;
-      if (g.lds_tab >= 0) { s_anc[g.lds_tab + (int)kLdsKeyWord + 2] = 0; s_anc[g.lds_tab + (int)kLdsKeyWord - 1] = 0; }   // no sequence is packed yet (tables_lds: a length of 0 matches none), nothing prepared
+      if (g.lds_tab >= 0) { s_anc[g.lds_tab + (int)kLdsKeyWord + 2] = 0; s_anc[g.lds_tab + (int)kLdsKeyWord - 3] = 0; }   // no sequence is packed yet (tables_lds: a length of 0 matches none), nothing prepared
     }
     __syncthreads();
     if (ref.n <= 2) kind = -1;                                                   // :414
