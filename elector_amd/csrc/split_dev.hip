@@ -494,6 +494,7 @@ __device__ __forceinline__ MaskN<NW> lane_positions_of(const uint32_t *seq, uint
 #pragma unroll
   for (int wd = 0; wd < NW; ++wd) {
     uint32_t bitsw = 0;
+#pragma nounroll
     for (uint32_t b0 = 0; b0 < 32u && 32u * (uint32_t)wd + b0 < cnt; b0 += 8u) {
       const uint32_t p0 = base + 32u * (uint32_t)wd + b0, bit = 2u * p0, i = bit >> 5, sh = bit & 31u;
       // 46 bits from position p0 on: eight positions of up to 30 bits each, two bits apart
