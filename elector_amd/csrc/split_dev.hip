@@ -4,17 +4,22 @@
 // read loop), restated for one workgroup per read:
 //   * 2-bit k-mer codes of every position, with the reference's two letter maps (str2num for the first k
 //     letters, :26-38; the rolling update for the rest, :41-49);
-//   * three hash tables in HBM scratch (k-mers unique in the reference read; of those, unique in the
-//     uncorrected read; of those, unique in the corrected read), filled by all threads with atomics -- "unique"
-//     does not depend on insertion order;
-//   * anchors: the greedy "more than minSize after the last one" pass over the reference positions, by one
-//     wavefront on ballots of 64 positions; the longest chain with steps < 1000 in all three reads (:79-126) as
-//     a back-to-front DP in LDS, one wavefront, the inner maximum over the <= 64 reachable successors in
-//     parallel; windows from the chain by one lane, with the reference's re-split of a missing start / end of
-//     the corrected read (:268-277,295-301) as a second, workgroup-wide pass;
-//   * best_split's loop over k = 15, 13, 11, 9 while the largest fragment shrinks (:310-332).
-// A read that does not fit the on-chip arrays (more than kMaxAnchors anchors, window list overflow) is
-// flagged and split by the host code (splitter.cpp) instead: same result, never silently different.
+//   * three hash tables (k-mers unique in the reference read; of those, unique in the uncorrected read; of those,
+//     unique in the corrected read) -- "unique" does not depend on insertion order.  Reads of up to 12.5 kb: 16-bit
+//     slots in LDS, checked against a 2-bit packed copy of the sequences (tables_lds); reads of up to 123 kb: 32-bit
+//     slots in LDS, one partition of the k-mer space at a time (tables_long); longer ones: 64-bit slots in HBM;
+//     every table phase a FLAT loop (one probe per lane and turn, look-ups and insertions in separate loops);
+//   * anchors: the greedy "more than minSize after the last one" pass over the candidate bitmap as per-word exit
+//     tables chained by fixed-point rounds (anchors_bitmap); the longest chain with steps < 1000 in all three reads
+//     (:79-126) back to front by one wavefront, every finished anchor offering itself to the waiting ones; while
+//     that wavefront works, the others prepare best_split's next round; windows from the chain by hopping along
+//     per-anchor links, with the reference's re-split of a missing start / end of the corrected read
+//     (:268-277,295-301) as a second, workgroup-wide pass;
+//   * best_split's loop over k = 15, 13, 11, 9 while the largest fragment shrinks (:310-332);
+//   * the reads of a batch drawn from a counter, longest first, in up to two launches (short reads / long reads).
+// A read whose anchors or windows do not fit the arrays sized for its launch gets a second try with an anchor per
+// base; one that still does not fit is flagged and the batch split by the host code (splitter.cpp) instead: same
+// result, never silently different.
 // Byte / integer work, latency-bound; no MFMA.  The unsigned-conversion quirks of the reference that decide
 // which windows come out are kept (marked "ref:").
 #include <hip/hip_runtime.h>
