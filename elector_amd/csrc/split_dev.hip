@@ -44,6 +44,7 @@ namespace elector {
 #define ELECTOR_SPLIT_THREADS 512
 #endif
 constexpr int kSplitThreads = ELECTOR_SPLIT_THREADS;
+static_assert(kSplitThreads >= 128 && kSplitThreads % 64 == 0, "wavefront 0 and at least one more (split_core: the next round's preparation)");
 constexpr int kMaxAnchors = 3000;          // LDS: 5 ints per anchor
 
 struct DSeq { int64_t base; uint32_t n; };   // base: byte offset into the reads buffer
