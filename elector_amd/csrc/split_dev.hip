@@ -426,10 +426,13 @@ struct LongCfg {
   static_assert(6 * (kBitWords / 2) <= CAPREF_ + CAPOTHER_, "the exit tables of the anchor walk overlay the dead tables");
   static_assert(kDwords * 4 <= 160 * 1024 - 1024, "one workgroup's LDS");
 };
+using LongS = LongCfg<2, 32767u, 8192u, 4096u, 3600u, 3000u>;    // reads of up to 32,767 bases: 78 KB, two workgroups per CU
 using LongA = LongCfg<4, 65535u, 16384u, 8192u, 7200u, 6000u>;
 using LongB = LongCfg<8, 122879u, 8192u, 4096u, 3600u, 3000u>;
 constexpr uint32_t kLongMaxN = LongB::kMaxN;
 constexpr size_t kLongBytes = (size_t)(LongA::kDwords > LongB::kDwords ? LongA::kDwords : LongB::kDwords) * 4;
+constexpr size_t kLongSBytes = (size_t)LongS::kDwords * 4;
+static_assert(2 * (kLongSBytes + 128) <= 160 * 1024, "two workgroups of the medium class per CU");
 
 template <int NW>
 struct MaskN {
@@ -962,9 +965,9 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 
 // tables, anchors and the best chain of one split() call (ref: split :175-255, best_chain :79-126).
 // Workgroup-wide.  On return L.s->n anchors, L.s->nchain chain entries (indices of the chain in L.cl[0 .. nchain), reused).
-// ROOMY: the copy of this function that the kernel of long batches calls (one workgroup per CU there: twice the
-// registers, and the long reads' on-chip tables)
-template <bool ROOMY, class LV>
+// LONG: which kernel's copy of this function -- 0: no partitioned tables; 1: the kernel of the medium reads (up to
+// 32,767 bases, two workgroups per CU); 2: the kernel of the long reads (one workgroup per CU there: twice the registers)
+template <int LONG, class LV>
 __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DSeq S2, int k, uint32_t minSize, int next_k = 0)
 {
   // This function is not inlined (three call sites, a long body): behind the references its arguments live in the
@@ -993,12 +996,17 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
   if (g.stamps && tid == 0) { atomicAdd(g.stamps + 11, (unsigned long long)ref.n); atomicAdd(g.stamps + 12, (unsigned long long)S1.n); }
   if (on_chip) on_chip = tables_lds(g, sp_t_, g.lds_tab, pr, ref.n, p1, S1.n, p2, S2.n, k);
   bool long_chip = false, long_small = true;
-  if constexpr (ROOMY) {                                        // (only the kernel of the long batches carries that code)
+  if constexpr (LONG == 2) {                                    // (only the kernel of the long batches carries that code)
     const uint32_t longest = max(max(ref.n, S1.n), S2.n);
     long_chip = !on_chip && g.lds_long >= 0 && longest <= (g.long_b ? LongB::kMaxN : LongA::kMaxN) && ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
     long_small = longest <= LongA::kMaxN;
     if (long_chip) long_chip = long_small ? tables_long<LongA>(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k)
                                           : tables_long<LongB>(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k);
+    if (long_chip && g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
+  } else if constexpr (LONG == 1) {
+    const uint32_t longest = max(max(ref.n, S1.n), S2.n);
+    long_chip = !on_chip && g.lds_long >= 0 && longest <= LongS::kMaxN && ref.n >= (uint32_t)k && S1.n >= (uint32_t)k && S2.n >= (uint32_t)k;
+    if (long_chip) long_chip = tables_long<LongS>(g, sp_t_, g.lds_long, pr, ref.n, p1, S1.n, p2, S2.n, k);
     if (long_chip && g.stamps && tid == 0) atomicAdd(g.stamps + 10, 1ull);
   }
   if (on_chip) {
@@ -1012,7 +1020,7 @@ __device__ void split_core(const WG &g_in, const LV &L_in, DSeq ref, DSeq S1, DS
     // from the dense arrays -- only the anchors' entries of those are ever read
     extern __shared__ int32_t dyn_lds_[];
     uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + g.lds_long;
-    const uint32_t *bm = lds + (long_small ? LongA::kBmWord : LongB::kBmWord);
+    const uint32_t *bm = lds + (LONG == 1 ? LongS::kBmWord : long_small ? LongA::kBmWord : LongB::kBmWord);
     anchors_bitmap(L, bm, lds, n_kmers(ref.n, k), minSize, [&](uint32_t p, int &a, int &b) { a = ldg(g.ca + p); b = ldg(g.cb + p); }, g.stamps);
     SP_STAMP(5);
   } else {
@@ -1321,13 +1329,13 @@ __device__ __forceinline__ DSeq dsub(DSeq s, uint32_t pos) { return dsub(s, pos,
 
 // one split() of the reference (:175-308) including the two re-splits of a missing start / end.  Workgroup-wide;
 // the window list `out` (in HBM) is built by wavefront 0; returns its length through sh[0] (LDS).
-template <bool ROOMY, class LV>
+template <int LONG, class LV>
 __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DSeq S1, DSeq S2, int k, int32_t *out, int32_t *tmp,
                            int *sh /* LDS ints: [0] n out, [1] overflow, [2..] scratch */, int next_k = 0 /* the k of best_split's next round, if any */)
 {
   (void)tmp;
   const int tid = threadIdx.x;
-  split_core<ROOMY>(g, L0, ref, S1, S2, k, 20u, next_k);
+  split_core<LONG>(g, L0, ref, S1, S2, k, 20u, next_k);
   unsigned long long sp_t_ = g.stamps ? __builtin_readcyclecounter() : 0;
   const int64_t cap = g.maxwin;
   // the list's length and overflow flag: the same in all lanes of wavefront 0, which is the only one that uses them
@@ -1422,7 +1430,7 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   const bool rec_start = (uint64_t)s2 * 2 < sr && sr - s2 > 200;
   if (rec_start) {
     SP_STAMP(15);
-    split_core<ROOMY>(g, L1, DSeq{ref.base, sr}, DSeq{S1.base, s1}, DSeq{ref.base, sr}, k, (uint32_t)(1.2 * s2));
+    split_core<LONG>(g, L1, DSeq{ref.base, sr}, DSeq{S1.base, s1}, DSeq{ref.base, sr}, k, (uint32_t)(1.2 * s2));
     if (g.stamps) sp_t_ = __builtin_readcyclecounter();
     if (tid < 64) resplit_windows(sr, s1, 0u, 0u, (uint32_t)(1.2 * s2), true, 0u, s2);
     pred_S1 = (uint32_t)(L0.aa[a0] + k); pred_ref = (uint32_t)(L0.ar[a0] + k); pred_S2 = (uint32_t)(L0.ab[a0] + k);
@@ -1450,7 +1458,7 @@ __device__ void split_read(const WG &g, const LV &L0, const LV &L1, DSeq ref, DS
   if (rec_end) {
     const DSeq gr{ref.base + er.base, er.n}, g1{S1.base + e1.base, e1.n};
     SP_STAMP(15);
-    split_core<ROOMY>(g, L1, gr, g1, gr, k, (uint32_t)(1.2 * e2.n));
+    split_core<LONG>(g, L1, gr, g1, gr, k, (uint32_t)(1.2 * e2.n));
     if (g.stamps) sp_t_ = __builtin_readcyclecounter();
     if (tid < 64) resplit_windows(er.n, e1.n, (uint32_t)er.base, (uint32_t)e1.base, (uint32_t)(1.2 * e2.n), false, (uint32_t)e2.base, e2.n);
   } else if (tid < 64) {
@@ -1483,8 +1491,8 @@ __device__ uint32_t largest_fragment(const int32_t *wl, int n, uint32_t hdr_len,
   return res;
 }
 
-template <bool BIG, bool ROOMY = false>
-__global__ void __launch_bounds__(kSplitThreads, (ROOMY ? kSplitThreads / 256 : kSplitThreads >= 1024 ? 8 : kSplitThreads >= 768 ? 6 : kSplitThreads >= 512 ? 4 : 2)) k_split(SplitArgs a)
+template <bool BIG, int LONG = 0>
+__global__ void __launch_bounds__(kSplitThreads, (LONG == 2 ? kSplitThreads / 256 : kSplitThreads >= 1024 ? 8 : kSplitThreads >= 768 ? 6 : kSplitThreads >= 512 ? 4 : 2)) k_split(SplitArgs a)
 {
   extern __shared__ int32_t s_anc[];              // !BIG: 2 levels x 5 arrays x a.maxanc entries (sized by the batch's longest read)
   __shared__ LvlState s_lvl[2];
@@ -1550,7 +1558,7 @@ __global__ void __launch_bounds__(kSplitThreads, (ROOMY ? kSplitThreads / 256 : 
       // best_split (:310-332): k = 15, then smaller k while the largest fragment shrinks
       int32_t *best = g.wl, *aux = g.wl + a.maxwin * 8, *tmp = g.wl + 2 * a.maxwin * 8;
       int kk = 15;
-      split_read<ROOMY>(g, L0, L1, ref, S1, S2, kk, best, tmp, sh, kk - 2);
+      split_read<LONG>(g, L0, L1, ref, S1, S2, kk, best, tmp, sh, kk - 2);
       int nbest = sh[0];
       bool over = sh[1] != 0;
       uint32_t largest = largest_fragment(best, nbest, (uint32_t)a.hdr_len[r], &sh[2]);
@@ -1558,7 +1566,7 @@ __global__ void __launch_bounds__(kSplitThreads, (ROOMY ? kSplitThreads / 256 : 
         kk -= 2;
         if (kk < 9 || over) break;
         __syncthreads();
-        split_read<ROOMY>(g, L0, L1, ref, S1, S2, kk, aux, tmp, sh, kk - 2 >= 9 ? kk - 2 : 0);
+        split_read<LONG>(g, L0, L1, ref, S1, S2, kk, aux, tmp, sh, kk - 2 >= 9 ? kk - 2 : 0);
         const int naux = sh[0];
         over = over || sh[1] != 0;
         const uint32_t la = largest_fragment(aux, naux, (uint32_t)a.hdr_len[r], &sh[3]);
@@ -1671,14 +1679,16 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     std::vector<int32_t> reads;                 // longest first: the order the workgroups take them in
     int64_t maxlen = 1, maxwin = 16, tab_cap = 64, maxanc = 8, per_block = 0;
     int blocks = 0;
-    bool roomy = false, big = false;
+    int lng = 0;                                // 0: small tables / HBM tables; 1: medium reads' kernel; 2: long reads' kernel
+    bool big = false;
   };
-  Launch part[2];
+  Launch part[3];
   const bool no_long = std::getenv("ELECTOR_SPLIT_HBM_TABLES") || std::getenv("ELECTOR_SPLIT_NO_LONG");
+  const bool no_medium = std::getenv("ELECTOR_SPLIT_NO_MEDIUM") != nullptr;       // (A/B: the medium reads with the long ones)
   for (int64_t r = 0; r < n_in; ++r) {
     const int64_t m = std::max(std::max(read_off[3 * r + 1] - read_off[3 * r], read_off[3 * r + 2] - read_off[3 * r + 1]),
                                read_off[3 * r + 3] - read_off[3 * r + 2]);
-    Launch &L = part[!no_long && m > (int64_t)kLdsMaxN ? 1 : 0];
+    Launch &L = part[no_long || m <= (int64_t)kLdsMaxN ? 0 : m <= (int64_t)LongS::kMaxN && !no_medium ? 1 : 2];
     L.reads.push_back((int32_t)r);
     L.maxlen = std::max(L.maxlen, m);
     L.maxwin = std::max(L.maxwin, (read_off[3 * r + 1] - read_off[3 * r]) / 16 + 16);
@@ -1691,7 +1701,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   // reads anyway), and a workspace that still cannot be had sends the batch to the host splitter (ELECTOR_E_LIMIT).
   const int64_t budget = (int64_t)8 << 30;
   size_t need_keys = 0, need_ca = 0, need_wl = 0, need_anc = 0;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     Launch &L = part[k];
     if (L.reads.empty()) continue;
     std::sort(L.reads.begin(), L.reads.end(), [&](int32_t x, int32_t y) {
@@ -1702,10 +1712,10 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     // anchors are more than 20 bases apart on the reference (the re-split of a missing end can use less: it
     // overflows into the host path, like a window list that does not fit)
     L.maxanc = L.maxlen / 21 + 8;
-    L.roomy = k == 1;
-    L.big = L.roomy || L.maxanc > kMaxAnchors;
+    L.lng = k;
+    L.big = L.lng != 0 || L.maxanc > kMaxAnchors;
     L.per_block = 3 * L.tab_cap * 8 + 2 * (L.maxlen + 2) * 4 + 3 * L.maxwin * 8 * 4;
-    L.blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)L.reads.size(), L.roomy ? std::max(1, dev_cus) : max_blocks),
+    L.blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)L.reads.size(), L.lng == 2 ? std::max(1, dev_cus) : L.lng == 1 ? 2 * std::max(1, dev_cus) : max_blocks),
                                                              std::max<int64_t>(64, budget / L.per_block)));
     need_keys = std::max(need_keys, (size_t)L.blocks * 3 * (size_t)L.tab_cap * 8);
     need_ca = std::max(need_ca, (size_t)L.blocks * (size_t)(L.maxlen + 2) * 4);
@@ -1775,9 +1785,10 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   }
   {
     // the counters the workgroups draw their reads from, and the two launches' reads behind them
-    std::vector<int32_t> order((size_t)n_in + 4, 0);
-    std::copy(part[0].reads.begin(), part[0].reads.end(), order.begin() + 4);
-    std::copy(part[1].reads.begin(), part[1].reads.end(), order.begin() + 4 + (ptrdiff_t)part[0].reads.size());
+    std::vector<int32_t> order((size_t)n_in + 8, 0);
+    std::copy(part[0].reads.begin(), part[0].reads.end(), order.begin() + 8);
+    std::copy(part[1].reads.begin(), part[1].reads.end(), order.begin() + 8 + (ptrdiff_t)part[0].reads.size());
+    std::copy(part[2].reads.begin(), part[2].reads.end(), order.begin() + 8 + (ptrdiff_t)(part[0].reads.size() + part[1].reads.size()));
     HIPCHK(c, hipMemcpyAsync(c->d_sp_wfirst.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));                               // (the vector goes out of scope)
   }
@@ -1785,21 +1796,27 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     if (L.reads.empty()) return 0;
     a.n_reads = (int64_t)L.reads.size();
     a.next = c->d_sp_wfirst.as<int32_t>() + 2 * k;
-    a.order = c->d_sp_wfirst.as<int32_t>() + 4 + order_at;
+    a.order = c->d_sp_wfirst.as<int32_t>() + 8 + order_at;
     a.tab_cap = L.tab_cap; a.maxlen = L.maxlen; a.maxwin = L.maxwin;
     a.anc = nullptr; a.maxanc = L.maxanc;
     a.lds_tables = 0;
-    a.lds_long = L.roomy ? (std::getenv("ELECTOR_SPLIT_LONG") ? std::atoi(std::getenv("ELECTOR_SPLIT_LONG")) : 2) : 0;
+    a.lds_long = L.lng == 2 ? (std::getenv("ELECTOR_SPLIT_LONG") ? std::atoi(std::getenv("ELECTOR_SPLIT_LONG")) : 2) : L.lng;
     if (L.big) {
       a.anc = c->d_sp_anc.as<int32_t>();
-      static DeviceOnce once_big;
-      if (L.roomy && once_big.need()) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      static DeviceOnce once_long, once_medium;
+      if (L.lng == 2 && once_long.need()) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024 - 512));
-        once_big.done();
+        once_long.done();
       }
-      if (L.roomy) hipLaunchKernelGGL((k_split<true, true>), dim3((unsigned)L.blocks), dim3(kSplitThreads), kLongBytes, st, a);
-      else hipLaunchKernelGGL((k_split<true, false>), dim3((unsigned)L.blocks), dim3(kSplitThreads), (size_t)16, st, a);
+      if (L.lng == 1 && once_medium.need()) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 512));
+        once_medium.done();
+      }
+      if (L.lng == 2) hipLaunchKernelGGL((k_split<true, 2>), dim3((unsigned)L.blocks), dim3(kSplitThreads), kLongBytes, st, a);
+      else if (L.lng == 1) hipLaunchKernelGGL((k_split<true, 1>), dim3((unsigned)L.blocks), dim3(kSplitThreads), kLongSBytes, st, a);
+      else hipLaunchKernelGGL((k_split<true, 0>), dim3((unsigned)L.blocks), dim3(kSplitThreads), (size_t)16, st, a);
     } else {
       // the anchor arrays in LDS, as many entries as the launch's longest read can need
       static DeviceOnce once;
@@ -1823,7 +1840,8 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     HIPCHK(c, hipGetLastError());
     return 0;
   };
-  if ((rc = launch(part[1], 1, (int64_t)part[0].reads.size())) != 0) return rc;      // the long reads first
+  if ((rc = launch(part[2], 2, (int64_t)(part[0].reads.size() + part[1].reads.size()))) != 0) return rc;      // the long reads first
+  if ((rc = launch(part[1], 1, (int64_t)part[0].reads.size())) != 0) return rc;
   if ((rc = launch(part[0], 0, 0)) != 0) return rc;
   // kinds and counts to the host: the reads the device could not take are split by the host code
   std::vector<int32_t> cnt((size_t)n_in), kind((size_t)n_in);
@@ -1848,7 +1866,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     if (!again.reads.empty() && !no_long && (int64_t)again.reads.size() <= 4096) {
       while (again.tab_cap < 2 * again.maxlen + 2) again.tab_cap <<= 1;
       again.maxanc = again.maxlen + 8;
-      again.roomy = again.big = true;
+      again.lng = 2; again.big = true;
       again.blocks = (int)std::min<int64_t>((int64_t)again.reads.size(), std::max(1, dev_cus));
       if (c->d_sp_keys.ensure((size_t)again.blocks * 3 * (size_t)again.tab_cap * 8 + 64) | c->d_sp_ca.ensure((size_t)again.blocks * (size_t)(again.maxlen + 2) * 4 + 64) |
           c->d_sp_cb.ensure((size_t)again.blocks * (size_t)(again.maxlen + 2) * 4 + 64) | c->d_sp_wl.ensure((size_t)again.blocks * 3 * (size_t)again.maxwin * 8 * 4 + 64) |
@@ -1856,8 +1874,8 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
         return elector_fail(c, ELECTOR_E_LIMIT, "device splitter workspace does not fit device memory: the host splitter takes this batch");
       a.ent = c->d_sp_keys.as<unsigned long long>();
       a.ca = c->d_sp_ca.as<int32_t>(); a.cb = c->d_sp_cb.as<int32_t>(); a.wl = c->d_sp_wl.as<int32_t>();
-      std::vector<int32_t> order(again.reads.size() + 4, 0);
-      std::copy(again.reads.begin(), again.reads.end(), order.begin() + 4);
+      std::vector<int32_t> order(again.reads.size() + 8, 0);
+      std::copy(again.reads.begin(), again.reads.end(), order.begin() + 8);
       HIPCHK(c, hipMemcpyAsync(c->d_sp_wfirst.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
       HIPCHK(c, hipStreamSynchronize(st));
       if ((rc = launch(again, 0, 0)) != 0) return rc;
