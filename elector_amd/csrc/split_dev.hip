@@ -1681,6 +1681,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     int blocks = 0;
     int lng = 0;                                // 0: small tables / HBM tables; 1: medium reads' kernel; 2: long reads' kernel
     bool big = false;
+    size_t at_keys = 0, at_ca = 0, at_wl = 0, at_anc = 0;     // its share of the workspace (the launches run side by side)
   };
   Launch part[3];
   const bool no_long = std::getenv("ELECTOR_SPLIT_HBM_TABLES") || std::getenv("ELECTOR_SPLIT_NO_LONG");
@@ -1717,10 +1718,11 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     L.per_block = 3 * L.tab_cap * 8 + 2 * (L.maxlen + 2) * 4 + 3 * L.maxwin * 8 * 4;
     L.blocks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)L.reads.size(), L.lng == 2 ? std::max(1, dev_cus) : L.lng == 1 ? 2 * std::max(1, dev_cus) : max_blocks),
                                                              std::max<int64_t>(64, budget / L.per_block)));
-    need_keys = std::max(need_keys, (size_t)L.blocks * 3 * (size_t)L.tab_cap * 8);
-    need_ca = std::max(need_ca, (size_t)L.blocks * (size_t)(L.maxlen + 2) * 4);
-    need_wl = std::max(need_wl, (size_t)L.blocks * 3 * (size_t)L.maxwin * 8 * 4);
-    if (L.big) need_anc = std::max(need_anc, (size_t)L.blocks * 2 * 5 * (size_t)L.maxanc * 4 + 64);
+    L.at_keys = need_keys; L.at_ca = need_ca; L.at_wl = need_wl; L.at_anc = need_anc;
+    need_keys += (size_t)L.blocks * 3 * (size_t)L.tab_cap * 8;
+    need_ca += ((size_t)L.blocks * (size_t)(L.maxlen + 2) * 4 + 63) & ~(size_t)63;
+    need_wl += (size_t)L.blocks * 3 * (size_t)L.maxwin * 8 * 4;
+    if (L.big) need_anc += ((size_t)L.blocks * 2 * 5 * (size_t)L.maxanc * 4 + 127) & ~(size_t)63;
   }
   hipStream_t st = c->stream;
   int rc = c->d_sp_reads.ensure((size_t)total + 64) | c->d_sp_off.ensure((size_t)(3 * n_in + 1) * 8 + 64) |
@@ -1792,9 +1794,12 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     HIPCHK(c, hipMemcpyAsync(c->d_sp_wfirst.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));                               // (the vector goes out of scope)
   }
-  auto launch = [&](const Launch &L, int k, int64_t order_at) -> int {
+  auto launch = [&](const Launch &L, int k, int64_t order_at, hipStream_t st) -> int {      // (st: the stream of this launch)
     if (L.reads.empty()) return 0;
     a.n_reads = (int64_t)L.reads.size();
+    a.ent = reinterpret_cast<unsigned long long *>(c->d_sp_keys.as<uint8_t>() + L.at_keys);
+    a.ca = reinterpret_cast<int32_t *>(c->d_sp_ca.as<uint8_t>() + L.at_ca); a.cb = reinterpret_cast<int32_t *>(c->d_sp_cb.as<uint8_t>() + L.at_ca);
+    a.wl = reinterpret_cast<int32_t *>(c->d_sp_wl.as<uint8_t>() + L.at_wl);
     a.next = c->d_sp_wfirst.as<int32_t>() + 2 * k;
     a.order = c->d_sp_wfirst.as<int32_t>() + 8 + order_at;
     a.tab_cap = L.tab_cap; a.maxlen = L.maxlen; a.maxwin = L.maxwin;
@@ -1802,7 +1807,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     a.lds_tables = 0;
     a.lds_long = L.lng == 2 ? (std::getenv("ELECTOR_SPLIT_LONG") ? std::atoi(std::getenv("ELECTOR_SPLIT_LONG")) : 2) : L.lng;
     if (L.big) {
-      a.anc = c->d_sp_anc.as<int32_t>();
+      a.anc = reinterpret_cast<int32_t *>(c->d_sp_anc.as<uint8_t>() + L.at_anc);
       static DeviceOnce once_long, once_medium;
       if (L.lng == 2 && once_long.need()) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_split<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1840,9 +1845,25 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     HIPCHK(c, hipGetLastError());
     return 0;
   };
-  if ((rc = launch(part[2], 2, (int64_t)(part[0].reads.size() + part[1].reads.size()))) != 0) return rc;      // the long reads first
-  if ((rc = launch(part[1], 1, (int64_t)part[0].reads.size())) != 0) return rc;
-  if ((rc = launch(part[0], 0, 0)) != 0) return rc;
+  // the launches side by side on streams of their own (a launch's last workgroups leave most of the chip idle: the
+  // next launch's workgroups move in), the long reads first
+  if (!c->aux_ready) {
+    for (int k = 0; k < elector_ctx::kAux; ++k) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->aux_done[k], hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    c->aux_ready = true;
+  }
+  {
+    const int64_t at[3] = {0, (int64_t)part[0].reads.size(), (int64_t)(part[0].reads.size() + part[1].reads.size())};
+    for (int k = 2; k >= 0; --k) {
+      if (part[k].reads.empty()) continue;
+      if ((rc = launch(part[k], k, at[k], c->aux[k])) != 0) return rc;
+      HIPCHK(c, hipEventRecord(c->aux_done[k], c->aux[k]));
+      HIPCHK(c, hipStreamWaitEvent(st, c->aux_done[k], 0));
+    }
+  }
   // kinds and counts to the host: the reads the device could not take are split by the host code
   std::vector<int32_t> cnt((size_t)n_in), kind((size_t)n_in);
   auto fetch_kinds = [&]() -> int {
@@ -1878,7 +1899,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
       std::copy(again.reads.begin(), again.reads.end(), order.begin() + 8);
       HIPCHK(c, hipMemcpyAsync(c->d_sp_wfirst.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
       HIPCHK(c, hipStreamSynchronize(st));
-      if ((rc = launch(again, 0, 0)) != 0) return rc;
+      if ((rc = launch(again, 0, 0, st)) != 0) return rc;
       if ((rc = fetch_kinds()) != 0) return rc;
     }
   }
