@@ -262,3 +262,36 @@ def test_getpoa_four_ranks_empty_shard_and_dominant_read(tmp_path, engine, capsy
     assert (tmp_path / "out2" / "msa.fa").read_bytes() == (tmp_path / "out1" / "msa.fa").read_bytes()
     assert (four["small"], four["wrong"]) == (small, wrong) and four["hit"]
     assert four["tuple"] == json.loads(json.dumps(tup)) and four["log"] == log.getvalue()
+
+
+def test_getpoa_mixed_lengths_device_split_equals_host_split(tmp_path, engine, capsys, monkeypatch):
+    """Reads from 3 kb to 40 kb in one batch (the device splitter takes them in three launches: small on-chip
+    tables, medium and long partitioned tables; some corrected reads trimmed, so re-splits too): msa.fa and the
+    counters must not depend on whether the windows were cut on the device or by the host splitter."""
+    import hashlib
+    import numpy as np
+    import synth
+    rng = np.random.default_rng(41)
+    reads = []
+    for i, n in enumerate((3000, 9000, 12400, 12600, 15000, 21000, 32000, 33000, 40000, 7000, 18000, 5000)):
+        r = synth.random_seq(rng, n)
+        c = synth.mutate(rng, r, 0.01)
+        if i % 4 == 1:
+            c = c[len(c) // 5:]
+        elif i % 4 == 2:
+            c = c[: 3 * len(c) // 4]
+        reads.append((b">read_%d" % i, r, c, synth.mutate(rng, r, 0.13)))
+    got = {}
+    for mode in ("device", "host"):
+        d = tmp_path / mode
+        d.mkdir()
+        _write_reads(d, reads)
+        if mode == "host":
+            monkeypatch.setenv("ELECTOR_HOST_SPLIT", "1")
+        small, wrong = alignment.getPOA(str(d / "cor.fa"), str(d / "ref.fa"), str(d / "unc.fa"), 8, str(d), 0.1)
+        capsys.readouterr()
+        with open(d / "msa.fa", "rb") as f:
+            got[mode] = (small, wrong, hashlib.sha256(f.read()).hexdigest(), os.path.getsize(d / "msa.fa"))
+    monkeypatch.delenv("ELECTOR_HOST_SPLIT", raising=False)
+    assert got["device"] == got["host"]
+    assert got["device"][3] > 0
