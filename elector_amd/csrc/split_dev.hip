@@ -16,7 +16,7 @@
 //     per-anchor links, with the reference's re-split of a missing start / end of the corrected read
 //     (:268-277,295-301) as a second, workgroup-wide pass;
 //   * best_split's loop over k = 15, 13, 11, 9 while the largest fragment shrinks (:310-332);
-//   * the reads of a batch drawn from a counter, longest first, in up to two launches (short reads / long reads).
+//   * the reads of a batch drawn from a counter, longest first, in up to three launches side by side (short / medium / long reads).
 // A read whose anchors or windows do not fit the arrays sized for its launch gets a second try with an anchor per
 // base; one that still does not fit is flagged and the batch split by the host code (splitter.cpp) instead: same
 // result, never silently different.
@@ -1670,11 +1670,13 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     first[(size_t)r + 1] = first[(size_t)r] + cap;
     maxwin = std::max(maxwin, cap);
   }
-  // The batch goes to the device in up to two launches.  Reads within the small on-chip tables (12.5 kb) take the
-  // kernel with the anchor arrays in LDS, two workgroups per CU; longer ones the kernel of the partitioned on-chip
-  // tables (tables_long: one workgroup per CU, 153 KB of LDS, anchor arrays in HBM), which also holds the HBM-table
-  // path for what is longer still.  A PacBio batch whose lengths straddle 12.5 kb thus keeps both kinds on chip.
-  // (ELECTOR_SPLIT_NO_LONG / ELECTOR_SPLIT_HBM_TABLES: one launch as before, HBM tables for the long reads.)
+  // The batch goes to the device in up to three launches.  Reads within the small on-chip tables (12.5 kb) take the
+  // kernel with the anchor arrays in LDS, two workgroups per CU; reads of up to 32,767 bases the kernel of the medium
+  // partitioned tables (78 KB of LDS, two workgroups per CU, anchor arrays in HBM); longer ones the kernel of the large
+  // partitioned tables (tables_long: one workgroup per CU, 153 KB of LDS), which also holds the HBM-table path for
+  // what is longer still.  A PacBio batch whose lengths straddle 12.5 kb thus keeps all its reads on chip.
+  // (ELECTOR_SPLIT_NO_LONG / ELECTOR_SPLIT_HBM_TABLES: one launch as before, HBM tables for the long reads;
+  // ELECTOR_SPLIT_NO_MEDIUM: the medium reads with the long ones.)
   struct Launch {
     std::vector<int32_t> reads;                 // longest first: the order the workgroups take them in
     int64_t maxlen = 1, maxwin = 16, tab_cap = 64, maxanc = 8, per_block = 0;
@@ -1786,7 +1788,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
     HIPCHK(c, hipMemsetAsync(a.stamps, 0, 256, st));
   }
   {
-    // the counters the workgroups draw their reads from, and the two launches' reads behind them
+    // the counters the workgroups draw their reads from, and the launches' reads behind them
     std::vector<int32_t> order((size_t)n_in + 8, 0);
     std::copy(part[0].reads.begin(), part[0].reads.end(), order.begin() + 8);
     std::copy(part[1].reads.begin(), part[1].reads.end(), order.begin() + 8 + (ptrdiff_t)part[0].reads.size());
