@@ -185,8 +185,12 @@ def _prepare(rb, size_threshold, threads, splitter=None):
     if splitter is not None:
         win = split.split_packed_device(splitter, rb.seq, rb.seq_off, rb.hdr_len, size_threshold, nthreads=max(1, int(threads)))
         # out of the splitter's workspace, which its next call reuses
+        t1 = time.perf_counter()
         b.d_bases = win.d_bases.to_tensor() if isinstance(win.d_bases, split.DevBases) else win.d_bases
         win.d_bases = None
+        if os.environ.get("ELECTOR_DEBUG_HOST"):
+            sys.stderr.write("[elector] split stage: call + arrays %.1f ms, bases to a tensor of their own %.1f ms\n"
+                             % (1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)))
         _tick("split (device, incl. reads H2D)", t0)
     else:
         win = split.split_packed(rb.seq, rb.seq_off, rb.hdr_len, size_threshold, nthreads=max(1, int(threads)))

@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -33,18 +35,30 @@ namespace {
 struct BigBuf {
   char *p = nullptr;
   size_t n = 0, cap = 0;
-  ~BigBuf() { if (p) ::munmap(p, cap); }
+  // pin: the buffer is registered with the HIP runtime (page-locked) whenever it (re)grows, so that the device
+  // splitter's copy of a batch's reads is ONE DMA out of this buffer -- staged through pinned memory by host threads it
+  // took 5 ms when the host was idle and up to 37 ms beside the parser's, the writers' and the page cache's copies.
+  // Without a device (CPU tests) the registration fails and the buffer is plain memory.
+  bool pin = false, pinned = false;
+  ~BigBuf() { if (p) { unpin(); ::munmap(p, cap); } }
+  void unpin() { if (pinned) { (void)hipHostUnregister(p); pinned = false; } }
   bool reserve(size_t want)
   {
     if (want <= cap) return true;
     size_t nc = std::max<size_t>(std::max(want, cap * 2), (size_t)32 << 20);
+    if (pin) nc = std::max(nc, want + want / 8);                  // (a registration costs tens of milliseconds: grow rarely)
     nc = (nc + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    unpin();
     void *q = cap ? ::mremap(p, cap, nc, MREMAP_MAYMOVE)
                   : ::mmap(nullptr, nc, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (q == MAP_FAILED) return false;
     (void)::madvise(q, nc, MADV_HUGEPAGE);
     p = static_cast<char *>(q);
     cap = nc;
+    if (pin) {
+      pinned = hipHostRegister(p, cap, hipHostRegisterDefault) == hipSuccess;
+      if (!pinned) (void)hipGetLastError();
+    }
     return true;
   }
   bool append(const char *a, size_t len)
@@ -258,6 +272,7 @@ extern "C" int elector_reads_open(const char *reference, const char *uncorrected
   if (!reference || !uncorrected || !corrected || !handle) return ELECTOR_E_INVAL;
   Reader *rd = new (std::nothrow) Reader();
   if (!rd) return ELECTOR_E_NOMEM;
+  if (!std::getenv("ELECTOR_NO_PINNED_READS")) rd->set[0].seq.pin = rd->set[1].seq.pin = true;
   if (!rd->ref.open(reference) || !rd->unc.open(uncorrected) || !rd->cor.open(corrected)) {
     rd->ref.close(); rd->unc.close(); rd->cor.close();
     delete rd;

@@ -1740,7 +1740,14 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   const double t0 = now_ms();
   // the reads to the device through pinned staging, `nthreads` host threads filling one half while the other half's
   // copy runs (a pageable source is otherwise staged by the runtime on one thread, several times slower)
-  {
+  hipPointerAttribute_t src_attr;
+  const bool src_pinned = hipPointerGetAttributes(&src_attr, reads) == hipSuccess && src_attr.type == hipMemoryTypeHost;
+  if (!src_pinned) (void)hipGetLastError();
+  if (src_pinned) {
+    // the reader's buffers are registered with the runtime (io_host.cpp): one DMA, no staging
+    HIPCHK(c, hipMemcpyAsync(c->d_sp_reads.p, reads, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  } else {
     constexpr size_t kChunk = (size_t)32 << 20;
     if (c->h_rows.ensure(2 * kChunk)) return elector_fail(c, ELECTOR_E_NOMEM, "pinned staging");
     uint8_t *stage = c->h_rows.as<uint8_t>();

@@ -192,8 +192,11 @@ def split_packed_device(engine, buf, off, hl, size_threshold=0.1, nthreads=None)
     hl = np.ascontiguousarray(hl, dtype=np.int32)
     n = (len(off) - 1) // 3
     w = ElectorWindowsDev()
+    import time
+    t_call = time.perf_counter()
     rc = L.elector_split_reads_device(engine._h, n, buf.ctypes.data, off.ctypes.data, hl.ctypes.data,
                                       float(size_threshold), int(nthreads), C.byref(w))
+    t_done = time.perf_counter()
     out = DevWindows()
     if rc == _capi.E_LIMIT:
         hw = split_packed(buf, off, hl, size_threshold, nthreads)
@@ -213,6 +216,10 @@ def split_packed_device(engine, buf, off, hl, size_threshold=0.1, nthreads=None)
         out.small_reads, out.wrong_reads = int(w.small_reads), int(w.wrong_reads)
         out.bases = None
         out.d_bases = DevBases(w.d_bases, int(out.off[-1]), engine)
+        if os.environ.get("ELECTOR_DEBUG_HOST"):
+            import sys
+            sys.stderr.write("[elector] split_packed_device: library call %.1f ms, arrays to numpy %.1f ms\n"
+                             % (1e3 * (t_done - t_call), 1e3 * (time.perf_counter() - t_done)))
         return out
     finally:
         L.elector_windows_dev_free(C.byref(w))
