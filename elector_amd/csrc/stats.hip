@@ -1322,7 +1322,10 @@ extern "C" int64_t elector_msa_records_pwrite(elector_ctx *c, int64_t n_pieces, 
                                          (int64_t)c->h_text.size(), nthreads);
   if (got != need) return elector_fail(c, ELECTOR_E_INVAL, "records");
   const double t2 = now_ms();
-  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, nthreads), got >> 22));      // at least 4 MB per thread
+  // (buffered writes to one file go through one lock: the page cache takes ~10 GB/s from one thread or from sixteen, a
+  // couple of threads keep it fed while other writers are in the same call; with sixteen each the end-to-end run was 10 % slower)
+  static const int pw_max = std::getenv("ELECTOR_PWRITE_THREADS") ? std::max(1, std::atoi(std::getenv("ELECTOR_PWRITE_THREADS"))) : 2;
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(std::max(1, nthreads), pw_max), got >> 22));      // at least 4 MB per thread
   std::vector<int> bad((size_t)nt, 0);
   auto work = [&](int t) {
     int64_t at = got * t / nt;
