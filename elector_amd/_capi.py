@@ -44,7 +44,7 @@ EXPORTS = [
     "elector_msa_rows_fetch", "elector_homopolymer_pairs",
     "elector_split_reads", "elector_windows_free", "elector_merge_windows", "elector_msa_free",
     "elector_split_reads_device", "elector_windows_dev_free", "elector_ctx_copy", "elector_ctx_copy_to_host",
-    "elector_reads_open", "elector_reads_next", "elector_reads_close", "elector_reads_scan", "elector_reads_index_free",
+    "elector_reads_open", "elector_reads_set_device", "elector_reads_next", "elector_reads_close", "elector_reads_scan", "elector_reads_index_free",
     "elector_msa_format", "elector_msa_records_write", "elector_msa_records_pwrite",
     "elector_report_aggregate", "elector_report_free", "elector_read_size_lines", "elector_write_count_lines",
 ]

@@ -379,7 +379,7 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     def parser():
         import time
         try:
-            rf = split.ReadsFile(reference, uncorrected, corrected)
+            rf = split.ReadsFile(reference, uncorrected, corrected, device=engines[0].device)
             try:
                 seq = 0
                 while not stop_all.is_set():

@@ -13,6 +13,7 @@
 #include "elector_split.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <ctime>
 #include <cstdlib>
@@ -32,6 +33,8 @@ namespace {
 
 // growable byte buffer for a batch's sequences: anonymous mapping that asks for huge pages (a fresh 250 MB batch
 // buffer otherwise costs 60,000 page faults, more than reading the files) and grows in place where it can
+static std::atomic<int> g_pin_device{-1};      // elector_reads_set_device
+
 struct BigBuf {
   char *p = nullptr;
   size_t n = 0, cap = 0;
@@ -56,6 +59,8 @@ struct BigBuf {
     p = static_cast<char *>(q);
     cap = nc;
     if (pin) {
+      const int dev = g_pin_device.load();
+      if (dev >= 0) (void)hipSetDevice(dev);                       // (this thread's current device from here on)
       pinned = hipHostRegister(p, cap, hipHostRegisterDefault) == hipSuccess;
       if (!pinned) (void)hipGetLastError();
     }
@@ -266,6 +271,8 @@ struct Reader {
 };
 
 }  // namespace
+
+extern "C" void elector_reads_set_device(int device) { g_pin_device.store(device); }
 
 extern "C" int elector_reads_open(const char *reference, const char *uncorrected, const char *corrected, void **handle)
 {

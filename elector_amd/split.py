@@ -241,8 +241,12 @@ class ReadsFile:
     """The three sorted FASTA files read as masterSplitter reads them, cut into processing batches
     (include/elector_split.h: elector_reads_open / _next)."""
 
-    def __init__(self, reference, uncorrected, corrected):
+    def __init__(self, reference, uncorrected, corrected, device=None):
         self._h = C.c_void_p()
+        if device is not None:
+            _lib().elector_reads_set_device.argtypes = [C.c_int]
+            _lib().elector_reads_set_device.restype = None
+            _lib().elector_reads_set_device(int(device))      # its batch buffers: page-locked for that device's runtime
         rc = _lib().elector_reads_open(os.fsencode(reference), os.fsencode(uncorrected), os.fsencode(corrected),
                                        C.byref(self._h))
         if rc:

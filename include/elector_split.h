@@ -89,6 +89,10 @@ typedef struct elector_reads {
   uint8_t *hdr;  int64_t *hdr_off;     /*  n + 1 offsets */
 } elector_reads;
 int  elector_reads_open(const char *reference, const char *uncorrected, const char *corrected, void **handle);
+/* The device whose runtime the readers opened from now on register their batch buffers with (page-locked memory: the
+ * device splitter copies a batch's reads out of it in one DMA); -1, the default, is the calling thread's current device.
+ * Without a device the buffers are plain memory. */
+void elector_reads_set_device(int device);
 int  elector_reads_next(void *handle, int64_t min_records, int64_t start, int64_t stop, elector_reads *out);
 void elector_reads_close(void *handle);
 
