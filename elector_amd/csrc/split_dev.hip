@@ -414,19 +414,22 @@ __device__ __forceinline__ void flat_add(const LTab &t, uint32_t todo, int *fill
 // One workgroup per CU (148 KB of LDS).
 // Two sizes: reads of up to 65,535 bases with tables of 16,384 / 8,192 slots (a partition holds up to ~6,000 k-mers),
 // reads of up to 122,879 bases with half the tables and twice the partitions -- the packed sequences take the room.
-template <int NW_, uint32_t MAXN_, uint32_t CAPREF_, uint32_t CAPOTHER_, uint32_t FILL_, uint32_t PART_>
+template <int NW_, uint32_t MAXN_, uint32_t CAPREF_, uint32_t CAPOTHER_, uint32_t FILL_, uint32_t PART_, bool S16_ = false>
 struct LongCfg {
+  static constexpr bool kS16 = S16_;                               // 16-bit slots (positions below 32,768), two to a dword
+  static constexpr uint32_t kRefWords = CAPREF_ / (S16_ ? 2 : 1), kOtherWords = CAPOTHER_ / (S16_ ? 2 : 1);
   static constexpr int NW = NW_;                                   // 32-bit words of a lane's position mask
   static constexpr uint32_t kMaxN = MAXN_, kCapRef = CAPREF_, kCapOther = CAPOTHER_, kFill = FILL_, kPart = PART_;
   static constexpr uint32_t kSeqWords = MAXN_ / 16 + 3;
   static constexpr uint32_t kBitWords = 2 * ((MAXN_ + 63) / 64 + 1);                  // candidate bitmap, as dwords
-  static constexpr uint32_t kBmWord = CAPREF_ + CAPOTHER_ + 3 * kSeqWords + 2;        // dwords from the region's start
+  static constexpr uint32_t kBmWord = kRefWords + kOtherWords + 3 * kSeqWords + 2;     // dwords from the region's start
   static constexpr uint32_t kDwords = kBmWord + kBitWords;
   static_assert(MAXN_ <= 32u * NW_ * (uint32_t)kSplitThreads, "a lane's positions as one mask");
-  static_assert(6 * (kBitWords / 2) <= CAPREF_ + CAPOTHER_, "the exit tables of the anchor walk overlay the dead tables");
+  static_assert(6 * (kBitWords / 2) <= kRefWords + kOtherWords, "the exit tables of the anchor walk overlay the dead tables");
+  static_assert(!S16_ || MAXN_ <= 32767u, "a position and the seen-twice bit in 16 bits");
   static_assert(kDwords * 4 <= 160 * 1024 - 1024, "one workgroup's LDS");
 };
-using LongS = LongCfg<2, 32767u, 8192u, 4096u, 3600u, 3000u>;    // reads of up to 32,767 bases: 78 KB, two workgroups per CU
+using LongS = LongCfg<2, 32767u, 16384u, 8192u, 7200u, 6000u, true>;    // reads of up to 32,767 bases: 16-bit slots, 78 KB, two workgroups per CU
 using LongA = LongCfg<4, 65535u, 16384u, 8192u, 7200u, 6000u>;
 using LongB = LongCfg<8, 122879u, 8192u, 4096u, 3600u, 3000u>;
 constexpr uint32_t kLongMaxN = LongB::kMaxN;
@@ -469,19 +472,45 @@ struct MaskN {
   }
 };
 
-struct LTab32 {
-  uint32_t *w;            // one slot per word
+// a partition's table: 32-bit slots ([31] seen twice, [30:0] position, all ones empty), or 16-bit ones, two to a dword
+// ([15] seen twice, [14:0] position, 0xFFFF empty) -- the accessors below give both the same face
+template <bool S16>
+struct LTabP {
+  uint32_t *w;
   uint32_t mask;
   const uint32_t *seq;    // packed sequence the positions refer to
   uint32_t kmsk;
+  static constexpr uint32_t kEmpty = 0xFFFFFFFFu, kTwice = 0x80000000u, kPos = 0x7FFFFFFFu;
+  __device__ __forceinline__ uint32_t get(uint32_t h) const             // the slot in the 32-bit form
+  {
+    if constexpr (S16) {
+      const uint32_t e = (__hip_atomic_load(w + (h >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> ((h & 1u) * 16u)) & 0xFFFFu;
+      return e == 0xFFFFu ? kEmpty : ((e & 0x8000u) << 16) | (e & 0x7FFFu);
+    } else return __hip_atomic_load(w + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ bool claim(uint32_t h, uint32_t pos) const   // an empty slot takes pos; false: look at the slot again
+  {
+    if constexpr (S16) {
+      uint32_t *word = w + (h >> 1);
+      const uint32_t sh = (h & 1u) * 16u;
+      const uint32_t old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (((old >> sh) & 0xFFFFu) != 0xFFFFu) return false;
+      return atomicCAS(word, old, (old & ~(0xFFFFu << sh)) | (pos << sh)) == old;
+    } else return atomicCAS(w + h, kEmpty, pos) == kEmpty;
+  }
+  __device__ __forceinline__ void twice(uint32_t h) const
+  {
+    if constexpr (S16) atomicOr(w + (h >> 1), 0x8000u << ((h & 1u) * 16u));
+    else atomicOr(w + h, kTwice);
+  }
   __device__ __forceinline__ int find(uint32_t code) const              // position of the k-mer when it occurs exactly once, else -1
   {
     uint32_t h = LTab::slot_of(code, mask);
     const uint32_t step = LTab::step_of(code);
     for (uint32_t probes = 0; probes <= mask; ++probes) {
-      const uint32_t e = w[h];
-      if (e == 0xFFFFFFFFu) return -1;
-      if (LTab::bits(seq, e & 0x7FFFFFFFu, kmsk) == code) return (e & 0x80000000u) ? -1 : (int)e;
+      const uint32_t e = get(h);
+      if (e == kEmpty) return -1;
+      if (LTab::bits(seq, e & kPos, kmsk) == code) return (e & kTwice) ? -1 : (int)e;
       h = (h + step) & mask;
     }
     return -1;
@@ -520,8 +549,8 @@ __device__ __forceinline__ MaskN<NW> lane_positions_of(const uint32_t *seq, uint
 }
 
 // flat loops (see flat_find / flat_add) on a 32-bit table and a lane's position mask
-template <int NW>
-__device__ __forceinline__ MaskN<NW> flat_find32(const LTab32 &t, const uint32_t *seq, uint32_t base, MaskN<NW> todo, uint32_t kmsk)
+template <int NW, class TAB>
+__device__ __forceinline__ MaskN<NW> flat_find32(const TAB &t, const uint32_t *seq, uint32_t base, MaskN<NW> todo, uint32_t kmsk)
 {
   MaskN<NW> hits;
 #pragma unroll
@@ -532,10 +561,10 @@ __device__ __forceinline__ MaskN<NW> flat_find32(const LTab32 &t, const uint32_t
   uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0;
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
     if (active) {
-      const uint32_t e = t.w[h];
+      const uint32_t e = t.get(h);
       int res = -2;                                                  // -2: go on probing
-      if (e == 0xFFFFFFFFu || probes > t.mask) res = -1;
-      else if (LTab::bits(t.seq, e & 0x7FFFFFFFu, t.kmsk) == code) res = (e & 0x80000000u) ? -1 : 0;
+      if (e == TAB::kEmpty || probes > t.mask) res = -1;
+      else if (LTab::bits(t.seq, e & TAB::kPos, t.kmsk) == code) res = (e & TAB::kTwice) ? -1 : 0;
       if (res == -2) { h = (h + step) & t.mask; ++probes; }
       else {
         if (res >= 0) hits.set(q);
@@ -550,8 +579,8 @@ __device__ __forceinline__ MaskN<NW> flat_find32(const LTab32 &t, const uint32_t
   return hits;
 }
 
-template <int NW>
-__device__ __forceinline__ void flat_add32(const LTab32 &t, uint32_t base, MaskN<NW> todo, int *fill = nullptr, int limit = 0)
+template <int NW, class TAB>
+__device__ __forceinline__ void flat_add32(const TAB &t, uint32_t base, MaskN<NW> todo, int *fill = nullptr, int limit = 0)
 {
   bool active = todo.any();
   uint32_t p = active ? base + todo.first() : 0u;
@@ -559,13 +588,12 @@ __device__ __forceinline__ void flat_add32(const LTab32 &t, uint32_t base, MaskN
   uint32_t h = LTab::slot_of(code, t.mask), step = LTab::step_of(code), probes = 0, nturn = 0;
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
     if (active) {
-      uint32_t *word = t.w + h;
-      const uint32_t cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t cur = t.get(h);
       bool fin = false;
-      if (cur == 0xFFFFFFFFu) {
-        fin = atomicCAS(word, 0xFFFFFFFFu, p) == 0xFFFFFFFFu;        // lost the race: look at the slot again
+      if (cur == TAB::kEmpty) {
+        fin = t.claim(h, p);                                         // lost the race: look at the slot again
         if (fin && fill) atomicAdd(fill, 1);
-      } else if (LTab::bits(t.seq, cur & 0x7FFFFFFFu, t.kmsk) == code) { if (!(cur & 0x80000000u)) atomicOr(word, 0x80000000u); fin = true; }
+      } else if (LTab::bits(t.seq, cur & TAB::kPos, t.kmsk) == code) { if (!(cur & TAB::kTwice)) t.twice(h); fin = true; }
       else { h = (h + step) & t.mask; fin = ++probes > t.mask; }
       if (fin) {
         todo.drop_first();
@@ -590,8 +618,8 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
   const int tid = threadIdx.x;
   extern __shared__ int32_t dyn_lds_[];
   uint32_t *lds = reinterpret_cast<uint32_t *>(dyn_lds_) + lds_off;
-  uint32_t *wr = lds, *w1 = wr + C::kCapRef, *w2 = wr;           // the third table takes the place of the first, which is dead by then
-  uint32_t *sr = w1 + C::kCapOther, *s1 = sr + C::kSeqWords, *s2 = s1 + C::kSeqWords;
+  uint32_t *wr = lds, *w1 = wr + C::kRefWords, *w2 = wr;         // the third table takes the place of the first, which is dead by then
+  uint32_t *sr = w1 + C::kOtherWords, *s1 = sr + C::kSeqWords, *s2 = s1 + C::kSeqWords;
   int *flag = reinterpret_cast<int *>(s2 + C::kSeqWords);
   uint32_t *bm = lds + C::kBmWord;                                // the candidates as a bitmap, for the anchor walk
   const uint32_t kmsk = (1u << (2 * k)) - 1u;
@@ -623,11 +651,12 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
   share(npr, br, cr); share(np1, b1, c1); share(np2, b2, c2);
   uint32_t lg = 0;
   while (max(max(npr, np1), np2) > (C::kPart << lg)) ++lg;
-  const LTab32 tr{wr, C::kCapRef - 1, sr, kmsk}, t1{w1, C::kCapOther - 1, s1, kmsk}, t2{w2, C::kCapOther - 1, s2, kmsk};
+  using TAB = LTabP<C::kS16>;
+  const TAB tr{wr, C::kCapRef - 1, sr, kmsk}, t1{w1, C::kCapOther - 1, s1, kmsk}, t2{w2, C::kCapOther - 1, s2, kmsk};
   __syncthreads();
   SP_STAMP(0);
   for (uint32_t part = 0; part < (1u << lg); ++part) {
-    for (uint32_t i = tid; i < C::kCapRef + C::kCapOther; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < C::kRefWords + C::kOtherWords; i += kSplitThreads) wr[i] = 0xFFFFFFFFu;
     if (tid == 0) flag[0] = 0;
     __syncthreads();
     SP_STAMP(0);
@@ -639,7 +668,7 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
     __syncthreads();
     SP_STAMP(2);
     if (flag[0] > (int)C::kFill) return false;
-    for (uint32_t i = tid; i < C::kCapOther; i += kSplitThreads) w2[i] = 0xFFFFFFFFu;   // nobody looks the reference's k-mers up any more
+    for (uint32_t i = tid; i < C::kOtherWords; i += kSplitThreads) w2[i] = 0xFFFFFFFFu;   // nobody looks the reference's k-mers up any more
     __syncthreads();
     flat_add32<NW>(t2, b2, flat_find32<NW>(t1, s2, b2, lane_positions_of<NW>(s2, b2, c2, kmsk, part, lg), kmsk));   // no more distinct k-mers than the table before holds
     __syncthreads();
@@ -1672,7 +1701,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   }
   // The batch goes to the device in up to three launches.  Reads within the small on-chip tables (12.5 kb) take the
   // kernel with the anchor arrays in LDS, two workgroups per CU; reads of up to 32,767 bases the kernel of the medium
-  // partitioned tables (78 KB of LDS, two workgroups per CU, anchor arrays in HBM); longer ones the kernel of the large
+  // partitioned tables (16-bit slots, 78 KB of LDS, two workgroups per CU, anchor arrays in HBM); longer ones the kernel of the large
   // partitioned tables (tables_long: one workgroup per CU, 153 KB of LDS), which also holds the HBM-table path for
   // what is longer still.  A PacBio batch whose lengths straddle 12.5 kb thus keeps all its reads on chip.
   // (ELECTOR_SPLIT_NO_LONG / ELECTOR_SPLIT_HBM_TABLES: one launch as before, HBM tables for the long reads;
