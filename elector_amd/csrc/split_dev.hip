@@ -549,8 +549,9 @@ __device__ __forceinline__ MaskN<NW> lane_positions_of(const uint32_t *seq, uint
 }
 
 // flat loops (see flat_find / flat_add) on a 32-bit table and a lane's position mask
-template <int NW, class TAB>
-__device__ __forceinline__ MaskN<NW> flat_find32(const TAB &t, const uint32_t *seq, uint32_t base, MaskN<NW> todo, uint32_t kmsk)
+// (found(q, position in the table's sequence) is called for every k-mer that occurs exactly once)
+template <int NW, class TAB, class Found>
+__device__ __forceinline__ MaskN<NW> flat_find32(const TAB &t, const uint32_t *seq, uint32_t base, MaskN<NW> todo, uint32_t kmsk, Found &&found)
 {
   MaskN<NW> hits;
 #pragma unroll
@@ -567,7 +568,7 @@ __device__ __forceinline__ MaskN<NW> flat_find32(const TAB &t, const uint32_t *s
       else if (LTab::bits(t.seq, e & TAB::kPos, t.kmsk) == code) res = (e & TAB::kTwice) ? -1 : 0;
       if (res == -2) { h = (h + step) & t.mask; ++probes; }
       else {
-        if (res >= 0) hits.set(q);
+        if (res >= 0) { hits.set(q); found(q, e & TAB::kPos); }
         todo.drop_first();
         active = todo.any();
         q = active ? todo.first() : 0u;
@@ -577,6 +578,11 @@ __device__ __forceinline__ MaskN<NW> flat_find32(const TAB &t, const uint32_t *s
     }
   }
   return hits;
+}
+template <int NW, class TAB>
+__device__ __forceinline__ MaskN<NW> flat_find32(const TAB &t, const uint32_t *seq, uint32_t base, MaskN<NW> todo, uint32_t kmsk)
+{
+  return flat_find32<NW>(t, seq, base, todo, kmsk, [](uint32_t, uint32_t) {});
 }
 
 template <int NW, class TAB>
@@ -674,12 +680,14 @@ __device__ bool tables_long(const WG &g, unsigned long long &sp_t_, int lds_off,
     __syncthreads();
     SP_STAMP(3);
     // candidates: the reference positions whose k-mer is unique in all three reads, with their partner positions
-    for (MaskN<NW> c = flat_find32<NW>(t2, sr, br, mine_r, kmsk); c.any(); c.drop_first()) {
-      const uint32_t p = br + c.first();
-      const uint32_t code = LTab::bits(sr, p, kmsk);
-      const int b = t2.find(code), a = t1.find(code);               // (a k-mer only enters the third table when it is unique in the second)
-      if (a >= 0 && b >= 0) { stg_global(g.ca + p, a); stg_global(g.cb + p, b); atomicOr(bm + (p >> 5), 1u << (p & 31u)); }
-    }
+    // (two flat look-ups that write the partner positions as they find them; a k-mer only enters the third table when
+    // it is unique in the second, so the second look-up finds every k-mer the first one found)
+    const MaskN<NW> in2 = flat_find32<NW>(t2, sr, br, mine_r, kmsk, [&](uint32_t q, uint32_t pos) { stg_global(g.cb + br + q, (int)pos); });
+    flat_find32<NW>(t1, sr, br, in2, kmsk, [&](uint32_t q, uint32_t pos) {
+      const uint32_t p = br + q;
+      stg_global(g.ca + p, (int)pos);
+      atomicOr(bm + (p >> 5), 1u << (p & 31u));
+    });
     __syncthreads();
     SP_STAMP(4);
   }
