@@ -226,7 +226,7 @@ def cpu_baseline(windows, ref_bases_per_window, seconds, device_msa=None):
 
 def pmc_file(profile, reads):
     """The committed PMC passes over `bench.py --serial` on this workload (profiles/pmc_traffic_<profile>.json,
-    written by tests/_pmc_traffic.py from tests/_r3_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes,
+    written by tools/_pmc_traffic.py from tools/_r3_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes,
     gfx950 correction applied, SQ_INSTS_VALU) -> (dict, provenance text); (None, None) when there is none for this
     workload and batch size.  Counters cannot be read from inside the process being measured: the bench line
     REPLAYS them and says so."""
@@ -342,6 +342,18 @@ def main():
     lu = off[3::3] - off[2:-1:3]
     dev = torch.device("cuda", local)
     d_bases = torch.from_numpy(win.bases).to(dev)
+    # the window offsets are resident in HBM like the bases (the device splitter leaves both there): the timed entry
+    # is elector_poa_batch_device_offsets, which does no per-window work on the host.  ELECTOR_BENCH_HOST_OFFSETS=1
+    # times the entry that takes them from a host array instead (A/B)
+    d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.int64)).to(dev)
+    total_bases = int(off[-1])
+    host_offsets = os.environ.get("ELECTOR_BENCH_HOST_OFFSETS", "0") not in ("", "0")
+
+    def align(engine, dc, dn, ds):
+        if host_offsets:
+            engine.align_device(d_bases, off, dc, dn, ds)
+        else:
+            engine.align_device_offsets(d_bases, d_off, n, total_bases, dc, dn, ds)
     # E engine contexts (four by default) take the steps in turn (several batches in flight: the serial head and tail
     # of one batch -- symbolize / trivial pass / list sort, merge / statistics -- run beside the
     # alignment kernels of the other).  Every context has its own output buffers.
@@ -423,7 +435,7 @@ def main():
         turn[0] += 1
         dc, dn, ds = outs[e]
         th = time.perf_counter()
-        engines[e].align_device(d_bases, off, dc, dn, ds)
+        align(engines[e], dc, dn, ds)
         pending.append((e, engines[e].msa_stats_enqueue(n, dc, dn, ds, piece_first, read_first)))
         host_s[0] += time.perf_counter() - th
         return collect() if len(pending) > n_eng else None
@@ -511,7 +523,7 @@ def main():
             if futs[e] is not None:
                 futs[e].result()                     # this context's previous step is on the host, rows included
             dc, dn, ds = outs[e]
-            engines[e].align_device(d_bases, off, dc, dn, ds)
+            align(engines[e], dc, dn, ds)
             futs[e] = pool.submit(finish_rows, e, engines[e].msa_stats_enqueue(n, dc, dn, ds, piece_first, read_first))
 
         def drain_rows():
@@ -555,7 +567,7 @@ def main():
         eng.option("chains", 1)
 
         def serial_step():
-            eng.align_device(d_bases, off, d_cols, d_ncol, d_status)
+            align(eng, d_cols, d_ncol, d_status)
             eng.msa_stats_collect(eng.msa_stats_enqueue(n, d_cols, d_ncol, d_status, piece_first, read_first))
         for _ in range(4):                       # grow the workspace, settle the clocks
             serial_step()

@@ -37,7 +37,7 @@ EXPORTS = [
     "elector_version", "elector_strerror", "elector_device_count",
     "elector_params_default", "elector_params_read",
     "elector_ctx_create", "elector_ctx_destroy", "elector_ctx_last_error",
-    "elector_poa_batch", "elector_poa_batch_device", "elector_ctx_sync",
+    "elector_poa_batch", "elector_poa_batch_device", "elector_poa_batch_device_offsets", "elector_ctx_sync",
     "elector_ctx_timing_enable", "elector_ctx_timing_read", "elector_ctx_timing_reset",
     "elector_ctx_last_po_sizes", "elector_ctx_option", "elector_ctx_keep_graph", "elector_poa_bundles",
     "elector_stats_batch", "elector_msa_stats_device", "elector_msa_stats_enqueue", "elector_msa_stats_collect",
@@ -90,6 +90,7 @@ def lib():
     L.elector_ctx_last_error.restype = C.c_char_p
     L.elector_poa_batch.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp]
     L.elector_poa_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    L.elector_poa_batch_device_offsets.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, vp]
     L.elector_ctx_sync.argtypes = [vp]
     L.elector_ctx_timing_enable.argtypes = [vp, C.c_int]
     L.elector_ctx_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]

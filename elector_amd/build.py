@@ -1,20 +1,27 @@
 """Build the HIP shared library in-tree (elector_amd/lib/libelector_poa.so).
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only
-container as well as on the GPU box.  Usage: python -m elector_amd.build [--force]
+container as well as on the GPU box.  Every source is compiled to an object of
+its own (elector_amd/lib/obj/, several at a time, only what changed) and the
+objects are linked.  Usage: python -m elector_amd.build [--force]
 """
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("poa_kernels.hip", "poa_fused.hip", "poa_pack.hip", "poa_host.hip", "stats.hip", "bundle.hip", "split_dev.hip", "splitter.cpp", "io_host.cpp", "report_host.cpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("poa_kernels.hip", "poa_fused.hip", "poa_pack.hip", "poa_classify.hip", "poa_host.hip",
+                                               "stats.hip", "bundle.hip", "split_dev.hip", "splitter.cpp", "io_host.cpp",
+                                               "report_host.cpp")]
 HDR = [os.path.join(HERE, "csrc", "poa_device.h"), os.path.join(HERE, "csrc", "ctx.h"), os.path.join(HERE, "csrc", "poa_serial.h"),
+       os.path.join(HERE, "csrc", "poa_classes.h"),
        os.path.join(ROOT, "include", "elector_poa.h"), os.path.join(ROOT, "include", "elector_stats.h"),
        os.path.join(ROOT, "include", "elector_split.h")]
 OUT = os.path.join(HERE, "lib", "libelector_poa.so")
+OBJ = os.path.join(HERE, "lib", "obj")
 POA_BIN = os.path.join(HERE, "bin", "poa")
 
 
@@ -25,30 +32,46 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
 def up_to_date():
     if not os.path.exists(OUT):
         return False
     t = os.path.getmtime(OUT)
-    return os.path.exists(POA_BIN) and all(os.path.getmtime(p) <= t for p in SRC + HDR + [os.path.join(HERE, "csrc", "poa_main.cpp")])
+    return os.path.exists(POA_BIN) and all(_mtime(p) <= t for p in SRC + HDR + [os.path.join(HERE, "csrc", "poa_main.cpp")])
 
 
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
-           "-o", OUT] + SRC
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = hipcc_path()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread",
+             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
+    extra = os.environ.get("ELECTOR_HIPCC_FLAGS", "").split()
+    newest_hdr = max(_mtime(h) for h in HDR)
+    jobs = []
+    for s in SRC:
+        o = os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o")
+        if force or _mtime(o) < max(_mtime(s), newest_hdr):
+            jobs.append([hipcc] + flags + extra + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=max(1, min(6, (os.cpu_count() or 2) - 1))) as pool:
+            list(pool.map(run, jobs))
+    objs = [os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o") for s in SRC]
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs)
     # the `poa`-compatible executable on top of the library (elector_amd/bin/poa; finds the library through its rpath)
     os.makedirs(os.path.dirname(POA_BIN), exist_ok=True)
-    cmd = [hipcc_path(), "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", POA_BIN,
-           os.path.join(HERE, "csrc", "poa_main.cpp"), "-L" + os.path.dirname(OUT), "-lelector_poa", "-Wl,-rpath,$ORIGIN/../lib"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    run([hipcc, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", POA_BIN,
+         os.path.join(HERE, "csrc", "poa_main.cpp"), "-L" + os.path.dirname(OUT), "-lelector_poa", "-Wl,-rpath,$ORIGIN/../lib"])
     return OUT
 
 

@@ -87,7 +87,8 @@ struct elector_ctx {
   // per-batch workspace
   elector::DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
       d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_fmv, d_tstate, d_tlist, d_gring,
-      d_hand, d_mvpool, d_mvbusy, d_pdesc, d_psym;
+      d_hand, d_mvpool, d_mvbusy, d_pdesc, d_psym,
+      d_bin16, d_wkey, d_acc, d_ginfo;   // device-side classification (poa_classify.hip): launch bin and size key per window, per-bin totals
   // device splitter (split_dev.hip)
   elector::DevBuf d_sp_reads, d_sp_off, d_sp_hdr, d_sp_keys, d_sp_vals, d_sp_ca, d_sp_cb, d_sp_wl, d_sp_win, d_sp_first,
       d_sp_cnt, d_sp_wfirst, d_sp_wlen, d_sp_woff, d_sp_scan, d_sp_bases, d_sp_anc;
@@ -100,6 +101,9 @@ struct elector_ctx {
   elector::HostPinned h_rows;          // merged rows on their way to msa.fa (elector_msa_records_write)
   std::vector<uint8_t> h_text;         // ... and the formatted records
   hipEvent_t h_meta_done[2] = {nullptr, nullptr};
+  elector::HostPinned h_acc, h_gen;    // per-bin totals / the generic list's windows on their way back (read after a wait)
+  elector::HostPinned h_off;           // a caller's host offsets on their way to the device
+  hipEvent_t h_off_done = nullptr;
   int h_meta_cur = 0;
   // statistics workspace
   elector::DevBuf d_st_rows, d_st_rowoff, d_st_cols, d_st_first, d_st_clips, d_st_cnt, d_st_mask, d_st_scr, d_st_dense, d_st_outoff;

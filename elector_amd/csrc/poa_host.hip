@@ -19,6 +19,7 @@
 
 #include "elector_poa.h"
 #include "poa_device.h"
+#include "poa_classes.h"
 
 namespace elector {
 void launch_symbolize(const uint8_t *in, uint8_t *out, int64_t nbytes, const DevTables *tab, hipStream_t st);
@@ -339,10 +340,13 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit,
                     &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy, &c->d_pdesc, &c->d_psym,
+                    &c->d_bin16, &c->d_wkey, &c->d_acc, &c->d_ginfo,
                     &c->d_sp_reads, &c->d_sp_off, &c->d_sp_hdr, &c->d_sp_keys, &c->d_sp_vals, &c->d_sp_ca, &c->d_sp_cb, &c->d_sp_wl,
                     &c->d_sp_win, &c->d_sp_first, &c->d_sp_cnt, &c->d_sp_wfirst, &c->d_sp_wlen, &c->d_sp_woff, &c->d_sp_scan, &c->d_sp_bases, &c->d_sp_anc};
   for (DevBuf *b : bufs) b->release();
   for (auto &s : c->st_slot) s.release();
+  c->h_acc.release(); c->h_gen.release(); c->h_off.release();
+  if (c->h_off_done) (void)hipEventDestroy(c->h_off_done);
   for (int k = 0; k < 2; ++k) {
     c->h_meta_buf[k].release();
     c->h_rows.release();
@@ -441,34 +445,9 @@ static const int64_t kWindowMovesMaxDwords = (int64_t)8 << 30;   // moves of ONE
 static const int kLeftRoundsMax = 6;                          // passes over the handed-back windows (see run_device_batch)
 static const int64_t kDeepRingBytes = (int64_t)4 << 30;       // HBM shadow rings of the deep-graph alignment #2 (k_dp2 DEEP)
 
-// fused-kernel geometry classes: G lanes per window x R rows per lane, ordered by the rows one
-// strip holds (must match ELECTOR_FUSED_CLASSES in poa_fused.hip).  A window goes to the first
-// class whose strip is at least as tall as its longer read, so few lanes idle.
-static const int kNC = 17;
-static const int kClsG[kNC] = {8, 8, 8, 8, 8, 16, 16, 16, 16, 32, 32, 32, 32, 64, 64, 64, 64};
-static const int kClsR[kNC] = {4, 5, 6, 7, 8, 5, 6, 7, 8, 5, 6, 7, 8, 5, 6, 7, 8};
-// LDS slot sizes (bytes per window): a launch bin is (geometry class, slot tier)
-static const int kNT = 61;
-static int g_tier_bytes[kNT];
-static void build_tiers()
-{
-  static std::once_flag once;
-  std::call_once(once, [] {
-    int k = 0, v = 512;
-    auto run = [&](int step, int upto) { for (; v <= upto; v += step) g_tier_bytes[k++] = v; };
-    run(128, 2048); run(256, 4096); run(512, 8192); run(1024, 16384); run(2048, 32768); run(4096, 65536); run(8192, 131072);
-  });
-}
-static const int kBins = kNC * kNT;
 static const int kPartChunk = 2048;     // list entries per block of the trivial-window partition
 // a bin with fewer windows than this joins the next larger populated slot tier of its class
 static const int64_t kMinBinWindows = std::getenv("ELECTOR_MIN_BIN") ? std::atoll(std::getenv("ELECTOR_MIN_BIN")) : 4096;
-// largest slot a class can give each of its 64/G windows (k_fused_b: 64 B table + one score ring per wave)
-static int class_max_slot(int ci)
-{
-  const int nw = 64 / kClsG[ci];
-  return ((160 * 1024 - 256 - 64 - fused_ring_bytes(kClsR[ci], 8)) / nw) & ~127;
-}
 
 static int ensure_streams(elector_ctx *c)
 {
@@ -482,12 +461,35 @@ static int ensure_streams(elector_ctx *c)
   return 0;
 }
 
-static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *off,
+// pinned staging of a caller's host offsets on their way to the device: several threads copy, one DMA follows
+static int upload_offsets(elector_ctx *c, int64_t n, const int64_t *off, hipStream_t st)
+{
+  const size_t bytes = (size_t)(3 * n + 1) * 8;
+  int rc = c->h_off.ensure(bytes) | c->d_off.ensure(bytes);
+  if (rc) return ELECTOR_E_NOMEM;
+  if (c->h_off_done) { if (hipEventSynchronize(c->h_off_done) != hipSuccess) return ELECTOR_E_HIP; }
+  else if (hipEventCreateWithFlags(&c->h_off_done, hipEventDisableTiming) != hipSuccess) return ELECTOR_E_HIP;
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(8, n / 65536));
+  auto work = [&](int t) {
+    const size_t b0 = bytes * (size_t)t / (size_t)T & ~(size_t)7, b1 = t + 1 == T ? bytes : (bytes * (size_t)(t + 1) / (size_t)T & ~(size_t)7);
+    std::memcpy(c->h_off.as<uint8_t>() + b0, reinterpret_cast<const uint8_t *>(off) + b0, b1 - b0);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &x : th) x.join();
+  if (hipMemcpyAsync(c->d_off.p, c->h_off.p, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ELECTOR_E_HIP;
+  if (hipEventRecord(c->h_off_done, st) != hipSuccess) return ELECTOR_E_HIP;
+  return 0;
+}
+
+// d_off: the 3n + 1 window offsets in DEVICE memory (c->d_off itself, or a caller's array that is copied there: the
+// merge / statistics stage and the bundle search read the last batch's offsets from the context)
+static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *d_off, int64_t total,
                             uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status, int32_t *d_scores)
 {
   if (n == 0) { c->last_n = 0; c->last_total = 0; c->graph_valid = false; return ELECTOR_OK; }
-  const int64_t total = off[3 * n];
-  if (off[0] != 0 || total < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
+  if (total < 0) return fail(c, ELECTOR_E_INVAL, "negative total");
   const bool use_fused = !c->gen && !std::getenv("ELECTOR_NO_FUSED");
   // alignment #1 without a dynamic program for windows whose corrected sequence equals the reference:
   // valid when the diagonal is strictly best (see k_trivial)
@@ -499,47 +501,23 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const bool use_pack = use_trivial && !std::getenv("ELECTOR_NO_PACK") && !c->keep_graph && c->kp.open_x == c->kp.open_y &&
                         c->kp.ext_x == c->kp.ext_y && c->kp.match == 0;
 
-  // ---- host metadata ----
   const bool host_prof = std::getenv("ELECTOR_DEBUG_HOST") != nullptr;
   auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
   const double tp0 = now_ms();
-  c->h_meta_cur ^= 1;
-  elector::HostPinned &h_meta = c->h_meta_buf[c->h_meta_cur];
-  hipEvent_t &h_done = c->h_meta_done[c->h_meta_cur];
-  if (!h_done) HIPCHK(c, hipEventCreateWithFlags(&h_done, hipEventDisableTiming));
-  else HIPCHK(c, hipEventSynchronize(h_done));                     // the copies of the batch before last have run
-  const size_t part_chunks_max = (size_t)n / kPartChunk + kBins + 1;
-  const size_t meta_bytes = (size_t)n * (4 + 8 + 8 + 4 + 4) + (size_t)(3 * n + 1) * 8 + (size_t)kBins * 24 +
-                            part_chunks_max * 16 + 64;
-  int rc = h_meta.ensure(meta_bytes);
-  if (!rc && c->h_meta_buf[c->h_meta_cur ^ 1].cap < meta_bytes) {
-    // grow the other buffer now too (a pipelined caller's next batch must not pay for it); it may
-    // still feed pending copies, so wait for them first
-    if (c->h_meta_done[c->h_meta_cur ^ 1]) HIPCHK(c, hipEventSynchronize(c->h_meta_done[c->h_meta_cur ^ 1]));
-    rc = c->h_meta_buf[c->h_meta_cur ^ 1].ensure(meta_bytes);
-  }
-  if (rc) return fail(c, rc, "pinned metadata");
-  int64_t *h_off = h_meta.as<int64_t>();                           // copy of off[]: the caller's array may be pageable
-  int32_t *h_status = reinterpret_cast<int32_t *>(h_off + 3 * n + 1);
-  int64_t *h_mv1 = reinterpret_cast<int64_t *>(h_status + n + (n & 1));
-  int64_t *h_mv2 = h_mv1 + n;
-  uint32_t *h_generic = reinterpret_cast<uint32_t *>(h_mv2 + n);   // generic-path windows, processing order
-  uint32_t *h_list = h_generic + n;                                // fused classes, concatenated
-  int64_t *h_bins = reinterpret_cast<int64_t *>(h_list + n);   // (first, count) of every occupied fused bin
-  int64_t *h_chunks = h_bins + 2 * kBins;                      // partition chunks: first, (len | bin << 32)
-  int32_t *h_bin_chunks = reinterpret_cast<int32_t *>(h_chunks + 2 * part_chunks_max);   // first chunk, #chunks per bin
+  hipStream_t st = c->stream;
 
-  // window sizes -> status, coarse size key (counting sort, largest first), launch class
-  const int host_threads_max = std::getenv("ELECTOR_HOST_THREADS") ? std::max(1, std::atoi(std::getenv("ELECTOR_HOST_THREADS"))) : 16;
-  constexpr int NB = 256;
-  build_tiers();
-  std::vector<int16_t> bin((size_t)n, -1);
-  int64_t key_cnt[NB + 1] = {0}, n_generic = 0;
-  int64_t left_worst = 0;        // moves (dwords) of alignment #2 if every fused-routed window were handed back
-  int64_t max_po_bound = 0;      // largest Lr + Lc of the batch (bounds |PO| and with it a strip's steps)
-  std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)6 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc, k_poa's slot need
-  int64_t *bin_max_lr = bin_need_a.data() + kBins, *bin_max_lc = bin_max_lr + kBins, *bin_max_lu = bin_max_lc + kBins,
-          *bin_max_po = bin_max_lu + kBins, *bin_need_pack = bin_max_po + kBins;
+  // ---- per-window bookkeeping on the device (poa_classify.hip): status, launch class, size key; the host reads
+  // back the per-class totals only ----
+  const size_t part_chunks_max = (size_t)n / kPartChunk + kBins + 1;
+  const size_t acc_ints = (size_t)kAccRows * kBins + 8;                      // + four 64-bit totals
+  int rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_bin16.ensure((size_t)n * 2 + 64) | c->d_wkey.ensure((size_t)n + 64) |
+           c->d_acc.ensure(acc_ints * 4 + (size_t)kSortDestMax * kKeys * 4 + (size_t)(kBins + 2) * 2 + (size_t)kSortDestMax * 8 + 256) |
+           c->d_perm.ensure((size_t)n * 4 + 64) | c->d_mv1.ensure((size_t)n * 8) | c->d_mv2.ensure((size_t)n * 8) |
+           c->d_list.ensure((size_t)3 * n * 4 + (size_t)kBins * 32 + part_chunks_max * (16 + 4 * (size_t)partition_buckets()) + 64) |
+           c->h_acc.ensure(acc_ints * 4 + 64);
+  if (rc) return fail(c, ELECTOR_E_NOMEM, "classification workspace");
+  if (d_off != c->d_off.as<int64_t>())
+    HIPCHK(c, hipMemcpyAsync(c->d_off.p, d_off, (size_t)(3 * n + 1) * 8, hipMemcpyDeviceToDevice, st));
   int pen_abs_max = 1;                       // largest |score| or gap penalty of the parameter set
   for (int i = 0; i < c->params.nsymbol; ++i)
     for (int j = 0; j < c->params.nsymbol; ++j) pen_abs_max = std::max(pen_abs_max, std::abs(c->params.score[i][j]));
@@ -549,122 +527,36 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   for (int ci = 0; ci < kNC; ++ci) cls_max_slot[ci] = class_max_slot(ci);
   // testing knob: every window into one geometry class (multi-strip paths of the small classes)
   const int force_cls = std::getenv("ELECTOR_FORCE_CLASS") ? std::atoi(std::getenv("ELECTOR_FORCE_CLASS")) : -1;
-  std::vector<uint8_t> wkey((size_t)n);
-  std::atomic<int> bad_offsets(0);
+  int32_t *d_acc = c->d_acc.as<int32_t>();
+  uint32_t *d_hist = reinterpret_cast<uint32_t *>(d_acc + acc_ints);
+  int64_t *d_dest_first = reinterpret_cast<int64_t *>(d_hist + (size_t)kSortDestMax * kKeys);
+  int16_t *d_dest_of = reinterpret_cast<int16_t *>(d_dest_first + kSortDestMax);
   {
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads_max, n / 32768));
-    // per thread: size keys, bin counts, generic count, then per bin the maxima of
-    // alignment #1's slot need, Lr, Lc, Lu and Lr + Lc (the bound on |PO|)
-    std::vector<std::vector<int64_t>> tcnt((size_t)T, std::vector<int64_t>(NB + kBins + 1 + 6 * kBins + 2, 0));
-    struct Memo { uint32_t key; int16_t bin; int32_t need_a, need_pack; };
-    constexpr size_t kMemo = 8192;
-    auto work = [&](int t) {
-      const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
-      int64_t *cnt = tcnt[(size_t)t].data();
-      std::vector<Memo> memo(kMemo, Memo{0u, -1, 0, 0});
-      std::memcpy(h_off + 3 * w0, off + 3 * w0, (size_t)(3 * (w1 - w0) + (w1 == n ? 1 : 0)) * 8);
-      for (int64_t w = w0; w < w1; ++w) {
-        const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
-                      lu = off[3 * w + 3] - off[3 * w + 2];
-        int st = ELECTOR_W_OK;
-        if (lr < 0 || lc < 0 || lu < 0) { bad_offsets.store(1); continue; }
-        if (lr == 0 || lc == 0 || lu == 0) st = ELECTOR_W_EMPTY;
-        else if (lr > ELECTOR_MAX_SEQ || lc > ELECTOR_MAX_SEQ || lu > ELECTOR_MAX_SEQ ||
-                 (int64_t)pen_abs_max * (lr + lc + lu + 4) >= ((int64_t)1 << 24) ||
-                 (int64_t)n_strips((int)lc) * mv_tw((int)lr) * 64 + (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64 >
-                     kWindowMovesMaxDwords)
-          st = ELECTOR_W_TOOLONG;
-        h_status[w] = st;
-        h_mv1[w] = h_mv2[w] = -1;
-        // the class search below depends on the three lengths only, and the splitter's windows repeat the same few
-        // thousand length triples over and over: a small direct-mapped memo per thread
-        const bool memo_ok = !st && use_fused && lr < 1024 && lc < 1024 && lu < 1024;
-        const uint32_t mkey = memo_ok ? (uint32_t)((lr << 20) | (lc << 10) | lu) + 1u : 0u;
-        Memo &me = memo[(size_t)((mkey * 2654435761u) >> 19) & (kMemo - 1)];
-        if (memo_ok && me.key == mkey) {
-          if (me.bin >= 0) {
-            bin[(size_t)w] = me.bin;
-            int64_t *mx = cnt + NB + kBins + 1 + me.bin;
-            mx[0] = std::max<int64_t>(mx[0], me.need_a);
-            mx[kBins] = std::max<int64_t>(mx[kBins], lr);
-            mx[2 * kBins] = std::max<int64_t>(mx[2 * kBins], lc);
-            mx[3 * kBins] = std::max<int64_t>(mx[3 * kBins], lu);
-            mx[4 * kBins] = std::max<int64_t>(mx[4 * kBins], lr + lc);
-            mx[5 * kBins] = std::max<int64_t>(mx[5 * kBins], me.need_pack);
-          }
-        } else
-        if (!st && use_fused) {
-          // one class for both fused kernels; |PO| is not known yet: typical growth estimate, windows
-          // whose graph turns out larger are handed back by the device (k_left_b)
-          const int rows = (int)std::max(lc, lu);
-          int c0 = 0;
-          while (c0 < kNC - 1 && kClsG[c0] * kClsR[c0] < rows) ++c0;
-          if (force_cls >= 0 && force_cls < kNC) c0 = force_cls;
-          for (int ci = c0; ci < kNC && bin[(size_t)w] < 0; ++ci) {
-            const int G = kClsG[ci], R = kClsR[ci];
-            // k_fused_b's 16-bit ring cells hold scores up to about +-16000 (it hands larger windows back)
-            if (score_span(c->kp, lr + lr / 16 + 6 + G, ((lu + G * R - 1) / (G * R)) * (int64_t)(G * R)) >= 16000) continue;
-            const int need_a = fused_a_slot_need((int)lr, (int)lc, G, R);
-            const int need = std::max(need_a, fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G, R));
-            if (need > cls_max_slot[ci]) {
-              if (force_cls >= 0) break;
-              continue;                                                    // a class with fewer windows per wave has larger slots
-            }
-            const int t = (int)(std::lower_bound(g_tier_bytes, g_tier_bytes + kNT, need) - g_tier_bytes);
-            if (t >= kNT) break;
-            if (g_tier_bytes[t] > cls_max_slot[ci]) {
-              if (force_cls >= 0) break;
-              continue;
-            }
-            const int b = ci * kNT + t;
-            bin[(size_t)w] = (int16_t)b;
-            int64_t *mx = cnt + NB + kBins + 1 + b;         // alignment #1 needs less than the class slot
-            mx[0] = std::max<int64_t>(mx[0], need_a);
-            mx[kBins] = std::max<int64_t>(mx[kBins], lr);
-            mx[2 * kBins] = std::max<int64_t>(mx[2 * kBins], lc);
-            mx[3 * kBins] = std::max<int64_t>(mx[3 * kBins], lu);
-            mx[4 * kBins] = std::max<int64_t>(mx[4 * kBins], lr + lc);
-            const int need_pack = poa_slot_need((int)lr, (int)lc, (int)lu, G);
-            mx[5 * kBins] = std::max<int64_t>(mx[5 * kBins], need_pack);
-            if (memo_ok) { me.key = mkey; me.bin = (int16_t)b; me.need_a = need_a; me.need_pack = need_pack; }
-          }
-          if (memo_ok && bin[(size_t)w] < 0) { me.key = mkey; me.bin = -1; me.need_a = 0; me.need_pack = 0; }
-        }
-        if (bin[(size_t)w] >= 0) {
-          cnt[NB + bin[(size_t)w]]++;
-          // moves the generic alignment #2 needs if the fused kernels hand this window back
-          cnt[NB + kBins + 1 + 6 * kBins] += (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64;
-        } else cnt[NB + kBins]++;                         // generic (incl. failed windows)
-        if (!st) cnt[NB + kBins + 2 + 6 * kBins] = std::max(cnt[NB + kBins + 2 + 6 * kBins], lr + lc);
-        // Size key of the lists (largest first).  Inside a geometry class the rows per lane are fixed and a
-        // wavefront runs for as many steps as its longest window has columns: the exact reference length as the
-        // key makes the wavefronts of a list homogeneous in steps (the device's stable partition by the
-        // trivial-window key keeps this order inside each of its buckets).  Long windows share keys 16 apart;
-        // with ELECTOR_SORT_COARSE the key is max(Lr, Lu) / 8 as up to round 2 (A/B).
-        static const bool coarse = std::getenv("ELECTOR_SORT_COARSE") != nullptr;
-        int k = coarse ? (int)(std::max(lr, lu) >> 3) : lr < 192 ? (int)lr : 192 + (int)std::min<int64_t>(63, (lr - 192) >> 4);
-        if (k >= NB) k = NB - 1;
-        wkey[(size_t)w] = (uint8_t)(NB - 1 - k);
-        cnt[NB - 1 - k]++;
-      }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-    for (int t = 0; t < T; ++t) {
-      for (int k = 0; k < NB; ++k) key_cnt[k + 1] += tcnt[(size_t)t][(size_t)k];
-      for (int b = 0; b < kBins; ++b) bin_cnt[b] += tcnt[(size_t)t][(size_t)(NB + b)];
-      n_generic += tcnt[(size_t)t][(size_t)(NB + kBins)];
-      for (int b = 0; b < 6 * kBins; ++b) bin_need_a[b] = std::max(bin_need_a[b], tcnt[(size_t)t][(size_t)(NB + kBins + 1 + b)]);
-      left_worst += tcnt[(size_t)t][(size_t)(NB + kBins + 1 + 6 * kBins)];
-      max_po_bound = std::max(max_po_bound, tcnt[(size_t)t][(size_t)(NB + kBins + 2 + 6 * kBins)]);
-    }
+    HIPCHK(c, hipMemsetAsync(d_acc, 0, acc_ints * 4 + (size_t)kSortDestMax * kKeys * 4, st));
+    ClassifyArgs ca;
+    ca.n = n; ca.total = total; ca.off = c->d_off.as<int64_t>(); ca.kp = c->kp; ca.pen_abs_max = pen_abs_max;
+    ca.use_fused = use_fused ? 1 : 0; ca.force_cls = force_cls;
+    ca.coarse = std::getenv("ELECTOR_SORT_COARSE") ? 1 : 0;
+    ca.window_moves_max = kWindowMovesMaxDwords;
+    ca.status = d_status; ca.bin = c->d_bin16.as<int16_t>(); ca.wkey = c->d_wkey.as<uint8_t>();
+    ca.acc = d_acc; ca.glob = reinterpret_cast<unsigned long long *>(d_acc + (size_t)kAccRows * kBins);
+    timed_begin(c, 2, st);
+    launch_classify(ca, st);
+    timed_end(c, st);
+    HIPCHK(c, hipMemcpyAsync(c->h_acc.p, d_acc, acc_ints * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
   }
-  if (bad_offsets.load()) return fail(c, ELECTOR_E_INVAL, "offsets must be non-decreasing");
   const double tp1 = now_ms();
-  for (int k = 0; k < NB; ++k) key_cnt[k + 1] += key_cnt[k];
-  // stable placement in descending size order, per destination list
+  const int32_t *h_acc = c->h_acc.as<int32_t>();
+  const unsigned long long *h_glob = reinterpret_cast<const unsigned long long *>(h_acc + (size_t)kAccRows * kBins);
+  if (h_glob[3]) return fail(c, ELECTOR_E_INVAL, "offsets must start at 0, be non-decreasing and end at the total");
+  const int64_t n_generic = (int64_t)h_glob[0];
+  const int64_t left_worst = (int64_t)h_glob[1];     // moves (dwords) of alignment #2 if every fused-routed window were handed back
+  const int64_t max_po_bound = (int64_t)h_glob[2];   // largest Lr + Lc of the batch (bounds |PO| and with it a strip's steps)
+  std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)6 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc, k_poa's slot need
+  int64_t *bin_max_lr = bin_need_a.data() + kBins, *bin_max_lc = bin_max_lr + kBins, *bin_max_lu = bin_max_lc + kBins,
+          *bin_max_po = bin_max_lu + kBins, *bin_need_pack = bin_max_po + kBins;
+  std::vector<int16_t> bin_final((size_t)kBins);
   // Launches are expensive in tails and ramps (measured: one launch per geometry class is 7 % faster
   // than one per 4096-window slot tier, and a handful of tiny extra launches costs 8 %), so:
   //  * a geometry class with few windows joins the next class of its group size (more rows per lane
@@ -672,116 +564,141 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   //  * a class becomes ONE bin with its largest needed slot (a larger slot always fits the smaller
   //    needs) unless that is more than 1.5x what 98 % of its windows need -- then those 98 % form the
   //    main bin and the outliers keep their own tiers, sparse ones joining the next larger populated one.
-  std::vector<int16_t> bin_final((size_t)kBins);
-  for (int b = 0; b < kBins; ++b) bin_final[(size_t)b] = (int16_t)b;
-  auto merge_into = [&](int b, int into) {
-    bin_cnt[(size_t)into] += bin_cnt[(size_t)b];
-    for (int q = 0; q < 6; ++q)
-      bin_need_a[(size_t)(q * kBins + into)] = std::max(bin_need_a[(size_t)(q * kBins + into)], bin_need_a[(size_t)(q * kBins + b)]);
-    bin_cnt[(size_t)b] = 0;
-    for (int x = 0; x < kBins; ++x) if (bin_final[(size_t)x] == b) bin_final[(size_t)x] = (int16_t)into;
+  // (min_bin grows until the batch has no more lists than the device sort takes.)
+  auto decide_bins = [&](int64_t min_bin) {
+    for (int b = 0; b < kBins; ++b) {
+      bin_cnt[(size_t)b] = h_acc[b];
+      for (int q = 0; q < 6; ++q) bin_need_a[(size_t)(q * kBins + b)] = h_acc[(size_t)(q + 1) * kBins + b];
+      bin_final[(size_t)b] = (int16_t)b;
+    }
+    auto merge_into = [&](int b, int into) {
+      bin_cnt[(size_t)into] += bin_cnt[(size_t)b];
+      for (int q = 0; q < 6; ++q)
+        bin_need_a[(size_t)(q * kBins + into)] = std::max(bin_need_a[(size_t)(q * kBins + into)], bin_need_a[(size_t)(q * kBins + b)]);
+      bin_cnt[(size_t)b] = 0;
+      for (int x = 0; x < kBins; ++x) if (bin_final[(size_t)x] == b) bin_final[(size_t)x] = (int16_t)into;
+    };
+    for (int ci = 0; ci + 1 < kNC; ++ci) {
+      if (cls_G(ci + 1) != cls_G(ci)) continue;
+      int64_t tot = 0;
+      for (int t = 0; t < kNT; ++t) tot += bin_cnt[(size_t)(ci * kNT + t)];
+      if (!tot || tot >= min_bin / 2) continue;
+      for (int t = 0; t < kNT; ++t)
+        if (bin_cnt[(size_t)(ci * kNT + t)] && tier_bytes(t) <= cls_max_slot[ci + 1]) merge_into(ci * kNT + t, (ci + 1) * kNT + t);
+    }
+    for (int ci = 0; ci < kNC; ++ci) {
+      int64_t tot = 0, acc = 0;
+      int t_max = -1;
+      for (int t = 0; t < kNT; ++t) { tot += bin_cnt[(size_t)(ci * kNT + t)]; if (bin_cnt[(size_t)(ci * kNT + t)]) t_max = t; }
+      if (!tot) continue;
+      int t_main = t_max;
+      for (int t = 0; t < kNT; ++t) {
+        acc += bin_cnt[(size_t)(ci * kNT + t)];
+        if (acc * 50 >= tot * 49) { t_main = t; break; }
+      }
+      if (2 * tier_bytes(t_max) <= 3 * tier_bytes(t_main)) t_main = t_max;
+      int into = -1;                                     // nearest larger tier that stays a launch
+      for (int t = kNT - 1; t > t_main; --t) {
+        const int b = ci * kNT + t;
+        if (!bin_cnt[(size_t)b]) continue;
+        if (into >= 0 && bin_cnt[(size_t)b] < min_bin) merge_into(b, into);
+        else into = b;
+      }
+      for (int t = 0; t < t_main; ++t)
+        if (bin_cnt[(size_t)(ci * kNT + t)]) merge_into(ci * kNT + t, ci * kNT + t_main);
+    }
+    int lists = 0;
+    for (int b = 0; b < kBins; ++b) lists += bin_cnt[(size_t)b] != 0;
+    return lists;
   };
-  for (int ci = 0; ci + 1 < kNC; ++ci) {
-    if (kClsG[ci + 1] != kClsG[ci]) continue;
-    int64_t total = 0;
-    for (int t = 0; t < kNT; ++t) total += bin_cnt[(size_t)(ci * kNT + t)];
-    if (!total || total >= kMinBinWindows / 2) continue;
-    for (int t = 0; t < kNT; ++t)
-      if (bin_cnt[(size_t)(ci * kNT + t)] && g_tier_bytes[t] <= cls_max_slot[ci + 1]) merge_into(ci * kNT + t, (ci + 1) * kNT + t);
-  }
-  for (int ci = 0; ci < kNC; ++ci) {
-    int64_t total = 0, acc = 0;
-    int t_max = -1;
-    for (int t = 0; t < kNT; ++t) { total += bin_cnt[(size_t)(ci * kNT + t)]; if (bin_cnt[(size_t)(ci * kNT + t)]) t_max = t; }
-    if (!total) continue;
-    int t_main = t_max;
-    for (int t = 0; t < kNT; ++t) {
-      acc += bin_cnt[(size_t)(ci * kNT + t)];
-      if (acc * 50 >= total * 49) { t_main = t; break; }
-    }
-    if (2 * g_tier_bytes[t_max] <= 3 * g_tier_bytes[t_main]) t_main = t_max;
-    int into = -1;                                     // nearest larger tier that stays a launch
-    for (int t = kNT - 1; t > t_main; --t) {
-      const int b = ci * kNT + t;
-      if (!bin_cnt[(size_t)b]) continue;
-      if (into >= 0 && bin_cnt[(size_t)b] < kMinBinWindows) merge_into(b, into);
-      else into = b;
-    }
-    for (int t = 0; t < t_main; ++t)
-      if (bin_cnt[(size_t)(ci * kNT + t)]) merge_into(ci * kNT + t, ci * kNT + t_main);
+  {
+    int64_t min_bin = kMinBinWindows;
+    while (decide_bins(min_bin) + 1 > kSortDestMax) min_bin = min_bin < ((int64_t)1 << 40) ? min_bin * 8 : min_bin;   // ends: at most two bins per class are left
   }
   std::vector<int64_t> bin_first((size_t)kBins + 1);
   bin_first[0] = 0;
   for (int b = 0; b < kBins; ++b) bin_first[(size_t)b + 1] = bin_first[(size_t)b] + bin_cnt[(size_t)b];
+
+  // ---- the small tables of this batch in pinned memory (double-buffered: the copies are asynchronous) ----
+  c->h_meta_cur ^= 1;
+  elector::HostPinned &h_meta = c->h_meta_buf[c->h_meta_cur];
+  hipEvent_t &h_done = c->h_meta_done[c->h_meta_cur];
+  if (!h_done) HIPCHK(c, hipEventCreateWithFlags(&h_done, hipEventDisableTiming));
+  else HIPCHK(c, hipEventSynchronize(h_done));                     // the copies of the batch before last have run
+  const size_t meta_bytes = (size_t)kBins * 24 + part_chunks_max * 16 + (size_t)(kBins + 2) * 2 + (size_t)kSortDestMax * 8 + 256;
+  rc = h_meta.ensure(meta_bytes);
+  if (rc) return fail(c, rc, "pinned metadata");
+  int64_t *h_bins = h_meta.as<int64_t>();                      // (first, count) of every occupied fused bin
+  int64_t *h_chunks = h_bins + 2 * kBins;                      // partition chunks: first, (len | bin << 32)
+  int64_t *h_dest_first = h_chunks + 2 * part_chunks_max;
+  int32_t *h_bin_chunks = reinterpret_cast<int32_t *>(h_dest_first + kSortDestMax);   // first chunk, #chunks per bin
+  int16_t *h_dest_of = reinterpret_cast<int16_t *>(h_bin_chunks + 2 * kBins);
+
+  // ---- the lists: counting sort of the windows by (list, size key) on the device ----
+  uint32_t *d_generic = c->d_perm.as<uint32_t>();
+  uint32_t *d_lists = c->d_list.as<uint32_t>();
   {
-    // parallel stable counting sort of the windows by (destination list, size key): every thread counts
-    // its contiguous range, the counts are scanned destination-major / key / thread, every thread places
-    // its range.  Destination = a launch bin's list, or the generic-path list.
+    int ndest = 0;
     std::vector<int> dest_of_bin((size_t)kBins, -1);
-    std::vector<int64_t> dest_first;
     for (int b = 0; b < kBins; ++b)
-      if (bin_cnt[(size_t)b]) { dest_of_bin[(size_t)b] = (int)dest_first.size(); dest_first.push_back(bin_first[(size_t)b]); }
-    const int gen_dest = (int)dest_first.size(), nbuckets = (gen_dest + 1) * NB;
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads_max, n / 32768));
-    std::vector<std::vector<int64_t>> cnt((size_t)T, std::vector<int64_t>((size_t)nbuckets, 0));
-    auto dest = [&](int64_t w) { const int b = bin[(size_t)w]; return b >= 0 ? dest_of_bin[(size_t)bin_final[(size_t)b]] : gen_dest; };
-    auto pass = [&](int t, bool place) {
-      const int64_t w0 = n * t / T, w1 = n * (t + 1) / T;
-      int64_t *my = cnt[(size_t)t].data();
-      for (int64_t w = w0; w < w1; ++w) {
-        const int dd = dest(w);
-        int64_t &slot = my[dd * NB + wkey[(size_t)w]];
-        if (!place) { ++slot; continue; }
-        const int64_t pos = slot++;
-        if (dd == gen_dest) h_generic[pos] = (uint32_t)w;
-        else h_list[dest_first[(size_t)dd] + pos] = (uint32_t)w;
-      }
-    };
-    auto run = [&](bool place) {
-      std::vector<std::thread> th;
-      for (int t = 1; t < T; ++t) th.emplace_back(pass, t, place);
-      pass(0, place);
-      for (auto &x : th) x.join();
-    };
-    run(false);
-    for (int dd = 0; dd <= gen_dest; ++dd) {
-      int64_t at = 0;
-      for (int k = 0; k < NB; ++k)
-        for (int t = 0; t < T; ++t) { int64_t &v = cnt[(size_t)t][(size_t)(dd * NB + k)]; const int64_t c0 = v; v = at; at += c0; }
-    }
-    run(true);
+      if (bin_cnt[(size_t)b]) { dest_of_bin[(size_t)b] = ndest; h_dest_first[ndest++] = bin_first[(size_t)b]; }
+    h_dest_first[ndest] = 0;                                            // the generic list, an array of its own
+    for (int b = 0; b < kBins; ++b) h_dest_of[b] = (int16_t)std::max(0, dest_of_bin[(size_t)bin_final[(size_t)b]]);
+    h_dest_of[kBins] = (int16_t)ndest;
+    HIPCHK(c, hipMemcpyAsync(d_dest_of, h_dest_of, (size_t)(kBins + 1) * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_dest_first, h_dest_first, (size_t)(ndest + 1) * 8, hipMemcpyHostToDevice, st));
+    SortArgs sa;
+    sa.n = n; sa.bin = c->d_bin16.as<int16_t>(); sa.wkey = c->d_wkey.as<uint8_t>(); sa.dest_of = d_dest_of; sa.ndest = ndest + 1;
+    sa.hist = d_hist; sa.dest_first = d_dest_first; sa.lists = d_lists; sa.generic = d_generic;
+    timed_begin(c, 2, st);
+    if (launch_sort(sa, st)) return fail(c, ELECTOR_E_HIP, "list sort");
+    timed_end(c, st);
   }
   if (std::getenv("ELECTOR_DEBUG_BINS")) {
-    int64_t nbad = 0;
-    for (int64_t w = 0; w < n; ++w) nbad += h_status[w] != 0;
-    std::fprintf(stderr, "[elector] windows refused by the host checks: %lld\n", (long long)nbad);
     std::fprintf(stderr, "[elector] n=%lld generic=%lld classes:", (long long)n, (long long)n_generic);
     for (int b = 0; b < kBins; ++b)
       if (bin_cnt[(size_t)b])
-        std::fprintf(stderr, " G%dxR%d/%d:%lld", kClsG[b / kNT], kClsR[b / kNT], g_tier_bytes[b % kNT], (long long)bin_cnt[(size_t)b]);
+        std::fprintf(stderr, " G%dxR%d/%d:%lld", cls_G(b / kNT), cls_R(b / kNT), tier_bytes(b % kNT), (long long)bin_cnt[(size_t)b]);
     std::fprintf(stderr, "\n");
   }
   const double tp2 = now_ms();
-  // moves scratch of the generic-path windows, in chunks
+  // moves scratch of the generic-path windows, in chunks.  The generic list is short on the shipped parameters (windows
+  // no fused class takes); the host reads its windows' lengths back, lays their moves out and sends the offsets
+  // down again.  Every other window's entry stays -1.
   struct Chunk { int64_t k0, k1, dwords; };
   std::vector<Chunk> chunks;
-  {
+  HIPCHK(c, hipMemsetAsync(c->d_mv1.p, 0xFF, (size_t)n * 8, st));
+  HIPCHK(c, hipMemsetAsync(c->d_mv2.p, 0xFF, (size_t)n * 8, st));
+  const int32_t *g_info = nullptr;                     // per generic-list entry: Lr, Lc, Lu, status
+  std::vector<uint32_t> g_list;                        // ... and its window
+  if (n_generic) {
+    if (c->h_gen.ensure((size_t)n_generic * (16 + 16) + 64) || c->d_ginfo.ensure((size_t)n_generic * (16 + 16) + 64))
+      return fail(c, ELECTOR_E_NOMEM, "generic-list staging");
+    int32_t *d_info = c->d_ginfo.as<int32_t>();
+    int64_t *d_gmv = reinterpret_cast<int64_t *>(d_info + 4 * n_generic);
+    launch_generic_info(d_generic, n_generic, c->d_off.as<int64_t>(), d_status, d_info, st);
+    HIPCHK(c, hipMemcpyAsync(c->h_gen.p, d_info, (size_t)n_generic * 16, hipMemcpyDeviceToHost, st));
+    g_list.resize((size_t)n_generic);
+    HIPCHK(c, hipMemcpyAsync(g_list.data(), d_generic, (size_t)n_generic * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    g_info = c->h_gen.as<int32_t>();
+    int64_t *h_gmv = reinterpret_cast<int64_t *>(c->h_gen.as<int32_t>() + 4 * n_generic);
     int64_t k0 = 0, acc = 0;
     for (int64_t k = 0; k < n_generic; ++k) {
-      const int64_t w = h_generic[k];
       int64_t d1 = 0, d2 = 0;
-      if (!h_status[w]) {
-        const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1],
-                      lu = off[3 * w + 3] - off[3 * w + 2];
+      if (!g_info[4 * k + 3]) {
+        const int64_t lr = g_info[4 * k], lc = g_info[4 * k + 1], lu = g_info[4 * k + 2];
         d1 = (int64_t)n_strips((int)lc) * mv_tw((int)lr) * 64;
         d2 = (int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64;   // |PO| <= Lr + Lc
       }
       if (acc + d1 + d2 > kMovesBudgetDwords && k > k0) { chunks.push_back({k0, k, acc}); k0 = k; acc = 0; }
-      h_mv1[w] = acc; acc += d1;
-      h_mv2[w] = acc; acc += d2;
+      h_gmv[2 * k] = acc; acc += d1;
+      h_gmv[2 * k + 1] = acc; acc += d2;
     }
     chunks.push_back({k0, n_generic, acc});
-  }
+    HIPCHK(c, hipMemcpyAsync(d_gmv, h_gmv, (size_t)n_generic * 16, hipMemcpyHostToDevice, st));
+    launch_generic_moves(d_generic, n_generic, d_gmv, c->d_mv1.as<int64_t>(), c->d_mv2.as<int64_t>(), st);
+  } else chunks.push_back({0, 0, 0});
   int64_t max_dwords = 0;
   for (auto &ch : chunks) max_dwords = std::max(max_dwords, ch.dwords);
   // Windows the fused kernels hand back get their moves from a device-side bump allocator.  Its budget covers
@@ -802,12 +719,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // blocks of the k_fused_a / k_fused_b launches of a bin: one per 64 / G windows -- behind k_poa they only see
   // the windows it handed back (a device-built list), with a grid of a sixteenth and a loop inside
   auto old_grid = [&](int b) {
-    const int G = kClsG[b / kNT];
+    const int G = cls_G(b / kNT);
     const int64_t full = (bin_cnt[(size_t)b] + 64 / G - 1) / (64 / G);
     return use_pack ? std::min<int64_t>(full, std::max<int64_t>(256, full / 16)) : full;
   };
   auto fmv_geom = [&](int b, bool second, int *tw, int *ns) {
-    const int G = kClsG[b / kNT], R = kClsR[b / kNT];
+    const int G = cls_G(b / kNT), R = cls_R(b / kNT);
     *tw = (int)(second ? bin_max_po[b] : bin_max_lr[b]) + G;
     *ns = (int)(((second ? bin_max_lu[b] : bin_max_lc[b]) + G * R - 1) / (G * R));
     const int64_t blocks = old_grid(b);
@@ -816,10 +733,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // k_poa: LDS slot, moves geometry and scratch-slot pool of a bin
   struct PackGeom { int slot, tw, slots; int64_t pool_words; };
   auto pack_geom = [&](int b) {
-    const int G = kClsG[b / kNT], nw = 2 * (64 / G);
+    const int G = cls_G(b / kNT), nw = 2 * (64 / G);
     PackGeom pg;
     const int max_slot = ((160 * 1024 - 256 - 64) / nw) & ~15;
-    pg.slot = (int)std::min<int64_t>(max_slot, (bin_need_pack[b] + 15) & ~(int64_t)15);
+    // ELECTOR_POA_SLOT_PCT (experiment): the slot inflated to that many percent -- what the occupancy is worth
+    static const int slot_pct = std::getenv("ELECTOR_POA_SLOT_PCT") ? std::max(100, std::atoi(std::getenv("ELECTOR_POA_SLOT_PCT"))) : 100;
+    pg.slot = (int)std::min<int64_t>(max_slot, ((bin_need_pack[b] * slot_pct / 100) + 15) & ~(int64_t)15);
     pg.tw = (int)bin_max_po[b] + 8 + G + 4;
     const int lds_block = 64 + nw * pg.slot;
     const int waves_cu = std::max(1, std::min(32, (160 * 1024) / lds_block));
@@ -843,7 +762,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   std::vector<int> bin_stream((size_t)kBins, 0), bin_order;
   int n_used = n_chains;                               // auxiliary streams that carry launch chains
   {
-    auto group_of = [&](int b) { const int G = kClsG[b / kNT]; return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };
+    auto group_of = [&](int b) { const int G = cls_G(b / kNT); return G == 64 ? 0 : G == 32 ? 1 : G == 16 ? 2 : 3; };
     int64_t gwork[4] = {0, 0, 0, 0};
     for (int b = 0; b < kBins; ++b)
       if (bin_cnt[(size_t)b]) gwork[group_of(b)] += bin_cnt[(size_t)b] * (bin_max_lr[b] + 8) * (bin_max_lu[b] + 8);
@@ -877,7 +796,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     if (n_chains == 2 && small_waves > 0 && use_pack) {
       for (int b = 0; b < kBins; ++b) {
         if (!bin_cnt[(size_t)b]) continue;
-        const int64_t waves = bin_cnt[(size_t)b] / (2 * (64 / kClsG[b / kNT])) + 1;
+        const int64_t waves = bin_cnt[(size_t)b] / (2 * (64 / cls_G(b / kNT))) + 1;
         if (waves < small_waves) { bin_stream[(size_t)b] = 2; n_used = 3; }
       }
     }
@@ -898,13 +817,13 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   if (merge_hand) {
     for (int b = 0; b < kBins; ++b) {
       if (!bin_cnt[(size_t)b]) continue;
-      const int ci = b / kNT, G = kClsG[ci];
+      const int ci = b / kNT, G = cls_G(ci);
       HandGroup &hg = hgrp[G == 8 ? 0 : G == 16 ? 1 : G == 32 ? 2 : 3];
       if (hg.first_bin < 0) { hg.first_bin = b; hg.G = G; }
       hg.bins.push_back(b);
       hg.cnt += bin_cnt[(size_t)b];
       hg.slot_a = std::max<int>(hg.slot_a, (int)((bin_need_a[(size_t)b] + 127) & ~(int64_t)127));
-      hg.slot_b = std::max(hg.slot_b, g_tier_bytes[b % kNT]);
+      hg.slot_b = std::max(hg.slot_b, tier_bytes(b % kNT));
       hg.tw_a = std::max<int>(hg.tw_a, (int)bin_max_lr[b] + G);
       hg.tw_b = std::max<int>(hg.tw_b, (int)bin_max_po[b] + G);
       hg.ns_a = std::max<int>(hg.ns_a, (int)((bin_max_lc[b] + G * 8 - 1) / (G * 8)));
@@ -912,7 +831,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     }
     for (HandGroup &hg : hgrp) {
       if (hg.first_bin < 0) continue;
-      for (int ci = 0; ci < kNC; ++ci) if (kClsG[ci] == hg.G && kClsR[ci] == 8) hg.ci8 = ci;
+      for (int ci = 0; ci < kNC; ++ci) if (cls_G(ci) == hg.G && cls_R(ci) == 8) hg.ci8 = ci;
       hg.slot_a = std::min(hg.slot_a, cls_max_slot[hg.ci8]);
       hg.slot_b = std::min(hg.slot_b, cls_max_slot[hg.ci8]);
       const int64_t full = (hg.cnt + 64 / hg.G - 1) / (64 / hg.G);
@@ -941,13 +860,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
 
   // ---- workspace ----
   const size_t nodes = (size_t)total + (size_t)n + 8;
-  rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_perm.ensure((size_t)n * 4 + 64) | c->d_mv1.ensure((size_t)n * 8) |
-       c->d_mv2.ensure((size_t)n * 8) | c->d_sym.ensure((size_t)total + 64) | c->d_xinfo.ensure(nodes * 8) |
+  // (the offsets, both lists and the moves offsets were sized in front of the classification)
+  rc = c->d_sym.ensure((size_t)total + 64) | c->d_xinfo.ensure(nodes * 8) |
        c->d_ring1.ensure(nodes * 2) | c->d_map16.ensure(nodes * 4) | c->d_carry.ensure(nodes * 4) |
        c->d_moves.ensure((size_t)(max_dwords + bump_dwords) * 4 + 1024) | c->d_n1.ensure((size_t)n * 4) |
        c->d_cls.ensure((size_t)n) | c->d_score1.ensure((size_t)n * 4) | c->d_score2.ensure((size_t)n * 4) |
        c->d_bx2.ensure((size_t)n * 4) |
-       c->d_list.ensure((size_t)3 * n * 4 + (size_t)kBins * 32 + part_chunks_max * (16 + 4 * (size_t)partition_buckets()) + 64) |
        c->d_done.ensure((size_t)5 * n + 64) |
        c->d_rowinit.ensure(1024 + 256 * (size_t)kBins) |
        c->d_fmv.ensure((size_t)(fmv_stream[0] + fmv_stream[1] + fmv_stream[2] + fmv_stream[3]) + 256) |
@@ -970,9 +888,6 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   if (use_fused && (rc = ensure_streams(c))) return fail(c, rc, "auxiliary streams");
 
   const double tp3 = now_ms();
-  hipStream_t st = c->stream;
-  uint32_t *d_generic = c->d_perm.as<uint32_t>();
-  uint32_t *d_lists = c->d_list.as<uint32_t>();
   uint32_t *d_leftb = d_lists + n;                 // device-built list for alignment #2 leftovers
   uint32_t *d_lists2 = d_lists + 2 * n;            // the fused bins' lists, windows that need alignment #1 first
   int64_t *d_bins = reinterpret_cast<int64_t *>(d_lists2 + n + (n & 1));
@@ -1005,12 +920,6 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   }
   // device counters: [0] = leftover count (int32), [2..3] = bump allocator (u64)
   int32_t *d_counters = reinterpret_cast<int32_t *>(c->d_rowinit.p);
-  HIPCHK(c, hipMemcpyAsync(c->d_off.p, h_off, (size_t)(3 * n + 1) * 8, hipMemcpyHostToDevice, st));
-  if (n_generic) HIPCHK(c, hipMemcpyAsync(d_generic, h_generic, (size_t)n_generic * 4, hipMemcpyHostToDevice, st));
-  if (n - n_generic) HIPCHK(c, hipMemcpyAsync(d_lists, h_list, (size_t)(n - n_generic) * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_mv1.p, h_mv1, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->d_mv2.p, h_mv2, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(d_status, h_status, (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipEventRecord(h_done, st));
   HIPCHK(c, hipMemsetAsync(c->d_done.p, 0, (size_t)5 * n, st));
   HIPCHK(c, hipMemsetAsync(d_counters, 0, 64, st));
@@ -1023,7 +932,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
 
   const double tp4 = now_ms();
   if (host_prof)
-    std::fprintf(stderr, "[elector] host: classify %.2f ms, sort+lists %.2f ms, chunks+workspace %.2f ms, uploads %.2f ms\n",
+    std::fprintf(stderr, "[elector] host: classification (device, with the wait) %.2f ms, bins + list sort %.2f ms, generic list + workspace %.2f ms, tables %.2f ms\n",
                  tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
   timed_begin(c, 2, st);
   launch_symbolize(d_bases, c->d_sym.as<uint8_t>(), total, c->d_tab.as<DevTables>(), st);
@@ -1061,14 +970,13 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // tiles of 63 rows x kTileCols columns, one launch per tile anti-diagonal (k_dp1_tile / k_dp2_tile),
   // so that one window keeps up to min(strips, column blocks) wavefronts busy instead of one.
   const int64_t tile_cells = std::getenv("ELECTOR_TILE_CELLS") ? std::atoll(std::getenv("ELECTOR_TILE_CELLS")) : ((int64_t)1 << 24);
-  struct LongWin { uint32_t w; int lr, lc, lu; };
+  struct LongWin { uint32_t w; int lr, lc, lu; int64_t k; };
   auto long_windows = [&](int64_t k0, int64_t k1) {
     std::vector<LongWin> v;
     for (int64_t k = k0; k < k1; ++k) {
-      const int64_t w = h_generic[k];
-      if (h_status[w]) continue;
-      const int64_t lr = off[3 * w + 1] - off[3 * w], lc = off[3 * w + 2] - off[3 * w + 1], lu = off[3 * w + 3] - off[3 * w + 2];
-      if (std::max(lr * lc, (lr + lc) * lu) >= tile_cells) v.push_back({(uint32_t)w, (int)lr, (int)lc, (int)lu});
+      if (g_info[4 * k + 3]) continue;
+      const int64_t lr = g_info[4 * k], lc = g_info[4 * k + 1], lu = g_info[4 * k + 2];
+      if (std::max(lr * lc, (lr + lc) * lu) >= tile_cells) v.push_back({g_list[(size_t)k], (int)lr, (int)lc, (int)lu, k});
     }
     return v;
   };
@@ -1099,7 +1007,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     if (phase == 1)
       for (const LongWin &x : lw) {
         const int64_t d1 = (int64_t)n_strips(x.lc) * mv_tw(x.lr) * 64, d2 = (int64_t)n_strips(x.lu) * mv_tw(x.lr + x.lc) * 64;
-        HIPCHK(c, hipMemsetAsync(c->d_moves.as<uint32_t>() + h_mv1[x.w], 0, (size_t)(d1 + d2) * 4, st));
+        HIPCHK(c, hipMemsetAsync(c->d_moves.as<uint32_t>() + reinterpret_cast<const int64_t *>(g_info + 4 * n_generic)[2 * x.k], 0, (size_t)(d1 + d2) * 4, st));
         HIPCHK(c, hipMemsetAsync(d_tiled + x.w, 1, 1, st));
       }
     TileArgs ta;
@@ -1133,7 +1041,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     for (int pass = 0; pass < (split_ab ? 2 : 1); ++pass)
     for (int b : bin_order) {                       // within a chain: most work first
       if (!bin_cnt[(size_t)b]) continue;
-      const int bG = kClsG[b / kNT], bR = kClsR[b / kNT], bslot = g_tier_bytes[b % kNT];
+      const int bG = cls_G(b / kNT), bR = cls_R(b / kNT), bslot = tier_bytes(b % kNT);
       const int sk = stream_of(b);
       hipStream_t sx = c->aux[sk];
       const int fdebug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
@@ -1320,9 +1228,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           (void)hipMemcpy(lw.data(), d_leftb, lw.size() * 4, hipMemcpyDeviceToHost);
           std::vector<uint8_t> cls((size_t)n);
           (void)hipMemcpy(cls.data(), c->d_cls.p, (size_t)n, hipMemcpyDeviceToHost);
-          for (uint32_t w : lw)
-            std::fprintf(stderr, "[elector]   window %u: Lr %lld Lc %lld Lu %lld class byte %d\n", w, (long long)(off[3 * w + 1] - off[3 * w]),
-                         (long long)(off[3 * w + 2] - off[3 * w + 1]), (long long)(off[3 * w + 3] - off[3 * w + 2]), (int)cls[w]);
+          for (uint32_t w : lw) {
+            int64_t o[4] = {0, 0, 0, 0};
+            (void)hipMemcpy(o, c->d_off.as<int64_t>() + 3 * (size_t)w, sizeof o, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[elector]   window %u: Lr %lld Lc %lld Lu %lld class byte %d\n", w, (long long)(o[1] - o[0]),
+                         (long long)(o[2] - o[1]), (long long)(o[3] - o[2]), (int)cls[w]);
+          }
         }
       }
       a.perm = d_leftb;
@@ -1375,7 +1286,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     (void)hipMemcpy(hc.data(), c->d_hand.as<uint32_t>() + n, (size_t)nbins_used * 4, hipMemcpyDeviceToHost);
     std::fprintf(stderr, "[elector] k_poa handed back:");
     for (int b = 0; b < kBins; ++b)
-      if (bin_cnt[(size_t)b]) std::fprintf(stderr, " G%dxR%d:%d/%lld", kClsG[b / kNT], kClsR[b / kNT], hc[(size_t)bin_slot[(size_t)b]], (long long)bin_cnt[(size_t)b]);
+      if (bin_cnt[(size_t)b]) std::fprintf(stderr, " G%dxR%d:%d/%lld", cls_G(b / kNT), cls_R(b / kNT), hc[(size_t)bin_slot[(size_t)b]], (long long)bin_cnt[(size_t)b]);
     std::fprintf(stderr, "\n");
   }
   if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 4)) {
@@ -1399,13 +1310,13 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       const unsigned long long *p = hs.data() + 32 * (size_t)b;
       if (p[16 + 15])
         std::fprintf(stderr, "[elector] bin G%dxR%d  k_poa waves %llu: stage %.0f dpA %.0f tbA %.0f fus1 %.0f ord %.0f dpB %.0f tbB %.0f cols+out %.0f | of stage: descriptors %.0f symbols %.0f slot %.0f rest %.0f; traceback #2 rounds %.1f; alignment #2 steps %.1f, two-predecessor %.1f, virtual %.1f  (cycles per wave)\n",
-                     kClsG[b / kNT], kClsR[b / kNT], p[31], (double)(p[16] + p[24] + p[25] + p[26]) / p[31], (double)p[17] / p[31], (double)p[18] / p[31],
+                     cls_G(b / kNT), cls_R(b / kNT), p[31], (double)(p[16] + p[24] + p[25] + p[26]) / p[31], (double)p[17] / p[31], (double)p[18] / p[31],
                      (double)p[19] / p[31], (double)p[20] / p[31], (double)p[21] / p[31], (double)p[22] / p[31], (double)p[23] / p[31],
                      (double)p[24] / p[31], (double)p[25] / p[31], (double)p[26] / p[31], (double)p[16] / p[31], (double)p[27] / p[31],
                      (double)p[28] / p[31], (double)p[29] / p[31], (double)p[30] / p[31]);
       if (!p[4]) continue;
       std::fprintf(stderr, "[elector] bin G%dxR%d/%d  A waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f | B waves %llu: stage %.0f dp %.0f traceback %.0f fusion %.0f out %.0f  (cycles per wave)\n",
-                   kClsG[b / kNT], kClsR[b / kNT], g_tier_bytes[b % kNT], p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[5] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],
+                   cls_G(b / kNT), cls_R(b / kNT), tier_bytes(b % kNT), p[4], (double)p[0] / p[4], (double)p[1] / p[4], (double)p[5] / p[4], (double)p[2] / p[4], (double)p[3] / p[4],
                    p[12], p[12] ? (double)p[8] / p[12] : 0, p[12] ? (double)p[9] / p[12] : 0, p[12] ? (double)p[13] / p[12] : 0,
                    p[12] ? (double)p[10] / p[12] : 0, p[12] ? (double)p[11] / p[12] : 0);
     }
@@ -1421,7 +1332,23 @@ extern "C" int elector_poa_batch_device(elector_ctx *c, int64_t n, const uint8_t
     return fail(c, ELECTOR_E_INVAL, "bad arguments");
   std::lock_guard<std::mutex> lock(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  return run_device_batch(c, n, d_bases, off, d_cols, d_ncol, d_status, d_scores);
+  if (n == 0) return run_device_batch(c, 0, d_bases, nullptr, 0, d_cols, d_ncol, d_status, d_scores);
+  if (off[0] != 0 || off[3 * n] < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
+  const int rc = upload_offsets(c, n, off, c->stream);
+  if (rc) return fail(c, rc, "offsets upload");
+  return run_device_batch(c, n, d_bases, c->d_off.as<int64_t>(), off[3 * n], d_cols, d_ncol, d_status, d_scores);
+}
+
+extern "C" int elector_poa_batch_device_offsets(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *d_off,
+                                                 int64_t total, uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status,
+                                                 int32_t *d_scores)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n < 0 || n > 0x7fffffff || (n > 0 && (!d_off || !d_bases || !d_cols || !d_ncol || !d_status)))
+    return fail(c, ELECTOR_E_INVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  return run_device_batch(c, n, d_bases, d_off, total, d_cols, d_ncol, d_status, d_scores);
 }
 
 extern "C" int elector_poa_batch(elector_ctx *c, int64_t n, const uint8_t *bases, const int64_t *off, uint8_t *rows,
@@ -1442,7 +1369,9 @@ extern "C" int elector_poa_batch(elector_ctx *c, int64_t n, const uint8_t *bases
   if (rc) return fail(c, ELECTOR_E_NOMEM, "device staging");
   hipStream_t st = c->stream;
   HIPCHK(c, hipMemcpyAsync(c->d_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
-  rc = run_device_batch(c, n, c->d_bases.as<uint8_t>(), off, c->d_cols.as<uint8_t>(), c->d_ncol.as<int32_t>(),
+  rc = upload_offsets(c, n, off, st);
+  if (rc) return fail(c, rc, "offsets upload");
+  rc = run_device_batch(c, n, c->d_bases.as<uint8_t>(), c->d_off.as<int64_t>(), total, c->d_cols.as<uint8_t>(), c->d_ncol.as<int32_t>(),
                         c->d_status.as<int32_t>(), scores ? c->d_scores.as<int32_t>() : nullptr);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(ncol, c->d_ncol.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));

@@ -110,6 +110,16 @@ class PoaEngine:
             d_scores.data_ptr() if d_scores is not None else None)
         self._check(rc)
 
+    def align_device_offsets(self, d_bases, d_off, n, total, d_cols, d_ncol, d_status, d_scores=None):
+        """align_device with the 3n + 1 window offsets resident in device memory as well (int64; what the device
+        splitter leaves behind): no per-window work on the host at all.  d_bases / d_off: torch CUDA tensors or
+        objects with data_ptr()."""
+        rc = self._lib.elector_poa_batch_device_offsets(
+            self._h, int(n), d_bases.data_ptr(), d_off.data_ptr(), int(total), d_cols.data_ptr(),
+            d_ncol.data_ptr(), d_status.data_ptr(),
+            d_scores.data_ptr() if d_scores is not None else None)
+        self._check(rc)
+
     def msa_stats_device(self, n_windows, d_cols, d_ncol, d_status, piece_first, read_first, clips=None,
                          last_cap=0):
         """Second half of the MSA stage on the windows of the last align_device call:

@@ -112,6 +112,16 @@ int elector_poa_batch_device(elector_ctx *ctx, int64_t n,
                              const uint8_t *d_bases, const int64_t *off,
                              uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status,
                              int32_t *d_scores);
+/* The same with the offsets in device memory too: d_off = 3n+1 int64 byte offsets (d_off[0] = 0, d_off[3n] = total,
+ * checked on the device), e.g. the array the device splitter leaves behind (include/elector_split.h:
+ * elector_windows_dev.d_off).  No per-window work happens on the host: window status, launch class and the class
+ * lists are computed by kernels, the host reads back per-class totals (29 KB) and queues the launches.  This is
+ * the entry the pipeline and bench.py use; the reference has no counterpart (its poa reads the windows from three
+ * FASTA files in file order, main.c:265-284). */
+int elector_poa_batch_device_offsets(elector_ctx *ctx, int64_t n,
+                                     const uint8_t *d_bases, const int64_t *d_off, int64_t total,
+                                     uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status,
+                                     int32_t *d_scores);
 int elector_ctx_sync(elector_ctx *ctx);
 
 /* measurement hooks for bench.py: HIP-event time (ms) and span count of a

@@ -1,4 +1,4 @@
-# GPU-box round script: parity tests, smoke, bench, rocprof kernel stats.  Usage: gpurun -- 'bash tests/_gpu_round.sh TAG'
+# GPU-box round script: parity tests, smoke, bench, rocprof kernel stats.  Usage: gpurun -- 'bash tools/_gpu_round.sh TAG'
 : ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 TAG=${1:-run}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

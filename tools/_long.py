@@ -1,7 +1,7 @@
 """Timing of the long-window path (no parity check here: tests/test_poa_gpu.py does that)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import synth
 from elector_amd.poa import PoaEngine
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 17000

@@ -2,9 +2,9 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 : ${GRAFT_REPO_ROOT:?}   # these helpers run on the GPU box only (they cd and delete below that path)
 export FB_DEBUGS=0
 rm -rf gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d gpurun_out/pmc1 -- python3 tests/_fbench.py > gpurun_out/pmc1.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc2 -- python3 tests/_fbench.py > gpurun_out/pmc2.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc3 -- python3 tests/_fbench.py > gpurun_out/pmc3.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d gpurun_out/pmc1 -- python3 tools/_fbench.py > gpurun_out/pmc1.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc2 -- python3 tools/_fbench.py > gpurun_out/pmc2.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc3 -- python3 tools/_fbench.py > gpurun_out/pmc3.log 2>&1
 for d in pmc1 pmc2 pmc3; do
 f=$(find gpurun_out/$d -name "*counter_collection.csv" | head -1)
 echo "== $d $f"

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/$TAG
 CMD="python3 bench.py --no-cpu-baseline --steps 3 --warmup 1"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/$TAG/p3 -- $CMD > gpurun_out/$TAG/p3.log 2>&1 && \
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA --output-format csv -d gpurun_out/$TAG/p4 -- $CMD > gpurun_out/$TAG/p4.log 2>&1
-python3 tests/_pmc_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.json
+python3 tools/_pmc_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.json
 python3 - gpurun_out/$TAG/summary.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))

@@ -1,5 +1,5 @@
-"""profiles/pmc_traffic_<profile>.json from a PMC summary (tests/_r3_pmc.sh -> tests/_pmc_summary.py).
-Usage: python tests/_pmc_traffic.py gpurun_out/TAG/summary.json [reads_per_gpu] [profile] [collected]"""
+"""profiles/pmc_traffic_<profile>.json from a PMC summary (tools/_r3_pmc.sh -> tools/_pmc_summary.py).
+Usage: python tools/_pmc_traffic.py gpurun_out/TAG/summary.json [reads_per_gpu] [profile] [collected]"""
 import json, os, sys
 src = sys.argv[1]
 reads = int(sys.argv[2]) if len(sys.argv) > 2 else 10001

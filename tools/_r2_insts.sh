@@ -6,7 +6,7 @@ TAG=${1:-r2insts}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 for D in 32 64 128 256 0; do
-  DBG=$D timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/$TAG/d$D -- python3 tests/_r2_dbg.py ecoli30x_simlord_lordec 10001 > gpurun_out/$TAG/d$D.log 2>&1 || echo "run $D failed" >> gpurun_out/$TAG/fail.txt
+  DBG=$D timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/$TAG/d$D -- python3 tools/_r2_dbg.py ecoli30x_simlord_lordec 10001 > gpurun_out/$TAG/d$D.log 2>&1 || echo "run $D failed" >> gpurun_out/$TAG/fail.txt
   python3 - gpurun_out/$TAG/d$D $D <<'PY'
 import csv,glob,sys,collections
 agg=collections.defaultdict(float)

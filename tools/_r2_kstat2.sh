@@ -5,5 +5,5 @@ for P in ecoli30x_simlord_lordec yeast50x_nanosim_consent_split; do
 for BW in default 256 512 0; do
   if [ $BW = default ]; then unset ELECTOR_STATS_BITWORDS; else export ELECTOR_STATS_BITWORDS=$BW; fi
   echo "== $P bitwords $BW"
-  KS_EXTRA="--profile $P" bash tests/_r2_kstat.sh r2ks_$BW | grep -E "k_stats|k_merge" | cut -d, -f1-4
+  KS_EXTRA="--profile $P" bash tools/_r2_kstat.sh r2ks_$BW | grep -E "k_stats|k_merge" | cut -d, -f1-4
 done; done

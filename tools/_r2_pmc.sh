@@ -11,7 +11,7 @@ if [ "$2" = traffic ]; then
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/$TAG/p5 -- $CMD > gpurun_out/$TAG/p5.log 2>&1 || exit 3
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/$TAG/p6 -- $CMD > gpurun_out/$TAG/p6.log 2>&1 || exit 4
 fi
-python3 tests/_pmc_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.json
+python3 tools/_pmc_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.json
 python3 - gpurun_out/$TAG/summary.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))

@@ -13,7 +13,7 @@ for grp in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_su
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/$TAG/p$i -- $CMD > gpurun_out/$TAG/p$i.log 2>&1 || echo "pass $i failed" >> gpurun_out/$TAG/fail.txt
 done
-python3 tests/_pmc_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.json
+python3 tools/_pmc_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.json
 find gpurun_out/$TAG -name "*kernel_trace.csv" -delete; find gpurun_out/$TAG -name "*counter_collection.csv" -size +20M -delete
 python3 - gpurun_out/$TAG/summary.json <<'PY'
 import json,sys

@@ -10,5 +10,5 @@ for P in ecoli30x_simlord_lordec yeast50x_nanosim_consent_split chr1_20x_ont_50k
   RD=10001; [ $P = chr1_20x_ont_50kb ] && RD=2000
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$P -o serial -- python3 $R/bench.py --serial --profile $P --reads $RD --steps 5 --warmup 1 --no-cpu-baseline > $R/$O/prof_$P.json 2> $R/$O/prof_$P.err ) || exit 6
 done
-FB_DEBUGS=4 python tests/_fbench.py > $O/phases.txt 2>&1 || exit 7
+FB_DEBUGS=4 python tools/_fbench.py > $O/phases.txt 2>&1 || exit 7
 ls -R $O | head -60

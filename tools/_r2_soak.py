@@ -1,8 +1,8 @@
 """GPU-box helper: random windows (many with one-indel / one-substitution corrected sequences) through the C ABI
-against the oracle, bit-exact rows and scores.  Usage: python tests/_r2_soak.py [seeds...]"""
+against the oracle, bit-exact rows and scores.  Usage: python tools/_r2_soak.py [seeds...]"""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle_lib, synth
 from elector_amd import poa

@@ -6,7 +6,7 @@ set -o pipefail
 O=gpurun_out/${1:-r3cfg}
 mkdir -p $O
 for P in yeast50x_nanosim_consent_split celegans30x_simlord_mixed; do
-  DBG=4 python tests/_r2_dbg.py $P 10001 > $O/dbg_$P.log 2>&1 || exit 1
+  DBG=4 python tools/_r2_dbg.py $P 10001 > $O/dbg_$P.log 2>&1 || exit 1
 done
 export TMPDIR=/tmp
 R=$PWD

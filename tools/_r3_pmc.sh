@@ -13,8 +13,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA --output-format csv -d $O/p4 -- $CMD > $O/p4.log 2>&1 || exit 2
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p5 -- $CMD > $O/p5.log 2>&1 || exit 3
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p6 -- $CMD > $O/p6.log 2>&1 || exit 4
-python3 tests/_pmc_summary.py $O > $O/summary.json || exit 5
-python3 tests/_pmc_traffic.py $O/summary.json $READS $P "round 3, final build" > $O/traffic.log || exit 6
+python3 tools/_pmc_summary.py $O > $O/summary.json || exit 5
+python3 tools/_pmc_traffic.py $O/summary.json $READS $P "round 3, final build" > $O/traffic.log || exit 6
 cp profiles/pmc_traffic_$P.json $O/
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
 python3 -c "

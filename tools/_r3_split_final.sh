@@ -7,7 +7,7 @@ mkdir -p $O
 : > $O/k_split.txt
 for P in ecoli30x_simlord_lordec yeast50x_nanosim_consent yeast50x_nanosim_consent_split celegans30x_simlord_mixed chr1_20x_ont_50kb; do
   N=10001; [ $P = chr1_20x_ont_50kb ] && N=1559
-  timeout -k 10 500 python tests/_r3_split.py $P $N > $O/$P.log 2>&1 || { echo "FAILED $P"; tail -3 $O/$P.log; exit 1; }
+  timeout -k 10 500 python tools/_r3_split.py $P $N > $O/$P.log 2>&1 || { echo "FAILED $P"; tail -3 $O/$P.log; exit 1; }
   grep "k_split:" $O/$P.log | tail -1 >> $O/k_split.txt
   grep "host view" $O/$P.log | tail -1 >> $O/k_split.txt
   tail -2 $O/$P.log >> $O/k_split.txt

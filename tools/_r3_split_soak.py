@@ -1,5 +1,5 @@
 """GPU-box helper: device splitter against the host splitter over several seeds and profiles (more reads than the
-test suite's soak).  Usage: python tests/_r3_split_soak.py [reads per case]"""
+test suite's soak).  Usage: python tools/_r3_split_soak.py [reads per case]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
