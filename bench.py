@@ -384,7 +384,9 @@ def main():
     gpool = None
     if dist_on:
         from concurrent.futures import ThreadPoolExecutor as _TPE
-        gpool = _TPE(max_workers=1)
+        # (a new thread's current device is 0 whatever this thread set: the helper binds itself to the rank's GPU, and the
+        # pipe is told the device as well)
+        gpool = _TPE(max_workers=1, initializer=torch.cuda.set_device, initargs=(local,))
     turn = [0]
     host_s = [0.0]                               # host time of classifying and enqueueing (the GPU work is asynchronous)
     gather_s = [0.0]                             # host time of starting a step's gather and taking in an earlier one
@@ -414,7 +416,7 @@ def main():
             block = np.concatenate(held) if k > 1 else held[0]
             held.clear()
             sizes = [x * k for x in gather_sizes]
-            gathers.append((k, gpool.submit(lambda c=block, z=sizes: edist.gather_rows_async(c, z, cap=gather_cap).wait())))
+            gathers.append((k, gpool.submit(lambda c=block, z=sizes: edist.gather_rows_async(c, z, cap=gather_cap, device=local if backend == "nccl" else None).wait())))
         while gathers and (force or len(gathers) > 3):
             k, fut = gathers.pop(0)
             got = fut.result()

@@ -280,20 +280,25 @@ def _shard(reference, uncorrected, corrected, world, rank=0, dist=None, device=N
 
 
 def _append_file(out, path):
-    """the bytes of `path` appended to the open file `out` inside the kernel (copy_file_range / sendfile) where the
-    platform offers it"""
+    """the bytes of `path` appended to the open file `out` inside the kernel (sendfile) where the platform offers it.
+    `out` must NOT be open in append mode (Linux refuses sendfile onto an O_APPEND descriptor with EINVAL): it is
+    positioned at its end here and written from there."""
+    import errno
     out.flush()
     size = os.path.getsize(path)
+    fd = out.fileno()
+    os.lseek(fd, 0, os.SEEK_END)
     with open(path, "rb") as f:
         done = 0
         try:
             while done < size:
-                k = os.sendfile(out.fileno(), f.fileno(), done, min(size - done, 1 << 30))
+                k = os.sendfile(fd, f.fileno(), done, min(size - done, 1 << 30))
                 if k <= 0:
                     break
                 done += k
-        except OSError:
-            pass
+        except OSError as e:
+            if e.errno not in (errno.EINVAL, errno.ENOSYS):      # "not offered here": fall back; anything else is an I/O error
+                raise
         if done < size:
             f.seek(done)
             while True:
@@ -640,7 +645,8 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
         hdr_all = [None] * world if rank == 0 else None
         dist.gather_object(mine, hdr_all, dst=0)          # every part is on disk before rank 0 goes on
         if rank == 0:
-            with open(mergeOut, "ab") as out:
+            # (not "ab": sendfile refuses an O_APPEND descriptor; _append_file positions the file at its end itself)
+            with open(mergeOut, "r+b" if os.path.exists(mergeOut) else "wb") as out:
                 for r in range(world):
                     part = mergeOut + ".part%d" % r
                     _append_file(out, part)

@@ -205,6 +205,10 @@ struct MapFile {
   void scan_ahead(size_t lines)
   {
     if (ahead_head == ahead.size()) { ahead.clear(); ahead_head = 0; }
+    else if (ahead_head >= 4096) {                      // the spans handed out are dropped: the vector stays a batch long
+      ahead.erase(ahead.begin(), ahead.begin() + (std::ptrdiff_t)ahead_head);
+      ahead_head = 0;
+    }
     const size_t have = ahead.size() - ahead_head;
     for (size_t i = have; i < lines && pos < size; ++i) {
       const char *b = data + pos;

@@ -57,12 +57,17 @@ struct KParams {
 };
 
 // Largest |score| (plus the headroom the recurrences need around it) that a live cell of a DP over nx columns and ny
-// rows can hold under simple scoring: every cell is at least as good as the path made of one x-gap and one y-gap
-// (open_x + open_y + the extensions), and at most min(nx, ny) matches good; the offers built from a cell (score less a
-// gap penalty, score plus a substitution score) reach three penalties further.  The 16-bit kernels take a window when
-// this stays below 16000.  (Up to round 2 the test was maxpen x (nx + ny): twice as strict as needed with the shipped
-// extension penalty of 5 against an opening penalty of 10, and the long un-anchored windows of trimmed / split reads
-// -- 700 x 700 letters -- fell to the one-wave generic kernels.)
+// rows can hold under simple scoring.  The 16-bit kernels take a window when this stays below 16000.
+//
+// The safe bound is maxpen x (nx + ny): no step of a path costs more than the largest penalty.  The tighter one --
+// every cell is at least as good as the path made of one x-gap and one y-gap, 2 open + ext (nx + ny) -- is NOT a
+// property of this recurrence in general: a cell keeps ONE gap state (align_lpo_po2.c:374-407) and a match wins only
+// strictly (:384), so below a cell whose diagonal won by a hair the column pays a full opening again, and a column
+// can fall by up to open - 1 per row instead of ext.  When open, ext and both substitution scores are multiples of
+// ext (the shipped 0 / -10 / 10 / 5), "wins by a hair" is "wins by at least ext": whatever the diagonal gains on the
+// gap path it loses again when the next gap opens, and the all-gap path bounds every live cell from below.  Only then
+// is the tight bound used (it admits windows twice as long: the 700 x 700 un-anchored windows of trimmed / split reads
+// stay in the 16-bit kernels); any other parameter set gets the safe bound.
 __host__ __device__ inline int64_t score_span(const KParams &kp, int64_t nx, int64_t ny)
 {
   auto ab = [](int64_t v) { return v < 0 ? -v : v; };
@@ -70,7 +75,9 @@ __host__ __device__ inline int64_t score_span(const KParams &kp, int64_t nx, int
   const int64_t open = ab(kp.open_x) > ab(kp.open_y) ? ab(kp.open_x) : ab(kp.open_y);
   const int64_t sub = ab(kp.match) > ab(kp.mismatch) ? ab(kp.match) : ab(kp.mismatch);
   const int64_t pen = open > sub ? (open > ext ? open : ext) : (sub > ext ? sub : ext);
-  const int64_t down = 2 * open + ext * (nx + ny);                 // the all-gap path
+  const bool lattice = kp.ext_x > 0 && kp.ext_x == kp.ext_y && kp.open_x % kp.ext_x == 0 && kp.open_y % kp.ext_x == 0 &&
+                       kp.match % kp.ext_x == 0 && kp.mismatch % kp.ext_x == 0;
+  const int64_t down = lattice ? 2 * open + ext * (nx + ny) : pen * (nx + ny);
   const int64_t up = (kp.match > 0 ? kp.match : 0) * (nx < ny ? nx : ny);
   return (down > up ? down : up) + 3 * pen;
 }
@@ -221,13 +228,14 @@ __host__ __device__ inline int poa_slot_need(int Lr, int Lc, int Lu, int G)
 // process may hold contexts on several (one bit per device id; setting the attribute twice from two threads is harmless)
 struct DeviceOnce {
   std::atomic<unsigned long long> mask{0};
-  int dev = 0;
-  bool need()
+  static unsigned long long bit()
   {
+    int dev = 0;                                       // (a local: several threads ask at once)
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    return (mask.load(std::memory_order_acquire) & (1ull << (dev & 63))) == 0;
+    return 1ull << (dev & 63);
   }
-  void done() { mask.fetch_or(1ull << (dev & 63), std::memory_order_release); }
+  bool need() { return (mask.load(std::memory_order_acquire) & bit()) == 0; }
+  void done() { mask.fetch_or(bit(), std::memory_order_release); }
 };
 
 }  // namespace elector

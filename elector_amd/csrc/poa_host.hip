@@ -509,7 +509,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // ---- per-window bookkeeping on the device (poa_classify.hip): status, launch class, size key; the host reads
   // back the per-class totals only ----
   const size_t part_chunks_max = (size_t)n / kPartChunk + kBins + 1;
-  const size_t acc_ints = (size_t)kAccRows * kBins + 8;                      // + four 64-bit totals
+  const size_t acc_glob = ((size_t)kAccRows * kBins + 1) & ~(size_t)1;         // the four 64-bit totals behind the rows, 8-byte aligned
+  const size_t acc_ints = acc_glob + 8;
   int rc = c->d_off.ensure((size_t)(3 * n + 1) * 8) | c->d_bin16.ensure((size_t)n * 2 + 64) | c->d_wkey.ensure((size_t)n + 64) |
            c->d_acc.ensure(acc_ints * 4 + (size_t)kSortDestMax * kKeys * 4 + (size_t)(kBins + 2) * 2 + (size_t)kSortDestMax * 8 + 256) |
            c->d_perm.ensure((size_t)n * 4 + 64) | c->d_mv1.ensure((size_t)n * 8) | c->d_mv2.ensure((size_t)n * 8) |
@@ -539,7 +540,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     ca.coarse = std::getenv("ELECTOR_SORT_COARSE") ? 1 : 0;
     ca.window_moves_max = kWindowMovesMaxDwords;
     ca.status = d_status; ca.bin = c->d_bin16.as<int16_t>(); ca.wkey = c->d_wkey.as<uint8_t>();
-    ca.acc = d_acc; ca.glob = reinterpret_cast<unsigned long long *>(d_acc + (size_t)kAccRows * kBins);
+    ca.acc = d_acc; ca.glob = reinterpret_cast<unsigned long long *>(d_acc + acc_glob);
     timed_begin(c, 2, st);
     launch_classify(ca, st);
     timed_end(c, st);
@@ -548,7 +549,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   }
   const double tp1 = now_ms();
   const int32_t *h_acc = c->h_acc.as<int32_t>();
-  const unsigned long long *h_glob = reinterpret_cast<const unsigned long long *>(h_acc + (size_t)kAccRows * kBins);
+  const unsigned long long *h_glob = reinterpret_cast<const unsigned long long *>(h_acc + acc_glob);
   if (h_glob[3]) return fail(c, ELECTOR_E_INVAL, "offsets must start at 0, be non-decreasing and end at the total");
   const int64_t n_generic = (int64_t)h_glob[0];
   const int64_t left_worst = (int64_t)h_glob[1];     // moves (dwords) of alignment #2 if every fused-routed window were handed back

@@ -54,7 +54,7 @@ def gather_sizes(n_local, group=None):
     return [int(s.item()) for s in sizes]
 
 
-def gather_rows(local, group=None, dst=0, sizes=None):
+def gather_rows(local, group=None, dst=0, sizes=None, device=None):
     """Gather variable-length int64 [k_i, C] blocks from every rank to `dst`, in rank
     order.  Returns the concatenated array on dst and None elsewhere.  sizes: the ranks' row counts when the
     caller already has them (gather_sizes) -- one collective instead of two."""
@@ -63,7 +63,8 @@ def gather_rows(local, group=None, dst=0, sizes=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return np.asarray(local)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    dev = (torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+           if dist.get_backend(group) == "nccl" else torch.device("cpu"))
     local = np.ascontiguousarray(local, dtype=np.int64)
     ncol = local.shape[1] if local.ndim == 2 else 1
     if sizes is None:
@@ -104,16 +105,33 @@ class GatherPipe:
     nccl backend (RCCL over xGMI) the blocks travel device to device; with gloo everything stays on the host.
     cap: rows a rank's block may have (the buffers are allocated once, for that)."""
 
-    def __init__(self, cap, ncol, group=None, dst=0, depth=4):
+    def __init__(self, cap, ncol, group=None, dst=0, depth=4, device=None):
+        import contextlib
         import torch
         import torch.distributed as dist
         self.group, self.dst, self.ncol = group, dst, int(ncol)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.nccl = dist.get_backend(group) == "nccl"
         self.cap = max(int(cap), 1)
-        dev = torch.device("cuda", torch.cuda.current_device()) if self.nccl else torch.device("cpu")
-        self.stream = torch.cuda.Stream() if self.nccl else None
+        # The device is an argument, not "the current one": HIP's current device is per THREAD and a new thread starts
+        # on device 0, so a pipe built or started on a helper thread (bench.py does both) would put its buffers and its
+        # stream on GPU 0 in every rank while the process group is bound to GPU local_rank.
+        self.device = None
+        if self.nccl:
+            self.device = int(torch.cuda.current_device() if device is None else device)
+        dev = torch.device("cuda", self.device) if self.nccl else torch.device("cpu")
+        self._on_device = (lambda: torch.cuda.device(self.device)) if self.nccl else contextlib.nullcontext
+        self.stream = torch.cuda.Stream(device=dev) if self.nccl else None
         self.slots = []
+        with self._on_device():
+            self._alloc(depth, dev, dst)
+        if self.nccl:
+            # the zero fills above ran on the device's default stream: the pipe's stream starts behind them
+            self.stream.wait_stream(torch.cuda.default_stream(dev))
+        self.turn = 0
+
+    def _alloc(self, depth, dev, dst):
+        import torch
         for _ in range(depth):
             s = {"busy": False}
             s["stage"] = torch.zeros((self.cap, self.ncol), dtype=torch.int64)
@@ -129,7 +147,6 @@ class GatherPipe:
                     s["host"] = s["host"].pin_memory()
             s["done"] = torch.cuda.Event() if self.nccl else _HostDone()
             self.slots.append(s)
-        self.turn = 0
 
     def start(self, local, sizes):
         import torch
@@ -147,7 +164,7 @@ class GatherPipe:
         s["stage"].numpy()[: local.shape[0]] = local
         is_dst = self.rank == self.dst
         if self.nccl:
-            with torch.cuda.stream(self.stream):
+            with self._on_device(), torch.cuda.stream(self.stream):
                 s["pad"].copy_(s["stage"], non_blocking=True)
                 dist.gather(s["pad"], s["out"] if is_dst else None, dst=self.dst, group=self.group, async_op=True).wait()
                 if is_dst:
@@ -173,18 +190,20 @@ class _HostDone:
                 self._slot["host"][r].copy_(o)
 
 
-def gather_rows_async(local, sizes, group=None, dst=0, cap=None, _pipes={}):
+def gather_rows_async(local, sizes, group=None, dst=0, cap=None, device=None, _pipes={}):
     """gather_rows without waiting for it: the collective runs while the caller goes on (bench.py: the next
     steps' kernels are already queued); sizes as from gather_sizes.  -> object with wait().  The calls of a process
     share one GatherPipe per row width (at most four gathers in flight); cap: rows to make room for when the pipe is
-    created or has to grow (growing allocates pinned memory: callers that know their largest block say so up front)."""
+    created or has to grow (growing allocates pinned memory: callers that know their largest block say so up front).
+    device: the GPU of this rank (nccl backend) -- REQUIRED knowledge when the call comes from a helper thread, whose
+    current device is 0 whatever the main thread set; None = the calling thread's current device."""
     local = np.ascontiguousarray(local, dtype=np.int64)
     ncol = local.shape[1] if local.ndim == 2 else 1
     need = max(max(int(x) for x in sizes), int(cap or 0), 1)
-    key = (ncol, id(group), dst)
+    key = (ncol, group, dst, device)              # the group object itself: an id() can be reused after collection
     pipe = _pipes.get(key)
     if pipe is None or pipe.cap < need:
-        pipe = _pipes[key] = GatherPipe(need, ncol, group, dst)
+        pipe = _pipes[key] = GatherPipe(need, ncol, group, dst, device=device)
     return pipe.start(local, sizes)
 
 

@@ -289,6 +289,38 @@ def test_windows_up_to_the_score_span(engine):
     check(engine, score_range_triples(71))
 
 
+def uniform_matrix(match, mismatch, gaps="10 5 5"):
+    letters = "A a c g t n".split()
+    rows = ["  " + " ".join(letters)]
+    for i, a in enumerate(letters):
+        rows.append(a + " " + " ".join(str(match if i == j else mismatch) for j in range(len(letters))))
+    return "GAP-TRUNCATION-LENGTH=10\nGAP-DECAY-LENGTH=5\nGAP-PENALTIES=%s\n" % gaps + "\n".join(rows) + "\n"
+
+
+@pytest.mark.parametrize("mismatch,gaps", [(-7, "10 5 5"), (-9, "11 4 4"), (-3, "12 7 7")])
+def test_simple_scores_off_the_extension_lattice(tmp_path, mismatch, gaps):
+    """Uniform scoring whose numbers are not multiples of the extension penalty: the tight score span (poa_device.h:
+    score_span) is not a bound for such a set -- a diagonal that wins by less than an extension is followed by a full
+    gap opening (align_lpo_po2.c:374-407) -- so these sets must get the safe span; long un-anchored windows near the
+    16-bit range, rows and scores against the oracle with the same matrix."""
+    from elector_amd import poa
+    path = tmp_path / "u.mat"
+    path.write_text(uniform_matrix(0, mismatch, gaps))
+    eng = poa.PoaEngine(0, poa.read_params(path))
+    par = oracle_lib.read_params(path)
+    try:
+        for triples in (score_range_triples(73), synth.window_triples(74, 400, 5, 150), synth.adversarial_triples(75, 200)):
+            bases, off = synth.pack_windows(triples)
+            exp_rows, _, exp_scores, _ = oracle_lib.batch(np.frombuffer(bases, dtype=np.uint8), off, par)
+            got, scores = eng.align(triples, want_scores=True)
+            bad = [w for w in range(len(triples)) if got[w] != exp_rows[w]]
+            assert not bad, "first differing window %d of %d (Lr %d Lc %d Lu %d)" % (
+                bad[0], len(bad), len(triples[bad[0]][0]), len(triples[bad[0]][1]), len(triples[bad[0]][2]))
+            assert np.array_equal(scores, exp_scores)
+    finally:
+        eng.close()
+
+
 def alphabet_shortcut_triples(seed):
     """The windows alignment #1 is settled for without a dynamic program (corrected = reference, one substitution,
     one inserted or deleted letter: k_trivial / trivial_graph) over the WHOLE input alphabet of a2 (create_seq.c:121-132,

@@ -2,7 +2,7 @@
 # GPU-box helper (round 4): parity tests of the POA engine, then bench A/B of the device classification and the slot size
 : ${GRAFT_REPO_ROOT:?}
 O=gpurun_out/${1:-r4first}; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_poa_gpu.py tests/test_configs_gpu.py -x -q -m gpu > $O/pytest.log 2>&1 || { echo "PYTEST FAILED"; tail -30 $O/pytest.log; exit 1; }
+timeout -k 10 600 python -m pytest tests/test_poa_gpu.py tests/test_configs_gpu.py -x -q -m gpu --capture=sys > $O/pytest.log 2>&1 || { echo "PYTEST FAILED"; tail -30 $O/pytest.log; exit 1; }
 tail -3 $O/pytest.log
 run() { # tag, env...
   local tag=$1; shift
