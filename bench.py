@@ -8,20 +8,27 @@ WORLD_SIZE is not set and N > 1 this script starts them itself (fresh child proc
 anything in this process touches a GPU) and relays rank 0's JSON line.  A WORLD_SIZE that differs
 from --gpus is an error (exit 2).
 
-A *step* is one pass of the hot path (symbolize -> alignment #1 -> fusion -> alignment #2 ->
-fusion + MSA columns -> merge of each piece's windows -> per-piece integer counters back on the
-host) over one batch of window triples that is already resident in HBM.  The batch is what
-ELECTOR's own batch protocol hands to its POA engine: the windows of `--reads` synthetic long
-reads (default 10,001, profile = BASELINE.json configs[1]: E. coli 30X SimLord-like PacBio reads,
-15 % error, LoRDEC-like 1 % corrected), cut by this repository's reference-compatible splitter
-on the host before the timed region.  Weak scaling: every rank processes its own shard of reads
-(independent triples, no data-path collective); rank 0 gathers the per-piece integer counters
-over RCCL once per step.  Several engine contexts per GPU take the steps in turn, so several
-batches are in flight (the serial head and tail of one batch overlap the alignment kernels of
-the others).
+A *step* is one pass of the hot path (window classification -> symbolize -> alignment #1 -> fusion ->
+alignment #2 -> fusion + MSA columns -> merge of each piece's windows -> per-piece integer counters AND
+the merged MSA rows back on the host: SURVEY.md 8(d)) over one batch of window triples that is already
+resident in HBM, bases and offsets.  The batch is what ELECTOR's own batch protocol hands to its POA
+engine: the windows of `--reads` synthetic long reads (default 10,001), cut by this repository's
+reference-compatible splitter on the host before the timed region.  The steps rotate over `--batches`
+(default 3) differently seeded batches per rank, ~0.9 GB of input: more than the Infinity Cache holds.
+The default profile follows BASELINE.json's configs by GPU count: 1 or 2 -> configs[2] (yeast 50X ONT-like,
+CONSENT `-split`: the larger of the two 1-GPU configs), 4 -> configs[3] (C. elegans mixed), 8 -> configs[4]
+(chr1 50 kb reads).  At N = 1 the line also carries a `configs` array: the other single-GPU profiles of
+BASELINE.json through the same code at one batch each, with their own reference-parity sample.
+Weak scaling (default): every rank processes its own reads (independent triples, no data-path
+collective); rank 0 gathers the per-piece integer counters over RCCL.  `--scaling strong`: ONE read set
+(`--strong-units` x `--reads` reads, whatever N) is cut into per-rank ranges by the partitioner of
+DESIGN.md section 5 (distributed.shard_bounds over distributed.read_cell_estimate), the line reports the
+DP cells per rank and their imbalance.  Several engine contexts per GPU take the steps in turn, so several
+batches are in flight.
 
 Prints ONE JSON line (rank 0).  `value` = reference-read bases of all ranks' triples per second
-of the slowest rank.  `roofline` prices the dominant kernel against HBM peak using the
+of the slowest rank, rows and counters on the host; `value_rows_in_hbm` = the same steps with the merged
+rows left in HBM (call site #2 needs the counters only).  `roofline` prices the dominant kernel against HBM peak using the
 algorithmic bytes of DESIGN.md and that kernel's UN-OVERLAPPED launch durations: HIP events on
 the launch stream during a serial pass (one context, one launch chain, every kernel alone on
 the chip) that follows the timed region -- with `--serial` the timed region itself runs that
@@ -65,6 +72,13 @@ WORKLOADS = {   # BASELINE.json configs restated as synthetic profiles (elector_
 }
 
 
+DEFAULT_PROFILE_BY_GPUS = {1: "yeast50x_nanosim_consent_split", 2: "yeast50x_nanosim_consent_split",
+                           4: "celegans30x_simlord_mixed", 8: "chr1_20x_ont_50kb"}
+# the single-GPU profiles the `configs` array runs beside the headline one: (profile, reads per batch)
+CONFIGS_ARRAY = [("ecoli30x_simlord_lordec", 10001), ("yeast50x_nanosim_consent_split", 10001),
+                 ("celegans30x_simlord_mixed", 10001), ("chr1_20x_ont_50kb", 2000)]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,21 +87,39 @@ def parse():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("ELECTOR_BENCH_READS", "10001")),
                     help="synthetic long reads per rank and step (10,001 = one batch of ELECTOR's own protocol, "
                          "elector/alignment.py:82, Master_Splitter.cpp:397-399)")
-    ap.add_argument("--profile", default="ecoli30x_simlord_lordec", choices=sorted(WORKLOADS))
+    ap.add_argument("--profile", default=None, choices=sorted(WORKLOADS),
+                    help="default by GPU count: 1, 2 -> yeast50x_nanosim_consent_split, 4 -> celegans30x_simlord_mixed, "
+                         "8 -> chr1_20x_ont_50kb (BASELINE.json configs[2..4])")
+    ap.add_argument("--batches", type=int, default=3, help="differently seeded batches per rank the steps rotate over")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--strong-units", type=int, default=8, help="--scaling strong: the read set is this many x --reads reads, whatever N")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` array (the other single-GPU profiles)")
+    ap.add_argument("--configs-steps", type=int, default=20, help="timed steps per entry of the `configs` array")
     ap.add_argument("--serial", action="store_true",
                     help="one engine context, one launch chain: every kernel runs alone on the chip (per-kernel times add up to the step)")
     ap.add_argument("--serial-steps", type=int, default=10, help="steps of the serial pass behind the timed region")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N > 1: steps whose counters travel to rank 0 in one RCCL gather")
-    ap.add_argument("--no-rows-to-host", action="store_true",
-                    help="skip the second timed loop (the same steps plus the merged MSA rows copied to pinned host memory)")
+    ap.add_argument("--no-rows-in-hbm", "--no-rows-to-host", dest="no_second_loop", action="store_true",
+                    help="skip the second timed loop (the same steps with the merged MSA rows left in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--end-to-end", action="store_true",
                     help="three FASTA files -> getPOA -> outputRecallPrecision with a stage table (see bench_e2e.py)")
     if "--end-to-end" in sys.argv[1:]:              # bench_e2e.py has options of its own (--reference-sample, --no-reference)
-        return ap.parse_known_args()[0]
-    return ap.parse_args()
+        args = ap.parse_known_args()[0]
+    else:
+        args = ap.parse_args()
+    if args.profile is None:
+        args.profile = DEFAULT_PROFILE_BY_GPUS.get(args.gpus, "yeast50x_nanosim_consent_split")
+        args.profile_defaulted = True
+    else:
+        args.profile_defaulted = False
+    if args.serial and "--batches" not in sys.argv[1:]:
+        args.batches = 1                                # the per-kernel passes (profiles/) look at one batch
+    if args.profile == "chr1_20x_ont_50kb" and "--reads" not in " ".join(sys.argv[1:]) and "ELECTOR_BENCH_READS" not in os.environ:
+        args.reads = 2000                               # 50 kb reads: 2,000 of them are a batch of the usual size in bases
+    return args
 
 
 def self_launch(args):
@@ -288,6 +320,59 @@ def skipped_alignment1(win, lr, lc):
     return out
 
 
+class Batch(object):
+    """one batch of window triples: host side (the splitter's Windows + grouping) and, after upload(), the device side"""
+    __slots__ = ("profile", "seed", "win", "n", "total", "lr", "lc", "lu", "piece_first", "read_first", "n_pieces_in",
+                 "piece_bases", "n_reads", "d_bases", "d_off", "po", "ncol_sum")
+
+
+def prepare_batch(job):
+    """Worker (a forked process that never touches a GPU): synthetic reads -> windows on the host.
+    job = (profile, reads, seed, nthreads, read range or None).  The read range (--scaling strong) keeps the pieces of
+    the reads [lo, hi) of the seeded unit only."""
+    import numpy as np
+    from elector_amd import split, synthetic
+    profile, reads, seed, nthreads, rng = job
+    triples, headers, read_of = synthetic.read_pieces(profile, reads, seed=seed)
+    if rng is not None:
+        lo, hi = rng
+        keep = [i for i, r in enumerate(read_of) if lo <= r < hi]
+        triples = [triples[i] for i in keep]
+        headers = [headers[i] for i in keep]
+        read_of = [read_of[i] for i in keep]
+    b = Batch()
+    b.profile, b.seed = profile, seed
+    b.n_pieces_in = len(triples)
+    b.piece_bases = int(sum(len(r[0]) for r in triples))
+    b.n_reads = len(set(read_of))
+    b.win = split.split_reads(triples, 0.1, headers, nthreads=nthreads)
+    off = b.win.off
+    b.n, b.total = b.win.n_windows, int(off[-1])
+    b.lr, b.lc, b.lu = off[1::3] - off[0:-1:3], off[2::3] - off[1:-1:3], off[3::3] - off[2:-1:3]
+    b.piece_first = b.win.read_first
+    b.read_first = synthetic.piece_groups(read_of, b.win.read_index)
+    b.d_bases = b.d_off = b.po = None
+    b.ncol_sum = 0
+    return b
+
+
+def unit_read_lengths(job):
+    """Worker: per read of a seeded unit the lengths (reference, corrected pieces together, uncorrected) -- what the
+    partitioner weighs (distributed.read_cell_estimate)"""
+    import numpy as np
+    from elector_amd import synthetic
+    profile, reads, seed = job
+    triples, _, read_of = synthetic.read_pieces(profile, reads, seed=seed)
+    ids = np.asarray(read_of, dtype=np.int64)
+    nr = int(ids.max()) + 1 if len(ids) else 0
+    lr, lc, lu = np.zeros(nr, dtype=np.int64), np.zeros(nr, dtype=np.int64), np.zeros(nr, dtype=np.int64)
+    for (r, c, u), i in zip(triples, ids):
+        lr[i] = len(r)
+        lu[i] = len(u)
+        lc[i] += len(c)
+    return lr, lc, lu
+
+
 def main():
     args = parse()
     if args.end_to_end:
@@ -306,6 +391,61 @@ def main():
                              % (args.gpus, world, args.gpus, args.gpus))
         sys.exit(2)
     import numpy as np
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    strong = args.scaling == "strong"
+    n_batches = max(1, args.batches)
+    with_configs = world == 1 and not strong and not args.no_configs and not args.serial and args.profile_defaulted
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        ncpu = os.cpu_count() or 1
+    ncores = max(1, ncpu // max(1, world))
+
+    # ---- untimed setup, part 1 (before this process touches a GPU): synthetic reads -> windows on the host, the
+    # batches side by side in forked workers ----
+    jobs = []            # (kind, profile, reads, seed, range)
+    if strong:
+        units = max(1, args.strong_units)
+        if os.environ.get("ELECTOR_BENCH_NO_FORK", "0") in ("", "0"):
+            with ProcessPoolExecutor(max_workers=min(units, ncores), mp_context=mp.get_context("fork")) as ex:
+                lens = list(ex.map(unit_read_lengths, [(args.profile, args.reads, 1000 + 7919 * u) for u in range(units)]))
+        else:
+            lens = [unit_read_lengths((args.profile, args.reads, 1000 + 7919 * u)) for u in range(units)]
+        from elector_amd import distributed as edist0
+        lr_all = np.concatenate([x[0] for x in lens]); lc_all = np.concatenate([x[1] for x in lens]); lu_all = np.concatenate([x[2] for x in lens])
+        weights = edist0.read_cell_estimate(lr_all, lc_all, lu_all)
+        bounds = edist0.shard_bounds(weights, world)
+        unit_first = np.concatenate([[0], np.cumsum([len(x[0]) for x in lens])])
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        for u in range(units):
+            lo, hi = max(r0, int(unit_first[u])), min(r1, int(unit_first[u + 1]))
+            if lo < hi:
+                jobs.append((args.profile, args.reads, 1000 + 7919 * u, (lo - int(unit_first[u]), hi - int(unit_first[u]))))
+        est_per_rank = [float(weights[int(bounds[r]):int(bounds[r + 1])].sum()) for r in range(world)]
+        n_head = len(jobs)
+    else:
+        for b in range(n_batches):
+            jobs.append((args.profile, args.reads, 1000 + rank + 7919 * b, None))
+        n_head = len(jobs)
+        if with_configs:
+            for prof, reads in CONFIGS_ARRAY:
+                if prof != args.profile:
+                    # (a caller that asks for small batches -- the tests -- gets small entries too)
+                    jobs.append((prof, reads if args.reads >= 10001 else min(reads, args.reads), 1000, None))
+    nproc = max(1, min(len(jobs), ncores // 4 if ncores >= 8 else 1, 8))
+    nthreads = max(1, ncores // nproc)
+    t_setup = time.perf_counter()
+    # (one job, or ELECTOR_BENCH_NO_FORK=1 -- runs under a profiler, whose preloaded library has initialised the GPU
+    # before this program starts: in this process)
+    if len(jobs) > 1 and os.environ.get("ELECTOR_BENCH_NO_FORK", "0") in ("", "0"):
+        with ProcessPoolExecutor(max_workers=nproc, mp_context=mp.get_context("fork")) as ex:
+            prepared = list(ex.map(prepare_batch, [(j[0], j[1], j[2], nthreads, j[3]) for j in jobs]))
+    else:
+        prepared = [prepare_batch((j[0], j[1], j[2], ncores, j[3])) for j in jobs]
+    t_setup = time.perf_counter() - t_setup
+    head_batches, other_batches = prepared[:n_head], prepared[n_head:]
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -325,242 +465,246 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from elector_amd import split, synthetic
+    from elector_amd import distributed as edist
     from elector_amd.poa import PoaEngine
-
-    # ---- untimed setup: synthetic reads -> windows (host), upload --------
-    triples, headers, read_of = synthetic.read_pieces(args.profile, args.reads, seed=1000 + rank)
-    piece_bases = int(sum(len(r[0]) for r in triples))
-    nthreads = max(1, (os.cpu_count() or 1) // max(1, world))
-    win = split.split_reads(triples, 0.1, headers, nthreads=nthreads)
-    n_pieces_in = len(triples)
-    del triples
-    off = win.off
-    n = win.n_windows
-    lr = off[1::3] - off[0:-1:3]
-    lc = off[2::3] - off[1:-1:3]
-    lu = off[3::3] - off[2:-1:3]
+    from elector_amd._capi import ES_NCOUNTERS
     dev = torch.device("cuda", local)
-    d_bases = torch.from_numpy(win.bases).to(dev)
-    # the window offsets are resident in HBM like the bases (the device splitter leaves both there): the timed entry
-    # is elector_poa_batch_device_offsets, which does no per-window work on the host.  ELECTOR_BENCH_HOST_OFFSETS=1
-    # times the entry that takes them from a host array instead (A/B)
-    d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.int64)).to(dev)
-    total_bases = int(off[-1])
     host_offsets = os.environ.get("ELECTOR_BENCH_HOST_OFFSETS", "0") not in ("", "0")
 
-    def align(engine, dc, dn, ds):
-        if host_offsets:
-            engine.align_device(d_bases, off, dc, dn, ds)
-        else:
-            engine.align_device_offsets(d_bases, d_off, n, total_bases, dc, dn, ds)
-    # E engine contexts (four by default) take the steps in turn (several batches in flight: the serial head and tail
-    # of one batch -- symbolize / trivial pass / list sort, merge / statistics -- run beside the
-    # alignment kernels of the other).  Every context has its own output buffers.
+    def upload(b):
+        """bases AND offsets resident in HBM (the device splitter leaves both there)"""
+        b.d_bases = torch.from_numpy(b.win.bases).to(dev) if b.n else torch.zeros(64, dtype=torch.uint8, device=dev)
+        b.d_off = torch.from_numpy(np.ascontiguousarray(b.win.off, dtype=np.int64)).to(dev)
+
+    for b in head_batches:
+        upload(b)
+    all_batches = head_batches + other_batches
+    max_total = max([b.total for b in all_batches] + [64])
+    max_n = max([b.n for b in all_batches] + [1])
+    # E engine contexts (four by default) take the batches in turn (several in flight: the serial head and tail
+    # of one batch -- classification / symbolize / trivial pass / list sort, merge / statistics -- run beside the
+    # alignment kernels of the others).  Every context has its own output buffers.
     n_eng = 1 if args.serial else max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "4")))
     engines = [PoaEngine(local) for _ in range(n_eng)]
     if args.serial:
         engines[0].option("chains", 1)
-    outs = [(torch.empty(3 * int(off[-1]) + 64, dtype=torch.uint8, device=dev),
-             torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+    outs = [(torch.empty(3 * max_total + 64, dtype=torch.uint8, device=dev),
+             torch.empty(max_n, dtype=torch.int32, device=dev), torch.empty(max_n, dtype=torch.int32, device=dev))
             for _ in range(n_eng)]
-    eng = engines[0]
-    d_cols, d_ncol, d_status = outs[0]
-    # one msa.fa record per corrected piece (= per emitted read of the splitter); the pieces of one
-    # read are one read again for the statistics (computeStats.py:45-56)
-    piece_first = win.read_first
-    read_first = synthetic.piece_groups(read_of, win.read_index)
-    from elector_amd import distributed as edist
-    from elector_amd._capi import ES_NCOUNTERS
+    rows_cap = 3 * max_total + 64
+    pinned = [torch.empty(rows_cap, dtype=torch.uint8).pin_memory() for _ in range(n_eng)]
 
-    # every step gathers the same number of counter rows per rank (one per piece of the rank's batch): the ranks
-    # tell each other once, the steps then need one collective each
-    gather_sizes = edist.gather_sizes(len(piece_first) - 1) if dist_on else None
-    pending = []
-    gathers = []
-    held = []
-    gather_every = max(1, args.gather_every)
-    gather_cap = gather_every * max(gather_sizes) if gather_sizes else 0       # rows of the largest block a gather carries
+    def align(engine, b, dc, dn, ds):
+        if host_offsets:
+            engine.align_device(b.d_bases, b.win.off, dc, dn, ds)
+        else:
+            engine.align_device_offsets(b.d_bases, b.d_off, b.n, b.total, dc, dn, ds)
+
+    class Runner(object):
+        """the step loop over a list of units (a unit = the batches of one step)"""
+
+        def __init__(self, units, gather=False):
+            self.units = units
+            self.pending = []                 # (engine, step id, batch, pieces) oldest first
+            self.turn = 0
+            self.step_id = 0
+            self.parts = {}                   # step id -> [unit index, counters of its batches so far]
+            self.host_enqueue_s = self.host_wait_s = self.gather_s = 0.0
+            self.last_counters = None
+            self.last_batch_of_engine = [None] * n_eng
+            self.rows_bytes = 0
+            self.gather = gather and dist_on
+            self.held, self.gathers = [], []
+            if self.gather:
+                # every rank tells the others once how many counter rows each unit brings
+                self.sizes_u = [edist.gather_sizes(sum(len(b.piece_first) - 1 for b in u)) for u in units]
+                self.gather_cap = max(1, args.gather_every) * max(max(s) for s in self.sizes_u)
+
+        def collect_oldest(self):
+            e, sid, b, npieces = self.pending.pop(0)
+            t = time.perf_counter()
+            counters, pc = engines[e].msa_stats_collect(npieces)
+            self.host_wait_s += time.perf_counter() - t
+            self.rows_bytes = 3 * int(pc.sum())
+            ui, got = self.parts[sid]
+            got.append(counters)
+            if len(got) == len(self.units[ui]):
+                del self.parts[sid]
+                c = np.concatenate(got) if len(got) > 1 else got[0]
+                if self.gather:
+                    tg = time.perf_counter()
+                    self.held.append((ui, c))
+                    res = self.flush_gather(False)
+                    if res is not None:
+                        self.last_counters = res
+                    self.gather_s += time.perf_counter() - tg
+                else:
+                    self.last_counters = c
+
+        def flush_gather(self, force):
+            """Fewer, larger collectives: the counters of `gather_every` steps travel together (every step's counters
+            still reach rank 0 inside the timed region).  An RCCL collective holds compute units while it runs and its
+            small copies queue up behind whole launch chains: one gather per step cost 19 % of the step rate in a one-rank
+            rehearsal on RCCL, one per eight steps nothing measurable.  Staging, collective and taking the result in run
+            on a helper thread; up to three are in flight.  -> the last step's rows of the oldest finished gather (rank 0)"""
+            res = None
+            if self.held and (force or len(self.held) >= max(1, args.gather_every)):
+                held, self.held = self.held, []
+                block = np.concatenate([c for _, c in held]) if len(held) > 1 else held[0][1]
+                sizes = [sum(self.sizes_u[ui][r] for ui, _ in held) for r in range(len(self.sizes_u[0]))]
+                last = [(sum(self.sizes_u[ui][r] for ui, _ in held[:-1]), self.sizes_u[held[-1][0]][r]) for r in range(len(sizes))]
+                self.gathers.append((sizes, last, gpool.submit(
+                    lambda c=block, z=sizes: edist.gather_rows_async(c, z, cap=self.gather_cap,
+                                                                     device=local if backend == "nccl" else None).wait())))
+            while self.gathers and (force or len(self.gathers) > 3):
+                sizes, last, fut = self.gathers.pop(0)
+                got = fut.result()
+                if got is not None:
+                    parts, at = [], 0
+                    for r, z in enumerate(sizes):
+                        parts.append(got[at + last[r][0]: at + last[r][0] + last[r][1]])
+                        at += z
+                    res = np.concatenate(parts) if len(parts) > 1 else parts[0]
+            return res
+
+        def step(self, rows):
+            """Queue one step: per batch of the unit, windows in HBM -> POA kernels -> merge -> counters (and with `rows`
+            the merged rows) -> pinned host memory.  A context's previous job is taken in right before the context is
+            used again: the host prepares step i+1 while the GPU still works on the batches before it, as a run over
+            many 10,001-read batches would."""
+            ui = self.step_id % len(self.units)
+            sid = self.step_id
+            self.step_id += 1
+            self.parts[sid] = [ui, []]
+            for b in self.units[ui]:
+                e = self.turn % n_eng
+                self.turn += 1
+                while len(self.pending) >= n_eng:
+                    self.collect_oldest()
+                dc, dn, ds = outs[e]
+                t = time.perf_counter()
+                align(engines[e], b, dc, dn, ds)
+                npieces = engines[e].msa_stats_enqueue(b.n, dc, dn, ds, b.piece_first, b.read_first,
+                                                       rows_out=pinned[e].data_ptr() if rows else None, rows_cap=rows_cap)
+                self.host_enqueue_s += time.perf_counter() - t
+                self.pending.append((e, sid, b, npieces))
+                self.last_batch_of_engine[e] = b
+
+        def drain(self):
+            while self.pending:
+                self.collect_oldest()
+            if self.gather:
+                res = self.flush_gather(True)
+                if res is not None:
+                    self.last_counters = res
+
+        def timed(self, steps, rows):
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            for g in engines:
+                g.sync()
+            self.host_enqueue_s = self.host_wait_s = self.gather_s = 0.0
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(rows)
+            self.drain()                         # every step's counters (and rows) are on the host before the clock stops
+            for g in engines:
+                g.sync()
+            torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
+            return time.perf_counter() - t0
+
     gpool = None
     if dist_on:
         from concurrent.futures import ThreadPoolExecutor as _TPE
         # (a new thread's current device is 0 whatever this thread set: the helper binds itself to the rank's GPU, and the
         # pipe is told the device as well)
         gpool = _TPE(max_workers=1, initializer=torch.cuda.set_device, initargs=(local,))
-    turn = [0]
-    host_s = [0.0]                               # host time of classifying and enqueueing (the GPU work is asynchronous)
-    gather_s = [0.0]                             # host time of starting a step's gather and taking in an earlier one
 
-    def collect():
-        """per-piece counters of the oldest queued step on the host (rank 0 receives every rank's rows)"""
-        e, npieces = pending.pop(0)
-        counters, _ = engines[e].msa_stats_collect(npieces)
-        if not dist_on:
-            return counters
-        # Fewer, larger collectives: the counters of `gather_every` steps travel together (every step's counters
-        # still reach rank 0 inside the timed region).  An RCCL collective holds compute units while it runs and its
-        # small copies queue up behind whole launch chains of the alignment kernels: one gather per step cost 19 % of
-        # the step rate in a one-rank rehearsal on RCCL, one per eight steps costs nothing measurable.  The staging,
-        # the collective and taking its result in run on a helper thread; up to three are in flight.
-        tg = time.perf_counter()
-        held.append(counters)
-        res = flush_gather(False)
-        gather_s[0] += time.perf_counter() - tg
+    def measure(batches, steps, warmup, units=None, gather=False, second_loop=True):
+        """warm up, then the two timed loops over `batches` -> dict of raw results"""
+        units = units if units is not None else [[b] for b in batches]
+        run = Runner(units, gather)
+        # untimed: grow every workspace (both statistics slots of every context) and let the HIP runtime size its queues
+        # for overlapped batches -- the first batch enqueued while another still runs pays a one-time ~14 ms inside it
+        for _ in range(max(3 * n_eng // max(1, len(units[0])), len(units)) + 1):
+            run.step(True)
+        run.drain()
+        # |PO| per window and the column total of every batch (DP cells, algorithmic bytes) from an untimed pass
+        for b in batches:
+            if b.po is None:
+                dc, dn, ds = outs[0]
+                align(engines[0], b, dc, dn, ds)
+                engines[0].sync()
+                st = ds[:b.n].cpu().numpy()
+                if st.any():
+                    raise SystemExit("bench: %d windows failed on device" % int((st != 0).sum()))
+                b.po = engines[0].last_po_sizes(b.n).astype(np.int64)
+                b.ncol_sum = int(dn[:b.n].cpu().numpy().astype(np.int64).sum())
+        for _ in range(warmup):
+            run.step(True)
+        run.drain()
+        for g in engines:
+            g.sync()
+            g.timing_enable(args.serial)
+            g.timing_reset()
+        dt = run.timed(steps, True)
+        res = {"dt": dt, "host_enqueue_ms": run.host_enqueue_s / steps * 1e3, "host_wait_ms": run.host_wait_s / steps * 1e3,
+               "gather_ms": run.gather_s / steps * 1e3, "counters": run.last_counters, "rows_bytes": run.rows_bytes,
+               "last_batch_of_engine": list(run.last_batch_of_engine), "dt_hbm": None}
+        # the MSA the timed kernels wrote (context 0's last timed batch), for the comparison with the reference binary
+        # behind the clock
+        res["msa0"] = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and run.last_batch_of_engine[0] is not None:
+            b0 = run.last_batch_of_engine[0]
+            res["msa0"] = (b0, outs[0][0][:3 * b0.total + 64].cpu().numpy(), outs[0][1][:b0.n].cpu().numpy())
+        if second_loop:
+            run2 = Runner(units, gather)
+            for _ in range(n_eng + 1):
+                run2.step(False)
+            run2.drain()
+            res["dt_hbm"] = run2.timed(steps, False)
         return res
 
-    def flush_gather(force):
-        """-> the last step's rows of the oldest finished gather (rank 0), or None"""
-        res = None
-        if held and (force or len(held) >= gather_every):
-            k = len(held)
-            block = np.concatenate(held) if k > 1 else held[0]
-            held.clear()
-            sizes = [x * k for x in gather_sizes]
-            gathers.append((k, gpool.submit(lambda c=block, z=sizes: edist.gather_rows_async(c, z, cap=gather_cap, device=local if backend == "nccl" else None).wait())))
-        while gathers and (force or len(gathers) > 3):
-            k, fut = gathers.pop(0)
-            got = fut.result()
-            if got is not None:
-                # rows arrive rank by rank, each rank's k steps back to back: the last step of every rank
-                parts, at = [], 0
-                for x in gather_sizes:
-                    parts.append(got[at + (k - 1) * x: at + k * x])
-                    at += k * x
-                res = np.concatenate(parts) if len(parts) > 1 else parts[0]
-        return res
+    # ---- headline: the timed region ----------------------------------------------------
+    head_units = [list(head_batches)] if strong else None
+    steps = args.steps
+    R = measure(head_batches, steps, args.warmup, units=head_units, gather=True, second_loop=not args.no_second_loop and not args.serial)
+    dt, dt_hbm = R["dt"], R["dt_hbm"]
+    counters = R["counters"]
+    b0 = head_batches[0] if head_batches else None
 
-    def step():
-        """Queue one step (windows in HBM -> POA kernels -> merge -> counters -> pinned host memory),
-        then hand out the counters of the oldest step in flight: the host prepares step i+1 while the
-        GPU still works on step i, as a run over many 10,001-read batches would."""
-        e = turn[0] % n_eng
-        turn[0] += 1
-        dc, dn, ds = outs[e]
-        th = time.perf_counter()
-        align(engines[e], dc, dn, ds)
-        pending.append((e, engines[e].msa_stats_enqueue(n, dc, dn, ds, piece_first, read_first)))
-        host_s[0] += time.perf_counter() - th
-        return collect() if len(pending) > n_eng else None
-
-    # untimed setup, continued: grow every workspace (both halves of the double-buffered upload staging
-    # and of the statistics slots) and let the HIP runtime size its queues for overlapped batches -- the
-    # first batch that is enqueued while another still runs pays a one-time ~14 ms inside the runtime
-    def drain():
-        while pending:
-            collect()
-        flush_gather(True)
-
-    for _ in range(3 * n_eng):
-        step()
-    drain()
-    for _ in range(args.warmup):
-        step()
-    drain()
-    for g in engines:
-        g.sync()
-        g.timing_enable(args.serial)
-        g.timing_reset()
-
-    # ---- timed region ----------------------------------------------------
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    for g in engines:
-        g.sync()
-    host_s[0] = 0.0
-    gather_s[0] = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    while pending:
-        counters = collect()                     # every step's counters are on the host before the clock stops
-    if dist_on:
-        last = flush_gather(True)                # ... and, with several ranks, on rank 0
-        counters = last if last is not None else counters
-    for g in engines:
-        g.sync()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    host_ms_per_step = host_s[0] / args.steps * 1e3
-    gather_ms_per_step = gather_s[0] / args.steps * 1e3
-
-    # the MSA the timed kernels wrote (context 0's last timed step), for the every-window comparison with the
-    # reference binary behind the clock
-    cols_timed = ncol_timed = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cols_timed = outs[0][0].cpu().numpy()
-        ncol_timed = outs[0][1].cpu().numpy()
-    exit_code = 0
-    status = d_status.cpu().numpy()
-    ncol = d_ncol.cpu().numpy().astype(np.int64)
-    if status.any():
-        raise SystemExit("bench: %d windows failed on device" % int((status != 0).sum()))
-    po = eng.last_po_sizes(n).astype(np.int64)
-
-    # ---- second timed loop: the same steps, and every step's merged MSA rows (the body of msa.fa, Donatello.cpp:86-91)
-    # copied to pinned host memory as well -- SURVEY.md 8(d) words the metric "MSA rows + per-read counters back on
-    # host"; `value` keeps the rows in HBM (call site #2 needs the counters only, 8(f2)), this figure brings them over
-    # PCIe.  One helper thread per context collects the counters and fetches the rows (the library releases the GIL),
-    # so the copies of one context run beside the kernels of the others.
-    dt_rows = None
-    rows_bytes = 0
-    if not args.no_rows_to_host and not args.serial:
-        from concurrent.futures import ThreadPoolExecutor
-        cap = 3 * int(off[-1]) + 64
-        pinned = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(n_eng)]
-        pool = ThreadPoolExecutor(max_workers=n_eng)
-        futs = [None] * n_eng
-        fetched = [0]
-
-        def finish_rows(e, npieces):
-            c, pc = engines[e].msa_stats_collect(npieces)
-            fetched[0] = engines[e].msa_rows_fetch_into(pc, pinned[e].data_ptr(), cap)
-            return c
-
-        def step_rows():
-            e = turn[0] % n_eng
-            turn[0] += 1
-            if futs[e] is not None:
-                futs[e].result()                     # this context's previous step is on the host, rows included
-            dc, dn, ds = outs[e]
-            align(engines[e], dc, dn, ds)
-            futs[e] = pool.submit(finish_rows, e, engines[e].msa_stats_enqueue(n, dc, dn, ds, piece_first, read_first))
-
-        def drain_rows():
-            for e in range(n_eng):
-                if futs[e] is not None:
-                    futs[e].result()
-                    futs[e] = None
-
-        for _ in range(n_eng + 1):
-            step_rows()
-        drain_rows()
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_rows()
-        drain_rows()
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        dt_rows = time.perf_counter() - t0
-        rows_bytes = int(fetched[0])
-        pool.shutdown()
-        del pinned
+    # ---- the `configs` array: the other single-GPU profiles, one batch each ----
+    configs = []
+    if with_configs:
+        for ob in other_batches:
+            upload(ob)
+            Ro = measure([ob], max(1, args.configs_steps), 2, second_loop=True)
+            entry = {"profile": ob.profile, "workload": WORKLOADS[ob.profile], "reads_per_step": ob.n_reads, "windows_per_step": ob.n,
+                     "ref_bases_per_step": ob.piece_bases, "steps": max(1, args.configs_steps), "batches_rotated": 1,
+                     "value": round(ob.piece_bases * max(1, args.configs_steps) / Ro["dt"] / 1e6, 3),
+                     "ms_per_step": round(Ro["dt"] / max(1, args.configs_steps) * 1e3, 3),
+                     "value_rows_in_hbm": round(ob.piece_bases * max(1, args.configs_steps) / Ro["dt_hbm"] / 1e6, 3),
+                     "counters_checksum": int(Ro["counters"][:, :ES_NCOUNTERS - 1].sum())}
+            if Ro["msa0"] is not None:
+                mb, mcols, mncol = Ro["msa0"]
+                base, par = cpu_baseline(mb.win, mb.lr, min(4.0, args.cpu_seconds), (mcols, mncol))
+                entry["cpu_baseline"] = base
+                if par is not None:
+                    entry["parity_vs_reference"] = par
+            configs.append(entry)
+            ob.d_bases = ob.d_off = None
 
     # ---- after the clock: serial pass for the per-kernel roofline -------------------------------------------
     # A context of its own with ONE launch chain from its first step on, after the timed contexts are gone: exactly
-    # what `bench.py --serial` times and what profiles/*_serial_kernel_stats.csv (rocprofv3 over that command) shows,
-    # so the figures below can be recomputed from the committed profile.  (Up to round 2 this pass reused a timed
-    # context switched to one chain: its moves pool kept the two-chain size, twice the slots in rotation and a lower
-    # hit rate in L2 / Infinity Cache -- k_poa came out 13 % slower than in the profile.)
+    # what `bench.py --serial --batches 1` times and what profiles/*_serial_kernel_stats.csv (rocprofv3 over that
+    # command) shows, so the figures below can be recomputed from the committed profile.  Batch 0 only.
     serial_steps = args.steps if args.serial else max(1, args.serial_steps)
     serial_wall = dt / args.steps
-    if not args.serial:
+    d_cols, d_ncol, d_status = outs[0]
+    if not args.serial and b0 is not None:
         for g in engines[1:]:
             g.close()
         engines[0].close()
@@ -569,8 +713,8 @@ def main():
         eng.option("chains", 1)
 
         def serial_step():
-            align(eng, d_cols, d_ncol, d_status)
-            eng.msa_stats_collect(eng.msa_stats_enqueue(n, d_cols, d_ncol, d_status, piece_first, read_first))
+            align(eng, b0, d_cols, d_ncol, d_status)
+            eng.msa_stats_collect(eng.msa_stats_enqueue(b0.n, d_cols, d_ncol, d_status, b0.piece_first, b0.read_first))
         for _ in range(4):                       # grow the workspace, settle the clocks
             serial_step()
         eng.sync()
@@ -581,35 +725,50 @@ def main():
             serial_step()
         eng.sync()
         serial_wall = (time.perf_counter() - ts) / serial_steps
-    skipped = skipped_alignment1(win, lr, lc)
-    cells1, cells2 = int((lr * lc).sum()), int((po * lu).sum())
-    cells1_computed = int((lr * lc)[~skipped].sum())
+    eng = engines[0]
     t_dp1, k_dp1 = eng.timing_read(0)
     t_dp2, k_dp2 = eng.timing_read(1)
     t_oth = eng.timing_read(2)[0]
     t_st = eng.timing_read(3)[0]
     t_poa, k_poa = eng.timing_read(4)
+
+    # per step (averaged over the rotation): bases, windows, DP cells
+    def per_step(f):
+        if strong:
+            return float(sum(f(b) for b in head_batches))
+        return float(sum(f(b) for b in head_batches)) / max(1, len(head_batches))
+    skipped = {id(b): skipped_alignment1(b.win, b.lr, b.lc) for b in head_batches}
+    bases_step = per_step(lambda b: b.piece_bases)
+    windows_step = per_step(lambda b: b.n)
+    cells_step = per_step(lambda b: int((b.lr * b.lc).sum()) + int((b.po * b.lu).sum()))
+    cells_comp_step = per_step(lambda b: int((b.lr * b.lc)[~skipped[id(b)]].sum()) + int((b.po * b.lu).sum()))
+    my_cells = float(sum(int((b.lr * b.lc).sum()) + int((b.po * b.lu).sum()) for b in head_batches)) if strong else cells_step
     rdev = dev if backend == "nccl" else torch.device("cpu")
-    tmax = torch.tensor([dt, dt_rows or 0.0], dtype=torch.float64, device=rdev)
-    tot = torch.tensor([piece_bases, n, cells1 + cells2, cells1_computed + cells2], dtype=torch.int64, device=rdev)
+    tmax = torch.tensor([dt, dt_hbm or 0.0], dtype=torch.float64, device=rdev)
+    tot = torch.tensor([bases_step, windows_step, cells_step, cells_comp_step], dtype=torch.float64, device=rdev)
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt_max, dt_rows_max = float(tmax[0].item()), float(tmax[1].item())
+    dt_max, dt_hbm_max = float(tmax[0].item()), float(tmax[1].item())
     # what the process group actually spans: one entry per rank, gathered over it (RCCL when the backend is nccl)
     props = torch.cuda.get_device_properties(local)
     me = {"rank": rank, "local_rank": local, "device": props.name, "uuid": str(getattr(props, "uuid", "")),
-          "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "host": socket.gethostname()}
+          "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "host": socket.gethostname(),
+          "reads": int(sum(b.n_reads for b in head_batches)) if strong else int(b0.n_reads if b0 else 0),
+          "dp_cells_per_step": my_cells}
     ranks = [me]
     if dist_on:
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
-    bases_all, windows_all, cells_all, cells_comp_all = (int(x) for x in tot.tolist())
+    bases_all, windows_all, cells_all, cells_comp_all = (float(x) for x in tot.tolist())
 
+    exit_code = 0
     if rank == 0:
         value = bases_all * args.steps / dt_max / 1e6
-        # roofline of the dominant kernel: algorithmic bytes = 8-bit inputs + 8-bit MSA out + descriptors
-        alg_bytes = int((lr + lc + lu).sum() + 3 * ncol.sum() + 28 * n)
+        step_s = dt_max / args.steps
+        # roofline of the dominant kernel: algorithmic bytes = 8-bit inputs + 8-bit MSA out + descriptors (batch 0, the
+        # serial pass's batch)
+        alg_bytes = int((b0.lr + b0.lc + b0.lu).sum() + 3 * b0.ncol_sum + 28 * b0.n) if b0 is not None else 0
         # kernel classes: 4 = k_poa (the whole window in one kernel: both alignments, tracebacks, fusions); 0 / 1 =
         # alignment #1 / #2 stage of the two-kernel path (k_fused_a / k_fused_b; behind k_poa only the windows it
         # handed back); measured un-overlapped (serial pass)
@@ -626,51 +785,57 @@ def main():
                 valu = int(pmc["valu_wave_insts_per_step"])
             except (KeyError, ValueError):
                 pass
-        step_s = dt_max / args.steps
+        cells_ranks = [r["dp_cells_per_step"] for r in ranks]
         out = {
             "metric": "triplet-MSA Mbases/s", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "%s: %d reads per GPU per step, cut into windows by the ELECTOR splitter rules"
-                                   % (WORKLOADS[args.profile], args.reads),
-                       "profile": args.profile, "reads_per_gpu": args.reads, "triples_per_gpu": n_pieces_in,
-                       "windows_per_gpu": n, "ref_bases_per_gpu": piece_bases,
-                       "filler_windows_per_gpu": int((lc == 1).sum()),
+                                   % (WORKLOADS[args.profile], args.reads) if not strong else
+                                   "%s: ONE read set of %d x %d reads per step whatever the GPU count, cut into per-rank ranges by "
+                                   "DP-cell estimate (distributed.shard_bounds)" % (WORKLOADS[args.profile], args.strong_units, args.reads),
+                       "profile": args.profile, "reads_per_gpu": args.reads, "triples_per_gpu": int(b0.n_pieces_in if b0 else 0),
+                       "windows_per_gpu": int(round(windows_all / world)), "ref_bases_per_gpu": int(round(bases_all / world)),
+                       "filler_windows_per_gpu": int((b0.lc == 1).sum()) if b0 is not None else 0,
                        "parallelism": "shard-by-read x%d" % world,
                        "batches_in_flight_per_gpu": n_eng, "serial": bool(args.serial),
-                       # `value`: per-read counters back on the host, the merged MSA rows stay in HBM (SURVEY.md 8(f2):
-                       # call site #2 is served from the device counters); `value_rows_to_host` adds the rows
-                       "rows_to_host": False},
-            "value_rows_to_host": None if not dt_rows_max else round(bases_all * args.steps / dt_rows_max / 1e6, 3),
-            "rows_to_host": None if not dt_rows_max else {
-                "ms_per_step": round(dt_rows_max / args.steps * 1e3, 3), "bytes_per_step_per_gpu": rows_bytes,
-                "pcie_gbs_per_gpu": round(rows_bytes * args.steps / dt_rows_max / 1e9, 2),
-                "note": "the same %d steps timed again with every step's merged rows (3 x columns bytes per piece) copied "
-                        "to pinned host memory by a helper thread per context" % args.steps},
+                       "batches_rotated": len(head_batches), "input_bytes_rotated_per_gpu": int(sum(b.total + 8 * (3 * b.n + 1) for b in head_batches)),
+                       # `value`: per-read counters AND the merged MSA rows back on the host; the rows
+                       # are written to pinned host memory by the compaction kernel's own stores, inside the queue
+                       "rows_to_host": True, "offsets_resident_in_hbm": not host_offsets},
+            "rows_to_host": {"bytes_per_step_per_gpu": int(R["rows_bytes"]),
+                             "pcie_gbs_per_gpu": round(R["rows_bytes"] * (len(head_batches) if strong else 1) / step_s / 1e9, 2)},
+            "value_rows_in_hbm": None if not dt_hbm_max else round(bases_all * args.steps / dt_hbm_max / 1e6, 3),
+            "rows_in_hbm": None if not dt_hbm_max else {
+                "ms_per_step": round(dt_hbm_max / args.steps * 1e3, 3),
+                "note": "the same %d steps timed again with the merged rows left in HBM: call site #2 is served from the "
+                        "device counters (SURVEY.md 8(f2)), only they cross PCIe" % args.steps},
             "ranks": {"world": world, "backend": backend if dist_on else None,
                       "distinct_devices": len({(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks}),
+                      "dp_cells_imbalance_max_over_mean": round(max(cells_ranks) / (sum(cells_ranks) / len(cells_ranks)), 4) if sum(cells_ranks) > 0 else None,
                       "devices": ranks},
-            # dtype: k_poa's recurrences run on 16-bit scores, two windows per 32-bit lane (the fall-back kernels, 0.2 %
-            # of the windows, on 32-bit ones)
             # DP cells per second.  effective: every cell the reference computes (Lr*Lc + |PO|*Lu per window);
             # computed: without alignment #1 of the windows whose corrected sequence equals the reference or
             # differs by one substitution or one indel, which the device settles without a dynamic program (k_trivial)
             "gcups_effective": round(cells_all * args.steps / dt_max / 1e9, 3),
             "gcups_computed": round(cells_comp_all * args.steps / dt_max / 1e9, 3),
-            "alignment1_skipped_windows_frac": round(float(skipped.mean()), 4),
+            "alignment1_skipped_windows_frac": round(float(np.mean(np.concatenate([skipped[id(b)] for b in head_batches]))), 4) if head_batches else None,
             "kernel_ms_per_step": {"k_poa": round(t_poa / serial_steps, 3),
                                    "alignment1_stage": round(t_dp1 / serial_steps, 3),
                                    "alignment2_stage": round(t_dp2 / serial_steps, 3),
                                    "other": round(t_oth / serial_steps, 3),
                                    "merge_and_counters": round(t_st / serial_steps, 3),
                                    "serial_step_wall": round(serial_wall * 1e3, 3),
-                                   "host_classify_and_enqueue": round(host_ms_per_step, 3),
-                                   "host_counters_gather": round(gather_ms_per_step, 3),
-                                   "note": "HIP-event time per launch, summed per step, from %d un-overlapped steps "
+                                   # host time of the timed region per step: inside the two calls that queue a batch (they
+                                   # include one short wait for the classification kernel's totals), and waiting for results
+                                   "host_classify_and_enqueue": round(R["host_enqueue_ms"], 3),
+                                   "host_wait_for_results": round(R["host_wait_ms"], 3),
+                                   "host_counters_gather": round(R["gather_ms"], 3),
+                                   "note": "HIP-event time per launch, summed per step, from %d un-overlapped steps over batch 0 "
                                            "(one context, one launch chain)%s"
                                            % (serial_steps, "" if args.serial else
-                                              " in a fresh context after the timed region, = what `bench.py --serial` times")},
+                                              " in a fresh context after the timed region, = what `bench.py --serial --batches 1` times")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_provenance": pmc_prov if traffic is not None else None,
@@ -678,29 +843,39 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "whole_step_frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 6)},
             # what actually binds: VALU issue + latency.  Per GPU: wave-instructions per
-            # step from the committed PMC passes of this command, time measured live
+            # step from the committed PMC passes of this command (batch 0), time measured live
             "roofline_valu": None if valu is None else {
                 "bound": "valu-issue", "wave_insts_per_step": valu, "provenance": pmc_prov, "peak": round(VALU_PEAK_GINSTS, 1),
                 "peak_two_operand_32bit": round(VALU_PEAK_GINSTS_SIMPLE, 1),
                 "peak_note": "packed 16-bit, three-operand and DPP instructions issue once per 4 cycles per SIMD "
                              "(measured: tests/micro/valu_rate.hip, profiles/r02_valu_rate.txt)",
                 "unit": "G wave-insts/s per GPU",
-                "achieved": round(valu / step_s / 1e9, 1),
-                "frac": round(valu / step_s / 1e9 / VALU_PEAK_GINSTS, 4)},
-            "pieces_gathered": int(counters.shape[0]),
-            "counters_checksum": int(counters[:, :ES_NCOUNTERS - 1].sum()),
+                "achieved": round(valu / (dt_hbm_max / args.steps if dt_hbm_max else step_s) / 1e9, 1),
+                "frac": round(valu / (dt_hbm_max / args.steps if dt_hbm_max else step_s) / 1e9 / VALU_PEAK_GINSTS, 4)},
+            "pieces_gathered": int(counters.shape[0]) if counters is not None else 0,
+            "counters_checksum": int(counters[:, :ES_NCOUNTERS - 1].sum()) if counters is not None else 0,
+            "setup_s": round(t_setup, 1),
         }
+        if strong:
+            out["strong"] = {"units": args.strong_units, "reads_total": int(sum(r["reads"] for r in ranks)),
+                             "estimated_cells_per_rank": est_per_rank,
+                             "estimate_imbalance_max_over_mean": round(max(est_per_rank) / (sum(est_per_rank) / len(est_per_rank)), 4)}
         parity = None
-        if world == 1 and not args.no_cpu_baseline:
-            # the MSA columns of the batch the timed region worked on, as the last timed step of context 0 left them
-            out["cpu_baseline"], parity = cpu_baseline(win, lr, args.cpu_seconds, (cols_timed, ncol_timed))
+        if world == 1 and not args.no_cpu_baseline and R["msa0"] is not None:
+            # the MSA columns of a batch the timed region worked on, as the last timed batch of context 0 left them
+            mb, mcols, mncol = R["msa0"]
+            out["cpu_baseline"], parity = cpu_baseline(mb.win, mb.lr, args.cpu_seconds, (mcols, mncol))
             if parity is not None:
                 out["parity_vs_reference"] = parity
+        if configs:
+            out["configs"] = configs
         print(json.dumps(out), flush=True)
-        if parity is not None and parity["differing"]:
-            sys.stderr.write("bench.py: %d of %d windows differ from the reference poa's output\n"
-                             % (parity["differing"], parity["windows"]))
-            exit_code = 1
+        bad = [("headline", parity)] + [(c["profile"], c.get("parity_vs_reference")) for c in configs]
+        for name, par in bad:
+            if par is not None and par["differing"]:
+                sys.stderr.write("bench.py: %s: %d of %d windows differ from the reference poa's output\n"
+                                 % (name, par["differing"], par["windows"]))
+                exit_code = 1
     for g in engines:
         g.close()
     if dist_on:

@@ -176,12 +176,17 @@ __global__ void __launch_bounds__(kStatsThreads) k_merge(MergeArgs a)
   }
 }
 
-// copy the pieces' rows from their roomy device layout to a dense one (out_off[p] = 3 * sum of cols before p)
+// copy the pieces' rows from their roomy device layout to a dense one (out_off[p] = 3 * sum of cols before p).  The
+// destination may be page-locked HOST memory (elector_msa_stats_enqueue_rows: the rows cross PCIe as this kernel's
+// stores, no copy engine, no staging): 16-byte stores to 16-byte aligned addresses, a wavefront's stores side by
+// side; the source's misalignment is taken out with a funnel shift over aligned dwords.
 struct CompactArgs {
   const uint8_t *rows;
   const int64_t *row_off, *cols, *out_off;
   uint8_t *out;
 };
+
+typedef uint4 __attribute__((aligned(4))) uint4_a4;
 
 __global__ void __launch_bounds__(kStatsThreads) k_compact(CompactArgs a)
 {
@@ -189,7 +194,52 @@ __global__ void __launch_bounds__(kStatsThreads) k_compact(CompactArgs a)
   const uint8_t *src = a.rows + a.row_off[p];
   uint8_t *dst = a.out + a.out_off[p];
   const int64_t nb = 3 * a.cols[p];
-  for (int64_t i = threadIdx.x; i < nb; i += kStatsThreads) dst[i] = src[i];
+  const int64_t head = min(nb, (int64_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15));
+  for (int64_t i = threadIdx.x; i < head; i += kStatsThreads) dst[i] = src[i];
+  const uint8_t *s2 = src + head;
+  uint8_t *d2 = dst + head;
+  const int64_t n2 = nb - head, nv = n2 >> 4;
+  const int mis = (int)(reinterpret_cast<uintptr_t>(s2) & 3);
+  const uint32_t *s4 = reinterpret_cast<const uint32_t *>(s2 - mis);
+  for (int64_t v = threadIdx.x; v < nv; v += kStatsThreads) {
+    // (the rows buffer has slack behind its last byte: the dword behind a piece's end may be read)
+    const uint4 lo = *reinterpret_cast<const uint4_a4 *>(s4 + 4 * v);
+    const uint32_t hi = s4[4 * v + 4];
+    const int sh = 8 * mis;
+    uint4 o;
+    o.x = (uint32_t)(((((uint64_t)lo.y) << 32) | lo.x) >> sh);
+    o.y = (uint32_t)(((((uint64_t)lo.z) << 32) | lo.y) >> sh);
+    o.z = (uint32_t)(((((uint64_t)lo.w) << 32) | lo.z) >> sh);
+    o.w = (uint32_t)(((((uint64_t)hi) << 32) | lo.w) >> sh);
+    reinterpret_cast<uint4 *>(d2)[v] = o;
+  }
+  for (int64_t i = (nv << 4) + threadIdx.x; i < n2; i += kStatsThreads) d2[i] = s2[i];
+}
+
+// out_off[p] = 3 * (columns of the pieces before p), out_off[n] = 3 * all columns (one block)
+__global__ void __launch_bounds__(1024) k_scan_cols(const int64_t *cols, int64_t n, int64_t *out_off)
+{
+  __shared__ int64_t part[1024];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int64_t v = i < n ? 3 * cols[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {
+      const int64_t t = (int)threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n) out_off[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_off[n] = carry;
 }
 
 // --------------------------------------------------------------------- stats ---
@@ -1087,9 +1137,30 @@ int enqueue_stats(elector_ctx *c, elector::StatsSlot &s, unsigned long long ints
 
 }  // namespace
 
+static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
+                         const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
+                         int64_t n_reads, const int64_t *read_first, const int32_t *clips, uint8_t *rows_out, int64_t rows_cap);
+
 extern "C" int elector_msa_stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
                                          const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
                                          int64_t n_reads, const int64_t *read_first, const int32_t *clips)
+{
+  return stats_enqueue(c, n_windows, d_cols, d_ncol, d_status, n_pieces, piece_first, n_reads, read_first, clips, nullptr, 0);
+}
+
+extern "C" int elector_msa_stats_enqueue_rows(elector_ctx *c, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
+                                              const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
+                                              int64_t n_reads, const int64_t *read_first, const int32_t *clips,
+                                              uint8_t *rows_out, int64_t rows_cap)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (!rows_out || rows_cap < 0) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  return stats_enqueue(c, n_windows, d_cols, d_ncol, d_status, n_pieces, piece_first, n_reads, read_first, clips, rows_out, rows_cap);
+}
+
+static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
+                         const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
+                         int64_t n_reads, const int64_t *read_first, const int32_t *clips, uint8_t *rows_out, int64_t rows_cap)
 {
   if (!c) return ELECTOR_E_INVAL;
   if (n_windows < 0 || n_pieces < 0 || n_reads < 0 || !piece_first || !read_first ||
@@ -1106,6 +1177,17 @@ extern "C" int elector_msa_stats_enqueue(elector_ctx *c, int64_t n_windows, cons
   std::lock_guard<std::mutex> lock(c->mu);
   if (c->st_inflight >= elector_ctx::kStatsSlots) return elector_fail(c, ELECTOR_E_INVAL, "two statistics jobs in flight: collect one first");
   HIPCHK(c, hipSetDevice(c->device));
+  uint8_t *rows_dev = nullptr;                // the rows' destination as the device sees it
+  if (rows_out) {
+    if (rows_cap < 3 * c->last_total) return elector_fail(c, ELECTOR_E_INVAL, "rows_cap must hold 3 bytes per base of the batch");
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, rows_out) != hipSuccess) { (void)hipGetLastError(); return elector_fail(c, ELECTOR_E_INVAL, "rows_out must be page-locked host memory or device memory"); }
+    if (at.type == hipMemoryTypeDevice) rows_dev = rows_out;
+    else if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rows_dev), rows_out, 0) != hipSuccess || !rows_dev) {
+      (void)hipGetLastError();
+      return elector_fail(c, ELECTOR_E_INVAL, "rows_out must be page-locked host memory or device memory");
+    }
+  }
   elector::StatsSlot &s = c->st_slot[c->st_head];
   if (!s.done) HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   s.n_pieces = n_pieces; s.n_reads = n_reads; s.total = c->last_total; s.has_clips = clips != nullptr;
@@ -1155,6 +1237,18 @@ extern "C" int elector_msa_stats_enqueue(elector_ctx *c, int64_t n_windows, cons
     HIPCHK(c, hipGetLastError());
     const int rc2 = enqueue_stats(c, s, pool_first_size(total));
     if (rc2) return rc2;
+    if (rows_dev) {
+      // the merged rows, dense, to where the caller wants them -- in the queue, behind the counters: by the time the job
+      // is collected they are there (a host destination is written by the kernel's own stores over PCIe)
+      if (c->d_st_outoff.ensure((size_t)(n_pieces + 1) * 8)) return elector_fail(c, ELECTOR_E_NOMEM, "row offsets");
+      timed_begin(c, 3, st);
+      hipLaunchKernelGGL(k_scan_cols, dim3(1), dim3(1024), 0, st, s.cols.as<int64_t>(), n_pieces, c->d_st_outoff.as<int64_t>());
+      CompactArgs ca{s.rows.as<uint8_t>(), s.rowoff.as<int64_t>(), s.cols.as<int64_t>(), c->d_st_outoff.as<int64_t>(), rows_dev};
+      hipLaunchKernelGGL(k_compact, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, ca);
+      timed_end(c, st);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(s.done, st));
+    }
   }
   c->st_head = (c->st_head + 1) % elector_ctx::kStatsSlots;
   ++c->st_inflight;

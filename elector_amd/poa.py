@@ -147,17 +147,24 @@ class PoaEngine:
             last_rows, last_mask = last_rows[:3 * nl], last_mask[:nl]
         return counters, piece_cols, last_rows, last_mask
 
-    def msa_stats_enqueue(self, n_windows, d_cols, d_ncol, d_status, piece_first, read_first, clips=None):
+    def msa_stats_enqueue(self, n_windows, d_cols, d_ncol, d_status, piece_first, read_first, clips=None,
+                          rows_out=None, rows_cap=0):
         """First half of msa_stats_device: queue merge + counters behind the POA kernels and
-        return at once (at most two jobs in flight).  -> n_pieces, to pass to msa_stats_collect."""
+        return at once (at most two jobs in flight).  -> n_pieces, to pass to msa_stats_collect.
+        rows_out (an address: page-locked host memory or device memory of rows_cap bytes, at least 3 per base of the
+        batch): the merged rows are delivered there in the same queue (elector_msa_stats_enqueue_rows), complete when
+        the job is collected."""
         piece_first = np.ascontiguousarray(piece_first, dtype=np.int64)
         read_first = np.ascontiguousarray(read_first, dtype=np.int64)
         if clips is not None:
             clips = np.ascontiguousarray(clips, dtype=np.int32)
-        self._check(self._lib.elector_msa_stats_enqueue(
-            self._h, n_windows, d_cols.data_ptr(), d_ncol.data_ptr(), d_status.data_ptr(),
-            len(piece_first) - 1, piece_first.ctypes.data, len(read_first) - 1, read_first.ctypes.data,
-            clips.ctypes.data if clips is not None else None))
+        args = (self._h, n_windows, d_cols.data_ptr(), d_ncol.data_ptr(), d_status.data_ptr(),
+                len(piece_first) - 1, piece_first.ctypes.data, len(read_first) - 1, read_first.ctypes.data,
+                clips.ctypes.data if clips is not None else None)
+        if rows_out is None:
+            self._check(self._lib.elector_msa_stats_enqueue(*args))
+        else:
+            self._check(self._lib.elector_msa_stats_enqueue_rows(*args, C.c_void_p(int(rows_out)), int(rows_cap)))
         return len(piece_first) - 1
 
     def msa_stats_collect(self, n_pieces, last_cap=0):

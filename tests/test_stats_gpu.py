@@ -101,6 +101,25 @@ def test_device_merge_and_stats_equal_oracle(tmp_path, engine, seed, n, L):
     assert np.array_equal(piece_cols, pieces.cols)
     rows = engine.msa_rows_fetch(piece_cols)
     assert np.array_equal(rows, pieces.rows)
+    # the same records delivered inside the queue (elector_msa_stats_enqueue_rows): to page-locked host memory (the
+    # kernel's own stores cross PCIe) at an odd address, to device memory, and with the windows taken from DEVICE offsets
+    cap = 3 * int(win.off[-1]) + 64
+    pinned = torch.zeros(cap + 16, dtype=torch.uint8).pin_memory()
+    d_off = torch.from_numpy(np.ascontiguousarray(win.off)).to(dev)
+    engine.align_device_offsets(d_bases, d_off, win.n_windows, int(win.off[-1]), d_cols, d_ncol, d_status)
+    npc = engine.msa_stats_enqueue(win.n_windows, d_cols, d_ncol, d_status, win.read_first, pieces.read_first,
+                                   rows_out=pinned.data_ptr() + 3, rows_cap=cap)
+    got2, piece_cols2 = engine.msa_stats_collect(npc)
+    assert np.array_equal(piece_cols2, pieces.cols) and np.array_equal(got2, got)
+    assert np.array_equal(pinned.numpy()[3:3 + len(pieces.rows)], pieces.rows)
+    d_rows = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    npc = engine.msa_stats_enqueue(win.n_windows, d_cols, d_ncol, d_status, win.read_first, pieces.read_first,
+                                   rows_out=d_rows.data_ptr(), rows_cap=cap)
+    engine.msa_stats_collect(npc)
+    assert np.array_equal(d_rows.cpu().numpy()[:len(pieces.rows)], pieces.rows)
+    with pytest.raises(Exception):
+        engine.msa_stats_enqueue(win.n_windows, d_cols, d_ncol, d_status, win.read_first, pieces.read_first,
+                                 rows_out=pinned.data_ptr(), rows_cap=16)
     proc = exp[:, cs.ES_PROCESSED] == 1
     assert np.array_equal(got[:, cs.ES_PROCESSED], exp[:, cs.ES_PROCESSED])
     assert np.array_equal(got[proc], exp[proc]), np.argwhere(got[proc] != exp[proc])[:5]

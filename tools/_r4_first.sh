@@ -6,7 +6,7 @@ timeout -k 10 600 python -m pytest tests/test_poa_gpu.py tests/test_configs_gpu.
 tail -3 $O/pytest.log
 run() { # tag, env...
   local tag=$1; shift
-  env "$@" timeout -k 10 300 python bench.py --steps 40 --no-cpu-baseline --no-rows-to-host --serial-steps 4 > $O/$tag.json 2> $O/$tag.err || { echo FAILED $tag; tail -5 $O/$tag.err; return 1; }
+  env "$@" timeout -k 10 300 python bench.py --profile ecoli30x_simlord_lordec --batches 1 --steps 40 --no-cpu-baseline --serial-steps 4 > $O/$tag.json 2> $O/$tag.err || { echo FAILED $tag; tail -5 $O/$tag.err; return 1; }
   python3 -c "
 import json
 j=json.load(open('$O/$tag.json'))
