@@ -320,6 +320,32 @@ def skipped_alignment1(win, lr, lc):
     return out
 
 
+def cpu_share():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (a GPU box hands a
+    container 16 cores' worth of a 256-core host)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = int(f.read().split()[0])
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 class Batch(object):
     """one batch of window triples: host side (the splitter's Windows + grouping) and, after upload(), the device side"""
     __slots__ = ("profile", "seed", "win", "n", "total", "lr", "lc", "lu", "piece_first", "read_first", "n_pieces_in",
@@ -396,11 +422,7 @@ def main():
     strong = args.scaling == "strong"
     n_batches = max(1, args.batches)
     with_configs = world == 1 and not strong and not args.no_configs and not args.serial and args.profile_defaulted
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        ncpu = os.cpu_count() or 1
-    ncores = max(1, ncpu // max(1, world))
+    ncores = max(1, cpu_share() // max(1, world))
 
     # ---- untimed setup, part 1 (before this process touches a GPU): synthetic reads -> windows on the host, the
     # batches side by side in forked workers ----
@@ -583,6 +605,8 @@ def main():
                     self.collect_oldest()
                 dc, dn, ds = outs[e]
                 t = time.perf_counter()
+                if rows:
+                    engines[e].msa_rows_wait()        # the context's earlier rows have left its pinned buffer's way (long ago)
                 align(engines[e], b, dc, dn, ds)
                 npieces = engines[e].msa_stats_enqueue(b.n, dc, dn, ds, b.piece_first, b.read_first,
                                                        rows_out=pinned[e].data_ptr() if rows else None, rows_cap=rows_cap)
@@ -593,6 +617,8 @@ def main():
         def drain(self):
             while self.pending:
                 self.collect_oldest()
+            for g in engines:
+                g.msa_rows_wait()                 # ... and every step's rows have arrived
             if self.gather:
                 res = self.flush_gather(True)
                 if res is not None:
@@ -801,8 +827,8 @@ def main():
                        "parallelism": "shard-by-read x%d" % world,
                        "batches_in_flight_per_gpu": n_eng, "serial": bool(args.serial),
                        "batches_rotated": len(head_batches), "input_bytes_rotated_per_gpu": int(sum(b.total + 8 * (3 * b.n + 1) for b in head_batches)),
-                       # `value`: per-read counters AND the merged MSA rows back on the host; the rows
-                       # are written to pinned host memory by the compaction kernel's own stores, inside the queue
+                       # `value`: per-read counters AND the merged MSA rows back on the host; a kernel packs
+                       # the rows, one copy per batch takes them to pinned host memory on the context's copy stream
                        "rows_to_host": True, "offsets_resident_in_hbm": not host_offsets},
             "rows_to_host": {"bytes_per_step_per_gpu": int(R["rows_bytes"]),
                              "pcie_gbs_per_gpu": round(R["rows_bytes"] * (len(head_batches) if strong else 1) / step_s / 1e9, 2)},

@@ -40,7 +40,7 @@ EXPORTS = [
     "elector_poa_batch", "elector_poa_batch_device", "elector_poa_batch_device_offsets", "elector_ctx_sync",
     "elector_ctx_timing_enable", "elector_ctx_timing_read", "elector_ctx_timing_reset",
     "elector_ctx_last_po_sizes", "elector_ctx_option", "elector_ctx_keep_graph", "elector_poa_bundles",
-    "elector_stats_batch", "elector_msa_stats_device", "elector_msa_stats_enqueue", "elector_msa_stats_enqueue_rows", "elector_msa_stats_collect",
+    "elector_stats_batch", "elector_msa_stats_device", "elector_msa_stats_enqueue", "elector_msa_stats_enqueue_rows", "elector_msa_rows_wait", "elector_msa_stats_collect",
     "elector_msa_rows_fetch", "elector_homopolymer_pairs",
     "elector_split_reads", "elector_windows_free", "elector_merge_windows", "elector_msa_free",
     "elector_split_reads_device", "elector_windows_dev_free", "elector_ctx_copy", "elector_ctx_copy_to_host",
@@ -103,6 +103,7 @@ def lib():
     L.elector_msa_rows_fetch.argtypes = [vp, i64, vp, vp]
     L.elector_msa_stats_enqueue.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp]
     L.elector_msa_stats_enqueue_rows.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64]
+    L.elector_msa_rows_wait.argtypes = [vp]
     L.elector_msa_stats_collect.argtypes = [vp, i64, vp, vp, vp, vp, i64]
     _lib = L
     return L

@@ -52,15 +52,20 @@ struct TimedSpan { hipEvent_t a, b; int kind; };
 // one merge + statistics job of the device pipeline (elector_msa_stats_enqueue / _collect)
 struct StatsSlot {
   DevBuf rows, rowoff, cols, first, clips, cnt, mask, woff;
+  DevBuf dense, outoff;         // elector_msa_stats_enqueue_rows: the merged rows packed (host destinations), their offsets
   HostPinned h;                 // [overflow flag, pad to 16][counters][cols][inputs]
   hipEvent_t done = nullptr;
+  hipEvent_t rows_done = nullptr;   // the packed rows have arrived at rows_host (recorded on the context's copy stream)
+  uint8_t *rows_host = nullptr;     // this job's rows go to this page-locked host address when it is collected
+  bool rows_inflight = false;
   int64_t n_pieces = 0, n_reads = 0, total = 0, last_piece = 0, max_windows = 0;
   bool has_clips = false;
   void release()
   {
     rows.release(); rowoff.release(); cols.release(); first.release(); clips.release(); cnt.release();
-    mask.release(); woff.release(); h.release();
+    mask.release(); woff.release(); h.release(); dense.release(); outoff.release();
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
+    if (rows_done) { (void)hipEventDestroy(rows_done); rows_done = nullptr; }
   }
 };
 
@@ -110,6 +115,7 @@ struct elector_ctx {
   static constexpr int kStatsSlots = 2;
   elector::StatsSlot st_slot[kStatsSlots];
   int st_head = 0, st_tail = 0, st_inflight = 0, st_last = -1;
+  hipStream_t copy_stream = nullptr;   // the rows' way to the host: the copy engine works beside the kernels of the next batch
   // timing
   bool timing = false;
   std::vector<elector::TimedSpan> spans;

@@ -344,6 +344,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_sp_reads, &c->d_sp_off, &c->d_sp_hdr, &c->d_sp_keys, &c->d_sp_vals, &c->d_sp_ca, &c->d_sp_cb, &c->d_sp_wl,
                     &c->d_sp_win, &c->d_sp_first, &c->d_sp_cnt, &c->d_sp_wfirst, &c->d_sp_wlen, &c->d_sp_woff, &c->d_sp_scan, &c->d_sp_bases, &c->d_sp_anc};
   for (DevBuf *b : bufs) b->release();
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   for (auto &s : c->st_slot) s.release();
   c->h_acc.release(); c->h_gen.release(); c->h_off.release();
   if (c->h_off_done) (void)hipEventDestroy(c->h_off_done);
@@ -356,6 +357,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
     for (int k = 0; k < elector_ctx::kAux; ++k) { (void)hipStreamDestroy(c->aux[k]); (void)hipEventDestroy(c->aux_done[k]); }
     (void)hipEventDestroy(c->fork);
   }
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

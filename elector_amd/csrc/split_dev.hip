@@ -2011,6 +2011,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(st));
   out->n_reads = nreads; out->n_windows = nwin; out->d_bases = la.bases; out->small_reads = small; out->wrong_reads = wrong;
+  out->d_off = c->d_sp_woff.as<int64_t>();
   if (dbg) std::fprintf(stderr, "[elector] device splitter, host view: reads to the device %.1f ms, k_split %.1f ms, layout + window bases %.1f ms\n", t1 - t0, t2 - t1, now_ms() - t2);
   return ELECTOR_OK;
 }

@@ -1177,18 +1177,18 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
   std::lock_guard<std::mutex> lock(c->mu);
   if (c->st_inflight >= elector_ctx::kStatsSlots) return elector_fail(c, ELECTOR_E_INVAL, "two statistics jobs in flight: collect one first");
   HIPCHK(c, hipSetDevice(c->device));
-  uint8_t *rows_dev = nullptr;                // the rows' destination as the device sees it
+  uint8_t *rows_dev = nullptr;                // a device destination
+  bool rows_is_host = false;
   if (rows_out) {
     if (rows_cap < 3 * c->last_total) return elector_fail(c, ELECTOR_E_INVAL, "rows_cap must hold 3 bytes per base of the batch");
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, rows_out) != hipSuccess) { (void)hipGetLastError(); return elector_fail(c, ELECTOR_E_INVAL, "rows_out must be page-locked host memory or device memory"); }
     if (at.type == hipMemoryTypeDevice) rows_dev = rows_out;
-    else if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rows_dev), rows_out, 0) != hipSuccess || !rows_dev) {
-      (void)hipGetLastError();
-      return elector_fail(c, ELECTOR_E_INVAL, "rows_out must be page-locked host memory or device memory");
-    }
+    else if (at.type == hipMemoryTypeHost) rows_is_host = true;
+    else return elector_fail(c, ELECTOR_E_INVAL, "rows_out must be page-locked host memory or device memory");
   }
   elector::StatsSlot &s = c->st_slot[c->st_head];
+  s.rows_host = nullptr;
   if (!s.done) HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   s.n_pieces = n_pieces; s.n_reads = n_reads; s.total = c->last_total; s.has_clips = clips != nullptr;
   s.last_piece = n_reads > 0 ? read_first[n_reads - 1] : 0;
@@ -1237,17 +1237,30 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
     HIPCHK(c, hipGetLastError());
     const int rc2 = enqueue_stats(c, s, pool_first_size(total));
     if (rc2) return rc2;
-    if (rows_dev) {
-      // the merged rows, dense, to where the caller wants them -- in the queue, behind the counters: by the time the job
-      // is collected they are there (a host destination is written by the kernel's own stores over PCIe)
-      if (c->d_st_outoff.ensure((size_t)(n_pieces + 1) * 8)) return elector_fail(c, ELECTOR_E_NOMEM, "row offsets");
+    if (rows_out) {
+      // The merged rows, packed, to where the caller wants them -- in the queue, behind the counters.  Device memory:
+      // the packing kernel writes there.  Host memory: it packs into a device buffer, and the moment the job is
+      // collected (the host then knows the byte count) ONE copy of exactly that size goes out on the context's copy
+      // stream: the copy engine moves it (57 GB/s on this box, measured; a kernel's own stores to host memory reach
+      // 20) while the kernels of the following batches run.  elector_msa_rows_wait() waits for it.
+      if (s.rows_inflight) { HIPCHK(c, hipEventSynchronize(s.rows_done)); s.rows_inflight = false; }
+      if (s.outoff.ensure((size_t)(n_pieces + 1) * 8)) return elector_fail(c, ELECTOR_E_NOMEM, "row offsets");
+      uint8_t *dst = rows_dev;
+      if (rows_is_host) {
+        for (int k = 0; k < elector_ctx::kStatsSlots; ++k)
+          if (c->st_slot[k].dense.ensure((size_t)3 * total + 64)) return elector_fail(c, ELECTOR_E_NOMEM, "packed rows");
+        dst = s.dense.as<uint8_t>();
+        if (!s.rows_done) HIPCHK(c, hipEventCreateWithFlags(&s.rows_done, hipEventDisableTiming));
+        if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+      }
       timed_begin(c, 3, st);
-      hipLaunchKernelGGL(k_scan_cols, dim3(1), dim3(1024), 0, st, s.cols.as<int64_t>(), n_pieces, c->d_st_outoff.as<int64_t>());
-      CompactArgs ca{s.rows.as<uint8_t>(), s.rowoff.as<int64_t>(), s.cols.as<int64_t>(), c->d_st_outoff.as<int64_t>(), rows_dev};
+      hipLaunchKernelGGL(k_scan_cols, dim3(1), dim3(1024), 0, st, s.cols.as<int64_t>(), n_pieces, s.outoff.as<int64_t>());
+      CompactArgs ca{s.rows.as<uint8_t>(), s.rowoff.as<int64_t>(), s.cols.as<int64_t>(), s.outoff.as<int64_t>(), dst};
       hipLaunchKernelGGL(k_compact, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, ca);
       timed_end(c, st);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipEventRecord(s.done, st));
+      s.rows_host = rows_is_host ? rows_out : nullptr;
     }
   }
   c->st_head = (c->st_head + 1) % elector_ctx::kStatsSlots;
@@ -1281,6 +1294,17 @@ extern "C" int elector_msa_stats_collect(elector_ctx *c, int64_t n_pieces, int64
   std::memcpy(counters, h + 16, (size_t)n_pieces * ES_NCOUNTERS * 8);
   const int64_t *hcols = reinterpret_cast<const int64_t *>(h + 16 + (size_t)n_pieces * ES_NCOUNTERS * 8);
   if (piece_cols) std::memcpy(piece_cols, hcols, (size_t)n_pieces * 8);
+  if (s.rows_host) {
+    // the packed rows leave for the host now that their size is known; nothing waits here (elector_msa_rows_wait)
+    int64_t nbytes = 0;
+    for (int64_t p = 0; p < n_pieces; ++p) nbytes += 3 * hcols[p];
+    if (nbytes > 0) {
+      HIPCHK(c, hipMemcpyAsync(s.rows_host, s.dense.p, (size_t)nbytes, hipMemcpyDeviceToHost, c->copy_stream));
+      HIPCHK(c, hipEventRecord(s.rows_done, c->copy_stream));
+      s.rows_inflight = true;
+    }
+    s.rows_host = nullptr;
+  }
   const int64_t pl = s.last_piece, npl = n_pieces - pl;
   if ((last_rows || last_mask) && npl > 0) {
     int64_t need = 0;
@@ -1300,6 +1324,16 @@ extern "C" int elector_msa_stats_collect(elector_ctx *c, int64_t n_pieces, int64
     }
     HIPCHK(c, hipStreamSynchronize(st));
   }
+  return ELECTOR_OK;
+}
+
+extern "C" int elector_msa_rows_wait(elector_ctx *c)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  for (auto &s : c->st_slot)
+    if (s.rows_inflight) { HIPCHK(c, hipEventSynchronize(s.rows_done)); s.rows_inflight = false; }
   return ELECTOR_OK;
 }
 

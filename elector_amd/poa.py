@@ -152,8 +152,8 @@ class PoaEngine:
         """First half of msa_stats_device: queue merge + counters behind the POA kernels and
         return at once (at most two jobs in flight).  -> n_pieces, to pass to msa_stats_collect.
         rows_out (an address: page-locked host memory or device memory of rows_cap bytes, at least 3 per base of the
-        batch): the merged rows are delivered there in the same queue (elector_msa_stats_enqueue_rows), complete when
-        the job is collected."""
+        batch): the merged rows are delivered there without a call in between (elector_msa_stats_enqueue_rows): device
+        memory is complete when the job is collected, host memory after msa_rows_wait()."""
         piece_first = np.ascontiguousarray(piece_first, dtype=np.int64)
         read_first = np.ascontiguousarray(read_first, dtype=np.int64)
         if clips is not None:
@@ -183,6 +183,10 @@ class PoaEngine:
         if last_cap > 0:
             return counters, piece_cols, last_rows, last_mask
         return counters, piece_cols
+
+    def msa_rows_wait(self):
+        """wait until the rows of every collected job that named a host `rows_out` have arrived there"""
+        self._check(self._lib.elector_msa_rows_wait(self._h))
 
     def msa_rows_fetch(self, piece_cols):
         """Merged records of the last msa_stats_device call: uint8[3 * sum(piece_cols)],

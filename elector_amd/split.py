@@ -26,7 +26,7 @@ class ElectorWindowsDev(C.Structure):
     _fields_ = [
         ("n_reads", C.c_int64), ("n_windows", C.c_int64), ("d_bases", C.c_void_p),
         ("off", C.POINTER(C.c_int64)), ("read_first", C.POINTER(C.c_int64)), ("read_index", C.POINTER(C.c_int64)),
-        ("small_reads", C.c_int64), ("wrong_reads", C.c_int64),
+        ("small_reads", C.c_int64), ("wrong_reads", C.c_int64), ("d_off", C.c_void_p),
     ]
 
 
@@ -149,8 +149,9 @@ class DevBases:
 
 
 class DevWindows(Windows):
-    """Windows whose bases live in device memory (`d_bases`); `.bases` fetches them (tests)."""
-    __slots__ = ("d_bases",)
+    """Windows whose bases live in device memory (`d_bases`), and -- when the device splitter made them -- their
+    offsets too (`d_off`: what PoaEngine.align_device_offsets takes); `.host_bases` fetches the bases (tests)."""
+    __slots__ = ("d_bases", "d_off")
 
     @property
     def host_bases(self):
@@ -205,6 +206,7 @@ def split_packed_device(engine, buf, off, hl, size_threshold=0.1, nthreads=None)
         t = torch.from_numpy(hw.bases).to(torch.device("cuda", engine.device))
         out.bases = None
         out.d_bases = t                      # a torch tensor has data_ptr() too
+        out.d_off = torch.from_numpy(np.ascontiguousarray(hw.off, dtype=np.int64)).to(torch.device("cuda", engine.device))
         return out
     if rc:
         raise ElectorError(rc, L.elector_ctx_last_error(engine._h).decode())
@@ -216,6 +218,7 @@ def split_packed_device(engine, buf, off, hl, size_threshold=0.1, nthreads=None)
         out.small_reads, out.wrong_reads = int(w.small_reads), int(w.wrong_reads)
         out.bases = None
         out.d_bases = DevBases(w.d_bases, int(out.off[-1]), engine)
+        out.d_off = DevBases(w.d_off, 8 * (3 * out.n_windows + 1), engine)
         if os.environ.get("ELECTOR_DEBUG_HOST"):
             import sys
             sys.stderr.write("[elector] split_packed_device: library call %.1f ms, arrays to numpy %.1f ms\n"

@@ -63,6 +63,9 @@ typedef struct elector_windows_dev {
   uint8_t *d_bases;
   int64_t *off, *read_first, *read_index;
   int64_t small_reads, wrong_reads;
+  int64_t *d_off;          /* the same 3 n_windows + 1 offsets in DEVICE memory (valid as long as d_bases is): what
+                              elector_poa_batch_device_offsets takes, so that no per-window array crosses to the host
+                              on the way from the splitter to the POA kernels */
 } elector_windows_dev;
 
 int  elector_split_reads_device(elector_ctx *ctx, int64_t n_reads_in, const uint8_t *reads, const int64_t *read_off,

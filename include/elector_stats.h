@@ -91,16 +91,19 @@ int elector_msa_stats_enqueue(elector_ctx *ctx, int64_t n_windows, const uint8_t
 int elector_msa_stats_collect(elector_ctx *ctx, int64_t n_pieces, int64_t *counters, int64_t *piece_cols,
                               uint8_t *last_rows, uint8_t *last_mask, int64_t last_cap);
 /* _enqueue that also delivers the merged records -- the body of msa.fa (Donatello.cpp:86-91): piece p's three rows
- * (3 * piece_cols[p] bytes) back to back in piece order, what elector_msa_rows_fetch returns -- to rows_out inside the
- * same queue: rows_out is page-locked host memory the device can address (hipHostMalloc / hipHostRegister; torch's
- * pin_memory()) or device memory, rows_cap its size, at least 3 bytes per base of the batch.  The rows are written by
- * a kernel's own 16-byte stores (a host destination: straight over PCIe, no copy engine, no staging buffer) and are
- * complete when _collect returns for this job; _collect's piece_cols say where each piece starts.  Nothing else of
- * the call changes.  The d_st_outoff scratch is shared: one such job per context at a time is the intended use. */
+ * (3 * piece_cols[p] bytes) back to back in piece order, what elector_msa_rows_fetch returns -- to rows_out, without a
+ * call of its own in between: rows_out is page-locked host memory (hipHostMalloc / hipHostRegister; torch's
+ * pin_memory()) or device memory, rows_cap its size, at least 3 bytes per base of the batch.  A kernel packs the rows
+ * in the same queue; a device destination is complete when _collect returns for this job.  For a host destination
+ * _collect (which learns the byte count with the counters) starts ONE copy of exactly that size on the context's copy
+ * stream and returns; the copy engine moves the rows while the kernels of the following batches run, and
+ * elector_msa_rows_wait() returns when every such copy of the context has arrived (call it before reading the rows
+ * or handing the same destination to another job).  _collect's piece_cols say where each piece starts. */
 int elector_msa_stats_enqueue_rows(elector_ctx *ctx, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
                                    const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
                                    int64_t n_reads, const int64_t *read_first, const int32_t *clips,
                                    uint8_t *rows_out, int64_t rows_cap);
+int elector_msa_rows_wait(elector_ctx *ctx);
 
 /* The merged records of the context's last COLLECTED statistics job, copied
  * to the host (elector_msa_stats_device collects its own job): piece p's three rows (3 * piece_cols[p] bytes) back to back in

@@ -62,11 +62,21 @@ def run_workload(engine, triples, headers, read_of, tmp_path, oracle_windows=500
     win = split.split_reads(triples, 0.1, headers, nthreads=nthreads)
     off, n = win.off, win.n_windows
     dev = torch.device("cuda", 0)
-    d_bases = torch.from_numpy(win.bases).to(dev)
+    # The DEVICE splitter on the same batch, at the size bench.py runs it (its launch-class mix -- on-chip / partitioned
+    # / HBM tables side by side, the longest-first work queue -- depends on the batch): every window, every list and
+    # both counters equal the host splitter's (which tests/test_splitter.py pins to the real masterSplitter,
+    # Master_Splitter.cpp:175-332,396-446).  Its windows -- bases AND offsets in device memory -- are what the engine aligns.
+    dwin = split.split_reads_device(engine, triples, 0.1, headers, nthreads=nthreads)
+    assert dwin.n_windows == n and dwin.n_reads == win.n_reads
+    assert np.array_equal(dwin.off, off) and np.array_equal(dwin.read_first, win.read_first)
+    assert np.array_equal(dwin.read_index, win.read_index)
+    assert (dwin.small_reads, dwin.wrong_reads) == (win.small_reads, win.wrong_reads)
+    assert np.array_equal(dwin.host_bases, win.bases), "device splitter: window bases differ from the host splitter's"
+    d_bases, d_off = dwin.d_bases, dwin.d_off
     d_cols = torch.zeros(3 * int(off[-1]) + 64, dtype=torch.uint8, device=dev)
     d_ncol = torch.empty(n, dtype=torch.int32, device=dev)
     d_status = torch.empty(n, dtype=torch.int32, device=dev)
-    engine.align_device(d_bases, off, d_cols, d_ncol, d_status)
+    engine.align_device_offsets(d_bases, d_off, n, int(off[-1]), d_cols, d_ncol, d_status)
     engine.sync()
     status = d_status.cpu().numpy()
     assert not status.any(), "windows failed (status, count): %s" % (np.unique(status, return_counts=True),)

@@ -102,7 +102,7 @@ def test_device_merge_and_stats_equal_oracle(tmp_path, engine, seed, n, L):
     rows = engine.msa_rows_fetch(piece_cols)
     assert np.array_equal(rows, pieces.rows)
     # the same records delivered inside the queue (elector_msa_stats_enqueue_rows): to page-locked host memory (the
-    # kernel's own stores cross PCIe) at an odd address, to device memory, and with the windows taken from DEVICE offsets
+    # one copy on the context's copy stream) at an odd address, to device memory, and with the windows taken from DEVICE offsets
     cap = 3 * int(win.off[-1]) + 64
     pinned = torch.zeros(cap + 16, dtype=torch.uint8).pin_memory()
     d_off = torch.from_numpy(np.ascontiguousarray(win.off)).to(dev)
@@ -111,6 +111,7 @@ def test_device_merge_and_stats_equal_oracle(tmp_path, engine, seed, n, L):
                                    rows_out=pinned.data_ptr() + 3, rows_cap=cap)
     got2, piece_cols2 = engine.msa_stats_collect(npc)
     assert np.array_equal(piece_cols2, pieces.cols) and np.array_equal(got2, got)
+    engine.msa_rows_wait()
     assert np.array_equal(pinned.numpy()[3:3 + len(pieces.rows)], pieces.rows)
     d_rows = torch.zeros(cap, dtype=torch.uint8, device=dev)
     npc = engine.msa_stats_enqueue(win.n_windows, d_cols, d_ncol, d_status, win.read_first, pieces.read_first,

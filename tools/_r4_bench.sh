@@ -7,8 +7,8 @@ if [ -z "$SKIP_TESTS" ]; then
 timeout -k 10 900 python -m pytest tests/test_stats_gpu.py tests/test_bench_gpu.py -x -q -m gpu --capture=sys > $O/pytest.log 2>&1 || { echo "PYTEST FAILED"; tail -40 $O/pytest.log; exit 1; }
 tail -3 $O/pytest.log
 fi
-/usr/bin/time -v timeout -k 10 900 python bench.py --steps ${STEPS:-20} --warmup 5 > $O/bench.json 2> $O/bench.err || { echo BENCH FAILED; tail -20 $O/bench.err; exit 2; }
-grep -E "Elapsed|Maximum resident" $O/bench.err
+time timeout -k 10 900 python bench.py --steps ${STEPS:-20} --warmup 5 > $O/bench.json 2> $O/bench.err || { echo BENCH FAILED; tail -20 $O/bench.err; exit 2; }
+
 python3 - $O/bench.json <<'PY'
 import json,sys
 j=json.load(open(sys.argv[1]))
