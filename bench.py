@@ -514,7 +514,10 @@ def main():
              torch.empty(max_n, dtype=torch.int32, device=dev), torch.empty(max_n, dtype=torch.int32, device=dev))
             for _ in range(n_eng)]
     rows_cap = 3 * max_total + 64
-    pinned = [torch.empty(rows_cap, dtype=torch.uint8).pin_memory() for _ in range(n_eng)]
+    # two pinned destinations per context, used in turn: a job's rows leave for the host when the job is collected and
+    # travel while the context already works on its next batch
+    pinned = [[torch.empty(rows_cap, dtype=torch.uint8).pin_memory() for _ in range(2)] for _ in range(n_eng)]
+    pin_turn = [0] * n_eng
 
     def align(engine, b, dc, dn, ds):
         if host_offsets:
@@ -605,11 +608,10 @@ def main():
                     self.collect_oldest()
                 dc, dn, ds = outs[e]
                 t = time.perf_counter()
-                if rows:
-                    engines[e].msa_rows_wait()        # the context's earlier rows have left its pinned buffer's way (long ago)
                 align(engines[e], b, dc, dn, ds)
+                pin_turn[e] ^= 1
                 npieces = engines[e].msa_stats_enqueue(b.n, dc, dn, ds, b.piece_first, b.read_first,
-                                                       rows_out=pinned[e].data_ptr() if rows else None, rows_cap=rows_cap)
+                                                       rows_out=pinned[e][pin_turn[e]].data_ptr() if rows else None, rows_cap=rows_cap)
                 self.host_enqueue_s += time.perf_counter() - t
                 self.pending.append((e, sid, b, npieces))
                 self.last_batch_of_engine[e] = b

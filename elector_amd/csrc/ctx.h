@@ -93,6 +93,7 @@ struct elector_ctx {
   elector::DevBuf d_off, d_perm, d_mv1, d_mv2, d_sym, d_xinfo, d_ring1, d_map16, d_carry, d_moves,
       d_n1, d_cls, d_score1, d_score2, d_bx2, d_list, d_done, d_rowinit, d_fmv, d_tstate, d_tlist, d_gring,
       d_hand, d_mvpool, d_mvbusy, d_pdesc, d_psym,
+      d_far,                             // k_poa's far-edge lists (one region per lane-group size) and their four counters
       d_bin16, d_wkey, d_acc, d_ginfo;   // device-side classification (poa_classify.hip): launch bin and size key per window, per-bin totals
   // device splitter (split_dev.hip)
   elector::DevBuf d_sp_reads, d_sp_off, d_sp_hdr, d_sp_keys, d_sp_vals, d_sp_ca, d_sp_cb, d_sp_wl, d_sp_win, d_sp_first,

@@ -122,6 +122,46 @@ struct BatchArgs {
   const uint8_t *tiled;         // per window: bit 0 = alignment #1, bit 1 = alignment #2 computed by the tiled kernels
 };
 
+// arguments of k_poa (poa_pack.hip): the whole window in one kernel
+struct PackArgs {
+  BatchArgs b;
+  const uint32_t *list;     // window ids of this bin, in processing order; entries 2p, 2p+1 form pair p
+  int64_t nlist;
+  const uint4 *pdesc;       // k_gather's output for this bin: two uint4 per list entry (PackDesc)
+  const uint32_t *psym;     // ... and the entry's three symbol strings back to back, pstride dwords per entry
+  int pstride;
+  int slot_bytes;           // LDS bytes per window slot
+  uint8_t *done_a;
+  uint8_t *done_b;
+  const uint8_t *triv;      // per window: 0 = needs alignment #1, 1 = corrected == reference, 2 = one substitution
+  uint32_t *mv_pool;        // moves scratch: [XCD][slot][mv_tw steps][64 lanes] words; a wave borrows a slot of its XCD
+  int mv_tw;
+  int32_t *mv_q;            // per XCD a queue of free slot ids: [head][tail][ids ...], kPoolStride ints apart
+  int mv_slots;             // slots per XCD: at least the wavefronts an XCD can hold of any launch of the chain
+  uint32_t *hand;           // windows handed back to the two-kernel path, appended at hand[atomicAdd(hand_count, 1)]
+  int32_t *hand_count;
+  uint32_t *far;            // windows whose graph has ONE edge from more than two nodes back and qualifies otherwise: the
+  int32_t *far_count;       // group's k_poa<G, 8, true> launch takes them (far_cap entries; what does not fit goes to `hand`)
+  int far_cap;
+  const int32_t *nlist_dev; // when set: the list length lives on the device (a far list), nlist is its capacity
+  int debug;
+  unsigned long long *stamps;
+};
+
+// arguments of k_gather (poa_pack.hip): k_poa's inputs laid out in list order
+struct GatherArgs {
+  const uint32_t *list;
+  int64_t nlist;
+  const int64_t *off;
+  const uint8_t *sym;
+  const int32_t *status;
+  const uint8_t *done_a, *done_b, *triv;
+  uint4 *pdesc;
+  uint32_t *psym;
+  int pstride;               // dwords per entry
+  const int32_t *nlist_dev;  // when set: the list length lives on the device (a far list), nlist is its capacity
+};
+
 // Long windows (the reference's whole-read fallback) are cut into tiles of one strip of 63 rows by
 // kTileCols columns; the tiles of one anti-diagonal (strip + column block) are independent and run
 // in one launch (k_dp1_tile / k_dp2_tile), so a window of many strips uses many wavefronts.

@@ -54,39 +54,9 @@ struct FusedArgs {
   const uint8_t *triv;
   int64_t grid_blocks;
 };
-struct PackArgs {
-  BatchArgs b;
-  const uint32_t *list;
-  int64_t nlist;
-  const uint4 *pdesc;
-  const uint32_t *psym;
-  int pstride;
-  int slot_bytes;
-  uint8_t *done_a;
-  uint8_t *done_b;
-  const uint8_t *triv;
-  uint32_t *mv_pool;
-  int mv_tw;
-  int32_t *mv_q;
-  int mv_slots;
-  uint32_t *hand;
-  int32_t *hand_count;
-  int debug;
-  unsigned long long *stamps;
-};
-struct GatherArgs {
-  const uint32_t *list;
-  int64_t nlist;
-  const int64_t *off;
-  const uint8_t *sym;
-  const int32_t *status;
-  const uint8_t *done_a, *done_b, *triv;
-  uint4 *pdesc;
-  uint32_t *psym;
-  int pstride;
-};
 void launch_gather(const GatherArgs &a, hipStream_t st);
 int launch_poa(const PackArgs &a, int G, int R, hipStream_t st);
+int launch_poa_far(const PackArgs &a, int G, hipStream_t st);
 void launch_poa_pool_init(int32_t *q, int nq, int slots, hipStream_t st);
 int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
 int launch_fused_b(const FusedArgs &a, int G, int R, int D, hipStream_t st);
@@ -340,7 +310,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit,
                     &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy, &c->d_pdesc, &c->d_psym,
-                    &c->d_bin16, &c->d_wkey, &c->d_acc, &c->d_ginfo,
+                    &c->d_bin16, &c->d_wkey, &c->d_acc, &c->d_ginfo, &c->d_far,
                     &c->d_sp_reads, &c->d_sp_off, &c->d_sp_hdr, &c->d_sp_keys, &c->d_sp_vals, &c->d_sp_ca, &c->d_sp_cb, &c->d_sp_wl,
                     &c->d_sp_win, &c->d_sp_first, &c->d_sp_cnt, &c->d_sp_wfirst, &c->d_sp_wlen, &c->d_sp_woff, &c->d_sp_scan, &c->d_sp_bases, &c->d_sp_anc};
   for (DevBuf *b : bufs) b->release();
@@ -814,9 +784,16 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // classes of one lane-group size share a hand-back list instead (their regions of d_hand are neighbours) and ONE
   // launch pair with 8 rows per lane, which holds every window of the group's classes.
   struct HandGroup { int G = 0, first_bin = -1, ci8 = 0, slot_a = 0, slot_b = 0, tw_a = 0, ns_a = 0, tw_b = 0, ns_b = 0;
-                     int64_t cnt = 0, blocks = 0; std::vector<int> bins; };
+                     int64_t cnt = 0, blocks = 0; std::vector<int> bins;
+                     // the group's far-edge launch (k_poa<G, 8, true>): list capacity, LDS slot, moves steps, symbol stride,
+                     // where its descriptors / symbols start behind the bins', the moves pool it borrows from
+                     int64_t far_cap = 0, far_desc_first = 0, far_psym_first = 0; int far_slot = 0, far_tw = 0, far_stride = 0, far_pool = 0; };
   HandGroup hgrp[4];
   const bool merge_hand = use_pack && !std::getenv("ELECTOR_HAND_PER_BIN") && !std::getenv("ELECTOR_LAUNCH_ORDER");
+  // graphs with ONE far edge (a corrected piece that aligns at both ends of its window, an indel of two or more letters)
+  // stay in k_poa: a launch of their own per lane-group size behind the group's bins.  ELECTOR_NO_FAR=1: the two-kernel
+  // path and the generic kernels take them, as up to round 3 (A/B)
+  const bool use_far = merge_hand && !std::getenv("ELECTOR_NO_FAR") && n_chains <= 3 && !std::getenv("ELECTOR_POA_BLOCKSCRATCH");
   if (merge_hand) {
     for (int b = 0; b < kBins; ++b) {
       if (!bin_cnt[(size_t)b]) continue;
@@ -857,6 +834,24 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         pool_stream[sk] = std::max(pool_stream[sk], pg.pool_words);      // (block-scratch experiment)
       }
     }
+  if (use_far)
+    for (HandGroup &hg : hgrp) {
+      if (hg.first_bin < 0) continue;
+      const int nw = 2 * (64 / hg.G), max_slot = ((160 * 1024 - 256 - 64) / nw) & ~15;
+      for (int b : hg.bins) {
+        const PackGeom pg = pack_geom(b);
+        hg.far_slot = std::max(hg.far_slot, pg.slot);
+        hg.far_tw = std::max(hg.far_tw, pg.tw);
+        hg.far_stride = std::max<int>(hg.far_stride, (int)(((bin_max_lr[b] + bin_max_lc[b] + bin_max_lu[b] + 3) / 4 + 3) & ~(int64_t)3));
+      }
+      hg.far_slot = std::min(hg.far_slot, max_slot);
+      hg.far_cap = std::min<int64_t>(hg.cnt, std::max<int64_t>(2048, hg.cnt / 8));
+      // with several chains the launch runs on the hand-back stream (a pool of its own), otherwise in line on the chain's
+      hg.far_pool = n_chains > 1 ? 3 : stream_of(hg.first_bin);
+      const int waves_cu = std::max(1, std::min(8, (160 * 1024) / (64 + nw * hg.far_slot)));   // (two waves per SIMD: launch bounds)
+      pool_slots[hg.far_pool] = std::max(pool_slots[hg.far_pool], 32 * waves_cu + 8);
+      pool_tw[hg.far_pool] = std::max(pool_tw[hg.far_pool], hg.far_tw);
+    }
   if (use_pack && !std::getenv("ELECTOR_POA_BLOCKSCRATCH"))
     for (int k = 0; k < 4; ++k) pool_stream[k] = (int64_t)8 * pool_slots[k] * pool_tw[k] * 64;
   for (int k = 0; k < 4; ++k) fmv_stream[k] = (fmv_stream[k] + 255) & ~(int64_t)255;
@@ -882,8 +877,19 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       if (bin_cnt[(size_t)b]) pstride[(size_t)b] = (int)(((bin_max_lr[b] + bin_max_lc[b] + bin_max_lu[b] + 3) / 4 + 3) & ~(int64_t)3);
       psym_first[(size_t)b + 1] = psym_first[(size_t)b] + bin_cnt[(size_t)b] * pstride[(size_t)b];
     }
+  int64_t far_desc_total = 0, far_psym_total = 0;
+  if (use_far)
+    for (HandGroup &hg : hgrp) {
+      if (hg.first_bin < 0) continue;
+      hg.far_desc_first = (n - n_generic) + far_desc_total;
+      hg.far_psym_first = psym_first[(size_t)kBins] + far_psym_total;
+      far_desc_total += hg.far_cap;
+      far_psym_total += hg.far_cap * hg.far_stride;
+    }
   if (!rc && use_pack)
-    rc = c->d_pdesc.ensure((size_t)(n - n_generic) * 32 + 64) | c->d_psym.ensure((size_t)psym_first[(size_t)kBins] * 4 + 256) |
+    rc = c->d_pdesc.ensure((size_t)(n - n_generic + far_desc_total) * 32 + 64) |
+         c->d_psym.ensure((size_t)(psym_first[(size_t)kBins] + far_psym_total) * 4 + 256) |
+         c->d_far.ensure((size_t)n * 4 + 64) |
          c->d_hand.ensure((size_t)n * 4 + (size_t)kBins * 4 + 64) |
          c->d_mvpool.ensure((size_t)(pool_stream[0] + pool_stream[1] + pool_stream[2] + pool_stream[3]) * 4 + 256) |
          c->d_mvbusy.ensure((size_t)4 * 8 * kPoolStride * 4);
@@ -928,6 +934,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   HIPCHK(c, hipMemsetAsync(d_counters, 0, 64, st));
   if (use_pack) {
     HIPCHK(c, hipMemsetAsync(c->d_hand.as<uint32_t>() + n, 0, (size_t)kBins * 4, st));
+    HIPCHK(c, hipMemsetAsync(c->d_far.as<uint32_t>() + n, 0, 16, st));
     for (int k = 0; k < 4; ++k)
       if (pool_slots[k] > 0) launch_poa_pool_init(c->d_mvbusy.as<int32_t>() + (size_t)k * 8 * kPoolStride, 8, pool_slots[k], st);
   }
@@ -1065,6 +1072,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         ga.pdesc = c->d_pdesc.as<uint4>() + 2 * bin_first[(size_t)b];
         ga.psym = c->d_psym.as<uint32_t>() + psym_first[(size_t)b];
         ga.pstride = pstride[(size_t)b];
+        ga.nlist_dev = nullptr;
         timed_begin(c, 2, sx);
         launch_gather(ga, sx);
         timed_end(c, sx);
@@ -1086,6 +1094,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         pa.mv_slots = pg.slots > 0 ? pool_slots[sk] : 0;
         pa.hand = d_hand_list;
         pa.hand_count = d_hand_cnt;
+        const int gi = bG == 8 ? 0 : bG == 16 ? 1 : bG == 32 ? 2 : 3;
+        pa.far = use_far && hg ? c->d_far.as<uint32_t>() + bin_first[(size_t)hg->first_bin] : nullptr;
+        pa.far_count = use_far && hg ? reinterpret_cast<int32_t *>(c->d_far.as<uint32_t>() + n) + gi : nullptr;
+        pa.far_cap = use_far && hg ? (int)hg->far_cap : 0;
+        pa.nlist_dev = nullptr;
         pa.debug = fdebug;
         pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b) + 16;
         timed_begin(c, 4, sx);
@@ -1111,6 +1124,43 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         }
         if (b != hg->bins.front()) continue;          // bin_order runs from the last bin down: the group's first bin comes last
         hipStream_t sg = hb_own ? c->aux[3] : sx;
+        if (use_far && hg->far_cap > 0) {
+          // the group's far-edge windows, gathered and aligned by k_poa<G, 8, true>; what it cannot take either joins
+          // the group's hand-back list
+          const int gi = hg->G == 8 ? 0 : hg->G == 16 ? 1 : hg->G == 32 ? 2 : 3;
+          const int32_t *d_far_cnt = reinterpret_cast<const int32_t *>(c->d_far.as<uint32_t>() + n) + gi;
+          GatherArgs ga;
+          ga.list = c->d_far.as<uint32_t>() + bin_first[(size_t)hg->first_bin];
+          ga.nlist = hg->far_cap;
+          ga.nlist_dev = d_far_cnt;
+          ga.off = a.off; ga.sym = a.sym; ga.status = d_status;
+          ga.done_a = d_done_a; ga.done_b = d_done_b; ga.triv = d_triv;
+          ga.pdesc = c->d_pdesc.as<uint4>() + 2 * hg->far_desc_first;
+          ga.psym = c->d_psym.as<uint32_t>() + hg->far_psym_first;
+          ga.pstride = hg->far_stride;
+          timed_begin(c, 2, sg);
+          launch_gather(ga, sg);
+          timed_end(c, sg);
+          PackArgs pa;
+          pa.b = a;
+          pa.list = ga.list; pa.nlist = hg->far_cap; pa.nlist_dev = d_far_cnt;
+          pa.pdesc = ga.pdesc; pa.psym = ga.psym; pa.pstride = ga.pstride;
+          pa.slot_bytes = hg->far_slot;
+          pa.done_a = d_done_a; pa.done_b = d_done_b; pa.triv = d_triv;
+          pa.mv_pool = c->d_mvpool.as<uint32_t>();
+          for (int k = 0; k < hg->far_pool; ++k) pa.mv_pool += pool_stream[k];
+          pa.mv_tw = hg->far_tw;
+          pa.mv_q = c->d_mvbusy.as<int32_t>() + (size_t)hg->far_pool * 8 * kPoolStride;
+          pa.mv_slots = pool_slots[hg->far_pool];
+          pa.hand = d_hand_list;
+          pa.hand_count = d_hand_cnt;
+          pa.far = nullptr; pa.far_count = nullptr; pa.far_cap = 0;
+          pa.debug = fdebug & ~(32 | 64 | 128 | 256);
+          pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)hb) + 16;
+          timed_begin(c, 4, sg);
+          if (launch_poa_far(pa, hg->G, sg)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
+          timed_end(c, sg);
+        }
         FusedArgs fa;
         fa.b = a;
         fa.grid_blocks = hg->blocks;

@@ -32,26 +32,6 @@
 
 namespace elector {
 
-struct PackArgs {
-  BatchArgs b;
-  const uint32_t *list;     // window ids of this bin, in processing order; entries 2p, 2p+1 form pair p
-  int64_t nlist;
-  const uint4 *pdesc;       // k_gather's output for this bin: two uint4 per list entry (PackDesc)
-  const uint32_t *psym;     // ... and the entry's three symbol strings back to back, pstride dwords per entry
-  int pstride;
-  int slot_bytes;           // LDS bytes per window slot
-  uint8_t *done_a;
-  uint8_t *done_b;
-  const uint8_t *triv;      // per window: 0 = needs alignment #1, 1 = corrected == reference, 2 = one substitution
-  uint32_t *mv_pool;        // moves scratch: [XCD][slot][mv_tw steps][64 lanes] words; a wave borrows a slot of its XCD
-  int mv_tw;
-  int32_t *mv_q;            // per XCD a queue of free slot ids: [head][tail][ids ...], kPoolStride ints apart
-  int mv_slots;             // slots per XCD: at least the wavefronts an XCD can hold of any launch of the chain
-  uint32_t *hand;           // windows handed back to the two-kernel path, appended at hand[atomicAdd(hand_count, 1)]
-  int32_t *hand_count;
-  int debug;
-  unsigned long long *stamps;
-};
 
 // ------------------------------------------------------------ packed helpers ---
 // two 16-bit lanes per register: window A low, window B high.  Inline asm where hipcc would otherwise
@@ -205,7 +185,10 @@ __device__ __forceinline__ int pk_diag_run(bool flag, int q)
 //   back (a virtual start one or two columns back is column 0 in the registers: bits 0 / 1 as for any node)
 //   bit 4   unused                         bit 5   node opens a new MSA column (ring)
 //   bits 8-12 letter    bits 16-19 flags (kFlag*)    bits 24-31 ordinal among the two-predecessor nodes
+//   bit 6   (k_poa<.., true> only) the first predecessor is the window's FAR node (WinP::fnode: more than two nodes back;
+//           bits 0 / 3 then say "one back" and are not used)        bit 7   ... the second predecessor is
 constexpr uint32_t kN_Far1 = 1u, kN_Far2 = 2u, kN_Has2 = 4u, kN_Virt1 = 8u, kN_Virt2 = 16u, kN_NewCol = 32u;
+constexpr uint32_t kN_FarA = 64u, kN_FarB = 128u;
 
 // LDS slot of one window (bytes); must mirror poa_slot_need() below.
 //   [hdr 16][unc symbols][node records u32 (xi_cap + 2: records 1 .. n1 between two zero guards)][union]
@@ -220,6 +203,7 @@ struct WinP {
   uint8_t *slot;
   int off_xi, off_u;
   int score1, k2n;
+  int fnode;                // node the one far edge of the graph comes from (-1: none)
 };
 
 // phase stamps (debug bit 2): cycles per phase summed over waves
@@ -284,9 +268,11 @@ __device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&nee
 // fusion #1 (lpo.c:602-668 on two linear sequences) spread over the window's G lanes, as in k_fused_a; the
 // node records go to LDS.  Returns false when the graph does not qualify for this kernel (a predecessor more
 // than two nodes back, more nodes than the slot holds) -- the window is then handed back.
-template <int G, typename IT>
+// FAR: the kernel instance that holds ONE far edge per window (the column of its source node is kept aside by the
+// dynamic program); the others report such a graph through *far_out and do not take it.
+template <int G, typename IT, bool FAR>
 __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, const uint8_t *ys, IT *x2y,
-                                         uint32_t *xinfo, bool *bad_out)
+                                         uint32_t *xinfo, bool *bad_out, bool *far_out)
 {
   constexpr int kNoneI = (int)(IT)~(IT)0;                               // "not aligned" in the index type of this class
   const int Lr = W.Lr, Lc = W.Lc;
@@ -373,7 +359,7 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
   const int n1 = Lr + Lc - fused_all;
   bool fits = n1 <= W.xi_cap && n1 >= 1;
   // every lane of the group must agree before any node is written
-  int maxd = 1, k2 = 0;
+  int maxd = 1, k2 = 0, nfar = 0, fsrc = -1;
   if (on && fits) {
     auto emit = [&](int n, int letter, int flags, int ring, int sa, int sb) {
       // sa / sb: predecessor nodes (-1 none); an INITIAL node has the virtual start first (align_lpo_po2.c:69-79)
@@ -387,6 +373,10 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
       // a virtual start more than two columns back cannot come from the two register columns: the DP patches
       // in the cells of column 0, which depend on the row only
       if (v1 && d1 > 2) { rec |= kN_Virt1; d1 = 1; }
+      // an edge from more than two nodes back (a corrected piece that aligns at both ends of the window, an indel of
+      // two or more letters in the corrected read): one per window is kept aside by k_poa<.., true>
+      if (!v1 && d1 > 2) { ++nfar; fsrc = sa; d1 = 1; rec |= kN_FarA | (has2 ? 0u : kN_FarB); }
+      if (has2 && d2 > 2) { ++nfar; fsrc = sb; d2 = 1; rec |= kN_FarB; }
       maxd = max(maxd, max(d1, d2));
       if (d1 == 2) rec |= kN_Far1;
       if (has2) { rec |= kN_Has2; if (d2 == 2) rec |= kN_Far2; ++k2; }
@@ -424,10 +414,18 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
   for (int d = 1; d < G; d <<= 1) {
     maxd = max(maxd, __shfl_xor(maxd, d, G));
     bad = bad || __shfl_xor(bad ? 1 : 0, d, G) != 0;
+    nfar += __shfl_xor(nfar, d, G);
+    fsrc = max(fsrc, __shfl_xor(fsrc, d, G));
   }
   if (on) W.n1 = n1;
   *bad_out = bad;
-  return !on || (fits && maxd <= 2 && !bad);
+  const bool near_ok = !on || (fits && maxd <= 2 && !bad);
+  if (FAR) {
+    if (on && nfar == 1) W.fnode = fsrc;
+    return near_ok && (!on || nfar <= 1);
+  }
+  *far_out = on && near_ok && nfar == 1;
+  return near_ok && (!on || nfar == 0);
 }
 
 // the graph of a window whose corrected sequence equals its reference (chain, every node holds both letters)
@@ -631,7 +629,7 @@ __device__ __forceinline__ void traceback_b(const WinP (&W)[2], const uint32_t *
 // clamped addresses and merged with selects; the one rarely needed look-up (which of two predecessors a cell took:
 // one node per window has two) sits behind a wave-wide test.  The compiler turned the nested conditions of
 // traceback_b into some 250 instructions per round, most of them exec-mask bookkeeping.
-template <int G, int R>
+template <int G, int R, bool FAR>
 __device__ __forceinline__ void traceback_b2(const WinP (&W)[2], const uint32_t *mv, int q, int g, uint32_t *(&xinfo)[2],
                                              uint8_t *(&ordb)[2], uint16_t *(&x2y)[2], const int (&bestx)[2],
                                              bool (&bad)[2], int &rounds)
@@ -677,7 +675,12 @@ __device__ __forceinline__ void traceback_b2(const WinP (&W)[2], const uint32_t 
       const int xo = inb[h] ? (m | xw) : 0, yo = inb[h] ? (m | (xw ^ 1)) : 0;
       const int far = (int)((rec[h] >> sec[h]) & 1u);                   // bit 0: first predecessor two back, bit 1: second
       int px = cx[h] - 1 - far;                                        // < 0: the virtual start
-      const bool virt = px < -1 || (sec[h] == 0 && (rec[h] & kN_Virt1) != 0u);
+      bool virt = px < -1 || (sec[h] == 0 && (rec[h] & kN_Virt1) != 0u);
+      if (FAR) {                                                       // the chosen predecessor is the window's far node
+        const bool fx = (rec[h] & (sec[h] ? kN_FarB : kN_FarA)) != 0u;
+        px = fx ? W[h].fnode : px;
+        virt = virt && !fx;
+      }
       px = xo ? (virt ? -1 : px) : cx[h];
       const bool diag = xo && yo;                                      // (inb is in both)
       const int run = pk_diag_run<G>(diag && px == cx[h] - 1, q);
@@ -819,23 +822,13 @@ __device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *x
 // occupancy.  8 lanes per list entry.
 struct PackDesc { uint32_t w, Lr, Lc, Lu; uint32_t o0_lo, o0_hi, triv_ok, pad; };   // triv | ok << 8
 
-struct GatherArgs {
-  const uint32_t *list;
-  int64_t nlist;
-  const int64_t *off;
-  const uint8_t *sym;
-  const int32_t *status;
-  const uint8_t *done_a, *done_b, *triv;
-  uint4 *pdesc;
-  uint32_t *psym;
-  int pstride;               // dwords per entry
-};
 
 __global__ void __launch_bounds__(256) k_gather(GatherArgs a)
 {
   const int64_t p = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
   const int g = threadIdx.x & 7;
   if (p >= a.nlist) return;
+  if (a.nlist_dev && p >= (int64_t)*a.nlist_dev) return;                  // (k_poa reads the same count)
   const uint32_t w = a.list[p];
   const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
   const int64_t total = o3 - o0;
@@ -878,7 +871,7 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
   W.o0 = listed ? o0 : 0;
   W.Lr = listed ? Lr : 0; W.Lc = listed ? Lc : 0; W.Lu = listed ? Lu : 0;
   W.triv = listed ? triv : 0;
-  W.n1 = 0; W.score1 = kNeg; W.k2n = 0;
+  W.n1 = 0; W.score1 = kNeg; W.k2n = 0; W.fnode = -1;
   W.slot = slot;
   W.xi_cap = poa_xi_cap(W.Lr, W.Lc);
   W.off_xi = 16 + pk_align_up(W.Lu, 4);
@@ -892,8 +885,8 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
 #ifndef ELECTOR_POA_WAVES
 #define ELECTOR_POA_WAVES (R <= 6 ? 4 : 3)
 #endif
-template <int G, int R>
-__global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
+template <int G, int R, bool FAR>
+__global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NP = 64 / G;                       // pairs of windows per wave
@@ -931,9 +924,10 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
     bool inl[2];
     const uint32_t *src4[2];
     uint4 d0[2], d1[2];
+    const int64_t nlist = a.nlist_dev ? min(a.nlist, (int64_t)*a.nlist_dev) : a.nlist;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      inl[h] = 2 * pi + h < a.nlist;
+      inl[h] = 2 * pi + h < nlist;
       const int64_t e = inl[h] ? 2 * pi + h : 0;
       d0[h] = a.pdesc[2 * e];
       d1[h] = a.pdesc[2 * e + 1];
@@ -1110,7 +1104,7 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
   }
   PK_STAMP(1);
   // ---- traceback #1, fusion #1 (per window), trivial graphs ----
-  bool bad[2] = {false, false}, keep[2];
+  bool bad[2] = {false, false}, keep[2], farw[2] = {false, false};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
@@ -1128,7 +1122,8 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
   for (int h = 0; h < 2; ++h) {
     IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
     keep[h] = true;
-    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0) keep[h] = fusion_1<G, IT>(W[h], g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h]);
+    if (__builtin_amdgcn_ballot_w64(needA[h]) != 0)
+      keep[h] = fusion_1<G, IT, FAR>(W[h], g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h], &farw[h]);
     trivial_graph<G>(W[h], g, U[h], U[h] + W[h].Lr, xinfo[h]);
     if (W[h].valid && W[h].triv == 1) W[h].score1 = W[h].Lr * kp.match;
     if (W[h].valid && W[h].triv == 2) W[h].score1 = (W[h].Lr - 1) * kp.match + kp.mismatch;
@@ -1171,8 +1166,16 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
     const int cols_need = 2 * W[h].Lu + 4;
     if (on && !(k2n <= 255 && W[h].off_u + region + max(k2n * G, cols_need) <= a.slot_bytes && n1 + G + 2 <= a.mv_tw)) keep[h] = false;
     if (W[h].valid && (!keep[h] || bad[h])) {
-      // not for this kernel: the two-kernel path takes the window from scratch
-      if (g == 0) a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
+      // not for this kernel: a graph with ONE far edge goes to the group's k_poa<G, 8, true> launch (while its list
+      // has room), anything else to the two-kernel path, which takes the window from scratch
+      if (g == 0) {
+        bool placed = false;
+        if (!FAR && farw[h] && !bad[h] && a.far != nullptr) {
+          const int at = atomicAdd(a.far_count, 1);
+          if (at < a.far_cap) { a.far[at] = W[h].w; placed = true; }
+        }
+        if (!placed) a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
+      }
       W[h].valid = false;
     }
   }
@@ -1225,6 +1228,16 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
     const uint32_t finA_bit = (W[0].valid && g == gstar0) ? ((uint32_t)kFlagFinal << 16) : 0u;
     const uint32_t finB_bit = (W[1].valid && g == gstar1) ? ((uint32_t)kFlagFinal << 16) : 0u;
 
+    // k_poa<.., true>: the column of the window's far node (scores, what they offer a gap, the row above it, row -1
+    // over the graph) is kept aside when the lane passes it and stands in for a predecessor column at the one node
+    // whose record names it (kN_FarA / kN_FarB)
+    uint32_t FS[FAR ? R : 1], FE[FAR ? R : 1], Fup = 0, FBE = 0, up1_step = 0;
+    const int fcol0 = (FAR && W[0].valid && W[0].fnode >= 0) ? W[0].fnode + 1 : -100;
+    const int fcol1 = (FAR && W[1].valid && W[1].fnode >= 0) ? W[1].fnode + 1 : -100;
+    if (FAR) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) FS[k] = FE[k] = 0;
+    }
     int n_steps = 0, n_two = 0, n_virt = 0;                        // debug: steps per code path
     // FIRST: the steps in which some lane has not reached its first column yet (t < G)
     auto step = [&](auto first_tag, int t, uint32_t (&Sa)[R], uint32_t (&Ea)[R], uint32_t (&Sb)[R], uint32_t (&Eb)[R]) {
@@ -1243,10 +1256,11 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
       const uint32_t xor_ = xiA | xiB;
       const bool active = !FIRST || jj >= 1;                         // before its first column a lane keeps column 0
       uint32_t BRj, BEj, mvw = 0;
-      auto variant = [&](auto near_tag, auto two_tag, auto virt_tag) {
+      auto variant = [&](auto near_tag, auto two_tag, auto virt_tag, auto far_tag) {
         constexpr bool NEAR = decltype(near_tag)::value, TWO = decltype(two_tag)::value, VIRT = decltype(virt_tag)::value;
+        constexpr bool FARV = decltype(far_tag)::value;            // some lane at the node the far edge ends at (TWO and VIRT are on)
         // per-half select masks: predecessor two columns back (else one)
-        uint32_t M1 = 0, M2 = 0, V1 = 0, V2 = 0, bb1 = BE1;
+        uint32_t M1 = 0, M2 = 0, V1 = 0, V2 = 0, MA = 0, MB = 0, bb1 = BE1;
         if (!NEAR) {
           M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
           bb1 = bfi(M1, BE2, BE1);
@@ -1264,6 +1278,12 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
             bb1 = bfi(V1, KOPENNEG, bb1);
             bb2 = bfi(V2, KOPENNEG, bb2);
           }
+          if (FARV) {
+            MA = bfi(0xFFFFu, 0u - ((xiA >> 6) & 1u), 0u - ((xiB >> 6) & 1u));
+            MB = bfi(0xFFFFu, 0u - ((xiA >> 7) & 1u), 0u - ((xiB >> 7) & 1u));
+            bb1 = bfi(MA, FBE, bb1);
+            bb2 = bfi(MB, FBE, bb2);
+          }
           BRj = pk_max(bb1, bb2);
         }
         BEj = pk_subk(BRj, KEXT);
@@ -1271,12 +1291,14 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
         const uint32_t up2 = prev_up1;                                 // ... at column jj - 2
         prev_up1 = up1;
         const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
+        if (FAR) up1_step = up1;
         if (!active) return;
         uint32_t dt1 = up1, dt2, insY = upE, secw = 0;
         if (!NEAR) dt1 = bfi(M1, up2, up1);
         dt2 = dt1;
         if (TWO) dt2 = bfi(M2, up2, up1);
         if (VIRT) { dt1 = bfi(V1, colAbove, dt1); dt2 = bfi(V2, colAbove, dt2); }
+        if (FARV) { dt1 = bfi(MA, Fup, dt1); dt2 = bfi(MB, Fup, dt2); }
         uint32_t vcS = colS0;                                          // column 0 at this lane's rows, top down
         static_for<R>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
@@ -1288,10 +1310,12 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
             c1E = bfi(V1, pk_subk(vcS, KEXT), c1E);
             insX = c1E;
           }
+          if (FARV) { c1S = bfi(MA, FS[FAR ? k : 0], c1S); c1E = bfi(MA, FE[FAR ? k : 0], c1E); insX = c1E; }
           if (TWO) {
             c2S = bfi(M2, Sb[k], Sa[k]);
             uint32_t c2E = bfi(M2, Eb[k], Ea[k]);
             if (VIRT) { c2S = bfi(V2, vcS, c2S); c2E = bfi(V2, pk_subk(vcS, KEXT), c2E); }
+            if (FARV) { c2S = bfi(MB, FS[FAR ? k : 0], c2S); c2E = bfi(MB, FE[FAR ? k : 0], c2E); }
             insX = pk_max(c1E, c2E);                                // first maximum wins (:361-371)
             dmax = pk_max(dt1, dt2);                                // (:348-357)
           }
@@ -1313,14 +1337,27 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
         }
       };
       // debug bit 1024: never the plain-chain form (A/B)
-      if (!(a.debug & 1024) && __builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1)) != 0u) == 0)
-        variant(std::true_type{}, std::false_type{}, std::false_type{});
-      else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2)) != 0u) == 0)
-        variant(std::false_type{}, std::false_type{}, std::false_type{});
-      else if (__builtin_amdgcn_ballot_w64((xor_ & kN_Virt1) != 0u) == 0)
-        variant(std::false_type{}, std::true_type{}, std::false_type{});
+      if (!(a.debug & 1024) && __builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
+        variant(std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{});
+      else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
+        variant(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
+      else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
+        variant(std::false_type{}, std::true_type{}, std::false_type{}, std::false_type{});
+      else if (!FAR || __builtin_amdgcn_ballot_w64((xor_ & (kN_FarA | kN_FarB)) != 0u) == 0)
+        variant(std::false_type{}, std::true_type{}, std::true_type{}, std::false_type{});
       else
-        variant(std::false_type{}, std::true_type{}, std::true_type{});
+        variant(std::false_type{}, std::true_type{}, std::true_type{}, std::integral_constant<bool, FAR>{});
+      if (FAR) {
+        // the far node's column, just computed, is kept aside; one step later the row above it arrives
+        const bool sA = jj == fcol0, sB = jj == fcol1, uA = jj == fcol0 + 1, uB = jj == fcol1 + 1;
+        if (__builtin_amdgcn_ballot_w64(sA || sB || uA || uB) != 0) {
+          const uint32_t ms = (sA ? 0xFFFFu : 0u) | (sB ? 0xFFFF0000u : 0u), mu = (uA ? 0xFFFFu : 0u) | (uB ? 0xFFFF0000u : 0u);
+#pragma unroll
+          for (int k = 0; k < (FAR ? R : 1); ++k) { FS[k] = bfi(ms, Sb[k], FS[k]); FE[k] = bfi(ms, Eb[k], FE[k]); }
+          FBE = bfi(ms, BEj, FBE);
+          Fup = bfi(mu, up1_step, Fup);
+        }
+      }
       if (active) {
         BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
         mv[t * 64 + lane] = mvw;                                     // every lane: a lane past its window's end writes a word nobody reads
@@ -1364,8 +1401,8 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
   __syncthreads();
   bool badb[2] = {false, false};
   int tb_rounds = 0;
-  if (a.debug & 2048) traceback_b<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);      // round 2's form (A/B)
-  else traceback_b2<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);
+  if (!FAR && (a.debug & 2048)) traceback_b<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);      // round 2's form (A/B)
+  else traceback_b2<G, R, FAR>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);
   if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 11, (unsigned long long)tb_rounds);
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(6);
@@ -1422,18 +1459,18 @@ void launch_poa_pool_init(int32_t *q, int nq, int slots, hipStream_t st)
   hipLaunchKernelGGL(k_poa_pool_init, dim3((unsigned)nq), dim3(256), 0, st, q, nq, slots);
 }
 
-template <int G, int R>
+template <int G, int R, bool FAR>
 static int launch_poa_t(const PackArgs &a, hipStream_t st)
 {
   constexpr int NW = 2 * (64 / G);     // windows per block (one wave)
   static DeviceOnce once;
   if (once.need()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_poa<G, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_poa<G, R, FAR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 256) != hipSuccess)
       return -1;
     once.done();
   }
-  hipLaunchKernelGGL((k_poa<G, R>), dim3((unsigned)((a.nlist + NW - 1) / NW)), dim3(64), 64 + NW * a.slot_bytes, st, a);
+  hipLaunchKernelGGL((k_poa<G, R, FAR>), dim3((unsigned)((a.nlist + NW - 1) / NW)), dim3(64), 64 + NW * a.slot_bytes, st, a);
   return 0;
 }
 
@@ -1444,9 +1481,20 @@ static int launch_poa_t(const PackArgs &a, hipStream_t st)
 int launch_poa(const PackArgs &a, int G, int R, hipStream_t st)
 {
   if (a.nlist <= 0) return 0;
-#define X(g, r) if (G == g && R == r) return launch_poa_t<g, r>(a, st);
+#define X(g, r) if (G == g && R == r) return launch_poa_t<g, r, false>(a, st);
   ELECTOR_PACK_CLASSES(X)
 #undef X
+  return -2;
+}
+
+// the far-edge instance of a lane-group size: 8 rows per lane hold every window of the group's classes
+int launch_poa_far(const PackArgs &a, int G, hipStream_t st)
+{
+  if (a.nlist <= 0) return 0;
+  if (G == 8) return launch_poa_t<8, 8, true>(a, st);
+  if (G == 16) return launch_poa_t<16, 8, true>(a, st);
+  if (G == 32) return launch_poa_t<32, 8, true>(a, st);
+  if (G == 64) return launch_poa_t<64, 8, true>(a, st);
   return -2;
 }
 

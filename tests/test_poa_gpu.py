@@ -289,6 +289,63 @@ def test_windows_up_to_the_score_span(engine):
     check(engine, score_range_triples(71))
 
 
+def far_edge_triples(seed, n):
+    """Graphs with an edge from more than two nodes back after fusion #1: the corrected sequence lacks two or more
+    letters of the reference in one place (up to most of the window: a corrected piece that aligns at both ends of its
+    window, Master_Splitter.cpp:268-301), or has two or more extra letters in one place -- k_poa<G, 8, true> keeps ONE
+    such edge per window; two of them, or one beside other differences, exercise the paths around it."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        L = int(rng.choice([12, 30, 57, 64, 65, 90, 128, 200, 400]))
+        L = max(8, L + int(rng.integers(-3, 4)))
+        ref = synth.random_seq(rng, L)
+        kind = i % 6
+        cor = bytearray(ref)
+        def cut(c, lo_frac=0.0):
+            k = int(rng.integers(2, max(3, int(len(c) * rng.choice([0.1, 0.3, 0.8])))))
+            p = int(rng.integers(1, max(2, len(c) - k - 1)))
+            del c[p:p + k]
+        def ins(c):
+            k = int(rng.integers(2, 9))
+            p = int(rng.integers(1, max(2, len(c) - 1)))
+            c[p:p] = synth.random_seq(rng, k)
+        if kind == 0:
+            cut(cor)
+        elif kind == 1:
+            ins(cor)
+        elif kind == 2:                       # both ends only
+            a, b = int(rng.integers(3, 12)), int(rng.integers(3, 12))
+            cor = bytearray(ref[:a] + ref[L - b:]) if a + b < L else bytearray(ref)
+        elif kind == 3:                       # a far edge and a substitution elsewhere
+            cut(cor)
+            p = int(rng.integers(0, len(cor)))
+            cor[p] = ord("ACGT"[("ACGT".index(chr(cor[p])) + 1) % 4]) if chr(cor[p]) in "ACGT" else cor[p]
+        elif kind == 4:                       # two far edges: not for the far instance
+            cut(cor)
+            ins(cor)
+        else:                                 # far edge at the very start / end
+            k = int(rng.integers(2, 6))
+            cor = bytearray(ref[:1] + ref[1 + k:]) if rng.random() < 0.5 else bytearray(ref[:L - 1 - k] + ref[L - 1:])
+        if len(cor) == 0:
+            cor = bytearray(ref[:1])
+        out.append((ref, bytes(cor), synth.mutate(rng, ref, 0.12) or b"A"))
+    return out
+
+
+def test_far_edge_windows(engine):
+    check(engine, far_edge_triples(91, 1800))
+
+
+def test_far_edge_windows_equal_the_two_kernel_path(engine, monkeypatch):
+    """the same windows with the far instance switched off (ELECTOR_NO_FAR: two-kernel path and generic kernels)"""
+    triples = far_edge_triples(92, 600)
+    got, scores = engine.align(triples, want_scores=True)
+    monkeypatch.setenv("ELECTOR_NO_FAR", "1")
+    got2, scores2 = engine.align(triples, want_scores=True)
+    assert got == got2 and np.array_equal(scores, scores2)
+
+
 def uniform_matrix(match, mismatch, gaps="10 5 5"):
     letters = "A a c g t n".split()
     rows = ["  " + " ".join(letters)]

@@ -4,7 +4,7 @@
 O=gpurun_out/${1:-r4bench}; mkdir -p $O
 env | grep -i "HSA\|ROC\|HIP\|GPU_" > $O/env.txt; nproc >> $O/env.txt; python3 -c "import os; print('affinity', len(os.sched_getaffinity(0)), 'cpu_count', os.cpu_count())" >> $O/env.txt
 if [ -z "$SKIP_TESTS" ]; then
-timeout -k 10 900 python -m pytest tests/test_stats_gpu.py tests/test_bench_gpu.py -x -q -m gpu --capture=sys > $O/pytest.log 2>&1 || { echo "PYTEST FAILED"; tail -40 $O/pytest.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_stats_gpu.py tests/test_configs_gpu.py -x -q -m gpu --capture=sys > $O/pytest.log 2>&1 || { echo "PYTEST FAILED"; tail -40 $O/pytest.log; exit 1; }
 tail -3 $O/pytest.log
 fi
 time timeout -k 10 900 python bench.py --steps ${STEPS:-20} --warmup 5 > $O/bench.json 2> $O/bench.err || { echo BENCH FAILED; tail -20 $O/bench.err; exit 2; }
