@@ -124,6 +124,7 @@ def main(args=None):
     ap.add_argument("--end-to-end", action="store_true")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--workdir", default=None, help="directory for the input files and msa.fa (default: the system's temporary directory)")
+    ap.add_argument("--no-nomsa", action="store_true", help="skip the second run (getPOA(write_msa=False): no msa.fa)")
     ap.add_argument("--repeat", type=int, default=1, help="write the synthetic reads this many times over (distinct names): "
                                                           "--reads 40004 --repeat 5 is twenty batches")
     a, _ = ap.parse_known_args()
@@ -199,6 +200,26 @@ def main(args=None):
                 sys.stderr.write("%-12s|%s|\n" % (nm[:12], "".join(row)))
         # the same report from the text file (what call site #2 cost before the counters were handed over); left out
         # on long runs (the text of twenty batches is 5 GB)
+        # ... and the run again without msa.fa (getPOA(write_msa=False)): same report from the device
+        # counters, no records formatted or written
+        nomsa = None
+        if not a.no_nomsa:
+            outdir2 = os.path.join(work, "out_nomsa")
+            os.mkdir(outdir2)
+            alignment.STAGE_SECONDS.clear()
+            os.sync()
+            tn0 = time.perf_counter()
+            with redirect_stdout(buf):
+                small2, wrong2 = alignment.getPOA(paths[1], paths[0], paths[2], a.threads, outdir2, 0.1, write_msa=False)
+            tn1 = time.perf_counter()
+            with redirect_stdout(buf):
+                tupn = computeStats.outputRecallPrecision(paths[1], outdir2, io.StringIO(), small2, wrong2, 5, 0.1, "sizes.txt", {})
+            tn2 = time.perf_counter()
+            assert tupn == tup and not os.path.exists(outdir2 + "/msa.fa"), "the report without msa.fa differs"
+            nomsa = {"value": round(bases / (tn2 - tn0) / 1e6, 3), "unit": "Mbases/s",
+                     "seconds": {"getPOA (wall)": round(tn1 - tn0, 3), "outputRecallPrecision (wall)": round(tn2 - tn1, 3)},
+                     "getPOA_stage_seconds": {k: round(v, 3) for k, v in alignment.STAGE_SECONDS.items()},
+                     "report_equal_to_the_run_with_the_file": True}
         t3 = None
         if a.repeat <= 1 and a.reads <= 50000:
             alignment.MSA_CACHE.clear()
@@ -217,6 +238,7 @@ def main(args=None):
                         "outputRecallPrecision from the text file instead": None if t3 is None else round(t3 - t2, 3)},
             "getPOA_stage_seconds": stages,
             "device_counters_used": hit,
+            "without_msa_fa": nomsa,
             "recall": tup[3], "precision": tup[2], "assessed_reads": tup[0],
         }
         ref_dir = os.path.join(ROOT, "oracle", "_ref")

@@ -132,7 +132,7 @@ def _donatello_header(h):
 class _Batch:
     """One processing batch: reads, their msa.fa header lines, and where its first read stands in the
     reference's own batch protocol."""
-    __slots__ = ("first_index", "win", "piece_first", "read_first", "rec_hdr", "small", "wrong", "last", "d_bases")
+    __slots__ = ("first_index", "win", "piece_first", "read_first", "rec_hdr", "small", "wrong", "last", "d_bases", "d_off", "plain")
 
 
 def _triples(reference, uncorrected, corrected, start=0, stop=None):
@@ -181,13 +181,16 @@ def _prepare(rb, size_threshold, threads, splitter=None):
     b = _Batch()
     b.first_index = first_index = rb.first_index
     t0 = time.perf_counter()
-    b.d_bases = None
+    b.d_bases = b.d_off = None
     if splitter is not None:
         win = split.split_packed_device(splitter, rb.seq, rb.seq_off, rb.hdr_len, size_threshold, nthreads=max(1, int(threads)))
         # out of the splitter's workspace, which its next call reuses
         t1 = time.perf_counter()
         b.d_bases = win.d_bases.to_tensor() if isinstance(win.d_bases, split.DevBases) else win.d_bases
-        win.d_bases = None
+        # ... and the offsets with them: the engine then takes the windows without a per-window pass on the host
+        d_off = getattr(win, "d_off", None)
+        b.d_off = d_off.to_tensor() if isinstance(d_off, split.DevBases) else d_off
+        win.d_bases = win.d_off = None
         if os.environ.get("ELECTOR_DEBUG_HOST"):
             sys.stderr.write("[elector] split stage: call + arrays %.1f ms, bases to a tensor of their own %.1f ms\n"
                              % (1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)))
@@ -232,6 +235,7 @@ def _prepare(rb, size_threshold, threads, splitter=None):
     else:
         b.read_first = np.asarray([0, n_rec], dtype=np.int64) if n_rec else np.zeros(1, dtype=np.int64)
     b.last = False
+    b.plain = plain
     _tick("record / read boundaries (host)", t0)
     return b
 
@@ -310,8 +314,15 @@ def _append_file(out, path):
 
 
 def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_READ_THRESHOLD, soft=None,
-           engine=None, matrix=None, parity="raise"):
+           engine=None, matrix=None, parity="raise", write_msa=None):
     """elector/alignment.py:67-131.
+
+    write_msa=False (or ELECTOR_NO_MSA=1 when the argument is left None): msa[_soft].fa is NOT written.  The per-piece
+    counters, computed on the device while the MSAs are there, are all call site #2 needs
+    (computeStats.outputRecallPrecision takes them from this process's MSA_CACHE: same tuple, stdout, log and side
+    files), and the 3 x 3.3 bytes per base of records are the largest item of a run ("keep a flag to
+    still write it" -- the default).  Needs header lines without a title and no soft clips, which both make the
+    reference's statistics depend on the text of the file.
 
     parity="raise" (default): a window the device cannot align (ELECTOR_W_*: an empty sequence, a
     sequence beyond ELECTOR_MAX_SEQ) raises.  parity="skip": its record is left out of msa.fa, as a
@@ -320,6 +331,8 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     import torch
     amount_read = 1000 * 10
     print("- Means that a large amount of reads has been handled: " + str(amount_read))
+    if write_msa is None:
+        write_msa = os.environ.get("ELECTOR_NO_MSA", "0") in ("", "0")
     if engine is not None:
         pool = engine if isinstance(engine, EnginePool) else None
         engines = pool.engines if pool else [engine]
@@ -444,6 +457,9 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     # records already in the output file (append semantics, Donatello.cpp:48) are not this run's: call site #2
     # then parses the whole file instead of taking this run's device counters
     existed = os.path.exists(mergeOut) and os.path.getsize(mergeOut) > 0
+    if existed and not write_msa:
+        raise ValueError("getPOA(write_msa=False): %s already holds records; the counters of a run cannot stand for a "
+                         "file it only appended to" % mergeOut)
     all_hdr, all_cols, all_counters, all_read_first = [], [], [], [0]
     last_rows = last_mask = None
     cache_ok = not existed
@@ -487,6 +503,9 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
                 if drop.any():
                     skipped += int(drop.sum())
                     cache_ok = False               # the counters of a read's other pieces saw the dropped one
+                if not write_msa and not b.plain:
+                    raise ValueError("getPOA(write_msa=False): header lines with a title make the reference's statistics "
+                                     "depend on the text of msa.fa (computeStats.py:52,548); write the file")
                 all_hdr.extend(b.rec_hdr)
                 all_cols.append(piece_cols)
                 all_counters.append(counters)
@@ -503,12 +522,13 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
                 write_turn[0] = jno + 1
                 write_cv.notify_all()
         t0 = time.perf_counter()
-        # merged rows -> pinned host memory -> Donatello's records -> the file, in the library
-        got = split.msa_records_pwrite(eng, piece_cols, b.rec_hdr, drop if drop.any() else None, fd, at,
-                                       nthreads=max(1, min(16, int(threads))))
-        if got != nbytes:
-            raise ElectorError(-1, "msa.fa: %d bytes written where %d were reserved" % (got, nbytes))
-        _tick("merged rows D2H + write msa.fa (writer threads, native)", t0)
+        if write_msa:
+            # merged rows -> pinned host memory -> Donatello's records -> the file, in the library
+            got = split.msa_records_pwrite(eng, piece_cols, b.rec_hdr, drop if drop.any() else None, fd, at,
+                                           nthreads=max(1, min(16, int(threads))))
+            if got != nbytes:
+                raise ElectorError(-1, "msa.fa: %d bytes written where %d were reserved" % (got, nbytes))
+            _tick("merged rows D2H + write msa.fa (writer threads, native)", t0)
         sys.stdout.write('-' * 200)
         sys.stdout.flush()
 
@@ -532,8 +552,10 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
                 done.set()
 
     # Donatello appends (Donatello.cpp:48); a rank's part of a multi-rank run starts from scratch
-    fd = os.open(part_path, os.O_WRONLY | os.O_CREAT | (os.O_TRUNC if world > 1 else 0), 0o666)
-    write_at[0] = os.fstat(fd).st_size
+    fd = None
+    if write_msa:
+        fd = os.open(part_path, os.O_WRONLY | os.O_CREAT | (os.O_TRUNC if world > 1 else 0), 0o666)
+        write_at[0] = os.fstat(fd).st_size
     n_writers = max(1, min(len(engines), int(os.environ.get("ELECTOR_WRITERS", str(len(engines))))))
     tws = [threading.Thread(target=writer, args=(fd,), daemon=True) for _ in range(n_writers)]
     for t_ in tws:
@@ -594,9 +616,12 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
                 buf.bases[:total].copy_(torch.from_numpy(win.bases), non_blocking=False)
                 _tick("windows H2D", t0)
             bases = buf.bases if b.d_bases is None else b.d_bases
-            buf.held = bases                       # the batch's own tensor lives until the context's next batch
+            buf.held = (bases, b.d_off)            # the batch's own tensors live until the context's next batch
             t0 = time.perf_counter()
-            engines[e].align_device(bases, win.off, buf.cols, buf.ncol, buf.status)
+            if b.d_off is not None:
+                engines[e].align_device_offsets(bases, b.d_off, win.n_windows, total, buf.cols, buf.ncol, buf.status)
+            else:
+                engines[e].align_device(bases, win.off, buf.cols, buf.ncol, buf.status)
             npieces = engines[e].msa_stats_enqueue(win.n_windows, buf.cols, buf.ncol, buf.status, b.piece_first,
                                                    b.read_first)
             _tick("classify + enqueue kernels (host)", t0)
@@ -613,7 +638,8 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             jobs.put(None)
         for t_ in tws:
             t_.join()
-        os.close(fd)
+        if fd is not None:
+            os.close(fd)
         stop_all.set()
         splitter_done.set()
         for t_ in ths:
@@ -645,12 +671,13 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
         hdr_all = [None] * world if rank == 0 else None
         dist.gather_object(mine, hdr_all, dst=0)          # every part is on disk before rank 0 goes on
         if rank == 0:
-            # (not "ab": sendfile refuses an O_APPEND descriptor; _append_file positions the file at its end itself)
-            with open(mergeOut, "r+b" if os.path.exists(mergeOut) else "wb") as out:
-                for r in range(world):
-                    part = mergeOut + ".part%d" % r
-                    _append_file(out, part)
-                    os.remove(part)
+            if write_msa:
+                # (not "ab": sendfile refuses an O_APPEND descriptor; _append_file positions the file at its end itself)
+                with open(mergeOut, "r+b" if os.path.exists(mergeOut) else "wb") as out:
+                    for r in range(world):
+                        part = mergeOut + ".part%d" % r
+                        _append_file(out, part)
+                        os.remove(part)
             counters, piece_cols = meta[:, :ES_NCOUNTERS], meta[:, ES_NCOUNTERS]
             all_hdr, all_read_first = [], [0]
             for hs, rf, ok, lr in hdr_all:
@@ -666,12 +693,15 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             return small_reads, wrongly_cor_reads
 
     MSA_CACHE.pop(os.path.abspath(mergeOut), None)
+    if not write_msa and not (cache_ok and len(piece_cols)):
+        raise ValueError("getPOA(write_msa=False): this run's counters cannot stand for the file (records left out or no "
+                         "record at all); write the file")
     if cache_ok and len(piece_cols):
-        st = os.stat(mergeOut)
+        st = os.stat(mergeOut) if write_msa else None
         p0 = all_read_first[-2]
         plain = all(b" " not in h[1:-1] and b"\t" not in h for h in all_hdr)
         MSA_CACHE[os.path.abspath(mergeOut)] = dict(
-            sig=(st.st_size, st.st_mtime_ns), headers=all_hdr, plain_headers=plain, cols=piece_cols,
+            sig=(st.st_size, st.st_mtime_ns) if st else None, no_file=not write_msa, headers=all_hdr, plain_headers=plain, cols=piece_cols,
             read_first=np.asarray(all_read_first, dtype=np.int64), counters=counters,
             last_first_piece=p0, last_rows=last_rows, last_mask=last_mask)
     return small_reads, wrongly_cor_reads

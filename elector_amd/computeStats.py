@@ -230,18 +230,22 @@ def cached_pieces(fileName, clipsNb):
     The counters were computed on the device while the MSAs were there (elector_msa_stats_enqueue), so the
     text file does not have to be parsed or uploaded again.  None when there is nothing usable: another
     file, a file appended to, soft clips to apply (computeStats.py:718-741 needs them per header)."""
-    if clipsNb:
-        return None
     from . import alignment
     ent = alignment.MSA_CACHE.get(os.path.abspath(fileName))
-    if ent is None:
-        return None
-    try:
-        st = os.stat(fileName)
-    except OSError:
-        return None
-    if (st.st_size, st.st_mtime_ns) != ent["sig"]:
-        return None
+    if ent is not None and ent.get("no_file") and not os.path.exists(fileName):
+        # getPOA(write_msa=False): the run left no file, its counters are all there is
+        if clipsNb:
+            raise ValueError("soft clips are applied per header line of msa.fa (computeStats.py:718-741): run getPOA with "
+                             "write_msa=True")
+    else:
+        if clipsNb or ent is None or ent.get("no_file"):
+            return None
+        try:
+            st = os.stat(fileName)
+        except OSError:
+            return None
+        if (st.st_size, st.st_mtime_ns) != ent["sig"]:
+            return None
     # The reference finds a read's pieces through two different views of its header line (getSplit's key: the
     # line without blanks, computeStats.py:52; the walk's key: its first blank-delimited token, :548,612).  They
     # agree unless the header has a title; then the reference's own bookkeeping derails (KeyError, or pieces

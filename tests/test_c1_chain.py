@@ -95,6 +95,33 @@ def test_both_call_sites_reproduce_the_reference_chain(tmp_path, capsys):
     check_report(tup, capsys.readouterr().out, log.getvalue(), d)
 
 
+@pytest.mark.gpu
+def test_report_without_the_msa_file(tmp_path, capsys, monkeypatch):
+    """getPOA(write_msa=False) / ELECTOR_NO_MSA=1: no msa.fa, the same report -- tuple, stdout, log and
+    both side files of the pinned reference chain -- from the device counters"""
+    from elector_amd import alignment, computeStats
+    for mode in ("argument", "environment"):
+        d = str(tmp_path / mode)
+        os.makedirs(d)
+        write_reads(d, c1_reads())
+        if mode == "argument":
+            small, wrong = alignment.getPOA(d + "/cor.fa", d + "/ref.fa", d + "/unc.fa", 8, d, 0.1, write_msa=False)
+        else:
+            monkeypatch.setenv("ELECTOR_NO_MSA", "1")
+            small, wrong = alignment.getPOA(d + "/cor.fa", d + "/ref.fa", d + "/unc.fa", 8, d, 0.1)
+            monkeypatch.delenv("ELECTOR_NO_MSA")
+        capsys.readouterr()
+        assert (small, wrong) == (GOLD["small"], GOLD["wrong"])
+        assert not os.path.exists(d + "/msa.fa")
+        log = io.StringIO()
+        tup = computeStats.outputRecallPrecision(d + "/cor.fa", d, log, small, wrong, 5, 0.1, "read_size_distribution.txt", {})
+        check_report(tup, capsys.readouterr().out, log.getvalue(), d)
+        assert not os.path.exists(d + "/msa.fa")
+    # soft clips need the file's header lines: refused, not silently ignored
+    with pytest.raises(ValueError):
+        computeStats.cached_pieces(d + "/msa.fa", {"read1": (3, 4)})
+
+
 def _rank(rank, world, port, d, result):
     import torch.distributed as dist
     from contextlib import redirect_stdout
