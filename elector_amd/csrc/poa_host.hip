@@ -1342,6 +1342,21 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       if (bin_cnt[(size_t)b]) std::fprintf(stderr, " G%dxR%d:%d/%lld", cls_G(b / kNT), cls_R(b / kNT), hc[(size_t)bin_slot[(size_t)b]], (long long)bin_cnt[(size_t)b]);
     std::fprintf(stderr, "\n");
   }
+  if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 8)) {
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> hs((size_t)32 * kBins);
+    (void)hipMemcpy(hs.data(), c->d_rowinit.as<uint8_t>() + 1024, hs.size() * 8, hipMemcpyDeviceToHost);
+    int32_t fc[4] = {0, 0, 0, 0};
+    if (use_pack) (void)hipMemcpy(fc, c->d_far.as<uint32_t>() + n, sizeof fc, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[elector] far lists (G8 G16 G32 G64): %d %d %d %d\n", fc[0], fc[1], fc[2], fc[3]);
+    for (int b = 0; b < kBins; ++b) {
+      const unsigned long long *p = hs.data() + 32 * (size_t)b + 16;
+      if (p[1] | p[2] | p[3] | p[4] | p[5] | p[6])
+        std::fprintf(stderr, "[elector] bin G%dxR%d leaves k_poa: records beyond the slot %llu, broken path %llu, one far edge %llu, several far edges %llu, "
+                             "ordinal rows / steps %llu, refused at the door %llu (of %lld)\n", cls_G(b / kNT), cls_R(b / kNT), p[1], p[2], p[3], p[4], p[5], p[6],
+                     (long long)bin_cnt[(size_t)b]);
+    }
+  }
   if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 4)) {
     (void)hipStreamSynchronize(st);
     int32_t hc[4];

@@ -272,7 +272,7 @@ __device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&nee
 // dynamic program); the others report such a graph through *far_out and do not take it.
 template <int G, typename IT, bool FAR>
 __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, const uint8_t *ys, IT *x2y,
-                                         uint32_t *xinfo, bool *bad_out, bool *far_out)
+                                         uint32_t *xinfo, bool *bad_out, bool *far_out, int *why)
 {
   constexpr int kNoneI = (int)(IT)~(IT)0;                               // "not aligned" in the index type of this class
   const int Lr = W.Lr, Lc = W.Lc;
@@ -420,6 +420,7 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
   if (on) W.n1 = n1;
   *bad_out = bad;
   const bool near_ok = !on || (fits && maxd <= 2 && !bad);
+  *why = !on ? 0 : !fits ? 1 : bad ? 2 : nfar == 1 ? 3 : nfar > 1 ? 4 : 0;      // (debug: why a window is not kept)
   if (FAR) {
     if (on && nfar == 1) W.fnode = fsrc;
     return near_ok && (!on || nfar <= 1);
@@ -954,7 +955,10 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       fit_win<G, R>(W[h], a, listed, d0[h].x, o0, (int)d0[h].y, (int)d0[h].z, (int)d0[h].w, (int)(d1[h].z & 0xFFu),
                     lds + 64 + (size_t)(2 * q + h) * a.slot_bytes);
       // a listed window this kernel cannot take (slot, rows, score range) goes to the two-kernel path at once
-      if (listed && !W[h].valid && g == 0) a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
+      if (listed && !W[h].valid && g == 0) {
+        a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
+        if (a.debug & 8) atomicAdd(a.stamps + 6, 1ull);                // (debug: refused at the door: slot, rows, score range)
+      }
     }
     any_valid = __builtin_amdgcn_ballot_w64(W[0].valid || W[1].valid) != 0;
     PK_STAMP(8);
@@ -1105,6 +1109,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   PK_STAMP(1);
   // ---- traceback #1, fusion #1 (per window), trivial graphs ----
   bool bad[2] = {false, false}, keep[2], farw[2] = {false, false};
+  int why[2] = {0, 0};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
@@ -1123,7 +1128,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
     IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
     keep[h] = true;
     if (__builtin_amdgcn_ballot_w64(needA[h]) != 0)
-      keep[h] = fusion_1<G, IT, FAR>(W[h], g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h], &farw[h]);
+      keep[h] = fusion_1<G, IT, FAR>(W[h], g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h], &farw[h], &why[h]);
     trivial_graph<G>(W[h], g, U[h], U[h] + W[h].Lr, xinfo[h]);
     if (W[h].valid && W[h].triv == 1) W[h].score1 = W[h].Lr * kp.match;
     if (W[h].valid && W[h].triv == 2) W[h].score1 = (W[h].Lr - 1) * kp.match + kp.mismatch;
@@ -1170,6 +1175,9 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       // has room), anything else to the two-kernel path, which takes the window from scratch
       if (g == 0) {
         bool placed = false;
+        // debug bit 8: why windows leave this kernel (1 nodes beyond the slot's records, 2 broken path, 3 one far edge,
+        // 4 several far edges, 5 ordinal rows / moves steps beyond the slot), counted per bin
+        if (a.debug & 8) atomicAdd(a.stamps + (keep[h] && !bad[h] ? 5 : why[h]), 1ull);
         if (!FAR && farw[h] && !bad[h] && a.far != nullptr) {
           const int at = atomicAdd(a.far_count, 1);
           if (at < a.far_cap) { a.far[at] = W[h].w; placed = true; }
