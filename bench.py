@@ -104,6 +104,8 @@ def parse():
                     help="skip the second timed loop (the same steps with the merged MSA rows left in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--bundles", action="store_true",
+                    help="a12: time the heaviest-bundle consensus search (k_bundle) of one batch per step, with its roofline")
     ap.add_argument("--end-to-end", action="store_true",
                     help="three FASTA files -> getPOA -> outputRecallPrecision with a stage table (see bench_e2e.py)")
     if "--end-to-end" in sys.argv[1:]:              # bench_e2e.py has options of its own (--reference-sample, --no-reference)
@@ -399,11 +401,66 @@ def unit_read_lengths(job):
     return lr, lc, lu
 
 
+def bundles_mode(args):
+    """a12 (heaviest_bundle.c:16-172; optional output, the reference never calls it): per step one batch through the
+    alignment kernels that leave the graph in HBM (elector_ctx_keep_graph) and the bundle search on every window.
+    Prints ONE JSON line: ms per step of the search (HIP events on its stream), windows per second, its HBM roofline."""
+    import numpy as np
+    import torch
+    from elector_amd.poa import PoaEngine
+    profile = args.profile if not args.profile_defaulted else "ecoli30x_simlord_lordec"
+    b = prepare_batch((profile, args.reads, 1000, cpu_share(), None))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    d_bases = torch.from_numpy(b.win.bases).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(b.win.off, dtype=np.int64)).to(dev)
+    d_cols = torch.empty(3 * b.total + 64, dtype=torch.uint8, device=dev)
+    d_ncol = torch.empty(b.n, dtype=torch.int32, device=dev)
+    d_status = torch.empty(b.n, dtype=torch.int32, device=dev)
+    eng = PoaEngine(0)
+    eng.keep_graph(True)
+
+    def step():
+        eng.align_device_offsets(d_bases, d_off, b.n, b.total, d_cols, d_ncol, d_status)
+        eng.bundles_enqueue(b.n)
+    for _ in range(max(2, args.warmup)):
+        step()
+    eng.sync()
+    eng.timing_enable(True)
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    dt = time.perf_counter() - t0
+    ms, launches = eng.timing_read(5)
+    ncol = d_ncol.cpu().numpy().astype(np.int64)
+    po = eng.last_po_sizes(b.n).astype(np.int64)
+    # algorithmic bytes of the search: the graph after fusion #1 as the alignment kernels left it (8 + 2 + 4 bytes per node),
+    # the uncorrected symbols, the column counts in; up to three consensus rows and 32 bytes of bundle bookkeeping out
+    alg = int(14 * po.sum() + b.lu.sum() + 4 * b.n + 3 * ncol.sum() + 32 * b.n)
+    per_launch_ms = ms / max(1, launches)
+    out = {"metric": "heaviest-bundle consensus (a12) ms per step", "value": round(ms / args.steps, 3), "unit": "ms", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "higher_is_better": False, "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "%s: %d reads per step" % (WORKLOADS[profile], args.reads), "profile": profile, "windows": b.n},
+           "windows_per_s": round(b.n / (per_launch_ms * 1e-3), 1) if per_launch_ms > 0 else None,
+           "step_ms_with_alignment": round(dt / args.steps * 1e3, 3),
+           "roofline": {"bound": "hbm", "kernel": "k_bundle", "achieved": round(alg / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 else 0.0,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if per_launch_ms > 0 else 0.0,
+                        "traffic": None, "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
+                        "algorithmic_bytes_per_launch": alg}}
+    print(json.dumps(out), flush=True)
+    eng.close()
+
+
 def main():
     args = parse()
     if args.end_to_end:
         import bench_e2e
         return bench_e2e.main(args)
+    if args.bundles:
+        return bundles_mode(args)
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         sys.exit(self_launch(args))

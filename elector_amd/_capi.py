@@ -39,7 +39,7 @@ EXPORTS = [
     "elector_ctx_create", "elector_ctx_destroy", "elector_ctx_last_error",
     "elector_poa_batch", "elector_poa_batch_device", "elector_poa_batch_device_offsets", "elector_ctx_sync",
     "elector_ctx_timing_enable", "elector_ctx_timing_read", "elector_ctx_timing_reset",
-    "elector_ctx_last_po_sizes", "elector_ctx_option", "elector_ctx_keep_graph", "elector_poa_bundles",
+    "elector_ctx_last_po_sizes", "elector_ctx_option", "elector_ctx_keep_graph", "elector_poa_bundles", "elector_poa_bundles_enqueue",
     "elector_stats_batch", "elector_msa_stats_device", "elector_msa_stats_enqueue", "elector_msa_stats_enqueue_rows", "elector_msa_rows_wait", "elector_msa_stats_collect",
     "elector_msa_rows_fetch", "elector_homopolymer_pairs",
     "elector_split_reads", "elector_windows_free", "elector_merge_windows", "elector_msa_free",
@@ -99,6 +99,7 @@ def lib():
     L.elector_ctx_option.argtypes = [vp, C.c_char_p, i64]
     L.elector_ctx_keep_graph.argtypes = [vp, C.c_int]
     L.elector_poa_bundles.argtypes = [vp, i64, C.c_float, vp, i64, vp, vp]
+    L.elector_poa_bundles_enqueue.argtypes = [vp, i64, C.c_float]
     L.elector_msa_stats_device.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64]
     L.elector_msa_rows_fetch.argtypes = [vp, i64, vp, vp]
     L.elector_msa_stats_enqueue.argtypes = [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp]

@@ -245,14 +245,9 @@ extern "C" int elector_ctx_keep_graph(elector_ctx *c, int on)
   return ELECTOR_OK;
 }
 
-extern "C" int elector_poa_bundles(elector_ctx *c, int64_t n, float minimum_fraction, uint8_t *cons_rows,
-                                   int64_t cons_cap, int64_t *cons_off, int32_t *info)
+// the bundle search of the last batch queued on the context's stream; results stay in the context's device buffers
+static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
 {
-  if (!c) return ELECTOR_E_INVAL;
-  if (n < 0 || !cons_off || (n > 0 && !info)) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
-  std::lock_guard<std::mutex> lock(c->mu);
-  cons_off[0] = 0;
-  if (n == 0) return ELECTOR_OK;
   if (!c->keep_graph || !c->graph_valid || n != c->last_n)
     return elector_fail(c, ELECTOR_E_INVAL, "no graph kept: call elector_ctx_keep_graph(ctx, 1) before the POA batch");
   HIPCHK(c, hipSetDevice(c->device));
@@ -279,8 +274,33 @@ extern "C" int elector_poa_bundles(elector_ctx *c, int64_t n, float minimum_frac
   a.path = c->d_bpath.as<uint16_t>();
   a.cons = c->d_bcons.as<uint8_t>();
   a.info = c->d_binfo.as<int32_t>();
+  timed_begin(c, 5, st);
   hipLaunchKernelGGL(k_bundle, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
+  timed_end(c, st);
   HIPCHK(c, hipGetLastError());
+  return ELECTOR_OK;
+}
+
+extern "C" int elector_poa_bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n < 0) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (n == 0) return ELECTOR_OK;
+  return bundles_enqueue(c, n, minimum_fraction);
+}
+
+extern "C" int elector_poa_bundles(elector_ctx *c, int64_t n, float minimum_fraction, uint8_t *cons_rows,
+                                   int64_t cons_cap, int64_t *cons_off, int32_t *info)
+{
+  if (!c) return ELECTOR_E_INVAL;
+  if (n < 0 || !cons_off || (n > 0 && !info)) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
+  std::lock_guard<std::mutex> lock(c->mu);
+  cons_off[0] = 0;
+  if (n == 0) return ELECTOR_OK;
+  int rc = bundles_enqueue(c, n, minimum_fraction);
+  if (rc) return rc;
+  hipStream_t st = c->stream;
   HIPCHK(c, hipMemcpyAsync(info, c->d_binfo.p, (size_t)n * 32, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   for (int64_t w = 0; w < n; ++w) cons_off[w + 1] = cons_off[w] + (int64_t)info[8 * w] * info[8 * w + 7];

@@ -212,6 +212,10 @@ class PoaEngine:
         """Make the following batches keep the graph data the bundle search needs."""
         self._check(self._lib.elector_ctx_keep_graph(self._h, 1 if on else 0))
 
+    def bundles_enqueue(self, n, minimum_fraction=0.9):
+        """the bundle search of the last batch, queued; results stay on the device (timing: kind 5)"""
+        self._check(self._lib.elector_poa_bundles_enqueue(self._h, int(n), float(minimum_fraction)))
+
     def bundles(self, n, total_bases, minimum_fraction=0.9):
         """generate_lpo_bundles(lpo, minimum_fraction) (heaviest_bundle.c:144-172) on every window of
         the last batch -> list of (consensus rows [bytes], counts [int], bundle ids (ref, cor, unc))."""

@@ -131,7 +131,7 @@ int elector_ctx_sync(elector_ctx *ctx);
  * (k_fused_b<G,R,D>; k_dp2), 2 = everything else of the POA stage (symbolize, the
  * trivial-window pass and list sort, generic leftovers, tiled long windows),
  * 3 = merge + statistics kernels (include/elector_stats.h), 4 = k_poa (the whole window in one kernel,
- * poa_pack.hip: when it is in use, kinds 0 and 1 only see the windows it handed back).
+ * poa_pack.hip: when it is in use, kinds 0 and 1 only see the windows it handed back), 5 = k_bundle (a12).
  * The geometry classes run on two concurrent launch chains: the sums overlap in wall time. */
 int elector_ctx_timing_enable(elector_ctx *ctx, int on);
 int elector_ctx_timing_read(elector_ctx *ctx, int kernel, double *ms, int64_t *launches);
@@ -167,6 +167,9 @@ int elector_ctx_last_po_sizes(elector_ctx *ctx, int64_t n, int32_t *po_nodes);
  *               (3 * off[3n] always suffices)
  * The reference's default minimum_fraction is 0.9 (main.c:30). */
 int elector_ctx_keep_graph(elector_ctx *ctx, int on);
+/* the search alone, queued on the context's stream, its results left in the context's device buffers (what
+ * elector_poa_bundles then fetches): the entry bench.py --bundles times; timing kind 5 (elector_ctx_timing_read) */
+int elector_poa_bundles_enqueue(elector_ctx *ctx, int64_t n, float minimum_fraction);
 int elector_poa_bundles(elector_ctx *ctx, int64_t n, float minimum_fraction,
                         uint8_t *cons_rows, int64_t cons_cap, int64_t *cons_off,
                         int32_t *info);
