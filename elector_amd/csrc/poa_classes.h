@@ -135,6 +135,9 @@ struct SortArgs {
 };
 
 void launch_classify(const ClassifyArgs &a, hipStream_t st);
+// bytes (4-byte aligned both sides) from device memory into page-locked host memory by a kernel's stores; -1 when the
+// host address is not device-addressable
+int launch_words_to_host(void *host_dst, const void *src, size_t bytes, hipStream_t st);
 int launch_sort(const SortArgs &a, hipStream_t st);
 void launch_generic_info(const uint32_t *glist, int64_t ng, const int64_t *off, const int32_t *status, int32_t *info, hipStream_t st);
 void launch_generic_moves(const uint32_t *glist, int64_t ng, const int64_t *gmv, int64_t *mv1, int64_t *mv2, hipStream_t st);

@@ -10,6 +10,8 @@
 // (src/poa-graph/main.c:265-284).  The classes exist because a wavefront is fastest when its windows look alike.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "elector_poa.h"
 #include "poa_classes.h"
 
@@ -189,6 +191,27 @@ __global__ void __launch_bounds__(256) k_generic_moves(const uint32_t *glist, in
   const int64_t w = glist[k];
   mv1[w] = gmv[2 * k];
   mv2[w] = gmv[2 * k + 1];
+}
+
+// Small results on their way to the host WITHOUT the copy engine: a kernel stores them into page-locked host memory the
+// device can address.  The copy engine is busy with the merged rows of earlier batches (hundreds of megabytes each):
+// a 29 KB read-back queued behind one of those made the host wait milliseconds for totals it needs before it can
+// queue the next batch.  (dst and src 4-byte aligned, bytes a multiple of 4.)
+__global__ void __launch_bounds__(256) k_words_to_host(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, int64_t n)
+{
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+int launch_words_to_host(void *host_dst, const void *src, size_t bytes, hipStream_t st)
+{
+  if (!bytes) return 0;
+  void *d = nullptr;
+  if (hipHostGetDevicePointer(&d, host_dst, 0) != hipSuccess || !d) { (void)hipGetLastError(); return -1; }
+  const int64_t n = (int64_t)(bytes + 3) / 4;
+  const unsigned blocks = (unsigned)std::min<int64_t>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(k_words_to_host, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint32_t *>(d),
+                     reinterpret_cast<const uint32_t *>(src), n);
+  return 0;
 }
 
 void launch_classify(const ClassifyArgs &a, hipStream_t st)

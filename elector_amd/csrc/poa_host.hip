@@ -516,7 +516,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     timed_begin(c, 2, st);
     launch_classify(ca, st);
     timed_end(c, st);
-    HIPCHK(c, hipMemcpyAsync(c->h_acc.p, d_acc, acc_ints * 4, hipMemcpyDeviceToHost, st));
+    // the totals come back as a kernel's stores into page-locked memory, not through the copy engine (which may be
+    // busy for milliseconds with an earlier batch's merged rows)
+    if (launch_words_to_host(c->h_acc.p, d_acc, acc_ints * 4, st))
+      HIPCHK(c, hipMemcpyAsync(c->h_acc.p, d_acc, acc_ints * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
   }
   const double tp1 = now_ms();

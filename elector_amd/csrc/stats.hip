@@ -36,6 +36,7 @@
 #include <unistd.h>
 
 #include "ctx.h"
+#include "poa_classes.h"
 #include "elector_stats.h"
 #include "elector_split.h"
 
@@ -1128,9 +1129,15 @@ int enqueue_stats(elector_ctx *c, elector::StatsSlot &s, unsigned long long ints
   timed_end(c, st);
   HIPCHK(c, hipGetLastError());
   uint8_t *h = s.h.as<uint8_t>();
-  HIPCHK(c, hipMemcpyAsync(h, pv.overflow, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(h + 16, s.cnt.p, (size_t)s.n_pieces * ES_NCOUNTERS * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(h + 16 + (size_t)s.n_pieces * ES_NCOUNTERS * 8, s.cols.p, (size_t)s.n_pieces * 8, hipMemcpyDeviceToHost, st));
+  // (kernel stores into the slot's page-locked block: the copy engine belongs to the merged rows, and the counters of
+  // this batch must not wait behind an earlier batch's rows)
+  if (elector::launch_words_to_host(h, pv.overflow, 4, st) ||
+      elector::launch_words_to_host(h + 16, s.cnt.p, (size_t)s.n_pieces * ES_NCOUNTERS * 8, st) ||
+      elector::launch_words_to_host(h + 16 + (size_t)s.n_pieces * ES_NCOUNTERS * 8, s.cols.p, (size_t)s.n_pieces * 8, st)) {
+    HIPCHK(c, hipMemcpyAsync(h, pv.overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h + 16, s.cnt.p, (size_t)s.n_pieces * ES_NCOUNTERS * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h + 16 + (size_t)s.n_pieces * ES_NCOUNTERS * 8, s.cols.p, (size_t)s.n_pieces * 8, hipMemcpyDeviceToHost, st));
+  }
   HIPCHK(c, hipEventRecord(s.done, st));
   return ELECTOR_OK;
 }
