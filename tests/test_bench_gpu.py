@@ -72,3 +72,15 @@ def test_bench_strong_scaling_cuts_one_read_set_by_cells():
     assert one["config"]["ref_bases_per_gpu"] == 2 * two["config"]["ref_bases_per_gpu"] or \
         abs(one["config"]["ref_bases_per_gpu"] - 2 * two["config"]["ref_bases_per_gpu"]) <= 2
     assert two["ranks"]["dp_cells_imbalance_max_over_mean"] < 1.10          # 450 reads per rank: a read is 0.2 % of a shard
+
+
+def test_bench_two_ranks_over_rccl_on_two_devices():
+    """The N > 1 path as the driver launches it: RCCL, one GPU per rank.  Rank 1's counter gathers are started from a
+    helper thread, whose current device would be GPU 0 unless the pipe is told its device (the round-3 advisor's
+    finding): with two devices the gather must complete and rank 0 must see both ranks' rows.  Skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    two = _bench(["--gpus", "2", "--profile", "yeast50x_nanosim_consent_split", "--batches", "2"])
+    assert two["n_gpus"] == 2 and two["ranks"]["backend"] == "nccl" and two["ranks"]["distinct_devices"] == 2
+    assert two["pieces_gathered"] >= 600
