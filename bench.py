@@ -722,6 +722,9 @@ def main():
             if b.po is None:
                 dc, dn, ds = outs[0]
                 align(engines[0], b, dc, dn, ds)
+                # (the merge / statistics kernels too: every pass of this process then has the same launches, which the
+                # per-step arithmetic of tools/_pmc_traffic.py relies on)
+                engines[0].msa_stats_collect(engines[0].msa_stats_enqueue(b.n, dc, dn, ds, b.piece_first, b.read_first))
                 engines[0].sync()
                 st = ds[:b.n].cpu().numpy()
                 if st.any():

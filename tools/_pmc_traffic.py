@@ -26,7 +26,7 @@ if "k_poa" in d:
                  "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_SCA"):
         if name in d["k_poa"]:
             sq[name] = d["k_poa"][name]["total"]
-meta = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* (separate passes) -- python3 bench.py --serial --no-cpu-baseline --steps 3 --warmup 1 --profile " + profile,
+meta = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* (separate passes) -- python3 bench.py --serial --no-cpu-baseline --steps 3 --warmup 1 --profile " + profile + " (--serial implies --batches 1)",
         "collected": collected,
         "profile": profile, "reads_per_gpu": reads,
         "k_poa_sq_counters": sq,
