@@ -894,6 +894,8 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   // index type of the alignment #1 / fusion #1 maps: one byte in the classes whose windows are short
   using IT = typename std::conditional<poa_idx_bytes(G) == 1, uint8_t, uint16_t>::type;
   const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
+  // a far list is launched at its capacity: the blocks behind its length leave before they touch anything
+  if (a.nlist_dev && (int64_t)blockIdx.x * (2 * NP) >= (int64_t)*a.nlist_dev) return;
   const KParams kp = a.b.kp;
   uint8_t *chr = lds;
   unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
