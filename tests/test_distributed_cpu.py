@@ -143,3 +143,30 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_chr1_shards_of_eight_ranks_are_balanced():
+    """The partitioner of DESIGN.md section 5 on BASELINE.json's 8-GPU config: one batch of chr1-like 50 kb reads
+    (log-normal lengths) cut into eight contiguous ranges by shard_bounds over read_cell_estimate -- what every rank
+    computes before it has split a single read -- against the DP cells the windows of those reads really have
+    (Lr x Lc + max(Lr, Lc) x Lu per window of the host splitter): max / mean <= 1.05 at 2, 4 and 8 ranks."""
+    from elector_amd import split, synthetic
+    from elector_amd.distributed import read_cell_estimate, shard_bounds
+    triples, headers, read_of = synthetic.read_pieces("chr1_20x_ont_50kb", 2000, seed=1000)
+    win = split.split_reads(triples, 0.1, headers, nthreads=8)
+    off = win.off
+    lr, lc, lu = off[1::3] - off[0:-1:3], off[2::3] - off[1:-1:3], off[3::3] - off[2:-1:3]
+    cells_piece = np.add.reduceat(lr * lc + np.maximum(lr, lc) * lu, win.read_first[:-1])
+    ids = np.asarray(read_of)
+    nr = int(ids.max()) + 1
+    cells_read = np.bincount(ids[win.read_index], weights=cells_piece, minlength=nr)
+    R, C, U = np.zeros(nr), np.zeros(nr), np.zeros(nr)
+    for (r, c, u), i in zip(triples, ids):
+        R[i] = len(r)
+        U[i] = len(u)
+        C[i] += len(c)
+    w = read_cell_estimate(R, C, U)
+    for world in (2, 4, 8):
+        b = shard_bounds(w, world)
+        act = [cells_read[b[k]:b[k + 1]].sum() for k in range(world)]
+        assert max(act) / np.mean(act) <= 1.05, (world, max(act) / np.mean(act))
