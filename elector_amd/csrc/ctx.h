@@ -117,6 +117,7 @@ struct elector_ctx {
   elector::StatsSlot st_slot[kStatsSlots];
   int st_head = 0, st_tail = 0, st_inflight = 0, st_last = -1;
   hipStream_t copy_stream = nullptr;   // the rows' way to the host: the copy engine works beside the kernels of the next batch
+  hipStream_t copy_stream2 = nullptr;  // ELECTOR_ROWS_COPY_STREAMS=2 (experiment): the second half of a batch's rows on a stream of its own
   // timing
   bool timing = false;
   std::vector<elector::TimedSpan> spans;

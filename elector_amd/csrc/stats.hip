@@ -1306,7 +1306,20 @@ extern "C" int elector_msa_stats_collect(elector_ctx *c, int64_t n_pieces, int64
     int64_t nbytes = 0;
     for (int64_t p = 0; p < n_pieces; ++p) nbytes += 3 * hcols[p];
     if (nbytes > 0) {
-      HIPCHK(c, hipMemcpyAsync(s.rows_host, s.dense.p, (size_t)nbytes, hipMemcpyDeviceToHost, c->copy_stream));
+      static const int n_streams = std::getenv("ELECTOR_ROWS_COPY_STREAMS") ? std::atoi(std::getenv("ELECTOR_ROWS_COPY_STREAMS")) : 1;
+      // ELECTOR_ROWS_COPY_BYTES=N (experiment): at most N bytes of the rows are copied -- what the copy itself costs
+      static const long long cap_bytes = std::getenv("ELECTOR_ROWS_COPY_BYTES") ? std::atoll(std::getenv("ELECTOR_ROWS_COPY_BYTES")) : -1;
+      if (cap_bytes >= 0 && nbytes > cap_bytes) nbytes = std::max<long long>(4, cap_bytes);
+      if (n_streams >= 2 && nbytes > (1 << 22)) {
+        // experiment: the two halves on two streams (two copy engines, if the runtime gives them one each)
+        if (!c->copy_stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
+        const size_t half = ((size_t)nbytes / 2) & ~(size_t)4095;
+        HIPCHK(c, hipMemcpyAsync(s.rows_host + half, s.dense.as<uint8_t>() + half, (size_t)nbytes - half, hipMemcpyDeviceToHost, c->copy_stream2));
+        HIPCHK(c, hipEventRecord(s.rows_done, c->copy_stream2));
+        HIPCHK(c, hipMemcpyAsync(s.rows_host, s.dense.p, half, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.rows_done, 0));      // (the event as recorded just above: the other half)
+      } else
+        HIPCHK(c, hipMemcpyAsync(s.rows_host, s.dense.p, (size_t)nbytes, hipMemcpyDeviceToHost, c->copy_stream));
       HIPCHK(c, hipEventRecord(s.rows_done, c->copy_stream));
       s.rows_inflight = true;
     }
