@@ -53,6 +53,7 @@ struct TimedSpan { hipEvent_t a, b; int kind; };
 struct StatsSlot {
   DevBuf rows, rowoff, cols, first, clips, cnt, mask, woff;
   DevBuf dense, outoff;         // elector_msa_stats_enqueue_rows: the merged rows packed (host destinations), their offsets
+  DevBuf wcnt, wpiece;          // window-parallel merge: surviving columns per window and their scan, piece of a window
   HostPinned h;                 // [overflow flag, pad to 16][counters][cols][inputs]
   hipEvent_t done = nullptr;
   hipEvent_t rows_done = nullptr;   // the packed rows have arrived at rows_host (recorded on the context's copy stream)
@@ -63,7 +64,7 @@ struct StatsSlot {
   void release()
   {
     rows.release(); rowoff.release(); cols.release(); first.release(); clips.release(); cnt.release();
-    mask.release(); woff.release(); h.release(); dense.release(); outoff.release();
+    mask.release(); woff.release(); h.release(); dense.release(); outoff.release(); wcnt.release(); wpiece.release();
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     if (rows_done) { (void)hipEventDestroy(rows_done); rows_done = nullptr; }
   }

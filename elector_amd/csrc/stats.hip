@@ -24,6 +24,7 @@
 // elector_homopolymer_pairs: host-side integer state machine for the one read
 // whose homopolymer ratio the reference reports (computeStats.py:671-674).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cerrno>
@@ -174,6 +175,94 @@ __global__ void __launch_bounds__(kStatsThreads) k_merge(MergeArgs a)
     k2 = store_xyz(k2, x2, y2, z2);
     for (int c0 = 64; c0 < nc1; c0 += 64) { load_xyz(src1, nc1, c0, x1, y1, z1); k1 = store_xyz(k1, x1, y1, z1); }
     for (int c0 = 64; c0 < nc2; c0 += 64) { load_xyz(src2, nc2, c0, x2, y2, z2); k2 = store_xyz(k2, x2, y2, z2); }
+  }
+}
+
+// ---- the merge with the WINDOWS as the unit of parallel work (round 4) ----
+// k_merge above gives a block to a piece: a batch of 50 kb reads is 2,000 pieces of 850 windows, twelve blocks per CU
+// working through hundreds of windows each (3.5 ms per batch); the pieces of 8 kb reads have 140.  Here every window
+// has its 16-lane group whatever piece it belongs to: count its surviving columns (Donatello.cpp:13-31), one exclusive
+// scan over all windows of the batch, per piece its column total and its place, then every window copies its
+// columns to (its scan value less its piece's).
+struct MergeWinArgs {
+  int64_t n_windows, n_pieces;
+  const int64_t *piece_first;
+  const int64_t *off;
+  const uint8_t *cols_in;
+  const int32_t *ncol;
+  const int32_t *status;
+  int64_t *cnt;                 // n_windows + 1: surviving columns per window, then (in place) their exclusive scan
+  int32_t *piece_of;            // n_windows
+  uint8_t *rows;
+  int64_t *row_off, *cols;
+};
+
+__global__ void __launch_bounds__(kStatsThreads) k_merge_count(MergeWinArgs a)
+{
+  const int gl = threadIdx.x & 15, lane = threadIdx.x & 63, gshift = (lane >> 4) * 16;
+  const int64_t w = (int64_t)blockIdx.x * (kStatsThreads / 16) + (threadIdx.x >> 4);
+  const bool on = w < a.n_windows;
+  const int nc = on && a.status[w] == 0 ? a.ncol[w] : 0;
+  const uint8_t *src = a.cols_in + (on ? 3 * a.off[3 * w] : 0);
+  int cnt = 0;
+  int ncmax = nc;                                     // (the ballots below need the wavefront's four groups together)
+  for (int d = 16; d < 64; d <<= 1) ncmax = max(ncmax, __shfl_xor(ncmax, d));
+  for (int c0 = 0; c0 < ncmax; c0 += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + 16 * u + gl;
+      const uint8_t y = c < nc ? src[3 * c + 1] : (uint8_t)'n';
+      cnt += __popcll((__ballot(y != 'n') >> gshift) & 0xFFFFull);
+    }
+  }
+  if (on && gl == 0) a.cnt[w] = cnt;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt[a.n_windows] = 0;
+}
+
+__global__ void __launch_bounds__(kStatsThreads) k_merge_pieces(MergeWinArgs a)
+{
+  const int64_t p = blockIdx.x;
+  const int64_t w0 = a.piece_first[p], w1 = a.piece_first[p + 1];
+  for (int64_t w = w0 + threadIdx.x; w < w1; w += kStatsThreads) a.piece_of[w] = (int32_t)p;
+  if (threadIdx.x == 0) { a.cols[p] = a.cnt[w1] - a.cnt[w0]; a.row_off[p] = 3 * a.off[3 * w0]; }
+}
+
+__global__ void __launch_bounds__(kStatsThreads) k_merge_copy(MergeWinArgs a)
+{
+  const int gl = threadIdx.x & 15, lane = threadIdx.x & 63, gshift = (lane >> 4) * 16;
+  const int64_t w = (int64_t)blockIdx.x * (kStatsThreads / 16) + (threadIdx.x >> 4);
+  const bool on = w < a.n_windows;
+  const int nc = on && a.status[w] == 0 ? a.ncol[w] : 0;
+  const uint8_t *src = a.cols_in + (on ? 3 * a.off[3 * w] : 0);
+  int64_t k = 0, n = 0, rb = 0;
+  if (on) {
+    const int64_t p = a.piece_of[w], w0 = a.piece_first[p];
+    const int64_t e0 = a.cnt[w0];
+    k = a.cnt[w] - e0;
+    n = a.cnt[a.piece_first[p + 1]] - e0;
+    rb = 3 * a.off[3 * w0];
+  }
+  uint8_t *d0 = a.rows + rb, *d1 = d0 + n, *d2 = d1 + n;
+  int ncmax = nc;
+  for (int d = 16; d < 64; d <<= 1) ncmax = max(ncmax, __shfl_xor(ncmax, d));
+  for (int c0 = 0; c0 < ncmax; c0 += 64) {
+    uint8_t x[4], y[4], z[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + 16 * u + gl;
+      x[u] = 0; y[u] = 'n'; z[u] = 0;
+      if (c < nc) { x[u] = src[3 * c]; y[u] = src[3 * c + 1]; z[u] = src[3 * c + 2]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool keep = y[u] != 'n';
+      const unsigned long long m = (__ballot(keep) >> gshift) & 0xFFFFull;
+      if (keep) {
+        const int64_t at = k + __popcll(m & ((1ull << gl) - 1ull));
+        d0[at] = x[u]; d1[at] = y[u]; d2[at] = z[u];
+      }
+      k += __popcll(m);
+    }
   }
 }
 
@@ -1238,8 +1327,36 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
     m.row_off = s.rowoff.as<int64_t>();
     m.cols = s.cols.as<int64_t>();
     m.woff = s.woff.as<int32_t>();
+    // A block per piece (k_merge) while the pieces are short; a lane group per window when a piece has hundreds of
+    // windows (50 kb reads: 850): there the blocks' long serial loops were 3.45 ms of merge + counters per batch, 2.83 with
+    // the windows as the unit; on 8 kb reads (140 windows per piece) the four launches and the scan cost 0.2 ms more than
+    // they save.  ELECTOR_MERGE_PER_PIECE=1 / =0 force one or the other (A/B).
+    static const char *force = std::getenv("ELECTOR_MERGE_PER_PIECE");
+    const bool per_piece = force ? std::atoi(force) != 0 : s.max_windows < 400;
     timed_begin(c, 3, st);
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, m);
+    if (per_piece || n_windows == 0)
+      hipLaunchKernelGGL(k_merge, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, m);
+    else {
+      MergeWinArgs mw{};
+      mw.n_windows = n_windows; mw.n_pieces = n_pieces;
+      mw.piece_first = d_piece_first; mw.off = m.off; mw.cols_in = d_cols; mw.ncol = d_ncol; mw.status = d_status;
+      size_t tmp_bytes = 0;
+      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int)(n_windows + 1), st);
+      for (int k = 0; k < elector_ctx::kStatsSlots; ++k)
+        if (c->st_slot[k].wcnt.ensure((size_t)(n_windows + 1) * 8 * 2 + tmp_bytes + 256) | c->st_slot[k].wpiece.ensure((size_t)n_windows * 4 + 64))
+          return elector_fail(c, ELECTOR_E_NOMEM, "merge workspace");
+      int64_t *cnt_in = s.wcnt.as<int64_t>(), *cnt_ex = cnt_in + (n_windows + 1);
+      void *tmp = cnt_ex + (n_windows + 1);
+      mw.cnt = cnt_in; mw.piece_of = s.wpiece.as<int32_t>();
+      mw.rows = m.rows; mw.row_off = m.row_off; mw.cols = m.cols;
+      const unsigned wblocks = (unsigned)((n_windows + kStatsThreads / 16 - 1) / (kStatsThreads / 16));
+      hipLaunchKernelGGL(k_merge_count, dim3(wblocks), dim3(kStatsThreads), 0, st, mw);
+      if (hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt_in, cnt_ex, (int)(n_windows + 1), st) != hipSuccess)
+        return elector_fail(c, ELECTOR_E_HIP, "merge scan");
+      mw.cnt = cnt_ex;
+      hipLaunchKernelGGL(k_merge_pieces, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, mw);
+      hipLaunchKernelGGL(k_merge_copy, dim3(wblocks), dim3(kStatsThreads), 0, st, mw);
+    }
     timed_end(c, st);
     HIPCHK(c, hipGetLastError());
     const int rc2 = enqueue_stats(c, s, pool_first_size(total));
