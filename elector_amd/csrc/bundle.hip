@@ -25,6 +25,7 @@
 // node index wins among equal path scores); the windows are what is parallel.
 // Latency / L2 bound; integer only except the one float comparison of :96.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cstring>
 #include <vector>
@@ -49,9 +50,18 @@ struct BundleArgs {
   int32_t *status;
   const DevTables *tab;
   float min_fraction;
-  uint4 *node;                // node space: 16-byte records
-  int32_t *score;             // node space
-  uint16_t *path;             // node space: best right link
+  // Scratch of the search, private to a window: node records, path scores, best right links.  Round 4: laid out per
+  // BLOCK of 64 windows with the lane as the fastest index -- record k of the block's lane l at (base + k * 64 + l) --
+  // so that the lanes of a wavefront, which walk their windows' nodes in step, touch one or two kilobyte rows per
+  // instruction instead of 64 lines in 64 different windows' regions.  The blocks take the windows in the order of the
+  // class lists (similar sizes side by side); a block's room is 64 x its largest window's node bound.
+  const uint32_t *order_a;    // window of (block, lane): the fused classes' lists ...
+  const uint32_t *order_b;    // ... then the generic list
+  int64_t n_a;
+  const int64_t *blk_base;    // per block: first record slot
+  uint4 *node;                // 16-byte records
+  int32_t *score;
+  uint16_t *path;             // best right link
   uint8_t *cons;              // out: window w, bundle k: ncol bytes at cons + 3*off[3w] + k*ncol
   int32_t *info;              // out: 8 per window: nbundle, count[3], bundle id of ref/cor/unc, ncol
 };
@@ -82,25 +92,51 @@ __device__ __forceinline__ void store_node(uint4 *p, const NodeRec &r)
   *p = v;
 }
 
+__device__ __forceinline__ int64_t bundle_window(const BundleArgs &a, int64_t idx)
+{
+  if (idx >= a.n) return -1;
+  return idx < a.n_a ? (int64_t)a.order_a[idx] : (int64_t)a.order_b[idx - a.n_a];
+}
+
+// room of every block: 64 x the largest node bound (Lr + Lc + Lu + 1) among its windows; blk[b] holds it, a scan turns
+// the array into the blocks' first slots
+__global__ void __launch_bounds__(64) k_bundle_plan(BundleArgs a, int64_t *blk, int64_t nblocks)
+{
+  const int64_t w = bundle_window(a, (int64_t)blockIdx.x * 64 + threadIdx.x);
+  int bound = 0;
+  if (w >= 0 && a.status[w] == 0) {
+    const int64_t tot = a.off[3 * w + 3] - a.off[3 * w];
+    if (tot < 65535) bound = (int)tot + 1;
+  }
+  for (int d = 1; d < 64; d <<= 1) bound = max(bound, __shfl_xor(bound, d));
+  if (threadIdx.x == 0) { blk[blockIdx.x] = 64 * (int64_t)bound; if (blockIdx.x == 0) blk[nblocks] = 0; }
+}
+
 __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
 {
-  const int64_t w = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (w >= a.n) return;
-  int32_t *info = a.info + 8 * w;
-  for (int k = 0; k < 8; ++k) info[k] = k >= 4 && k <= 6 ? -1 : 0;
-  if (a.status[w]) return;
-  const int64_t o0 = a.off[3 * w], o1 = a.off[3 * w + 1], o2 = a.off[3 * w + 2], o3 = a.off[3 * w + 3];
-  if (o3 - o0 >= 65535) return;             // node records hold 16-bit node ids: no bundles for such windows
-  const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1), Lu = (int)(o3 - o2), n1 = a.n1[w];
-  const int64_t nb = o0 + w;
+  const int lane = threadIdx.x;
+  const int64_t w = bundle_window(a, (int64_t)blockIdx.x * 64 + lane);
+  bool act = w >= 0;
+  int32_t *info = a.info + 8 * (act ? w : 0);
+  if (act) {
+    for (int k = 0; k < 8; ++k) info[k] = k >= 4 && k <= 6 ? -1 : 0;
+    if (a.status[w]) act = false;
+  }
+  const int64_t o0 = act ? a.off[3 * w] : 0, o1 = act ? a.off[3 * w + 1] : 0, o2 = act ? a.off[3 * w + 2] : 0, o3 = act ? a.off[3 * w + 3] : 0;
+  if (o3 - o0 >= 65535) act = false;        // node records hold 16-bit node ids: no bundles for such windows
+  const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1), Lu = (int)(o3 - o2), n1 = act ? a.n1[w] : 0;
+  const int64_t nb = o0 + (act ? w : 0);
   const int2 *xinfo = a.xinfo + nb;
   const uint16_t *ring1 = a.ring1 + nb;
   const uint32_t *x2y = a.map16 + nb;
   const uint8_t *ys = a.sym + o2;
-  uint4 *node = a.node + nb;
+  // this lane's column of the block's scratch: record k at [k * 64]
+  const int64_t base = a.blk_base[blockIdx.x] + lane;
+  uint4 *node = a.node + base;
   uint16_t *nodeh = reinterpret_cast<uint16_t *>(node);
-  int32_t *score = a.score + nb;
-  uint16_t *path = a.path + nb;
+  int32_t *score = a.score + base;
+  uint16_t *path = a.path + base;
+  constexpr int ST = 64;                     // stride between a lane's consecutive records
 
   // ---- the graph after fusion #2 (lpo.c:431-459 node order), as node records ----
   int n = 0, col = 0, prev_ring = 0, posr = 0, posc = 0;
@@ -113,11 +149,11 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
     rec.pos[2] = upos >= 0 ? (uint16_t)upos : (uint16_t)kNone16;
     rec.nxt[0] = rec.nxt[1] = rec.nxt[2] = (uint16_t)kNone16;
     rec.col = (uint16_t)col; rec.letter = (uint8_t)letter; rec.cons = 0;
-    store_node(node + n, rec);
+    store_node(node + (int64_t)n * ST, rec);
     // the previous letter of each source now knows its right neighbour
-    if (r) { if (last[0] >= 0) nodeh[8 * last[0] + 3] = (uint16_t)n; last[0] = n; ++posr; }
-    if (c) { if (last[1] >= 0) nodeh[8 * last[1] + 4] = (uint16_t)n; last[1] = n; ++posc; }
-    if (upos >= 0) { if (last[2] >= 0) nodeh[8 * last[2] + 5] = (uint16_t)n; last[2] = n; }
+    if (r) { if (last[0] >= 0) nodeh[8 * ((int64_t)last[0] * ST) + 3] = (uint16_t)n; last[0] = n; ++posr; }
+    if (c) { if (last[1] >= 0) nodeh[8 * ((int64_t)last[1] * ST) + 4] = (uint16_t)n; last[1] = n; ++posc; }
+    if (upos >= 0) { if (last[2] >= 0) nodeh[8 * ((int64_t)last[2] * ST) + 5] = (uint16_t)n; last[2] = n; }
     ++n;
   };
   int iy = 0, blk_old = -1, blk_new = -1;
@@ -145,28 +181,37 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
     if (blk_new < 0) blk_new = n;
     add(blk_new, letter, (fl & kFlagHasRef) != 0, (fl & kFlagHasCor) != 0, fused_pos);
   }
-  while (iy < Lu) { add(n, ys[iy], false, false, iy); ++iy; }
+  if (act) while (iy < Lu) { add(n, ys[iy], false, false, iy); ++iy; }
   const int n2 = n, ncol = col + 1;
-  info[7] = ncol;
-  if (ncol != a.ncol[w] || posr != Lr || posc != Lc || n2 > Lr + Lc + Lu) { a.status[w] = 3; return; }
+  if (act) {
+    info[7] = ncol;
+    if (ncol != a.ncol[w] || posr != Lr || posc != Lc || n2 > Lr + Lc + Lu) { a.status[w] = 3; act = false; }
+  }
+  // the wavefront's lanes walk their nodes from the same index down: a lane whose window is shorter waits
+  int nmax = act ? n2 : 0;
+  for (int d = 1; d < 64; d <<= 1) nmax = max(nmax, __shfl_xor(nmax, d));
 
   // ---- generate_lpo_bundles (heaviest_bundle.c:144-172) ----
   int wt[3] = {1, 1, 1}, bid[3] = {-1, -1, -1};
   const int slen[3] = {Lr, Lc, Lu};
   int nbundled = 0, nseq = 3, ib = 0;
   uint8_t *cons = a.cons + 3 * o0;
-  while (nbundled < nseq && ib < kMaxBundles) {
+  bool go = act;
+  for (int pass = 0; pass < kMaxBundles; ++pass) {
+    go = go && nbundled < nseq && ib < kMaxBundles;
+    if (__ballot(go) == 0) break;
     // heaviest_bundle (:16-78): right-to-left over the nodes
     int best = kNeg, ibest = -1;
-    for (int i = n2 - 1; i >= 0; --i) {
-      const NodeRec me = load_node(node + i);
+    for (int i = nmax - 1; i >= 0; --i) {
+      if (!go || i >= n2) continue;
+      const NodeRec me = load_node(node + (int64_t)i * ST);
       int right_score = 0, right_overlap = 0, best_right = -1;
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int rn = me.nxt[s];
         if (rn == (int)kNone16) continue;
         if ((s >= 1 && rn == me.nxt[0]) || (s == 2 && rn == me.nxt[1])) continue;   // add_lpo_link keeps one copy
-        const NodeRec rt = load_node(node + rn);
+        const NodeRec rt = load_node(node + (int64_t)rn * ST);
         int ov = 0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -177,47 +222,53 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
           const int cp = me.pos[q] != (uint16_t)kNone16 ? me.pos[q] + 1 : 0;
           if (cp == (int)rt.pos[q]) ov += wt[q];
         }
-        const int sr = score[rn];
+        const int sr = score[(int64_t)rn * ST];
         if (ov > right_overlap || (ov == right_overlap && sr > right_score)) {
           right_overlap = ov; right_score = sr; best_right = rn;
         }
       }
-      path[i] = (uint16_t)(best_right < 0 ? (int)kNone16 : best_right);
+      path[(int64_t)i * ST] = (uint16_t)(best_right < 0 ? (int)kNone16 : best_right);
       const int sc = right_score + right_overlap;
-      score[i] = sc;
+      score[(int64_t)i * ST] = sc;
       if (sc > best) { best = sc; ibest = i; }
     }
-    // the path, its length, how many letters of each source lie on it
-    int plen = 0, cnt[3] = {0, 0, 0};
-    for (int i = ibest; i >= 0;) {
-      const NodeRec me = load_node(node + i);
-      ++plen;
+    if (go) {
+      // the path, its length, how many letters of each source lie on it
+      int plen = 0, cnt[3] = {0, 0, 0};
+      for (int i = ibest; i >= 0;) {
+        const NodeRec me = load_node(node + (int64_t)i * ST);
+        ++plen;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) cnt[q] += me.pos[q] != (uint16_t)kNone16;
-      const int nx = path[i];
-      i = nx == (int)kNone16 ? -1 : nx;
-    }
-    if (plen < 10) break;                                                   // :152
-    int count = 0;
+        for (int q = 0; q < 3; ++q) cnt[q] += me.pos[q] != (uint16_t)kNone16;
+        const int nx = path[(int64_t)i * ST];
+        i = nx == (int)kNone16 ? -1 : nx;
+      }
+      if (plen < 10) go = false;                                              // :152
+      else {
+        int count = 0;
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (bid[q] < 0 && (float)slen[q] * a.min_fraction <= (float)cnt[q]) { bid[q] = ib; wt[q] = 0; ++count; }   // :95-100
-    // add_path_sequence: the consensus row of this bundle
-    uint8_t *row = cons + (int64_t)ib * ncol;
-    for (int c = 0; c < ncol; ++c) row[c] = '.';
-    for (int i = ibest; i >= 0;) {
-      const NodeRec me = load_node(node + i);
-      row[me.col] = a.tab->chr[me.letter & 31];
-      const int nx = path[i];
-      i = nx == (int)kNone16 ? -1 : nx;
+        for (int q = 0; q < 3; ++q)
+          if (bid[q] < 0 && (float)slen[q] * a.min_fraction <= (float)cnt[q]) { bid[q] = ib; wt[q] = 0; ++count; }   // :95-100
+        // add_path_sequence: the consensus row of this bundle
+        uint8_t *row = cons + (int64_t)ib * ncol;
+        for (int c = 0; c < ncol; ++c) row[c] = '.';
+        for (int i = ibest; i >= 0;) {
+          const NodeRec me = load_node(node + (int64_t)i * ST);
+          row[me.col] = a.tab->chr[me.letter & 31];
+          const int nx = path[(int64_t)i * ST];
+          i = nx == (int)kNone16 ? -1 : nx;
+        }
+        info[1 + ib] = count;
+        ++ib; ++nseq;
+        nbundled += count;
+        if (count < 1) go = false;                                            // :166
+      }
     }
-    info[1 + ib] = count;
-    ++ib; ++nseq;
-    nbundled += count;
-    if (count < 1) break;                                                   // :166
   }
-  info[0] = ib;
-  info[4] = bid[0]; info[5] = bid[1]; info[6] = bid[2];
+  if (act) {
+    info[0] = ib;
+    info[4] = bid[0]; info[5] = bid[1]; info[6] = bid[2];
+  }
 }
 
 // consensus rows of all windows, packed: window w's nbundle[w] rows at out + cons_off[w]
@@ -251,9 +302,7 @@ static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
   if (!c->keep_graph || !c->graph_valid || n != c->last_n)
     return elector_fail(c, ELECTOR_E_INVAL, "no graph kept: call elector_ctx_keep_graph(ctx, 1) before the POA batch");
   HIPCHK(c, hipSetDevice(c->device));
-  const size_t nodes = (size_t)c->last_total + (size_t)n + 8;
-  int rc = c->d_bnode.ensure(nodes * 16) | c->d_bscore.ensure(nodes * 4) | c->d_bpath.ensure(nodes * 2) |
-           c->d_bcons.ensure((size_t)3 * c->last_total + 64) | c->d_binfo.ensure((size_t)n * 32) |
+  int rc = c->d_bcons.ensure((size_t)3 * c->last_total + 64) | c->d_binfo.ensure((size_t)n * 32) |
            c->d_rowoff.ensure((size_t)(n + 1) * 8);
   if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "bundle workspace");
   hipStream_t st = c->stream;
@@ -269,6 +318,26 @@ static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
   a.status = c->last_status;
   a.tab = c->d_tab.as<DevTables>();
   a.min_fraction = minimum_fraction;
+  // the windows in the order of the batch's class lists (d_list: the fused classes, largest windows first within a
+  // class; d_perm: the generic list), 64 per block
+  a.order_a = c->d_list.as<uint32_t>();
+  a.order_b = c->d_perm.as<uint32_t>();
+  a.n_a = n - c->last_n_generic;
+  const int64_t nblocks = (n + 63) / 64;
+  size_t tmp_bytes = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int)(nblocks + 1), st);
+  if (c->d_bplan.ensure((size_t)(nblocks + 1) * 16 + tmp_bytes + 256)) return elector_fail(c, ELECTOR_E_NOMEM, "bundle plan");
+  int64_t *blk_room = c->d_bplan.as<int64_t>(), *blk_base = blk_room + (nblocks + 1);
+  a.blk_base = blk_base;
+  a.node = nullptr; a.score = nullptr; a.path = nullptr; a.cons = nullptr; a.info = nullptr;
+  hipLaunchKernelGGL(k_bundle_plan, dim3((unsigned)nblocks), dim3(64), 0, st, a, blk_room, nblocks);
+  if (hipcub::DeviceScan::ExclusiveSum(blk_base + (nblocks + 1), tmp_bytes, blk_room, blk_base, (int)(nblocks + 1), st) != hipSuccess)
+    return elector_fail(c, ELECTOR_E_HIP, "bundle plan scan");
+  int64_t slots = 0;
+  HIPCHK(c, hipMemcpyAsync(&slots, blk_base + nblocks, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  rc = c->d_bnode.ensure((size_t)(slots + 64) * 16) | c->d_bscore.ensure((size_t)(slots + 64) * 4) | c->d_bpath.ensure((size_t)(slots + 64) * 2);
+  if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "bundle scratch");
   a.node = c->d_bnode.as<uint4>();
   a.score = c->d_bscore.as<int32_t>();
   a.path = c->d_bpath.as<uint16_t>();
