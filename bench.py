@@ -244,6 +244,7 @@ def cpu_baseline(windows, ref_bases_per_window, seconds, device_msa=None):
                                      % ("timed batch" if ns == nwin else "sample")}
         nb = float(cum[ns - 1])
         return {"value": round(nb / dt / 1e6, 4), "unit": "Mbases/s", "cores": len(cmds), "kind": "reference",
+                "cpu_share": cpu_share(),             # what the container may actually use of those (affinity mask, cgroup quota)
                 "sample": "%d windows (%d reference bases) of the step's window stream, one reference poa "
                           "process per core as elector/alignment.py's Pool does, wall %.2f s" % (ns, int(nb), dt)}, parity
     # port: single-threaded C oracle
