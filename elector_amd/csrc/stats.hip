@@ -46,6 +46,7 @@ namespace elector {
 constexpr int kThresh = 5;     // THRESH  computeStats.py:40
 constexpr int kThresh2 = 20;   // THRESH2 computeStats.py:41
 constexpr int kStatsThreads = 256;
+constexpr int kStatsThreadsMax = 1024;  // k_stats on batches of long reads: a block per read of tens of thousands of columns
 
 // --------------------------------------------------------------------- merge ---
 
@@ -425,7 +426,7 @@ __device__ void block_gap_run(const uint8_t *cor, const uint8_t *ref, int n, int
   const int tid = threadIdx.x;
   // the run's end
   int end = -1;
-  for (int base = s; end < 0; base += kStatsThreads) {
+  for (int base = s; end < 0; base += (int)blockDim.x) {
     __syncthreads();
     if (tid == 0) sh[0] = 0x7fffffff;
     __syncthreads();
@@ -439,7 +440,7 @@ __device__ void block_gap_run(const uint8_t *cor, const uint8_t *ref, int n, int
   __syncthreads();
   const int c0 = s == 0 ? 1 : entry;
   int fh = 0x7fffffff, lh = -1;
-  for (int x = s + kThresh - 1 + tid; x <= end; x += kStatsThreads) {
+  for (int x = s + kThresh - 1 + tid; x <= end; x += (int)blockDim.x) {
     int cgr;
     if (ref[x] != '.') cgr = 0;
     else {
@@ -520,7 +521,7 @@ __device__ inline int block_sum(int v, int *red)
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   int t = 0;
-  for (int k = 0; k < kStatsThreads / 64; ++k) t += red[k];
+  for (int k = 0; k < (int)blockDim.x / 64; ++k) t += red[k];
   return t;
 }
 
@@ -530,7 +531,7 @@ enum { kAccN = 18 };
 constexpr int kLdsRuns = 64;             // gap runs of a piece whose interval lists stay in LDS
 constexpr int kBitArrays = 6;
 enum { kGx = 0, kGc = 1, kGu = 2, kExc = 3, kExu = 4, kEuc = 5, kMk = kGu /* the mask takes the place of Gu */ };
-__shared__ int s_red[kStatsThreads / 64];
+__shared__ int s_red[kStatsThreadsMax / 64];
 __shared__ int s_end[4];                 // end-gap scans: left ref, left unc, right ref, right unc
 __shared__ int s_acc[kAccN];
 __shared__ int s_long[3];               // block_gap_run: end of the run, first and last hit
@@ -563,7 +564,7 @@ __device__ int count_range(int arr, int W2, int lo, int hi)
 {
   int v = 0;
   if (hi >= lo)
-    for (int j = (lo >> 6) + (int)threadIdx.x; j <= (hi >> 6); j += kStatsThreads) v += __popcll(bwr(arr, W2, j) & range_word(j, lo, hi));
+    for (int j = (lo >> 6) + (int)threadIdx.x; j <= (hi >> 6); j += (int)blockDim.x) v += __popcll(bwr(arr, W2, j) & range_word(j, lo, hi));
   return block_sum(v, s_red);
 }
 
@@ -631,7 +632,7 @@ __device__ void block_gap_run_bits(int W2, int s, int end, int entry, int *first
   __syncthreads();
   const int c0 = s == 0 ? 1 : entry;
   int fh = 0x7fffffff, lh = -1;
-  for (int x = s + kThresh - 1 + tid; x <= end; x += kStatsThreads) {
+  for (int x = s + kThresh - 1 + tid; x <= end; x += (int)blockDim.x) {
     int cgr;
     if (!bbit(kGx, W2, x)) cgr = 0;
     else {
@@ -662,7 +663,7 @@ __device__ __forceinline__ unsigned long long long_run_starts(int W2, int j, uns
   return first & ((g >> 1) | (gn << 63)) & ((g >> 2) | (gn << 62)) & ((g >> 3) | (gn << 61)) & ((g >> 4) | (gn << 60));
 }
 
-__global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
+__global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
 {
   const int64_t r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -682,7 +683,7 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
     __syncthreads();
     ucap = s_n[5];
     if (!s_uni) return;
-    for (int i = tid; i < ucap; i += kStatsThreads) s_uni[i] = 0;
+    for (int i = tid; i < ucap; i += (int)blockDim.x) s_uni[i] = 0;
   }
   uint8_t *uni = nfrag > 1 ? s_uni : nullptr;
 
@@ -713,21 +714,21 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
       if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = n - 1; s_n[4] = 0x7fffffff; s_n[6] = 0; s_lists = nullptr; }
       int gcx = 0, gcc = 0;
       constexpr int kU = 8;                                           // 24 byte loads in flight per thread
-      for (int c0 = 0; c0 < n; c0 += kU * kStatsThreads) {
+      for (int c0 = 0; c0 < n; c0 += kU * (int)blockDim.x) {
         uint8_t x[kU], c[kU], u[kU];
 #pragma unroll
         for (int k = 0; k < kU; ++k) {
-          const int i = min(c0 + k * kStatsThreads + tid, n - 1);
+          const int i = min(c0 + k * (int)blockDim.x + tid, n - 1);
           x[k] = ref[i]; c[k] = cor[i]; u[k] = unc[i];
         }
 #pragma unroll
         for (int k = 0; k < kU; ++k) {
-          const bool v = c0 + k * kStatsThreads + tid < n;
+          const bool v = c0 + k * (int)blockDim.x + tid < n;
           const unsigned long long bx = __ballot(v && x[k] == '.'), bc = __ballot(v && c[k] == '.'), bu = __ballot(v && u[k] == '.'),
                                    exc = __ballot(v && x[k] == c[k]), exu = __ballot(v && x[k] == u[k]), euc = __ballot(v && u[k] == c[k]);
           gcx += __popcll(__ballot(v && is_gc(x[k])));
           gcc += __popcll(__ballot(v && is_gc(c[k])));
-          const int j = ((c0 + k * kStatsThreads) >> 6) + wave;
+          const int j = ((c0 + k * (int)blockDim.x) >> 6) + wave;
           if (lane == 0 && j < nw) {
             bww(kGx, W2, j, bx); bww(kGc, W2, j, bc); bww(kGu, W2, j, bu);
             bww(kExc, W2, j, exc); bww(kExu, W2, j, exu); bww(kEuc, W2, j, euc);
@@ -749,7 +750,7 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
 
       // ---- findGapStretches (:104-189) ----
       int nlong = 0, nq = 0, qmin = 0x7fffffff;
-      for (int j = tid; j < nw; j += kStatsThreads) {
+      for (int j = tid; j < nw; j += (int)blockDim.x) {
         unsigned long long first;
         unsigned long long ls = long_run_starts(W2, j, &first);
         nlong += __popcll(ls);
@@ -779,9 +780,9 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
         int32_t *runs = lists, *tmp = runs + 2 * (m + 2), *mrg = tmp + 4 * (m + 2);
         dict = mrg + 4 * (m + 2);
         if (m <= kLdsRuns) {
-          for (int e = tid; e < m; e += kStatsThreads) tmp[e] = s_start[e];
+          for (int e = tid; e < m; e += (int)blockDim.x) tmp[e] = s_start[e];
         } else {
-          for (int j = tid; j < nw; j += kStatsThreads) {
+          for (int j = tid; j < nw; j += (int)blockDim.x) {
             unsigned long long first;
             unsigned long long ls = long_run_starts(W2, j, &first);
             while (ls) {
@@ -792,14 +793,14 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
           }
         }
         __syncthreads();
-        for (int e = tid; e < m; e += kStatsThreads) {
+        for (int e = tid; e < m; e += (int)blockDim.x) {
           const int v = tmp[e];
           int rank = 0;
           for (int x = 0; x < m; ++x) rank += tmp[x] < v;
           runs[rank] = v;
         }
         __syncthreads();
-        for (int e = tid; e < m; e += kStatsThreads) walk_gap_run_bits(W2, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1], &tmp[e]);
+        for (int e = tid; e < m; e += (int)blockDim.x) walk_gap_run_bits(W2, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1], &tmp[e]);
         __syncthreads();
         for (int e = 0; e < m; ++e) {                                   // long runs: all threads together
           if (mrg[2 * e] != kRunLong) continue;
@@ -852,7 +853,7 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
       int acc[kAccN];
 #pragma unroll
       for (int k = 0; k < kAccN; ++k) acc[k] = 0;
-      for (int j = tid; j < nw; j += kStatsThreads) {
+      for (int j = tid; j < nw; j += (int)blockDim.x) {
         unsigned long long M = range_word(j, lo, hi);
         for (int k = 0; k < nd; ++k) M &= ~range_word(j, dict[2 * k], dict[2 * k + 1]);
         const unsigned long long gx = bwr(kGx, W2, j), gc = bwr(kGc, W2, j), gu = bwr(kGu, W2, j),
@@ -878,7 +879,7 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
       }
       __syncthreads();
       if (tid == 0) { s_acc[15] = n - s_acc[15]; s_acc[16] = n - s_acc[16]; s_acc[17] = n - s_acc[17]; }
-      for (int i = tid; i < n; i += kStatsThreads) {
+      for (int i = tid; i < n; i += (int)blockDim.x) {
         const uint8_t mk = bbit(kMk, W2, i) ? 1 : 0;
         mask[i] = mk;
         if (nfrag > 1) uni[i] |= mk;                                          // realNotMissing (:589-591)
@@ -896,19 +897,19 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
       gl = min(s_end[0], s_end[1]); gr = min(s_end[2], s_end[3]);
       if (gl >= kThresh && gl >= kThresh2) {
         int dots = 0;
-        for (int i = tid; i < gl; i += kStatsThreads) dots += cor[i] == '.';
+        for (int i = tid; i < gl; i += (int)blockDim.x) dots += cor[i] == '.';
         ext_left = gl - block_sum(dots, s_red);
       }
       if (gr >= kThresh && gr >= kThresh2) {
         int dots = 0;
-        for (int i = n - gr + 1 + tid; i < n; i += kStatsThreads) dots += cor[i] == '.';
+        for (int i = n - gr + 1 + tid; i < n; i += (int)blockDim.x) dots += cor[i] == '.';
         ext_right = gr - block_sum(dots, s_red);
       }
 
       // ---- findGapStretches (:104-189) ----
       // pass 1: runs of >= THRESH corrected gaps, and the ends of runs that leave countGapsCor > 0
       int nlong = 0, nq = 0, qmin = 0x7fffffff;
-      for (int i = tid; i < n; i += kStatsThreads) {
+      for (int i = tid; i < n; i += (int)blockDim.x) {
         if (cor[i] != '.') continue;
         const bool first = i == 0 || cor[i - 1] != '.';
         if (first && i + kThresh - 1 < n) {
@@ -931,21 +932,21 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
         int32_t *runs = lists, *tmp = runs + 2 * (m + 2), *mrg = tmp + 4 * (m + 2);
         dict = mrg + 4 * (m + 2);
         // pass 2: the run starts, in any order, then sorted by rank
-        for (int i = tid; i < n; i += kStatsThreads) {
+        for (int i = tid; i < n; i += (int)blockDim.x) {
           if (cor[i] != '.' || !(i == 0 || cor[i - 1] != '.') || i + kThresh - 1 >= n) continue;
           bool all = true;
           for (int k = 1; k < kThresh; ++k) all = all && cor[i + k] == '.';
           if (all) tmp[atomicAdd(&s_n[0], 1)] = i;
         }
         __syncthreads();
-        for (int e = tid; e < m; e += kStatsThreads) {
+        for (int e = tid; e < m; e += (int)blockDim.x) {
           const int v = tmp[e];
           int rank = 0;
           for (int x = 0; x < m; ++x) rank += tmp[x] < v;
           runs[rank] = v;
         }
         __syncthreads();
-        for (int e = tid; e < m; e += kStatsThreads) walk_gap_run(cor, ref, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1]);
+        for (int e = tid; e < m; e += (int)blockDim.x) walk_gap_run(cor, ref, n, runs[e], &mrg[2 * e], &mrg[2 * e + 1]);
         __syncthreads();
         for (int e = 0; e < m; ++e) {                                   // long runs: all threads together
           if (mrg[2 * e] != kRunLong) continue;
@@ -975,7 +976,7 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
       for (int k = 0; k < nd; ++k) {
         const int s0 = dict[2 * k], s1 = dict[2 * k + 1];
         int dots = 0;
-        for (int i = s0 + tid; i <= s1; i += kStatsThreads) dots += ref[i] == '.';
+        for (int i = s0 + tid; i <= s1; i += (int)blockDim.x) dots += ref[i] == '.';
         missing += s1 - s0 - block_sum(dots, s_red);
       }
       missing -= gl + gr;
@@ -1001,7 +1002,7 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
       int acc[kAccN];
   #pragma unroll
       for (int k = 0; k < kAccN; ++k) acc[k] = 0;
-      for (int i = tid; i < n; i += kStatsThreads) {
+      for (int i = tid; i < n; i += (int)blockDim.x) {
         const uint8_t x = ref[i], c = cor[i], u = unc[i];
         bool mk = i >= clip_l && i <= clip_r;
         if (gl >= kThresh && i < gl) mk = false;
@@ -1024,14 +1025,14 @@ __global__ void __launch_bounds__(kStatsThreads) k_stats(StatsArgs a)
       }
       __syncthreads();
       if (nfrag > 1)
-        for (int i = tid; i < n; i += kStatsThreads) uni[i] |= mask[i];      // realNotMissing (:589-591)
+        for (int i = tid; i < n; i += (int)blockDim.x) uni[i] |= mask[i];      // realNotMissing (:589-591)
     }
     int64_t missing_last = -1;
     if (nfrag > 1) {
       if (p == p1 - 1) {                                                    // last piece (:595-599)
         __syncthreads();
         int miss = 0;
-        for (int i = tid; i < n; i += kStatsThreads) miss += (!uni[i] && ref[i] != '.');
+        for (int i = tid; i < n; i += (int)blockDim.x) miss += (!uni[i] && ref[i] != '.');
         missing_last = block_sum(miss, s_red);
       }
     }
@@ -1086,7 +1087,13 @@ int launch_stats(elector_ctx *c, StatsArgs a, int64_t max_cols, hipStream_t st)
     if (e != hipSuccess) return elector_fail(c, ELECTOR_E_HIP, "hipFuncSetAttribute(k_stats)", e);
     big_ok = true;
   }
-  hipLaunchKernelGGL(k_stats, dim3((unsigned)a.n_reads), dim3(kStatsThreads), lds, st, a);
+  // threads per read: 256 for reads of a few thousand columns; 1024 when the batch's reads run to tens of thousands
+  // (50 kb reads: 2,000 blocks of ~60 k columns each kept a CU's three resident blocks busy for 0.8 ms apiece).
+  // ELECTOR_STATS_THREADS=256|512|1024 forces one (A/B)
+  static const int forced = std::getenv("ELECTOR_STATS_THREADS") ? std::atoi(std::getenv("ELECTOR_STATS_THREADS")) : 0;
+  int threads = max_cols >= 64000 ? kStatsThreadsMax : kStatsThreads;
+  if (forced == 256 || forced == 512 || forced == 1024) threads = forced;
+  hipLaunchKernelGGL(k_stats, dim3((unsigned)a.n_reads), dim3((unsigned)threads), lds, st, a);
   return 0;
 }
 
