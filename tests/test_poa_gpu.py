@@ -120,6 +120,57 @@ def test_window_status_codes(engine):
     assert got[3] == oracle_lib.batch(np.frombuffer(bases, dtype=np.uint8), off)[0][0]
 
 
+def test_device_offsets_entry(engine):
+    """elector_poa_batch_device_offsets: windows AND offsets in HBM (status, launch class and class lists computed by
+    kernels).  Same rows as the host-offsets entry on a batch that spans every path -- k_poa, its far instance, the
+    two-kernel path, the generic kernels, empty and over-long windows -- and malformed offsets are refused, not aligned."""
+    import torch
+    from elector_amd import _capi
+    triples = (synth.window_triples(31, 3000, 5, 300) + synth.adversarial_triples(32, 300) + far_edge_triples(33, 300) +
+               [(b"ACGT", b"", b"ACGT"), (b"A" * (_capi.ELECTOR_MAX_SEQ + 1), b"ACGT", b"ACGT")] + synth.window_triples(34, 4, 1500, 2500))
+    bases, off = synth.pack_windows(triples)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    n, total = len(triples), int(off[-1])
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(np.frombuffer(bases, dtype=np.uint8).copy()).to(dev)
+    outs = []
+    for entry in ("host", "device"):
+        d_cols = torch.zeros(3 * total + 64, dtype=torch.uint8, device=dev)
+        d_ncol = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+        if entry == "host":
+            engine.align_device(d_bases, off, d_cols, d_ncol, d_status)
+        else:
+            engine.align_device_offsets(d_bases, torch.from_numpy(off).to(dev), n, total, d_cols, d_ncol, d_status)
+        engine.sync()
+        outs.append((d_cols.cpu().numpy(), d_ncol.cpu().numpy(), d_status.cpu().numpy()))
+    (c0, n0, s0), (c1, n1, s1) = outs
+    assert np.array_equal(s0, s1) and s0[-6] == _capi.W_EMPTY and s0[-5] == _capi.W_TOOLONG and not s0[:-6].any() and not s0[-4:].any()
+    ok = s0 == 0
+    assert np.array_equal(n0[ok], n1[ok])
+    for w in np.nonzero(ok)[0]:
+        a = 3 * int(off[3 * w])
+        assert np.array_equal(c0[a:a + 3 * n0[w]], c1[a:a + 3 * n0[w]]), int(w)
+    picks = [0, 17, 3100, 3400, n - 1]
+    pb, po = synth.pack_windows([triples[w] for w in picks])
+    exp_rows = oracle_lib.batch(np.frombuffer(pb, dtype=np.uint8), po)[0]
+    for k, w in enumerate(picks):
+        a, nc = 3 * int(off[3 * w]), int(n0[w])
+        blk = c1[a:a + 3 * nc].reshape(nc, 3)
+        assert tuple(bytes(blk[:, r]) for r in range(3)) == exp_rows[k], w
+    # malformed offsets: not starting at 0, decreasing, a total that is not the last offset
+    d_cols = torch.zeros(3 * total + 64, dtype=torch.uint8, device=dev)
+    d_ncol = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+    for bad, tot in ((off + 1, total + 1), (np.concatenate([off[:10], off[9:10] - 3, off[11:]]), total), (off, total + 5)):
+        with pytest.raises(_capi.ElectorError):
+            engine.align_device_offsets(d_bases, torch.from_numpy(np.ascontiguousarray(bad)).to(dev), n, int(tot), d_cols, d_ncol, d_status)
+    # ... and the engine is usable afterwards
+    engine.align_device_offsets(d_bases, torch.from_numpy(off).to(dev), n, total, d_cols, d_ncol, d_status)
+    engine.sync()
+    assert np.array_equal(d_ncol.cpu().numpy()[ok], n0[ok])
+
+
 def test_empty_batch(engine):
     assert engine.align([]) == []
 
