@@ -820,6 +820,7 @@ def main():
     t_oth = eng.timing_read(2)[0]
     t_st = eng.timing_read(3)[0]
     t_poa, k_poa = eng.timing_read(4)
+    t_far = eng.timing_read(6)[0]
 
     # per step (averaged over the rotation): bases, windows, DP cells
     def per_step(f):
@@ -911,6 +912,9 @@ def main():
             "gcups_computed": round(cells_comp_all * args.steps / dt_max / 1e9, 3),
             "alignment1_skipped_windows_frac": round(float(np.mean(np.concatenate([skipped[id(b)] for b in head_batches]))), 4) if head_batches else None,
             "kernel_ms_per_step": {"k_poa": round(t_poa / serial_steps, 3),
+                                   # k_poa<G, 8, true>: the windows with one far edge, one launch per lane-group size (a few
+                                   # hundred wavefronts each: as long as their longest window when alone on the chip)
+                                   "k_poa_far_instance": round(t_far / serial_steps, 3),
                                    "alignment1_stage": round(t_dp1 / serial_steps, 3),
                                    "alignment2_stage": round(t_dp2 / serial_steps, 3),
                                    "other": round(t_oth / serial_steps, 3),

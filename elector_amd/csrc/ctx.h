@@ -122,7 +122,7 @@ struct elector_ctx {
   // timing
   bool timing = false;
   std::vector<elector::TimedSpan> spans;
-  static constexpr int kTimedKinds = 6;   // alignment #1 stage, alignment #2 stage, other POA kernels, merge + statistics, k_poa, k_bundle
+  static constexpr int kTimedKinds = 7;   // alignment #1 stage, alignment #2 stage, other POA kernels, merge + statistics, k_poa, k_bundle, k_poa far instance
   double ms_acc[kTimedKinds] = {};
   int64_t launches_acc[kTimedKinds] = {};
   int64_t last_n = 0;          // windows of the last POA batch (their offsets stay in d_off)

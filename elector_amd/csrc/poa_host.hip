@@ -1161,7 +1161,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           pa.far = nullptr; pa.far_count = nullptr; pa.far_cap = 0;
           pa.debug = fdebug & ~(32 | 64 | 128 | 256);
           pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)hb) + 16;
-          timed_begin(c, 4, sg);
+          timed_begin(c, 6, sg);
           if (launch_poa_far(pa, hg->G, sg)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
           timed_end(c, sg);
         }

@@ -131,7 +131,8 @@ int elector_ctx_sync(elector_ctx *ctx);
  * (k_fused_b<G,R,D>; k_dp2), 2 = everything else of the POA stage (symbolize, the
  * trivial-window pass and list sort, generic leftovers, tiled long windows),
  * 3 = merge + statistics kernels (include/elector_stats.h), 4 = k_poa (the whole window in one kernel,
- * poa_pack.hip: when it is in use, kinds 0 and 1 only see the windows it handed back), 5 = k_bundle (a12).
+ * poa_pack.hip: when it is in use, kinds 0 and 1 only see the windows it handed back; its far-edge instance,
+ * four launches of a few hundred wavefronts per batch, is kind 6), 5 = k_bundle (a12).
  * The geometry classes run on two concurrent launch chains: the sums overlap in wall time. */
 int elector_ctx_timing_enable(elector_ctx *ctx, int on);
 int elector_ctx_timing_read(elector_ctx *ctx, int kernel, double *ms, int64_t *launches);
