@@ -1378,8 +1378,10 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
       if (s.outoff.ensure((size_t)(n_pieces + 1) * 8)) return elector_fail(c, ELECTOR_E_NOMEM, "row offsets");
       uint8_t *dst = rows_dev;
       if (rows_is_host) {
+        static const bool uncached = std::getenv("ELECTOR_ROWS_UNCACHED") != nullptr;
         for (int k = 0; k < elector_ctx::kStatsSlots; ++k)
-          if (c->st_slot[k].dense.ensure((size_t)3 * total + 64)) return elector_fail(c, ELECTOR_E_NOMEM, "packed rows");
+          if (uncached ? c->st_slot[k].dense.ensure_uncached((size_t)3 * total + 64) : c->st_slot[k].dense.ensure((size_t)3 * total + 64))
+            return elector_fail(c, ELECTOR_E_NOMEM, "packed rows");
         dst = s.dense.as<uint8_t>();
         if (!s.rows_done) HIPCHK(c, hipEventCreateWithFlags(&s.rows_done, hipEventDisableTiming));
         if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));

@@ -9,4 +9,4 @@ j=json.load(open('$O/$tag.json'))
 k=j['kernel_ms_per_step']
 print('$tag', 'value', j['value'], 'hbm', j['value_rows_in_hbm'], 'ms/step', j['ms_per_step'], 'pcie', j['rows_to_host']['pcie_gbs_per_gpu'], 'host', k['host_classify_and_enqueue'], 'wait', k['host_wait_for_results'])"
 }
-run full A=1 && run nocopy ELECTOR_ROWS_COPY_BYTES=4 && run half ELECTOR_ROWS_COPY_BYTES=180000000 && run full_b A=1
+run full A=1 && run unc ELECTOR_ROWS_UNCACHED=1 && run full_b A=1 && run unc_b ELECTOR_ROWS_UNCACHED=1
