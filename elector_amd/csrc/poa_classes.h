@@ -83,7 +83,8 @@ __host__ __device__ inline WindowClass window_class(const KParams &kp, int64_t l
   for (int ci = c0; ci < kNC; ++ci) {
     const int G = cls_G(ci), R = cls_R(ci);
     // k_fused_b's 16-bit ring cells hold scores up to about +-16000 (it hands larger windows back)
-    if (score_span(kp, lr + lr / 16 + 6 + G, ((lu + G * R - 1) / (G * R)) * (int64_t)(G * R)) >= 16000) continue;
+    // (32-bit arithmetic: the lengths are below ELECTOR_MAX_SEQ here, and a 64-bit division costs a hundred instructions)
+    if (score_span(kp, (int)lr + (int)lr / 16 + 6 + G, (((int)lu + G * R - 1) / (G * R)) * (G * R)) >= 16000) continue;
     const int need_a = fused_a_slot_need((int)lr, (int)lc, G, R);
     const int nb = fused_b_slot_need((int)(lr + lr / 16 + 6), (int)lu, G, R);
     const int need = need_a > nb ? need_a : nb;

@@ -31,10 +31,21 @@ __global__ void __launch_bounds__(256) k_classify(ClassifyArgs a)
   unsigned long long left = 0;
   int gen = 0, po = 0, bad = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0 && (a.off[0] != 0 || a.off[3 * a.n] != a.total)) bad = 1;
-  for (int k = threadIdx.x; k < kClsChunk; k += 256) {
-    const int64_t w = w0 + k;
+  // the thread's eight windows: their offsets are all asked for before any is looked at (the loop below was eight
+  // dependent trips to memory otherwise)
+  constexpr int PER = kClsChunk / 256;
+  int64_t o[PER][4];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int64_t w = min(w0 + threadIdx.x + 256 * j, a.n - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[j][q] = a.off[3 * w + q];
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int64_t w = w0 + threadIdx.x + 256 * j;
     if (w >= a.n) break;
-    const int64_t o0 = a.off[3 * w], o1 = a.off[3 * w + 1], o2 = a.off[3 * w + 2], o3 = a.off[3 * w + 3];
+    const int64_t o0 = o[j][0], o1 = o[j][1], o2 = o[j][2], o3 = o[j][3];
     const int64_t lr = o1 - o0, lc = o2 - o1, lu = o3 - o2;
     if (lr < 0 || lc < 0 || lu < 0) { bad = 1; a.status[w] = ELECTOR_W_TOOLONG; a.bin[w] = -1; a.wkey[w] = 0; continue; }
     const int st = window_status(lr, lc, lu, a.pen_abs_max, ELECTOR_MAX_SEQ, a.window_moves_max);
