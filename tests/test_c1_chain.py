@@ -156,3 +156,19 @@ def test_two_ranks_reproduce_the_reference_chain(tmp_path):
     check_msa(d + "/msa.fa")
     assert not [f for f in os.listdir(d) if ".part" in f]
     check_report(two["tuple"], two["stdout"], two["log"], d)
+
+
+@pytest.mark.gpu
+def test_two_ranks_without_the_msa_file(tmp_path, monkeypatch):
+    """ELECTOR_NO_MSA=1 under a process group: no msa.fa and no part files, the same report on rank 0"""
+    import torch.multiprocessing as mp
+    from portutil import free_port
+    d = str(tmp_path)
+    write_reads(d, c1_reads())
+    res = d + "/two.json"
+    monkeypatch.setenv("ELECTOR_NO_MSA", "1")
+    mp.spawn(_rank, args=(2, free_port(), d, res), nprocs=2, join=True)
+    two = json.load(open(res))
+    assert (two["small"], two["wrong"]) == (GOLD["small"], GOLD["wrong"]) and two["hit"]
+    assert not os.path.exists(d + "/msa.fa") and not [f for f in os.listdir(d) if ".part" in f]
+    check_report(two["tuple"], two["stdout"], two["log"], d)
