@@ -50,6 +50,7 @@ struct BundleArgs {
   int32_t *status;
   const DevTables *tab;
   float min_fraction;
+  int debug;                  // measurement: 1 = stop behind the graph's records, 2 = behind the first pass's dynamic program
   // Scratch of the search, private to a window: node records, path scores, best right links.  Round 4: laid out per
   // BLOCK of 64 windows with the lane as the fastest index -- record k of the block's lane l at (base + k * 64 + l) --
   // so that the lanes of a wavefront, which walk their windows' nodes in step, touch one or two kilobyte rows per
@@ -62,6 +63,11 @@ struct BundleArgs {
   uint4 *node;                // 16-byte records
   int32_t *score;
   uint16_t *path;             // best right link
+  // the search's inputs in the same per-block layout (k_bundle_inputs): letter | flags of node k of the graph after
+  // fusion #1, its ring id and x -> y entry, the uncorrected symbols
+  uint32_t *in_xy, *in_map;
+  uint16_t *in_ring;
+  uint8_t *in_ys;
   uint8_t *cons;              // out: window w, bundle k: ncol bytes at cons + 3*off[3w] + k*ncol
   int32_t *info;              // out: 8 per window: nbundle, count[3], bundle id of ref/cor/unc, ncol
 };
@@ -98,7 +104,7 @@ __device__ __forceinline__ int64_t bundle_window(const BundleArgs &a, int64_t id
   return idx < a.n_a ? (int64_t)a.order_a[idx] : (int64_t)a.order_b[idx - a.n_a];
 }
 
-// room of every block: 64 x the largest node bound (Lr + Lc + Lu + 1) among its windows; blk[b] holds it, a scan turns
+// room of every block: 64 x the largest node bound (|PO| after fusion #1 + Lu + 1) among its windows; blk[b] holds it, a scan turns
 // the array into the blocks' first slots
 __global__ void __launch_bounds__(64) k_bundle_plan(BundleArgs a, int64_t *blk, int64_t nblocks)
 {
@@ -106,10 +112,57 @@ __global__ void __launch_bounds__(64) k_bundle_plan(BundleArgs a, int64_t *blk, 
   int bound = 0;
   if (w >= 0 && a.status[w] == 0) {
     const int64_t tot = a.off[3 * w + 3] - a.off[3 * w];
-    if (tot < 65535) bound = (int)tot + 1;
+    // nodes after fusion #2: every uncorrected letter adds one at most
+    if (tot < 65535) bound = a.n1[w] + (int)(a.off[3 * w + 3] - a.off[3 * w + 2]) + 1;
   }
   for (int d = 1; d < 64; d <<= 1) bound = max(bound, __shfl_xor(bound, d));
   if (threadIdx.x == 0) { blk[blockIdx.x] = 64 * (int64_t)bound; if (blockIdx.x == 0) blk[nblocks] = 0; }
+}
+
+// The graph the alignment kernels left in HBM lives in every window's own node space: a lane that walks its window's
+// arrays touches lines no other lane of its wavefront shares.  This kernel turns the four arrays the search reads into
+// the per-block layout, 64 x 64 tiles through LDS: rows of one window in (coalesced), rows of one index out (coalesced).
+__global__ void __launch_bounds__(64) k_bundle_inputs(BundleArgs a)
+{
+  __shared__ uint32_t t_xy[64][65], t_map[64][65];
+  __shared__ uint16_t t_ring[64][66];
+  __shared__ uint8_t t_ys[64][68];
+  __shared__ int s_n1[64], s_lu[64];
+  __shared__ int64_t s_nb[64], s_o2[64];
+  const int lane = threadIdx.x;
+  const int64_t w = bundle_window(a, (int64_t)blockIdx.x * 64 + lane);
+  int n1 = 0, lu = 0;
+  int64_t nb = 0, o2 = 0;
+  if (w >= 0 && a.status[w] == 0) {
+    const int64_t o0 = a.off[3 * w], o3 = a.off[3 * w + 3];
+    o2 = a.off[3 * w + 2];
+    if (o3 - o0 < 65535) { n1 = a.n1[w]; lu = (int)(o3 - o2); nb = o0 + w; }
+  }
+  s_n1[lane] = n1; s_lu[lane] = lu; s_nb[lane] = nb; s_o2[lane] = o2;
+  int nmax = max(n1, lu);
+  for (int d = 1; d < 64; d <<= 1) nmax = max(nmax, __shfl_xor(nmax, d));
+  const int64_t base = a.blk_base[blockIdx.x];
+  __syncthreads();
+  for (int k0 = 0; k0 < nmax; k0 += 64) {
+    for (int wl = 0; wl < 64; ++wl) {                       // element k0 + lane of window wl
+      const int k = k0 + lane;
+      if (k < s_n1[wl]) {
+        const int64_t at = s_nb[wl] + k;
+        t_xy[wl][lane] = (uint32_t)a.xinfo[at + 1].y;
+        t_map[wl][lane] = a.map16[at];
+        t_ring[wl][lane] = a.ring1[at];
+      }
+      if (k < s_lu[wl]) t_ys[wl][lane] = a.sym[s_o2[wl] + k];
+    }
+    __syncthreads();
+    for (int kk = 0; kk < 64 && k0 + kk < nmax; ++kk) {      // index k0 + kk of window `lane`
+      const int k = k0 + kk;
+      const int64_t at = base + (int64_t)k * 64 + lane;
+      if (k < n1) { a.in_xy[at] = t_xy[lane][kk]; a.in_map[at] = t_map[lane][kk]; a.in_ring[at] = t_ring[lane][kk]; }
+      if (k < lu) a.in_ys[at] = t_ys[lane][kk];
+    }
+    __syncthreads();
+  }
 }
 
 __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
@@ -125,13 +178,14 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
   const int64_t o0 = act ? a.off[3 * w] : 0, o1 = act ? a.off[3 * w + 1] : 0, o2 = act ? a.off[3 * w + 2] : 0, o3 = act ? a.off[3 * w + 3] : 0;
   if (o3 - o0 >= 65535) act = false;        // node records hold 16-bit node ids: no bundles for such windows
   const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1), Lu = (int)(o3 - o2), n1 = act ? a.n1[w] : 0;
-  const int64_t nb = o0 + (act ? w : 0);
-  const int2 *xinfo = a.xinfo + nb;
-  const uint16_t *ring1 = a.ring1 + nb;
-  const uint32_t *x2y = a.map16 + nb;
-  const uint8_t *ys = a.sym + o2;
-  // this lane's column of the block's scratch: record k at [k * 64]
+  // this lane's column of the block's scratch and inputs: entry k at [k * 64]
   const int64_t base = a.blk_base[blockIdx.x] + lane;
+  const uint32_t *in_xy = a.in_xy + base, *in_map = a.in_map + base;
+  const uint16_t *in_ring = a.in_ring + base;
+  const uint8_t *in_ys = a.in_ys + base;
+  auto ring1 = [&](int k) { return (int)in_ring[(int64_t)k * 64]; };
+  auto x2y = [&](int k) { return in_map[(int64_t)k * 64]; };
+  auto ys = [&](int i) { return (int)in_ys[(int64_t)i * 64]; };
   uint4 *node = a.node + base;
   uint16_t *nodeh = reinterpret_cast<uint16_t *>(node);
   int32_t *score = a.score + base;
@@ -158,35 +212,36 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
   };
   int iy = 0, blk_old = -1, blk_new = -1;
   for (int ix = 0; ix < n1; ++ix) {
-    const int r0 = ring1[ix];
+    const int r0 = ring1(ix);
     if (r0 != blk_old) { blk_old = r0; blk_new = -1; }
-    for (int k = ix; k < n1 && ring1[k] == r0; ++k) {
-      const int ay = (int)x2y[k];
+    for (int k = ix; k < n1 && ring1(k) == r0; ++k) {
+      const int ay = (int)x2y(k);
       if (ay != (int)kNone32) {
-        while (iy < ay && iy < Lu) { add(n, ys[iy], false, false, iy); ++iy; }
+        while (iy < ay && iy < Lu) { add(n, ys(iy), false, false, iy); ++iy; }
         break;
       }
     }
-    const int xi = xinfo[ix + 1].y;
+    const int xi = (int)in_xy[(int64_t)ix * 64];
     const int letter = xi & 0xFF, fl = xi >> 8;
     int fused_pos = -1;
-    if (x2y[ix] != kNone32 && iy < Lu) {
-      if (letter == ys[iy]) fused_pos = iy;
+    if (x2y(ix) != kNone32 && iy < Lu) {
+      if (letter == ys(iy)) fused_pos = iy;
       else {
         if (blk_new < 0) blk_new = n;
-        add(blk_new, ys[iy], false, false, iy);
+        add(blk_new, ys(iy), false, false, iy);
       }
       ++iy;
     }
     if (blk_new < 0) blk_new = n;
     add(blk_new, letter, (fl & kFlagHasRef) != 0, (fl & kFlagHasCor) != 0, fused_pos);
   }
-  if (act) while (iy < Lu) { add(n, ys[iy], false, false, iy); ++iy; }
+  if (act) while (iy < Lu) { add(n, ys(iy), false, false, iy); ++iy; }
   const int n2 = n, ncol = col + 1;
   if (act) {
     info[7] = ncol;
     if (ncol != a.ncol[w] || posr != Lr || posc != Lc || n2 > Lr + Lc + Lu) { a.status[w] = 3; act = false; }
   }
+  if (a.debug == 1) return;
   // the wavefront's lanes walk their nodes from the same index down: a lane whose window is shorter waits
   int nmax = act ? n2 : 0;
   for (int d = 1; d < 64; d <<= 1) nmax = max(nmax, __shfl_xor(nmax, d));
@@ -232,6 +287,7 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
       score[(int64_t)i * ST] = sc;
       if (sc > best) { best = sc; ibest = i; }
     }
+    if (a.debug == 2) { if (act && best == -12345) info[0] = ibest; return; }
     if (go) {
       // the path, its length, how many letters of each source lie on it
       int plen = 0, cnt[3] = {0, 0, 0};
@@ -251,7 +307,13 @@ __global__ void __launch_bounds__(64) k_bundle(BundleArgs a)
           if (bid[q] < 0 && (float)slen[q] * a.min_fraction <= (float)cnt[q]) { bid[q] = ib; wt[q] = 0; ++count; }   // :95-100
         // add_path_sequence: the consensus row of this bundle
         uint8_t *row = cons + (int64_t)ib * ncol;
-        for (int c = 0; c < ncol; ++c) row[c] = '.';
+        {                                                                     // '.' everywhere: dwords where aligned
+          uint8_t *p = row;
+          int left = ncol;
+          while (left > 0 && (reinterpret_cast<uintptr_t>(p) & 3u)) { *p++ = '.'; --left; }
+          for (; left >= 4; left -= 4, p += 4) *reinterpret_cast<uint32_t *>(p) = 0x2E2E2E2Eu;
+          while (left-- > 0) *p++ = '.';
+        }
         for (int i = ibest; i >= 0;) {
           const NodeRec me = load_node(node + (int64_t)i * ST);
           row[me.col] = a.tab->chr[me.letter & 31];
@@ -318,6 +380,7 @@ static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
   a.status = c->last_status;
   a.tab = c->d_tab.as<DevTables>();
   a.min_fraction = minimum_fraction;
+  a.debug = std::getenv("ELECTOR_DEBUG_BUNDLE") ? std::atoi(std::getenv("ELECTOR_DEBUG_BUNDLE")) : 0;
   // the windows in the order of the batch's class lists (d_list: the fused classes, largest windows first within a
   // class; d_perm: the generic list), 64 per block
   a.order_a = c->d_list.as<uint32_t>();
@@ -336,14 +399,20 @@ static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
   int64_t slots = 0;
   HIPCHK(c, hipMemcpyAsync(&slots, blk_base + nblocks, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
-  rc = c->d_bnode.ensure((size_t)(slots + 64) * 16) | c->d_bscore.ensure((size_t)(slots + 64) * 4) | c->d_bpath.ensure((size_t)(slots + 64) * 2);
+  rc = c->d_bnode.ensure((size_t)(slots + 64) * 16) | c->d_bscore.ensure((size_t)(slots + 64) * 4) | c->d_bpath.ensure((size_t)(slots + 64) * 2) |
+       c->d_bin.ensure((size_t)(slots + 64) * 11 + 64);
   if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "bundle scratch");
+  a.in_xy = c->d_bin.as<uint32_t>();
+  a.in_map = a.in_xy + (slots + 64);
+  a.in_ring = reinterpret_cast<uint16_t *>(a.in_map + (slots + 64));
+  a.in_ys = reinterpret_cast<uint8_t *>(a.in_ring + (slots + 64));
   a.node = c->d_bnode.as<uint4>();
   a.score = c->d_bscore.as<int32_t>();
   a.path = c->d_bpath.as<uint16_t>();
   a.cons = c->d_bcons.as<uint8_t>();
   a.info = c->d_binfo.as<int32_t>();
   timed_begin(c, 5, st);
+  hipLaunchKernelGGL(k_bundle_inputs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
   hipLaunchKernelGGL(k_bundle, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, a);
   timed_end(c, st);
   HIPCHK(c, hipGetLastError());
