@@ -716,6 +716,17 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     // ELECTOR_POA_SLOT_PCT (experiment): the slot inflated to that many percent -- what the occupancy is worth
     static const int slot_pct = std::getenv("ELECTOR_POA_SLOT_PCT") ? std::max(100, std::atoi(std::getenv("ELECTOR_POA_SLOT_PCT"))) : 100;
     pg.slot = (int)std::min<int64_t>(max_slot, ((bin_need_pack[b] * slot_pct / 100) + 15) & ~(int64_t)15);
+    // LDS banks: the lane groups of a wavefront read the same index of their windows' arrays in one instruction, group q
+    // at q x (2 slots).  A half-wavefront is four groups of 8 lanes (two of 16): their 8 (16) consecutive dwords fall on
+    // 32 different banks when two slots are 8 (16) dwords off a multiple of 32 -- slot = 16 mod 32 bytes (32 mod 64).
+    // With slots of any multiple of 16 bytes half of the launches had 2- to 8-way conflicts on every such read
+    // (SQ_LDS_BANK_CONFLICT above SQ_INSTS_LDS in rounds 2-3).  ELECTOR_POA_SLOT_BANKS=0: as before (A/B)
+    static const bool banks = !(std::getenv("ELECTOR_POA_SLOT_BANKS") && std::atoi(std::getenv("ELECTOR_POA_SLOT_BANKS")) == 0);
+    if (banks && (G == 8 || G == 16)) {
+      const int mod = G == 8 ? 32 : 64, want = mod / 2;
+      int sl = pg.slot + ((want - pg.slot % mod) + mod) % mod;
+      if (sl <= max_slot) pg.slot = sl;
+    }
     pg.tw = (int)bin_max_po[b] + 8 + G + 4;
     const int lds_block = 64 + nw * pg.slot;
     const int waves_cu = std::max(1, std::min(32, (160 * 1024) / lds_block));
