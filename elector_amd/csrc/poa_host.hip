@@ -719,9 +719,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     // LDS banks: the lane groups of a wavefront read the same index of their windows' arrays in one instruction, group q
     // at q x (2 slots).  A half-wavefront is four groups of 8 lanes (two of 16): their 8 (16) consecutive dwords fall on
     // 32 different banks when two slots are 8 (16) dwords off a multiple of 32 -- slot = 16 mod 32 bytes (32 mod 64).
-    // With slots of any multiple of 16 bytes half of the launches had 2- to 8-way conflicts on every such read
-    // (SQ_LDS_BANK_CONFLICT above SQ_INSTS_LDS in rounds 2-3).  ELECTOR_POA_SLOT_BANKS=0: as before (A/B)
-    static const bool banks = !(std::getenv("ELECTOR_POA_SLOT_BANKS") && std::atoi(std::getenv("ELECTOR_POA_SLOT_BANKS")) == 0);
+    // With slots of any multiple of 16 bytes half of the launches have 2- to 8-way conflicts on every such read
+    // (SQ_LDS_BANK_CONFLICT above SQ_INSTS_LDS).  Measured (ELECTOR_POA_SLOT_BANKS=1): conflict cycles -36 %, but the
+    // wavefronts never wait for the LDS pipeline (SQ_WAIT_INST_LDS 0.13 % of their cycles) and the 16-48 bytes a slot
+    // grows by cost more occupancy than the conflicts cost time: k_poa +2 % on the yeast -split batch.  Off by default.
+    static const bool banks = std::getenv("ELECTOR_POA_SLOT_BANKS") && std::atoi(std::getenv("ELECTOR_POA_SLOT_BANKS")) != 0;
     if (banks && (G == 8 || G == 16)) {
       const int mod = G == 8 ? 32 : 64, want = mod / 2;
       int sl = pg.slot + ((want - pg.slot % mod) + mod) % mod;
