@@ -184,20 +184,26 @@ def main(args=None):
             prof.disable()
             pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(18)
         stages = {k: round(v, 3) for k, v in alignment.STAGE_SECONDS.items()}
-        if alignment.STAGE_TRACE is not None:
-            # a text Gantt chart of getPOA: one row per thread, one column per 10 ms
-            tr = [x for x in alignment.STAGE_TRACE if x[2] >= t0]
+
+        def gantt(t_from, t_to, title):
+            """a text Gantt chart of getPOA: one row per thread, one column per 10 ms"""
+            if alignment.STAGE_TRACE is None:
+                return
+            tr = [x for x in alignment.STAGE_TRACE if t_from <= x[2] < t_to]
             names = sorted({x[1] for x in tr})
-            width = int((t1 - t0) / 0.01) + 1
+            width = int((t_to - t_from) / 0.01) + 1
+            sys.stderr.write(title + "\n")
             for nm in names:
                 row = [" "] * width
                 for stage, th_, a_, b_ in tr:
                     if th_ != nm:
                         continue
                     ch = stage[0].upper() if not stage.startswith("wait") else "."
-                    for c in range(int((a_ - t0) / 0.01), min(width, int((b_ - t0) / 0.01) + 1)):
+                    for c in range(int((a_ - t_from) / 0.01), min(width, int((b_ - t_from) / 0.01) + 1)):
                         row[c] = ch
                 sys.stderr.write("%-12s|%s|\n" % (nm[:12], "".join(row)))
+
+        gantt(t0, t1, "getPOA with msa.fa")
         # the same report from the text file (what call site #2 cost before the counters were handed over); left out
         # on long runs (the text of twenty batches is 5 GB)
         # ... and the run again without msa.fa (getPOA(write_msa=False), SURVEY.md 8(f2)): same report from the device
@@ -212,6 +218,7 @@ def main(args=None):
             with redirect_stdout(buf):
                 small2, wrong2 = alignment.getPOA(paths[1], paths[0], paths[2], a.threads, outdir2, 0.1, write_msa=False)
             tn1 = time.perf_counter()
+            gantt(tn0, tn1, "getPOA(write_msa=False)")
             with redirect_stdout(buf):
                 tupn = computeStats.outputRecallPrecision(paths[1], outdir2, io.StringIO(), small2, wrong2, 5, 0.1, "sizes.txt", {})
             tn2 = time.perf_counter()

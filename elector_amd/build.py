@@ -13,6 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_spills  # noqa: E402
 SRC = [os.path.join(HERE, "csrc", f) for f in ("poa_kernels.hip", "poa_fused.hip", "poa_pack.hip", "poa_classify.hip", "poa_host.hip",
                                                "stats.hip", "bundle.hip", "split_dev.hip", "splitter.cpp", "io_host.cpp",
                                                "report_host.cpp")]
@@ -63,9 +65,36 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
+    def compile_checked(cmd):
+        """Device code is compiled with --save-temps and its assembly scanned for VGPR spill stores that the compiler
+        put in front of the `s_or_b64 exec` closing a divergent region (tools/check_spills.py: such a store runs under
+        the region's narrowed mask and the reload reads garbage -- seen with ROCm 7.2 in k_poa).  The object is only
+        kept when the scan is clean."""
+        src, obj = cmd[-3], cmd[-1]
+        if not src.endswith(".hip"):
+            return run(cmd)
+        tmp = obj + ".tmp"
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        try:
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd[:-1] + [os.path.join(tmp, "out.o"), "--save-temps"], check=True, cwd=tmp)
+            found = []
+            for f in os.listdir(tmp):
+                if f.endswith(".s") and "amdgcn" in f:
+                    found += check_spills.check(os.path.join(tmp, f))
+            if found:
+                raise RuntimeError("%s: the compiler placed %d VGPR spill store(s) under a narrowed EXEC mask (%s); change "
+                                   "the kernel's register pressure (see tools/check_spills.py)"
+                                   % (os.path.basename(src), len(found), ", ".join(sorted({k for k, _, _ in found}))))
+            os.replace(os.path.join(tmp, "out.o"), obj)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
     if jobs:
         with ThreadPoolExecutor(max_workers=max(1, min(6, (os.cpu_count() or 2) - 1))) as pool:
-            list(pool.map(run, jobs))
+            list(pool.map(compile_checked, jobs))
     objs = [os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o") for s in SRC]
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs)
     # the `poa`-compatible executable on top of the library (elector_amd/bin/poa; finds the library through its rpath)

@@ -69,13 +69,13 @@ __host__ __device__ inline int window_size_key(int64_t lr, int64_t lu, bool coar
   return kKeys - 1 - k;
 }
 
-struct WindowClass { int bin, need_a, need_pack; };   // bin < 0: no fused class takes the window (generic path)
+struct WindowClass { int bin, need_a, need_pack, need_triv; };   // bin < 0: no fused class takes the window (generic path)
 
 // One class for both fused kernels and k_poa; |PO| is not known yet: typical growth estimate, windows whose graph turns
 // out larger are handed back by the device.  force_cls >= 0 (testing): that geometry class or none.
 __host__ __device__ inline WindowClass window_class(const KParams &kp, int64_t lr, int64_t lc, int64_t lu, int force_cls)
 {
-  WindowClass r{-1, 0, 0};
+  WindowClass r{-1, 0, 0, 0};
   const int rows = (int)(lc > lu ? lc : lu);
   int c0 = 0;
   while (c0 < kNC - 1 && cls_G(c0) * cls_R(c0) < rows) ++c0;
@@ -102,13 +102,14 @@ __host__ __device__ inline WindowClass window_class(const KParams &kp, int64_t l
     r.bin = ci * kNT + t;
     r.need_a = need_a;
     r.need_pack = poa_slot_need((int)lr, (int)lc, (int)lu, G);
+    r.need_triv = poa_slot_need_triv((int)lr, (int)lc, (int)lu, G);
     break;
   }
   return r;
 }
 
 // ---- device-side classification and list sort (poa_classify.hip) ----
-constexpr int kAccRows = 7;             // per bin: count, then the maxima of need_a, Lr, Lc, Lu, Lr + Lc, need_pack
+constexpr int kAccRows = 8;             // per bin: count, then the maxima of need_a, Lr, Lc, Lu, Lr + Lc, need_pack, need_triv
 constexpr int kSortDestMax = 40;        // lists a batch may have (launch bins + the generic list)
 
 struct ClassifyArgs {

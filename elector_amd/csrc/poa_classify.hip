@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_classify(ClassifyArgs a)
     if (lr < 0 || lc < 0 || lu < 0) { bad = 1; a.status[w] = ELECTOR_W_TOOLONG; a.bin[w] = -1; a.wkey[w] = 0; continue; }
     const int st = window_status(lr, lc, lu, a.pen_abs_max, ELECTOR_MAX_SEQ, a.window_moves_max);
     a.status[w] = st;
-    WindowClass wc{-1, 0, 0};
+    WindowClass wc{-1, 0, 0, 0};
     if (!st && a.use_fused) wc = window_class(a.kp, lr, lc, lu, a.force_cls);
     a.bin[w] = (int16_t)wc.bin;
     a.wkey[w] = (uint8_t)window_size_key(lr, lu, a.coarse != 0);
@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256) k_classify(ClassifyArgs a)
       raise(4, (int)lu);
       raise(5, (int)(lr + lc));
       raise(6, wc.need_pack);
+      raise(7, wc.need_triv);
       left += (unsigned long long)((int64_t)n_strips((int)lu) * mv_tw((int)(lr + lc)) * 64);
     } else ++gen;
     if (!st) po = max(po, (int)(lr + lc));

@@ -144,6 +144,12 @@ struct PackArgs {
   int32_t *far_count;       // group's k_poa<G, 8, true> launch takes them (far_cap entries; what does not fit goes to `hand`)
   int far_cap;
   const int32_t *nlist_dev; // when set: the list length lives on the device (a far list), nlist is its capacity
+  // A list in two launches.  Its first *split_dev entries run alignment #1, the rest have a shortcut graph (corrected
+  // sequence within one edit of the reference) and need neither index maps nor records for more than Lr + 1 nodes:
+  // part 1 = the head up to the split rounded up to whole wavefronts, part 2 = the tail with a smaller LDS slot (more
+  // wavefronts per CU).  Both are launched over the whole list; the blocks outside their part leave at once.  part 0 = all.
+  const int32_t *split_dev;
+  int part;
   int debug;
   unsigned long long *stamps;
 };
@@ -261,6 +267,17 @@ __host__ __device__ inline int poa_slot_need(int Lr, int Lc, int Lu, int G)
 {
   const int cap = poa_xi_cap(Lr, Lc);
   const int ua = poa_union_a(Lr, Lc, G), ub = poa_union_b(cap, Lu, G);
+  return 16 + ((Lu + 3) & ~3) + 4 * (cap + 2) + (ua > ub ? ua : ub);
+}
+
+// ... of a window that skips alignment #1 (corrected sequence within one edit of its reference: trivial_graph builds the
+// graph, at most Lr + 1 nodes): no index maps in union A, records for Lr + 2 nodes
+__host__ __device__ inline int poa_xi_cap_triv(int Lr) { return Lr + 2; }
+
+__host__ __device__ inline int poa_slot_need_triv(int Lr, int Lc, int Lu, int G)
+{
+  const int cap = poa_xi_cap_triv(Lr);
+  const int ua = (Lr + Lc + 3) & ~3, ub = poa_union_b(cap, Lu, G);
   return 16 + ((Lu + 3) & ~3) + 4 * (cap + 2) + (ua > ub ? ua : ub);
 }
 

@@ -37,7 +37,8 @@ void launch_rows(const uint8_t *cols, const int64_t *off, const int32_t *ncol, c
 void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, bool flags_only, hipStream_t st);
 int partition_buckets();
 void launch_partition(const uint32_t *in, uint32_t *out, const int64_t *bins, int nbins, const void *chunks, int nchunks,
-                      const int32_t *bin_chunks, const uint8_t *pkey, int32_t *chunk_cnt, int32_t *count, hipStream_t st);
+                      const int32_t *bin_chunks, const uint8_t *pkey, int32_t *chunk_cnt, int32_t *count, int32_t *count_a1,
+                      hipStream_t st);
 struct FusedArgs {
   BatchArgs b;
   const uint32_t *list;
@@ -57,6 +58,7 @@ struct FusedArgs {
 void launch_gather(const GatherArgs &a, hipStream_t st);
 int launch_poa(const PackArgs &a, int G, int R, hipStream_t st);
 int launch_poa_far(const PackArgs &a, int G, hipStream_t st);
+bool poa_debug_built();
 void launch_poa_pool_init(int32_t *q, int nq, int slots, hipStream_t st);
 int launch_fused_a(const FusedArgs &a, int G, int R, hipStream_t st);
 int launch_fused_b(const FusedArgs &a, int G, int R, int D, hipStream_t st);
@@ -530,9 +532,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const int64_t n_generic = (int64_t)h_glob[0];
   const int64_t left_worst = (int64_t)h_glob[1];     // moves (dwords) of alignment #2 if every fused-routed window were handed back
   const int64_t max_po_bound = (int64_t)h_glob[2];   // largest Lr + Lc of the batch (bounds |PO| and with it a strip's steps)
-  std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)6 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc, k_poa's slot need
+  std::vector<int64_t> bin_cnt((size_t)kBins, 0), bin_need_a((size_t)7 * kBins, 0);   // need_a, then maxima of Lr, Lc, Lu, Lr + Lc, k_poa's slot need (any window / a trivial one)
   int64_t *bin_max_lr = bin_need_a.data() + kBins, *bin_max_lc = bin_max_lr + kBins, *bin_max_lu = bin_max_lc + kBins,
-          *bin_max_po = bin_max_lu + kBins, *bin_need_pack = bin_max_po + kBins;
+          *bin_max_po = bin_max_lu + kBins, *bin_need_pack = bin_max_po + kBins, *bin_need_triv = bin_need_pack + kBins;
   std::vector<int16_t> bin_final((size_t)kBins);
   // Launches are expensive in tails and ramps (measured: one launch per geometry class is 7 % faster
   // than one per 4096-window slot tier, and a handful of tiny extra launches costs 8 %), so:
@@ -545,12 +547,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   auto decide_bins = [&](int64_t min_bin) {
     for (int b = 0; b < kBins; ++b) {
       bin_cnt[(size_t)b] = h_acc[b];
-      for (int q = 0; q < 6; ++q) bin_need_a[(size_t)(q * kBins + b)] = h_acc[(size_t)(q + 1) * kBins + b];
+      for (int q = 0; q < 7; ++q) bin_need_a[(size_t)(q * kBins + b)] = h_acc[(size_t)(q + 1) * kBins + b];
       bin_final[(size_t)b] = (int16_t)b;
     }
     auto merge_into = [&](int b, int into) {
       bin_cnt[(size_t)into] += bin_cnt[(size_t)b];
-      for (int q = 0; q < 6; ++q)
+      for (int q = 0; q < 7; ++q)
         bin_need_a[(size_t)(q * kBins + into)] = std::max(bin_need_a[(size_t)(q * kBins + into)], bin_need_a[(size_t)(q * kBins + b)]);
       bin_cnt[(size_t)b] = 0;
       for (int x = 0; x < kBins; ++x) if (bin_final[(size_t)x] == b) bin_final[(size_t)x] = (int16_t)into;
@@ -708,7 +710,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     return blocks * *ns * *tw * 64 * fused_mv_bytes(R);
   };
   // k_poa: LDS slot, moves geometry and scratch-slot pool of a bin
-  struct PackGeom { int slot, tw, slots; int64_t pool_words; };
+  struct PackGeom { int slot, slot_tail, tw, slots; int64_t pool_words; };
+  // ELECTOR_POA_SPLIT=0: every list in one launch with the slot of its largest window, as up to round 3 (A/B)
+  static const bool split_lists = !(std::getenv("ELECTOR_POA_SPLIT") && std::atoi(std::getenv("ELECTOR_POA_SPLIT")) == 0);
   auto pack_geom = [&](int b) {
     const int G = cls_G(b / kNT), nw = 2 * (64 / G);
     PackGeom pg;
@@ -730,7 +734,17 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       if (sl <= max_slot) pg.slot = sl;
     }
     pg.tw = (int)bin_max_po[b] + 8 + G + 4;
-    const int lds_block = 64 + nw * pg.slot;
+    // The windows of a list that have a shortcut graph (nine in ten on the bench batch) come behind those that run
+    // alignment #1 and need a third less LDS (no index maps, records for Lr + 1 nodes): where that buys another wavefront
+    // per CU below the register cap, the list's tail is a launch of its own (PackArgs::part).
+    pg.slot_tail = 0;
+    {
+      const int R = cls_R(b / kNT), reg_cap = 4 * (R <= 6 ? 4 : 3);                        // (k_poa's launch bounds)
+      const int st = (int)std::min<int64_t>(max_slot, (bin_need_triv[b] + 15) & ~(int64_t)15);
+      auto waves = [&](int slot) { return std::min(reg_cap, (160 * 1024) / (64 + nw * slot)); };
+      if (split_lists && use_trivial && bin_need_triv[b] > 0 && st < pg.slot && waves(st) > waves(pg.slot)) pg.slot_tail = st;
+    }
+    const int lds_block = 64 + nw * (pg.slot_tail ? pg.slot_tail : pg.slot);
     const int waves_cu = std::max(1, std::min(32, (160 * 1024) / lds_block));
     pg.slots = 32 * waves_cu + 8;                                  // per XCD: 32 CUs, every wave they can hold, and a margin
     pg.pool_words = (int64_t)8 * pg.slots * pg.tw * 64;
@@ -920,6 +934,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   int64_t *d_chunks = d_bins + 2 * kBins;
   int32_t *d_bin_need = reinterpret_cast<int32_t *>(d_chunks + 2 * part_chunks_max);
   int32_t *d_bin_chunks = d_bin_need + kBins, *d_chunk_need = d_bin_chunks + 2 * kBins;
+  static_assert(kSortDestMax <= kBins / 2, "d_bin_need holds two counts per list");
+  int32_t *d_bin_a1 = d_bin_need + kBins / 2;     // per list: the entries in front that run alignment #1 (no shortcut graph)
   uint8_t *d_done_a = c->d_done.as<uint8_t>(), *d_done_b = d_done_a + n, *d_triv = d_done_b + n, *d_pkey = d_triv + n,
           *d_tiled = d_pkey + n;
   int nbins_used = 0, nchunks = 0;
@@ -1051,7 +1067,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     a.n = n;
     timed_begin(c, 2, st);
     launch_trivial(a, d_done_a, d_triv, d_pkey, use_pack, st);
-    launch_partition(d_lists, d_lists2, d_bins, nbins_used, d_chunks, nchunks, d_bin_chunks, d_pkey, d_chunk_need, d_bin_need, st);
+    launch_partition(d_lists, d_lists2, d_bins, nbins_used, d_chunks, nchunks, d_bin_chunks, d_pkey, d_chunk_need, d_bin_need, d_bin_a1, st);
     timed_end(c, st);
   }
   const uint32_t *d_fused_lists = use_trivial ? d_lists2 : d_lists;
@@ -1072,6 +1088,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       const int sk = stream_of(b);
       hipStream_t sx = c->aux[sk];
       const int fdebug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
+      if (use_pack && (fdebug & (4 | 8 | 32 | 64 | 128 | 256 | 1024 | 2048)) && !poa_debug_built()) {
+        static std::atomic<bool> told{false};
+        if (!told.exchange(true))
+          std::fprintf(stderr, "[elector] ELECTOR_DEBUG_FUSED=%d: k_poa was built without its debug branches; rebuild with "
+                               "ELECTOR_HIPCC_FLAGS=-DELECTOR_POA_DEBUG=1 python -m elector_amd.build --force\n", fdebug);
+      }
       // the hand-back list of this bin -- or, merged, of the bin's lane-group size (the region of the group's first bin,
       // which its neighbours' regions follow)
       HandGroup *hg = merge_hand ? &hgrp[bG == 8 ? 0 : bG == 16 ? 1 : bG == 32 ? 2 : 3] : nullptr;
@@ -1116,10 +1138,17 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         pa.far_count = use_far && hg ? reinterpret_cast<int32_t *>(c->d_far.as<uint32_t>() + n) + gi : nullptr;
         pa.far_cap = use_far && hg ? (int)hg->far_cap : 0;
         pa.nlist_dev = nullptr;
+        pa.split_dev = pg.slot_tail ? d_bin_a1 + bin_slot[(size_t)b] : nullptr;
+        pa.part = pg.slot_tail ? 1 : 0;
         pa.debug = fdebug;
         pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b) + 16;
         timed_begin(c, 4, sx);
         if (launch_poa(pa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
+        if (pg.slot_tail) {
+          pa.part = 2;
+          pa.slot_bytes = pg.slot_tail;
+          if (launch_poa(pa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
+        }
         timed_end(c, sx);
       }
       // behind k_poa the two-kernel path only sees the windows handed back: its small launches go to a stream
@@ -1172,6 +1201,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           pa.hand = d_hand_list;
           pa.hand_count = d_hand_cnt;
           pa.far = nullptr; pa.far_count = nullptr; pa.far_cap = 0;
+          pa.split_dev = nullptr; pa.part = 0;
           pa.debug = fdebug & ~(32 | 64 | 128 | 256);
           pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)hb) + 16;
           timed_begin(c, 6, sg);
@@ -1358,6 +1388,16 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     std::fprintf(stderr, "[elector] k_poa handed back:");
     for (int b = 0; b < kBins; ++b)
       if (bin_cnt[(size_t)b]) std::fprintf(stderr, " G%dxR%d:%d/%lld", cls_G(b / kNT), cls_R(b / kNT), hc[(size_t)bin_slot[(size_t)b]], (long long)bin_cnt[(size_t)b]);
+    std::fprintf(stderr, "\n");
+    std::vector<int32_t> ha((size_t)kBins, 0);
+    (void)hipMemcpy(ha.data(), d_bin_a1, (size_t)nbins_used * 4, hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[elector] k_poa lists (windows that run alignment #1 / all, LDS slot, slot of the tail launch):");
+    for (int b = 0; b < kBins; ++b)
+      if (bin_cnt[(size_t)b]) {
+        const auto pg = pack_geom(b);
+        std::fprintf(stderr, " G%dxR%d:%d/%lld,%d,%d", cls_G(b / kNT), cls_R(b / kNT), ha[(size_t)bin_slot[(size_t)b]], (long long)bin_cnt[(size_t)b],
+                     pg.slot, pg.slot_tail);
+      }
     std::fprintf(stderr, "\n");
   }
   if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 8)) {

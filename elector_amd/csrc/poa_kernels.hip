@@ -715,12 +715,14 @@ __global__ void __launch_bounds__(256) k_part_count(const uint32_t *__restrict__
 // one wave per bin: exclusive scan over its (bucket-major, chunk-minor) counts, in place;
 // the windows in front of the last bucket are the ones that need alignment #1
 __global__ void __launch_bounds__(64) k_part_scan(const int32_t *__restrict__ bin_chunks /* first chunk, #chunks per bin */,
-                                                  int32_t *__restrict__ chunk_cnt, int32_t *__restrict__ count)
+                                                  int32_t *__restrict__ chunk_cnt, int32_t *__restrict__ count,
+                                                  int32_t *__restrict__ count_a1)
 {
   const int c0 = bin_chunks[2 * blockIdx.x], nc = bin_chunks[2 * blockIdx.x + 1], lane = threadIdx.x;
   int run = 0;
   for (int k = 0; k < kPartBuckets; ++k) {
     if (k == kPartBuckets - 1 && lane == 0) count[blockIdx.x] = run;
+    if (k == 16 && lane == 0) count_a1[blockIdx.x] = run;      // buckets 0..15: no shortcut graph, alignment #1 runs
     for (int base = 0; base < nc; base += 64) {
       const int i = base + lane;
       const int v = i < nc ? chunk_cnt[(c0 + i) * kPartBuckets + k] : 0;
@@ -879,12 +881,13 @@ void launch_trivial(const BatchArgs &a, uint8_t *done_a, uint8_t *triv, uint8_t 
 int partition_buckets() { return kPartBuckets; }
 
 void launch_partition(const uint32_t *in, uint32_t *out, const int64_t *bins, int nbins, const void *chunks, int nchunks,
-                      const int32_t *bin_chunks, const uint8_t *pkey, int32_t *chunk_cnt, int32_t *count, hipStream_t st)
+                      const int32_t *bin_chunks, const uint8_t *pkey, int32_t *chunk_cnt, int32_t *count, int32_t *count_a1,
+                      hipStream_t st)
 {
   if (nbins <= 0 || nchunks <= 0) return;
   const PartChunk *ch = reinterpret_cast<const PartChunk *>(chunks);
   hipLaunchKernelGGL(k_part_count, dim3((unsigned)nchunks), dim3(256), 0, st, in, ch, pkey, chunk_cnt);
-  hipLaunchKernelGGL(k_part_scan, dim3((unsigned)nbins), dim3(64), 0, st, bin_chunks, chunk_cnt, count);
+  hipLaunchKernelGGL(k_part_scan, dim3((unsigned)nbins), dim3(64), 0, st, bin_chunks, chunk_cnt, count, count_a1);
   hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)nchunks), dim3(256), 0, st, in, out, ch, bins, pkey, chunk_cnt);
 }
 

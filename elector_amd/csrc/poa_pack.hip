@@ -207,9 +207,18 @@ struct WinP {
 };
 
 // phase stamps (debug bit 2): cycles per phase summed over waves
+// The debug facilities of k_poa (PackArgs::debug: phase stamps, why windows leave, phases dropped for instruction counts,
+// round 2's traceback) are compiled in with -DELECTOR_POA_DEBUG=1 only (ELECTOR_HIPCC_FLAGS): their branches -- each an
+// EXEC-narrowing region around an atomic -- cost scalar registers and, with ROCm 7.2's compiler, gave the register
+// allocator places to put a VGPR spill store IN FRONT of the `s_or_b64 exec` that closes the region (the store then runs
+// under an empty mask and the reload reads garbage: tools/check_spills.py, run by the build).
+#ifndef ELECTOR_POA_DEBUG
+#define ELECTOR_POA_DEBUG 0
+#endif
+constexpr bool kPoaDebug = ELECTOR_POA_DEBUG != 0;
 #define PK_STAMP(idx)                                                                             \
   do {                                                                                            \
-    if ((a.debug & 4) && threadIdx.x == 0) {                                                      \
+    if ((dbg & 4) && threadIdx.x == 0) {                                                      \
       const unsigned long long now_ = __builtin_readcyclecounter();                               \
       atomicAdd(a.stamps + (idx), now_ - stamp_);                                                 \
       stamp_ = now_;                                                                              \
@@ -874,11 +883,13 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
   W.triv = listed ? triv : 0;
   W.n1 = 0; W.score1 = kNeg; W.k2n = 0; W.fnode = -1;
   W.slot = slot;
-  W.xi_cap = poa_xi_cap(W.Lr, W.Lc);
+  // (a.part == 2: a launch of shortcut graphs only -- poa_slot_need_triv; a window that needs alignment #1 is refused)
+  const bool tail = a.part == 2;
+  W.xi_cap = tail ? poa_xi_cap_triv(W.Lr) : poa_xi_cap(W.Lr, W.Lc);
   W.off_xi = 16 + pk_align_up(W.Lu, 4);
   W.off_u = W.off_xi + 4 * (W.xi_cap + 2);                     // records 1 .. n1 between two zero guards
-  const int ua = poa_union_a(W.Lr, W.Lc, G), ub = poa_union_b(W.xi_cap, W.Lu, G);
-  W.valid = W.valid && W.off_u + max(ua, ub) <= a.slot_bytes && W.Lc <= RS && W.Lu <= RS &&
+  const int ua = tail ? pk_align_up(W.Lr + W.Lc, 4) : poa_union_a(W.Lr, W.Lc, G), ub = poa_union_b(W.xi_cap, W.Lu, G);
+  W.valid = W.valid && (!tail || W.triv != 0) && W.off_u + max(ua, ub) <= a.slot_bytes && W.Lc <= RS && W.Lu <= RS &&
             (poa_idx_bytes(G) > 1 || W.Lr + W.Lc <= 254) &&
             max(W.Lr, W.xi_cap) + G + 2 <= a.mv_tw && score_span(kp, max(W.Lr, W.xi_cap) + G, RS) < 16000;
 }
@@ -894,11 +905,18 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   // index type of the alignment #1 / fusion #1 maps: one byte in the classes whose windows are short
   using IT = typename std::conditional<poa_idx_bytes(G) == 1, uint8_t, uint16_t>::type;
   const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
-  // a far list is launched at its capacity: the blocks behind its length leave before they touch anything
-  if (a.nlist_dev && (int64_t)blockIdx.x * (2 * NP) >= (int64_t)*a.nlist_dev) return;
+  const int dbg = kPoaDebug ? a.debug : 0;         // (a build without ELECTOR_POA_DEBUG holds none of the debug branches)
+  // a far list is launched at its capacity, the two parts of a split list over the whole list: the blocks outside leave
+  // before they touch anything
+  int64_t nlist = a.nlist_dev ? min(a.nlist, (int64_t)*a.nlist_dev) : a.nlist, first = 0;
+  if (a.part) {
+    const int64_t head = min(nlist, (((int64_t)*a.split_dev + 2 * NP - 1) / (2 * NP)) * (2 * NP));
+    if (a.part == 1) nlist = head; else first = head;
+  }
+  if (first + (int64_t)blockIdx.x * (2 * NP) >= nlist) return;
   const KParams kp = a.b.kp;
   uint8_t *chr = lds;
-  unsigned long long stamp_ = (a.debug & 4) ? __builtin_readcyclecounter() : 0;
+  unsigned long long stamp_ = (dbg & 4) ? __builtin_readcyclecounter() : 0;
 
   // Moves scratch.  The moves of a wave are dead when it ends, so the scratch is a pool of slots as large as the
   // number of waves that can be resident, not one region per block: the same few dozen megabytes are written and
@@ -918,7 +936,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   // have arrived (a fixed number of dwords per entry, the class's stride); what lies behind a window's end is read
   // and dropped. ----
   WinP W[2];
-  const int64_t pi = (int64_t)blockIdx.x * NP + q;
+  const int64_t pi = first / 2 + (int64_t)blockIdx.x * NP + q;
   uint8_t *us[2], *U[2];
   uint32_t *xinfo[2];
   bool any_valid;
@@ -927,7 +945,6 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
     bool inl[2];
     const uint32_t *src4[2];
     uint4 d0[2], d1[2];
-    const int64_t nlist = a.nlist_dev ? min(a.nlist, (int64_t)*a.nlist_dev) : a.nlist;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       inl[h] = 2 * pi + h < nlist;
@@ -959,7 +976,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       // a listed window this kernel cannot take (slot, rows, score range) goes to the two-kernel path at once
       if (listed && !W[h].valid && g == 0) {
         a.hand[atomicAdd(a.hand_count, 1)] = W[h].w;
-        if (a.debug & 8) atomicAdd(a.stamps + 6, 1ull);                // (debug: refused at the door: slot, rows, score range)
+        if (dbg & 8) atomicAdd(a.stamps + 6, 1ull);                // (debug: refused at the door: slot, rows, score range)
       }
     }
     any_valid = __builtin_amdgcn_ballot_w64(W[0].valid || W[1].valid) != 0;
@@ -1029,7 +1046,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   __syncthreads();
   PK_STAMP(0);
   // instruction-count experiments (debug bits 32 .. 256): drop the windows after a phase, the rest of the kernel idles
-  if (a.debug & 32) { W[0].valid = W[1].valid = false; }
+  if (dbg & 32) { W[0].valid = W[1].valid = false; }
 
   // packed constants (both halves alike)
   const uint32_t ONES = 0x00010001u;
@@ -1139,7 +1156,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   }
   __syncthreads();
   PK_STAMP(3);
-  if (a.debug & 64) { W[0].valid = W[1].valid = false; }
+  if (dbg & 64) { W[0].valid = W[1].valid = false; }
 
   // ---- ordinals of the two-predecessor nodes (they own a row of ordinal bytes); final fit check ----
 #pragma unroll
@@ -1179,7 +1196,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
         bool placed = false;
         // debug bit 8: why windows leave this kernel (1 nodes beyond the slot's records, 2 broken path, 3 one far edge,
         // 4 several far edges, 5 ordinal rows / moves steps beyond the slot), counted per bin
-        if (a.debug & 8) atomicAdd(a.stamps + (keep[h] && !bad[h] ? 5 : why[h]), 1ull);
+        if (dbg & 8) atomicAdd(a.stamps + (keep[h] && !bad[h] ? 5 : why[h]), 1ull);
         if (!FAR && farw[h] && !bad[h] && a.far != nullptr) {
           const int at = atomicAdd(a.far_count, 1);
           if (at < a.far_cap) { a.far[at] = W[h].w; placed = true; }
@@ -1340,14 +1357,14 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
           dt1 = c1S; dt2 = c2S;
           Sb[k] = Sn; Eb[k] = En; insY = En;
         });
-        if (a.debug & 4) { ++n_steps; n_two += TWO && !VIRT; n_virt += VIRT; }
+        if (dbg & 4) { ++n_steps; n_two += TWO && !VIRT; n_virt += VIRT; }
         if (TWO) {
           if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
           if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
         }
       };
       // debug bit 1024: never the plain-chain form (A/B)
-      if (!(a.debug & 1024) && __builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
+      if (!(dbg & 1024) && __builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
         variant(std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{});
       else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
         variant(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
@@ -1392,14 +1409,14 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
         step(std::false_type{}, t + 1, S2, E2, S1, E1);
       }
     }
-    if ((a.debug & 4) && threadIdx.x == 0) {
+    if ((dbg & 4) && threadIdx.x == 0) {
       atomicAdd(a.stamps + 12, (unsigned long long)n_steps);
       atomicAdd(a.stamps + 13, (unsigned long long)n_two);
       atomicAdd(a.stamps + 14, (unsigned long long)n_virt);
     }
   }
   PK_STAMP(5);
-  if (a.debug & 128) { W[0].valid = W[1].valid = false; }
+  if (dbg & 128) { W[0].valid = W[1].valid = false; }
   // best end cell to every lane of the group
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1411,12 +1428,12 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   __syncthreads();
   bool badb[2] = {false, false};
   int tb_rounds = 0;
-  if (!FAR && (a.debug & 2048)) traceback_b<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);      // round 2's form (A/B)
+  if (!FAR && (dbg & 2048)) traceback_b<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);      // round 2's form (A/B)
   else traceback_b2<G, R, FAR>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);
-  if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 11, (unsigned long long)tb_rounds);
+  if ((dbg & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 11, (unsigned long long)tb_rounds);
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(6);
-  if (a.debug & 256) { W[0].valid = W[1].valid = false; }
+  if (dbg & 256) { W[0].valid = W[1].valid = false; }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (__builtin_amdgcn_ballot_w64(W[h].valid) == 0) continue;
@@ -1442,7 +1459,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
     }
   }
   PK_STAMP(7);
-  if ((a.debug & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
+  if ((dbg & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
   // give the moves slot back: every access of this wave to it has completed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && a.mv_slots > 0) {
@@ -1496,6 +1513,9 @@ int launch_poa(const PackArgs &a, int G, int R, hipStream_t st)
 #undef X
   return -2;
 }
+
+// were k_poa's debug facilities compiled in (-DELECTOR_POA_DEBUG=1)?
+bool poa_debug_built() { return kPoaDebug; }
 
 // the far-edge instance of a lane-group size: 8 rows per lane hold every window of the group's classes
 int launch_poa_far(const PackArgs &a, int G, hipStream_t st)
