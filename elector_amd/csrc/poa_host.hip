@@ -711,8 +711,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   };
   // k_poa: LDS slot, moves geometry and scratch-slot pool of a bin
   struct PackGeom { int slot, slot_tail, tw, slots; int64_t pool_words; };
-  // ELECTOR_POA_SPLIT=0: every list in one launch with the slot of its largest window, as up to round 3 (A/B)
-  static const bool split_lists = !(std::getenv("ELECTOR_POA_SPLIT") && std::atoi(std::getenv("ELECTOR_POA_SPLIT")) == 0);
+  // ELECTOR_POA_SPLIT=1 (experiment, see pack_geom): a list's tail of shortcut graphs as a launch of its own
+  const bool split_lists = std::getenv("ELECTOR_POA_SPLIT") && std::atoi(std::getenv("ELECTOR_POA_SPLIT")) != 0;
   auto pack_geom = [&](int b) {
     const int G = cls_G(b / kNT), nw = 2 * (64 / G);
     PackGeom pg;
@@ -735,8 +735,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     }
     pg.tw = (int)bin_max_po[b] + 8 + G + 4;
     // The windows of a list that have a shortcut graph (nine in ten on the bench batch) come behind those that run
-    // alignment #1 and need a third less LDS (no index maps, records for Lr + 1 nodes): where that buys another wavefront
-    // per CU below the register cap, the list's tail is a launch of its own (PackArgs::part).
+    // alignment #1 and need a third less LDS (no index maps, records for Lr + 1 nodes).  With ELECTOR_POA_SPLIT=1 the
+    // list's tail is a launch of its own (PackArgs::part) where that buys another wavefront per CU below the register
+    // cap: 13 -> 16 wavefronts per CU in G16xR6, 9 -> 12 in G16xR8.  Measured (three rotating batches, two runs each):
+    // E. coli -3 %, yeast -split -1 % (-2 % with the rows left in HBM), 50 kb reads -1 % -- the second launch's ramp and
+    // tail cost more than the occupancy gives.  Off by default.
     pg.slot_tail = 0;
     {
       const int R = cls_R(b / kNT), reg_cap = 4 * (R <= 6 ? 4 : 3);                        // (k_poa's launch bounds)

@@ -505,3 +505,28 @@ def test_soak_slice(engine):
             check(engine, triples)
             total += len(triples)
     assert total == 228000
+
+
+def test_list_in_two_launches(engine, monkeypatch, capfd):
+    """ELECTOR_POA_SPLIT=1: the windows of a list that run alignment #1 and the windows with a shortcut graph (corrected
+    sequence within one edit of the reference) as two launches of k_poa, the second with the smaller LDS slot of
+    poa_slot_need_triv.  Same rows and scores as the oracle; the debug line says that lists were in fact split."""
+    monkeypatch.setenv("ELECTOR_POA_SPLIT", "1")
+    monkeypatch.setenv("ELECTOR_DEBUG_BINS", "1")
+    rng = np.random.default_rng(77)
+    triples = []
+    for t in synth.window_triples(78, 5000, 66, 250, err_cor=0.004):
+        ref, cor, unc = t
+        k = int(rng.integers(0, 10))
+        if k == 0 and len(ref) > 4:                      # one inserted / deleted letter
+            p = int(rng.integers(1, len(ref) - 1))
+            cor = ref[:p] + ref[p + 1:] if rng.integers(0, 2) else ref[:p] + b"A" + ref[p:]
+        elif k < 6:
+            cor = ref
+        triples.append((ref, cor, unc))
+    check(engine, triples)
+    err = capfd.readouterr().err
+    line = [ln for ln in err.split("\n") if "k_poa lists" in ln]
+    assert line, err[-2000:]
+    tails = [int(tok.split(",")[2]) for tok in line[-1].split("): ")[1].split()]
+    assert any(t > 0 for t in tails), line[-1]
