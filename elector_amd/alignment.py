@@ -10,7 +10,7 @@ bytes.  Where the reference spawns `masterSplitter`, 200 `poa` processes and 200
 (alignment.py:98-129), a batch here never leaves memory, and the bulk of it never
 leaves the GPU:
 
-    parser thread   three FASTA files -> batches of reads (elector_reads_next, native; two buffer sets in turn)
+    parser thread   three FASTA files -> batches of reads (elector_reads_next, native; four buffer sets in turn)
     splitter thread batches -> HBM -> windows (elector_split_reads_device: one workgroup per read on a splitter
                     context of its own; ELECTOR_HOST_SPLIT=1 keeps the host threads of elector_split_reads instead)
     main thread     windows (already in HBM) -> triplet MSAs (elector_poa_batch_device) -> one record per piece
@@ -368,8 +368,10 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
     # Threads in front of the main thread: one cuts the files into batches (native code), two split them, each with a
     # splitter context of its own -- the host's share of a split (reads into pinned staging, waiting for the kernel,
     # window offsets back, record boundaries) is as long as the kernel, and two batches in flight hide it.  The
-    # batches carry sequence numbers; the main thread takes them in order.  The reader hands out views of its two
-    # buffer sets in turn, so batch i may only be read when batch i - 2 has been split.
+    # batches carry sequence numbers; the main thread takes them in order.  The reader hands out views of its
+    # split.READ_SETS buffer sets in turn, so batch i may only be read when batch i - READ_SETS has been split (with two
+    # sets a splitter waited a whole parse for its next batch: the parser could not start it before that splitter's
+    # previous batch was through).
     parsed = queue.Queue(maxsize=2)
     split_done = {}                                # sequence number -> Event: the batch's reads are no longer needed
     stop_all = threading.Event()                   # set when the main thread gives up: the threads wind down
@@ -401,7 +403,7 @@ def getPOA(corrected, reference, uncorrected, threads, outDir, SIZE_CORRECTED_RE
             try:
                 seq = 0
                 while not stop_all.is_set():
-                    if seq >= 2 and not wait_for(split_done[seq - 2]):
+                    if seq >= split.READ_SETS and not wait_for(split_done[seq - split.READ_SETS]):
                         break
                     t0 = time.perf_counter()
                     rb = rf.next(READS_PER_BATCH, start, stop)

@@ -239,13 +239,15 @@ struct Reader {
   bool done = false;
   // a kept record: its reference header line and the three sequence lines, as spans of the mappings
   struct Rec { const char *h, *s[3]; size_t hl, sl[3]; };
-  // The batch handed out lives in one of two buffer sets, used in turn: the batch handed out by a call stays valid
-  // until the call after the next one, so a caller can read batch i + 1 while another thread still works on batch i.
+  // The batch handed out lives in one of kReadSets buffer sets, used in turn: the batch handed out by a call stays
+  // valid until kReadSets - 1 more calls have been made, so a caller can read ahead while other threads still work on
+  // the batches before (two sets, as up to round 3, tied the parser to the splitters: batch i + 2 could only be read
+  // when batch i had been split completely, and a splitter then waited a whole parse for its next batch).
   // A record read ahead of a batch's end opens the next batch.
   struct Set {
     BigBuf seq, hdr;
     std::vector<int64_t> seq_off, hdr_off;
-  } set[2];
+  } set[ELECTOR_READ_SETS];
   int cur = 0;
   bool has_pending = false;
   Rec pending;
@@ -283,7 +285,8 @@ extern "C" int elector_reads_open(const char *reference, const char *uncorrected
   if (!reference || !uncorrected || !corrected || !handle) return ELECTOR_E_INVAL;
   Reader *rd = new (std::nothrow) Reader();
   if (!rd) return ELECTOR_E_NOMEM;
-  if (!std::getenv("ELECTOR_NO_PINNED_READS")) rd->set[0].seq.pin = rd->set[1].seq.pin = true;
+  if (!std::getenv("ELECTOR_NO_PINNED_READS"))
+    for (auto &s : rd->set) s.seq.pin = true;
   if (!rd->ref.open(reference) || !rd->unc.open(uncorrected) || !rd->cor.open(corrected)) {
     rd->ref.close(); rd->unc.close(); rd->cor.close();
     delete rd;
@@ -310,7 +313,7 @@ extern "C" int elector_reads_next(void *handle, int64_t min_records, int64_t sta
   static const bool prof = std::getenv("ELECTOR_DEBUG_HOST") != nullptr;
   auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
   const double t0 = now_ms();
-  rd->cur ^= 1;                                    // the other buffer set takes the new batch
+  rd->cur = (rd->cur + 1) % ELECTOR_READ_SETS;     // the next buffer set takes the new batch
   Reader::Set &S = rd->set[rd->cur];
   S.seq.clear(); S.hdr.clear(); S.seq_off.assign(1, 0); S.hdr_off.assign(1, 0);
   if (rd->done && !rd->has_pending) return ELECTOR_OK;

@@ -12,6 +12,8 @@ import numpy as np
 from . import _capi
 from ._capi import ElectorError
 
+READ_SETS = 4            # ELECTOR_READ_SETS of include/elector_split.h: buffer sets a ReadsFile hands out in turn
+
 
 class ElectorWindows(C.Structure):
     _fields_ = [

@@ -85,7 +85,8 @@ int  elector_ctx_copy_to_host(elector_ctx *ctx, const void *d_src, void *h_dst, 
  * same).  start / stop: range of kept-record indices to hand out (stop < 0: to the end).  A batch with n == 0
  * is the end.  seq holds per record the reference, uncorrected and corrected sequence (the order
  * elector_split_reads takes), hdr the reference records' header lines; the buffers belong to the handle and stay
- * valid until the call after its next one (two sets are used in turn). */
+ * valid until ELECTOR_READ_SETS - 1 more calls have been made on the handle (that many sets are used in turn). */
+#define ELECTOR_READ_SETS 4
 typedef struct elector_reads {
   int64_t n, first_index;
   uint8_t *seq;  int64_t *seq_off;     /* 3n + 1 offsets */

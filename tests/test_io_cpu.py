@@ -165,3 +165,23 @@ def test_shard_bounds_cut_at_read_boundaries(tmp_path):
             assert (0, 1) in set(zip(b, b[1:]))                 # the dominant read is a shard of its own
         if world == 16:
             assert any(x == y for x, y in zip(b, b[1:]))        # more ranks than reads: some shard is empty
+
+
+def test_reader_batches_stay_valid_for_the_buffer_sets(tmp_path):
+    """include/elector_split.h: a batch's buffers stay valid until ELECTOR_READ_SETS - 1 more calls have been made
+    (getPOA's parser reads that far ahead of its splitter threads)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "elector_split.h")).read()
+    assert int(re.search(r"#define ELECTOR_READ_SETS (\d+)", hdr).group(1)) == split.READ_SETS >= 3
+    paths = _write(tmp_path, _records(400, 91, False))
+    rf = split.ReadsFile(paths[0], paths[1], paths[2])
+    held = []                       # (batch, copy of its bytes at the time it was handed out)
+    while True:
+        b = rf.next(9, 0, None)
+        if b is None:
+            break
+        held.append((b, b.seq.tobytes(), bytes(b.hdr)))
+        for old, seq, hd in held[-split.READ_SETS:]:
+            assert old.seq.tobytes() == seq and bytes(old.hdr) == hd
+    assert len(held) > 2 * split.READ_SETS
+    rf.close()

@@ -530,3 +530,16 @@ def test_list_in_two_launches(engine, monkeypatch, capfd):
     assert line, err[-2000:]
     tails = [int(tok.split(",")[2]) for tok in line[-1].split("): ")[1].split()]
     assert any(t > 0 for t in tails), line[-1]
+
+
+@pytest.mark.parametrize("split_lists", ["0", "1"])
+def test_first_call_of_a_fresh_process(split_lists):
+    """tests/first_call_check.py in a process of its own: k_poa's first launches, on untouched scratch memory, give the
+    rows of the two-kernel path (with the lists whole and in two launches)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ELECTOR_POA_SPLIT=split_lists)
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "first_call_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "differing 0" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -18,7 +18,7 @@ for r in rows:
     a = agg.setdefault(k, [0, 0.0]); a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"])
 j = json.load(open(o + "/e2e.json"))
 print("e2e", j["value"], j["seconds"])
-for k, (c, t) in sorted(agg.items(), key=lambda x: -x[1][1])[:12]:
+for k, (c, t) in sorted(agg.items(), key=lambda x: -x[1][1])[:24]:
     print("  %-28s calls %6d total %9.1f ms  %5.1f%%" % (k, c, t / 1e6, 100 * t / tot))
 print("  all kernels %.1f ms" % (tot / 1e6))
 PY
