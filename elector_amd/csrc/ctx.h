@@ -142,7 +142,7 @@ struct elector_ctx {
   bool graph_valid = false;    // the last batch ran with keep_graph
   const int32_t *last_ncol = nullptr;   // device arrays of the last batch (caller's or the staging ones)
   int32_t *last_status = nullptr;
-  elector::DevBuf d_bnode, d_bscore, d_bpath, d_bcons, d_binfo, d_bplan, d_bin;
+  elector::DevBuf d_bnode, d_bscore, d_bpath, d_bcons, d_binfo, d_bplan, d_bin, d_bcls;
   int64_t last_n_generic = 0;           // windows of the last batch on the generic list (d_perm); the others are in d_list
 };
 

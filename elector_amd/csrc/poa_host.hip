@@ -311,7 +311,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
                     &c->d_scores, &c->d_rowoff, &c->d_rows, &c->d_st_rows, &c->d_st_rowoff, &c->d_st_cols,
                     &c->d_st_first, &c->d_st_clips, &c->d_st_cnt, &c->d_st_mask, &c->d_st_scr, &c->d_st_dense, &c->d_st_outoff,
                     &c->d_list, &c->d_done, &c->d_rowinit,
-                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_bplan, &c->d_bin, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy, &c->d_pdesc, &c->d_psym,
+                    &c->d_bnode, &c->d_bscore, &c->d_bpath, &c->d_bcons, &c->d_binfo, &c->d_bplan, &c->d_bin, &c->d_bcls, &c->d_fmv, &c->d_tstate, &c->d_tlist, &c->d_gring, &c->d_hand, &c->d_mvpool, &c->d_mvbusy, &c->d_pdesc, &c->d_psym,
                     &c->d_bin16, &c->d_wkey, &c->d_acc, &c->d_ginfo, &c->d_far,
                     &c->d_sp_reads, &c->d_sp_off, &c->d_sp_hdr, &c->d_sp_keys, &c->d_sp_vals, &c->d_sp_ca, &c->d_sp_cb, &c->d_sp_wl,
                     &c->d_sp_win, &c->d_sp_first, &c->d_sp_cnt, &c->d_sp_wfirst, &c->d_sp_wlen, &c->d_sp_woff, &c->d_sp_scan, &c->d_sp_bases, &c->d_sp_anc};

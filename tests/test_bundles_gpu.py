@@ -60,3 +60,30 @@ def test_bundles_need_keep_graph(engine):
     engine.align(t)
     with pytest.raises(ElectorError):
         engine.bundles(len(t), 10000)
+
+
+def test_bundles_first_form(engine, monkeypatch):
+    """ELECTOR_BUNDLE_HBM=1: every block through the first form of the search (node records in HBM) -- the path of
+    windows beyond 208 nodes -- on windows the LDS form takes otherwise."""
+    monkeypatch.setenv("ELECTOR_BUNDLE_HBM", "1")
+    check(engine, synth.window_triples(27, 1500, 7, 160))
+    check(engine, synth.adversarial_triples(28, 1200))
+
+
+def test_bundles_lds_class_borders(engine):
+    """windows whose graphs have about 52 / 69 / 104 / 208 nodes: the borders of the LDS classes and of the first form"""
+    t = []
+    for k, lo in enumerate((40, 56, 88, 180)):
+        t += synth.window_triples(30 + k, 700, lo, lo + 30, err_unc=0.12, err_cor=0.02)
+    check(engine, t)
+
+
+@pytest.mark.parametrize("pct", ["0", "100"])
+def test_bundles_lds_and_global_forms(engine, monkeypatch, pct):
+    """the second form of the search with its records in LDS (ELECTOR_BUNDLE_GLOBAL_PCT=0) and in HBM (100); the default
+    sends half of every class's blocks each way"""
+    monkeypatch.setenv("ELECTOR_BUNDLE_GLOBAL_PCT", pct)
+    check(engine, synth.window_triples(41, 2500, 7, 200))
+    check(engine, synth.adversarial_triples(42, 1200))
+    t = synth.window_triples(43, 600, 10, 200, err_unc=0.3, err_cor=0.25)
+    check(engine, t, frac=0.5)
