@@ -446,7 +446,7 @@ def bundles_mode(args):
            "config": {"workload": "%s: %d reads per step" % (WORKLOADS[profile], args.reads), "profile": profile, "windows": b.n},
            "windows_per_s": round(b.n / (per_launch_ms * 1e-3), 1) if per_launch_ms > 0 else None,
            "step_ms_with_alignment": round(dt / args.steps * 1e3, 3),
-           "roofline": {"bound": "hbm", "kernel": "k_bundle", "achieved": round(alg / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 else 0.0,
+           "roofline": {"bound": "hbm", "kernel": "k_bundle_inputs + k_bundle_lds<C, LDS | HBM> + k_bundle_hbm (side by side: the time is the search's, plan to last row)", "achieved": round(alg / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 else 0.0,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if per_launch_ms > 0 else 0.0,
                         "traffic": None, "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
