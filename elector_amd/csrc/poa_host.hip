@@ -422,7 +422,12 @@ static const int64_t kDeepRingBytes = (int64_t)4 << 30;       // HBM shadow ring
 
 static const int kPartChunk = 2048;     // list entries per block of the trivial-window partition
 // a bin with fewer windows than this joins the next larger populated slot tier of its class
-static const int64_t kMinBinWindows = std::getenv("ELECTOR_MIN_BIN") ? std::atoll(std::getenv("ELECTOR_MIN_BIN")) : 4096;
+// (16,384 since the end of round 4, 4,096 before: a class of a few thousand windows of the 32- and 64-lane groups is a few
+// hundred wavefronts that last as long as their longest window -- a launch that is all ramp and tail.  Same-box A/B,
+// two runs each: un-overlapped k_poa 5.66 -> 5.47 ms on the E. coli batch, 9.93 -> 8.87 on the yeast -split batch
+// (140 -> 130 and 180 -> 170 launches per ten steps), the pipelined rate +0.9 / +0.4 %; 65,536: 5.15 / 8.83 ms but
+// -0.5 % pipelined on E. coli)
+static const int64_t kMinBinWindows = std::getenv("ELECTOR_MIN_BIN") ? std::atoll(std::getenv("ELECTOR_MIN_BIN")) : 16384;
 
 static int ensure_streams(elector_ctx *c)
 {
