@@ -168,6 +168,17 @@ struct GatherArgs {
   const int32_t *nlist_dev;  // when set: the list length lives on the device (a far list), nlist is its capacity
 };
 
+// k_gather for all lists of a batch in ONE launch: the lists lie back to back (entry i of the batch's fused-routed
+// windows; descriptors at the same index), only the symbols' place and stride differ from list to list
+constexpr int kGatherLists = 40;           // (= kSortDestMax of poa_classes.h: the lists a batch may have)
+struct GatherAllArgs {
+  GatherArgs g;                            // list / pdesc / psym = the arrays' starts, nlist = all entries
+  int nb;
+  int64_t first[kGatherLists + 1];         // first entry of list k (ascending); first[nb] = nlist
+  int64_t psym_first[kGatherLists];        // dwords
+  int32_t stride[kGatherLists];
+};
+
 // Long windows (the reference's whole-read fallback) are cut into tiles of one strip of 63 rows by
 // kTileCols columns; the tiles of one anti-diagonal (strip + column block) are independent and run
 // in one launch (k_dp1_tile / k_dp2_tile), so a window of many strips uses many wavefronts.

@@ -56,6 +56,7 @@ struct FusedArgs {
   int64_t grid_blocks;
 };
 void launch_gather(const GatherArgs &a, hipStream_t st);
+void launch_gather_all(const GatherAllArgs &a, hipStream_t st);
 int launch_poa(const PackArgs &a, int G, int R, hipStream_t st);
 int launch_poa_far(const PackArgs &a, int G, hipStream_t st);
 bool poa_debug_built();
@@ -1081,6 +1082,30 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const uint32_t *d_fused_lists = use_trivial ? d_lists2 : d_lists;
 
   // ---- fused classes: launch chains on the auxiliary streams (A then B of each bin) ----
+  // ELECTOR_GATHER_ALL=1 (experiment): k_poa's inputs of every list in ONE launch in front of the chains instead of a
+  // launch per list on the list's chain.  Thirteen to eighteen launches of a few dozen microseconds less, but no k_poa
+  // starts before all of it is through: +1.1 % on the E. coli batch (rows in HBM, same box, two runs each), -1.8 % on
+  // the yeast -split batch, whose lists are half as large again.  Off.
+  const bool gather_all = use_pack && use_fused && n > n_generic && std::getenv("ELECTOR_GATHER_ALL") &&
+                          std::atoi(std::getenv("ELECTOR_GATHER_ALL")) != 0;
+  if (gather_all) {
+    static_assert(kGatherLists >= kSortDestMax, "one table entry per list");
+    GatherAllArgs gg;
+    gg.g.list = d_fused_lists; gg.g.nlist = n - n_generic;
+    gg.g.off = a.off; gg.g.sym = a.sym; gg.g.status = d_status;
+    gg.g.done_a = d_done_a; gg.g.done_b = d_done_b; gg.g.triv = d_triv;
+    gg.g.pdesc = c->d_pdesc.as<uint4>(); gg.g.psym = c->d_psym.as<uint32_t>(); gg.g.pstride = 0; gg.g.nlist_dev = nullptr;
+    gg.nb = 0;
+    for (int b = 0; b < kBins && gg.nb < kGatherLists; ++b)
+      if (bin_cnt[(size_t)b]) {
+        gg.first[gg.nb] = bin_first[(size_t)b]; gg.psym_first[gg.nb] = psym_first[(size_t)b]; gg.stride[gg.nb] = pstride[(size_t)b];
+        ++gg.nb;
+      }
+    gg.first[gg.nb] = n - n_generic;
+    timed_begin(c, 2, st);
+    launch_gather_all(gg, st);
+    timed_end(c, st);
+  }
   if (use_fused && n > n_generic) {
     HIPCHK(c, hipEventRecord(c->fork, st));
     const int used = n_used;                           // launch chains = auxiliary streams in use
@@ -1120,9 +1145,11 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         ga.psym = c->d_psym.as<uint32_t>() + psym_first[(size_t)b];
         ga.pstride = pstride[(size_t)b];
         ga.nlist_dev = nullptr;
-        timed_begin(c, 2, sx);
-        launch_gather(ga, sx);
-        timed_end(c, sx);
+        if (!gather_all) {
+          timed_begin(c, 2, sx);
+          launch_gather(ga, sx);
+          timed_end(c, sx);
+        }
         PackArgs pa;
         pa.b = a;
         pa.list = ga.list;

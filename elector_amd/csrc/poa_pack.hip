@@ -833,16 +833,35 @@ __device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *x
 struct PackDesc { uint32_t w, Lr, Lc, Lu; uint32_t o0_lo, o0_hi, triv_ok, pad; };   // triv | ok << 8
 
 
+// one entry's work: p = its index in list / pdesc, psym / pstride = its list's
+__device__ __forceinline__ void gather_entry(const GatherArgs &a, int64_t p, int g, uint32_t *psym, int pstride);
+
 __global__ void __launch_bounds__(256) k_gather(GatherArgs a)
 {
   const int64_t p = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
   const int g = threadIdx.x & 7;
   if (p >= a.nlist) return;
   if (a.nlist_dev && p >= (int64_t)*a.nlist_dev) return;                  // (k_poa reads the same count)
+  gather_entry(a, p, g, a.psym + p * (int64_t)a.pstride, a.pstride);
+}
+
+// every list of the batch at once (a launch per list was thirteen to eighteen launches of a few dozen microseconds)
+__global__ void __launch_bounds__(256) k_gather_all(GatherAllArgs a)
+{
+  const int64_t p = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int g = threadIdx.x & 7;
+  if (p >= a.g.nlist) return;
+  int k = 0;
+  while (k + 1 < a.nb && p >= a.first[k + 1]) ++k;
+  gather_entry(a.g, p, g, a.g.psym + a.psym_first[k] + (p - a.first[k]) * (int64_t)a.stride[k], a.stride[k]);
+}
+
+__device__ __forceinline__ void gather_entry(const GatherArgs &a, int64_t p, int g, uint32_t *dst, int pstride)
+{
   const uint32_t w = a.list[p];
   const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
   const int64_t total = o3 - o0;
-  const bool ok = a.status[w] == 0 && a.done_a[w] == 0 && a.done_b[w] == 0 && total <= 4 * (int64_t)a.pstride;
+  const bool ok = a.status[w] == 0 && a.done_a[w] == 0 && a.done_b[w] == 0 && total <= 4 * (int64_t)pstride;
   if (g == 0) {
     a.pdesc[2 * p] = make_uint4(w, (uint32_t)(o1 - o0), (uint32_t)(o2 - o1), (uint32_t)(o3 - o2));
     a.pdesc[2 * p + 1] = make_uint4((uint32_t)((uint64_t)o0 & 0xFFFFFFFFu), (uint32_t)((uint64_t)o0 >> 32),
@@ -852,7 +871,6 @@ __global__ void __launch_bounds__(256) k_gather(GatherArgs a)
   const uint8_t *src = a.sym + o0;
   const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
   const uint32_t *src4 = reinterpret_cast<const uint32_t *>(src - mis);
-  uint32_t *dst = a.psym + p * (int64_t)a.pstride;
   const int nd = (int)((total + 3) >> 2);
   for (int k = g; k < nd; k += 8) {
     // (d_sym is padded: the dword behind the window's last may be read)
@@ -865,6 +883,12 @@ void launch_gather(const GatherArgs &a, hipStream_t st)
 {
   if (a.nlist <= 0) return;
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((a.nlist + 31) / 32)), dim3(256), 0, st, a);
+}
+
+void launch_gather_all(const GatherAllArgs &a, hipStream_t st)
+{
+  if (a.g.nlist <= 0 || a.nb <= 0) return;
+  hipLaunchKernelGGL(k_gather_all, dim3((unsigned)((a.g.nlist + 31) / 32)), dim3(256), 0, st, a);
 }
 
 // ------------------------------------------------------------------------ k_poa ---

@@ -543,3 +543,9 @@ def test_first_call_of_a_fresh_process(split_lists):
     here = os.path.dirname(os.path.abspath(__file__))
     p = subprocess.run([sys.executable, os.path.join(here, "first_call_check.py")], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "differing 0" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_gather_in_one_launch(engine, monkeypatch):
+    """ELECTOR_GATHER_ALL=1: k_poa's inputs of all lists laid out by one launch (k_gather_all) instead of one per list"""
+    monkeypatch.setenv("ELECTOR_GATHER_ALL", "1")
+    check(engine, synth.window_triples(91, 4000, 7, 400) + synth.adversarial_triples(92, 600))
