@@ -95,6 +95,7 @@ struct BundleArgs {
 constexpr int kBundleClasses = 6;
 constexpr int kBundleCap[4] = {52, 69, 104, 208};
 constexpr int kBundleHbmPacked = 4, kBundleHbmWide = 5;
+constexpr int kBundleGlobalPct[4] = {50, 50, 50, 50};   // share of a class's blocks whose records live in HBM instead of LDS
 constexpr uint32_t kPxNone = 0xFFu;
 constexpr int kLdsSt = 65;                 // dwords between a lane's consecutive entries: a row of 64 lanes + 1 (staging
                                            // writes a window's entries from 64 lanes: stride 65 spreads them over the banks)
@@ -868,7 +869,13 @@ static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
     else {
       // ELECTOR_BUNDLE_GLOBAL_PCT: share of an LDS class's blocks that go through the same code on records in HBM
       // (E. coli batch: 7.5 ms with 0, 5.8 / 5.2 / 5.6 with 30 / 50 / 70, 6.1 with 100)
-      const int gpct = std::getenv("ELECTOR_BUNDLE_GLOBAL_PCT") ? std::max(0, std::min(100, std::atoi(std::getenv("ELECTOR_BUNDLE_GLOBAL_PCT")))) : 50;
+      // (one number for every class, or four separated by commas: the classes of 52 / 69 / 104 / 208 nodes)
+      int gpct = kBundleGlobalPct[q];
+      if (const char *e = std::getenv("ELECTOR_BUNDLE_GLOBAL_PCT")) {
+        int v[4] = {0, 0, 0, 0};
+        const int got = std::sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+        if (got >= 1) gpct = std::max(0, std::min(100, got == 4 ? v[q] : v[0]));
+      }
       const int ng = (int)((int64_t)cnt[q] * gpct / 100), nl = cnt[q] - ng;
       if (nl > 0 && (rc = launch_bundle_lds(a, q, nl, sx)) != 0) return elector_fail(c, ELECTOR_E_HIP, "k_bundle_lds attribute");
       if (ng > 0) {
