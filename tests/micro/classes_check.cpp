@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include "poa_classes.h"
 using namespace elector;
 int main()
@@ -32,6 +33,10 @@ int main()
         const int ci = wc.bin / kNT, t = wc.bin % kNT;
         const int need = std::max(fused_a_slot_need(lr, lc, cls_G(ci), cls_R(ci)), fused_b_slot_need(lr + lr / 16 + 6, lu, cls_G(ci), cls_R(ci)));
         if (tier_bytes(t) < need || tier_bytes(t) > class_max_slot(ci) || (t > 0 && tier_bytes(t - 1) >= need)) { std::printf("slot %d %d %d\n", lr, lc, lu); return 1; }
+        // k_poa's slot needs: what the classification hands the host is what the kernel's fit test computes, and a
+        // window that skips alignment #1 (no index maps, records for Lr + 1 nodes) never needs more than one that runs it
+        if (wc.need_pack != poa_slot_need(lr, lc, lu, cls_G(ci)) || wc.need_triv != poa_slot_need_triv(lr, lc, lu, cls_G(ci)) ||
+            (std::abs(lr - lc) <= 1 && wc.need_triv > wc.need_pack)) { std::printf("k_poa slot %d %d %d\n", lr, lc, lu); return 1; }
         if (ci > 0 && cls_G(ci - 1) * cls_R(ci - 1) >= std::max(lc, lu) && wc.bin >= 0) {
           // an earlier class would have been tall enough: it must have been refused for its slot or its score range
           const int pg = cls_G(ci - 1), pr = cls_R(ci - 1);
