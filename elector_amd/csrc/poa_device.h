@@ -144,12 +144,6 @@ struct PackArgs {
   int32_t *far_count;       // group's k_poa<G, 8, true> launch takes them (far_cap entries; what does not fit goes to `hand`)
   int far_cap;
   const int32_t *nlist_dev; // when set: the list length lives on the device (a far list), nlist is its capacity
-  // A list in two launches.  Its first *split_dev entries run alignment #1, the rest have a shortcut graph (corrected
-  // sequence within one edit of the reference) and need neither index maps nor records for more than Lr + 1 nodes:
-  // part 1 = the head up to the split rounded up to whole wavefronts, part 2 = the tail with a smaller LDS slot (more
-  // wavefronts per CU).  Both are launched over the whole list; the blocks outside their part leave at once.  part 0 = all.
-  const int32_t *split_dev;
-  int part;
   int debug;
   unsigned long long *stamps;
 };
@@ -166,17 +160,6 @@ struct GatherArgs {
   uint32_t *psym;
   int pstride;               // dwords per entry
   const int32_t *nlist_dev;  // when set: the list length lives on the device (a far list), nlist is its capacity
-};
-
-// k_gather for all lists of a batch in ONE launch: the lists lie back to back (entry i of the batch's fused-routed
-// windows; descriptors at the same index), only the symbols' place and stride differ from list to list
-constexpr int kGatherLists = 40;           // (= kSortDestMax of poa_classes.h: the lists a batch may have)
-struct GatherAllArgs {
-  GatherArgs g;                            // list / pdesc / psym = the arrays' starts, nlist = all entries
-  int nb;
-  int64_t first[kGatherLists + 1];         // first entry of list k (ascending); first[nb] = nlist
-  int64_t psym_first[kGatherLists];        // dwords
-  int32_t stride[kGatherLists];
 };
 
 // Long windows (the reference's whole-read fallback) are cut into tiles of one strip of 63 rows by

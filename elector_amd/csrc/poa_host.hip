@@ -56,7 +56,6 @@ struct FusedArgs {
   int64_t grid_blocks;
 };
 void launch_gather(const GatherArgs &a, hipStream_t st);
-void launch_gather_all(const GatherAllArgs &a, hipStream_t st);
 int launch_poa(const PackArgs &a, int G, int R, hipStream_t st);
 int launch_poa_far(const PackArgs &a, int G, hipStream_t st);
 bool poa_debug_built();
@@ -716,9 +715,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     return blocks * *ns * *tw * 64 * fused_mv_bytes(R);
   };
   // k_poa: LDS slot, moves geometry and scratch-slot pool of a bin
-  struct PackGeom { int slot, slot_tail, tw, slots; int64_t pool_words; };
-  // ELECTOR_POA_SPLIT=1 (experiment, see pack_geom): a list's tail of shortcut graphs as a launch of its own
-  const bool split_lists = std::getenv("ELECTOR_POA_SPLIT") && std::atoi(std::getenv("ELECTOR_POA_SPLIT")) != 0;
+  struct PackGeom { int slot, tw, slots; int64_t pool_words; };
   auto pack_geom = [&](int b) {
     const int G = cls_G(b / kNT), nw = 2 * (64 / G);
     PackGeom pg;
@@ -726,41 +723,15 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     // ELECTOR_POA_SLOT_PCT (experiment): the slot inflated to that many percent -- what the occupancy is worth
     static const int slot_pct = std::getenv("ELECTOR_POA_SLOT_PCT") ? std::max(100, std::atoi(std::getenv("ELECTOR_POA_SLOT_PCT"))) : 100;
     pg.slot = (int)std::min<int64_t>(max_slot, ((bin_need_pack[b] * slot_pct / 100) + 15) & ~(int64_t)15);
-    // LDS banks: the lane groups of a wavefront read the same index of their windows' arrays in one instruction, group q
-    // at q x (2 slots).  A half-wavefront is four groups of 8 lanes (two of 16): their 8 (16) consecutive dwords fall on
-    // 32 different banks when two slots are 8 (16) dwords off a multiple of 32 -- slot = 16 mod 32 bytes (32 mod 64).
-    // With slots of any multiple of 16 bytes half of the launches have 2- to 8-way conflicts on every such read
-    // (SQ_LDS_BANK_CONFLICT above SQ_INSTS_LDS).  Measured (ELECTOR_POA_SLOT_BANKS=1): conflict cycles -36 %, but the
-    // wavefronts never wait for the LDS pipeline (SQ_WAIT_INST_LDS 0.13 % of their cycles) and the 16-48 bytes a slot
-    // grows by cost more occupancy than the conflicts cost time: k_poa +2 % on the yeast -split batch.  Off by default.
-    static const bool banks = std::getenv("ELECTOR_POA_SLOT_BANKS") && std::atoi(std::getenv("ELECTOR_POA_SLOT_BANKS")) != 0;
-    if (banks && (G == 8 || G == 16)) {
-      const int mod = G == 8 ? 32 : 64, want = mod / 2;
-      int sl = pg.slot + ((want - pg.slot % mod) + mod) % mod;
-      if (sl <= max_slot) pg.slot = sl;
-    }
+    // (Slots sized for the LDS banks -- 16 mod 32 bytes for the 8-lane classes, 32 mod 64 for the 16-lane ones -- took a
+    // third off the bank-conflict cycles and made k_poa 0.5-2 % slower: the wavefronts never wait for the LDS pipeline and
+    // the bytes a slot grows by cost occupancy.  A list in two launches, its shortcut-graph windows with a third less LDS,
+    // lost 1-3 % to the second launch's ramp and tail.  Both measured in round 4; neither is kept.)
     pg.tw = (int)bin_max_po[b] + 8 + G + 4;
-    // The windows of a list that have a shortcut graph (nine in ten on the bench batch) come behind those that run
-    // alignment #1 and need a third less LDS (no index maps, records for Lr + 1 nodes).  With ELECTOR_POA_SPLIT=1 the
-    // list's tail is a launch of its own (PackArgs::part) where that buys another wavefront per CU below the register
-    // cap: 13 -> 16 wavefronts per CU in G16xR6, 9 -> 12 in G16xR8.  Measured (three rotating batches, two runs each):
-    // E. coli -3 %, yeast -split -1 % (-2 % with the rows left in HBM), 50 kb reads -1 % -- the second launch's ramp and
-    // tail cost more than the occupancy gives.  Off by default.
-    pg.slot_tail = 0;
-    {
-      const int R = cls_R(b / kNT), reg_cap = 4 * (R <= 6 ? 4 : 3);                        // (k_poa's launch bounds)
-      const int st = (int)std::min<int64_t>(max_slot, (bin_need_triv[b] + 15) & ~(int64_t)15);
-      auto waves = [&](int slot) { return std::min(reg_cap, (160 * 1024) / (64 + nw * slot)); };
-      if (split_lists && use_trivial && bin_need_triv[b] > 0 && st < pg.slot && waves(st) > waves(pg.slot)) pg.slot_tail = st;
-    }
-    const int lds_block = 64 + nw * (pg.slot_tail ? pg.slot_tail : pg.slot);
+    const int lds_block = 64 + nw * pg.slot;
     const int waves_cu = std::max(1, std::min(32, (160 * 1024) / lds_block));
     pg.slots = 32 * waves_cu + 8;                                  // per XCD: 32 CUs, every wave they can hold, and a margin
     pg.pool_words = (int64_t)8 * pg.slots * pg.tw * 64;
-    if (std::getenv("ELECTOR_POA_BLOCKSCRATCH")) {                 // experiment: one region per block
-      pg.slots = 0;
-      pg.pool_words = ((bin_cnt[(size_t)b] + nw - 1) / nw) * (int64_t)pg.tw * 64;
-    }
     return pg;
   };
   int64_t pool_stream[4] = {0, 0, 0, 0};
@@ -833,7 +804,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // graphs with ONE far edge (a corrected piece that aligns at both ends of its window, an indel of two or more letters)
   // stay in k_poa: a launch of their own per lane-group size behind the group's bins.  ELECTOR_NO_FAR=1: the two-kernel
   // path and the generic kernels take them, as up to round 3 (A/B)
-  const bool use_far = merge_hand && !std::getenv("ELECTOR_NO_FAR") && n_chains <= 3 && !std::getenv("ELECTOR_POA_BLOCKSCRATCH");
+  const bool use_far = merge_hand && !std::getenv("ELECTOR_NO_FAR") && n_chains <= 3;
   if (merge_hand) {
     for (int b = 0; b < kBins; ++b) {
       if (!bin_cnt[(size_t)b]) continue;
@@ -871,7 +842,6 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         const int sk = stream_of(b);
         pool_slots[sk] = std::max(pool_slots[sk], pg.slots);
         pool_tw[sk] = std::max(pool_tw[sk], pg.tw);
-        pool_stream[sk] = std::max(pool_stream[sk], pg.pool_words);      // (block-scratch experiment)
       }
     }
   if (use_far)
@@ -892,7 +862,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       pool_slots[hg.far_pool] = std::max(pool_slots[hg.far_pool], 32 * waves_cu + 8);
       pool_tw[hg.far_pool] = std::max(pool_tw[hg.far_pool], hg.far_tw);
     }
-  if (use_pack && !std::getenv("ELECTOR_POA_BLOCKSCRATCH"))
+  if (use_pack)
     for (int k = 0; k < 4; ++k) pool_stream[k] = (int64_t)8 * pool_slots[k] * pool_tw[k] * 64;
   for (int k = 0; k < 4; ++k) fmv_stream[k] = (fmv_stream[k] + 255) & ~(int64_t)255;
 
@@ -1082,30 +1052,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   const uint32_t *d_fused_lists = use_trivial ? d_lists2 : d_lists;
 
   // ---- fused classes: launch chains on the auxiliary streams (A then B of each bin) ----
-  // ELECTOR_GATHER_ALL=1 (experiment): k_poa's inputs of every list in ONE launch in front of the chains instead of a
-  // launch per list on the list's chain.  Thirteen to eighteen launches of a few dozen microseconds less, but no k_poa
-  // starts before all of it is through: +1.1 % on the E. coli batch (rows in HBM, same box, two runs each), -1.8 % on
-  // the yeast -split batch, whose lists are half as large again.  Off.
-  const bool gather_all = use_pack && use_fused && n > n_generic && std::getenv("ELECTOR_GATHER_ALL") &&
-                          std::atoi(std::getenv("ELECTOR_GATHER_ALL")) != 0;
-  if (gather_all) {
-    static_assert(kGatherLists >= kSortDestMax, "one table entry per list");
-    GatherAllArgs gg;
-    gg.g.list = d_fused_lists; gg.g.nlist = n - n_generic;
-    gg.g.off = a.off; gg.g.sym = a.sym; gg.g.status = d_status;
-    gg.g.done_a = d_done_a; gg.g.done_b = d_done_b; gg.g.triv = d_triv;
-    gg.g.pdesc = c->d_pdesc.as<uint4>(); gg.g.psym = c->d_psym.as<uint32_t>(); gg.g.pstride = 0; gg.g.nlist_dev = nullptr;
-    gg.nb = 0;
-    for (int b = 0; b < kBins && gg.nb < kGatherLists; ++b)
-      if (bin_cnt[(size_t)b]) {
-        gg.first[gg.nb] = bin_first[(size_t)b]; gg.psym_first[gg.nb] = psym_first[(size_t)b]; gg.stride[gg.nb] = pstride[(size_t)b];
-        ++gg.nb;
-      }
-    gg.first[gg.nb] = n - n_generic;
-    timed_begin(c, 2, st);
-    launch_gather_all(gg, st);
-    timed_end(c, st);
-  }
+  // (k_poa's inputs of every list in ONE launch in front of the chains instead of a launch per list on the list's chain was
+  // +1 % on the E. coli batch and -2 % on the yeast -split batch -- no k_poa starts before the whole pass is through --
+  // and is not kept: DESIGN.md section 4.2.)
   if (use_fused && n > n_generic) {
     HIPCHK(c, hipEventRecord(c->fork, st));
     const int used = n_used;                           // launch chains = auxiliary streams in use
@@ -1121,7 +1070,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       const int sk = stream_of(b);
       hipStream_t sx = c->aux[sk];
       const int fdebug = std::getenv("ELECTOR_DEBUG_FUSED") ? std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) : 0;
-      if (use_pack && (fdebug & (4 | 8 | 32 | 64 | 128 | 256 | 1024 | 2048)) && !poa_debug_built()) {
+      if (use_pack && (fdebug & (4 | 8 | 32 | 64 | 128 | 256)) && !poa_debug_built()) {
         static std::atomic<bool> told{false};
         if (!told.exchange(true))
           std::fprintf(stderr, "[elector] ELECTOR_DEBUG_FUSED=%d: k_poa was built without its debug branches; rebuild with "
@@ -1145,11 +1094,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         ga.psym = c->d_psym.as<uint32_t>() + psym_first[(size_t)b];
         ga.pstride = pstride[(size_t)b];
         ga.nlist_dev = nullptr;
-        if (!gather_all) {
-          timed_begin(c, 2, sx);
-          launch_gather(ga, sx);
-          timed_end(c, sx);
-        }
+        timed_begin(c, 2, sx);
+        launch_gather(ga, sx);
+        timed_end(c, sx);
         PackArgs pa;
         pa.b = a;
         pa.list = ga.list;
@@ -1165,7 +1112,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         for (int k = 0; k < sk; ++k) pa.mv_pool += pool_stream[k];
         pa.mv_tw = pg.tw;
         pa.mv_q = c->d_mvbusy.as<int32_t>() + (size_t)sk * 8 * kPoolStride;
-        pa.mv_slots = pg.slots > 0 ? pool_slots[sk] : 0;
+        pa.mv_slots = pool_slots[sk];
         pa.hand = d_hand_list;
         pa.hand_count = d_hand_cnt;
         const int gi = bG == 8 ? 0 : bG == 16 ? 1 : bG == 32 ? 2 : 3;
@@ -1173,17 +1120,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         pa.far_count = use_far && hg ? reinterpret_cast<int32_t *>(c->d_far.as<uint32_t>() + n) + gi : nullptr;
         pa.far_cap = use_far && hg ? (int)hg->far_cap : 0;
         pa.nlist_dev = nullptr;
-        pa.split_dev = pg.slot_tail ? d_bin_a1 + bin_slot[(size_t)b] : nullptr;
-        pa.part = pg.slot_tail ? 1 : 0;
         pa.debug = fdebug;
         pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b) + 16;
         timed_begin(c, 4, sx);
         if (launch_poa(pa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
-        if (pg.slot_tail) {
-          pa.part = 2;
-          pa.slot_bytes = pg.slot_tail;
-          if (launch_poa(pa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
-        }
         timed_end(c, sx);
       }
       // behind k_poa the two-kernel path only sees the windows handed back: its small launches go to a stream
@@ -1236,7 +1176,6 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           pa.hand = d_hand_list;
           pa.hand_count = d_hand_cnt;
           pa.far = nullptr; pa.far_count = nullptr; pa.far_cap = 0;
-          pa.split_dev = nullptr; pa.part = 0;
           pa.debug = fdebug & ~(32 | 64 | 128 | 256);
           pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)hb) + 16;
           timed_begin(c, 6, sg);
@@ -1426,12 +1365,12 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     std::fprintf(stderr, "\n");
     std::vector<int32_t> ha((size_t)kBins, 0);
     (void)hipMemcpy(ha.data(), d_bin_a1, (size_t)nbins_used * 4, hipMemcpyDeviceToHost);
-    std::fprintf(stderr, "[elector] k_poa lists (windows that run alignment #1 / all, LDS slot, slot of the tail launch):");
+    std::fprintf(stderr, "[elector] k_poa lists (windows that run alignment #1 / all, LDS slot):");
     for (int b = 0; b < kBins; ++b)
       if (bin_cnt[(size_t)b]) {
         const auto pg = pack_geom(b);
-        std::fprintf(stderr, " G%dxR%d:%d/%lld,%d,%d", cls_G(b / kNT), cls_R(b / kNT), ha[(size_t)bin_slot[(size_t)b]], (long long)bin_cnt[(size_t)b],
-                     pg.slot, pg.slot_tail);
+        std::fprintf(stderr, " G%dxR%d:%d/%lld,%d", cls_G(b / kNT), cls_R(b / kNT), ha[(size_t)bin_slot[(size_t)b]], (long long)bin_cnt[(size_t)b],
+                     pg.slot);
       }
     std::fprintf(stderr, "\n");
   }

@@ -138,16 +138,77 @@ __device__ __forceinline__ int med3(int x, int lo, int hi)
   return d;
 }
 
-__device__ __forceinline__ int dpp_row_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xF, 0xF, false); }
-__device__ __forceinline__ int dpp_wave_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xF, 0xF, false); }
+// ------------------------------------------------------------------ lane groups ---
+// A pair of windows is worked on by a group of G lanes.  G = 16 .. 64: lanes q G .. q G + G - 1.  G = 8: the two groups
+// of a DPP row of 16 lanes are INTERLEAVED -- lane 16 r + 2 g + p is lane g of group 2 r + p -- so that "the lane
+// above" is row_shr:2, which leaves the row's first two lanes (the two groups' first lanes) with the border value they
+// hold: one instruction per shift, as for G = 16 (row_shr:1) and G = 64 (wave_shr:1).  With contiguous groups of 8 the
+// second group's first lane received its neighbour's value and every shift needed a select behind it.
+template <int G>
+struct LG {
+  static __device__ __forceinline__ int q(int lane) { return G == 8 ? ((lane >> 4) << 1) | (lane & 1) : lane / G; }
+  static __device__ __forceinline__ int g(int lane) { return G == 8 ? (lane >> 1) & 7 : lane & (G - 1); }
+  // lane gg of the group `lane` belongs to
+  static __device__ __forceinline__ int lane_of(int lane, int gg) { return G == 8 ? (lane & ~0xE) | (gg << 1) : (lane & ~(G - 1)) | gg; }
+};
 
-// value of the lane above inside a group of G lanes; the group's first lane gets `border`
+// DPP move: lanes without a source (or outside row mask RM) keep `old`
+template <int CTRL, int RM = 0xF>
+__device__ __forceinline__ int dpp_mov(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xF, false); }
+constexpr int kRowShr = 0x110, kRowShl = 0x100, kWaveShr1 = 0x138, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+
+// value of lane g - D of the group; a lane with g < D keeps its own (the scans' __shfl_up): one DPP move for G = 8, 16
+template <int G, int D>
+__device__ __forceinline__ int grp_up(int v)
+{
+  if constexpr (G == 8) return dpp_mov<kRowShr + 2 * D>(v, v);
+  else if constexpr (G == 16) return dpp_mov<kRowShr + D>(v, v);
+  else return __shfl_up(v, D, G);
+}
+// value of lane g + D of the group; own value where g + D >= G
+template <int G, int D>
+__device__ __forceinline__ int grp_down(int v)
+{
+  if constexpr (G == 8) return dpp_mov<kRowShl + 2 * D>(v, v);
+  else if constexpr (G == 16) return dpp_mov<kRowShl + D>(v, v);
+  else return __shfl_down(v, D, G);
+}
+// value of lane src of the group
+template <int G>
+__device__ __forceinline__ int grp_get(int v, int src, int lane) { return __shfl(v, LG<G>::lane_of(lane, src)); }
+// value of lane g ^ d of the group
+template <int G>
+__device__ __forceinline__ int grp_xor(int v, int d) { return G == 8 ? __shfl_xor(v, 2 * d) : __shfl_xor(v, d, G); }
+
+// f(integral_constant<int, 1>), f(<2>), f(<4>) ... below G: the distances of a scan over the group's lanes
+template <int G, int D = 1, class F>
+__device__ __forceinline__ void for_pow2_below(F &&f)
+{
+  if constexpr (D < G) {
+    f(std::integral_constant<int, D>{});
+    for_pow2_below<G, 2 * D>(f);
+  }
+}
+
+// maximum over the wavefront, uniform (six DPP moves and a readlane instead of ds_bpermute round trips)
+__device__ __forceinline__ int wave_max(int v)
+{
+  v = max(v, dpp_mov<kRowShr + 1>(v, v));
+  v = max(v, dpp_mov<kRowShr + 2>(v, v));
+  v = max(v, dpp_mov<kRowShr + 4>(v, v));
+  v = max(v, dpp_mov<kRowShr + 8>(v, v));
+  v = max(v, dpp_mov<kRowBcast15, 0xA>(v, v));
+  v = max(v, dpp_mov<kRowBcast31, 0xC>(v, v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// value of the lane above inside the group; the group's first lane gets `border`
 template <int G>
 __device__ __forceinline__ uint32_t pk_shift_in(uint32_t border, uint32_t v, int g)
 {
-  if (G == 16) return (uint32_t)dpp_row_shr1((int)border, (int)v);
-  if (G == 8) { const uint32_t r = (uint32_t)dpp_row_shr1((int)border, (int)v); return g == 0 ? border : r; }
-  const uint32_t r = (uint32_t)dpp_wave_shr1((int)border, (int)v);
+  if (G == 16) return (uint32_t)dpp_mov<kRowShr + 1>((int)border, (int)v);
+  if (G == 8) return (uint32_t)dpp_mov<kRowShr + 2>((int)border, (int)v);
+  const uint32_t r = (uint32_t)dpp_mov<kWaveShr1>((int)border, (int)v);
   return (G < 64 && g == 0) ? border : r;
 }
 
@@ -163,16 +224,21 @@ __device__ __forceinline__ int pk_align_up(int x, int a) { return (x + a - 1) & 
 // Moves layout: [step t][64 lanes], one coalesced 256-byte row per DP step.  (A layout that keeps four steps of a
 // lane group in one 128-byte line -- [group][t / 4][lane][t % 4], written from a four-step register buffer -- halves
 // the traceback's L2 requests but costs four v_cndmask per step; the kernel is bound by VALU issue, and it was 3 %
-// slower on the bench batch.)
+// slower on the bench batch.)  l: lane of the group that holds the cell's row.
 template <int G>
-__device__ __forceinline__ int mv_word(int q, int t, int l) { return t * 64 + q * G + l; }
+__device__ __forceinline__ int mv_word(int lane, int t, int l) { return t * 64 + LG<G>::lane_of(lane, l); }
 
+// leading lanes of the group (from g = 0) whose flag is set
 template <int G>
-__device__ __forceinline__ int pk_diag_run(bool flag, int q)
+__device__ __forceinline__ int pk_diag_run(bool flag, int lane)
 {
   const unsigned long long bm = __builtin_amdgcn_ballot_w64(flag);
   if (G == 64) return ~bm == 0ull ? 64 : __builtin_ctzll(~bm);
-  const unsigned long long gm = (bm >> (q * G)) & ((1ull << (G & 63)) - 1);
+  if (G == 8) {
+    const uint32_t gm = (uint32_t)(bm >> (lane & 0x31)) & 0x5555u;     // the group's eight bits, two apart
+    return __builtin_ctz((~gm & 0x5555u) | 0x10000u) >> 1;
+  }
+  const unsigned long long gm = (bm >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1);
   return __builtin_ctzll(~gm | (1ull << (G & 63)));
 }
 
@@ -231,7 +297,7 @@ constexpr bool kPoaDebug = ELECTOR_POA_DEBUG != 0;
 // match (diagonal), bit 0 = x-insertion beats y-insertion; window half h of the word at [step][lane].  Both
 // windows of the lane group walk in lockstep: a round is one trip to the moves scratch (L2) for the two of them.
 template <int G, int R, typename IT>
-__device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&need)[2], const uint32_t *mv, int q, int g,
+__device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&need)[2], const uint32_t *mv, int lane, int g,
                                             IT *(&x2y)[2])
 {
   int x[2], y[2], guard[2];
@@ -248,7 +314,7 @@ __device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&nee
       inb[h] = alive[h] && cx[h] >= 0 && cy[h] >= 0;
       const int rl = inb[h] ? cy[h] / R : 0;
       rk[h] = cy[h] - rl * R;
-      word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(q, cx[h] + 1 + rl, rl) : 0));     // unconditional: both in flight
+      word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(lane, cx[h] + 1 + rl, rl) : 0));  // unconditional: both in flight
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -258,12 +324,12 @@ __device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&nee
         const int m = two >> 1, xw = two & 1;
         xo = m | xw; yo = m | (xw ^ 1);
       }
-      const int run = pk_diag_run<G>(inb[h] && xo && yo, q);
+      const int run = pk_diag_run<G>(inb[h] && xo && yo, lane);
       if (g < run) x2y[h][cx[h]] = (IT)cy[h];
       // where the walk goes on, from the lane at the end of the run: one shuffle for (x, y, stop)
       int nx = cx[h] - xo, ny = cy[h] - yo, fl = inb[h] ? 0 : 1;
       const int src = min(run, G - 1);
-      const int nxt = __shfl(((nx + 2) & 0xFFF) | (((ny + 2) & 0xFFF) << 12) | (fl << 24), src, G);
+      const int nxt = grp_get<G>(((nx + 2) & 0xFFF) | (((ny + 2) & 0xFFF) << 12) | (fl << 24), src, lane);
       nx = (nxt & 0xFFF) - 2; ny = ((nxt >> 12) & 0xFFF) - 2; fl = nxt >> 24;
       if (run >= G) { nx = x[h] - G; ny = y[h] - G; fl = 0; }
       if (alive[h]) {
@@ -280,7 +346,7 @@ __device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&nee
 // FAR: the kernel instance that holds ONE far edge per window (the column of its source node is kept aside by the
 // dynamic program); the others report such a graph through *far_out and do not take it.
 template <int G, typename IT, bool FAR>
-__device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, const uint8_t *ys, IT *x2y,
+__device__ __forceinline__ bool fusion_1(WinP &W, int lane, int g, const uint8_t *xs, const uint8_t *ys, IT *x2y,
                                          uint32_t *xinfo, bool *bad_out, bool *far_out, int *why)
 {
   constexpr int kNoneI = (int)(IT)~(IT)0;                               // "not aligned" in the index type of this class
@@ -291,13 +357,7 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
   IT *node_cor = node_ref + ((Lr + 1) & ~1);
   IT *y2x = node_cor + ((Lc + 1) & ~1);
   const int cx = (Lr + G - 1) / G, cy = (Lc + G - 1) / G;               // letters per lane
-  int cxmax = on ? cx : 0, cymax = on ? cy : 0;
-  for (int d = G; d < 64; d <<= 1) {
-    cxmax = max(cxmax, __shfl_xor(cxmax, d));
-    cymax = max(cymax, __shfl_xor(cymax, d));
-  }
-  cxmax = __builtin_amdgcn_readfirstlane(cxmax);
-  cymax = __builtin_amdgcn_readfirstlane(cymax);
+  const int cxmax = wave_max(on ? cx : 0), cymax = wave_max(on ? cy : 0);
   if (on) for (int i = g; i < Lc; i += G) y2x[i] = (IT)kNoneI;
   __builtin_amdgcn_wave_barrier();
   const int x0 = g * cx, x1 = on ? min(Lr, x0 + cx) : 0;
@@ -316,12 +376,13 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
     }
   }
   int sp = pmax, sf = fcnt;
-  for (int d = 1; d < G; d <<= 1) {
-    const int tp = __shfl_up(sp, d, G), tf = __shfl_up(sf, d, G);
+  for_pow2_below<G>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    const int tp = grp_up<G, d>(sp), tf = grp_up<G, d>(sf);
     if (g >= d) { sp = max(sp, tp); sf += tf; }
-  }
-  const int fused_all = __shfl(sf, G - 1, G);
-  int P = __shfl_up(sp, 1, G), F = sf - fcnt;
+  });
+  const int fused_all = grp_get<G>(sf, G - 1, lane);
+  int P = grp_up<G, 1>(sp), F = sf - fcnt;
   if (g == 0) P = 0;
   if (pmax > 0 && x1 > x0) {
     int first = 0;
@@ -347,12 +408,13 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
     }
   }
   int sfy = fy, sfx = klow;
-  for (int d = 1; d < G; d <<= 1) {
-    const int tf = __shfl_up(sfy, d, G), tk = __shfl_down(sfx, d, G);
+  for_pow2_below<G>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    const int tf = grp_up<G, d>(sfy), tk = grp_down<G, d>(sfx);
     if (g >= d) sfy += tf;
     if (g + d < G && sfx == kUndef) sfx = tk;
-  }
-  int K = __shfl_down(sfx, 1, G), fy_run = sfy;
+  });
+  int K = grp_down<G, 1>(sfx), fy_run = sfy;
   if (g == G - 1 || K == kUndef) K = Lr;
   for (int it = 0; it < cymax; ++it) {
     const int y = y1 - 1 - it;
@@ -421,10 +483,10 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int g, const uint8_t *xs, cons
     }
   }
   for (int d = 1; d < G; d <<= 1) {
-    maxd = max(maxd, __shfl_xor(maxd, d, G));
-    bad = bad || __shfl_xor(bad ? 1 : 0, d, G) != 0;
-    nfar += __shfl_xor(nfar, d, G);
-    fsrc = max(fsrc, __shfl_xor(fsrc, d, G));
+    maxd = max(maxd, grp_xor<G>(maxd, d));
+    bad = bad || grp_xor<G>(bad ? 1 : 0, d) != 0;
+    nfar += grp_xor<G>(nfar, d);
+    fsrc = max(fsrc, grp_xor<G>(fsrc, d));
   }
   if (on) W.n1 = n1;
   *bad_out = bad;
@@ -471,7 +533,7 @@ __device__ __forceinline__ void trivial_graph(WinP &W, int g, const uint8_t *xs,
   const int Lc = W.Lc, nm = min(L, Lc);
   int e = nm;
   for (int i = g; i < nm && i < e; i += G) if (xs[i] != ys[i]) e = i;
-  for (int d = 1; d < G; d <<= 1) e = min(e, __shfl_xor(e, d, G));
+  for (int d = 1; d < G; d <<= 1) e = min(e, grp_xor<G>(e, d));
   if (W.triv == 3) {
     // one deleted letter, reference letter e (k_trivial): the chain of the reference with letter e on its own;
     // the node after it has the corrected read's edge from two nodes back as its second predecessor -- or, when
@@ -579,68 +641,12 @@ __device__ __noinline__ int pk_columns_serial(int n1, int Lu, const uint32_t *xi
 // traceback of alignment #2 (align_lpo_po2.c:108-168), G cells per round: a cell keeps the walk on its
 // diagonal when it is a match whose chosen predecessor is the node right before it.  Both windows of the lane
 // group in lockstep, as in traceback_a.
-template <int G, int R>
-__device__ __forceinline__ void traceback_b(const WinP (&W)[2], const uint32_t *mv, int q, int g, uint32_t *(&xinfo)[2],
-                                            uint8_t *(&ordb)[2], uint16_t *(&x2y)[2], const int (&bestx)[2],
-                                            bool (&bad)[2], int &rounds)
-{
-  int x[2], y[2], guard[2];
-  bool alive[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    x[h] = W[h].valid ? bestx[h] : -1; y[h] = W[h].Lu - 1; guard[h] = W[h].n1 + W[h].Lu + 2; alive[h] = W[h].valid;
-    bad[h] = false;
-  }
-  while (__builtin_amdgcn_ballot_w64(alive[0] || alive[1]) != 0) {
-    ++rounds;
-    int cx[2], cy[2], rk[2], rlv[2];
-    bool inb[2];
-    uint32_t word[2], rec[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      cx[h] = x[h] - g; cy[h] = y[h] - g;
-      inb[h] = alive[h] && cx[h] >= 0 && cy[h] >= 0;
-      const int rl = inb[h] ? cy[h] / R : 0;
-      rlv[h] = rl; rk[h] = cy[h] - rl * R;
-      word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(q, cx[h] + 1 + rl, rl) : 0));
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) rec[h] = inb[h] ? xinfo[h][cx[h] + 1] : 0u;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int xo = 0, yo = 0, px = cx[h];
-      if (inb[h]) {
-        const uint32_t two = (word[h] >> (16 * h + 2 * rk[h])) & 3u;
-        const int m = two >> 1, xw = two & 1;
-        xo = m | xw; yo = m | (xw ^ 1);
-        if (xo) {
-          const int sec = (rec[h] & kN_Has2) ? (ordb[h][(rec[h] >> 24) * G + rlv[h]] >> rk[h]) & 1 : 0;
-          const int far = sec ? (int)((rec[h] >> 1) & 1u) : (int)(rec[h] & 1u);
-          px = cx[h] - 1 - far;                                        // < 0: the virtual start
-          if (px < -1 || (!sec && (rec[h] & kN_Virt1))) px = -1;
-        }
-      }
-      const int run = pk_diag_run<G>(inb[h] && xo && yo && px == cx[h] - 1, q);
-      if (inb[h] && xo && yo && g <= run) x2y[h][cx[h]] = (uint16_t)cy[h];   // the run's pairs, and the breaker's if it is a match
-      int nx = px, ny = cy[h] - yo, fl = inb[h] ? 0 : 1;
-      const int src = min(run, G - 1);
-      const int nxt = __shfl(((nx + 2) & 0xFFF) | (((ny + 2) & 0xFFF) << 12) | (fl << 24), src, G);
-      nx = (nxt & 0xFFF) - 2; ny = ((nxt >> 12) & 0xFFF) - 2; fl = nxt >> 24;
-      if (run >= G) { nx = x[h] - G; ny = y[h] - G; fl = 0; }
-      if (alive[h]) {
-        x[h] = nx; y[h] = ny;
-        if ((fl & 1) || --guard[h] <= 0) { if (guard[h] <= 0) bad[h] = true; alive[h] = false; }
-      }
-    }
-  }
-}
-
-// The same walk with the per-lane work of a round as straight code: everything is computed for every lane on
-// clamped addresses and merged with selects; the one rarely needed look-up (which of two predecessors a cell took:
-// one node per window has two) sits behind a wave-wide test.  The compiler turned the nested conditions of
-// traceback_b into some 250 instructions per round, most of them exec-mask bookkeeping.
+// The per-lane work of a round is straight code: everything is computed for every lane on clamped addresses and merged
+// with selects; the one rarely needed look-up (which of two predecessors a cell took: one node per window has two) sits
+// behind a wave-wide test.  (With nested conditions a round was some 250 instructions, most of them exec-mask
+// bookkeeping.)
 template <int G, int R, bool FAR>
-__device__ __forceinline__ void traceback_b2(const WinP (&W)[2], const uint32_t *mv, int q, int g, uint32_t *(&xinfo)[2],
+__device__ __forceinline__ void traceback_b2(const WinP (&W)[2], const uint32_t *mv, int lane, int g, uint32_t *(&xinfo)[2],
                                              uint8_t *(&ordb)[2], uint16_t *(&x2y)[2], const int (&bestx)[2],
                                              bool (&bad)[2], int &rounds)
 {
@@ -663,7 +669,7 @@ __device__ __forceinline__ void traceback_b2(const WinP (&W)[2], const uint32_t 
       const int cyc = inb[h] ? cy[h] : 0, cxc = inb[h] ? cx[h] : -1;
       const int rl = cyc / R;
       rlv[h] = rl; rk[h] = cyc - rl * R;
-      word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(q, cxc + 1 + rl, rl) : 0));
+      word[h] = ld_moves(mv + (inb[h] ? mv_word<G>(lane, cxc + 1 + rl, rl) : 0));
       rec[h] = xinfo[h][cxc + 1];                                        // record 0 is the zero guard
     }
     // which of two predecessors: only cells at the (rare) two-predecessor nodes that step along x ask
@@ -693,10 +699,10 @@ __device__ __forceinline__ void traceback_b2(const WinP (&W)[2], const uint32_t 
       }
       px = xo ? (virt ? -1 : px) : cx[h];
       const bool diag = xo && yo;                                      // (inb is in both)
-      const int run = pk_diag_run<G>(diag && px == cx[h] - 1, q);
+      const int run = pk_diag_run<G>(diag && px == cx[h] - 1, lane);
       if (diag && g <= run) x2y[h][cx[h]] = (uint16_t)cy[h];           // the run's pairs, and the breaker's if it is a match
       const int nxp = ((px + 2) & 0xFFF) | (((cy[h] - yo + 2) & 0xFFF) << 12) | (inb[h] ? 0 : 1 << 24);
-      const int nxt = __shfl(nxp, min(run, G - 1), G);
+      const int nxt = grp_get<G>(nxp, min(run, G - 1), lane);
       const bool whole = run >= G;
       const int nx = whole ? x[h] - G : (nxt & 0xFFF) - 2, ny = whole ? y[h] - G : ((nxt >> 12) & 0xFFF) - 2;
       const bool stop = !whole && (nxt >> 24) != 0;
@@ -714,19 +720,13 @@ __device__ __forceinline__ void traceback_b2(const WinP (&W)[2], const uint32_t 
 // one of the ring's nodes joins it, every other uncorrected letter gets a column of its own just before the
 // next ring that holds an aligned letter.  Returns the number of columns staged in cols_st.
 template <int G>
-__device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *xinfo, const uint16_t *x2y, const uint8_t *ys,
+__device__ __forceinline__ int columns_2(const WinP &W, int lane, int g, const uint32_t *xinfo, const uint16_t *x2y, const uint8_t *ys,
                                          const uint8_t *chr, uint8_t *cols_st, uint16_t *col_y, bool bad)
 {
   const bool valid = W.valid;
   const int n1 = W.n1, Lu = W.Lu;
   const int cn = (n1 + G - 1) / G, cy = (Lu + G - 1) / G;
-  int cnmax = valid ? cn : 0, cymax = valid ? cy : 0;
-  for (int d = G; d < 64; d <<= 1) {
-    cnmax = max(cnmax, __shfl_xor(cnmax, d));
-    cymax = max(cymax, __shfl_xor(cymax, d));
-  }
-  cnmax = __builtin_amdgcn_readfirstlane(cnmax);
-  cymax = __builtin_amdgcn_readfirstlane(cymax);
+  const int cnmax = wave_max(valid ? cn : 0), cymax = wave_max(valid ? cy : 0);
   if (valid) for (int i = g; i < Lu; i += G) col_y[i] = (uint16_t)kNone16;
   const int i0 = g * cn, i1 = valid ? min(n1, i0 + cn) : 0;
   auto starts = [&](int ix) { return (xinfo[ix + 1] & kN_NewCol) != 0; };
@@ -751,13 +751,14 @@ __device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *x
     }
   }
   int sg = ngs, sa = nal, sy = last_ay;                                  // inclusive scans over the group's lanes
-  for (int d = 1; d < G; d <<= 1) {
-    const int tg = __shfl_up(sg, d, G), ta = __shfl_up(sa, d, G), ty = __shfl_up(sy, d, G);
+  for_pow2_below<G>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    const int tg = grp_up<G, d>(sg), ta = grp_up<G, d>(sa), ty = grp_up<G, d>(sy);
     if (g >= d) { sg += tg; sa += ta; sy = max(sy, ty); }
-  }
-  const int prev_ay = __shfl_up(sy, 1, G);
+  });
+  const int prev_ay = grp_up<G, 1>(sy);
   int gcount = sg - ngs, alc = sa - nal, A = g > 0 ? prev_ay : -1;
-  const int ngroups = __shfl(sg, G - 1, G), nal_all = __shfl(sa, G - 1, G);
+  const int ngroups = grp_get<G>(sg, G - 1, lane), nal_all = grp_get<G>(sa, G - 1, lane);
   int ncol = ngroups + Lu - nal_all;
   __builtin_amdgcn_wave_barrier();
   for (int it = 0; it < cnmax; ++it) {
@@ -794,11 +795,12 @@ __device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *x
     if (y >= y0) { const int c = col_y[y]; if (c != (int)kNone16) klow = c - y; }
   }
   int sfx = klow;                                                        // nearest defined value at or after this lane
-  for (int d = 1; d < G; d <<= 1) {
-    const int t = __shfl_down(sfx, d, G);
+  for_pow2_below<G>([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    const int t = grp_down<G, d>(sfx);
     if (g + d < G && sfx == kUndef) sfx = t;
-  }
-  int K = __shfl_down(sfx, 1, G);
+  });
+  int K = grp_down<G, 1>(sfx);
   if (g == G - 1 || K == kUndef) K = ncol - Lu;
   for (int it = 0; it < cymax; ++it) {
     const int y = y1 - 1 - it;
@@ -813,12 +815,12 @@ __device__ __forceinline__ int columns_2(const WinP &W, int g, const uint32_t *x
       }
     }
   }
-  for (int d = 1; d < G; d <<= 1) odd = odd || __shfl_xor(odd ? 1 : 0, d, G) != 0;
+  for (int d = 1; d < G; d <<= 1) odd = odd || grp_xor<G>(odd ? 1 : 0, d) != 0;
   __builtin_amdgcn_wave_barrier();
   // an alignment that is not a monotone path through the rings cannot happen; if it ever does, the plain
   // serial form of the rule decides
   if (valid && odd && g == 0 && !bad) ncol = pk_columns_serial(n1, Lu, xinfo, x2y, ys, chr, cols_st);
-  ncol = __shfl(ncol, 0, G);
+  ncol = grp_get<G>(ncol, 0, lane);
   return ncol;
 }
 
@@ -843,17 +845,6 @@ __global__ void __launch_bounds__(256) k_gather(GatherArgs a)
   if (p >= a.nlist) return;
   if (a.nlist_dev && p >= (int64_t)*a.nlist_dev) return;                  // (k_poa reads the same count)
   gather_entry(a, p, g, a.psym + p * (int64_t)a.pstride, a.pstride);
-}
-
-// every list of the batch at once (a launch per list was thirteen to eighteen launches of a few dozen microseconds)
-__global__ void __launch_bounds__(256) k_gather_all(GatherAllArgs a)
-{
-  const int64_t p = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int g = threadIdx.x & 7;
-  if (p >= a.g.nlist) return;
-  int k = 0;
-  while (k + 1 < a.nb && p >= a.first[k + 1]) ++k;
-  gather_entry(a.g, p, g, a.g.psym + a.psym_first[k] + (p - a.first[k]) * (int64_t)a.stride[k], a.stride[k]);
 }
 
 __device__ __forceinline__ void gather_entry(const GatherArgs &a, int64_t p, int g, uint32_t *dst, int pstride)
@@ -885,12 +876,6 @@ void launch_gather(const GatherArgs &a, hipStream_t st)
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((a.nlist + 31) / 32)), dim3(256), 0, st, a);
 }
 
-void launch_gather_all(const GatherAllArgs &a, hipStream_t st)
-{
-  if (a.g.nlist <= 0 || a.nb <= 0) return;
-  hipLaunchKernelGGL(k_gather_all, dim3((unsigned)((a.g.nlist + 31) / 32)), dim3(256), 0, st, a);
-}
-
 // ------------------------------------------------------------------------ k_poa ---
 
 // window descriptor -> WinP; the loads were issued by the caller (all of both windows in flight together)
@@ -907,13 +892,11 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
   W.triv = listed ? triv : 0;
   W.n1 = 0; W.score1 = kNeg; W.k2n = 0; W.fnode = -1;
   W.slot = slot;
-  // (a.part == 2: a launch of shortcut graphs only -- poa_slot_need_triv; a window that needs alignment #1 is refused)
-  const bool tail = a.part == 2;
-  W.xi_cap = tail ? poa_xi_cap_triv(W.Lr) : poa_xi_cap(W.Lr, W.Lc);
+  W.xi_cap = poa_xi_cap(W.Lr, W.Lc);
   W.off_xi = 16 + pk_align_up(W.Lu, 4);
   W.off_u = W.off_xi + 4 * (W.xi_cap + 2);                     // records 1 .. n1 between two zero guards
-  const int ua = tail ? pk_align_up(W.Lr + W.Lc, 4) : poa_union_a(W.Lr, W.Lc, G), ub = poa_union_b(W.xi_cap, W.Lu, G);
-  W.valid = W.valid && (!tail || W.triv != 0) && W.off_u + max(ua, ub) <= a.slot_bytes && W.Lc <= RS && W.Lu <= RS &&
+  const int ua = poa_union_a(W.Lr, W.Lc, G), ub = poa_union_b(W.xi_cap, W.Lu, G);
+  W.valid = W.valid && W.off_u + max(ua, ub) <= a.slot_bytes && W.Lc <= RS && W.Lu <= RS &&
             (poa_idx_bytes(G) > 1 || W.Lr + W.Lc <= 254) &&
             max(W.Lr, W.xi_cap) + G + 2 <= a.mv_tw && score_span(kp, max(W.Lr, W.xi_cap) + G, RS) < 16000;
 }
@@ -928,16 +911,11 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   constexpr int NP = 64 / G;                       // pairs of windows per wave
   // index type of the alignment #1 / fusion #1 maps: one byte in the classes whose windows are short
   using IT = typename std::conditional<poa_idx_bytes(G) == 1, uint8_t, uint16_t>::type;
-  const int lane = threadIdx.x, q = lane / G, g = lane & (G - 1);
+  const int lane = threadIdx.x, q = LG<G>::q(lane), g = LG<G>::g(lane);
   const int dbg = kPoaDebug ? a.debug : 0;         // (a build without ELECTOR_POA_DEBUG holds none of the debug branches)
-  // a far list is launched at its capacity, the two parts of a split list over the whole list: the blocks outside leave
-  // before they touch anything
-  int64_t nlist = a.nlist_dev ? min(a.nlist, (int64_t)*a.nlist_dev) : a.nlist, first = 0;
-  if (a.part) {
-    const int64_t head = min(nlist, (((int64_t)*a.split_dev + 2 * NP - 1) / (2 * NP)) * (2 * NP));
-    if (a.part == 1) nlist = head; else first = head;
-  }
-  if (first + (int64_t)blockIdx.x * (2 * NP) >= nlist) return;
+  // a far list is launched at its capacity: the blocks outside leave before they touch anything
+  const int64_t nlist = a.nlist_dev ? min(a.nlist, (int64_t)*a.nlist_dev) : a.nlist;
+  if ((int64_t)blockIdx.x * (2 * NP) >= nlist) return;
   const KParams kp = a.b.kp;
   uint8_t *chr = lds;
   unsigned long long stamp_ = (dbg & 4) ? __builtin_readcyclecounter() : 0;
@@ -960,7 +938,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   // have arrived (a fixed number of dwords per entry, the class's stride); what lies behind a window's end is read
   // and dropped. ----
   WinP W[2];
-  const int64_t pi = first / 2 + (int64_t)blockIdx.x * NP + q;
+  const int64_t pi = (int64_t)blockIdx.x * NP + q;
   uint8_t *us[2], *U[2];
   uint32_t *xinfo[2];
   bool any_valid;
@@ -989,7 +967,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       }
     // the ticket is drawn behind the loads: memory operations return in order, so the loads do not wait for the
     // (slower) atomic
-    if (a.mv_slots > 0 && lane == 0) ticket = (uint32_t)atomicAdd(mvq, 1);
+    if (lane == 0) ticket = (uint32_t)atomicAdd(mvq, 1);
     if (lane < 32) chr[lane] = chr_l;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1019,8 +997,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
         ntot[h] = W[h].valid ? nrc[h] + W[h].Lu : 0;
         ndw = max(ndw, (ntot[h] + 3) >> 2);
       }
-      for (int d = G; d < 64; d <<= 1) ndw = max(ndw, __shfl_xor(ndw, d));
-      ndw = __builtin_amdgcn_readfirstlane(ndw);
+      ndw = wave_max(ndw);
       for (int kb = 0; kb < ndw; kb += UB * G) {
         if (kb > 0) {
 #pragma unroll
@@ -1051,16 +1028,15 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(9);
   int mslot = 0;
-  if (a.mv_slots <= 0) { xcc = 0; mslot = (int)blockIdx.x; }          // experiment: one scratch region per block
-  else if (lane == 0) {
+  if (lane == 0) {
     int32_t *e = mvq + 32 + ticket % (uint32_t)a.mv_slots;
     while ((mslot = atomicExch(e, -1)) < 0) __builtin_amdgcn_s_sleep(2);
   }
   mslot = __builtin_amdgcn_readfirstlane(mslot);
   PK_STAMP(10);
-  uint32_t *mv = a.mv_pool + ((size_t)xcc * (a.mv_slots > 0 ? a.mv_slots : 0) + mslot) * (size_t)a.mv_tw * 64;
+  uint32_t *mv = a.mv_pool + ((size_t)xcc * a.mv_slots + mslot) * (size_t)a.mv_tw * 64;
   if (!any_valid) {                                                    // nothing for this wave: the slot goes straight back
-    if (lane == 0 && a.mv_slots > 0) {
+    if (lane == 0) {
       const uint32_t t = (uint32_t)atomicAdd(mvq + 16, 1);
       int32_t *e = mvq + 32 + t % (uint32_t)a.mv_slots;
       while (atomicCAS(e, -1, mslot) != -1) __builtin_amdgcn_s_sleep(2);
@@ -1092,9 +1068,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       E[k] = pk1(v - kp.ext_x);
     }
     uint32_t dg0 = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // cell (row above, column -1)
-    int tmax = max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0) + G - 1;
-    for (int d = G; d < 64; d <<= 1) tmax = max(tmax, __shfl_xor(tmax, d));
-    tmax = __builtin_amdgcn_readfirstlane(tmax);
+    const int tmax = wave_max(max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0)) + G - 1;
     int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? xsA[0] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? xsB[0] : 0;
     const int gstar0 = (W[0].Lc - 1) / R, kstar0 = (W[0].Lc - 1) % R, gstar1 = (W[1].Lc - 1) / R, kstar1 = (W[1].Lc - 1) % R;
     uint32_t bS = pk1(-kp.open_x);                             // row -1 at column t: -(open_x + (t - 1) ext_x)
@@ -1146,7 +1120,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   // the score sits with the lane that holds the corrected read's last row
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int sc = __shfl(W[h].score1, needA[h] ? (W[h].Lc - 1) / R : 0, G);
+    const int sc = grp_get<G>(W[h].score1, needA[h] ? (W[h].Lc - 1) / R : 0, lane);
     if (needA[h]) W[h].score1 = sc;
   }
   PK_STAMP(1);
@@ -1162,7 +1136,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   {
     IT *x2ya[2] = {reinterpret_cast<IT *>(U[0] + pk_align_up(W[0].Lr + W[0].Lc, 4)),
                          reinterpret_cast<IT *>(U[1] + pk_align_up(W[1].Lr + W[1].Lc, 4))};
-    traceback_a<G, R, IT>(W, needA, mv, q, g, x2ya);
+    traceback_a<G, R, IT>(W, needA, mv, lane, g, x2ya);
   }
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(2);
@@ -1171,7 +1145,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
     IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
     keep[h] = true;
     if (__builtin_amdgcn_ballot_w64(needA[h]) != 0)
-      keep[h] = fusion_1<G, IT, FAR>(W[h], g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h], &farw[h], &why[h]);
+      keep[h] = fusion_1<G, IT, FAR>(W[h], lane, g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h], &farw[h], &why[h]);
     trivial_graph<G>(W[h], g, U[h], U[h] + W[h].Lr, xinfo[h]);
     if (W[h].valid && W[h].triv == 1) W[h].score1 = W[h].Lr * kp.match;
     if (W[h].valid && W[h].triv == 2) W[h].score1 = (W[h].Lr - 1) * kp.match + kp.mismatch;
@@ -1189,16 +1163,18 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
     const bool cnt_on = on && W[h].triv == 0;           // the directly written graphs have at most one such node, ordinal 0
     const int n1 = W[h].n1;
     const int cn = (n1 + G - 1) / G;
-    int cnmax = cnt_on ? cn : 0;
-    for (int d = G; d < 64; d <<= 1) cnmax = max(cnmax, __shfl_xor(cnmax, d));
-    cnmax = __builtin_amdgcn_readfirstlane(cnmax);
+    const int cnmax = wave_max(cnt_on ? cn : 0);
     const int j0 = 1 + g * cn, j1 = cnt_on ? min(n1 + 1, j0 + cn) : 0;
     int cnt = 0;
     for (int it = 0; it < cnmax; ++it) { const int jj = j0 + it; if (jj < j1) cnt += (xinfo[h][jj] & kN_Has2) != 0; }
     int sc = cnt, scl = 0;
     if (cnmax > 0) {                                   // (wave-uniform: no window of this wavefront came out of fusion #1)
-      for (int d = 1; d < G; d <<= 1) { const int t = __shfl_up(sc, d, G); if (g >= d) sc += t; }
-      scl = __shfl(sc, G - 1, G);
+      for_pow2_below<G>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        const int t = grp_up<G, d>(sc);
+        if (g >= d) sc += t;
+      });
+      scl = grp_get<G>(sc, G - 1, lane);
     }
     const int k2n = cnt_on ? scl : W[h].k2n;
     int k = sc - cnt;
@@ -1248,9 +1224,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   }
   int best[2] = {kNeg, kNeg}, bestx[2] = {-1, -1};
   {
-    int tmax = max(W[0].valid ? W[0].n1 : 0, W[1].valid ? W[1].n1 : 0) + G - 1;
-    for (int d = G; d < 64; d <<= 1) tmax = max(tmax, __shfl_xor(tmax, d));
-    tmax = (__builtin_amdgcn_readfirstlane(tmax) + 1) & ~1;
+    const int tmax = (wave_max(max(W[0].valid ? W[0].n1 : 0, W[1].valid ? W[1].n1 : 0)) + G - 1 + 1) & ~1;
     uint32_t ylp[R], S1[R], E1[R], S2[R], E2[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -1387,8 +1361,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
           if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
         }
       };
-      // debug bit 1024: never the plain-chain form (A/B)
-      if (!(dbg & 1024) && __builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
+      if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
         variant(std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{});
       else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
         variant(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
@@ -1445,15 +1418,14 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int gs = (W[h].Lu - 1) / R;
-    best[h] = __shfl(best[h], W[h].valid ? gs : 0, G);
-    bestx[h] = __shfl(bestx[h], W[h].valid ? gs : 0, G);
+    best[h] = grp_get<G>(best[h], W[h].valid ? gs : 0, lane);
+    bestx[h] = grp_get<G>(bestx[h], W[h].valid ? gs : 0, lane);
     if (W[h].valid) for (int i = g; i < W[h].n1; i += G) x2yb[h][i] = (uint16_t)kNone16;
   }
   __syncthreads();
   bool badb[2] = {false, false};
   int tb_rounds = 0;
-  if (!FAR && (dbg & 2048)) traceback_b<G, R>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);      // round 2's form (A/B)
-  else traceback_b2<G, R, FAR>(W, mv, q, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);
+  traceback_b2<G, R, FAR>(W, mv, lane, g, xinfo, ordb, x2yb, bestx, badb, tb_rounds);
   if ((dbg & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 11, (unsigned long long)tb_rounds);
   __builtin_amdgcn_wave_barrier();
   PK_STAMP(6);
@@ -1465,8 +1437,8 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
     // n1 + Lu columns); the column of every uncorrected letter lives where the ordinal bytes were
     uint8_t *cols_st = a.b.cols + 3 * W[h].o0;
     uint16_t *col_y = reinterpret_cast<uint16_t *>(ordb[h]);
-    for (int d = 1; d < G; d <<= 1) badb[h] = badb[h] || __shfl_xor(badb[h] ? 1 : 0, d, G) != 0;
-    const int ncol = columns_2<G>(W[h], g, xinfo[h], x2yb[h], us[h], chr, cols_st, col_y, badb[h]);
+    for (int d = 1; d < G; d <<= 1) badb[h] = badb[h] || grp_xor<G>(badb[h] ? 1 : 0, d) != 0;
+    const int ncol = columns_2<G>(W[h], lane, g, xinfo[h], x2yb[h], us[h], chr, cols_st, col_y, badb[h]);
     __builtin_amdgcn_wave_barrier();
     if (W[h].valid) {
       if (g == 0) {
@@ -1486,7 +1458,7 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   if ((dbg & 4) && threadIdx.x == 0) atomicAdd(a.stamps + 15, 1ull);
   // give the moves slot back: every access of this wave to it has completed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0 && a.mv_slots > 0) {
+  if (lane == 0) {
     const uint32_t t = (uint32_t)atomicAdd(mvq + 16, 1);
     int32_t *e = mvq + 32 + t % (uint32_t)a.mv_slots;
     while (atomicCAS(e, -1, mslot) != -1) __builtin_amdgcn_s_sleep(2);

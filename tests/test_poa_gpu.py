@@ -507,45 +507,17 @@ def test_soak_slice(engine):
     assert total == 228000
 
 
-def test_list_in_two_launches(engine, monkeypatch, capfd):
-    """ELECTOR_POA_SPLIT=1: the windows of a list that run alignment #1 and the windows with a shortcut graph (corrected
-    sequence within one edit of the reference) as two launches of k_poa, the second with the smaller LDS slot of
-    poa_slot_need_triv.  Same rows and scores as the oracle; the debug line says that lists were in fact split."""
-    monkeypatch.setenv("ELECTOR_POA_SPLIT", "1")
-    monkeypatch.setenv("ELECTOR_DEBUG_BINS", "1")
-    rng = np.random.default_rng(77)
-    triples = []
-    for t in synth.window_triples(78, 5000, 66, 250, err_cor=0.004):
-        ref, cor, unc = t
-        k = int(rng.integers(0, 10))
-        if k == 0 and len(ref) > 4:                      # one inserted / deleted letter
-            p = int(rng.integers(1, len(ref) - 1))
-            cor = ref[:p] + ref[p + 1:] if rng.integers(0, 2) else ref[:p] + b"A" + ref[p:]
-        elif k < 6:
-            cor = ref
-        triples.append((ref, cor, unc))
-    check(engine, triples)
-    err = capfd.readouterr().err
-    line = [ln for ln in err.split("\n") if "k_poa lists" in ln]
-    assert line, err[-2000:]
-    tails = [int(tok.split(",")[2]) for tok in line[-1].split("): ")[1].split()]
-    assert any(t > 0 for t in tails), line[-1]
-
-
-@pytest.mark.parametrize("split_lists", ["0", "1"])
-def test_first_call_of_a_fresh_process(split_lists):
+@pytest.mark.parametrize("cls", [-1] + list(range(17)))
+def test_first_call_of_a_fresh_process(cls):
     """tests/first_call_check.py in a process of its own: k_poa's first launches, on untouched scratch memory, give the
-    rows of the two-kernel path (with the lists whole and in two launches)."""
+    rows of the two-kernel path -- with the windows in their own classes (-1) and with every geometry class forced in turn
+    (ELECTOR_FORCE_CLASS: all windows that fit go to that instance of k_poa)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, ELECTOR_POA_SPLIT=split_lists)
+    env = dict(os.environ)
+    if cls >= 0:
+        env["ELECTOR_FORCE_CLASS"] = str(cls)
     here = os.path.dirname(os.path.abspath(__file__))
     p = subprocess.run([sys.executable, os.path.join(here, "first_call_check.py")], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "differing 0" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
-
-
-def test_gather_in_one_launch(engine, monkeypatch):
-    """ELECTOR_GATHER_ALL=1: k_poa's inputs of all lists laid out by one launch (k_gather_all) instead of one per list"""
-    monkeypatch.setenv("ELECTOR_GATHER_ALL", "1")
-    check(engine, synth.window_triples(91, 4000, 7, 400) + synth.adversarial_triples(92, 600))
