@@ -120,6 +120,95 @@ __device__ __forceinline__ void pk_row(uint32_t xlp, uint32_t ylp, uint32_t insX
         [kext] "s"(KEXT), [kdelta] "s"(KDELTA), [sh] "n"(SH));
 }
 
+// The same row IN PLACE: Sb / Eb hold the cell two columns back on entry (a form that can name that column has read it)
+// and the new cell on exit, so that a column's values never change register from step to step -- with fresh outputs the
+// compiler rotated the arrays through copies (three v_mov_b64 per step and a dozen v_mov in alignment #1's loop).  The
+// first row of a step (SH = 0) starts the step's word of moves.
+template <int SH>
+__device__ __forceinline__ void pk_row_ip(uint32_t xlp, uint32_t ylp, uint32_t insX, uint32_t insY, uint32_t dmax, uint32_t ONES,
+                                          uint32_t KSUB, uint32_t KEXT, uint32_t KDELTA, uint32_t &Sb, uint32_t &Eb, uint32_t &mbit,
+                                          uint32_t &mvw)
+{
+  uint32_t mx;
+  if constexpr (SH == 0) {
+    asm("v_xor_b32 %[mb], %[xl], %[yl]\n\t"
+        "v_pk_max_i16 %[mx], %[ix], %[iy]\n\t"
+        "v_pk_min_u16 %[mb], %[mb], %[one]\n\t"
+        "v_pk_mad_i16 %[mb], %[mb], %[ksub], %[dm]\n\t"
+        "v_pk_max_i16 %[sn], %[mb], %[mx]\n\t"
+        "v_pk_sub_i16 %[mb], %[sn], %[mx]\n\t"
+        "v_pk_sub_i16 %[mx], %[mx], %[iy]\n\t"
+        "v_pk_sub_i16 %[en], %[sn], %[kext]\n\t"
+        "v_pk_min_u16 %[mb], %[mb], %[one]\n\t"
+        "v_pk_min_u16 %[mx], %[mx], %[one]\n\t"
+        "v_pk_mad_i16 %[en], %[mb], %[kdelta], %[en]\n\t"
+        "v_lshl_or_b32 %[mv], %[mb], 1, %[mx]"
+        : [sn] "+v"(Sb), [en] "+v"(Eb), [mb] "=&v"(mbit), [mv] "=&v"(mvw), [mx] "=&v"(mx)
+        : [xl] "v"(xlp), [yl] "v"(ylp), [ix] "v"(insX), [iy] "v"(insY), [dm] "v"(dmax), [one] "s"(ONES), [ksub] "s"(KSUB),
+          [kext] "s"(KEXT), [kdelta] "s"(KDELTA));
+  } else {
+    asm("v_xor_b32 %[mb], %[xl], %[yl]\n\t"
+        "v_pk_max_i16 %[mx], %[ix], %[iy]\n\t"
+        "v_pk_min_u16 %[mb], %[mb], %[one]\n\t"
+        "v_pk_mad_i16 %[mb], %[mb], %[ksub], %[dm]\n\t"
+        "v_pk_max_i16 %[sn], %[mb], %[mx]\n\t"
+        "v_pk_sub_i16 %[mb], %[sn], %[mx]\n\t"
+        "v_pk_sub_i16 %[mx], %[mx], %[iy]\n\t"
+        "v_pk_sub_i16 %[en], %[sn], %[kext]\n\t"
+        "v_pk_min_u16 %[mb], %[mb], %[one]\n\t"
+        "v_pk_min_u16 %[mx], %[mx], %[one]\n\t"
+        "v_pk_mad_i16 %[en], %[mb], %[kdelta], %[en]\n\t"
+        "v_lshl_or_b32 %[mx], %[mb], 1, %[mx]\n\t"
+        "v_lshl_or_b32 %[mv], %[mx], %[sh], %[mv]"
+        : [sn] "+v"(Sb), [en] "+v"(Eb), [mb] "=&v"(mbit), [mv] "+v"(mvw), [mx] "=&v"(mx)
+        : [xl] "v"(xlp), [yl] "v"(ylp), [ix] "v"(insX), [iy] "v"(insY), [dm] "v"(dmax), [one] "s"(ONES), [ksub] "s"(KSUB),
+          [kext] "s"(KEXT), [kdelta] "s"(KDELTA), [sh] "n"(SH));
+  }
+}
+
+// A row of a step in which some lane of the wavefront sits at a node with TWO predecessors (one and two columns back, in
+// either order: masks M1 / M2 say "two back" per half for the first / second; a node without a second repeats the first).
+// In: what the row above hands down -- dt1, the first predecessor's cell on the diagonal, and dmax, the better of the two
+// (the first wins ties, align_lpo_po2.c:348-357) -- and insY.  Out: the same for the row below, the cell in place, the
+// move bits, and in sec bit K "the second predecessor gave the move that won" (strictly better on the diagonal if the
+// cell is a match, for the x-insertion otherwise, :361-371).  25 instructions, one block.
+template <int K>
+__device__ __forceinline__ void pk_row_two(uint32_t xlp, uint32_t ylp, uint32_t M1, uint32_t M2, uint32_t Sa, uint32_t Ea, uint32_t insY,
+                                           uint32_t ONES, uint32_t KSUB, uint32_t KEXT, uint32_t KDELTA, uint32_t &dt1, uint32_t &dmax,
+                                           uint32_t &Sb, uint32_t &Eb, uint32_t &mvw, uint32_t &sec)
+{
+  uint32_t t0, mx, e1, d1;
+  asm("v_xor_b32 %[t0], %[xl], %[yl]\n\t"
+      "v_pk_min_u16 %[t0], %[t0], %[one]\n\t"
+      "v_pk_sub_i16 %[d1], %[dm], %[dt]\n\t"
+      "v_pk_mad_i16 %[t0], %[t0], %[ksub], %[dm]\n\t"
+      "v_bfi_b32 %[dt], %[m1], %[sb], %[sa]\n\t"
+      "v_bfi_b32 %[dm], %[m2], %[sb], %[sa]\n\t"
+      "v_pk_max_i16 %[dm], %[dt], %[dm]\n\t"
+      "v_bfi_b32 %[e1], %[m1], %[eb], %[ea]\n\t"
+      "v_bfi_b32 %[mx], %[m2], %[eb], %[ea]\n\t"
+      "v_pk_max_i16 %[mx], %[e1], %[mx]\n\t"
+      "v_pk_sub_i16 %[e1], %[mx], %[e1]\n\t"
+      "v_pk_max_i16 %[mx], %[mx], %[iy]\n\t"
+      "v_pk_max_i16 %[sb], %[t0], %[mx]\n\t"
+      "v_pk_sub_i16 %[t0], %[sb], %[mx]\n\t"
+      "v_pk_sub_i16 %[mx], %[mx], %[iy]\n\t"
+      "v_pk_sub_i16 %[eb], %[sb], %[kext]\n\t"
+      "v_pk_min_u16 %[t0], %[t0], %[one]\n\t"
+      "v_pk_min_u16 %[mx], %[mx], %[one]\n\t"
+      "v_pk_mad_i16 %[eb], %[t0], %[kdelta], %[eb]\n\t"
+      "v_lshl_or_b32 %[mx], %[t0], 1, %[mx]\n\t"
+      "v_lshl_or_b32 %[mv], %[mx], %[sh], %[mv]\n\t"
+      "v_pk_sub_i16 %[t0], 0, %[t0]\n\t"
+      "v_bfi_b32 %[e1], %[t0], %[d1], %[e1]\n\t"
+      "v_pk_min_u16 %[e1], %[e1], %[one]\n\t"
+      "v_lshl_or_b32 %[sec], %[e1], %[k], %[sec]"
+      : [sb] "+v"(Sb), [eb] "+v"(Eb), [dt] "+v"(dt1), [dm] "+v"(dmax), [mv] "+v"(mvw), [sec] "+v"(sec), [t0] "=&v"(t0),
+        [mx] "=&v"(mx), [e1] "=&v"(e1), [d1] "=&v"(d1)
+      : [xl] "v"(xlp), [yl] "v"(ylp), [m1] "v"(M1), [m2] "v"(M2), [sa] "v"(Sa), [ea] "v"(Ea), [iy] "v"(insY), [one] "s"(ONES),
+        [ksub] "s"(KSUB), [kext] "s"(KEXT), [kdelta] "s"(KDELTA), [sh] "n"(2 * K), [k] "n"(K));
+}
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression
 template <int N, int I = 0, class F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -255,6 +344,8 @@ __device__ __forceinline__ int pk_diag_run(bool flag, int lane)
 //           bits 0 / 3 then say "one back" and are not used)        bit 7   ... the second predecessor is
 constexpr uint32_t kN_Far1 = 1u, kN_Far2 = 2u, kN_Has2 = 4u, kN_Virt1 = 8u, kN_Virt2 = 16u, kN_NewCol = 32u;
 constexpr uint32_t kN_FarA = 64u, kN_FarB = 128u;
+
+#include "poa_engine_gen.h"
 
 // LDS slot of one window (bytes); must mirror poa_slot_need() below.
 //   [hdr 16][unc symbols][node records u32 (xi_cap + 2: records 1 .. n1 between two zero guards)][union]
@@ -1225,9 +1316,12 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   int best[2] = {kNeg, kNeg}, bestx[2] = {-1, -1};
   {
     const int tmax = (wave_max(max(W[0].valid ? W[0].n1 : 0, W[1].valid ? W[1].n1 : 0)) + G - 1 + 1) & ~1;
-    uint32_t ylp[R], S1[R], E1[R], S2[R], E2[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
+    // the letters of the lane's rows and the two columns it holds, each a tuple of R registers: the generated loop
+    // (poa_engine_gen.h) takes them pinned to fixed registers
+    typedef uint32_t VR __attribute__((ext_vector_type(R)));
+    VR ylp, S1, E1, S2, E2;
+    static_for<R>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
       const int ii = R * g + 1 + k;
       const int ya = (W[0].valid && ii <= W[0].Lu) ? us[0][ii - 1] : 255;
       const int yb = (W[1].valid && ii <= W[1].Lu) ? us[1][ii - 1] : 255;
@@ -1235,28 +1329,44 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       const int v = -(kp.open_y + (ii - 1) * kp.ext_y);        // column 0 (the virtual start): ii gap steps, not a match
       S1[k] = S2[k] = pk1(v);
       E1[k] = E2[k] = pk1(v - kp.ext_x);
-    }
+    });
     // the row above at column jj - 2 is what the shift delivered as "column jj - 1" one step earlier: one DPP
     // shift per step instead of two (before the first step: column 0 on both sides)
     uint32_t prev_up1 = pk_shift_in<G>(0u, S1[R - 1], g);
     const uint32_t colS0 = pk1(-(kp.open_y + (R * g) * kp.ext_y));               // column 0 at this lane's first row
     const uint32_t colAbove = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // ... at the row above it (the origin for lane 0)
     const uint32_t KOPENNEG = pk1(-kp.open_x);
-    // row -1 over the graph (align_lpo_po2.c:275-286) at the two columns before this one: score, and score less
-    // the gap it offers; the origin counts as "open"
-    uint32_t BR1 = 0, BR2 = 0, BE1 = pk1(-kp.open_x), BE2 = pk1(-kp.open_x);
+    // row -1 over the graph (align_lpo_po2.c:275-286): its score at the column before this one, and what the cells of the
+    // two columns before offer a gap (score less the extension; the origin counts as "open").  Only the group's first
+    // lane reads them, as the border of the shifts.
+    uint32_t BR1 = 0, BE1 = pk1(-kp.open_x), BE2 = pk1(-kp.open_x);
     const int gstar0 = (W[0].Lu - 1) / R, kstar0 = (W[0].Lu - 1) % R, gstar1 = (W[1].Lu - 1) / R, kstar1 = (W[1].Lu - 1) % R;
     const int n1c0 = (W[0].valid ? W[0].n1 : 0) + 1, n1c1 = (W[1].valid ? W[1].n1 : 0) + 1;   // index of the upper guard
-    uint32_t xiA_next = xinfo[0][min(max(1 - g, 0), n1c0)];
-    uint32_t xiB_next = xinfo[1][min(max(1 - g, 0), n1c1)];
+    // node records by their byte offset in LDS: record i of window h at xb_h + 4 i, the upper zero guard at xe_h
+    const uint32_t xbA = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_xi), xbB = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_xi);
+    const uint32_t xeA = xbA + 4u * (uint32_t)n1c0, xeB = xbB + 4u * (uint32_t)n1c1;
+    auto rec_at = [&](uint32_t o) { return *reinterpret_cast<const uint32_t *>(lds + o); };
+    uint32_t oA = xbA + 4u * (uint32_t)min(max(1 - g, 0), n1c0), oB = xbB + 4u * (uint32_t)min(max(1 - g, 0), n1c1);
+    uint32_t xiA_next = rec_at(oA), xiB_next = rec_at(oB);
     // the lane that holds a window's last row watches for nodes that can end the alignment
     const uint32_t finA_bit = (W[0].valid && g == gstar0) ? ((uint32_t)kFlagFinal << 16) : 0u;
     const uint32_t finB_bit = (W[1].valid && g == gstar1) ? ((uint32_t)kFlagFinal << 16) : 0u;
+    // ... from the step on at which it can meet the first of them: a final node holds the last letter of the reference or
+    // of the corrected sequence, and the node of a sequence's letter i has index i at least (a filler's lone letter comes
+    // behind the whole reference).  Up to that step the loop runs without the test.
+    int tfin;
+    {
+      int nf = 0x3fffffff;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (W[h].valid) nf = min(nf, (W[h].triv == 5 ? W[h].Lr : min(W[h].Lr, W[h].Lc)) + (W[h].Lu - 1) / R);   // index + 1 + lane
+      tfin = -wave_max(-nf);
+    }
 
     // k_poa<.., true>: the column of the window's far node (scores, what they offer a gap, the row above it, row -1
     // over the graph) is kept aside when the lane passes it and stands in for a predecessor column at the one node
     // whose record names it (kN_FarA / kN_FarB)
-    uint32_t FS[FAR ? R : 1], FE[FAR ? R : 1], Fup = 0, FBE = 0, up1_step = 0;
+    uint32_t FS[FAR ? R : 1], FE[FAR ? R : 1], Fup = 0, FBE = 0;
     const int fcol0 = (FAR && W[0].valid && W[0].fnode >= 0) ? W[0].fnode + 1 : -100;
     const int fcol1 = (FAR && W[1].valid && W[1].fnode >= 0) ? W[1].fnode + 1 : -100;
     if (FAR) {
@@ -1264,148 +1374,247 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       for (int k = 0; k < R; ++k) FS[k] = FE[k] = 0;
     }
     int n_steps = 0, n_two = 0, n_virt = 0;                        // debug: steps per code path
-    // FIRST: the steps in which some lane has not reached its first column yet (t < G)
-    auto step = [&](auto first_tag, int t, uint32_t (&Sa)[R], uint32_t (&Ea)[R], uint32_t (&Sb)[R], uint32_t (&Eb)[R]) {
-      constexpr bool FIRST = decltype(first_tag)::value;
+    const uint32_t kFormBits = kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u);
+    const uint32_t kFarBits = FAR ? kN_FarA | kN_FarB : 0u;
+
+    // One step = one anti-diagonal: lane g computes column jj = t - g of its R rows, reading column jj - 1 from (Sa, Ea)
+    // and writing column jj over column jj - 2 in (Sb, Eb): the rows work IN PLACE (the forms that can name column jj - 2
+    // read it first), so no value changes register between steps.  SLOW: the steps in which some lane has not reached its
+    // first column yet (t <= G: such a lane keeps column 0) and the steps in which a window's last row can meet a final
+    // node (t >= tfin); the steps in between run without either test and fetch their node records through a running
+    // offset.  Five forms of the step, each straight code of its own, chosen by wave-wide tests on the records' low bits:
+    // NEAR -- every lane at a node whose only predecessor is the node before it (a stretch of plain chain in all windows
+    // of the wave): nothing to select; PLAIN -- some lane's predecessor lies two columns back; TWO -- some lane at a node
+    // with a second predecessor; VIRT1 -- some lane's predecessor is the virtual start more than two columns back (the
+    // lone letter of a filler window), no second predecessors; and everything together (with the far column, FAR).
+    auto step = [&](auto slow_tag, int t, VR &Sa, VR &Ea, VR &Sb, VR &Eb) {
+      constexpr bool SLOW = decltype(slow_tag)::value;
       const int jj = t - g;
       const uint32_t xiA = xiA_next, xiB = xiB_next;
-      xiA_next = xinfo[0][med3(jj + 1, 0, n1c0)];
-      xiB_next = xinfo[1][med3(jj + 1, 0, n1c1)];
+      if constexpr (SLOW) {
+        oA = xbA + 4u * (uint32_t)med3(jj + 1, 0, n1c0);
+        oB = xbB + 4u * (uint32_t)med3(jj + 1, 0, n1c1);
+      } else {
+        oA = min(oA + 4u, xeA);                                      // (LDS offsets reach 160 K: no 16-bit minimum)
+        oB = min(oB + 4u, xeB);
+      }
+      xiA_next = rec_at(oA);
+      xiB_next = rec_at(oB);
       // the two letters (byte 1 of each record) to the low bytes of the two halves: one v_perm_b32
       const uint32_t xlp = __builtin_amdgcn_perm(xiB, xiA, 0x0c050c01u);
-      // Four forms of the step, each a straight piece of code of its own (chosen by wave-wide tests on the records'
-      // low bits): NEAR -- every lane at a node whose only predecessor is the node before it (a stretch of plain
-      // chain in all windows of the wave): the column one back is the predecessor, nothing to select; plain -- some
-      // lane's predecessor lies two columns back; TWO -- some lane at a node with a second predecessor; VIRT -- some
-      // lane's first predecessor is the virtual start more than two columns back.
       const uint32_t xor_ = xiA | xiB;
-      const bool active = !FIRST || jj >= 1;                         // before its first column a lane keeps column 0
-      uint32_t BRj, BEj, mvw = 0;
-      auto variant = [&](auto near_tag, auto two_tag, auto virt_tag, auto far_tag) {
-        constexpr bool NEAR = decltype(near_tag)::value, TWO = decltype(two_tag)::value, VIRT = decltype(virt_tag)::value;
-        constexpr bool FARV = decltype(far_tag)::value;            // some lane at the node the far edge ends at (TWO and VIRT are on)
-        // per-half select masks: predecessor two columns back (else one)
-        uint32_t M1 = 0, M2 = 0, V1 = 0, V2 = 0, MA = 0, MB = 0, bb1 = BE1;
-        if (!NEAR) {
-          M1 = bfi(0xFFFFu, 0u - (xiA & 1u), 0u - (xiB & 1u));
-          bb1 = bfi(M1, BE2, BE1);
-        }
-        BRj = bb1;
-        // a node without a second predecessor repeats the first (bit 1 = bit 0): when no lane of the wave has one,
-        // everything about the second candidate is left out
-        if (TWO) {
-          M2 = bfi(0xFFFFu, 0u - ((xiA >> 1) & 1u), 0u - ((xiB >> 1) & 1u));
-          uint32_t bb2 = bfi(M2, BE2, BE1);
-          if (VIRT) {
-            V1 = bfi(0xFFFFu, 0u - ((xiA >> 3) & 1u), 0u - ((xiB >> 3) & 1u));
-            // the repeat of a virtual first predecessor is virtual too
-            V2 = V1 & ~bfi(0xFFFFu, 0u - ((xiA >> 2) & 1u), 0u - ((xiB >> 2) & 1u));
-            bb1 = bfi(V1, KOPENNEG, bb1);
-            bb2 = bfi(V2, KOPENNEG, bb2);
-          }
-          if (FARV) {
-            MA = bfi(0xFFFFu, 0u - ((xiA >> 6) & 1u), 0u - ((xiB >> 6) & 1u));
-            MB = bfi(0xFFFFu, 0u - ((xiA >> 7) & 1u), 0u - ((xiB >> 7) & 1u));
-            bb1 = bfi(MA, FBE, bb1);
-            bb2 = bfi(MB, FBE, bb2);
-          }
-          BRj = pk_max(bb1, bb2);
-        }
+      const bool active = !SLOW || jj >= 1;                          // before its first column a lane keeps column 0
+      uint32_t BRj, BEj, mvw = 0, up1 = 0;
+      // the row above: at column jj - 1 (up1), at column jj - 2 (up2, last step's up1), and what it offers a y-gap at column jj
+      auto shifts = [&](uint32_t &up2, uint32_t &upE) {
         BEj = pk_subk(BRj, KEXT);
-        const uint32_t up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);        // row above at column jj - 1
-        const uint32_t up2 = prev_up1;                                 // ... at column jj - 2
+        up1 = pk_shift_in<G>(BR1, Sb[R - 1], g);
+        up2 = prev_up1;
         prev_up1 = up1;
-        const uint32_t upE = pk_shift_in<G>(BEj, Ea[R - 1], g);        // what the row above offers a y-gap at column jj
-        if (FAR) up1_step = up1;
-        if (!active) return;
-        uint32_t dt1 = up1, dt2, insY = upE, secw = 0;
-        if (!NEAR) dt1 = bfi(M1, up2, up1);
-        dt2 = dt1;
-        if (TWO) dt2 = bfi(M2, up2, up1);
-        if (VIRT) { dt1 = bfi(V1, colAbove, dt1); dt2 = bfi(V2, colAbove, dt2); }
-        if (FARV) { dt1 = bfi(MA, Fup, dt1); dt2 = bfi(MB, Fup, dt2); }
-        uint32_t vcS = colS0;                                          // column 0 at this lane's rows, top down
-        static_for<R>([&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-          uint32_t c1S = NEAR ? Sa[k] : bfi(M1, Sb[k], Sa[k]), c1E = NEAR ? Ea[k] : bfi(M1, Eb[k], Ea[k]);
-          uint32_t insX = c1E, dmax = dt1, c2S = c1S;
-          if (VIRT) {
-            if (k > 0) vcS = pk_subk(vcS, KEXT);
-            c1S = bfi(V1, vcS, c1S);
-            c1E = bfi(V1, pk_subk(vcS, KEXT), c1E);
-            insX = c1E;
-          }
-          if (FARV) { c1S = bfi(MA, FS[FAR ? k : 0], c1S); c1E = bfi(MA, FE[FAR ? k : 0], c1E); insX = c1E; }
-          if (TWO) {
-            c2S = bfi(M2, Sb[k], Sa[k]);
-            uint32_t c2E = bfi(M2, Eb[k], Ea[k]);
-            if (VIRT) { c2S = bfi(V2, vcS, c2S); c2E = bfi(V2, pk_subk(vcS, KEXT), c2E); }
-            if (FARV) { c2S = bfi(MB, FS[FAR ? k : 0], c2S); c2E = bfi(MB, FE[FAR ? k : 0], c2E); }
-            insX = pk_max(c1E, c2E);                                // first maximum wins (:361-371)
-            dmax = pk_max(dt1, dt2);                                // (:348-357)
-          }
-          uint32_t Sn, En, mbit;
-          pk_row<2 * k>(xlp, ylp[k], insX, insY, dmax, ONES, KSUB, KEXT, KDELTA, Sn, En, mbit, mvw);
-          if (TWO) {
-            const uint32_t pm = pk_bit(pk_sub(dmax, dt1), ONES);   // second predecessor strictly better on the diagonal
-            const uint32_t px = pk_bit(pk_sub(insX, c1E), ONES);   // ... for the x-insertion
-            secw |= bfi(pk_sub(0u, mbit), pm, px) << k;
-            pin(secw);
-          }
-          dt1 = c1S; dt2 = c2S;
-          Sb[k] = Sn; Eb[k] = En; insY = En;
-        });
-        if (dbg & 4) { ++n_steps; n_two += TWO && !VIRT; n_virt += VIRT; }
-        if (TWO) {
+        upE = pk_shift_in<G>(BEj, Ea[R - 1], g);
+      };
+      auto mask16 = [&](int bit) { return bfi(0xFFFFu, 0u - ((xiA >> bit) & 1u), 0u - ((xiB >> bit) & 1u)); };
+      // one row, the cell in place (an element of a register tuple cannot be bound to a reference: through locals)
+      auto row = [&](auto kc, uint32_t insX, uint32_t iy, uint32_t dm, uint32_t &mb) {
+        constexpr int k = decltype(kc)::value;
+        uint32_t sn = Sb[k], en = Eb[k];
+        pk_row_ip<2 * k>(xlp, ylp[k], insX, iy, dm, ONES, KSUB, KEXT, KDELTA, sn, en, mb, mvw);
+        Sb[k] = sn; Eb[k] = en;
+      };
+      if (__builtin_amdgcn_ballot_w64((xor_ & kFormBits) != 0u) == 0) {
+        // ---- NEAR ----
+        uint32_t up2, upE;
+        BRj = BE1;
+        shifts(up2, upE);
+        if (active) {
+          uint32_t dm = up1, iy = upE, mb;
+          static_for<R>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            row(kc, Ea[k], iy, dm, mb);
+            dm = Sa[k]; iy = Eb[k];
+          });
+        }
+      } else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2 | kFarBits)) != 0u) == 0) {
+        // ---- PLAIN: per half, the predecessor one or two columns back ----
+        const uint32_t M1 = mask16(0);
+        uint32_t up2, upE;
+        BRj = bfi(M1, BE2, BE1);
+        shifts(up2, upE);
+        if (active) {
+          uint32_t dm = bfi(M1, up2, up1), iy = upE, mb;
+          static_for<R>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const uint32_t c1S = bfi(M1, Sb[k], Sa[k]), c1E = bfi(M1, Eb[k], Ea[k]);
+            row(kc, c1E, iy, dm, mb);
+            dm = c1S; iy = Eb[k];
+          });
+        }
+      } else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kFarBits)) != 0u) == 0) {
+        // ---- TWO: some lane at a node with a second predecessor (a node without one repeats the first: bit 1 = bit 0) ----
+        const uint32_t M1 = mask16(0), M2 = mask16(1);
+        uint32_t up2, upE;
+        BRj = pk_max(bfi(M1, BE2, BE1), bfi(M2, BE2, BE1));
+        shifts(up2, upE);
+        if (active) {
+          uint32_t dt1 = bfi(M1, up2, up1), dm = pk_max(dt1, bfi(M2, up2, up1)), iy = upE, secw = 0;
+          static_for<R>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            uint32_t sn = Sb[k], en = Eb[k];
+            pk_row_two<k>(xlp, ylp[k], M1, M2, Sa[k], Ea[k], iy, ONES, KSUB, KEXT, KDELTA, dt1, dm, sn, en, mvw, secw);
+            Sb[k] = sn; Eb[k] = en;
+            iy = en;
+          });
           if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
           if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
+          if (dbg & 4) ++n_two;
         }
-      };
-      if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
-        variant(std::true_type{}, std::false_type{}, std::false_type{}, std::false_type{});
-      else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | kN_Has2 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
-        variant(std::false_type{}, std::false_type{}, std::false_type{}, std::false_type{});
-      else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u))) != 0u) == 0)
-        variant(std::false_type{}, std::true_type{}, std::false_type{}, std::false_type{});
-      else if (!FAR || __builtin_amdgcn_ballot_w64((xor_ & (kN_FarA | kN_FarB)) != 0u) == 0)
-        variant(std::false_type{}, std::true_type{}, std::true_type{}, std::false_type{});
-      else
-        variant(std::false_type{}, std::true_type{}, std::true_type{}, std::integral_constant<bool, FAR>{});
+      } else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Has2 | kFarBits)) != 0u) == 0) {
+        // ---- VIRT1: some lane's predecessor is the virtual start, more than two columns back: column 0, which depends on
+        // the row only ----
+        const uint32_t M1 = mask16(0), V1 = mask16(3);
+        uint32_t up2, upE;
+        BRj = bfi(V1, KOPENNEG, bfi(M1, BE2, BE1));
+        shifts(up2, upE);
+        if (active) {
+          uint32_t dm = bfi(V1, colAbove, bfi(M1, up2, up1)), iy = upE, mb, vcS = colS0;
+          static_for<R>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const uint32_t vcE = pk_subk(vcS, KEXT);                  // (= column 0 one row down)
+            const uint32_t c1S = bfi(V1, vcS, bfi(M1, Sb[k], Sa[k])), c1E = bfi(V1, vcE, bfi(M1, Eb[k], Ea[k]));
+            row(kc, c1E, iy, dm, mb);
+            dm = c1S; iy = Eb[k]; vcS = vcE;
+          });
+          if (dbg & 4) ++n_virt;
+        }
+      } else {
+        // ---- everything: second predecessors, far virtual starts and (FAR) the column kept aside ----
+        const bool farv = FAR && __builtin_amdgcn_ballot_w64((xor_ & (kN_FarA | kN_FarB)) != 0u) != 0;
+        const uint32_t M1 = mask16(0), M2 = mask16(1), V1 = mask16(3);
+        const uint32_t V2 = V1 & ~mask16(2);                         // the repeat of a virtual first predecessor is virtual too
+        const uint32_t MA = farv ? mask16(6) : 0u, MB = farv ? mask16(7) : 0u;
+        uint32_t up2, upE;
+        {
+          uint32_t bb1 = bfi(V1, KOPENNEG, bfi(M1, BE2, BE1)), bb2 = bfi(V2, KOPENNEG, bfi(M2, BE2, BE1));
+          if (FAR) { bb1 = bfi(MA, FBE, bb1); bb2 = bfi(MB, FBE, bb2); }
+          BRj = pk_max(bb1, bb2);
+        }
+        shifts(up2, upE);
+        if (active) {
+          uint32_t dt1 = bfi(V1, colAbove, bfi(M1, up2, up1)), dt2 = bfi(V2, colAbove, bfi(M2, up2, up1));
+          if (FAR) { dt1 = bfi(MA, Fup, dt1); dt2 = bfi(MB, Fup, dt2); }
+          uint32_t iy = upE, secw = 0, vcS = colS0;
+          static_for<R>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const uint32_t vcE = pk_subk(vcS, KEXT);
+            uint32_t c1S = bfi(V1, vcS, bfi(M1, Sb[k], Sa[k])), c1E = bfi(V1, vcE, bfi(M1, Eb[k], Ea[k]));
+            uint32_t c2S = bfi(V2, vcS, bfi(M2, Sb[k], Sa[k])), c2E = bfi(V2, vcE, bfi(M2, Eb[k], Ea[k]));
+            if (FAR) {
+              c1S = bfi(MA, FS[FAR ? k : 0], c1S); c1E = bfi(MA, FE[FAR ? k : 0], c1E);
+              c2S = bfi(MB, FS[FAR ? k : 0], c2S); c2E = bfi(MB, FE[FAR ? k : 0], c2E);
+            }
+            const uint32_t insX = pk_max(c1E, c2E);                  // first maximum wins (:361-371)
+            const uint32_t dmax = pk_max(dt1, dt2);                  // (:348-357)
+            uint32_t mb;
+            row(kc, insX, iy, dmax, mb);
+            const uint32_t pm = pk_bit(pk_sub(dmax, dt1), ONES);     // second predecessor strictly better on the diagonal
+            const uint32_t px = pk_bit(pk_sub(insX, c1E), ONES);     // ... for the x-insertion
+            secw |= bfi(pk_sub(0u, mb), pm, px) << k;
+            pin(secw);
+            dt1 = c1S; dt2 = c2S; iy = Eb[k]; vcS = vcE;
+          });
+          if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
+          if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
+          if (dbg & 4) ++n_virt;
+        }
+      }
+      if (dbg & 4) ++n_steps;
       if (FAR) {
         // the far node's column, just computed, is kept aside; one step later the row above it arrives
         const bool sA = jj == fcol0, sB = jj == fcol1, uA = jj == fcol0 + 1, uB = jj == fcol1 + 1;
         if (__builtin_amdgcn_ballot_w64(sA || sB || uA || uB) != 0) {
           const uint32_t ms = (sA ? 0xFFFFu : 0u) | (sB ? 0xFFFF0000u : 0u), mu = (uA ? 0xFFFFu : 0u) | (uB ? 0xFFFF0000u : 0u);
-#pragma unroll
-          for (int k = 0; k < (FAR ? R : 1); ++k) { FS[k] = bfi(ms, Sb[k], FS[k]); FE[k] = bfi(ms, Eb[k], FE[k]); }
+          static_for<FAR ? R : 1>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            FS[k] = bfi(ms, Sb[k], FS[k]); FE[k] = bfi(ms, Eb[k], FE[k]);
+          });
           FBE = bfi(ms, BEj, FBE);
-          Fup = bfi(mu, up1_step, Fup);
+          Fup = bfi(mu, up1, Fup);
         }
       }
       if (active) {
-        BR2 = BR1; BR1 = BRj; BE2 = BE1; BE1 = BEj;
-        mv[t * 64 + lane] = mvw;                                     // every lane: a lane past its window's end writes a word nobody reads
-        if (((xiA & finA_bit) | (xiB & finB_bit)) != 0u) {
-          const bool finA = (xiA & finA_bit) != 0u, finB = (xiB & finB_bit) != 0u;
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
-            if (finA && k == kstar0) { const int v = pk_half(Sb[k], 0); if (v > best[0]) { best[0] = v; bestx[0] = jj - 1; } }
-            if (finB && k == kstar1) { const int v = pk_half(Sb[k], 1); if (v > best[1]) { best[1] = v; bestx[1] = jj - 1; } }
+        BR1 = BRj; BE2 = BE1; BE1 = BEj;
+        // every lane stores: a lane past its window's end writes a word nobody reads.  The row's address is uniform.
+        typedef __attribute__((address_space(1))) uint32_t gu32;
+        gu32 *mrow = (gu32 *)(mv + (size_t)t * 64);
+        asm volatile("" : "+s"(mrow));
+        mrow[lane] = mvw;
+        if constexpr (SLOW) {
+          if (((xiA & finA_bit) | (xiB & finB_bit)) != 0u) {
+            const bool finA = (xiA & finA_bit) != 0u, finB = (xiB & finB_bit) != 0u;
+            static_for<R>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              if (finA && k == kstar0) { const int v = pk_half(Sb[k], 0); if (v > best[0]) { best[0] = v; bestx[0] = jj - 1; } }
+              if (finB && k == kstar1) { const int v = pk_half(Sb[k], 1); if (v > best[1]) { best[1] = v; bestx[1] = jj - 1; } }
+            });
           }
         }
       }
     };
     {
+      // pairs of steps (t, t + 1), t odd: (S1, E1) and (S2, E2) swap roles.  G is even: the pairs line up with the phases.
+      const int tF = min(tmax + 1, max(G + 1, (tfin - 1) | 1));      // first step of the closing slow phase
       int t = 1;
-      for (; t <= tmax && t < G; t += 2) {                           // G is even: the pairs line up
+      for (; t <= tmax && t <= G; t += 2) {
         step(std::true_type{}, t, S1, E1, S2, E2);
         step(std::true_type{}, t + 1, S2, E2, S1, E1);
       }
+      // the steps in between: the generated loop (the classes that have one), which leaves at a step it has no form for --
+      // that step, or the pair it opens, is then run here -- or the same steps as C++
+      auto offsets_at = [&](int tt) {                                // the running record offsets: record min(jj, n1 + 1) of step tt
+        oA = xbA + 4u * (uint32_t)min(tt - g, n1c0);
+        oB = xbB + 4u * (uint32_t)min(tt - g, n1c1);
+      };
+      if constexpr (!FAR && !kPoaDebug && Dp2Engine<G, R>::kHave) {
+        Dp2Consts cst;
+        cst.xea = xeA; cst.xeb = xeB; cst.cs0 = colS0; cst.cab = colAbove;
+        cst.orda = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_u + pk_align_up(2 * W[0].n1, 4) + g);
+        cst.ordb = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_u + pk_align_up(2 * W[1].n1, 4) + g);
+        cst.one = ONES; cst.ksub = KSUB; cst.kext = KEXT; cst.kdelta = KDELTA; cst.kopen = KOPENNEG; cst.k16 = 0xFFFFu;
+        cst.psel = 0x0c050c01u;
+        const unsigned long long g0mask = __builtin_amdgcn_ballot_w64(g == 0);
+        while (t < tF) {
+          offsets_at(t);
+          Dp2State st;
+          st.a[0] = xiA_next; st.a[1] = xiB_next; st.a[2] = 0u; st.a[3] = 0u; st.a[4] = oA; st.a[5] = oB; st.a[6] = BR1; st.a[7] = prev_up1;
+          st.b[0] = BE1; st.b[1] = BE2;
+          uint32_t loff = (uint32_t)(t * 256 + lane * 4);
+          Dp2Engine<G, R>::run(ylp, S1, E1, S2, E2, st, cst, t, tF, loff, mv, g0mask);
+          xiA_next = st.a[0]; xiB_next = st.a[1]; BR1 = st.a[6]; prev_up1 = st.a[7]; BE1 = st.b[0]; BE2 = st.b[1];
+          if (t < tF) {
+            offsets_at(t);
+            if (t & 1) {
+              step(std::false_type{}, t, S1, E1, S2, E2);
+              step(std::false_type{}, t + 1, S2, E2, S1, E1);
+              t += 2;
+            } else {
+              step(std::false_type{}, t, S2, E2, S1, E1);
+              t += 1;
+            }
+          }
+        }
+      } else if (t < tF) {
+        offsets_at(t);
+        for (; t < tF; t += 2) {
+          step(std::false_type{}, t, S1, E1, S2, E2);
+          step(std::false_type{}, t + 1, S2, E2, S1, E1);
+        }
+      }
       for (; t <= tmax; t += 2) {
-        step(std::false_type{}, t, S1, E1, S2, E2);
-        step(std::false_type{}, t + 1, S2, E2, S1, E1);
+        step(std::true_type{}, t, S1, E1, S2, E2);
+        step(std::true_type{}, t + 1, S2, E2, S1, E1);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the generated loop's stores of moves)
     if ((dbg & 4) && threadIdx.x == 0) {
       atomicAdd(a.stamps + 12, (unsigned long long)n_steps);
       atomicAdd(a.stamps + 13, (unsigned long long)n_two);
