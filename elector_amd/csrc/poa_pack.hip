@@ -373,6 +373,17 @@ struct WinP {
 #define ELECTOR_POA_DEBUG 0
 #endif
 constexpr bool kPoaDebug = ELECTOR_POA_DEBUG != 0;
+// (bisection switches of the generated loops: -DELECTOR_NO_ENG_DP1 / -DELECTOR_NO_ENG_FIRST leave a loop to the C++ steps)
+#ifdef ELECTOR_NO_ENG_DP1
+constexpr bool kUseEngDp1 = false;
+#else
+constexpr bool kUseEngDp1 = true;
+#endif
+#ifdef ELECTOR_NO_ENG_FIRST
+constexpr bool kUseEngFirst = false;
+#else
+constexpr bool kUseEngFirst = true;
+#endif
 #define PK_STAMP(idx)                                                                             \
   do {                                                                                            \
     if ((dbg & 4) && threadIdx.x == 0) {                                                      \
@@ -992,8 +1003,14 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
             max(W.Lr, W.xi_cap) + G + 2 <= a.mv_tw && score_span(kp, max(W.Lr, W.xi_cap) + G, RS) < 16000;
 }
 
+// Three wavefronts per SIMD (168 registers) for every class.  Up to round 4 the classes of up to six rows per lane ran four
+// (128 registers, a dozen or two of them spilled): +6 % then, when a wavefront's life was mostly waiting.  With the
+// dynamic programs as generated loops a wavefront issues close to what a SIMD can take; three of them measured 1-2.5 %
+// FASTER than four (un-overlapped k_poa 5.38 against 5.44 ms on the E. coli batch, 8.41 against 8.62 on yeast -split) --
+// and the four-wave build, at 54 spilled registers beside the loops' pinned ones, ran into the compiler's
+// spill-under-a-narrowed-mask fault again: windows differing from call to call.
 #ifndef ELECTOR_POA_WAVES
-#define ELECTOR_POA_WAVES (R <= 6 ? 4 : 3)
+#define ELECTOR_POA_WAVES 3
 #endif
 template <int G, int R, bool FAR>
 __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArgs a)
@@ -1147,9 +1164,11 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   bool needA[2] = {W[0].valid && W[0].triv == 0, W[1].valid && W[1].triv == 0};
   if (__builtin_amdgcn_ballot_w64(needA[0] || needA[1]) != 0) {
     const uint8_t *xsA = U[0], *xsB = U[1];
-    uint32_t ylp[R], S[R], E[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
+    // (register tuples: the generated loop, poa_engine_gen.h, takes them pinned to fixed registers; S2 is its second column)
+    typedef uint32_t VR __attribute__((ext_vector_type(R)));
+    VR ylp, S, E, S2;
+    static_for<R>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
       const int ii = R * g + 1 + k;
       const int ya = (needA[0] && ii <= W[0].Lc) ? U[0][W[0].Lr + ii - 1] : 255;
       const int yb = (needA[1] && ii <= W[1].Lc) ? U[1][W[1].Lr + ii - 1] : 255;
@@ -1157,7 +1176,8 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       const int v = -(kp.open_y + (ii - 1) * kp.ext_y);       // column -1: ii gap steps from the origin
       S[k] = pk1(v);
       E[k] = pk1(v - kp.ext_x);
-    }
+      S2[k] = 0u;
+    });
     uint32_t dg0 = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // cell (row above, column -1)
     const int tmax = wave_max(max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0)) + G - 1;
     int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? xsA[0] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? xsB[0] : 0;
@@ -1194,19 +1214,50 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
         // the alignment's score: last column, last row -- the lane that holds that row watches for its column
         const bool endA = jj == capA, endB = jj == capB;
         if (endA || endB) {
-#pragma unroll
-          for (int k = 0; k < R; ++k) {
+          static_for<R>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
             if (endA && k == kstar0) W[0].score1 = pk_half(S[k], 0);
             if (endB && k == kstar1) W[1].score1 = pk_half(S[k], 1);
-          }
+          });
         }
       }
     };
     {
       int t = 1;
       for (; t <= tmax && t < G; ++t) stepA(std::true_type{}, t);
+      if constexpr (!kPoaDebug && kUseEngDp1 && Dp1Engine<G, R>::kHave) {
+        // the steps from the first in which every lane computes up to the one in which a window's score appears (its last
+        // row at its last column): the generated loop, in pairs.  It fetches the reference letters without the clamp of
+        // the steps here: every address stays inside the window's slot.
+        int tcap = 0x3fffffff, inside = 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (needA[h]) {
+            tcap = min(tcap, W[h].Lr + (W[h].Lc - 1) / R);
+            if (W[h].off_u + tmax + 2 > a.slot_bytes) inside = 0;
+          }
+        tcap = -wave_max(-tcap);
+        inside = -wave_max(-inside);
+        const int t1 = min(tcap, tmax + 1);
+        if (inside && t == G && t + 2 <= t1) {
+          const int tend = t + ((t1 - t) & ~1);
+          EngState st;
+          st.a[0] = (uint32_t)xa_next; st.a[1] = (uint32_t)xb_next; st.a[2] = 0u; st.a[3] = 0u;
+          // (the letters in hand are those of column t - g: index t - 1 - g, never negative from here on, clamped at the end)
+          st.a[4] = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_u + min(t - 1 - g, lastA));
+          st.a[5] = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_u + min(t - 1 - g, lastB));
+          st.a[6] = dg0; st.a[7] = 0u;
+          st.b[0] = bS; st.b[1] = 0u;
+          EngConsts cst;
+          cst.one = ONES; cst.ksub = KSUB; cst.kext = KEXT; cst.kdelta = KDELTA; cst.kopen = 0u; cst.k16 = 0xFFFFu; cst.psel = 0u;
+          uint32_t loff = (uint32_t)(t * 256 + lane * 4);
+          Dp1Engine<G, R>::run(ylp, S, E, S2, st, cst, t, tend, loff, mv, __builtin_amdgcn_ballot_w64(g == 0));
+          xa_next = (int)st.a[0]; xb_next = (int)st.a[1]; dg0 = st.a[6]; bS = st.b[0];
+        }
+      }
       for (; t <= tmax; ++t) stepA(std::false_type{}, t);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the generated loop's stores of moves)
   }
   // the score sits with the lane that holds the corrected read's last row
 #pragma unroll
@@ -1564,6 +1615,51 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       // pairs of steps (t, t + 1), t odd: (S1, E1) and (S2, E2) swap roles.  G is even: the pairs line up with the phases.
       const int tF = min(tmax + 1, max(G + 1, (tfin - 1) | 1));      // first step of the closing slow phase
       int t = 1;
+      // the generated loops (poa_engine_gen.h) and what they take and hand back
+      constexpr bool kEngine = !FAR && !kPoaDebug && Dp2Engine<G, R>::kHave;
+      EngState est;
+      EngLane ecn;
+      EngConsts ecs;
+      const unsigned long long g0mask = __builtin_amdgcn_ballot_w64(g == 0);
+      if constexpr (kEngine) {
+        ecn.v[0] = xeA; ecn.v[1] = xeB; ecn.v[2] = colS0; ecn.v[3] = colAbove;
+        ecn.v[4] = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_u + pk_align_up(2 * W[0].n1, 4) + g);
+        ecn.v[5] = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_u + pk_align_up(2 * W[1].n1, 4) + g);
+        ecn.v[6] = (uint32_t)g; ecn.v[7] = 0u;
+        ecs.one = ONES; ecs.ksub = KSUB; ecs.kext = KEXT; ecs.kdelta = KDELTA; ecs.kopen = KOPENNEG; ecs.k16 = 0xFFFFu;
+        ecs.psel = 0x0c050c01u;
+      }
+      auto eng_in = [&]() {
+        est.a[0] = xiA_next; est.a[1] = xiB_next; est.a[2] = 0u; est.a[3] = 0u; est.a[4] = oA; est.a[5] = oB; est.a[6] = BR1; est.a[7] = prev_up1;
+        est.b[0] = BE1; est.b[1] = BE2;
+      };
+      auto eng_out = [&]() {
+        xiA_next = est.a[0]; xiB_next = est.a[1]; BR1 = est.a[6]; prev_up1 = est.a[7]; BE1 = est.b[0]; BE2 = est.b[1];
+      };
+      // behind the steps in which some lane has no column yet -- or, sooner, at the step from which final nodes are watched
+      // for (short windows): those steps run here, with the test
+      const int tG = min(min(tmax, G) + 1, (tfin - 1) | 1);
+      if constexpr (kEngine && kUseEngFirst) {
+        while (t < tG) {
+          // (the record offsets: record max(t - g, 0) of the step to run; the statement advances them lane by lane)
+          oA = xbA + 4u * (uint32_t)min(max(t - g, 0), n1c0);
+          oB = xbB + 4u * (uint32_t)min(max(t - g, 0), n1c1);
+          eng_in();
+          uint32_t loff = (uint32_t)(t * 256 + lane * 4);
+          Dp2Engine<G, R>::run_first(ylp, S1, E1, S2, E2, est, ecn, ecs, t, tG, loff, mv, g0mask);
+          eng_out();
+          if (t < tG) {
+            if (t & 1) {
+              step(std::true_type{}, t, S1, E1, S2, E2);
+              step(std::true_type{}, t + 1, S2, E2, S1, E1);
+              t += 2;
+            } else {
+              step(std::true_type{}, t, S2, E2, S1, E1);
+              t += 1;
+            }
+          }
+        }
+      }
       for (; t <= tmax && t <= G; t += 2) {
         step(std::true_type{}, t, S1, E1, S2, E2);
         step(std::true_type{}, t + 1, S2, E2, S1, E1);
@@ -1574,22 +1670,13 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
         oA = xbA + 4u * (uint32_t)min(tt - g, n1c0);
         oB = xbB + 4u * (uint32_t)min(tt - g, n1c1);
       };
-      if constexpr (!FAR && !kPoaDebug && Dp2Engine<G, R>::kHave) {
-        Dp2Consts cst;
-        cst.xea = xeA; cst.xeb = xeB; cst.cs0 = colS0; cst.cab = colAbove;
-        cst.orda = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_u + pk_align_up(2 * W[0].n1, 4) + g);
-        cst.ordb = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_u + pk_align_up(2 * W[1].n1, 4) + g);
-        cst.one = ONES; cst.ksub = KSUB; cst.kext = KEXT; cst.kdelta = KDELTA; cst.kopen = KOPENNEG; cst.k16 = 0xFFFFu;
-        cst.psel = 0x0c050c01u;
-        const unsigned long long g0mask = __builtin_amdgcn_ballot_w64(g == 0);
+      if constexpr (kEngine) {
         while (t < tF) {
           offsets_at(t);
-          Dp2State st;
-          st.a[0] = xiA_next; st.a[1] = xiB_next; st.a[2] = 0u; st.a[3] = 0u; st.a[4] = oA; st.a[5] = oB; st.a[6] = BR1; st.a[7] = prev_up1;
-          st.b[0] = BE1; st.b[1] = BE2;
+          eng_in();
           uint32_t loff = (uint32_t)(t * 256 + lane * 4);
-          Dp2Engine<G, R>::run(ylp, S1, E1, S2, E2, st, cst, t, tF, loff, mv, g0mask);
-          xiA_next = st.a[0]; xiB_next = st.a[1]; BR1 = st.a[6]; prev_up1 = st.a[7]; BE1 = st.b[0]; BE2 = st.b[1];
+          Dp2Engine<G, R>::run(ylp, S1, E1, S2, E2, est, ecn, ecs, t, tF, loff, mv, g0mask);
+          eng_out();
           if (t < tF) {
             offsets_at(t);
             if (t & 1) {
