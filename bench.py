@@ -117,8 +117,8 @@ def parse():
         args.profile_defaulted = True
     else:
         args.profile_defaulted = False
-    if args.serial and "--batches" not in sys.argv[1:]:
-        args.batches = 1                                # the per-kernel passes (profiles/) look at one batch
+    # (--serial rotates over the same batches as the timed region: the per-kernel tables and PMC passes under profiles/ are
+    # averages over the rotation, like `value`; --batches 1 is the single batch of rounds 2-4)
     if args.profile == "chr1_20x_ont_50kb" and "--reads" not in " ".join(sys.argv[1:]) and "ELECTOR_BENCH_READS" not in os.environ:
         args.reads = 2000                               # 50 kb reads: 2,000 of them are a batch of the usual size in bases
     return args
@@ -243,10 +243,12 @@ def cpu_baseline(windows, ref_bases_per_window, seconds, device_msa=None):
                                      "the %s: header lines and the three rows, byte by byte"
                                      % ("timed batch" if ns == nwin else "sample")}
         nb = float(cum[ns - 1])
-        return {"value": round(nb / dt / 1e6, 4), "unit": "Mbases/s", "cores": len(cmds), "kind": "reference",
-                "cpu_share": cpu_share(),             # what the container may actually use of those (affinity mask, cgroup quota)
-                "sample": "%d windows (%d reference bases) of the step's window stream, one reference poa "
-                          "process per core as elector/alignment.py's Pool does, wall %.2f s" % (ns, int(nb), dt)}, parity
+        # cores: what the processes could actually run on (affinity mask / cgroup quota of this box), not the host's count
+        return {"value": round(nb / dt / 1e6, 4), "unit": "Mbases/s", "cores": min(len(cmds), cpu_share()), "kind": "reference",
+                "processes": len(cmds), "host_cores": ncores,
+                "sample": "%d windows (%d reference bases) of the step's window stream, one reference poa process per host core "
+                          "as elector/alignment.py's Pool does (%d processes on the %d cores this box may use), wall %.2f s"
+                          % (ns, int(nb), len(cmds), min(len(cmds), cpu_share()), dt)}, parity
     # port: single-threaded C oracle
     target_bases = 0.4e6 * seconds
     cum = np.cumsum(ref_bases_per_window)
@@ -596,6 +598,7 @@ def main():
             self.last_counters = None
             self.last_batch_of_engine = [None] * n_eng
             self.rows_bytes = 0
+            self.done_at = {}                 # step id -> when its counters were on the host
             self.gather = gather and dist_on
             self.held, self.gathers = [], []
             if self.gather:
@@ -613,6 +616,7 @@ def main():
             got.append(counters)
             if len(got) == len(self.units[ui]):
                 del self.parts[sid]
+                self.done_at[sid] = time.perf_counter()
                 c = np.concatenate(got) if len(got) > 1 else got[0]
                 if self.gather:
                     tg = time.perf_counter()
@@ -691,6 +695,7 @@ def main():
             for g in engines:
                 g.sync()
             self.host_enqueue_s = self.host_wait_s = self.gather_s = 0.0
+            self.first_timed = self.step_id
             t0 = time.perf_counter()
             for _ in range(steps):
                 self.step(rows)
@@ -740,15 +745,31 @@ def main():
             g.timing_enable(args.serial)
             g.timing_reset()
         dt = run.timed(steps, True)
-        res = {"dt": dt, "host_enqueue_ms": run.host_enqueue_s / steps * 1e3, "host_wait_ms": run.host_wait_s / steps * 1e3,
+        # between the completions of the sixth and the last timed step: the region without its fill (the first batches find an
+        # empty pipeline) -- the drain at the end stays in
+        steady = None
+        f0 = run.first_timed
+        if steps >= 8 and f0 + 5 in run.done_at and f0 + steps - 1 in run.done_at:
+            steady = (run.done_at[f0 + steps - 1] - run.done_at[f0 + 5]) / (steps - 6)
+        res = {"dt": dt, "steady_s_per_step": steady, "host_enqueue_ms": run.host_enqueue_s / steps * 1e3, "host_wait_ms": run.host_wait_s / steps * 1e3,
                "gather_ms": run.gather_s / steps * 1e3, "counters": run.last_counters, "rows_bytes": run.rows_bytes,
                "last_batch_of_engine": list(run.last_batch_of_engine), "dt_hbm": None}
         # the MSA the timed kernels wrote (context 0's last timed batch), for the comparison with the reference binary
         # behind the clock
+        # (one entry per DISTINCT batch: the last timed steps went round the contexts, so between them the contexts hold every
+        # batch of the rotation)
         res["msa0"] = None
-        if rank == 0 and world == 1 and not args.no_cpu_baseline and run.last_batch_of_engine[0] is not None:
-            b0 = run.last_batch_of_engine[0]
-            res["msa0"] = (b0, outs[0][0][:3 * b0.total + 64].cpu().numpy(), outs[0][1][:b0.n].cpu().numpy())
+        res["msa_all"] = []
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            seen = set()
+            for e in range(n_eng):
+                be = run.last_batch_of_engine[e]
+                if be is None or id(be) in seen:
+                    continue
+                seen.add(id(be))
+                res["msa_all"].append((be, outs[e][0][:3 * be.total + 64].cpu().numpy(), outs[e][1][:be.n].cpu().numpy()))
+            if res["msa_all"]:
+                res["msa0"] = res["msa_all"][0]
         if second_loop:
             run2 = Runner(units, gather)
             for _ in range(n_eng + 1):
@@ -801,17 +822,22 @@ def main():
         engines = [eng]
         eng.option("chains", 1)
 
-        def serial_step():
-            align(eng, b0, d_cols, d_ncol, d_status)
-            eng.msa_stats_collect(eng.msa_stats_enqueue(b0.n, d_cols, d_ncol, d_status, b0.piece_first, b0.read_first))
-        for _ in range(4):                       # grow the workspace, settle the clocks
-            serial_step()
+        # (the serial pass goes round the batches of the rotation like the timed region: a step per batch and round)
+        ser_batches = [b0] if strong else list(head_batches)
+        serial_steps = len(ser_batches) * max(1, (serial_steps + len(ser_batches) - 1) // len(ser_batches))
+
+        def serial_step(i):
+            bs = ser_batches[i % len(ser_batches)]
+            align(eng, bs, d_cols, d_ncol, d_status)
+            eng.msa_stats_collect(eng.msa_stats_enqueue(bs.n, d_cols, d_ncol, d_status, bs.piece_first, bs.read_first))
+        for i in range(max(4, len(ser_batches))):  # grow the workspace, settle the clocks
+            serial_step(i)
         eng.sync()
         eng.timing_enable(True)
         eng.timing_reset()
         ts = time.perf_counter()
-        for _ in range(serial_steps):
-            serial_step()
+        for i in range(serial_steps):
+            serial_step(i)
         eng.sync()
         serial_wall = (time.perf_counter() - ts) / serial_steps
     eng = engines[0]
@@ -845,7 +871,11 @@ def main():
     me = {"rank": rank, "local_rank": local, "device": props.name, "uuid": str(getattr(props, "uuid", "")),
           "pci_bus_id": int(getattr(props, "pci_bus_id", -1)), "host": socket.gethostname(),
           "reads": int(sum(b.n_reads for b in head_batches)) if strong else int(b0.n_reads if b0 else 0),
-          "dp_cells_per_step": my_cells}
+          "dp_cells_per_step": my_cells,
+          # this rank's host side of the timed region (ms per step) and its setup: what eight ranks on one node's cores cost
+          "host_classify_and_enqueue_ms": round(R["host_enqueue_ms"], 3), "host_wait_for_results_ms": round(R["host_wait_ms"], 3),
+          "ms_per_step": round(dt / args.steps * 1e3, 3), "setup_s": round(t_setup, 1),
+          "counters_checksum": int(counters[:, :ES_NCOUNTERS - 1].sum()) if (counters is not None and rank == 0) else None}
     ranks = [me]
     if dist_on:
         ranks = [None] * world
@@ -856,9 +886,10 @@ def main():
     if rank == 0:
         value = bases_all * args.steps / dt_max / 1e6
         step_s = dt_max / args.steps
-        # roofline of the dominant kernel: algorithmic bytes = 8-bit inputs + 8-bit MSA out + descriptors (batch 0, the
-        # serial pass's batch)
-        alg_bytes = int((b0.lr + b0.lc + b0.lu).sum() + 3 * b0.ncol_sum + 28 * b0.n) if b0 is not None else 0
+        # roofline of the dominant kernel: algorithmic bytes = 8-bit inputs + 8-bit MSA out + descriptors (a step's average
+        # over the rotated batches, which the serial pass goes round too)
+        ab = [b0] if (strong or args.serial and len(head_batches) == 1) else list(head_batches)
+        alg_bytes = int(sum(int((b.lr + b.lc + b.lu).sum()) + 3 * b.ncol_sum + 28 * b.n for b in ab) / max(1, len(ab))) if b0 is not None else 0
         # kernel classes: 4 = k_poa (the whole window in one kernel: both alignments, tracebacks, fusions); 0 / 1 =
         # alignment #1 / #2 stage of the two-kernel path (k_fused_a / k_fused_b; behind k_poa only the windows it
         # handed back); measured un-overlapped (serial pass)
@@ -880,6 +911,11 @@ def main():
             "metric": "triplet-MSA Mbases/s", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            # the timed region without its fill: from the completion (counters on the host) of its sixth step to that of its last
+            "steady_state": None if not R.get("steady_s_per_step") else {
+                "ms_per_step": round(R["steady_s_per_step"] * 1e3, 3), "value": round(bases_all / R["steady_s_per_step"] / 1e6, 3),
+                "note": "steps 6 .. %d of the timed region between completion events on rank 0; `value` and `ms_per_step` above are "
+                        "the whole region (fill and drain included)" % args.steps},
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "%s: %d reads per GPU per step, cut into windows by the ELECTOR splitter rules"
                                    % (WORKLOADS[args.profile], args.reads) if not strong else
@@ -925,10 +961,10 @@ def main():
                                    "host_classify_and_enqueue": round(R["host_enqueue_ms"], 3),
                                    "host_wait_for_results": round(R["host_wait_ms"], 3),
                                    "host_counters_gather": round(R["gather_ms"], 3),
-                                   "note": "HIP-event time per launch, summed per step, from %d un-overlapped steps over batch 0 "
-                                           "(one context, one launch chain)%s"
-                                           % (serial_steps, "" if args.serial else
-                                              " in a fresh context after the timed region, = what `bench.py --serial --batches 1` times")},
+                                   "note": "HIP-event time per launch, summed per step, from %d un-overlapped steps over the %d rotated "
+                                           "batches (one context, one launch chain)%s"
+                                           % (serial_steps, len(head_batches), "" if args.serial else
+                                              " in a fresh context after the timed region, = what `bench.py --serial` times")},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_provenance": pmc_prov if traffic is not None else None,
@@ -936,15 +972,18 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "whole_step_frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 6)},
             # what actually binds: VALU issue + latency.  Per GPU: wave-instructions per
-            # step from the committed PMC passes of this command (batch 0), time measured live
+            # step from the committed PMC passes of `bench.py --serial` (averaged over the rotated batches), time measured live
             "roofline_valu": None if valu is None else {
                 "bound": "valu-issue", "wave_insts_per_step": valu, "provenance": pmc_prov, "peak": round(VALU_PEAK_GINSTS, 1),
                 "peak_two_operand_32bit": round(VALU_PEAK_GINSTS_SIMPLE, 1),
                 "peak_note": "packed 16-bit, three-operand and DPP instructions issue once per 4 cycles per SIMD "
                              "(measured: tests/micro/valu_rate.hip, profiles/r02_valu_rate.txt)",
                 "unit": "G wave-insts/s per GPU",
-                "achieved": round(valu / (dt_hbm_max / args.steps if dt_hbm_max else step_s) / 1e9, 1),
-                "frac": round(valu / (dt_hbm_max / args.steps if dt_hbm_max else step_s) / 1e9 / VALU_PEAK_GINSTS, 4)},
+                # of `value`'s own step time; the same with the rows left in HBM beside it
+                "achieved": round(valu / step_s / 1e9, 1),
+                "frac": round(valu / step_s / 1e9 / VALU_PEAK_GINSTS, 4),
+                "achieved_rows_in_hbm": None if not dt_hbm_max else round(valu / (dt_hbm_max / args.steps) / 1e9, 1),
+                "frac_rows_in_hbm": None if not dt_hbm_max else round(valu / (dt_hbm_max / args.steps) / 1e9 / VALU_PEAK_GINSTS, 4)},
             "pieces_gathered": int(counters.shape[0]) if counters is not None else 0,
             "counters_checksum": int(counters[:, :ES_NCOUNTERS - 1].sum()) if counters is not None else 0,
             "setup_s": round(t_setup, 1),
@@ -958,7 +997,15 @@ def main():
             # the MSA columns of a batch the timed region worked on, as the last timed batch of context 0 left them
             mb, mcols, mncol = R["msa0"]
             out["cpu_baseline"], parity = cpu_baseline(mb.win, mb.lr, args.cpu_seconds, (mcols, mncol))
+            # ... and the other batches of the rotation, each as a context left it (their CPU time is not the baseline's)
+            for (ob_, ocols, oncol) in R["msa_all"][1:]:
+                _, par2 = cpu_baseline(ob_.win, ob_.lr, args.cpu_seconds, (ocols, oncol))
+                if parity is not None and par2 is not None:
+                    parity["windows"] += par2["windows"]
+                    parity["differing"] += par2["differing"]
             if parity is not None:
+                parity["batches_compared"] = len(R["msa_all"])
+                parity["batches_rotated"] = len(head_batches)
                 out["parity_vs_reference"] = parity
         if configs:
             out["configs"] = configs

@@ -60,13 +60,20 @@ struct HostPinned {
 struct TimedSpan { hipEvent_t a, b; int kind; };
 
 // one merge + statistics job of the device pipeline (elector_msa_stats_enqueue / _collect)
+// the rows' copy on the DMA engine through the HSA runtime (rows_dma.cpp)
+int rows_dma_start(int hip_device, void *dst, const void *src, size_t n, uint64_t *sig);
+int rows_dma_wait(uint64_t sig);
+void rows_dma_release(uint64_t *sig);
+
 struct StatsSlot {
   DevBuf rows, rowoff, cols, first, clips, cnt, mask, woff;
   DevBuf dense, outoff;         // elector_msa_stats_enqueue_rows: the merged rows packed (host destinations), their offsets
   DevBuf wcnt, wpiece;          // window-parallel merge: surviving columns per window and their scan, piece of a window
   HostPinned h;                 // [overflow flag, pad to 16][counters][cols][inputs]
   hipEvent_t done = nullptr;
-  hipEvent_t rows_done = nullptr;   // the packed rows have arrived at rows_host (recorded on the context's copy stream)
+  hipEvent_t rows_done = nullptr;   // the packed rows have arrived at rows_host (recorded on the context's copy stream) ...
+  uint64_t rows_sig = 0;            // ... or, the copy started through HSA, its completion signal (rows_by_dma)
+  bool rows_by_dma = false;
   uint8_t *rows_host = nullptr;     // this job's rows go to this page-locked host address when it is collected
   bool rows_inflight = false;
   int64_t n_pieces = 0, n_reads = 0, total = 0, last_piece = 0, max_windows = 0;
@@ -77,6 +84,7 @@ struct StatsSlot {
     mask.release(); woff.release(); h.release(); dense.release(); outoff.release(); wcnt.release(); wpiece.release();
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     if (rows_done) { (void)hipEventDestroy(rows_done); rows_done = nullptr; }
+    rows_dma_release(&rows_sig);
   }
 };
 
@@ -128,7 +136,6 @@ struct elector_ctx {
   elector::StatsSlot st_slot[kStatsSlots];
   int st_head = 0, st_tail = 0, st_inflight = 0, st_last = -1;
   hipStream_t copy_stream = nullptr;   // the rows' way to the host: the copy engine works beside the kernels of the next batch
-  hipStream_t copy_stream2 = nullptr;  // ELECTOR_ROWS_COPY_STREAMS=2 (experiment): the second half of a batch's rows on a stream of its own
   // timing
   bool timing = false;
   std::vector<elector::TimedSpan> spans;

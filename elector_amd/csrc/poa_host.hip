@@ -329,7 +329,6 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
     for (int k = 0; k < elector_ctx::kAux; ++k) { (void)hipStreamDestroy(c->aux[k]); (void)hipEventDestroy(c->aux_done[k]); }
     (void)hipEventDestroy(c->fork);
   }
-  if (c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

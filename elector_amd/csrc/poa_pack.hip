@@ -363,6 +363,40 @@ struct WinP {
   int fnode;                // node the one far edge of the graph comes from (-1: none)
 };
 
+// Across a dynamic program nothing of a window is wanted but what the loop itself holds; the rest -- lengths, flags, what the
+// phases so far have found -- waits in the 16-byte header of the window's LDS slot (free once the symbols are staged) and is
+// read back behind the loop, the window's id and output offset from its descriptor in memory.  The compiler parked the same
+// values in scratch memory (up to 33 registers spilled per instance); spilled registers are what its fault of DESIGN.md 4.1
+// needs, and the build accepts none in k_poa (tools/check_spills.py).
+//   [0] Lr | Lc << 16   [1] Lu | triv << 16 | valid << 20 | k2n << 24   [2] n1 | (fnode + 1) << 16   [3] score1
+__device__ __forceinline__ void park_win(const WinP &W, int g)
+{
+  if (g == 0) {
+    uint4 hd;
+    hd.x = (uint32_t)W.Lr | ((uint32_t)W.Lc << 16);
+    hd.y = (uint32_t)W.Lu | ((uint32_t)W.triv << 16) | (W.valid ? 1u << 20 : 0u) | ((uint32_t)W.k2n << 24);
+    hd.z = (uint32_t)W.n1 | ((uint32_t)(W.fnode + 1) << 16);
+    hd.w = (uint32_t)W.score1;
+    *reinterpret_cast<uint4 *>(W.slot) = hd;
+  }
+}
+// desc: the window's two descriptor words in memory (k_gather's PackDesc)
+__device__ __forceinline__ void unpark_win(WinP &W, uint8_t *slot, const uint4 *desc)
+{
+  const uint4 d0 = desc[0], d1 = desc[1];
+  const uint4 hd = *reinterpret_cast<const uint4 *>(slot);
+  W.slot = slot;
+  W.Lr = (int)(hd.x & 0xFFFFu); W.Lc = (int)(hd.x >> 16);
+  W.Lu = (int)(hd.y & 0xFFFFu); W.triv = (int)((hd.y >> 16) & 7u); W.valid = ((hd.y >> 20) & 1u) != 0u; W.k2n = (int)(hd.y >> 24);
+  W.n1 = (int)(hd.z & 0xFFFFu); W.fnode = (int)(hd.z >> 16) - 1;
+  W.score1 = (int)hd.w;
+  W.xi_cap = poa_xi_cap(W.Lr, W.Lc);
+  W.off_xi = 16 + pk_align_up(W.Lu, 4);
+  W.off_u = W.off_xi + 4 * (W.xi_cap + 2);
+  W.w = d0.x;
+  W.o0 = W.valid ? (int64_t)(((uint64_t)d1.y << 32) | d1.x) : 0;
+}
+
 // phase stamps (debug bit 2): cycles per phase summed over waves
 // The debug facilities of k_poa (PackArgs::debug: phase stamps, why windows leave, phases dropped for instruction counts,
 // round 2's traceback) are compiled in with -DELECTOR_POA_DEBUG=1 only (ELECTOR_HIPCC_FLAGS): their branches -- each an
@@ -1013,7 +1047,7 @@ __device__ __forceinline__ void fit_win(WinP &W, const PackArgs &a, bool listed,
 #define ELECTOR_POA_WAVES 3
 #endif
 template <int G, int R, bool FAR>
-__global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArgs a)
+__global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
 {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NP = 64 / G;                       // pairs of windows per wave
@@ -1050,6 +1084,17 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   uint8_t *us[2], *U[2];
   uint32_t *xinfo[2];
   bool any_valid;
+  // the windows' values back from their slot headers (park_win), the pointers into the slots with them
+  auto unpark = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t e = 2 * pi + h < nlist ? 2 * pi + h : 0;
+      unpark_win(W[h], lds + 64 + (size_t)(2 * LG<G>::q((int)threadIdx.x) + h) * a.slot_bytes, a.pdesc + 2 * e);
+      us[h] = W[h].slot + 16;
+      xinfo[h] = reinterpret_cast<uint32_t *>(W[h].slot + W[h].off_xi);
+      U[h] = W[h].slot + W[h].off_u;
+    }
+  };
   {
     constexpr int UB = G == 8 ? 8 : 4;                          // dwords per lane, window and round
     bool inl[2];
@@ -1163,7 +1208,8 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
   // ================= alignment #1 (linear x linear), the windows that need it =================
   bool needA[2] = {W[0].valid && W[0].triv == 0, W[1].valid && W[1].triv == 0};
   if (__builtin_amdgcn_ballot_w64(needA[0] || needA[1]) != 0) {
-    const uint8_t *xsA = U[0], *xsB = U[1];
+    // (the reference letters by their LDS offset: no pointer lives through the loop)
+    const uint32_t oxA = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_u), oxB = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_u);
     // (register tuples: the generated loop, poa_engine_gen.h, takes them pinned to fixed registers; S2 is its second column)
     typedef uint32_t VR __attribute__((ext_vector_type(R)));
     VR ylp, S, E, S2;
@@ -1180,11 +1226,12 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
     });
     uint32_t dg0 = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // cell (row above, column -1)
     const int tmax = wave_max(max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0)) + G - 1;
-    int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? xsA[0] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? xsB[0] : 0;
+    int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? lds[oxA] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? lds[oxB] : 0;
     const int gstar0 = (W[0].Lc - 1) / R, kstar0 = (W[0].Lc - 1) % R, gstar1 = (W[1].Lc - 1) / R, kstar1 = (W[1].Lc - 1) % R;
     uint32_t bS = pk1(-kp.open_x);                             // row -1 at column t: -(open_x + (t - 1) ext_x)
     const int lastA = max(W[0].Lr - 1, 0), lastB = max(W[1].Lr - 1, 0);
     const int capA = (needA[0] && g == gstar0) ? W[0].Lr : -1, capB = (needA[1] && g == gstar1) ? W[1].Lr : -1;   // column to watch, or none
+    int sc1a = kNeg, sc1b = kNeg;                              // the two scores, where they appear
     // FIRST: the steps in which some lane has not reached its first column yet (t < G)
     auto stepA = [&](auto first_tag, int t) {
       constexpr bool FIRST = decltype(first_tag)::value;
@@ -1194,8 +1241,8 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       const int jj = t - g;
       const uint32_t xlp = (uint32_t)xa_next | ((uint32_t)xb_next << 16);
       // (clamped, no test: past the window's last column a lane computes cells nobody reads)
-      xa_next = xsA[med3(jj, 0, lastA)];
-      xb_next = xsB[med3(jj, 0, lastB)];
+      xa_next = lds[oxA + (uint32_t)med3(jj, 0, lastA)];
+      xb_next = lds[oxB + (uint32_t)med3(jj, 0, lastB)];
       if (!FIRST || jj >= 1) {                                     // (past its window's last column a lane computes on: nobody reads it)
         uint32_t diag = dg0, insY = upE, mvw = 0;
         static_for<R>([&](auto kc) {
@@ -1216,26 +1263,29 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
         if (endA || endB) {
           static_for<R>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            if (endA && k == kstar0) W[0].score1 = pk_half(S[k], 0);
-            if (endB && k == kstar1) W[1].score1 = pk_half(S[k], 1);
+            if (endA && k == kstar0) sc1a = pk_half(S[k], 0);
+            if (endB && k == kstar1) sc1b = pk_half(S[k], 1);
           });
         }
       }
     };
     {
       int t = 1;
+      // (what the loop below needs of the windows, taken before they go to their slot headers)
+      int tcap = 0x3fffffff, inside = 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (needA[h]) {
+          tcap = min(tcap, W[h].Lr + (W[h].Lc - 1) / R);
+          if (W[h].off_u + tmax + 2 > a.slot_bytes) inside = 0;
+        }
+      park_win(W[0], g);
+      park_win(W[1], g);
       for (; t <= tmax && t < G; ++t) stepA(std::true_type{}, t);
-      if constexpr (!kPoaDebug && kUseEngDp1 && Dp1Engine<G, R>::kHave) {
+      if constexpr (kUseEngDp1 && Dp1Engine<G, R>::kHave) {
         // the steps from the first in which every lane computes up to the one in which a window's score appears (its last
         // row at its last column): the generated loop, in pairs.  It fetches the reference letters without the clamp of
         // the steps here: every address stays inside the window's slot.
-        int tcap = 0x3fffffff, inside = 1;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          if (needA[h]) {
-            tcap = min(tcap, W[h].Lr + (W[h].Lc - 1) / R);
-            if (W[h].off_u + tmax + 2 > a.slot_bytes) inside = 0;
-          }
         tcap = -wave_max(-tcap);
         inside = -wave_max(-inside);
         const int t1 = min(tcap, tmax + 1);
@@ -1244,8 +1294,8 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
           EngState st;
           st.a[0] = (uint32_t)xa_next; st.a[1] = (uint32_t)xb_next; st.a[2] = 0u; st.a[3] = 0u;
           // (the letters in hand are those of column t - g: index t - 1 - g, never negative from here on, clamped at the end)
-          st.a[4] = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_u + min(t - 1 - g, lastA));
-          st.a[5] = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_u + min(t - 1 - g, lastB));
+          st.a[4] = oxA + (uint32_t)min(t - 1 - g, lastA);
+          st.a[5] = oxB + (uint32_t)min(t - 1 - g, lastB);
           st.a[6] = dg0; st.a[7] = 0u;
           st.b[0] = bS; st.b[1] = 0u;
           EngConsts cst;
@@ -1258,6 +1308,9 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       for (; t <= tmax; ++t) stepA(std::false_type{}, t);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the generated loop's stores of moves)
+    unpark();
+    if (needA[0]) W[0].score1 = sc1a;
+    if (needA[1]) W[1].score1 = sc1b;
   }
   // the score sits with the lane that holds the corrected read's last row
 #pragma unroll
@@ -1425,6 +1478,9 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       for (int k = 0; k < R; ++k) FS[k] = FE[k] = 0;
     }
     int n_steps = 0, n_two = 0, n_virt = 0;                        // debug: steps per code path
+    // the two windows' ordinal bytes (this lane's column of them) by LDS offset
+    const uint32_t ordA = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_u + pk_align_up(2 * W[0].n1, 4) + g);
+    const uint32_t ordB = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_u + pk_align_up(2 * W[1].n1, 4) + g);
     const uint32_t kFormBits = kN_Far1 | kN_Far2 | kN_Has2 | kN_Virt1 | (FAR ? kN_FarA | kN_FarB : 0u);
     const uint32_t kFarBits = FAR ? kN_FarA | kN_FarB : 0u;
 
@@ -1515,8 +1571,8 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
             Sb[k] = sn; Eb[k] = en;
             iy = en;
           });
-          if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
-          if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
+          if (xiA & kN_Has2) lds[ordA + (xiA >> 24) * G] = (uint8_t)secw;
+          if (xiB & kN_Has2) lds[ordB + (xiB >> 24) * G] = (uint8_t)(secw >> 16);
           if (dbg & 4) ++n_two;
         }
       } else if (__builtin_amdgcn_ballot_w64((xor_ & (kN_Has2 | kFarBits)) != 0u) == 0) {
@@ -1573,8 +1629,8 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
             pin(secw);
             dt1 = c1S; dt2 = c2S; iy = Eb[k]; vcS = vcE;
           });
-          if (xiA & kN_Has2) ordb[0][(xiA >> 24) * G + g] = (uint8_t)secw;
-          if (xiB & kN_Has2) ordb[1][(xiB >> 24) * G + g] = (uint8_t)(secw >> 16);
+          if (xiA & kN_Has2) lds[ordA + (xiA >> 24) * G] = (uint8_t)secw;
+          if (xiB & kN_Has2) lds[ordB + (xiB >> 24) * G] = (uint8_t)(secw >> 16);
           if (dbg & 4) ++n_virt;
         }
       }
@@ -1615,16 +1671,19 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       // pairs of steps (t, t + 1), t odd: (S1, E1) and (S2, E2) swap roles.  G is even: the pairs line up with the phases.
       const int tF = min(tmax + 1, max(G + 1, (tfin - 1) | 1));      // first step of the closing slow phase
       int t = 1;
+      // nothing of the windows is wanted from here to the end of the loops: to their slot headers
+      park_win(W[0], g);
+      park_win(W[1], g);
       // the generated loops (poa_engine_gen.h) and what they take and hand back
-      constexpr bool kEngine = !FAR && !kPoaDebug && Dp2Engine<G, R>::kHave;
+      constexpr bool kEngine = !FAR && Dp2Engine<G, R>::kHave;           // (a debug build's step counters see the C++ steps only)
       EngState est;
       EngLane ecn;
       EngConsts ecs;
       const unsigned long long g0mask = __builtin_amdgcn_ballot_w64(g == 0);
       if constexpr (kEngine) {
         ecn.v[0] = xeA; ecn.v[1] = xeB; ecn.v[2] = colS0; ecn.v[3] = colAbove;
-        ecn.v[4] = (uint32_t)(64 + (2 * q) * a.slot_bytes + W[0].off_u + pk_align_up(2 * W[0].n1, 4) + g);
-        ecn.v[5] = (uint32_t)(64 + (2 * q + 1) * a.slot_bytes + W[1].off_u + pk_align_up(2 * W[1].n1, 4) + g);
+        ecn.v[4] = ordA;
+        ecn.v[5] = ordB;
         ecn.v[6] = (uint32_t)g; ecn.v[7] = 0u;
         ecs.one = ONES; ecs.ksub = KSUB; ecs.kext = KEXT; ecs.kdelta = KDELTA; ecs.kopen = KOPENNEG; ecs.k16 = 0xFFFFu;
         ecs.psel = 0x0c050c01u;
@@ -1702,11 +1761,17 @@ __global__ void __launch_bounds__(64, FAR ? 2 : ELECTOR_POA_WAVES) k_poa(PackArg
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (the generated loop's stores of moves)
+    unpark();
     if ((dbg & 4) && threadIdx.x == 0) {
       atomicAdd(a.stamps + 12, (unsigned long long)n_steps);
       atomicAdd(a.stamps + 13, (unsigned long long)n_two);
       atomicAdd(a.stamps + 14, (unsigned long long)n_virt);
     }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    x2yb[h] = reinterpret_cast<uint16_t *>(U[h]);
+    ordb[h] = U[h] + pk_align_up(2 * W[h].n1, 4);
   }
   PK_STAMP(5);
   if (dbg & 128) { W[0].valid = W[1].valid = false; }

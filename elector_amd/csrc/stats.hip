@@ -1251,6 +1251,15 @@ extern "C" int elector_msa_stats_enqueue(elector_ctx *c, int64_t n_windows, cons
   return stats_enqueue(c, n_windows, d_cols, d_ncol, d_status, n_pieces, piece_first, n_reads, read_first, clips, nullptr, 0);
 }
 
+// the fence of a slot's rows copy (see elector_msa_stats_collect)
+static int rows_fence(elector_ctx *c, elector::StatsSlot &s)
+{
+  if (!s.rows_inflight) return 0;
+  s.rows_inflight = false;
+  if (s.rows_by_dma) return elector::rows_dma_wait(s.rows_sig);
+  return hipEventSynchronize(s.rows_done) != hipSuccess;
+}
+
 extern "C" int elector_msa_stats_enqueue_rows(elector_ctx *c, int64_t n_windows, const uint8_t *d_cols, const int32_t *d_ncol,
                                               const int32_t *d_status, int64_t n_pieces, const int64_t *piece_first,
                                               int64_t n_reads, const int64_t *read_first, const int32_t *clips,
@@ -1374,7 +1383,7 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
       // collected (the host then knows the byte count) ONE copy of exactly that size goes out on the context's copy
       // stream: the copy engine moves it (57 GB/s on this box, measured; a kernel's own stores to host memory reach
       // 20) while the kernels of the following batches run.  elector_msa_rows_wait() waits for it.
-      if (s.rows_inflight) { HIPCHK(c, hipEventSynchronize(s.rows_done)); s.rows_inflight = false; }
+      if (rows_fence(c, s)) return elector_fail(c, ELECTOR_E_HIP, "rows copy");
       if (s.outoff.ensure((size_t)(n_pieces + 1) * 8)) return elector_fail(c, ELECTOR_E_NOMEM, "row offsets");
       uint8_t *dst = rows_dev;
       if (rows_is_host) {
@@ -1432,21 +1441,17 @@ extern "C" int elector_msa_stats_collect(elector_ctx *c, int64_t n_pieces, int64
     int64_t nbytes = 0;
     for (int64_t p = 0; p < n_pieces; ++p) nbytes += 3 * hcols[p];
     if (nbytes > 0) {
-      static const int n_streams = std::getenv("ELECTOR_ROWS_COPY_STREAMS") ? std::atoi(std::getenv("ELECTOR_ROWS_COPY_STREAMS")) : 1;
       // ELECTOR_ROWS_COPY_BYTES=N (experiment): at most N bytes of the rows are copied -- what the copy itself costs
       static const long long cap_bytes = std::getenv("ELECTOR_ROWS_COPY_BYTES") ? std::atoll(std::getenv("ELECTOR_ROWS_COPY_BYTES")) : -1;
       if (cap_bytes >= 0 && nbytes > cap_bytes) nbytes = std::max<long long>(4, cap_bytes);
-      if (n_streams >= 2 && nbytes > (1 << 22)) {
-        // experiment: the two halves on two streams (two copy engines, if the runtime gives them one each)
-        if (!c->copy_stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
-        const size_t half = ((size_t)nbytes / 2) & ~(size_t)4095;
-        HIPCHK(c, hipMemcpyAsync(s.rows_host + half, s.dense.as<uint8_t>() + half, (size_t)nbytes - half, hipMemcpyDeviceToHost, c->copy_stream2));
-        HIPCHK(c, hipEventRecord(s.rows_done, c->copy_stream2));
-        HIPCHK(c, hipMemcpyAsync(s.rows_host, s.dense.p, half, hipMemcpyDeviceToHost, c->copy_stream));
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, s.rows_done, 0));      // (the event as recorded just above: the other half)
-      } else
+      // On the DMA engine through the HSA runtime (rows_dma.cpp: the HIP runtime ran four such copies in five as blit kernels
+      // on the compute units); through HIP on the copy stream where that is not to be had.  Nothing waits here: the kernels
+      // that packed the rows are through (s.done above).
+      s.rows_by_dma = elector::rows_dma_start(c->device, s.rows_host, s.dense.p, (size_t)nbytes, &s.rows_sig) == 0;
+      if (!s.rows_by_dma) {
         HIPCHK(c, hipMemcpyAsync(s.rows_host, s.dense.p, (size_t)nbytes, hipMemcpyDeviceToHost, c->copy_stream));
-      HIPCHK(c, hipEventRecord(s.rows_done, c->copy_stream));
+        HIPCHK(c, hipEventRecord(s.rows_done, c->copy_stream));
+      }
       s.rows_inflight = true;
     }
     s.rows_host = nullptr;
@@ -1479,7 +1484,7 @@ extern "C" int elector_msa_rows_wait(elector_ctx *c)
   std::lock_guard<std::mutex> lock(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   for (auto &s : c->st_slot)
-    if (s.rows_inflight) { HIPCHK(c, hipEventSynchronize(s.rows_done)); s.rows_inflight = false; }
+    if (rows_fence(c, s)) return elector_fail(c, ELECTOR_E_HIP, "rows copy");
   return ELECTOR_OK;
 }
 

@@ -1,46 +1,10 @@
 #!/usr/bin/env python3
-"""Scan gfx950 assembly (hipcc --save-temps, *.s) for VGPR spill stores that sit in front of the `s_or_b64 exec, exec, ...`
-that ends a divergent region of the same block: such a store runs under the region's partial (or empty) EXEC mask and the
-lanes switched off there read garbage back on the reload.  (Seen with ROCm 7.2's compiler in k_poa<16, 6, false>: the
-window descriptors of half the windows came back from scratch as zeros.)  Prints the kernels and lines; exit code 1 if any.
-
-    python tools/check_spills.py file.s [...]
-"""
-import re
+"""The spill scan lives in the package (elector_amd/check_spills.py: the build runs it); this is its command line."""
+import os
 import sys
 
-
-def check(path):
-    bad = []
-    kernel = None
-    lines = open(path).read().split("\n")
-    for i, ln in enumerate(lines):
-        m = re.match(r"^(_Z\w+):", ln)
-        if m:
-            kernel = m.group(1)
-        if "Folded Spill" in ln and "scratch_store" in ln:
-            # forward within the basic block: an exec restore after the store = the store ran under the narrowed mask
-            for j in range(i + 1, min(i + 40, len(lines))):
-                t = lines[j].strip()
-                if re.match(r"^\.LBB\w+:", t) or t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
-                    break
-                if re.match(r"^s_or_b64 exec, exec, ", t):
-                    bad.append((kernel, i + 1, ln.strip()))
-                    break
-                if re.match(r"^s_\w+ exec(_lo|_hi)?, ", t) or re.match(r"^s_\w+saveexec\w* ", t):
-                    break                                   # a region that opens behind the store: the store ran in front of it
-    return bad
-
-
-def main():
-    n = 0
-    for p in sys.argv[1:]:
-        for kernel, line, text in check(p):
-            print("%s:%d: %s: %s" % (p, line, kernel, text))
-            n += 1
-    print("%d spill store(s) under a narrowed EXEC mask" % n)
-    return 1 if n else 0
-
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from elector_amd.check_spills import check, main  # noqa: E402,F401
 
 if __name__ == "__main__":
     sys.exit(main())
