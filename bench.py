@@ -263,7 +263,7 @@ def cpu_baseline(windows, ref_bases_per_window, seconds, device_msa=None):
 
 def pmc_file(profile, reads):
     """The committed PMC passes over `bench.py --serial` on this workload (profiles/pmc_traffic_<profile>.json,
-    written by tools/_pmc_traffic.py from tools/_r3_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes,
+    written by tools/pmc_traffic.py from tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes,
     gfx950 correction applied, SQ_INSTS_VALU) -> (dict, provenance text); (None, None) when there is none for this
     workload and batch size.  Counters cannot be read from inside the process being measured: the bench line
     REPLAYS them and says so."""
@@ -729,7 +729,7 @@ def main():
                 dc, dn, ds = outs[0]
                 align(engines[0], b, dc, dn, ds)
                 # (the merge / statistics kernels too: every pass of this process then has the same launches, which the
-                # per-step arithmetic of tools/_pmc_traffic.py relies on)
+                # per-step arithmetic of tools/pmc_traffic.py relies on)
                 engines[0].msa_stats_collect(engines[0].msa_stats_enqueue(b.n, dc, dn, ds, b.piece_first, b.read_first))
                 engines[0].sync()
                 st = ds[:b.n].cpu().numpy()

@@ -27,16 +27,6 @@ struct DevBuf {
     cap = want;
     return 0;
   }
-  // experiment (ELECTOR_ROWS_UNCACHED=1): device memory the caches do not keep lines of
-  int ensure_uncached(size_t bytes)
-  {
-    if (bytes <= cap) return 0;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 8 + 4096;
-    if (hipExtMallocWithFlags(&p, want, hipDeviceMallocUncached) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return ELECTOR_E_NOMEM; }
-    cap = want;
-    return 0;
-  }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };

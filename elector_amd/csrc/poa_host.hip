@@ -516,7 +516,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     ClassifyArgs ca;
     ca.n = n; ca.total = total; ca.off = c->d_off.as<int64_t>(); ca.kp = c->kp; ca.pen_abs_max = pen_abs_max;
     ca.use_fused = use_fused ? 1 : 0; ca.force_cls = force_cls;
-    ca.coarse = std::getenv("ELECTOR_SORT_COARSE") ? 1 : 0;
+    ca.coarse = 0;
     ca.window_moves_max = kWindowMovesMaxDwords;
     ca.status = d_status; ca.bin = c->d_bin16.as<int16_t>(); ca.wkey = c->d_wkey.as<uint8_t>();
     ca.acc = d_acc; ca.glob = reinterpret_cast<unsigned long long *>(d_acc + acc_glob);
@@ -719,9 +719,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     const int G = cls_G(b / kNT), nw = 2 * (64 / G);
     PackGeom pg;
     const int max_slot = ((160 * 1024 - 256 - 64) / nw) & ~15;
-    // ELECTOR_POA_SLOT_PCT (experiment): the slot inflated to that many percent -- what the occupancy is worth
-    static const int slot_pct = std::getenv("ELECTOR_POA_SLOT_PCT") ? std::max(100, std::atoi(std::getenv("ELECTOR_POA_SLOT_PCT"))) : 100;
-    pg.slot = (int)std::min<int64_t>(max_slot, ((bin_need_pack[b] * slot_pct / 100) + 15) & ~(int64_t)15);
+    pg.slot = (int)std::min<int64_t>(max_slot, (bin_need_pack[b] + 15) & ~(int64_t)15);
     // (Slots sized for the LDS banks -- 16 mod 32 bytes for the 8-lane classes, 32 mod 64 for the 16-lane ones -- took a
     // third off the bank-conflict cycles and made k_poa 0.5-2 % slower: the wavefronts never wait for the LDS pipeline and
     // the bytes a slot grows by cost occupancy.  A list in two launches, its shortcut-graph windows with a third less LDS,
@@ -764,25 +762,14 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     // two (or three) chains: the bins, in class order, are dealt in turn -- the chains then hold equal shares
     // of every group's work whatever the window distribution (as fast as the best hand-picked split of
     // the groups; a split by the work estimate above was 4 % slower), and the kernels that run side
-    // by side are of neighbouring classes.  ELECTOR_CHAINS_BY_GROUP keeps whole groups together.
-    static const bool deal = std::getenv("ELECTOR_CHAINS_BY_GROUP") == nullptr;
+    // by side are of neighbouring classes.
+    const bool deal = true;
     int turn = 0;
     for (int b = kBins - 1; b >= 0; --b)
       if (bin_cnt[(size_t)b]) {
         bin_stream[(size_t)b] = (deal && (n_chains == 2 || n_chains == 3)) ? (turn++ % n_chains) : chain_of_group[group_of(b)];
         bin_order.push_back(b);
       }
-    // ELECTOR_CHAINS_SMALL=<waves> (experiment): with two chains, the launches of fewer wavefronts than that -- long
-    // windows, a few hundred wavefronts that live long and leave the chip nearly empty -- form a third chain, so
-    // that they run beside the large launches from the start instead of one after the other at the chains' ends
-    static const int small_waves = std::getenv("ELECTOR_CHAINS_SMALL") ? std::atoi(std::getenv("ELECTOR_CHAINS_SMALL")) : 0;
-    if (n_chains == 2 && small_waves > 0 && use_pack) {
-      for (int b = 0; b < kBins; ++b) {
-        if (!bin_cnt[(size_t)b]) continue;
-        const int64_t waves = bin_cnt[(size_t)b] / (2 * (64 / cls_G(b / kNT))) + 1;
-        if (waves < small_waves) { bin_stream[(size_t)b] = 2; n_used = 3; }
-      }
-    }
     if (std::getenv("ELECTOR_DEBUG_BINS"))
       std::fprintf(stderr, "[elector] chains: G64->%d G32->%d G16->%d G8->%d (work %lld %lld %lld %lld)\n", chain_of_group[0],
                    chain_of_group[1], chain_of_group[2], chain_of_group[3], (long long)gwork[0], (long long)gwork[1],
@@ -799,7 +786,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
                      // where its descriptors / symbols start behind the bins', the moves pool it borrows from
                      int64_t far_cap = 0, far_desc_first = 0, far_psym_first = 0; int far_slot = 0, far_tw = 0, far_stride = 0, far_pool = 0; };
   HandGroup hgrp[4];
-  const bool merge_hand = use_pack && !std::getenv("ELECTOR_HAND_PER_BIN") && !std::getenv("ELECTOR_LAUNCH_ORDER");
+  const bool merge_hand = use_pack;
   // graphs with ONE far edge (a corrected piece that aligns at both ends of its window, an indel of two or more letters)
   // stay in k_poa: a launch of their own per lane-group size behind the group's bins.  ELECTOR_NO_FAR=1: the two-kernel
   // path and the generic kernels take them, as up to round 3 (A/B)
@@ -1059,10 +1046,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
     const int used = n_used;                           // launch chains = auxiliary streams in use
     for (int k = 0; k < used; ++k) HIPCHK(c, hipStreamWaitEvent(c->aux[k], c->fork, 0));
     if (use_pack && used <= 3) HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->fork, 0));
-    // ELECTOR_LAUNCH_ORDER=ab (experiment): per stream all alignment #1 launches first, then all #2
-    static const bool split_ab = std::getenv("ELECTOR_LAUNCH_ORDER") && std::string(std::getenv("ELECTOR_LAUNCH_ORDER")) == "ab";
     int hb_used = 0;
-    for (int pass = 0; pass < (split_ab ? 2 : 1); ++pass)
     for (int b : bin_order) {                       // within a chain: most work first
       if (!bin_cnt[(size_t)b]) continue;
       const int bG = cls_G(b / kNT), bR = cls_R(b / kNT), bslot = tier_bytes(b % kNT);
@@ -1081,7 +1065,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       const int hb = hg ? hg->first_bin : b;
       uint32_t *d_hand_list = use_pack ? c->d_hand.as<uint32_t>() + bin_first[(size_t)hb] : nullptr;
       int32_t *d_hand_cnt = use_pack ? reinterpret_cast<int32_t *>(c->d_hand.as<uint32_t>() + n) + bin_slot[(size_t)hb] : nullptr;
-      if (use_pack && (!split_ab || pass == 0)) {
+      if (use_pack) {
         // the whole window in one kernel; what it cannot take lands on the bin's hand-back list
         const PackGeom pg = pack_geom(b);
         GatherArgs ga;
@@ -1232,12 +1216,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       fa.mv_pool = c->d_fmv.as<uint8_t>();
       for (int k = 0; k < so; ++k) fa.mv_pool += fmv_stream[k];
       (void)fmv_geom(b, false, &fa.mv_tw, &fa.mv_ns);
-      if (!split_ab || pass == 0) {
-        timed_begin(c, 0, sx);
-        if (launch_fused_a(fa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
-        timed_end(c, sx);
-      }
-      if (split_ab && pass == 0) continue;
+      timed_begin(c, 0, sx);
+      if (launch_fused_a(fa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "fused kernel attribute");
+      timed_end(c, sx);
       fa.slot_bytes = bslot;
       fa.nlist_dev = use_pack ? d_hand_cnt : nullptr;
       (void)fmv_geom(b, true, &fa.mv_tw, &fa.mv_ns);

@@ -1387,9 +1387,8 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
       if (s.outoff.ensure((size_t)(n_pieces + 1) * 8)) return elector_fail(c, ELECTOR_E_NOMEM, "row offsets");
       uint8_t *dst = rows_dev;
       if (rows_is_host) {
-        static const bool uncached = std::getenv("ELECTOR_ROWS_UNCACHED") != nullptr;
         for (int k = 0; k < elector_ctx::kStatsSlots; ++k)
-          if (uncached ? c->st_slot[k].dense.ensure_uncached((size_t)3 * total + 64) : c->st_slot[k].dense.ensure((size_t)3 * total + 64))
+          if (c->st_slot[k].dense.ensure((size_t)3 * total + 64))
             return elector_fail(c, ELECTOR_E_NOMEM, "packed rows");
         dst = s.dense.as<uint8_t>();
         if (!s.rows_done) HIPCHK(c, hipEventCreateWithFlags(&s.rows_done, hipEventDisableTiming));
@@ -1441,9 +1440,6 @@ extern "C" int elector_msa_stats_collect(elector_ctx *c, int64_t n_pieces, int64
     int64_t nbytes = 0;
     for (int64_t p = 0; p < n_pieces; ++p) nbytes += 3 * hcols[p];
     if (nbytes > 0) {
-      // ELECTOR_ROWS_COPY_BYTES=N (experiment): at most N bytes of the rows are copied -- what the copy itself costs
-      static const long long cap_bytes = std::getenv("ELECTOR_ROWS_COPY_BYTES") ? std::atoll(std::getenv("ELECTOR_ROWS_COPY_BYTES")) : -1;
-      if (cap_bytes >= 0 && nbytes > cap_bytes) nbytes = std::max<long long>(4, cap_bytes);
       // On the DMA engine through the HSA runtime (rows_dma.cpp: the HIP runtime ran four such copies in five as blit kernels
       // on the compute units); through HIP on the copy stream where that is not to be had.  Nothing waits here: the kernels
       // that packed the rows are through (s.done above).

@@ -494,7 +494,7 @@ def test_shortcut_windows_over_the_whole_alphabet(engine, monkeypatch):
 
 
 def test_soak_slice(engine):
-    """A bounded slice of the builder's parity soak (tools/_r2_soak.py) inside the driver's own run: random windows of
+    """A bounded slice of the builder's parity soak (tools/parity_soak.py) inside the driver's own run: random windows of
     the four length / error mixes, most corrected sequences within one edit of the reference, rows and both scores
     bit-exact against the oracle."""
     total = 0
