@@ -95,6 +95,11 @@ def _get_splitter(device, k=0):
         return None
     if (device, k) not in _splitters:
         _splitters[(device, k)] = PoaEngine(device)
+        # ELECTOR_SPLIT_PRIORITY=-1|0|1: the splitter's streams at the device's highest / default / lowest priority (its
+        # long-lived workgroups and the alignment kernels' wavefronts share the chip)
+        prio = int(os.environ.get("ELECTOR_SPLIT_PRIORITY", "0") or 0)
+        if prio:
+            _splitters[(device, k)].option("priority", prio)
     return _splitters[(device, k)]
 
 

@@ -828,7 +828,7 @@ static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
   // they get their inputs and start first, on a chain of their own.
   if (!c->aux_ready) {
     for (int k = 0; k < elector_ctx::kAux; ++k) {
-      HIPCHK(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+      if (c->make_stream(&c->aux[k])) return elector_fail(c, ELECTOR_E_HIP, "stream");
       HIPCHK(c, hipEventCreateWithFlags(&c->aux_done[k], hipEventDisableTiming));
     }
     HIPCHK(c, hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));

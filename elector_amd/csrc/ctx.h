@@ -91,6 +91,15 @@ struct elector_ctx {
   bool aux_ready = false;
   std::vector<hipEvent_t> hb_events;   // k_poa -> hand-back launches (one per bin of a batch)
   int chains = 0;               // launch chains for the fused classes (elector_ctx_option "chains"; 0 = default)
+  int priority = 0;             // elector_ctx_option "priority": -1 / 0 / +1 = the context's streams at the device's highest / default / lowest priority
+  // a stream of this context (every one goes through here: the priority)
+  int make_stream(hipStream_t *s) const
+  {
+    if (priority == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : 1;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 1;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority < 0 ? greatest : least) == hipSuccess ? 0 : 1;
+  }
   elector_params params;
   elector::KParams kp;
   bool gen = false;
@@ -125,6 +134,7 @@ struct elector_ctx {
   static constexpr int kStatsSlots = 2;
   elector::StatsSlot st_slot[kStatsSlots];
   int st_head = 0, st_tail = 0, st_inflight = 0, st_last = -1;
+  uint64_t fetch_sig = 0;              // completion signal of elector_msa_rows_fetch's copy on the DMA engine (rows_dma.cpp)
   hipStream_t copy_stream = nullptr;   // the rows' way to the host: the copy engine works beside the kernels of the next batch
   // timing
   bool timing = false;

@@ -330,6 +330,7 @@ extern "C" void elector_ctx_destroy(elector_ctx *c)
     (void)hipEventDestroy(c->fork);
   }
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  elector::rows_dma_release(&c->fetch_sig);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -394,6 +395,18 @@ extern "C" int elector_ctx_option(elector_ctx *c, const char *name, int64_t valu
     c->chains = (int)value;
     return ELECTOR_OK;
   }
+  if (!std::strcmp(name, "priority")) {               // the context's streams at the device's highest (-1) / lowest (+1) priority
+    if (value < -1 || value > 1) return fail(c, ELECTOR_E_INVAL, "priority must be -1, 0 or 1");
+    if (c->aux_ready || c->copy_stream) return fail(c, ELECTOR_E_INVAL, "priority must be set before the context's first call");
+    c->priority = (int)value;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipStream_t ns = nullptr;
+    if (c->make_stream(&ns)) return fail(c, ELECTOR_E_HIP, "stream");
+    (void)hipStreamDestroy(c->stream);
+    c->stream = ns;
+    return ELECTOR_OK;
+  }
   return fail(c, ELECTOR_E_INVAL, "unknown option");
 }
 
@@ -432,7 +445,7 @@ static int ensure_streams(elector_ctx *c)
 {
   if (c->aux_ready) return 0;
   for (int k = 0; k < elector_ctx::kAux; ++k) {
-    if (hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking) != hipSuccess) return ELECTOR_E_HIP;
+    if (c->make_stream(&c->aux[k])) return ELECTOR_E_HIP;
     if (hipEventCreateWithFlags(&c->aux_done[k], hipEventDisableTiming) != hipSuccess) return ELECTOR_E_HIP;
   }
   if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) return ELECTOR_E_HIP;
@@ -1367,6 +1380,8 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         std::fprintf(stderr, "[elector] bin G%dxR%d leaves k_poa: records beyond the slot %llu, broken path %llu, one far edge %llu, several far edges %llu, "
                              "ordinal rows / steps %llu, refused at the door %llu (of %lld)\n", cls_G(b / kNT), cls_R(b / kNT), p[1], p[2], p[3], p[4], p[5], p[6],
                      (long long)bin_cnt[(size_t)b]);
+      if (p[10] | p[11] | p[12] | p[13] | p[14] | p[15])
+        std::fprintf(stderr, "[elector]   ... windows with 2 / 3 / 4 / 5 / 6 / 7+ far edges: %llu %llu %llu %llu %llu %llu\n", p[10], p[11], p[12], p[13], p[14], p[15]);
     }
   }
   if (std::getenv("ELECTOR_DEBUG_FUSED") && (std::atoi(std::getenv("ELECTOR_DEBUG_FUSED")) & 4)) {

@@ -483,7 +483,7 @@ __device__ __forceinline__ void traceback_a(const WinP (&W)[2], const bool (&nee
 // dynamic program); the others report such a graph through *far_out and do not take it.
 template <int G, typename IT, bool FAR>
 __device__ __forceinline__ bool fusion_1(WinP &W, int lane, int g, const uint8_t *xs, const uint8_t *ys, IT *x2y,
-                                         uint32_t *xinfo, bool *bad_out, bool *far_out, int *why)
+                                         uint32_t *xinfo, bool *bad_out, bool *far_out, int *why, int *nfar_out)
 {
   constexpr int kNoneI = (int)(IT)~(IT)0;                               // "not aligned" in the index type of this class
   const int Lr = W.Lr, Lc = W.Lc;
@@ -628,6 +628,7 @@ __device__ __forceinline__ bool fusion_1(WinP &W, int lane, int g, const uint8_t
   *bad_out = bad;
   const bool near_ok = !on || (fits && maxd <= 2 && !bad);
   *why = !on ? 0 : !fits ? 1 : bad ? 2 : nfar == 1 ? 3 : nfar > 1 ? 4 : 0;      // (debug: why a window is not kept)
+  *nfar_out = nfar;
   if (FAR) {
     if (on && nfar == 1) W.fnode = fsrc;
     return near_ok && (!on || nfar <= 1);
@@ -1204,6 +1205,14 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
   // packed constants (both halves alike)
   const uint32_t ONES = 0x00010001u;
   const uint32_t KSUB = pk1(kp.mismatch), KEXT = pk1(kp.ext_x), KDELTA = pk1(-(kp.open_x - kp.ext_x));   // match == 0 (host)
+  // Every score of the two dynamic programs is kept ONE BELOW its value (kBias: the borders start at -1, the scores reported
+  // add it back): the recurrences only compare scores and add penalties, so nothing else changes -- but every 16-bit half is
+  // then negative, negative halves are ordered as unsigned numbers the way the scores are, and a subtraction whose result
+  // cannot be negative (a maximum less one of its arguments, a score less a small constant) needs no borrow from the upper
+  // half: the generated loops do it as ONE 32-bit v_sub_u32 (2 cycles) instead of v_pk_sub_i16 (4).  Nothing wraps: every
+  // cell a lane ever holds -- rows below a window's last, columns behind its last node included -- is a cell of some
+  // alignment of at most the wavefront's longest window, and that window passed score_span() < 16000.
+  constexpr int kBias = -1;
 
   // ================= alignment #1 (linear x linear), the windows that need it =================
   bool needA[2] = {W[0].valid && W[0].triv == 0, W[1].valid && W[1].triv == 0};
@@ -1220,15 +1229,17 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
       const int yb = (needA[1] && ii <= W[1].Lc) ? U[1][W[1].Lr + ii - 1] : 255;
       ylp[k] = pk2(ya, yb);
       const int v = -(kp.open_y + (ii - 1) * kp.ext_y);       // column -1: ii gap steps from the origin
-      S[k] = pk1(v);
-      E[k] = pk1(v - kp.ext_x);
+      S[k] = pk1(v + kBias);
+      E[k] = pk1(v - kp.ext_x + kBias);
       S2[k] = 0u;
     });
-    uint32_t dg0 = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // cell (row above, column -1)
-    const int tmax = wave_max(max(needA[0] ? W[0].Lr : 0, needA[1] ? W[1].Lr : 0)) + G - 1;
+    uint32_t dg0 = pk1((g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y)) + kBias);   // cell (row above, column -1)
+    // the last step some lane needs: the lane of a window's last row at its last column (a class's strip is taller than most of
+    // its windows: the lanes below a window's last row never mattered, and the steps that only they took are not run)
+    const int tmax = wave_max(max(needA[0] ? W[0].Lr + (W[0].Lc - 1) / R : 0, needA[1] ? W[1].Lr + (W[1].Lc - 1) / R : 0));
     int xa_next = (needA[0] && g == 0 && W[0].Lr >= 1) ? lds[oxA] : 0, xb_next = (needA[1] && g == 0 && W[1].Lr >= 1) ? lds[oxB] : 0;
     const int gstar0 = (W[0].Lc - 1) / R, kstar0 = (W[0].Lc - 1) % R, gstar1 = (W[1].Lc - 1) / R, kstar1 = (W[1].Lc - 1) % R;
-    uint32_t bS = pk1(-kp.open_x);                             // row -1 at column t: -(open_x + (t - 1) ext_x)
+    uint32_t bS = pk1(-kp.open_x + kBias);                     // row -1 at column t: -(open_x + (t - 1) ext_x)
     const int lastA = max(W[0].Lr - 1, 0), lastB = max(W[1].Lr - 1, 0);
     const int capA = (needA[0] && g == gstar0) ? W[0].Lr : -1, capB = (needA[1] && g == gstar1) ? W[1].Lr : -1;   // column to watch, or none
     int sc1a = kNeg, sc1b = kNeg;                              // the two scores, where they appear
@@ -1263,8 +1274,8 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
         if (endA || endB) {
           static_for<R>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            if (endA && k == kstar0) sc1a = pk_half(S[k], 0);
-            if (endB && k == kstar1) sc1b = pk_half(S[k], 1);
+            if (endA && k == kstar0) sc1a = pk_half(S[k], 0) - kBias;
+            if (endB && k == kstar1) sc1b = pk_half(S[k], 1) - kBias;
           });
         }
       }
@@ -1296,7 +1307,7 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
           // (the letters in hand are those of column t - g: index t - 1 - g, never negative from here on, clamped at the end)
           st.a[4] = oxA + (uint32_t)min(t - 1 - g, lastA);
           st.a[5] = oxB + (uint32_t)min(t - 1 - g, lastB);
-          st.a[6] = dg0; st.a[7] = 0u;
+          st.a[6] = dg0; st.a[7] = KEXT;
           st.b[0] = bS; st.b[1] = 0u;
           EngConsts cst;
           cst.one = ONES; cst.ksub = KSUB; cst.kext = KEXT; cst.kdelta = KDELTA; cst.kopen = 0u; cst.k16 = 0xFFFFu; cst.psel = 0u;
@@ -1321,7 +1332,7 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
   PK_STAMP(1);
   // ---- traceback #1, fusion #1 (per window), trivial graphs ----
   bool bad[2] = {false, false}, keep[2], farw[2] = {false, false};
-  int why[2] = {0, 0};
+  int why[2] = {0, 0}, nfar_dbg[2] = {0, 0};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
@@ -1340,7 +1351,7 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
     IT *x2y = reinterpret_cast<IT *>(U[h] + pk_align_up(W[h].Lr + W[h].Lc, 4));
     keep[h] = true;
     if (__builtin_amdgcn_ballot_w64(needA[h]) != 0)
-      keep[h] = fusion_1<G, IT, FAR>(W[h], lane, g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h], &farw[h], &why[h]);
+      keep[h] = fusion_1<G, IT, FAR>(W[h], lane, g, U[h], U[h] + W[h].Lr, x2y, xinfo[h], &bad[h], &farw[h], &why[h], &nfar_dbg[h]);
     trivial_graph<G>(W[h], g, U[h], U[h] + W[h].Lr, xinfo[h]);
     if (W[h].valid && W[h].triv == 1) W[h].score1 = W[h].Lr * kp.match;
     if (W[h].valid && W[h].triv == 2) W[h].score1 = (W[h].Lr - 1) * kp.match + kp.mismatch;
@@ -1392,6 +1403,7 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
         // debug bit 8: why windows leave this kernel (1 nodes beyond the slot's records, 2 broken path, 3 one far edge,
         // 4 several far edges, 5 ordinal rows / moves steps beyond the slot), counted per bin
         if (dbg & 8) atomicAdd(a.stamps + (keep[h] && !bad[h] ? 5 : why[h]), 1ull);
+        if ((dbg & 8) && why[h] == 4) atomicAdd(a.stamps + 8 + min(nfar_dbg[h], 7), 1ull);   // (debug: how many far edges: 10 .. 15)
         if (!FAR && farw[h] && !bad[h] && a.far != nullptr) {
           const int at = atomicAdd(a.far_count, 1);
           if (at < a.far_cap) { a.far[at] = W[h].w; placed = true; }
@@ -1419,7 +1431,8 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
   }
   int best[2] = {kNeg, kNeg}, bestx[2] = {-1, -1};
   {
-    const int tmax = (wave_max(max(W[0].valid ? W[0].n1 : 0, W[1].valid ? W[1].n1 : 0)) + G - 1 + 1) & ~1;
+    // (the last step some lane needs: the lane of a window's last row at its last node; an even number of steps)
+    const int tmax = (wave_max(max(W[0].valid ? W[0].n1 + (W[0].Lu - 1) / R : 0, W[1].valid ? W[1].n1 + (W[1].Lu - 1) / R : 0)) + 1) & ~1;
     // the letters of the lane's rows and the two columns it holds, each a tuple of R registers: the generated loop
     // (poa_engine_gen.h) takes them pinned to fixed registers
     typedef uint32_t VR __attribute__((ext_vector_type(R)));
@@ -1431,19 +1444,19 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
       const int yb = (W[1].valid && ii <= W[1].Lu) ? us[1][ii - 1] : 255;
       ylp[k] = pk2(ya, yb);
       const int v = -(kp.open_y + (ii - 1) * kp.ext_y);        // column 0 (the virtual start): ii gap steps, not a match
-      S1[k] = S2[k] = pk1(v);
-      E1[k] = E2[k] = pk1(v - kp.ext_x);
+      S1[k] = S2[k] = pk1(v + kBias);
+      E1[k] = E2[k] = pk1(v - kp.ext_x + kBias);
     });
     // the row above at column jj - 2 is what the shift delivered as "column jj - 1" one step earlier: one DPP
     // shift per step instead of two (before the first step: column 0 on both sides)
-    uint32_t prev_up1 = pk_shift_in<G>(0u, S1[R - 1], g);
-    const uint32_t colS0 = pk1(-(kp.open_y + (R * g) * kp.ext_y));               // column 0 at this lane's first row
-    const uint32_t colAbove = pk1(g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y));   // ... at the row above it (the origin for lane 0)
-    const uint32_t KOPENNEG = pk1(-kp.open_x);
+    uint32_t prev_up1 = pk_shift_in<G>(pk1(kBias), S1[R - 1], g);
+    const uint32_t colS0 = pk1(-(kp.open_y + (R * g) * kp.ext_y) + kBias);       // column 0 at this lane's first row
+    const uint32_t colAbove = pk1((g == 0 ? 0 : -(kp.open_y + (R * g - 1) * kp.ext_y)) + kBias);   // ... at the row above it (the origin for lane 0)
+    const uint32_t KOPENNEG = pk1(-kp.open_x + kBias);
     // row -1 over the graph (align_lpo_po2.c:275-286): its score at the column before this one, and what the cells of the
     // two columns before offer a gap (score less the extension; the origin counts as "open").  Only the group's first
     // lane reads them, as the border of the shifts.
-    uint32_t BR1 = 0, BE1 = pk1(-kp.open_x), BE2 = pk1(-kp.open_x);
+    uint32_t BR1 = pk1(kBias), BE1 = pk1(-kp.open_x + kBias), BE2 = pk1(-kp.open_x + kBias);
     const int gstar0 = (W[0].Lu - 1) / R, kstar0 = (W[0].Lu - 1) % R, gstar1 = (W[1].Lu - 1) / R, kstar1 = (W[1].Lu - 1) % R;
     const int n1c0 = (W[0].valid ? W[0].n1 : 0) + 1, n1c1 = (W[1].valid ? W[1].n1 : 0) + 1;   // index of the upper guard
     // node records by their byte offset in LDS: record i of window h at xb_h + 4 i, the upper zero guard at xe_h
@@ -1660,8 +1673,8 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
             const bool finA = (xiA & finA_bit) != 0u, finB = (xiB & finB_bit) != 0u;
             static_for<R>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
-              if (finA && k == kstar0) { const int v = pk_half(Sb[k], 0); if (v > best[0]) { best[0] = v; bestx[0] = jj - 1; } }
-              if (finB && k == kstar1) { const int v = pk_half(Sb[k], 1); if (v > best[1]) { best[1] = v; bestx[1] = jj - 1; } }
+              if (finA && k == kstar0) { const int v = pk_half(Sb[k], 0) - kBias; if (v > best[0]) { best[0] = v; bestx[0] = jj - 1; } }
+              if (finB && k == kstar1) { const int v = pk_half(Sb[k], 1) - kBias; if (v > best[1]) { best[1] = v; bestx[1] = jj - 1; } }
             });
           }
         }
@@ -1684,7 +1697,7 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
         ecn.v[0] = xeA; ecn.v[1] = xeB; ecn.v[2] = colS0; ecn.v[3] = colAbove;
         ecn.v[4] = ordA;
         ecn.v[5] = ordB;
-        ecn.v[6] = (uint32_t)g; ecn.v[7] = 0u;
+        ecn.v[6] = (uint32_t)g; ecn.v[7] = KEXT;
         ecs.one = ONES; ecs.ksub = KSUB; ecs.kext = KEXT; ecs.kdelta = KDELTA; ecs.kopen = KOPENNEG; ecs.k16 = 0xFFFFu;
         ecs.psel = 0x0c050c01u;
       }

@@ -1895,7 +1895,7 @@ extern "C" int elector_split_reads_device(elector_ctx *c, int64_t n_in, const ui
   // next launch's workgroups move in), the long reads first
   if (!c->aux_ready) {
     for (int k = 0; k < elector_ctx::kAux; ++k) {
-      HIPCHK(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+      if (c->make_stream(&c->aux[k])) return elector_fail(c, ELECTOR_E_HIP, "stream");
       HIPCHK(c, hipEventCreateWithFlags(&c->aux_done[k], hipEventDisableTiming));
     }
     HIPCHK(c, hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));

@@ -1526,6 +1526,18 @@ extern "C" int elector_msa_rows_fetch(elector_ctx *c, int64_t n_pieces, const in
                 c->d_st_dense.as<uint8_t>()};
   hipLaunchKernelGGL(k_compact, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, a);
   HIPCHK(c, hipGetLastError());
+  // to page-locked memory on the DMA engine (rows_dma.cpp; the writer threads of getPOA pass the context's pinned buffer),
+  // anywhere else through the HIP runtime
+  hipPointerAttribute_t at;
+  bool pinned = hipPointerGetAttributes(&at, rows) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();
+  if (pinned) {
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (elector::rows_dma_start(c->device, rows, c->d_st_dense.p, (size_t)total, &c->fetch_sig) == 0) {
+      if (elector::rows_dma_wait(c->fetch_sig)) return elector_fail(c, ELECTOR_E_HIP, "rows copy");
+      return ELECTOR_OK;
+    }
+  }
   HIPCHK(c, hipMemcpyAsync(rows, c->d_st_dense.p, (size_t)total, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   return ELECTOR_OK;

@@ -258,7 +258,8 @@ class PoaEngine:
         return ms.value, k.value
 
     def option(self, name, value):
-        """elector_ctx_option: "chains" = concurrent launch chains of the fused classes (0 = default)."""
+        """elector_ctx_option: "chains" = concurrent launch chains of the fused classes (0 = default); "priority" = -1 / 0 / +1,
+        the context's streams at the device's highest / default / lowest priority (before the context's first call)."""
         self._check(self._lib.elector_ctx_option(self._h, name.encode(), int(value)))
 
     def last_po_sizes(self, n):

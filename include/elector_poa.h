@@ -140,7 +140,10 @@ int elector_ctx_timing_reset(elector_ctx *ctx);
 /* tuning / measurement knobs.  "chains" = number of concurrent launch chains the
  * geometry classes of the fused kernels are dealt to (1..4; 0 = the default, 2):
  * with 1 every kernel of a batch runs alone on the chip, which is what an
- * un-overlapped per-kernel measurement needs (bench.py's serial pass). */
+ * un-overlapped per-kernel measurement needs (bench.py's serial pass).
+ * "priority" = -1 / 0 / +1: the context's streams at the device's highest / default / lowest priority (before the
+ * context's first call): a pipeline gives its splitter context the lowest, so that the alignment kernels' wavefronts
+ * go first where both want the chip. */
 int elector_ctx_option(elector_ctx *ctx, const char *name, int64_t value);
 /* diagnostics: |PO| (nodes after fusion #1) of the first n windows of the last
  * batch, so callers can count the DP cells of alignment #2 (|PO| x Lu). */

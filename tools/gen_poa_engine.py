@@ -33,7 +33,7 @@ OUT = os.path.join(os.path.dirname(HERE), "elector_amd", "csrc", "poa_engine_gen
 NT = 12          # vector temporaries
 NST1 = 8         # pinned state a[0..7]
 NST2 = 2         # pinned state b[0..1]
-NCN = 8          # pinned per-lane constants: xea xeb cs0 cab orda ordb g -
+NCN = 8          # pinned per-lane constants: xea xeb cs0 cab orda ordb g kext
 
 
 def stride_of(R):
@@ -64,7 +64,7 @@ class Regs:
         self.U = [self.A[6], self.A[7]]
         self.EE = ["v%d" % (s + 8), "v%d" % (s + 9)]            # state b[0..1]
         c = s + 10
-        self.XEA, self.XEB, self.CS0, self.CAB, self.ORDA, self.ORDB, self.GV = ["v%d" % (c + i) for i in range(7)]
+        self.XEA, self.XEB, self.CS0, self.CAB, self.ORDA, self.ORDB, self.GV, self.KEXT = ["v%d" % (c + i) for i in range(8)]
         self.T = ["v%d" % (c + NCN + i) for i in range(NT)]
         self.ranges = dict(YL=(B, B + R - 1), SA=(B + Q, B + Q + R - 1), EA=(B + 2 * Q, B + 2 * Q + R - 1), SB=(B + 3 * Q, B + 3 * Q + R - 1),
                            EB=(B + 4 * Q, B + 4 * Q + R - 1), ST1=(s, s + 7), ST2=(s + 8, s + 9), CN=(c, c + NCN - 1))
@@ -79,7 +79,16 @@ def shift_dpp(G):
     return "wave_shr:1 row_mask:0xf bank_mask:0xf"
 
 
-def core(o, xl, yl, ix, iy, dm, sn, en, mv, sh, t0, mx):
+def sub32(o, d, a, b):
+    """d = a - b per 16-bit half as ONE 32-bit v_sub_u32 (the 2-cycle class, profiles/r05_valu_rate2.txt; a packed subtraction
+    is 4 cycles): exact when no half borrows.  Every score in the loops is kept one BELOW its value (poa_pack.hip: the
+    borders start at -1), so every half is negative -- as unsigned numbers they are ordered like the scores -- and the
+    subtractions below have a >= b per half by construction (a maximum less one of its arguments, a score less a small
+    positive constant).  All operands VGPRs: with a scalar operand the instruction falls back to 4 cycles."""
+    o.append("v_sub_u32 %s, %s, %s" % (d, a, b))
+
+
+def core(o, xl, yl, ix, iy, dm, sn, en, mv, sh, t0, mx, kext):
     """the affine-gap recurrence of one row (two cells): 12 instructions for the step's first row, 13 otherwise.
     ix may be mx itself (a form that has built the x-gap offer there); en may be ix (alignment #1 keeps E in place)."""
     o.append("v_xor_b32 %s, %s, %s" % (t0, xl, yl))
@@ -87,9 +96,9 @@ def core(o, xl, yl, ix, iy, dm, sn, en, mv, sh, t0, mx):
     o.append("v_pk_min_u16 %s, %s, %%[one]" % (t0, t0))
     o.append("v_pk_mad_i16 %s, %s, %%[ksub], %s" % (t0, t0, dm))
     o.append("v_pk_max_i16 %s, %s, %s" % (sn, t0, mx))
-    o.append("v_pk_sub_i16 %s, %s, %s" % (t0, sn, mx))
-    o.append("v_pk_sub_i16 %s, %s, %s" % (mx, mx, iy))
-    o.append("v_pk_sub_i16 %s, %s, %%[kext]" % (en, sn))
+    sub32(o, t0, sn, mx)
+    sub32(o, mx, mx, iy)
+    sub32(o, en, sn, kext)
     o.append("v_pk_min_u16 %s, %s, %%[one]" % (t0, t0))
     o.append("v_pk_min_u16 %s, %s, %%[one]" % (mx, mx))
     o.append("v_pk_mad_i16 %s, %s, %%[kdelta], %s" % (en, t0, en))
@@ -154,13 +163,13 @@ def dp2_step(o, rg, G, role, masked):
     o.append("s_cbranch_vccnz %s" % L("notnear"))
     # ---- NEAR
     dpp_shift(o, G, Uc, nS[R - 1], TX)                       # up1 over BR1
-    o.append("v_pk_sub_i16 %s, %s, %%[kext]" % (Eo, Ec))     # BEj = BE1 - ext (BRj = BE1)
+    sub32(o, Eo, Ec, rg.KEXT)                                # BEj = BE1 - ext (BRj = BE1)
     o.append("v_mov_b32 %s, %s" % (Uo, Ec))                  # the next step's BR1
     o.append("s_nop 0")
     dpp_shift(o, G, Eo, cE[R - 1], TX)                       # upE; lane g = 0 keeps BEj
     rows_on()
     for k in range(R):
-        core(o, XL, rg.YL[k], cE[k], Eo if k == 0 else nE[k - 1], Uc if k == 0 else cS[k - 1], nS[k], nE[k], MV, 2 * k, t0, mx)
+        core(o, XL, rg.YL[k], cE[k], Eo if k == 0 else nE[k - 1], Uc if k == 0 else cS[k - 1], nS[k], nE[k], MV, 2 * k, t0, mx, rg.KEXT)
     o.append("s_branch %s" % L("store"))
     # ---- PLAIN
     o.append("%s:" % L("notnear"))
@@ -171,7 +180,7 @@ def dp2_step(o, rg, G, role, masked):
     dpp_shift(o, G, Uc, nS[R - 1], TX)
     o.append("v_bfi_b32 %s, %s, %s, %s" % (DA, M1, Uo, Uc))              # diagonal of the first row: up2 or up1
     o.append("v_bfi_b32 %s, %s, %s, %s" % (Uo, M1, Eo, Ec))              # BRj: what row -1 of the predecessor column offers
-    o.append("v_pk_sub_i16 %s, %s, %%[kext]" % (Eo, Uo))
+    sub32(o, Eo, Uo, rg.KEXT)
     o.append("s_nop 1")
     dpp_shift(o, G, Eo, cE[R - 1], TX)
     rows_on()
@@ -179,7 +188,7 @@ def dp2_step(o, rg, G, role, masked):
         dm, dn = (DA, DB) if k % 2 == 0 else (DB, DA)
         o.append("v_bfi_b32 %s, %s, %s, %s" % (dn, M1, nS[k], cS[k]))     # the predecessor's cell: the next row's diagonal
         o.append("v_bfi_b32 %s, %s, %s, %s" % (mx, M1, nE[k], cE[k]))     # ... and its x-gap offer
-        core(o, XL, rg.YL[k], mx, Eo if k == 0 else nE[k - 1], dm, nS[k], nE[k], MV, 2 * k, t0, mx)
+        core(o, XL, rg.YL[k], mx, Eo if k == 0 else nE[k - 1], dm, nS[k], nE[k], MV, 2 * k, t0, mx, rg.KEXT)
     o.append("s_branch %s" % L("store"))
     # ---- TWO
     o.append("%s:" % L("notplain"))
@@ -196,7 +205,7 @@ def dp2_step(o, rg, G, role, masked):
     o.append("v_bfi_b32 %s, %s, %s, %s" % (e1, M1, Eo, Ec))
     o.append("v_bfi_b32 %s, %s, %s, %s" % (Uo, M2, Eo, Ec))
     o.append("v_pk_max_i16 %s, %s, %s" % (Uo, e1, Uo))                    # BRj
-    o.append("v_pk_sub_i16 %s, %s, %%[kext]" % (Eo, Uo))
+    sub32(o, Eo, Uo, rg.KEXT)
     o.append("v_mov_b32 %s, 0" % SEC)
     o.append("v_mov_b32 %s, 0" % MV)
     dpp_shift(o, G, Eo, cE[R - 1], TX)
@@ -205,7 +214,7 @@ def dp2_step(o, rg, G, role, masked):
         iy = Eo if k == 0 else nE[k - 1]
         o.append("v_xor_b32 %s, %s, %s" % (t0, XL, rg.YL[k]))
         o.append("v_pk_min_u16 %s, %s, %%[one]" % (t0, t0))
-        o.append("v_pk_sub_i16 %s, %s, %s" % (d1, dm, dt))
+        sub32(o, d1, dm, dt)
         o.append("v_pk_mad_i16 %s, %s, %%[ksub], %s" % (t0, t0, dm))
         o.append("v_bfi_b32 %s, %s, %s, %s" % (dt, M1, nS[k], cS[k]))
         o.append("v_bfi_b32 %s, %s, %s, %s" % (dm, M2, nS[k], cS[k]))
@@ -213,12 +222,12 @@ def dp2_step(o, rg, G, role, masked):
         o.append("v_bfi_b32 %s, %s, %s, %s" % (e1, M1, nE[k], cE[k]))
         o.append("v_bfi_b32 %s, %s, %s, %s" % (mx, M2, nE[k], cE[k]))
         o.append("v_pk_max_i16 %s, %s, %s" % (mx, e1, mx))
-        o.append("v_pk_sub_i16 %s, %s, %s" % (e1, mx, e1))
+        sub32(o, e1, mx, e1)
         o.append("v_pk_max_i16 %s, %s, %s" % (mx, mx, iy))
         o.append("v_pk_max_i16 %s, %s, %s" % (nS[k], t0, mx))
-        o.append("v_pk_sub_i16 %s, %s, %s" % (t0, nS[k], mx))
-        o.append("v_pk_sub_i16 %s, %s, %s" % (mx, mx, iy))
-        o.append("v_pk_sub_i16 %s, %s, %%[kext]" % (nE[k], nS[k]))
+        sub32(o, t0, nS[k], mx)
+        sub32(o, mx, mx, iy)
+        sub32(o, nE[k], nS[k], rg.KEXT)
         o.append("v_pk_min_u16 %s, %s, %%[one]" % (t0, t0))
         o.append("v_pk_min_u16 %s, %s, %%[one]" % (mx, mx))
         o.append("v_pk_mad_i16 %s, %s, %%[kdelta], %s" % (nE[k], t0, nE[k]))
@@ -252,7 +261,7 @@ def dp2_step(o, rg, G, role, masked):
     o.append("v_bfi_b32 %s, %s, %s, %s" % (DA, V1, rg.CAB, DA))
     o.append("v_bfi_b32 %s, %s, %s, %s" % (Uo, M1, Eo, Ec))
     o.append("v_bfi_b32 %s, %s, %%[kopen], %s" % (Uo, V1, Uo))
-    o.append("v_pk_sub_i16 %s, %s, %%[kext]" % (Eo, Uo))
+    sub32(o, Eo, Uo, rg.KEXT)
     o.append("v_mov_b32 %s, %s" % (SEC, rg.CS0))                          # column 0 at the lane's first row
     o.append("s_nop 0")
     dpp_shift(o, G, Eo, cE[R - 1], TX)
@@ -260,12 +269,12 @@ def dp2_step(o, rg, G, role, masked):
     for k in range(R):
         dm, dn = (DA, DB) if k % 2 == 0 else (DB, DA)
         vc, ve = (SEC, d1) if k % 2 == 0 else (d1, SEC)
-        o.append("v_pk_sub_i16 %s, %s, %%[kext]" % (ve, vc))              # column 0 one row down = what this row's offers a gap
+        sub32(o, ve, vc, rg.KEXT)                                         # column 0 one row down = what this row's offers a gap
         o.append("v_bfi_b32 %s, %s, %s, %s" % (dn, M1, nS[k], cS[k]))
         o.append("v_bfi_b32 %s, %s, %s, %s" % (mx, M1, nE[k], cE[k]))
         o.append("v_bfi_b32 %s, %s, %s, %s" % (dn, V1, vc, dn))
         o.append("v_bfi_b32 %s, %s, %s, %s" % (mx, V1, ve, mx))
-        core(o, XL, rg.YL[k], mx, Eo if k == 0 else nE[k - 1], dm, nS[k], nE[k], MV, 2 * k, t0, mx)
+        core(o, XL, rg.YL[k], mx, Eo if k == 0 else nE[k - 1], dm, nS[k], nE[k], MV, 2 * k, t0, mx, rg.KEXT)
     # ---- the step's moves (every lane stores: a word of a lane that has no cell yet or none any more is never read), loop
     o.append("%s:" % L("store"))
     if masked:
@@ -316,6 +325,7 @@ def dp1_step(o, rg, G, role):
     cS, nS, E = rg.S[role], rg.S[1 - role], rg.E[0]
     XA, XB = rg.A[0], rg.A[1]
     P = rg.A[6]
+    KX = rg.A[7]                                             # the extension penalty, per half, in a VGPR (sub32)
     Qc, Qn = rg.EE[role], rg.EE[1 - role]
     T = rg.T
     t0, XL, mx, MV, TX = T[0], T[1], T[2], T[3], T[11]
@@ -327,11 +337,11 @@ def dp1_step(o, rg, G, role):
     dpp_shift(o, G, Qc, cS[R - 1], TX)                       # the row above at this column (next step's diagonal); lane g = 0: row -1
     o.append("ds_read_u8 %s, %s" % (XA, rg.OA))
     o.append("ds_read_u8 %s, %s" % (XB, rg.OB))
-    o.append("v_pk_sub_i16 %s, %s, %%[kext]" % (Qn, Qc))     # what it offers a y-gap; lane g = 0: row -1 one column on
+    sub32(o, Qn, Qc, KX)                                     # what it offers a y-gap; lane g = 0: row -1 one column on
     o.append("s_nop 1")
     dpp_shift(o, G, Qn, E[R - 1], TX)
     for k in range(R):
-        core(o, XL, rg.YL[k], E[k], Qn if k == 0 else E[k - 1], P if k == 0 else cS[k - 1], nS[k], E[k], MV, 2 * k, t0, mx)
+        core(o, XL, rg.YL[k], E[k], Qn if k == 0 else E[k - 1], P if k == 0 else cS[k - 1], nS[k], E[k], MV, 2 * k, t0, mx, KX)
     o.append("v_mov_b32 %s, %s" % (P, Qc))
     o.append("global_store_dword %%[loff], %s, %%[mvp]%s" % (MV, " offset:256" if role else ""))
     if role == 1:
@@ -432,13 +442,13 @@ def generate():
            "// a[5]), row -1's score at the column before (a[6]; becomes the shifted row above), the row above two columns back (a[7]);",
            "// b: what row -1 offers a gap at the two columns before (b[0]: one back, b[1]: two back).",
            "// Alignment #1 -- a[0], a[1]: the reference letters of the step to run, a[4], a[5]: their LDS addresses, a[6]: the row above",
-           "// on the diagonal; b[0]: row -1 at the column of the step (in the group's first lane).",
+           "// on the diagonal, a[7]: the extension penalty per half; b[0]: row -1 at the column of the step (in the group's first lane).",
            "struct EngState {",
            "  uint32_t a __attribute__((ext_vector_type(8)));",
            "  uint32_t b __attribute__((ext_vector_type(2)));",
            "};",
            "// per-lane constants of alignment #2: LDS offsets of the two upper guard records, column 0 at the lane's first row and at",
-           "// the row above it, LDS offsets of the two windows' ordinal bytes (+ g), g",
+           "// the row above it, LDS offsets of the two windows' ordinal bytes (+ g), g, the extension penalty per half",
            "struct EngLane { uint32_t v __attribute__((ext_vector_type(8))); };",
            "struct EngConsts { uint32_t one, ksub, kext, kdelta, kopen, k16, psel; };",
            "",
