@@ -439,7 +439,7 @@ static const int kPartChunk = 2048;     // list entries per block of the trivial
 // two runs each: un-overlapped k_poa 5.66 -> 5.47 ms on the E. coli batch, 9.93 -> 8.87 on the yeast -split batch
 // (140 -> 130 and 180 -> 170 launches per ten steps), the pipelined rate +0.9 / +0.4 %; 65,536: 5.15 / 8.83 ms but
 // -0.5 % pipelined on E. coli)
-static const int64_t kMinBinWindows = std::getenv("ELECTOR_MIN_BIN") ? std::atoll(std::getenv("ELECTOR_MIN_BIN")) : 16384;
+static const int64_t kMinBinWindows = std::getenv("ELECTOR_MIN_BIN") ? std::max<long long>(1, std::atoll(std::getenv("ELECTOR_MIN_BIN"))) : 16384;
 
 static int ensure_streams(elector_ctx *c)
 {
@@ -480,7 +480,11 @@ static int upload_offsets(elector_ctx *c, int64_t n, const int64_t *off, hipStre
 static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, const int64_t *d_off, int64_t total,
                             uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status, int32_t *d_scores)
 {
-  if (n == 0) { c->last_n = 0; c->last_total = 0; c->graph_valid = false; return ELECTOR_OK; }
+  // (from here to the end of a successful call the context describes no batch: a call that fails half way -- malformed
+  // offsets are only found by the classification kernel, after d_off has been overwritten -- must not leave the previous
+  // batch's sizes over the new batch's arrays for elector_msa_stats_enqueue / elector_poa_bundles to trust)
+  c->last_n = 0; c->last_total = 0; c->graph_valid = false;
+  if (n == 0) return ELECTOR_OK;
   if (total < 0) return fail(c, ELECTOR_E_INVAL, "negative total");
   const bool use_fused = !c->gen && !std::getenv("ELECTOR_NO_FUSED");
   // alignment #1 without a dynamic program for windows whose corrected sequence equals the reference:

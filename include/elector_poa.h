@@ -117,7 +117,12 @@ int elector_poa_batch_device(elector_ctx *ctx, int64_t n,
  * elector_windows_dev.d_off).  No per-window work happens on the host: window status, launch class and the class
  * lists are computed by kernels, the host reads back per-class totals (29 KB) and queues the launches.  This is
  * the entry the pipeline and bench.py use; the reference has no counterpart (its poa reads the windows from three
- * FASTA files in file order, main.c:265-284). */
+ * FASTA files in file order, main.c:265-284).
+ * The call is not fully asynchronous: it waits once for the classification kernel's totals on the context's stream
+ * -- that is, for whatever the context still had queued (the previous batch's merge / statistics) -- before it queues
+ * the alignment launches.  A caller that wants batch i + 1 queued while batch i runs uses several contexts in turn (the
+ * pipeline: three, bench.py: four); with one context the GPU idles while the host decides the launches.
+ * A call that fails leaves the context without a "last batch" (elector_msa_stats_enqueue / elector_poa_bundles refuse). */
 int elector_poa_batch_device_offsets(elector_ctx *ctx, int64_t n,
                                      const uint8_t *d_bases, const int64_t *d_off, int64_t total,
                                      uint8_t *d_cols, int32_t *d_ncol, int32_t *d_status,
