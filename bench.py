@@ -696,7 +696,7 @@ def main():
                 g.sync()
             self.host_enqueue_s = self.host_wait_s = self.gather_s = 0.0
             self.first_timed = self.step_id
-            t0 = time.perf_counter()
+            t0 = self.t0 = time.perf_counter()
             for _ in range(steps):
                 self.step(rows)
             self.drain()                         # every step's counters (and rows) are on the host before the clock stops
@@ -751,7 +751,8 @@ def main():
         f0 = run.first_timed
         if steps >= 8 and f0 + 5 in run.done_at and f0 + steps - 1 in run.done_at:
             steady = (run.done_at[f0 + steps - 1] - run.done_at[f0 + 5]) / (steps - 6)
-        res = {"dt": dt, "steady_s_per_step": steady, "host_enqueue_ms": run.host_enqueue_s / steps * 1e3, "host_wait_ms": run.host_wait_s / steps * 1e3,
+        done_ms = [round((run.done_at[f0 + k] - run.t0) * 1e3, 2) for k in range(steps) if f0 + k in run.done_at]
+        res = {"dt": dt, "steady_s_per_step": steady, "done_ms": done_ms, "host_enqueue_ms": run.host_enqueue_s / steps * 1e3, "host_wait_ms": run.host_wait_s / steps * 1e3,
                "gather_ms": run.gather_s / steps * 1e3, "counters": run.last_counters, "rows_bytes": run.rows_bytes,
                "last_batch_of_engine": list(run.last_batch_of_engine), "dt_hbm": None}
         # the MSA the timed kernels wrote (context 0's last timed batch), for the comparison with the reference binary
@@ -914,6 +915,7 @@ def main():
             # the timed region without its fill: from the completion (counters on the host) of its sixth step to that of its last
             "steady_state": None if not R.get("steady_s_per_step") else {
                 "ms_per_step": round(R["steady_s_per_step"] * 1e3, 3), "value": round(bases_all / R["steady_s_per_step"] / 1e6, 3),
+                "step_completions_ms": R.get("done_ms"),
                 "note": "steps 6 .. %d of the timed region between completion events on rank 0; `value` and `ms_per_step` above are "
                         "the whole region (fill and drain included)" % args.steps},
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",

@@ -51,6 +51,7 @@ struct TimedSpan { hipEvent_t a, b; int kind; };
 
 // one merge + statistics job of the device pipeline (elector_msa_stats_enqueue / _collect)
 // the rows' copy on the DMA engine through the HSA runtime (rows_dma.cpp)
+bool rows_dma_ready(int hip_device, uint64_t *sig);
 int rows_dma_start(int hip_device, void *dst, const void *src, size_t n, uint64_t *sig);
 int rows_dma_wait(uint64_t sig);
 void rows_dma_release(uint64_t *sig);
@@ -64,8 +65,10 @@ struct StatsSlot {
   hipEvent_t rows_done = nullptr;   // the packed rows have arrived at rows_host (recorded on the context's copy stream) ...
   uint64_t rows_sig = 0;            // ... or, the copy started through HSA, its completion signal (rows_by_dma)
   bool rows_by_dma = false;
-  uint8_t *rows_host = nullptr;     // this job's rows go to this page-locked host address when it is collected
+  uint8_t *rows_host = nullptr;     // this job's rows go to this page-locked host address: from the stream's host function
+                                    // behind the packing kernel (rows_go, stats.hip), else when the job is collected
   bool rows_inflight = false;
+  int device = -1;
   int64_t n_pieces = 0, n_reads = 0, total = 0, last_piece = 0, max_windows = 0;
   bool has_clips = false;
   void release()

@@ -189,9 +189,17 @@ __global__ void __launch_bounds__(64) k_dp1(BatchArgs a)
 // tail sits between two reference letters, Master_Splitter.cpp:295-301, puts hundreds of nodes between
 // a node and its predecessor) come from a shadow of the ring in HBM that holds every step of the strip:
 // gring[t][lane], written once per step (fire and forget), read only by the rare far accesses.
-template <bool GEN, int D, bool DEEP>
+//
+// NW wavefronts per window: wavefront v takes the strips v, v + NW, ... and runs strip s a good 128 steps behind strip
+// s - 1 (whose last lane hands down the carry row, column jj at step jj + 63; a strip asks for 64 columns of it at a
+// time).  A wavefront alone issues one instruction in 2 ns whatever it is, and a step of this recurrence is some 250
+// instructions: a 500-row window (9 strips x 1,100 steps) is 5 ms of one wavefront, which is what a batch's last
+// launches -- the few hundred windows the on-chip kernels hand back -- held the chip for; side by side the strips take
+// T + 128 (ns - 1) steps instead of ns T.  prog[v] = (strip << 20) | steps of it that are through (carry stores landed),
+// (strip + 1) << 20 when the strip is: monotone per wavefront, read by the wavefront of the next strip.
+template <bool GEN, int D, bool DEEP, int NW>
 __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring, const int cls, const uint32_t w,
-                           const int lane, int32_t *gring)
+                           const int lane, int32_t *gring, const int wv, volatile int *prog)
 {
   if (a.status[w] || (a.cls[w] & 3) != cls || (a.skip_b && a.skip_b[w]) || (a.tiled && (a.tiled[w] & 2))) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
@@ -205,7 +213,7 @@ __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring
   constexpr int kNoPred = 0;                      // d1 = 0 (virtual start), d2 = 0 (none)
 
   int best = kNeg, bestx = -1;
-  for (int s = 0; s < ns; ++s) {
+  for (int s = wv; s < ns; s += NW) {
     const int ii = s * kStripRows + lane;
     const bool rowok = lane >= 1 && ii <= Ly;
     const bool rowvirt = (s == 0 && lane == 0);
@@ -222,6 +230,12 @@ __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring
         const int j = t + lane;
         int2 xi = (j >= 1 && j <= Lx) ? xinfo[j] : make_int2(kNoPred, 0);
         xb_lo = xi.x; xb_hi = xi.y;
+        if (NW > 1 && s > 0) {
+          // the strip above is through step t + 126: its carry of the columns t .. t + 63 has landed
+          const int need = ((s - 1) << 20) | (t + 127);
+          while (prog[(wv + NW - 1) % NW] < need) __builtin_amdgcn_s_sleep(4);
+          asm volatile("" ::: "memory");
+        }
         c0blk = (s > 0 && j <= Lx) ? ld_carry(carry + j) : 0;
       }
       const int x0lo = __builtin_amdgcn_readlane(xb_lo, t & 63);
@@ -298,26 +312,38 @@ __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring
       if (wr_carry && lane == 63 && jj >= 0 && jj <= Lx) st_carry(carry + jj, pack_cell(S, g));
       // end cell: FINAL x node on the last row; ties keep the smaller column (:410-417)
       if (cell && ii == Ly && ((xhi >> 8) & kFlagFinal) && S > best) { best = S; bestx = jj - 1; }
+      if (NW > 1 && wr_carry && (t & 63) == 63) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) prog[wv] = (s << 20) | (t + 1);
+      }
     }
     if (wr_carry) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (NW > 1 && lane == 0) prog[wv] = (s + 1) << 20;
     }
   }
-  if (lane == (Ly - 1) % kStripRows + 1) { a.score2[w] = best; a.bx2[w] = bestx; }
+  if (wv == (ns - 1) % NW && lane == (Ly - 1) % kStripRows + 1) { a.score2[w] = best; a.bx2[w] = bestx; }
 }
 
-template <bool GEN, int D, bool DEEP>
-__global__ void __launch_bounds__(64) k_dp2(BatchArgs a, int cls, int32_t *gring, int64_t gring_block)
+template <bool GEN, int D, bool DEEP, int NW>
+__global__ void __launch_bounds__(64 * NW) k_dp2(BatchArgs a, int cls, int32_t *gring, int64_t gring_block)
 {
-  __shared__ int ring[D * 64];
+  extern __shared__ int dp2_lds[];                // NW rings of D * 64 cells, then prog[NW]
   __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
-  const int lane = threadIdx.x;
-  load_tables<GEN>(lds_tab, a.tab, lane);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  load_tables<GEN>(lds_tab, a.tab, threadIdx.x);
   Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
+  int *ring = dp2_lds + wv * (D * 64);
+  volatile int *prog = dp2_lds + NW * (D * 64);
   const int64_t cnt = list_count(a);
   for (int64_t i = blockIdx.x; i < cnt; i += gridDim.x) {
-    dp2_window<GEN, D, DEEP>(a, sc, ring, cls, a.perm[i], lane, DEEP ? gring + blockIdx.x * gring_block : nullptr);
+    if (NW > 1) {
+      if (threadIdx.x < NW) prog[threadIdx.x] = 0;
+      __syncthreads();
+    }
+    dp2_window<GEN, D, DEEP, NW>(a, sc, ring, cls, a.perm[i], lane,
+                                 DEEP ? gring + ((int64_t)blockIdx.x * NW + wv) * gring_block : nullptr, wv, prog);
     __syncthreads();
   }
 }
@@ -842,18 +868,25 @@ void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uin
 
 // cls 0: every predecessor within 30 nodes (LDS ring of 32 steps); cls 1: deeper graphs, the DEEP variant
 // with its HBM shadow ring -- gring holds `blocks` regions of gring_block ints, one per block of the launch
-void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st, int32_t *gring, int64_t gring_block, int blocks)
+// nw > 1: kDp2Waves wavefronts per window (the strips side by side), for the short lists whose longest window sets the time
+constexpr int kDp2Waves = 8;
+void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st, int32_t *gring, int64_t gring_block, int blocks, int nw)
 {
+  constexpr int NW = kDp2Waves;
+  const size_t lds1 = 32 * 256, ldsN = (size_t)NW * 32 * 256 + NW * 4;
   if (cls == 0) {
-    const dim3 g(list_grid(a, 1, 4096)), b(64);
-    if (gen) hipLaunchKernelGGL((k_dp2<true, 32, false>), g, b, 0, st, a, cls, nullptr, (int64_t)0);
-    else hipLaunchKernelGGL((k_dp2<false, 32, false>), g, b, 0, st, a, cls, nullptr, (int64_t)0);
+    const dim3 g(list_grid(a, 1, 4096));
+    if (gen) hipLaunchKernelGGL((k_dp2<true, 32, false, 1>), g, dim3(64), lds1, st, a, cls, nullptr, (int64_t)0);
+    else if (nw > 1) hipLaunchKernelGGL((k_dp2<false, 32, false, NW>), g, dim3(64 * NW), ldsN, st, a, cls, nullptr, (int64_t)0);
+    else hipLaunchKernelGGL((k_dp2<false, 32, false, 1>), g, dim3(64), lds1, st, a, cls, nullptr, (int64_t)0);
     return;
   }
   if (!gring || blocks <= 0) return;                  // no window of the batch can be that deep
-  const dim3 g((unsigned)blocks), b(64);
-  if (gen) hipLaunchKernelGGL((k_dp2<true, 32, true>), g, b, 0, st, a, cls, gring, gring_block);
-  else hipLaunchKernelGGL((k_dp2<false, 32, true>), g, b, 0, st, a, cls, gring, gring_block);
+  // (`blocks` regions of gring_block ints: a block of NW wavefronts takes NW of them)
+  if (gen) hipLaunchKernelGGL((k_dp2<true, 32, true, 1>), dim3((unsigned)blocks), dim3(64), lds1, st, a, cls, gring, gring_block);
+  else if (nw > 1 && blocks >= NW)
+    hipLaunchKernelGGL((k_dp2<false, 32, true, NW>), dim3((unsigned)(blocks / NW)), dim3(64 * NW), ldsN, st, a, cls, gring, gring_block);
+  else hipLaunchKernelGGL((k_dp2<false, 32, true, 1>), dim3((unsigned)blocks), dim3(64), lds1, st, a, cls, gring, gring_block);
 }
 
 void launch_fuse2(const BatchArgs &a, hipStream_t st)

@@ -49,34 +49,67 @@ hsa_status_t on_agent(hsa_agent_t ag, void *data)
   return HSA_STATUS_SUCCESS;
 }
 
-// the HSA agent of a HIP device, by PCI address; false when there is none (the caller then copies through HIP)
+// the HSA agent of a HIP device, by PCI address; false when there is none (the caller then copies through HIP).  The first
+// call per device asks the HIP runtime for the address; later ones only read the table (a stream's host function, which may
+// not call into HIP, can therefore start a copy once rows_dma_ready() has been through here on the caller's thread).
+constexpr int kMaxDev = 64;
+int g_dev_state[kMaxDev];                  // 0 unknown, 1 agent known, -1 none
+hsa_agent_t g_dev_agent[kMaxDev];
+
 bool agent_of(int hip_device, hsa_agent_t *gpu, hsa_agent_t *cpu)
 {
+  if (hip_device < 0 || hip_device >= kMaxDev) return false;
   std::lock_guard<std::mutex> lock(g_mu);
-  if (!g_agents.tried) {
-    g_agents.tried = true;
-    if (hsa_init() == HSA_STATUS_SUCCESS && hsa_iterate_agents(on_agent, &g_agents) == HSA_STATUS_SUCCESS)
-      g_agents.ok = g_agents.have_cpu && !g_agents.gpus.empty();
+  if (g_dev_state[hip_device] == 0) {
+    g_dev_state[hip_device] = -1;
+    if (!g_agents.tried) {
+      g_agents.tried = true;
+      if (hsa_init() == HSA_STATUS_SUCCESS && hsa_iterate_agents(on_agent, &g_agents) == HSA_STATUS_SUCCESS)
+        g_agents.ok = g_agents.have_cpu && !g_agents.gpus.empty();
+    }
+    char id[64] = {0};
+    unsigned dom = 0, bus = 0, dev = 0, fn = 0;
+    if (g_agents.ok && hipDeviceGetPCIBusId(id, (int)sizeof id, hip_device) == hipSuccess &&
+        std::sscanf(id, "%x:%x:%x.%x", &dom, &bus, &dev, &fn) == 4) {
+      const uint32_t want = (dom << 16) | ((bus & 0xFFu) << 8) | ((dev & 0x1Fu) << 3) | (fn & 7u);
+      for (size_t k = 0; k < g_agents.gpus.size(); ++k)
+        if (g_agents.gpu_bdf[k] == want) { g_dev_agent[hip_device] = g_agents.gpus[k]; g_dev_state[hip_device] = 1; break; }
+    }
   }
-  if (!g_agents.ok) return false;
-  char id[64] = {0};
-  if (hipDeviceGetPCIBusId(id, (int)sizeof id, hip_device) != hipSuccess) return false;
-  unsigned dom = 0, bus = 0, dev = 0, fn = 0;
-  if (std::sscanf(id, "%x:%x:%x.%x", &dom, &bus, &dev, &fn) != 4) return false;
-  const uint32_t want = (dom << 16) | ((bus & 0xFFu) << 8) | ((dev & 0x1Fu) << 3) | (fn & 7u);
-  for (size_t k = 0; k < g_agents.gpus.size(); ++k)
-    if (g_agents.gpu_bdf[k] == want) { *gpu = g_agents.gpus[k]; *cpu = g_agents.cpu; return true; }
-  return false;
+  if (g_dev_state[hip_device] != 1) return false;
+  *gpu = g_dev_agent[hip_device];
+  *cpu = g_agents.cpu;
+  return true;
+}
+
+bool dma_off()
+{
+  static const bool off = std::getenv("ELECTOR_ROWS_HIP_COPY") && std::atoi(std::getenv("ELECTOR_ROWS_HIP_COPY")) != 0;
+  return off;
 }
 
 }  // namespace
+
+// Can copies of this device go the HSA way?  Called on the caller's thread (it may ask the HIP runtime for the device's PCI
+// address); creates the slot's signal, so that rows_dma_start() behind it makes HSA calls only.
+bool rows_dma_ready(int hip_device, uint64_t *sig)
+{
+  if (dma_off()) return false;
+  hsa_agent_t gpu, cpu;
+  if (!agent_of(hip_device, &gpu, &cpu)) return false;
+  if (!*sig) {
+    hsa_signal_t s;
+    if (hsa_signal_create(0, 0, nullptr, &s) != HSA_STATUS_SUCCESS) return false;
+    *sig = s.handle;
+  }
+  return true;
+}
 
 // Start the copy of n bytes from device memory to page-locked host memory on the DMA engine.  *sig: the slot's signal
 // (created here at the first use, value 0 = none).  -> 0, or non-zero when the HSA way is not available (nothing started).
 int rows_dma_start(int hip_device, void *dst, const void *src, size_t n, uint64_t *sig)
 {
-  static const bool off = std::getenv("ELECTOR_ROWS_HIP_COPY") && std::atoi(std::getenv("ELECTOR_ROWS_HIP_COPY")) != 0;
-  if (off) return 1;
+  if (dma_off()) return 1;
   hsa_agent_t gpu, cpu;
   if (!agent_of(hip_device, &gpu, &cpu)) return 1;
   hsa_signal_t s;
