@@ -23,11 +23,12 @@
 
 namespace elector {
 void launch_symbolize(const uint8_t *in, uint8_t *out, int64_t nbytes, const DevTables *tab, hipStream_t st);
-void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st);
+void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st, int nw);
 void launch_fuse1(const BatchArgs &a, hipStream_t st);
 void launch_dp1_tile(const BatchArgs &a, const TileArgs &ta, bool gen, int ntiles, int nw, hipStream_t st);
 void launch_dp2_tile(const BatchArgs &a, const TileArgs &ta, bool gen, int ntiles, int nw, hipStream_t st);
 void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st, int32_t *gring, int64_t gring_block, int blocks, int nw);
+void launch_dp2_list(const BatchArgs &a, bool gen, hipStream_t st, int32_t *gring, int64_t gring_block, int blocks, int nw);
 void launch_fuse2(const BatchArgs &a, hipStream_t st);
 void launch_left_b(const BatchArgs &a, uint32_t *list, int32_t *count, const uint8_t *done_b, int64_t *mv2,
                    unsigned long long *bump, unsigned long long bump_base, unsigned long long bump_cap, int round,
@@ -1260,13 +1261,13 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       timed_begin(c, 2, st);
       const std::vector<LongWin> lw = long_windows(ch.k0, ch.k1);
       if ((rc = run_tiles(lw, 1))) return fail(c, rc, "tiled alignment #1");
-      launch_dp1(a, c->gen, st);
+      launch_dp1(a, c->gen, st, 16);
       launch_fuse1(a, st);
       if ((rc = run_tiles(lw, 2))) return fail(c, rc, "tiled alignment #2");
       {   // finish the host-routed windows here, beside the fused launch chains: a few long windows on one
           // wavefront each are a long critical path that must not wait for the chains to end
         a.mark_b = d_done_b;
-        for (int cls = 0; cls < 2; ++cls) launch_dp2(a, c->gen, cls, st, c->d_gring.as<int32_t>(), gring_block, deep_blocks, 8);
+        launch_dp2_list(a, c->gen, st, c->d_gring.as<int32_t>(), gring_block, deep_blocks, 16);
         launch_fuse2(a, st);
         a.mark_b = nullptr;
       }
@@ -1310,7 +1311,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       a.perm = d_leftb;
       a.count_ptr = d_counters;
       a.mark_b = d_done_b;
-      for (int cls = 0; cls < 2; ++cls) launch_dp2(a, c->gen, cls, st, c->d_gring.as<int32_t>(), gring_block, deep_blocks, 8);
+      launch_dp2_list(a, c->gen, st, c->d_gring.as<int32_t>(), gring_block, deep_blocks, 8);
       launch_fuse2(a, st);
       a.mark_b = nullptr;
     }
@@ -1325,7 +1326,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
       timed_begin(c, 0, st);
       const std::vector<LongWin> lw = long_windows(ch.k0, ch.k1);
       if ((rc = run_tiles(lw, 1))) return fail(c, rc, "tiled alignment #1");
-      launch_dp1(a, c->gen, st);
+      launch_dp1(a, c->gen, st, 1);
       timed_end(c, st);
       timed_begin(c, 2, st);
       launch_fuse1(a, st);

@@ -97,8 +97,10 @@ __global__ void __launch_bounds__(256) k_symbolize(const uint8_t *__restrict__ i
 // registers: left = own previous step, up = lane-1 previous step (DPP), diag =
 // the `up` received one step earlier.
 
-template <bool GEN>
-__device__ void dp1_window(const BatchArgs &a, const Scoring<GEN> &sc, const uint32_t w, const int lane)
+// NW wavefronts per window: the strips side by side, each a good 128 steps behind the one above (see dp2_window).
+template <bool GEN, int NW>
+__device__ void dp1_window(const BatchArgs &a, const Scoring<GEN> &sc, const uint32_t w, const int lane, const int wv,
+                           volatile int *prog)
 {
   if (a.status[w] || (a.skip_a && a.skip_a[w]) || (a.tiled && (a.tiled[w] & 1))) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o1 = a.off[3 * (int64_t)w + 1], o2 = a.off[3 * (int64_t)w + 2];
@@ -108,7 +110,7 @@ __device__ void dp1_window(const BatchArgs &a, const Scoring<GEN> &sc, const uin
   int32_t *carry = a.carry + (o0 + w);
   const int tw = mv_tw(Lx), ns = n_strips(Ly);
 
-  for (int s = 0; s < ns; ++s) {
+  for (int s = wv; s < ns; s += NW) {
     const int ii = s * kStripRows + lane;
     const bool rowok = lane >= 1 && ii <= Ly;
     const int yl = rowok ? ys[ii - 1] : 0;
@@ -123,6 +125,11 @@ __device__ void dp1_window(const BatchArgs &a, const Scoring<GEN> &sc, const uin
       if ((t & 63) == 0) {
         const int j = t + lane;
         xblk = (j >= 1 && j <= Lx) ? xs[j - 1] : 0;
+        if (NW > 1 && s > 0) {
+          const int need = ((s - 1) << 20) | (t + 127);
+          while (prog[(wv + NW - 1) % NW] < need) __builtin_amdgcn_s_sleep(4);
+          asm volatile("" ::: "memory");
+        }
         c0blk = (j <= Lx) ? ld_carry(src0 + j) : 0;
       }
       const int x0 = __builtin_amdgcn_readlane(xblk, t & 63);
@@ -151,10 +158,15 @@ __device__ void dp1_window(const BatchArgs &a, const Scoring<GEN> &sc, const uin
       if ((t & 7) == 7 || t == T) { mv[((int64_t)s * tw + (t >> 3)) * 64 + lane] = mvacc; mvacc = 0; }
       if (wr_carry && lane == 63 && jj >= 0 && jj <= Lx) st_carry(carry + jj, pack_cell(S, g));
       if (cell && ii == Ly && jj == Lx) a.score1[w] = S;    // the only FINAL x FINAL cell
+      if (NW > 1 && wr_carry && (t & 63) == 63) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) prog[wv] = (s << 20) | (t + 1);
+      }
     }
     if (wr_carry) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (NW > 1 && lane == 0) prog[wv] = (s + 1) << 20;
     }
   }
 }
@@ -166,15 +178,24 @@ __device__ __forceinline__ int64_t list_count(const BatchArgs &a)
   return a.count_ptr ? (int64_t)*a.count_ptr : a.n;
 }
 
-template <bool GEN>
-__global__ void __launch_bounds__(64) k_dp1(BatchArgs a)
+template <bool GEN, int NW>
+__global__ void __launch_bounds__(64 * NW) k_dp1(BatchArgs a)
 {
   __shared__ int lds_tab[GEN ? (128 + 1024) : 1];
-  const int lane = threadIdx.x;
-  load_tables<GEN>(lds_tab, a.tab, lane);
+  __shared__ int prog_lds[NW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  load_tables<GEN>(lds_tab, a.tab, threadIdx.x);
   Scoring<GEN> sc{lds_tab, lds_tab + 64, lds_tab + 128, a.kp};
+  volatile int *prog = prog_lds;
   const int64_t cnt = list_count(a);
-  for (int64_t i = blockIdx.x; i < cnt; i += gridDim.x) dp1_window<GEN>(a, sc, a.perm[i], lane);
+  for (int64_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+    if (NW > 1) {
+      __syncthreads();
+      if (threadIdx.x < NW) prog[threadIdx.x] = 0;
+      __syncthreads();
+    }
+    dp1_window<GEN, NW>(a, sc, a.perm[i], lane, wv, prog);
+  }
 }
 
 // ------------------------------------------------------------------ k_dp2 ---
@@ -201,7 +222,7 @@ template <bool GEN, int D, bool DEEP, int NW>
 __device__ void dp2_window(const BatchArgs &a, const Scoring<GEN> &sc, int *ring, const int cls, const uint32_t w,
                            const int lane, int32_t *gring, const int wv, volatile int *prog)
 {
-  if (a.status[w] || (a.cls[w] & 3) != cls || (a.skip_b && a.skip_b[w]) || (a.tiled && (a.tiled[w] & 2))) return;
+  if (a.status[w] || (cls >= 0 && (a.cls[w] & 3) != cls) || (a.skip_b && a.skip_b[w]) || (a.tiled && (a.tiled[w] & 2))) return;
   const int64_t o0 = a.off[3 * (int64_t)w], o2 = a.off[3 * (int64_t)w + 2], o3 = a.off[3 * (int64_t)w + 3];
   const int Lx = a.n1[w], Ly = (int)(o3 - o2);
   const uint8_t *ys = a.sym + o2;
@@ -832,11 +853,14 @@ static unsigned list_grid(const BatchArgs &a, int64_t per_block, unsigned device
   return (unsigned)(g < 1 ? 1 : g);
 }
 
-void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st)
+// nw > 1: kDp2Waves wavefronts per window (a short list of long windows: the longest one sets the time)
+void launch_dp1(const BatchArgs &a, bool gen, hipStream_t st, int nw)
 {
   const unsigned g = list_grid(a, 1, 4096);
-  if (gen) hipLaunchKernelGGL(k_dp1<true>, dim3(g), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL(k_dp1<false>, dim3(g), dim3(64), 0, st, a);
+  if (gen) hipLaunchKernelGGL((k_dp1<true, 1>), dim3(g), dim3(64), 0, st, a);
+  else if (nw >= 16) hipLaunchKernelGGL((k_dp1<false, 16>), dim3(g), dim3(64 * 16), 0, st, a);
+  else if (nw > 1) hipLaunchKernelGGL((k_dp1<false, 8>), dim3(g), dim3(64 * 8), 0, st, a);
+  else hipLaunchKernelGGL((k_dp1<false, 1>), dim3(g), dim3(64), 0, st, a);
 }
 
 // one launch per anti-diagonal of tiles; ntiles = upper bound of the tiles on it, nw = long windows
@@ -887,6 +911,32 @@ void launch_dp2(const BatchArgs &a, bool gen, int cls, hipStream_t st, int32_t *
   else if (nw > 1 && blocks >= NW)
     hipLaunchKernelGGL((k_dp2<false, 32, true, NW>), dim3((unsigned)(blocks / NW)), dim3(64 * NW), ldsN, st, a, cls, gring, gring_block);
   else hipLaunchKernelGGL((k_dp2<false, 32, true, 1>), dim3((unsigned)blocks), dim3(64), lds1, st, a, cls, gring, gring_block);
+}
+
+// Both classes of a short list in ONE launch of the DEEP instance (cls -1: it takes the near predecessors from the LDS ring
+// like the plain one; its shadow stores are fire and forget): the launch lasts as long as its longest window, not as the
+// longest of each class one after the other.  Where that instance cannot run, the two launches.
+void launch_dp2_list(const BatchArgs &a, bool gen, hipStream_t st, int32_t *gring, int64_t gring_block, int blocks, int nw)
+{
+  constexpr int NW = kDp2Waves;
+  if (!gen && gring && nw >= 16 && blocks >= 16) {
+    // (the host-routed windows: longer than any on-chip class takes, a dozen strips and more)
+    static bool attr_set = false;
+    if (!attr_set) {
+      attr_set = true;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dp2<false, 32, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                16 * 32 * 256 + 64);
+    }
+    hipLaunchKernelGGL((k_dp2<false, 32, true, 16>), dim3((unsigned)(blocks / 16)), dim3(64 * 16), (size_t)16 * 32 * 256 + 64, st,
+                       a, -1, gring, gring_block);
+    return;
+  }
+  if (!gen && gring && blocks >= NW) {
+    hipLaunchKernelGGL((k_dp2<false, 32, true, NW>), dim3((unsigned)(blocks / NW)), dim3(64 * NW), (size_t)NW * 32 * 256 + NW * 4, st,
+                       a, -1, gring, gring_block);
+    return;
+  }
+  for (int cls = 0; cls < 2; ++cls) launch_dp2(a, gen, cls, st, gring, gring_block, blocks, NW);
 }
 
 void launch_fuse2(const BatchArgs &a, hipStream_t st)
