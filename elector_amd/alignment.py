@@ -86,6 +86,12 @@ def _get_pool(matrix_path=None, n=None):
             # pipeline at one batch per 35 ms
             n = int(os.environ.get("ELECTOR_ENGINES", "3"))
         _pool = EnginePool(int(os.environ.get("LOCAL_RANK", "0")), n, params)
+        # ELECTOR_ENGINE_CUS=lo:hi: the alignment contexts' streams on the compute units lo .. hi - 1 of the queue mask
+        cus = os.environ.get("ELECTOR_ENGINE_CUS", "")
+        if cus:
+            lo, hi = (int(x) for x in cus.split(":"))
+            for g in _pool.engines:
+                g.option("cus", lo * 1000 + hi)
     return _pool
 
 
@@ -100,6 +106,11 @@ def _get_splitter(device, k=0):
         prio = int(os.environ.get("ELECTOR_SPLIT_PRIORITY", "0") or 0)
         if prio:
             _splitters[(device, k)].option("priority", prio)
+        # ELECTOR_SPLIT_CUS=lo:hi: the splitter's streams on the compute units lo .. hi - 1 of the queue mask (of 256)
+        cus = os.environ.get("ELECTOR_SPLIT_CUS", "")
+        if cus:
+            lo, hi = (int(x) for x in cus.split(":"))
+            _splitters[(device, k)].option("cus", lo * 1000 + hi)
     return _splitters[(device, k)]
 
 

@@ -96,8 +96,15 @@ struct elector_ctx {
   int chains = 0;               // launch chains for the fused classes (elector_ctx_option "chains"; 0 = default)
   int priority = 0;             // elector_ctx_option "priority": -1 / 0 / +1 = the context's streams at the device's highest / default / lowest priority
   // a stream of this context (every one goes through here: the priority)
+  int cu_lo = 0, cu_hi = 0;     // elector_ctx_option "cus": the context's streams on the compute units [cu_lo, cu_hi) of the queue mask
   int make_stream(hipStream_t *s) const
   {
+    if (cu_hi > cu_lo) {
+      // (bit i of the mask: the runtime deals the bits out to the XCDs in turn, so a range of 8 k bits is k units on each)
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = cu_lo; i < cu_hi && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+      return hipExtStreamCreateWithCUMask(s, 8, mask) == hipSuccess ? 0 : 1;
+    }
     if (priority == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : 1;
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 1;

@@ -408,6 +408,19 @@ extern "C" int elector_ctx_option(elector_ctx *c, const char *name, int64_t valu
     c->stream = ns;
     return ELECTOR_OK;
   }
+  if (!std::strcmp(name, "cus")) {                    // the context's streams on compute units lo .. hi - 1 of the queue mask: value = lo * 1000 + hi
+    const int lo = (int)(value / 1000), hi = (int)(value % 1000);
+    if (value < 0 || lo >= hi || hi > 256) return fail(c, ELECTOR_E_INVAL, "cus: lo * 1000 + hi with 0 <= lo < hi <= 256");
+    if (c->aux_ready || c->copy_stream) return fail(c, ELECTOR_E_INVAL, "cus must be set before the context's first call");
+    c->cu_lo = lo; c->cu_hi = hi;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipStream_t ns = nullptr;
+    if (c->make_stream(&ns)) return fail(c, ELECTOR_E_HIP, "stream with a compute-unit mask");
+    (void)hipStreamDestroy(c->stream);
+    c->stream = ns;
+    return ELECTOR_OK;
+  }
   return fail(c, ELECTOR_E_INVAL, "unknown option");
 }
 

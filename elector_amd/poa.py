@@ -259,7 +259,8 @@ class PoaEngine:
 
     def option(self, name, value):
         """elector_ctx_option: "chains" = concurrent launch chains of the fused classes (0 = default); "priority" = -1 / 0 / +1,
-        the context's streams at the device's highest / default / lowest priority (before the context's first call)."""
+        the context's streams at the device's highest / default / lowest priority; "cus" = lo * 1000 + hi, its streams on the
+        compute units lo .. hi - 1 of the queue mask (both before the context's first call)."""
         self._check(self._lib.elector_ctx_option(self._h, name.encode(), int(value)))
 
     def last_po_sizes(self, n):

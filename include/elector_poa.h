@@ -148,7 +148,11 @@ int elector_ctx_timing_reset(elector_ctx *ctx);
  * un-overlapped per-kernel measurement needs (bench.py's serial pass).
  * "priority" = -1 / 0 / +1: the context's streams at the device's highest / default / lowest priority (before the
  * context's first call): a pipeline gives its splitter context the lowest, so that the alignment kernels' wavefronts
- * go first where both want the chip. */
+ * go first where both want the chip (measured: no gain).
+ * "cus" = lo * 1000 + hi: the context's streams on the compute units lo .. hi - 1 of the 256-bit queue mask
+ * (hipExtStreamCreateWithCUMask; before the context's first call; the runtime deals the bits out to the XCDs in turn,
+ * so 8 k bits are k units on each).  Measured on the end-to-end pipeline: a splitter held to a part of the chip halves
+ * the rate; off unless asked for. */
 int elector_ctx_option(elector_ctx *ctx, const char *name, int64_t value);
 /* diagnostics: |PO| (nodes after fusion #1) of the first n windows of the last
  * batch, so callers can count the DP cells of alignment #2 (|PO| x Lu). */

@@ -397,6 +397,26 @@ def test_far_edge_windows_equal_the_two_kernel_path(engine, monkeypatch):
     assert got == got2 and np.array_equal(scores, scores2)
 
 
+def test_context_on_a_part_of_the_chip():
+    """elector_ctx_option "cus" / "priority": a context whose streams sit on a quarter of the compute units (and one at the
+    lowest priority) gives the windows the default context gives; the options are refused once the context has run"""
+    from elector_amd import poa
+    triples = synth.window_triples(93, 3000, 20, 160, err_unc=0.12, err_cor=0.03) + far_edge_triples(94, 300)
+    ref = poa.PoaEngine(0)
+    want, wscores = ref.align(triples, want_scores=True)
+    for name, value in (("cus", 0 * 1000 + 64), ("priority", 1)):
+        e = poa.PoaEngine(0)
+        e.option(name, value)
+        got, scores = e.align(triples, want_scores=True)
+        assert got == want and np.array_equal(scores, wscores), name
+        with pytest.raises(Exception):
+            e.option(name, value)
+        e.close()
+    with pytest.raises(Exception):
+        ref.option("cus", 64 * 1000 + 64)
+    ref.close()
+
+
 def uniform_matrix(match, mismatch, gaps="10 5 5"):
     letters = "A a c g t n".split()
     rows = ["  " + " ".join(letters)]

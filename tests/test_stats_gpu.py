@@ -113,6 +113,19 @@ def test_device_merge_and_stats_equal_oracle(tmp_path, engine, seed, n, L):
     assert np.array_equal(piece_cols2, pieces.cols) and np.array_equal(got2, got)
     engine.msa_rows_wait()
     assert np.array_equal(pinned.numpy()[3:3 + len(pieces.rows)], pieces.rows)
+    # ... and with the copy started when the job is collected (rounds 3-4) instead of from the stream's host function,
+    # twice in a row into the other slot and a fresh destination
+    for env in ("ELECTOR_ROWS_AT_COLLECT", "ELECTOR_ROWS_HIP_COPY"):
+        os.environ[env] = "1"
+        try:
+            pinned2 = torch.zeros(cap + 16, dtype=torch.uint8).pin_memory()
+            npc = engine.msa_stats_enqueue(win.n_windows, d_cols, d_ncol, d_status, win.read_first, pieces.read_first,
+                                           rows_out=pinned2.data_ptr() + 1, rows_cap=cap)
+            engine.msa_stats_collect(npc)
+            engine.msa_rows_wait()
+            assert np.array_equal(pinned2.numpy()[1:1 + len(pieces.rows)], pieces.rows), env
+        finally:
+            del os.environ[env]
     d_rows = torch.zeros(cap, dtype=torch.uint8, device=dev)
     npc = engine.msa_stats_enqueue(win.n_windows, d_cols, d_ncol, d_status, win.read_first, pieces.read_first,
                                    rows_out=d_rows.data_ptr(), rows_cap=cap)
