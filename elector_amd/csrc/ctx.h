@@ -68,6 +68,8 @@ struct StatsSlot {
   uint8_t *rows_host = nullptr;     // this job's rows go to this page-locked host address: from the stream's host function
                                     // behind the packing kernel (rows_go, stats.hip), else when the job is collected
   bool rows_inflight = false;
+  const void *rows_src = nullptr;   // where the job's packed rows lie on the device: `dense`, or `rows` itself when the merge wrote them without gaps
+  size_t rows_src_cap = 0;
   int device = -1;
   int64_t n_pieces = 0, n_reads = 0, total = 0, last_piece = 0, max_windows = 0;
   bool has_clips = false;

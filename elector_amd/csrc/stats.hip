@@ -190,79 +190,158 @@ struct MergeWinArgs {
   const int64_t *piece_first;
   const int64_t *off;
   const uint8_t *cols_in;
+  int64_t cols_bytes;           // 3 * off[3 * n_windows]: no load may reach beyond
   const int32_t *ncol;
   const int32_t *status;
-  int64_t *cnt;                 // n_windows + 1: surviving columns per window, then (in place) their exclusive scan
-  int32_t *piece_of;            // n_windows
+  int64_t *cnt;                 // n_windows + 1: surviving columns per window, then their exclusive scan
+  int64_t *wdst;                // n_windows: where the window's first kept column goes in row 0, from `rows` (k_merge_pieces)
+  int32_t *wn;                  // n_windows: columns of the window's piece
   uint8_t *rows;
   int64_t *row_off, *cols;
 };
 
-__global__ void __launch_bounds__(kStatsThreads) k_merge_count(MergeWinArgs a)
+// Four columns of a window per lane: 12 consecutive bytes x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3 as ONE load (the
+// address is byte-aligned: the hardware takes unaligned dwords), the three rows' letters sorted into a dword each by
+// byte permutes.  A wavefront instruction moves 768 bytes where the byte-wide form moved 64: the texture addresser, which
+// takes a wavefront's request at 64 lanes per 16 cycles whatever its width, was what the byte-wide kernels waited for
+// (11 M requests per yeast -split batch: 0.29 of k_merge_copy's 0.51 ms).
+struct __attribute__((packed)) Cols12 { uint32_t a, b, c; };
+
+// the letters of columns c .. c + 3 of a window (nv of them valid, 1 <= nv <= 4); y's bytes beyond nv come back as 'n'
+__device__ __forceinline__ void load_cols4(const uint8_t *src, int64_t src_at, int64_t limit, int c, int nv, uint32_t &x, uint32_t &y, uint32_t &z)
 {
-  const int gl = threadIdx.x & 15, lane = threadIdx.x & 63, gshift = (lane >> 4) * 16;
-  const int64_t w = (int64_t)blockIdx.x * (kStatsThreads / 16) + (threadIdx.x >> 4);
-  const bool on = w < a.n_windows;
-  const int nc = on && a.status[w] == 0 ? a.ncol[w] : 0;
-  const uint8_t *src = a.cols_in + (on ? 3 * a.off[3 * w] : 0);
-  int cnt = 0;
-  int ncmax = nc;                                     // (the ballots below need the wavefront's four groups together)
-  for (int d = 16; d < 64; d <<= 1) ncmax = max(ncmax, __shfl_xor(ncmax, d));
-  for (int c0 = 0; c0 < ncmax; c0 += 64) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + 16 * u + gl;
-      const uint8_t y = c < nc ? src[3 * c + 1] : (uint8_t)'n';
-      cnt += __popcll((__ballot(y != 'n') >> gshift) & 0xFFFFull);
+  if (src_at + 3 * (int64_t)c + 12 <= limit) {
+    Cols12 v;
+    __builtin_memcpy(&v, src + 3 * (int64_t)c, 12);
+    x = __builtin_amdgcn_perm(v.c, __builtin_amdgcn_perm(v.b, v.a, 0x00060300u), 0x05020100u);
+    y = __builtin_amdgcn_perm(v.c, __builtin_amdgcn_perm(v.b, v.a, 0x00070401u), 0x06020100u);
+    z = __builtin_amdgcn_perm(v.c, __builtin_amdgcn_perm(v.b, v.a, 0x00000502u), 0x07040100u);
+  } else {                                            // the batch's last bytes: letter by letter
+    x = 0; y = 0; z = 0;
+    for (int u = 0; u < nv; ++u) {
+      x |= (uint32_t)src[3 * (c + u)] << (8 * u); y |= (uint32_t)src[3 * (c + u) + 1] << (8 * u); z |= (uint32_t)src[3 * (c + u) + 2] << (8 * u);
     }
   }
-  if (on && gl == 0) a.cnt[w] = cnt;
+  if (nv < 4) { const uint32_t m = (1u << (8 * nv)) - 1u; y = (y & m) | (0x6E6E6E6Eu & ~m); }
+}
+
+// bit 7 of every byte of y that is not 'n' (Donatello.cpp:13-31: those columns stay)
+__device__ __forceinline__ uint32_t kept_bytes(uint32_t y)
+{
+  const uint32_t t = y ^ 0x6E6E6E6Eu;
+  return (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
+}
+
+// A 16-lane group takes kMergeNW consecutive windows, the first 128 columns of each (nearly always all of them) asked for
+// before any is looked at: the kernels wait for trips to memory, not for bandwidth, and a group with one window in
+// flight had two of them (the window's descriptor, then its columns) for 200 bytes.
+constexpr int kMergeNW = 2;
+constexpr int kMergeWinPerBlock = kMergeNW * (kStatsThreads / 16);
+
+__global__ void __launch_bounds__(kStatsThreads) k_merge_count(MergeWinArgs a)
+{
+  const int gl = threadIdx.x & 15;
+  const int64_t wb = ((int64_t)blockIdx.x * (kStatsThreads / 16) + (threadIdx.x >> 4)) * kMergeNW;
+  int nc[kMergeNW];
+  int64_t at[kMergeNW];
+#pragma unroll
+  for (int j = 0; j < kMergeNW; ++j) {
+    const int64_t w = wb + j;
+    const bool on = w < a.n_windows;
+    nc[j] = on && a.status[on ? w : 0] == 0 ? a.ncol[w] : 0;
+    at[j] = on ? 3 * a.off[3 * w] : 0;
+  }
+  uint32_t y[kMergeNW][2];
+#pragma unroll
+  for (int j = 0; j < kMergeNW; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = 64 * h + 4 * gl;
+      uint32_t x, z;
+      y[j][h] = 0x6E6E6E6Eu;
+      if (c < nc[j]) load_cols4(a.cols_in + at[j], at[j], a.cols_bytes, c, min(4, nc[j] - c), x, y[j][h], z);
+    }
+#pragma unroll
+  for (int j = 0; j < kMergeNW; ++j) {
+    int cnt = __popc(kept_bytes(y[j][0])) + __popc(kept_bytes(y[j][1]));
+    for (int c = 128 + 4 * gl; c < nc[j]; c += 64) {
+      uint32_t x, yy, z;
+      load_cols4(a.cols_in + at[j], at[j], a.cols_bytes, c, min(4, nc[j] - c), x, yy, z);
+      cnt += __popc(kept_bytes(yy));
+    }
+    for (int d = 1; d < 16; d <<= 1) cnt += __shfl_xor(cnt, d, 16);
+    if (gl == 0 && wb + j < a.n_windows) a.cnt[wb + j] = cnt;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.cnt[a.n_windows] = 0;
 }
 
+// (the rows go where the scan over ALL windows of the batch says: piece after piece without a gap -- what the copy to the
+// host wants; the block-per-piece form leaves every piece the room of its windows' letters and k_compact packs)
+// Per window: where its first kept column goes in the reference's row, and the piece's columns (the distance to the next
+// row) -- k_merge_copy then has one trip to memory in front of its columns instead of three.
 __global__ void __launch_bounds__(kStatsThreads) k_merge_pieces(MergeWinArgs a)
 {
   const int64_t p = blockIdx.x;
   const int64_t w0 = a.piece_first[p], w1 = a.piece_first[p + 1];
-  for (int64_t w = w0 + threadIdx.x; w < w1; w += kStatsThreads) a.piece_of[w] = (int32_t)p;
-  if (threadIdx.x == 0) { a.cols[p] = a.cnt[w1] - a.cnt[w0]; a.row_off[p] = 3 * a.off[3 * w0]; }
+  const int64_t e0 = a.cnt[w0], n = a.cnt[w1] - e0;
+  for (int64_t w = w0 + threadIdx.x; w < w1; w += kStatsThreads) { a.wdst[w] = 2 * e0 + a.cnt[w]; a.wn[w] = (int32_t)n; }
+  if (threadIdx.x == 0) { a.cols[p] = n; a.row_off[p] = 3 * e0; }
 }
 
 __global__ void __launch_bounds__(kStatsThreads) k_merge_copy(MergeWinArgs a)
 {
-  const int gl = threadIdx.x & 15, lane = threadIdx.x & 63, gshift = (lane >> 4) * 16;
-  const int64_t w = (int64_t)blockIdx.x * (kStatsThreads / 16) + (threadIdx.x >> 4);
-  const bool on = w < a.n_windows;
-  const int nc = on && a.status[w] == 0 ? a.ncol[w] : 0;
-  const uint8_t *src = a.cols_in + (on ? 3 * a.off[3 * w] : 0);
-  int64_t k = 0, n = 0, rb = 0;
-  if (on) {
-    const int64_t p = a.piece_of[w], w0 = a.piece_first[p];
-    const int64_t e0 = a.cnt[w0];
-    k = a.cnt[w] - e0;
-    n = a.cnt[a.piece_first[p + 1]] - e0;
-    rb = 3 * a.off[3 * w0];
+  const int gl = threadIdx.x & 15;
+  const int64_t wb = ((int64_t)blockIdx.x * (kStatsThreads / 16) + (threadIdx.x >> 4)) * kMergeNW;
+  int nc[kMergeNW];
+  int64_t at[kMergeNW], to[kMergeNW], n[kMergeNW];
+#pragma unroll
+  for (int j = 0; j < kMergeNW; ++j) {
+    const int64_t w = wb + j;
+    const bool on = w < a.n_windows;
+    nc[j] = on && a.status[on ? w : 0] == 0 ? a.ncol[w] : 0;
+    at[j] = on ? 3 * a.off[3 * w] : 0;
+    to[j] = on ? a.wdst[w] : 0;
+    n[j] = on ? a.wn[w] : 0;
   }
-  uint8_t *d0 = a.rows + rb, *d1 = d0 + n, *d2 = d1 + n;
-  int ncmax = nc;
-  for (int d = 16; d < 64; d <<= 1) ncmax = max(ncmax, __shfl_xor(ncmax, d));
-  for (int c0 = 0; c0 < ncmax; c0 += 64) {
-    uint8_t x[4], y[4], z[4];
+  uint32_t x[kMergeNW][2], y[kMergeNW][2], z[kMergeNW][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + 16 * u + gl;
-      x[u] = 0; y[u] = 'n'; z[u] = 0;
-      if (c < nc) { x[u] = src[3 * c]; y[u] = src[3 * c + 1]; z[u] = src[3 * c + 2]; }
+  for (int j = 0; j < kMergeNW; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = 64 * h + 4 * gl;
+      x[j][h] = 0; y[j][h] = 0x6E6E6E6Eu; z[j][h] = 0;
+      if (c < nc[j]) load_cols4(a.cols_in + at[j], at[j], a.cols_bytes, c, min(4, nc[j] - c), x[j][h], y[j][h], z[j][h]);
     }
+  // four columns of this lane go out; -> the columns the window's sixteen lanes kept together (they share nc: all of
+  // them are here, and the scan over the DPP row sees every one)
+  auto emit = [&](uint8_t *d0, int64_t nn, int64_t k, uint32_t xx, uint32_t yy, uint32_t zz) {
+    const uint32_t keep = kept_bytes(yy);
+    const int mine = __popc(keep);
+    int inc = mine;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);
+    uint8_t *p0 = d0 + k + (inc - mine), *p1 = p0 + nn, *p2 = p1 + nn;
+    if (mine == 4) {
+      __builtin_memcpy(p0, &xx, 4); __builtin_memcpy(p1, &yy, 4); __builtin_memcpy(p2, &zz, 4);
+    } else if (mine > 0) {
+      for (int u = 0; u < 4; ++u)
+        if ((keep >> (8 * u + 7)) & 1u) { *p0++ = (uint8_t)(xx >> (8 * u)); *p1++ = (uint8_t)(yy >> (8 * u)); *p2++ = (uint8_t)(zz >> (8 * u)); }
+    }
+    return (int64_t)__shfl(inc, 15, 16);
+  };
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool keep = y[u] != 'n';
-      const unsigned long long m = (__ballot(keep) >> gshift) & 0xFFFFull;
-      if (keep) {
-        const int64_t at = k + __popcll(m & ((1ull << gl) - 1ull));
-        d0[at] = x[u]; d1[at] = y[u]; d2[at] = z[u];
-      }
-      k += __popcll(m);
+  for (int j = 0; j < kMergeNW; ++j) {
+    if (nc[j] <= 0) continue;
+    uint8_t *d0 = a.rows + to[j];
+    int64_t k = emit(d0, n[j], 0, x[j][0], y[j][0], z[j][0]);
+    if (nc[j] > 64) k += emit(d0, n[j], k, x[j][1], y[j][1], z[j][1]);
+    for (int c0 = 128; c0 < nc[j]; c0 += 64) {
+      const int c = c0 + 4 * gl, nv = min(4, nc[j] - c);
+      uint32_t xx = 0, yy = 0x6E6E6E6Eu, zz = 0;
+      if (nv > 0) load_cols4(a.cols_in + at[j], at[j], a.cols_bytes, c, nv, xx, yy, zz);
+      k += emit(d0, n[j], k, xx, yy, zz);
     }
   }
 }
@@ -343,7 +422,7 @@ struct StatsArgs {
   const int64_t *cols;         // per piece
   const int32_t *clips;        // may be null
   int64_t *counters;
-  uint8_t *mask;               // 1 byte per column; piece p at mask + row_off[p] / 3
+  uint8_t *mask;               // 1 byte per column; piece p at mask + row_off[p] / 3 (written for the LAST read's pieces, and for pieces on the HBM path)
   int32_t *pool;               // bump-allocated scratch: interval lists, union bytes of split reads
   unsigned long long pool_cap; // in int32 units
   unsigned long long *pool_used;
@@ -670,6 +749,7 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
   const int64_t p0 = a.read_first[r], p1 = a.read_first[r + 1];
   const int nfrag = (int)(p1 - p0);
   const int W2 = a.bit_words + 2;
+  const bool last_read = r == a.n_reads - 1;
 
   // realNotMissing of a split read (:589-591): one byte per column of its longest piece
   int ucap = 0;
@@ -879,11 +959,15 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
       }
       __syncthreads();
       if (tid == 0) { s_acc[15] = n - s_acc[15]; s_acc[16] = n - s_acc[16]; s_acc[17] = n - s_acc[17]; }
-      for (int i = tid; i < n; i += (int)blockDim.x) {
-        const uint8_t mk = bbit(kMk, W2, i) ? 1 : 0;
-        mask[i] = mk;
-        if (nfrag > 1) uni[i] |= mk;                                          // realNotMissing (:589-591)
-      }
+      // the mask as bytes: only the batch's LAST read's is ever taken out (call site #2's report), a split read's
+      // pieces also fold theirs into the read's union -- for every other read the words in LDS were all of it
+      // (a byte per column of every read was 119 MB of byte-wide stores per yeast -split batch)
+      if (last_read || nfrag > 1)
+        for (int i = tid; i < n; i += (int)blockDim.x) {
+          const uint8_t mk = bbit(kMk, W2, i) ? 1 : 0;
+          if (last_read) mask[i] = mk;
+          if (nfrag > 1) uni[i] |= mk;                                        // realNotMissing (:589-591)
+        }
     } else {
 
       // ---- gapsAndExtensions (:472-498): the four end scans on four lanes ----
@@ -1265,8 +1349,8 @@ static void rows_go(void *p)
   const int64_t *hcols = reinterpret_cast<const int64_t *>(h + 16 + (size_t)s.n_pieces * ES_NCOUNTERS * 8);
   int64_t nbytes = 0;
   for (int64_t k = 0; k < s.n_pieces; ++k) nbytes += 3 * hcols[k];
-  if (nbytes <= 0 || nbytes > (int64_t)s.dense.cap) return;
-  if (elector::rows_dma_start(s.device, s.rows_host, s.dense.p, (size_t)nbytes, &s.rows_sig) != 0) return;
+  if (nbytes <= 0 || nbytes > (int64_t)s.rows_src_cap) return;
+  if (elector::rows_dma_start(s.device, s.rows_host, s.rows_src, (size_t)nbytes, &s.rows_sig) != 0) return;
   s.rows_by_dma = true;
   s.rows_inflight = true;
   s.rows_host = nullptr;
@@ -1329,10 +1413,18 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
   for (int64_t p = 0; p < n_pieces; ++p) s.max_windows = std::max(s.max_windows, piece_first[p + 1] - piece_first[p]);
   const int64_t total = s.total;            // bases of the batch: an upper bound of its MSA columns
   if (n_pieces > 0 && n_reads > 0) {
+    hipStream_t st = c->stream;
+    // The slot's rows buffer is about to be written again: a copy to the host that still reads from it (the merge with
+    // the windows as the unit leaves the rows packed, and they go out from where they lie) has to be through.
+    if (rows_fence(c, s)) return elector_fail(c, ELECTOR_E_HIP, "rows copy");
     // both slots grow together: the second job of a pipelined caller must not pay for allocations
     int rc = 0;
     for (int k = 0; k < elector_ctx::kStatsSlots; ++k) {
       elector::StatsSlot &z = c->st_slot[k];
+      if (z.rows_inflight && (size_t)3 * total + 64 > z.rows.cap) {     // (it grows = is freed: not under a copy out of it)
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (rows_fence(c, z)) return elector_fail(c, ELECTOR_E_HIP, "rows copy");
+      }
       rc |= z.rows.ensure((size_t)3 * total + 64) | z.rowoff.ensure((size_t)(n_pieces + 1) * 8) |
             z.cols.ensure((size_t)n_pieces * 8) | z.first.ensure((size_t)(n_reads + 1 + n_pieces + 1) * 8) |
             z.cnt.ensure((size_t)n_pieces * ES_NCOUNTERS * 8) | z.mask.ensure((size_t)total + 64) |
@@ -1341,7 +1433,6 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
                        (clips ? (size_t)n_pieces * 8 : 0));
     }
     if (rc) return elector_fail(c, ELECTOR_E_NOMEM, "statistics workspace");
-    hipStream_t st = c->stream;
     // inputs go through the slot's pinned block so that the uploads do not wait for the device
     uint8_t *hin = s.h.as<uint8_t>() + 16 + (size_t)n_pieces * (ES_NCOUNTERS + 1) * 8;
     std::memcpy(hin, read_first, (size_t)(n_reads + 1) * 8);
@@ -1364,12 +1455,15 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
     m.row_off = s.rowoff.as<int64_t>();
     m.cols = s.cols.as<int64_t>();
     m.woff = s.woff.as<int32_t>();
-    // A block per piece (k_merge) while the pieces are short; a lane group per window when a piece has hundreds of
-    // windows (50 kb reads: 850): there the blocks' long serial loops were 3.45 ms of merge + counters per batch, 2.83 with
-    // the windows as the unit; on 8 kb reads (140 windows per piece) the four launches and the scan cost 0.2 ms more than
-    // they save.  ELECTOR_MERGE_PER_PIECE=1 / =0 force one or the other (A/B).
-    static const char *force = std::getenv("ELECTOR_MERGE_PER_PIECE");
-    const bool per_piece = force ? std::atoi(force) != 0 : s.max_windows < 400;
+    // A block per piece (k_merge) for small batches; a lane group per window (k_merge_count, one scan over the batch's
+    // windows, k_merge_pieces, k_merge_copy) for the rest.  Round 4 drew the line at pieces of 400 windows (50 kb reads: the
+    // blocks' long serial loops were 3.45 ms of merge + counters per batch, 2.83 with the windows as the unit; on 8 kb reads
+    // the four launches and the scan cost 0.2 ms more than they saved).  Round 5: with twelve-byte loads, the windows'
+    // destinations worked out per piece and the rows written without gaps the window form is level with k_merge on 8 kb
+    // reads (0.40 against 0.44 ms) and the rows need no packing pass on their way to the host: every batch of 32,768
+    // windows or more takes it.  ELECTOR_MERGE_PER_PIECE=1 / =0 force one or the other (A/B, tests).
+    const char *force = std::getenv("ELECTOR_MERGE_PER_PIECE");
+    const bool per_piece = force ? std::atoi(force) != 0 : n_windows < 32768;
     timed_begin(c, 3, st);
     if (per_piece || n_windows == 0)
       hipLaunchKernelGGL(k_merge, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, m);
@@ -1377,6 +1471,7 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
       MergeWinArgs mw{};
       mw.n_windows = n_windows; mw.n_pieces = n_pieces;
       mw.piece_first = d_piece_first; mw.off = m.off; mw.cols_in = d_cols; mw.ncol = d_ncol; mw.status = d_status;
+      mw.cols_bytes = 3 * total;
       size_t tmp_bytes = 0;
       (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int)(n_windows + 1), st);
       for (int k = 0; k < elector_ctx::kStatsSlots; ++k)
@@ -1384,9 +1479,10 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
           return elector_fail(c, ELECTOR_E_NOMEM, "merge workspace");
       int64_t *cnt_in = s.wcnt.as<int64_t>(), *cnt_ex = cnt_in + (n_windows + 1);
       void *tmp = cnt_ex + (n_windows + 1);
-      mw.cnt = cnt_in; mw.piece_of = s.wpiece.as<int32_t>();
+      mw.cnt = cnt_in; mw.wn = s.wpiece.as<int32_t>();
+      mw.wdst = cnt_in;                  // (the counts are dead once they are scanned)
       mw.rows = m.rows; mw.row_off = m.row_off; mw.cols = m.cols;
-      const unsigned wblocks = (unsigned)((n_windows + kStatsThreads / 16 - 1) / (kStatsThreads / 16));
+      const unsigned wblocks = (unsigned)((n_windows + kMergeWinPerBlock - 1) / kMergeWinPerBlock);
       hipLaunchKernelGGL(k_merge_count, dim3(wblocks), dim3(kStatsThreads), 0, st, mw);
       if (hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt_in, cnt_ex, (int)(n_windows + 1), st) != hipSuccess)
         return elector_fail(c, ELECTOR_E_HIP, "merge scan");
@@ -1404,10 +1500,16 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
       // collected (the host then knows the byte count) ONE copy of exactly that size goes out on the context's copy
       // stream: the copy engine moves it (57 GB/s on this box, measured; a kernel's own stores to host memory reach
       // 20) while the kernels of the following batches run.  elector_msa_rows_wait() waits for it.
-      if (rows_fence(c, s)) return elector_fail(c, ELECTOR_E_HIP, "rows copy");
+      // (The merge with the windows as the unit puts the pieces' rows one behind the other already: a host destination
+      // then gets them from where they lie, no packing pass -- 0.16 ms and 714 MB of traffic per yeast -split batch.)
+      const bool packed = !(per_piece || n_windows == 0) && rows_is_host;
       if (s.outoff.ensure((size_t)(n_pieces + 1) * 8)) return elector_fail(c, ELECTOR_E_NOMEM, "row offsets");
       uint8_t *dst = rows_dev;
-      if (rows_is_host) {
+      if (rows_is_host && packed) {
+        s.rows_src = s.rows.p; s.rows_src_cap = s.rows.cap;
+        if (!s.rows_done) HIPCHK(c, hipEventCreateWithFlags(&s.rows_done, hipEventDisableTiming));
+        if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+      } else if (rows_is_host) {
         for (int k = 0; k < elector_ctx::kStatsSlots; ++k) {
           elector::StatsSlot &o = c->st_slot[k];
           if ((size_t)3 * total + 64 > o.dense.cap) {
@@ -1418,15 +1520,18 @@ static int stats_enqueue(elector_ctx *c, int64_t n_windows, const uint8_t *d_col
           if (o.dense.ensure((size_t)3 * total + 64)) return elector_fail(c, ELECTOR_E_NOMEM, "packed rows");
         }
         dst = s.dense.as<uint8_t>();
+        s.rows_src = s.dense.p; s.rows_src_cap = s.dense.cap;
         if (!s.rows_done) HIPCHK(c, hipEventCreateWithFlags(&s.rows_done, hipEventDisableTiming));
         if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
       }
-      timed_begin(c, 3, st);
-      hipLaunchKernelGGL(k_scan_cols, dim3(1), dim3(1024), 0, st, s.cols.as<int64_t>(), n_pieces, s.outoff.as<int64_t>());
-      CompactArgs ca{s.rows.as<uint8_t>(), s.rowoff.as<int64_t>(), s.cols.as<int64_t>(), s.outoff.as<int64_t>(), dst};
-      hipLaunchKernelGGL(k_compact, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, ca);
-      timed_end(c, st);
-      HIPCHK(c, hipGetLastError());
+      if (!(rows_is_host && packed)) {
+        timed_begin(c, 3, st);
+        hipLaunchKernelGGL(k_scan_cols, dim3(1), dim3(1024), 0, st, s.cols.as<int64_t>(), n_pieces, s.outoff.as<int64_t>());
+        CompactArgs ca{s.rows.as<uint8_t>(), s.rowoff.as<int64_t>(), s.cols.as<int64_t>(), s.outoff.as<int64_t>(), dst};
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)n_pieces), dim3(kStatsThreads), 0, st, ca);
+        timed_end(c, st);
+        HIPCHK(c, hipGetLastError());
+      }
       s.rows_host = rows_is_host ? rows_out : nullptr;
       s.device = c->device;
       if (rows_is_host && !std::getenv("ELECTOR_ROWS_AT_COLLECT") && elector::rows_dma_ready(c->device, &s.rows_sig))
@@ -1473,9 +1578,9 @@ extern "C" int elector_msa_stats_collect(elector_ctx *c, int64_t n_pieces, int64
       // On the DMA engine through the HSA runtime (rows_dma.cpp: the HIP runtime ran four such copies in five as blit kernels
       // on the compute units); through HIP on the copy stream where that is not to be had.  Nothing waits here: the kernels
       // that packed the rows are through (s.done above).
-      s.rows_by_dma = elector::rows_dma_start(c->device, s.rows_host, s.dense.p, (size_t)nbytes, &s.rows_sig) == 0;
+      s.rows_by_dma = elector::rows_dma_start(c->device, s.rows_host, s.rows_src, (size_t)nbytes, &s.rows_sig) == 0;
       if (!s.rows_by_dma) {
-        HIPCHK(c, hipMemcpyAsync(s.rows_host, s.dense.p, (size_t)nbytes, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipMemcpyAsync(s.rows_host, s.rows_src, (size_t)nbytes, hipMemcpyDeviceToHost, c->copy_stream));
         HIPCHK(c, hipEventRecord(s.rows_done, c->copy_stream));
       }
       s.rows_inflight = true;

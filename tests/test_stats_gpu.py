@@ -72,11 +72,17 @@ def test_stats_edge_cases(tmp_path, engine):
     assert np.array_equal(got[proc], exp[proc])
 
 
-@pytest.mark.parametrize("seed,n,L", [(31, 40, 900), (32, 16, 3000)])
-def test_device_merge_and_stats_equal_oracle(tmp_path, engine, seed, n, L):
+@pytest.mark.parametrize("seed,n,L,merge", [(31, 40, 900, None), (32, 16, 3000, None), (33, 40, 900, "0"), (34, 12, 4000, "0"),
+                                            (35, 30, 900, "1")])
+def test_device_merge_and_stats_equal_oracle(tmp_path, engine, monkeypatch, seed, n, L, merge):
     """Windows stay on the GPU from the POA kernels to the counters (elector_msa_stats_device):
-    merged records, column counts and counters must equal the oracle chain's msa.fa and statistics."""
+    merged records, column counts and counters must equal the oracle chain's msa.fa and statistics.
+    merge: ELECTOR_MERGE_PER_PIECE -- "1" a block per piece (what batches of short pieces get), "0" a lane group per
+    window, the rows packed as they are written and sent to the host from where they lie (no packing pass); None: the
+    library's choice."""
     import torch
+    if merge is not None:
+        monkeypatch.setenv("ELECTOR_MERGE_PER_PIECE", merge)
     from elector_amd import split
     reads = msa_gen.make_reads(seed, n, L)
     txt, _, _ = msa_gen.msa_text(reads)
