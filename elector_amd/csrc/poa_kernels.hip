@@ -640,6 +640,55 @@ constexpr int kPartBuckets = 32;        // 0..14: first difference in columns 8k
                                         // one-substitution / one-indel windows k_poa settles without alignment #1 (their wavefronts
                                         // then skip it altogether; 30 also takes the one-letter fillers); 31: corrected equals reference
 
+// first index i < n at which p[i] != q[i] (n: none), by the eight lanes of a window's group together: sixteen bytes of
+// each string per lane and round from wherever they start (the hardware takes unaligned addresses; d_sym is padded by 64
+// bytes), so a window of up to 128 letters is ONE trip to memory -- the byte-wise loop it replaces made a trip per
+// eight letters, each waiting for the one before (0.37 ms per yeast -split batch, most of it waiting)
+__device__ __forceinline__ int first_diff8(const uint8_t *p, const uint8_t *q, int n, int g)
+{
+  int fd = n;
+  for (int base = 0; base < n; base += 128) {
+    const int i0 = base + 16 * g;
+    if (i0 < n) {
+      uint4 x, y;
+      __builtin_memcpy(&x, p + i0, 16);
+      __builtin_memcpy(&y, q + i0, 16);
+      const uint32_t t0 = x.x ^ y.x, t1 = x.y ^ y.y, t2 = x.z ^ y.z, t3 = x.w ^ y.w;
+      int d = 16;
+      if (t3) d = 12 + (__builtin_ctz(t3) >> 3);
+      if (t2) d = 8 + (__builtin_ctz(t2) >> 3);
+      if (t1) d = 4 + (__builtin_ctz(t1) >> 3);
+      if (t0) d = __builtin_ctz(t0) >> 3;
+      if (d < 16 && i0 + d < n) fd = i0 + d;
+    }
+    for (int s = 1; s < 8; s <<= 1) fd = min(fd, __shfl_xor(fd, s, 8));
+    if (fd < n) break;
+  }
+  return fd;
+}
+
+// does letter c occur in p[0 .. n)?  (the same way)
+__device__ __forceinline__ bool has_letter8(const uint8_t *p, int n, uint8_t c, int g)
+{
+  const uint32_t cc = 0x01010101u * c;
+  bool any = false;
+  for (int base = 0; base < n; base += 128) {
+    const int i0 = base + 16 * g;
+    if (i0 < n) {
+      uint4 x;
+      __builtin_memcpy(&x, p + i0, 16);
+      const uint32_t v[4] = {x.x ^ cc, x.y ^ cc, x.z ^ cc, x.w ^ cc};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t z = ~(((v[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v[k]) & 0x80808080u;      // bit 7 of every byte that is zero
+        if (z && i0 + 4 * k + (__builtin_ctz(z) >> 3) < n) any = true;
+      }
+    }
+  }
+  for (int s = 1; s < 8; s <<= 1) any = __shfl_xor(any ? 1 : 0, s, 8) != 0 || any;
+  return any;
+}
+
 __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, uint8_t *triv, uint8_t *pkey, int one_sub_ok)
 {
   const int64_t w = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
@@ -649,9 +698,7 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
   const int Lr = (int)(o1 - o0), Lc = (int)(o2 - o1);
   const uint8_t *xs = a.sym + o0, *ys = a.sym + o1;
   const int nmin = min(Lr, Lc);
-  int fd = nmin;                                            // first index at which the two strings differ
-  for (int i = g; i < nmin && i < fd; i += 8) if (xs[i] != ys[i]) fd = i;
-  for (int d = 1; d < 8; d <<= 1) fd = min(fd, __shfl_xor(fd, d, 8));
+  const int fd = first_diff8(xs, ys, nmin, g);              // first index at which the two strings differ
   const bool eq = a.status[w] == 0 && Lr == Lc && fd == nmin;
   if (g == 0) { triv[w] = eq ? 1 : 0; pkey[w] = (uint8_t)(eq ? kPartBuckets - 1 : min(fd >> 3, 14)); }
   const bool flags_only = (one_sub_ok & 2) != 0;      // k_poa builds these graphs itself, in LDS
@@ -668,9 +715,7 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
     // (-(10 + 5 j) - 5) stand; no strict winner means "y-insertion" (:384-407), the traceback from the last cell
     // leaves the matrix at once, the letter stays unaligned and the fusion appends it behind the reference's
     // chain (lpo.c:602-668).  k_poa writes that graph (trivial_graph); no dynamic program of Lr steps for one row.
-    bool any = false;
-    for (int i = g; i < Lr; i += 8) any = any || xs[i] == ys[0];
-    for (int d = 1; d < 8; d <<= 1) any = __shfl_xor(any ? 1 : 0, d, 8) != 0 || any;
+    const bool any = has_letter8(xs, Lr, ys[0], g);
     if (!any && g == 0) { triv[w] = 5; pkey[w] = (uint8_t)(16 + 14); }
     if (!any) return;
   }
@@ -690,17 +735,12 @@ __global__ void __launch_bounds__(64) k_trivial(BatchArgs a, uint8_t *done_a, ui
       // the graph (poa_pack.hip trivial_graph); the other paths run the dynamic program.
       if (!flags_only || !indel_ok || nmin < 1 || (Lc != Lr - 1 && Lc != Lr + 1)) return;
       const bool del = Lc == Lr - 1;
-      bool rest = true;
-      if (del) { for (int i = fd + g; i < Lc; i += 8) rest = rest && xs[i + 1] == ys[i]; }
-      else { for (int i = fd + g; i < Lr; i += 8) rest = rest && xs[i] == ys[i + 1]; }
-      for (int d = 1; d < 8; d <<= 1) rest = __shfl_xor(rest ? 1 : 0, d, 8) != 0 && rest;
+      const bool rest = del ? first_diff8(xs + fd + 1, ys + fd, Lc - fd, g) == Lc - fd
+                            : first_diff8(xs + fd, ys + fd + 1, Lr - fd, g) == Lr - fd;
       if (rest && g == 0) { triv[w] = del ? 3 : 4; pkey[w] = (uint8_t)(16 + min(fd >> 3, 14)); }
       return;
     }
-    bool rest = true;
-    for (int i = fd + 1 + g; i < Lr; i += 8) rest = rest && xs[i] == ys[i];
-    for (int d = 1; d < 8; d <<= 1) rest = __shfl_xor(rest ? 1 : 0, d, 8) != 0 && rest;
-    if (!rest) return;
+    if (first_diff8(xs + fd + 1, ys + fd + 1, Lr - fd - 1, g) != Lr - fd - 1) return;
     if (flags_only) { if (g == 0) { triv[w] = 2; pkey[w] = (uint8_t)(16 + min(fd >> 3, 14)); } return; }
     const int e = fd, L = Lr;
     const int64_t nb = o0 + w;

@@ -996,14 +996,19 @@ __device__ __forceinline__ void gather_entry(const GatherArgs &a, int64_t p, int
                                     (uint32_t)a.triv[w] | (ok ? 0x100u : 0u), 0u);
   }
   if (!ok) return;
+  // Sixteen bytes per load from wherever the window starts (the hardware takes unaligned addresses), two loads of a lane
+  // asked for before either is stored: a window of up to 256 letters -- nearly all -- is ONE trip to memory for its eight
+  // lanes.  (Round 4: aligned dword pairs and a funnel shift per dword, a trip per 32 letters.)  d_sym is padded by 64
+  // bytes and an entry's stride is a multiple of 16 that holds the window: the sixteen bytes of the last piece stay inside.
   const uint8_t *src = a.sym + o0;
-  const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
-  const uint32_t *src4 = reinterpret_cast<const uint32_t *>(src - mis);
-  const int nd = (int)((total + 3) >> 2);
-  for (int k = g; k < nd; k += 8) {
-    // (d_sym is padded: the dword behind the window's last may be read)
-    const uint32_t lo = src4[k], hi = src4[k + 1];
-    dst[k] = (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * mis));
+  const int nq = (int)((total + 15) >> 4);
+  for (int k0 = 0; k0 < nq; k0 += 16) {
+    const int ka = k0 + g, kb = k0 + 8 + g;
+    uint4 va, vb;
+    if (ka < nq) __builtin_memcpy(&va, src + 16 * (int64_t)ka, 16);
+    if (kb < nq) __builtin_memcpy(&vb, src + 16 * (int64_t)kb, 16);
+    if (ka < nq) __builtin_memcpy(dst + 4 * ka, &va, 16);
+    if (kb < nq) __builtin_memcpy(dst + 4 * kb, &vb, 16);
   }
 }
 
