@@ -609,12 +609,14 @@ enum { kAccN = 18 };
 // ---- shared state of k_stats (file scope, so that the per-piece helpers address it as LDS) ----
 constexpr int kLdsRuns = 64;             // gap runs of a piece whose interval lists stay in LDS
 constexpr int kBitArrays = 6;
-enum { kGx = 0, kGc = 1, kGu = 2, kExc = 3, kExu = 4, kEuc = 5, kMk = kGu /* the mask takes the place of Gu */ };
+enum { kGx = 0, kGc = 1, kGu = 2, kExc = 3, kExu = 4, kEuc = 5, kMk = kGu /* the mask takes the place of Gu */,
+       kUn = 6 /* a split read's realNotMissing: the OR of its pieces' masks, column index by column index */ };
+constexpr int kBitRows = kBitArrays + 1;
 __shared__ int s_red[kStatsThreadsMax / 64];
 __shared__ int s_end[4];                 // end-gap scans: left ref, left unc, right ref, right unc
 __shared__ int s_acc[kAccN];
 __shared__ int s_long[3];               // block_gap_run: end of the run, first and last hit
-__shared__ int s_n[8];                   // 0: run starts filled  1: stretches kept  2: clip left  3: clip right  4: earliest qualifying run end  5: union size  6: run starts filled (pool)
+__shared__ int s_n[8];                   // 0: run starts filled  1: stretches kept  2: clip left  3: clip right  4: earliest qualifying run end  5: union size  6: run starts filled (pool)  7: the union is a bit row in LDS
 __shared__ int32_t *s_lists;
 __shared__ uint8_t *s_uni;
 __shared__ int32_t s_lst[14 * (kLdsRuns + 2)];
@@ -751,21 +753,29 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
   const int W2 = a.bit_words + 2;
   const bool last_read = r == a.n_reads - 1;
 
-  // realNotMissing of a split read (:589-591): one byte per column of its longest piece
+  // realNotMissing of a split read (:589-591): a bit per column of its longest piece in LDS (row kUn) when every piece
+  // has its bit rows there -- the pieces' mask words are ORed in, the last piece counts from the words; a byte per column
+  // in the pool otherwise (round 4 did that for every split read: three byte-wide passes over global memory per piece)
   int ucap = 0;
+  bool uni_lds = false;
   if (nfrag > 1) {
     if (tid == 0) {
       int64_t maxc = 0;
       for (int64_t p = p0; p < p1; ++p) maxc = a.cols[p] > maxc ? a.cols[p] : maxc;
       s_n[5] = (int)maxc;
-      s_uni = reinterpret_cast<uint8_t *>(pool_take(a, (unsigned long long)(maxc + 3) / 4 + 1));
+      s_n[7] = (maxc + 63) / 64 <= a.bit_words ? 1 : 0;
+      s_uni = s_n[7] ? nullptr : reinterpret_cast<uint8_t *>(pool_take(a, (unsigned long long)(maxc + 3) / 4 + 1));
     }
     __syncthreads();
     ucap = s_n[5];
-    if (!s_uni) return;
-    for (int i = tid; i < ucap; i += (int)blockDim.x) s_uni[i] = 0;
+    uni_lds = s_n[7] != 0;
+    if (uni_lds) { for (int j = tid; j < (ucap + 63) / 64; j += (int)blockDim.x) bww(kUn, W2, j, 0ull); }
+    else {
+      if (!s_uni) return;
+      for (int i = tid; i < ucap; i += (int)blockDim.x) s_uni[i] = 0;
+    }
   }
-  uint8_t *uni = nfrag > 1 ? s_uni : nullptr;
+  uint8_t *uni = nfrag > 1 && !uni_lds ? s_uni : nullptr;
 
   int64_t missing = 0;
   for (int64_t p = p0; p < p1; ++p) {
@@ -939,6 +949,7 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
         const unsigned long long gx = bwr(kGx, W2, j), gc = bwr(kGc, W2, j), gu = bwr(kGu, W2, j),
                                  exc = bwr(kExc, W2, j), exu = bwr(kExu, W2, j), euc = bwr(kEuc, W2, j);
         bww(kMk, W2, j, M);
+        if (uni_lds) bww(kUn, W2, j, bwr(kUn, W2, j) | M);                        // realNotMissing (:589-591)
         acc[15] += __popcll(gx); acc[16] += __popcll(gc); acc[17] += __popcll(gu);
         const unsigned long long dc = M & ~exc, du = M & ~exu, eq = M & exu;
         acc[12] += __popcll(dc & gx); acc[14] += __popcll(dc & ~gx & ~gc); acc[13] += __popcll(dc & ~gx & gc);
@@ -962,11 +973,11 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
       // the mask as bytes: only the batch's LAST read's is ever taken out (call site #2's report), a split read's
       // pieces also fold theirs into the read's union -- for every other read the words in LDS were all of it
       // (a byte per column of every read was 119 MB of byte-wide stores per yeast -split batch)
-      if (last_read || nfrag > 1)
+      if (last_read || uni)
         for (int i = tid; i < n; i += (int)blockDim.x) {
           const uint8_t mk = bbit(kMk, W2, i) ? 1 : 0;
           if (last_read) mask[i] = mk;
-          if (nfrag > 1) uni[i] |= mk;                                        // realNotMissing (:589-591)
+          if (uni) uni[i] |= mk;                                              // realNotMissing (:589-591)
         }
     } else {
 
@@ -1108,7 +1119,7 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
         if (lane == 0 && v) atomicAdd(&s_acc[k], v);
       }
       __syncthreads();
-      if (nfrag > 1)
+      if (uni)
         for (int i = tid; i < n; i += (int)blockDim.x) uni[i] |= mask[i];      // realNotMissing (:589-591)
     }
     int64_t missing_last = -1;
@@ -1116,7 +1127,10 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
       if (p == p1 - 1) {                                                    // last piece (:595-599)
         __syncthreads();
         int miss = 0;
-        for (int i = tid; i < n; i += (int)blockDim.x) miss += (!uni[i] && ref[i] != '.');
+        if (uni_lds)                                                        // (every piece was on the fast path: the rows are the last piece's)
+          for (int j = tid; j < nw; j += (int)blockDim.x) miss += __popcll(~bwr(kUn, W2, j) & ~bwr(kGx, W2, j) & range_word(j, 0, n - 1));
+        else
+          for (int i = tid; i < n; i += (int)blockDim.x) miss += (!uni[i] && ref[i] != '.');
         missing_last = block_sum(miss, s_red);
       }
     }
@@ -1155,7 +1169,7 @@ int pool_prepare(elector_ctx *c, unsigned long long ints, PoolView *v)
 }
 
 // k_stats with bit rows for pieces of up to `max_cols` columns (as far as LDS goes)
-constexpr int kBitWordsMax = 2560;       // 163,840 columns: 6 rows = 123 KB, one workgroup per CU
+constexpr int kBitWordsMax = 2560;       // 163,840 columns: 7 rows = 143 KB, one workgroup per CU
 int launch_stats(elector_ctx *c, StatsArgs a, int64_t max_cols, hipStream_t st)
 {
   const char *force = std::getenv("ELECTOR_STATS_BITWORDS");            // tests: 0 = every piece on the HBM path
@@ -1163,11 +1177,11 @@ int launch_stats(elector_ctx *c, StatsArgs a, int64_t max_cols, hipStream_t st)
   words = std::min<int64_t>(std::max<int64_t>(words, 64), kBitWordsMax);
   if (force) words = std::min<int64_t>(std::max(0, std::atoi(force)), kBitWordsMax);
   a.bit_words = (int)words;
-  const size_t lds = (size_t)kBitArrays * (size_t)(words + 2) * 8;
+  const size_t lds = (size_t)kBitRows * (size_t)(words + 2) * 8;
   static bool big_ok = false;
   if (lds > 48 * 1024 && !big_ok) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)((size_t)kBitArrays * (kBitWordsMax + 2) * 8));
+                                             (int)((size_t)kBitRows * (kBitWordsMax + 2) * 8));
     if (e != hipSuccess) return elector_fail(c, ELECTOR_E_HIP, "hipFuncSetAttribute(k_stats)", e);
     big_ok = true;
   }
