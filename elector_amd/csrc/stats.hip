@@ -829,10 +829,10 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
       if (lane == 0) { atomicAdd(&s_acc[7], gcx); atomicAdd(&s_acc[8], gcc); }
 
       // ---- gapsAndExtensions (:472-498) ----
-      if (tid == 0) s_end[0] = left_gaps_bits(kGx, W2, n);
-      if (tid == 64) s_end[1] = left_gaps_bits(kGu, W2, n);
-      if (tid == 128) s_end[2] = right_gaps_bits(kGx, W2, n);
-      if (tid == 192) s_end[3] = right_gaps_bits(kGu, W2, n);
+      // (the four end scans on the first lanes of the block's wavefronts, in turn where it has fewer than four)
+      for (int k = wave; k < 4; k += (int)blockDim.x >> 6)
+        if (lane == 0) s_end[k] = k == 0 ? left_gaps_bits(kGx, W2, n) : k == 1 ? left_gaps_bits(kGu, W2, n)
+                                : k == 2 ? right_gaps_bits(kGx, W2, n) : right_gaps_bits(kGu, W2, n);
       __syncthreads();
       gl = min(s_end[0], s_end[1]); gr = min(s_end[2], s_end[3]);
       if (gl >= kThresh && gl >= kThresh2) ext_left = gl - count_range(kGc, W2, 0, gl - 1);
@@ -982,10 +982,8 @@ __global__ void __launch_bounds__(kStatsThreadsMax) k_stats(StatsArgs a)
     } else {
 
       // ---- gapsAndExtensions (:472-498): the four end scans on four lanes ----
-      if (tid == 0) s_end[0] = left_gaps(ref, n);
-      if (tid == 64) s_end[1] = left_gaps(unc, n);
-      if (tid == 128) s_end[2] = right_gaps(ref, n);
-      if (tid == 192) s_end[3] = right_gaps(unc, n);
+      for (int k = wave; k < 4; k += (int)blockDim.x >> 6)
+        if (lane == 0) s_end[k] = k == 0 ? left_gaps(ref, n) : k == 1 ? left_gaps(unc, n) : k == 2 ? right_gaps(ref, n) : right_gaps(unc, n);
       if (tid < kAccN) s_acc[tid] = 0;
       if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = n - 1; s_n[4] = 0x7fffffff; s_lists = nullptr; }
       __syncthreads();
@@ -1190,7 +1188,7 @@ int launch_stats(elector_ctx *c, StatsArgs a, int64_t max_cols, hipStream_t st)
   // ELECTOR_STATS_THREADS=256|512|1024 forces one (A/B)
   static const int forced = std::getenv("ELECTOR_STATS_THREADS") ? std::atoi(std::getenv("ELECTOR_STATS_THREADS")) : 0;
   int threads = max_cols >= 64000 ? kStatsThreadsMax : kStatsThreads;
-  if (forced == 256 || forced == 512 || forced == 1024) threads = forced;
+  if (forced == 64 || forced == 128 || forced == 256 || forced == 512 || forced == 1024) threads = forced;
   hipLaunchKernelGGL(k_stats, dim3((unsigned)a.n_reads), dim3((unsigned)threads), lds, st, a);
   return 0;
 }
