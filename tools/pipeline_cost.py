@@ -9,7 +9,7 @@ import numpy as np, torch
 import bench
 from elector_amd.poa import PoaEngine
 prof = sys.argv[1] if len(sys.argv) > 1 else "yeast50x_nanosim_consent_split"
-steps = 40
+steps = int(os.environ.get("STEPS", "40"))
 bs = [bench.prepare_batch((prof, 10001, 1000 + k, bench.cpu_share(), None)) for k in range(3)]
 dev = torch.device("cuda", 0)
 for b in bs:
