@@ -443,11 +443,64 @@ def bundles_mode(args):
     # the uncorrected symbols, the column counts in; up to three consensus rows and 32 bytes of bundle bookkeeping out
     alg = int(14 * po.sum() + b.lu.sum() + 4 * b.n + 3 * ncol.sum() + 32 * b.n)
     per_launch_ms = ms / max(1, launches)
+    eng.timing_enable(False)
+
+    # What the search costs INSIDE the pipeline the headline runs: E contexts take the batch in turn (alignment, merge and
+    # counters as bench.py's step, rows left in HBM), first without the search, then with it queued behind every
+    # alignment; the difference of the two step times is its price there (the serial figure above hides nothing: one
+    # context, the search alone on the chip).
+    n_eng = max(1, int(os.environ.get("ELECTOR_BENCH_ENGINES", "4")))
+    pool = [eng] + [PoaEngine(0) for _ in range(n_eng - 1)]
+    outs = [(d_cols, d_ncol, d_status)] + [(torch.empty_like(d_cols), torch.empty_like(d_ncol), torch.empty_like(d_status))
+                                           for _ in range(n_eng - 1)]
+
+    def pipelined(keep, with_search):
+        for g in pool:
+            g.keep_graph(keep)
+        pending = []
+
+        def one(i):
+            e = i % n_eng
+            if len(pending) >= n_eng:
+                pe, np_ = pending.pop(0)
+                pool[pe].msa_stats_collect(np_)
+            dc, dn, ds = outs[e]
+            pool[e].align_device_offsets(d_bases, d_off, b.n, b.total, dc, dn, ds)
+            if with_search:
+                pool[e].bundles_enqueue(b.n)
+            pending.append((e, pool[e].msa_stats_enqueue(b.n, dc, dn, ds, b.piece_first, b.read_first)))
+
+        def drain():
+            while pending:
+                pe, np_ = pending.pop(0)
+                pool[pe].msa_stats_collect(np_)
+            for g in pool:
+                g.sync()
+        for i in range(2 * n_eng + 1):
+            one(i)
+        drain()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(args.steps):
+            one(i)
+        drain()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / args.steps * 1e3
+    pipe_plain = pipelined(False, False)        # the headline's alignment (k_poa; it leaves no graph behind)
+    pipe_without = pipelined(True, False)       # the alignment kernels that keep the graph in HBM, no search
+    pipe_with = pipelined(True, True)
+    for g in pool[1:]:
+        g.close()
     out = {"metric": "heaviest-bundle consensus (a12) ms per step", "value": round(ms / args.steps, 3), "unit": "ms", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "higher_is_better": False, "dtype": "int32", "data": "synthetic",
            "config": {"workload": "%s: %d reads per step" % (WORKLOADS[profile], args.reads), "profile": profile, "windows": b.n},
            "windows_per_s": round(b.n / (per_launch_ms * 1e-3), 1) if per_launch_ms > 0 else None,
            "step_ms_with_alignment": round(dt / args.steps * 1e3, 3),
+           "pipelined": {"contexts": n_eng, "step_ms_without_graph": round(pipe_plain, 3), "step_ms_without_search": round(pipe_without, 3), "step_ms_with_search": round(pipe_with, 3),
+                         "search_ms_inside_pipeline": round(pipe_with - pipe_without, 3),
+                         "note": "alignment + merge + counters per step, rows left in HBM, the contexts taking the batch in turn; "
+                                 "without_graph = the headline's kernels (k_poa keeps no graph), without_search = the graph-keeping "
+                                 "alignment kernels alone, with_search = the search queued behind every alignment"},
            "roofline": {"bound": "hbm", "kernel": "k_bundle_inputs + k_bundle_lds<C, LDS | HBM> + k_bundle_hbm (side by side: the time is the search's, plan to last row)", "achieved": round(alg / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 else 0.0,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if per_launch_ms > 0 else 0.0,

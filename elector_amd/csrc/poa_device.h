@@ -146,6 +146,8 @@ struct PackArgs {
   const int32_t *nlist_dev; // when set: the list length lives on the device (a far list), nlist is its capacity
   int debug;
   unsigned long long *stamps;
+  int keep_graph;           // a12: k_poa also leaves the graph after fusion #1 and the x -> y map of alignment #2 in HBM
+                            // (BatchArgs::xinfo .y / ring1 / map16, as the two-kernel path does: what k_bundle_inputs reads)
 };
 
 // arguments of k_gather (poa_pack.hip): k_poa's inputs laid out in list order

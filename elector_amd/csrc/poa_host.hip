@@ -507,8 +507,9 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
                            c->kp.mismatch <= c->kp.match && c->kp.open_x > 0 && c->kp.ext_x > 0 && c->kp.open_y > 0 &&
                            c->kp.ext_y > 0;
   // the one-kernel, two-windows-per-lane-group path (poa_pack.hip): symmetric gap penalties and a match score of 0
-  // (the shipped parameters), and not when the graph has to stay in HBM for the bundle search
-  const bool use_pack = use_trivial && !std::getenv("ELECTOR_NO_PACK") && !c->keep_graph && c->kp.open_x == c->kp.open_y &&
+  // (the shipped parameters).  With elector_ctx_keep_graph it leaves the graph the bundle search reads in HBM as the
+  // two-kernel path does (PackArgs::keep_graph; round 4 sent such batches through the two-kernel path: 2.4-3 x the step)
+  const bool use_pack = use_trivial && !std::getenv("ELECTOR_NO_PACK") && c->kp.open_x == c->kp.open_y &&
                         c->kp.ext_x == c->kp.ext_y && c->kp.match == 0;
 
   const bool host_prof = std::getenv("ELECTOR_DEBUG_HOST") != nullptr;
@@ -1135,6 +1136,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
         pa.far_cap = use_far && hg ? (int)hg->far_cap : 0;
         pa.nlist_dev = nullptr;
         pa.debug = fdebug;
+        pa.keep_graph = c->keep_graph ? 1 : 0;
         pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)b) + 16;
         timed_begin(c, 4, sx);
         if (launch_poa(pa, bG, bR, sx)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");
@@ -1191,6 +1193,7 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
           pa.hand_count = d_hand_cnt;
           pa.far = nullptr; pa.far_count = nullptr; pa.far_cap = 0;
           pa.debug = fdebug & ~(32 | 64 | 128 | 256);
+          pa.keep_graph = c->keep_graph ? 1 : 0;
           pa.stamps = reinterpret_cast<unsigned long long *>(c->d_rowinit.as<uint8_t>() + 1024 + 256 * (size_t)hb) + 16;
           timed_begin(c, 6, sg);
           if (launch_poa_far(pa, hg->G, sg)) return fail(c, ELECTOR_E_HIP, "k_poa attribute");

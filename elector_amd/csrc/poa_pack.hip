@@ -1817,6 +1817,23 @@ __global__ void __launch_bounds__(64, ELECTOR_POA_WAVES) k_poa(PackArgs a)
     uint8_t *cols_st = a.b.cols + 3 * W[h].o0;
     uint16_t *col_y = reinterpret_cast<uint16_t *>(ordb[h]);
     for (int d = 1; d < G; d <<= 1) badb[h] = badb[h] || grp_xor<G>(badb[h] ? 1 : 0, d) != 0;
+    if (a.keep_graph && W[h].valid) {
+      // a12 (heaviest_bundle.c works on the graph after both fusions): what the search rebuilds that graph from, in the
+      // window's node space as k_fused_a / k_fused_b leave it -- letter and flags of node i of the graph after fusion #1
+      // (xinfo[i + 1].y; the predecessor word .x is not written: only the alignment kernels of the two-kernel path read
+      // it, and they do not run on this window), its ring id (the ring's first node: a ring of two sequences' graph holds
+      // two nodes at most, so a node that opens no column follows the one that did) and its x -> y entry
+      const int64_t nb = W[h].o0 + (int64_t)W[h].w;
+      int2 *gx = a.b.xinfo + nb + 1;
+      uint16_t *gr = a.b.ring1 + nb;
+      uint32_t *gm = a.b.map16 + nb;
+      for (int i = g; i < W[h].n1; i += G) {
+        const uint32_t rec = xinfo[h][i + 1], m = x2yb[h][i];
+        gx[i].y = (int)(((rec >> 8) & 0x1Fu) | (((rec >> 16) & 0xFu) << 8));
+        gr[i] = (uint16_t)((rec & kN_NewCol) ? i : i - 1);
+        gm[i] = m == kNone16 ? kNone32 : m;
+      }
+    }
     const int ncol = columns_2<G>(W[h], lane, g, xinfo[h], x2yb[h], us[h], chr, cols_st, col_y, badb[h]);
     __builtin_amdgcn_wave_barrier();
     if (W[h].valid) {

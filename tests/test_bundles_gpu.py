@@ -87,3 +87,39 @@ def test_bundles_lds_and_global_forms(engine, monkeypatch, pct):
     check(engine, synth.adversarial_triples(42, 1200))
     t = synth.window_triples(43, 600, 10, 200, err_unc=0.3, err_cor=0.25)
     check(engine, t, frac=0.5)
+
+
+def test_bundles_on_k_poa_graphs(engine):
+    """Round 5: with elector_ctx_keep_graph the batch stays on k_poa, which writes what the search reads (letters and flags
+    of the graph after fusion #1, ring ids, the x -> y map) from its LDS records.  Every way k_poa comes by a graph:
+    shortcut graphs (corrected = reference, one substitution, one indel, the one-letter filler), the dynamic program,
+    the far-edge instance, and the windows it hands back to the two-kernel path."""
+    import test_poa_gpu as tp
+    rng = np.random.default_rng(51)
+    t = tp.one_indel_triples(52)[:1500] + tp.far_edge_triples(53, 900) + synth.window_triples(54, 1500, 5, 300)
+    for L in (9, 40, 130, 260):                       # corrected = reference, one substitution, a filler letter
+        for _ in range(40):
+            ref = synth.random_seq(rng, L)
+            unc = synth.mutate(rng, ref, 0.12) or b"A"
+            p = int(rng.integers(0, L))
+            sub = ref[:p] + bytes([b"ACGT"[(b"ACGT".index(ref[p:p + 1]) + 1) % 4]]) + ref[p + 1:]
+            t += [(ref, ref, unc), (ref, sub, unc), (ref, b"N", unc)]
+    check(engine, t)
+
+
+def test_bundles_k_poa_equals_two_kernel_path(engine, monkeypatch):
+    """the same batch with k_poa switched off (ELECTOR_NO_PACK: the graph from k_fused_a / k_fused_b, round 4's only way)"""
+    import test_poa_gpu as tp
+    t = synth.window_triples(55, 2000, 7, 200) + synth.adversarial_triples(56, 600) + tp.far_edge_triples(57, 300)
+    rows, got = engine.align_with_bundles(t)
+    monkeypatch.setenv("ELECTOR_NO_PACK", "1")
+    rows2, got2 = engine.align_with_bundles(t)
+    assert rows == rows2 and got == got2
+    check(engine, t)
+
+
+@pytest.mark.parametrize("cls", [0, 4, 7, 11, 16])
+def test_bundles_geometry_classes(engine, cls, monkeypatch):
+    """the graph output of several k_poa instances (lanes per window x rows per lane) on windows of every size"""
+    monkeypatch.setenv("ELECTOR_FORCE_CLASS", str(cls))
+    check(engine, synth.window_triples(300 + cls, 400, 5, 420) + synth.adversarial_triples(320 + cls, 200))
