@@ -95,7 +95,11 @@ struct BundleArgs {
 constexpr int kBundleClasses = 6;
 constexpr int kBundleCap[4] = {52, 69, 104, 208};
 constexpr int kBundleHbmPacked = 4, kBundleHbmWide = 5;
-constexpr int kBundleGlobalPct[4] = {50, 50, 50, 50};   // share of a class's blocks whose records live in HBM instead of LDS
+// share of a class's blocks whose records live in HBM instead of LDS.  Alone on the chip 50 % is the fastest split (E. coli batch
+// 4.8 ms; 4.9 with 70, 5.3 with 100, 5.7 with 30); beside the alignment kernels of a four-context pipeline -- whose window slots
+// want the LDS too -- the HBM form is the better neighbour: the pipelined step with the search 9.9 / 9.45 / 9.5 ms with 50 / 70 /
+// 100 (yeast -split: 15.9 / 15.1 / 14.9; profiles/r05_bundles_share.txt).  70: what a caller that streams batches gets.
+constexpr int kBundleGlobalPct[4] = {70, 70, 70, 70};
 constexpr uint32_t kPxNone = 0xFFu;
 constexpr int kLdsSt = 65;                 // dwords between a lane's consecutive entries: a row of 64 lanes + 1 (staging
                                            // writes a window's entries from 64 lanes: stride 65 spreads them over the banks)
