@@ -1,6 +1,8 @@
 """GPU-box helper : parity soak of the final build through the C ABI against the oracle -- the random window mixes of
 rounds 2-3 plus far-edge windows (tests/test_poa_gpu.py: far_edge_triples) and noisier corrected sequences (4-6 % error:
-several far edges, deep graphs), rows and both scores bit-exact.  Usage: python tools/parity_soak.py [seeds...]"""
+several far edges, deep graphs), rows and both scores bit-exact.  Usage: python tools/parity_soak.py [--bundles] [seeds...]
+--bundles: the batches run with elector_ctx_keep_graph and the heaviest-bundle search (a12) on every window is compared too
+(consensus rows, counts, bundle ids against the oracle's heaviest_bundle restatement) -- k_poa's graph output."""
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +14,8 @@ src = open(os.path.join(ROOT, "tests", "test_poa_gpu.py")).read()
 exec(src[src.index("def far_edge_triples"):src.index("def test_far_edge_windows(engine)")])
 
 eng = poa.PoaEngine(0)
-seeds = [int(x) for x in sys.argv[1:]] or [201, 202]
+BUNDLES = "--bundles" in sys.argv[1:]
+seeds = [int(x) for x in sys.argv[1:] if x != "--bundles"] or [201, 202]
 total = bad = 0
 def run(tag, triples):
     global total, bad
@@ -20,8 +23,14 @@ def run(tag, triples):
     t0 = time.time()
     exp_rows, exp_ncol, exp_scores, _ = oracle_lib.batch(np.frombuffer(bases, dtype=np.uint8), off)
     t1 = time.time()
-    got, scores = eng.align(triples, want_scores=True)
-    nb = sum(1 for w in range(len(triples)) if got[w] != exp_rows[w]) + int((scores != exp_scores).any(axis=1).sum())
+    if BUNDLES:
+        exp_b = oracle_lib.batch_bundles(np.frombuffer(bases, dtype=np.uint8), off, 0.9)
+        t1 = time.time()
+        got, got_b = eng.align_with_bundles(triples, 0.9)
+        nb = sum(1 for w in range(len(triples)) if got[w] != exp_rows[w] or got_b[w] != exp_b[w])
+    else:
+        got, scores = eng.align(triples, want_scores=True)
+        nb = sum(1 for w in range(len(triples)) if got[w] != exp_rows[w]) + int((scores != exp_scores).any(axis=1).sum())
     total += len(triples); bad += nb
     print(tag, "windows", len(triples), "differing", nb, "oracle %.1fs gpu %.1fs" % (t1 - t0, time.time() - t1), flush=True)
 for seed in seeds:
