@@ -177,11 +177,15 @@ __global__ void __launch_bounds__(64) k_bundle_plan(BundleArgs a, int64_t *blk, 
 // (aligned to it, same letter: lpo.c:620-640) -- n1 + Lu less that count is the number of nodes the search will see,
 // and the block's largest decides its class (cls_list).
 // (a.blocks set: the launch of the wide blocks, whose list k_bundle_plan made; otherwise every block but those)
+// WIDE: the launch of the wide blocks (three arrays as they are); the other launch packs a dword per node and needs the
+// tiles of the x -> y map and of the ring ids for nothing: 21 KB of LDS per workgroup instead of 47 (seven workgroups
+// per CU instead of three, and a lighter neighbour for the alignment kernels' window slots)
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_bundle_inputs(BundleArgs a, int all_hbm)
 {
   const int64_t blk = bundle_block(a);
-  __shared__ uint32_t t_xy[64][65], t_map[64][65];           // (packed blocks: t_xy holds the packed dwords)
-  __shared__ uint16_t t_ring[64][66];
+  __shared__ uint32_t t_xy[64][65], t_map[WIDE ? 64 : 1][65];           // (packed blocks: t_xy holds the packed dwords)
+  __shared__ uint16_t t_ring[WIDE ? 64 : 1][66];
   __shared__ uint8_t t_ys[64][68];
   __shared__ int s_n1[64], s_lu[64], s_fused[64], s_max, s_wide;
   __shared__ int64_t s_nb[64], s_o2[64];
@@ -202,8 +206,8 @@ __global__ void __launch_bounds__(256) k_bundle_inputs(BundleArgs a, int all_hbm
   }
   __syncthreads();
   const int nmax = s_max;
-  const bool wide = s_wide != 0;
-  if (wide != (a.blocks != nullptr)) return;
+  if ((s_wide != 0) != WIDE) return;
+  constexpr bool wide = WIDE;
   const int my_n1 = s_n1[lane], my_lu = s_lu[lane];
   const int64_t base = a.blk_base[blk];
   int fused = 0;                                              // of window `lane`, this wavefront's share of the indices
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(256) k_bundle_inputs(BundleArgs a, int all_hbm
         const int64_t at = s_nb[wl] + k;
         const uint32_t xy = (uint32_t)a.xinfo[at + 1].y, m = a.map16[at];
         const uint16_t r = a.ring1[at];
-        if (wide) { t_xy[wl][lane] = xy; t_map[wl][lane] = m; t_ring[wl][lane] = r; }
+        if constexpr (wide) { t_xy[wl][lane] = xy; t_map[wl][lane] = m; t_ring[wl][lane] = r; }
         else {
           const bool newring = k == 0 || a.ring1[at - 1] != r;
           t_xy[wl][lane] = (xy & 0xFFFFu) | ((m == kNone32 ? kPxNone : (m & 0xFFu)) << 16) | (newring ? 1u << 24 : 0u);
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(256) k_bundle_inputs(BundleArgs a, int all_hbm
       if (kx < my_n1) {
         const uint32_t v = t_xy[lane][kk];
         uint32_t m;
-        if (wide) { m = t_map[lane][kk]; a.in_xy[at] = v; a.in_map[at] = m; a.in_ring[at] = t_ring[lane][kk]; }
+        if constexpr (wide) { m = t_map[lane][kk]; a.in_xy[at] = v; a.in_map[at] = m; a.in_ring[at] = t_ring[lane][kk]; }
         else { m = (v >> 16) & 0xFFu; if (m == kPxNone) m = kNone32; a.in_px[at] = v; }
         // an uncorrected letter aligned to this node and equal to its letter will be fused into it: mostly a letter of
         // this tile (the alignment runs near the diagonal), else one load
@@ -848,11 +852,11 @@ static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
   if (cnt[kBundleHbmWide] > 0) {
     hipStream_t sx = chain(0);
     a.blocks = a.cls_list + (int64_t)kBundleHbmWide * nblocks;
-    hipLaunchKernelGGL(k_bundle_inputs, dim3((unsigned)cnt[kBundleHbmWide]), dim3(256), 0, sx, a, all_hbm ? 1 : 0);
+    hipLaunchKernelGGL(k_bundle_inputs<true>, dim3((unsigned)cnt[kBundleHbmWide]), dim3(256), 0, sx, a, all_hbm ? 1 : 0);
     hipLaunchKernelGGL(k_bundle_hbm<false>, dim3((unsigned)cnt[kBundleHbmWide]), dim3(64), 0, sx, a);
     a.blocks = nullptr;
   }
-  hipLaunchKernelGGL(k_bundle_inputs, dim3((unsigned)nblocks), dim3(256), 0, st, a, all_hbm ? 1 : 0);
+  hipLaunchKernelGGL(k_bundle_inputs<false>, dim3((unsigned)nblocks), dim3(256), 0, st, a, all_hbm ? 1 : 0);
   HIPCHK(c, hipMemcpyAsync(cnt, a.cls_count, 4 * kBundleHbmWide, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   HIPCHK(c, hipEventRecord(c->fork, st));                      // (the chains below start behind the inputs)
