@@ -98,8 +98,10 @@ constexpr int kBundleHbmPacked = 4, kBundleHbmWide = 5;
 // share of a class's blocks whose records live in HBM instead of LDS.  Alone on the chip 50 % is the fastest split (E. coli batch
 // 4.8 ms; 4.9 with 70, 5.3 with 100, 5.7 with 30); beside the alignment kernels of a four-context pipeline -- whose window slots
 // want the LDS too -- the HBM form is the better neighbour: the pipelined step with the search 9.9 / 9.45 / 9.5 ms with 50 / 70 /
-// 100 (yeast -split: 15.9 / 15.1 / 14.9; profiles/r05_bundles_share.txt).  70: what a caller that streams batches gets.
-constexpr int kBundleGlobalPct[4] = {70, 70, 70, 70};
+// 100 (yeast -split: 15.9 / 15.1 / 14.9; profiles/r05_bundles_share.txt).  Per class: the workgroups of the two large classes
+// hold 37-73 KB each (two or one per CU) and are the worst neighbours, the small ones' 19-25 KB are not -- 30 / 50 / 100 / 100
+// against 70 throughout: 8.8 against 8.9-9.0 ms (E. coli), 14.2 against 14.4 (yeast -split), and no slower alone (4.7 / 7.2).
+constexpr int kBundleGlobalPct[4] = {30, 50, 100, 100};
 constexpr uint32_t kPxNone = 0xFFu;
 constexpr int kLdsSt = 65;                 // dwords between a lane's consecutive entries: a row of 64 lanes + 1 (staging
                                            // writes a window's entries from 64 lanes: stride 65 spreads them over the banks)
