@@ -164,8 +164,11 @@ int elector_ctx_last_po_sizes(elector_ctx *ctx, int64_t n, int32_t *po_nodes);
  * :144-172 generate_lpo_bundles, lpo.c:762-781 add_path_sequence).
  *
  * elector_ctx_keep_graph(ctx, 1) makes the following POA batches keep what the
- * search needs in device memory (the x -> y map of the second alignment; the
- * fused kernels otherwise drop it).  elector_poa_bundles then runs the bundle
+ * search needs in device memory (letters and flags of the graph after the first
+ * fusion, its ring ids, the x -> y map of the second alignment: 14 bytes per node;
+ * the kernels otherwise keep them on chip).  The batches run through the same
+ * kernels as without it (round 5; earlier rounds took them off the one-kernel
+ * path).  elector_poa_bundles then runs the bundle
  * search on every window of the LAST batch of this context (n must equal that
  * batch's n; its ncol / status device arrays must still be alive) exactly as
  * generate_lpo_bundles(lpo, minimum_fraction) would on the window's final graph:
@@ -181,7 +184,9 @@ int elector_ctx_last_po_sizes(elector_ctx *ctx, int64_t n, int32_t *po_nodes);
  * The reference's default minimum_fraction is 0.9 (main.c:30). */
 int elector_ctx_keep_graph(elector_ctx *ctx, int on);
 /* the search alone, queued on the context's stream, its results left in the context's device buffers (what
- * elector_poa_bundles then fetches): the entry bench.py --bundles times; timing kind 5 (elector_ctx_timing_read) */
+ * elector_poa_bundles then fetches): the entry bench.py --bundles times; timing kind 5 (elector_ctx_timing_read).
+ * The call waits twice for the context's stream (the scratch size, the class counts): a caller that feeds several
+ * contexts from one thread calls it from a helper thread, or when the context comes round again. */
 int elector_poa_bundles_enqueue(elector_ctx *ctx, int64_t n, float minimum_fraction);
 int elector_poa_bundles(elector_ctx *ctx, int64_t n, float minimum_fraction,
                         uint8_t *cons_rows, int64_t cons_cap, int64_t *cons_off,
