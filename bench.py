@@ -457,12 +457,15 @@ def bundles_mode(args):
     from concurrent.futures import ThreadPoolExecutor
     helpers = ThreadPoolExecutor(max_workers=n_eng, initializer=torch.cuda.set_device, initargs=(0,))
 
-    def pipelined(keep, with_search, threaded=False, deferred=False):
-        """threaded: the search is queued from a helper thread per context -- elector_poa_bundles_enqueue waits twice for
-        its context's stream (the scratch size, the class counts), and on the thread that feeds every context those waits
-        hold up the other contexts' next batches"""
+    def pipelined(keep, with_search, threaded=False, deferred=False, now=False):
+        """The search waits twice for its context's stream (the scratch size, the class counts); queued inside
+        elector_poa_bundles_enqueue (`now`: option "bundles_now", the library's behaviour until round 5) those waits hold up
+        the thread that feeds every context.  By default the library only notes the search and queues it at the context's
+        next call that waits for it anyway (here elector_msa_stats_collect).  threaded / deferred: what a caller can do
+        about it with "bundles_now" -- a helper thread per context, or the call put in front of the collect."""
         for g in pool:
             g.keep_graph(keep)
+            g.option("bundles_now", 1 if (now or threaded or deferred) else 0)
         pending = []
 
         def take():
@@ -507,9 +510,12 @@ def bundles_mode(args):
     pipe_plain = pipelined(False, False)        # the headline's alignment (k_poa; it leaves no graph behind)
     pipe_without = pipelined(True, False)       # the alignment kernels that keep the graph in HBM, no search
     pipe_with = pipelined(True, True)
+    pipe_with_now = pipelined(True, True, now=True)
     pipe_with_thr = pipelined(True, True, threaded=True)
     pipe_with_def = pipelined(True, True, deferred=True)
     helpers.shutdown()
+    for g in pool:
+        g.option("bundles_now", 0)
     for g in pool[1:]:
         g.close()
     out = {"metric": "heaviest-bundle consensus (a12) ms per step", "value": round(ms / args.steps, 3), "unit": "ms", "n_gpus": 1,
@@ -517,12 +523,14 @@ def bundles_mode(args):
            "config": {"workload": "%s: %d reads per step" % (WORKLOADS[profile], args.reads), "profile": profile, "windows": b.n},
            "windows_per_s": round(b.n / (per_launch_ms * 1e-3), 1) if per_launch_ms > 0 else None,
            "step_ms_with_alignment": round(dt / args.steps * 1e3, 3),
-           "pipelined": {"contexts": n_eng, "step_ms_without_graph": round(pipe_plain, 3), "step_ms_without_search": round(pipe_without, 3), "step_ms_with_search": round(pipe_with, 3), "step_ms_with_search_from_helper_threads": round(pipe_with_thr, 3),
+           "pipelined": {"contexts": n_eng, "step_ms_without_graph": round(pipe_plain, 3), "step_ms_without_search": round(pipe_without, 3), "step_ms_with_search": round(pipe_with, 3), "step_ms_with_search_queued_inside_the_call": round(pipe_with_now, 3),
+                         "step_ms_with_search_from_helper_threads": round(pipe_with_thr, 3),
                          "step_ms_with_search_queued_a_turn_later": round(pipe_with_def, 3),
-                         "search_ms_inside_pipeline": round(min(pipe_with, pipe_with_thr, pipe_with_def) - pipe_without, 3),
+                         "search_ms_inside_pipeline": round(min(pipe_with, pipe_with_now, pipe_with_thr, pipe_with_def) - pipe_without, 3),
                          "note": "alignment + merge + counters per step, rows left in HBM, the contexts taking the batch in turn; "
                                  "without_graph = the headline's kernels (k_poa keeps no graph), without_search = the graph-keeping "
-                                 "alignment kernels alone, with_search = the search queued behind every alignment"},
+                                 "alignment kernels alone, with_search = elector_poa_bundles_enqueue behind every alignment (the library notes the search and queues it when "
+                                 "the context is collected); the other three with option bundles_now"},
            "roofline": {"bound": "hbm", "kernel": "k_bundle_inputs + k_bundle_lds<C, LDS | HBM> + k_bundle_hbm (side by side: the time is the search's, plan to last row)", "achieved": round(alg / (per_launch_ms * 1e-3) / 1e9, 3) if per_launch_ms > 0 else 0.0,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if per_launch_ms > 0 else 0.0,

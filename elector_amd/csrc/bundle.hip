@@ -902,13 +902,27 @@ static int bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
   return ELECTOR_OK;
 }
 
+int elector_bundles_flush(elector_ctx *c)
+{
+  if (!c->bundles_pending) return ELECTOR_OK;
+  c->bundles_pending = false;
+  return bundles_enqueue(c, c->bundles_n, c->bundles_fraction);
+}
+
 extern "C" int elector_poa_bundles_enqueue(elector_ctx *c, int64_t n, float minimum_fraction)
 {
   if (!c) return ELECTOR_E_INVAL;
   if (n < 0) return elector_fail(c, ELECTOR_E_INVAL, "bad arguments");
   std::lock_guard<std::mutex> lock(c->mu);
   if (n == 0) return ELECTOR_OK;
-  return bundles_enqueue(c, n, minimum_fraction);
+  if (c->bundles_now) return bundles_enqueue(c, n, minimum_fraction);
+  // noted; queued at the context's next call that waits for it anyway (ctx.h).  What can be refused is refused here.
+  if (!c->keep_graph || !c->graph_valid || n != c->last_n)
+    return elector_fail(c, ELECTOR_E_INVAL, "no graph kept: call elector_ctx_keep_graph(ctx, 1) before the POA batch");
+  c->bundles_pending = true;
+  c->bundles_n = n;
+  c->bundles_fraction = minimum_fraction;
+  return ELECTOR_OK;
 }
 
 extern "C" int elector_poa_bundles(elector_ctx *c, int64_t n, float minimum_fraction, uint8_t *cons_rows,
@@ -919,6 +933,7 @@ extern "C" int elector_poa_bundles(elector_ctx *c, int64_t n, float minimum_frac
   std::lock_guard<std::mutex> lock(c->mu);
   cons_off[0] = 0;
   if (n == 0) return ELECTOR_OK;
+  c->bundles_pending = false;                  // (a noted search of the same batch: this call runs it)
   int rc = bundles_enqueue(c, n, minimum_fraction);
   if (rc) return rc;
   hipStream_t st = c->stream;

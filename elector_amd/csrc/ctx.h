@@ -159,11 +159,21 @@ struct elector_ctx {
   // a12: heaviest-bundle consensus (bundle.hip) works on the graph data of the last batch
   bool keep_graph = false;     // POA kernels also leave the x -> y map of alignment #2 in d_map16
   bool graph_valid = false;    // the last batch ran with keep_graph
+  // elector_poa_bundles_enqueue notes the search and the context queues it at the next call that waits for the context
+  // anyway (statistics collect, sync, the fetch of the bundles, the next batch): the search's two host waits -- scratch
+  // size, class counts -- then last what its own first stages last instead of the alignment in front of them, and the
+  // thread that feeds several contexts is not held up (option "bundles_now": 1 = queue it inside the call as before)
+  bool bundles_pending = false, bundles_now = false;
+  int64_t bundles_n = 0;
+  float bundles_fraction = 0.0f;
   const int32_t *last_ncol = nullptr;   // device arrays of the last batch (caller's or the staging ones)
   int32_t *last_status = nullptr;
   elector::DevBuf d_bnode, d_bscore, d_bpath, d_bcons, d_binfo, d_bplan, d_bin, d_bcls;
   int64_t last_n_generic = 0;           // windows of the last batch on the generic list (d_perm); the others are in d_list
 };
+
+// queues a noted bundle search (bundle.hip); the caller holds c->mu
+int elector_bundles_flush(elector_ctx *c);
 
 inline int elector_fail(elector_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
 {

@@ -341,6 +341,11 @@ extern "C" const char *elector_ctx_last_error(const elector_ctx *c) { return c ?
 extern "C" int elector_ctx_sync(elector_ctx *c)
 {
   if (!c) return ELECTOR_E_INVAL;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    const int rc = elector_bundles_flush(c);
+    if (rc) return rc;
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ELECTOR_OK;
 }
@@ -406,6 +411,10 @@ extern "C" int elector_ctx_option(elector_ctx *c, const char *name, int64_t valu
     if (c->make_stream(&ns)) return fail(c, ELECTOR_E_HIP, "stream");
     (void)hipStreamDestroy(c->stream);
     c->stream = ns;
+    return ELECTOR_OK;
+  }
+  if (!std::strcmp(name, "bundles_now")) {            // 1: elector_poa_bundles_enqueue queues the search inside the call (ctx.h)
+    c->bundles_now = value != 0;
     return ELECTOR_OK;
   }
   if (!std::strcmp(name, "cus")) {                    // the context's streams on compute units lo .. hi - 1 of the queue mask: value = lo * 1000 + hi
@@ -497,6 +506,10 @@ static int run_device_batch(elector_ctx *c, int64_t n, const uint8_t *d_bases, c
   // (from here to the end of a successful call the context describes no batch: a call that fails half way -- malformed
   // offsets are only found by the classification kernel, after d_off has been overwritten -- must not leave the previous
   // batch's sizes over the new batch's arrays for elector_msa_stats_enqueue / elector_poa_bundles to trust)
+  {   // a bundle search noted for the previous batch reads that batch's graph: it is queued before this batch overwrites it
+    const int rcb = elector_bundles_flush(c);
+    if (rcb) return rcb;
+  }
   c->last_n = 0; c->last_total = 0; c->graph_valid = false;
   if (n == 0) return ELECTOR_OK;
   if (total < 0) return fail(c, ELECTOR_E_INVAL, "negative total");
@@ -1448,6 +1461,10 @@ extern "C" int elector_poa_batch_device(elector_ctx *c, int64_t n, const uint8_t
     return fail(c, ELECTOR_E_INVAL, "bad arguments");
   std::lock_guard<std::mutex> lock(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
+  {   // a bundle search noted for the previous batch goes in front of everything this call queues (offsets, buffers)
+    const int rcb = elector_bundles_flush(c);
+    if (rcb) return rcb;
+  }
   if (n == 0) return run_device_batch(c, 0, d_bases, nullptr, 0, d_cols, d_ncol, d_status, d_scores);
   if (off[0] != 0 || off[3 * n] < 0) return fail(c, ELECTOR_E_INVAL, "off[0] must be 0");
   const int rc = upload_offsets(c, n, off, c->stream);
@@ -1464,6 +1481,10 @@ extern "C" int elector_poa_batch_device_offsets(elector_ctx *c, int64_t n, const
     return fail(c, ELECTOR_E_INVAL, "bad arguments");
   std::lock_guard<std::mutex> lock(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
+  {   // a bundle search noted for the previous batch goes in front of everything this call queues (offsets, buffers)
+    const int rcb = elector_bundles_flush(c);
+    if (rcb) return rcb;
+  }
   return run_device_batch(c, n, d_bases, d_off, total, d_cols, d_ncol, d_status, d_scores);
 }
 
@@ -1475,6 +1496,10 @@ extern "C" int elector_poa_batch(elector_ctx *c, int64_t n, const uint8_t *bases
     return fail(c, ELECTOR_E_INVAL, "bad arguments");
   std::lock_guard<std::mutex> lock(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
+  {   // a bundle search noted for the previous batch goes in front of everything this call queues (offsets, buffers)
+    const int rcb = elector_bundles_flush(c);
+    if (rcb) return rcb;
+  }
   row_off[0] = 0;
   if (n == 0) return ELECTOR_OK;
   const int64_t total = off[3 * n];

@@ -1565,6 +1565,10 @@ extern "C" int elector_msa_stats_collect(elector_ctx *c, int64_t n_pieces, int64
   elector::StatsSlot &s = c->st_slot[c->st_tail];
   if (n_pieces != s.n_pieces || (n_pieces > 0 && !counters)) return elector_fail(c, ELECTOR_E_INVAL, "n_pieces differs from the job's");
   HIPCHK(c, hipSetDevice(c->device));
+  {   // (a bundle search noted for the context's last batch: queued here, where the caller waits for the context anyway)
+    const int rcb = elector_bundles_flush(c);
+    if (rcb) return rcb;
+  }
   c->st_last = c->st_tail;
   c->st_tail = (c->st_tail + 1) % elector_ctx::kStatsSlots;
   --c->st_inflight;

@@ -213,7 +213,9 @@ class PoaEngine:
         self._check(self._lib.elector_ctx_keep_graph(self._h, 1 if on else 0))
 
     def bundles_enqueue(self, n, minimum_fraction=0.9):
-        """the bundle search of the last batch, queued; results stay on the device (timing: kind 5)"""
+        """the bundle search of the last batch, noted: the context queues it at its next call that waits for it anyway
+        (statistics collect, sync, bundles(), the next batch); option("bundles_now", 1) queues it inside this call.
+        Results stay on the device (timing: kind 5)"""
         self._check(self._lib.elector_poa_bundles_enqueue(self._h, int(n), float(minimum_fraction)))
 
     def bundles(self, n, total_bases, minimum_fraction=0.9):
@@ -260,7 +262,8 @@ class PoaEngine:
     def option(self, name, value):
         """elector_ctx_option: "chains" = concurrent launch chains of the fused classes (0 = default); "priority" = -1 / 0 / +1,
         the context's streams at the device's highest / default / lowest priority; "cus" = lo * 1000 + hi, its streams on the
-        compute units lo .. hi - 1 of the queue mask (both before the context's first call)."""
+        compute units lo .. hi - 1 of the queue mask (both before the context's first call); "bundles_now" = 1: bundles_enqueue
+        queues the search inside the call."""
         self._check(self._lib.elector_ctx_option(self._h, name.encode(), int(value)))
 
     def last_po_sizes(self, n):

@@ -185,8 +185,12 @@ int elector_ctx_last_po_sizes(elector_ctx *ctx, int64_t n, int32_t *po_nodes);
 int elector_ctx_keep_graph(elector_ctx *ctx, int on);
 /* the search alone, queued on the context's stream, its results left in the context's device buffers (what
  * elector_poa_bundles then fetches): the entry bench.py --bundles times; timing kind 5 (elector_ctx_timing_read).
- * The call waits twice for the context's stream (the scratch size, the class counts): a caller that feeds several
- * contexts from one thread calls it from a helper thread, or when the context comes round again. */
+ * The search waits twice for the context's stream (the scratch size, the class counts); behind a whole alignment those
+ * waits would hold up a thread that feeds several contexts.  So the call only NOTES the search (and refuses at once what
+ * can be refused: no graph kept, n not the last batch's); the context queues it at its next call that waits for it
+ * anyway -- elector_msa_stats_collect, elector_ctx_sync, elector_poa_bundles, or the next batch, in front of everything
+ * that batch queues.  The last batch's ncol / status arrays must stay alive until then.
+ * elector_ctx_option(ctx, "bundles_now", 1) queues the search inside the call instead. */
 int elector_poa_bundles_enqueue(elector_ctx *ctx, int64_t n, float minimum_fraction);
 int elector_poa_bundles(elector_ctx *ctx, int64_t n, float minimum_fraction,
                         uint8_t *cons_rows, int64_t cons_cap, int64_t *cons_off,

@@ -123,3 +123,29 @@ def test_bundles_geometry_classes(engine, cls, monkeypatch):
     """the graph output of several k_poa instances (lanes per window x rows per lane) on windows of every size"""
     monkeypatch.setenv("ELECTOR_FORCE_CLASS", str(cls))
     check(engine, synth.window_triples(300 + cls, 400, 5, 420) + synth.adversarial_triples(320 + cls, 200))
+
+
+def test_bundles_enqueue_is_noted_and_queued_later(engine):
+    """elector_poa_bundles_enqueue notes the search; the context queues it at its next call that waits anyway -- in front
+    of the next batch (whose offsets and graph it must not see), at a sync, at the fetch.  Wrong sizes are refused at once."""
+    from elector_amd._capi import ElectorError
+    a = synth.window_triples(61, 1500, 7, 200) + synth.adversarial_triples(62, 300)
+    b = synth.window_triples(63, 900, 20, 260)
+    bases_b, off_b = synth.pack_windows(b)
+    exp_b = oracle_lib.batch_bundles(np.frombuffer(bases_b, dtype=np.uint8), off_b, 0.9)
+    engine.keep_graph(True)
+    try:
+        for now in (0, 1):
+            engine.option("bundles_now", now)
+            engine.align(a, strict=False)
+            with pytest.raises(ElectorError):
+                engine.bundles_enqueue(len(a) + 1)
+            engine.bundles_enqueue(len(a))
+            rows_b = engine.align(b, strict=False)               # the noted search of `a` runs before `b` takes its arrays
+            engine.bundles_enqueue(len(b))
+            engine.sync()                                        # ... and this one here
+            assert engine.bundles(len(b), int(off_b[-1])) == exp_b
+            assert rows_b == oracle_lib.batch(np.frombuffer(bases_b, dtype=np.uint8), off_b)[0]
+    finally:
+        engine.option("bundles_now", 0)
+        engine.keep_graph(False)
